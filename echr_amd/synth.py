@@ -1,0 +1,150 @@
+"""Synthetic options, parameters and video batches for the ECHR caption hot path.
+
+There is no dataset in this environment, so tests, golden fixtures and bench.py all draw their
+inputs from `np.random.RandomState` streams defined here (portable between the build container
+and the GPU box).  Shapes follow the ECHR recipe (reference: experiments/train_ECHR.sh:5 and the
+defaults in opts.py:81-161): the batch axis is the N events of ONE video (opts.py:93,187).
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+
+
+def default_opt(vocab_size=5000, seq_length=19, **over):
+    """The option namespace CaptionGenerator reads, at the values train_ECHR.sh selects."""
+    opt = SimpleNamespace(
+        caption_model='three_stream', CG_num_layers=3,
+        video_context_type='VL', event_context_type='ER3', clip_context_type='CC',
+        lda_dim=100, video_dim=500, hidden_dim=512,
+        fusion_model='TSRM8', use_posit=1, n_head=16, d_feats=512, d_o=512, fST_type='fST0',
+        CG_rnn_size=512, CG_rnn_type='lstm', CG_input_encoding_size=512, CG_att_hid_size=512,
+        CG_fc_feat_size=512, CG_drop_prob=0.5, CG_input_feats_type='', CG_init_feats_type='',
+        CG_vocab_size=vocab_size, CG_seq_length=seq_length,
+        video_context_dim=0, event_context_dim=0, clip_context_dim=0,
+        K=256, tap_model='SST', tap_rnn_type='LSTM', rnn_num_layers=2, rnn_dropout=0.5,
+        grad_clip=100.0, lr=5e-5, optim_alpha=0.9, optim_beta=0.999, optim_epsilon=1e-8, weight_decay=0,
+    )
+    for k, v in over.items():
+        setattr(opt, k, v)
+    return opt
+
+
+def state_dict_shapes(opt):
+    """Name -> shape of CaptionGenerator.state_dict() (printed from the reference)."""
+    V1 = opt.CG_vocab_size + 1
+    H = opt.CG_rnn_size
+    E = opt.CG_input_encoding_size
+    Ha = opt.CG_att_hid_size
+    D = opt.video_dim
+    Df = opt.d_feats
+    G = opt.n_head
+    tsrm_in = opt.video_dim + opt.hidden_dim          # 'ER3'
+    ev, cl, vi = opt.d_o, opt.video_dim, opt.lda_dim  # context widths for ER3 / CC / VL
+    s = {
+        'fusion_model.h2a_layer.weight': (10, 10), 'fusion_model.h2a_layer.bias': (10,),
+        'fusion_model.event_emb.weight': (Df, tsrm_in), 'fusion_model.event_emb.bias': (Df,),
+        'fusion_model.enc_attn.pair_pos_fc1.weight': (Df, Df), 'fusion_model.enc_attn.pair_pos_fc1.bias': (Df,),
+        'fusion_model.enc_attn.pair_pos_fc2.weight': (G, Df), 'fusion_model.enc_attn.pair_pos_fc2.bias': (G,),
+        'fusion_model.enc_attn.query_1.weight': (Df, Df), 'fusion_model.enc_attn.query_1.bias': (Df,),
+        'fusion_model.enc_attn.key_1.weight': (Df, Df), 'fusion_model.enc_attn.key_1.bias': (Df,),
+        'fusion_model.enc_attn.linear_out_1.weight': (opt.d_o, Df, 1, 1), 'fusion_model.enc_attn.linear_out_1.bias': (opt.d_o,),
+        'lm_model.embed.weight': (V1, E),
+        'lm_model.logit.weight': (V1, 3 * H), 'lm_model.logit.bias': (V1,),
+    }
+    for k, cin in ((0, ev + E), (1, cl + E), (2, vi + E)):
+        s['lm_model.core.layer%d.weight_ih' % k] = (4 * H, cin)
+        s['lm_model.core.layer%d.weight_hh' % k] = (4 * H, H)
+        s['lm_model.core.layer%d.bias_ih' % k] = (4 * H,)
+        s['lm_model.core.layer%d.bias_hh' % k] = (4 * H,)
+    s.update({
+        'lm_model.core.fusion_layer.weight': (H, 3 * H), 'lm_model.core.fusion_layer.bias': (H,),
+        'lm_model.core.attention.ctx2att.weight': (Ha, D), 'lm_model.core.attention.ctx2att.bias': (Ha,),
+        'lm_model.core.attention.h2att.weight': (Ha, H), 'lm_model.core.attention.h2att.bias': (Ha,),
+        'lm_model.core.attention.alpha_net.weight': (1, Ha), 'lm_model.core.attention.alpha_net.bias': (1,),
+    })
+    return s
+
+
+def _init_range(name, shapes, H):
+    if name in ('lm_model.embed.weight', 'lm_model.logit.weight'):
+        return 0.1                                    # OldModel_NEW.py:66-70
+    if name == 'lm_model.logit.bias':
+        return 0.0
+    if '.core.layer' in name:
+        return 1.0 / math.sqrt(H)                     # nn.LSTMCell default
+    wname = name[:-len('.bias')] + '.weight' if name.endswith('.bias') else name
+    fan_in = int(np.prod(shapes[wname][1:]))          # nn.Linear / Conv2d: bound = 1/sqrt(fan_in)
+    return 1.0 / math.sqrt(fan_in)
+
+
+def make_params(opt, seed=0):
+    """Deterministic parameter set keyed by state-dict name (float32 numpy arrays).
+
+    Filled in sorted-name order from one RandomState so that the reference-side golden tool and
+    the build draw identical values without storing any weights."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    shapes = state_dict_shapes(opt)
+    for name in sorted(shapes):
+        shp = shapes[name]
+        r = _init_range(name, shapes, opt.CG_rnn_size)
+        out[name] = rs.uniform(-r, r, size=shp).astype(np.float32) if r > 0 else np.zeros(shp, np.float32)
+    return out
+
+
+def make_video(N, A, L, V1, seed=1234, T_v=None, full_len=False, min_len=4, video_dim=500, hidden_dim=512, lda_dim=100):
+    """One synthetic video: features, N events (half-open [s,e) segment intervals), captions.
+
+    full_len=True makes every event exactly A segments long (the dense N x A x D case BASELINE
+    quotes); otherwise lengths are uniform in [min_len, A] with at least one event of length A
+    (SURVEY 8-d config 2).  Captions: column 0 = BOS (0), tokens in [1, V1), zero padded; at least
+    one caption uses all L-2 token slots so the decoder runs the full L-1 steps.  The mask follows
+    dataloader.py:437-439 (`nonzeros + 2` ones)."""
+    rs = np.random.RandomState(seed)
+    if T_v is None:
+        T_v = A + max(8, A // 4)
+    lens = np.full(N, A, dtype=np.int64) if full_len else rs.randint(min(min_len, A), A + 1, size=N)
+    lens[rs.randint(0, N)] = A
+    starts = np.array([rs.randint(0, T_v - l + 1) for l in lens], dtype=np.int64)
+    soi = np.stack([starts, starts + lens], axis=1)
+    ind = soi[:, 1] - 1                                   # proposal anchored at its last segment
+    c3d = rs.standard_normal((T_v, video_dim)).astype(np.float32)
+    tap = (0.5 * rs.standard_normal((T_v, hidden_dim))).astype(np.float32)
+    lda = np.abs(rs.standard_normal(lda_dim)).astype(np.float32)
+    lda /= lda.sum()
+    labels = np.zeros((N, L), dtype=np.int64)
+    masks = np.zeros((N, L), dtype=np.float32)
+    max_tok = L - 2
+    cap_len = rs.randint(1, max_tok + 1, size=N) if max_tok >= 1 else np.zeros(N, np.int64)
+    if max_tok >= 1:
+        cap_len[rs.randint(0, N)] = max_tok
+    for i in range(N):
+        labels[i, 1:1 + cap_len[i]] = rs.randint(1, V1, size=cap_len[i])
+        masks[i, :cap_len[i] + 2] = 1.0
+    return dict(c3d=c3d, tap=tap, lda=lda, labels=labels, masks=masks,
+                ind=ind.astype(np.int64), soi=soi.astype(np.int64), T_v=T_v)
+
+
+# Named parity / bench cases (BASELINE.json `configs`).  `opt` = overrides of default_opt.
+CASES = {
+    # every width shrunk (all multiples of 4) so that full tensors fit in a fixture
+    'tiny': dict(opt=dict(video_dim=20, hidden_dim=24, lda_dim=12, d_feats=32, d_o=32, n_head=4, CG_rnn_size=32,
+                          CG_input_encoding_size=16, CG_att_hid_size=24, CG_vocab_size=30, CG_seq_length=5),
+                 video=dict(N=3, A=7, L=7, seed=11)),
+    # config 1: N=2 events on a 16-segment video, 10 decoder steps, ECHR widths, V1 = 5001
+    'c1': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=9), video=dict(N=2, A=16, L=11, seed=21, T_v=16)),
+    # config 2/3 shape with ragged event lengths in [4,128]
+    'c2': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=31)),
+    # config 2/3 shape, every event 128 segments long (the dense batch 64 x 128 seg x 500-d bench workload)
+    'c2full': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=41, full_len=True)),
+}
+
+
+def make_case(name, param_seed=0):
+    """(opt, params, video) of a named case."""
+    c = CASES[name]
+    opt = default_opt(**c['opt'])
+    vid = make_video(V1=opt.CG_vocab_size + 1, video_dim=opt.video_dim, hidden_dim=opt.hidden_dim,
+                     lda_dim=opt.lda_dim, **c['video'])
+    return opt, make_params(opt, param_seed), vid

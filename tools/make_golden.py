@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures from the REFERENCE's own code (build container only).
+
+Imports /root/reference (never copied, never shipped), fills its modules with the deterministic
+parameters of echr_amd.synth, runs its PyTorch-CPU path on the named synthetic cases and writes
+small .npz fixtures under tests/golden/.  It also checks the repo's CPU oracle
+(oracle/echr_ref_cpu.py) against the reference on the same inputs and prints the max deviations
+(the oracle is "pinned" by this run + tests/test_oracle_golden.py).
+
+Two in-process shims let the Python-2 / CUDA-only reference run under Python 3 on CPU; neither
+touches a reference file:
+  1. torch.Tensor.cuda -> identity            (MA_attention_8_NEW.py:41 hard-codes .cuda())
+  2. torch.Tensor.view int-casts float sizes   (MA_attention_8_NEW.py:125,133 pass `d_q / group`)
+Train-mode fixtures patch torch.nn.functional.dropout in-process so that the reference consumes
+the build's counter-based (Philox) masks in its own call order.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [--cases tiny c1 c2 c2full]
+"""
+import argparse
+import copy
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+from echr_amd import philox, synth          # noqa: E402
+from oracle import echr_ref_cpu as O        # noqa: E402
+from oracle import summary as SM            # noqa: E402
+
+# ---- shims -------------------------------------------------------------------------------------
+torch.Tensor.cuda = lambda self, *a, **k: self
+_orig_view = torch.Tensor.view
+
+
+def _view(self, *shape):
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+        shape = tuple(shape[0])
+    shape = tuple(int(s) if isinstance(s, float) and float(s).is_integer() else s for s in shape)
+    return _orig_view(self, *shape)
+
+
+torch.Tensor.view = _view
+
+import models                                # noqa: E402  (reference)
+from CaptionGenerator import CaptionGenerator as RefCG   # noqa: E402  (reference)
+import misc.utils as ref_utils               # noqa: E402  (reference)
+import eval_utils as ref_eval                # noqa: E402  (reference)
+import torch.nn.functional as F              # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+SEED, OFFSET = 0x5EED0123456789, 7
+
+
+class MaskFeeder:
+    """Replaces F.dropout: hands out Philox masks in the reference's call order:
+    TSRM [N,G,N] once, then per step h0, h1, h2 [N,H] and out [N,3H]."""
+
+    def __init__(self, p_out):
+        self.calls = 0
+        self.p_out = p_out
+
+    def __call__(self, x, p=0.5, training=True, inplace=False):
+        if not training:
+            return x
+        if self.calls == 0:
+            site, step = philox.SITE_TSRM, 0
+        else:
+            k = self.calls - 1
+            step, site = k // 4, (philox.SITE_H0, philox.SITE_H1, philox.SITE_H2, philox.SITE_OUT)[k % 4]
+        self.calls += 1
+        m = philox.scale_mask(tuple(x.shape), p, SEED, OFFSET, site, step)
+        return x * torch.from_numpy(m)
+
+
+def oracle_drop(opt):
+    sites = dict(tsrm=(philox.SITE_TSRM, 0.3), h0=(philox.SITE_H0, 0.5), h1=(philox.SITE_H1, 0.5),
+                 h2=(philox.SITE_H2, 0.5), out=(philox.SITE_OUT, opt.CG_drop_prob))
+
+    def drop(site, step, shape):
+        s, p = sites[site]
+        return torch.from_numpy(philox.scale_mask(tuple(shape), p, SEED, OFFSET, s, step))
+    return drop
+
+
+def build_ref(opt, params):
+    m = RefCG(copy.copy(opt))
+    sd = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    missing = set(m.state_dict().keys()) ^ set(sd.keys())
+    assert not missing, missing
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), (k, v.shape, sd[k].shape)
+    m.load_state_dict(sd)
+    return m
+
+
+def run_ref(m, vid, train_mode, opt):
+    tap, c3d, lda = (torch.from_numpy(vid[k]) for k in ('tap', 'c3d', 'lda'))
+    labels = torch.from_numpy(vid['labels'])
+    masks = torch.from_numpy(vid['masks'])
+    m.zero_grad()
+    orig = F.dropout
+    if train_mode:
+        m.train()
+        F.dropout = MaskFeeder(opt.CG_drop_prob)
+    else:
+        m.eval()
+    try:
+        pred = m(tap, c3d, lda, labels, vid['ind'], vid['soi'].tolist(), mode='train')
+    finally:
+        F.dropout = orig
+    loss = ref_utils.LanguageModelCriterion()(pred, labels[:, 1:], masks[:, 1:])
+    loss.backward()
+    grads = {k: (p.grad.detach().numpy().copy() if p.grad is not None else None) for k, p in m.named_parameters()}
+    return pred.detach().numpy(), float(loss), grads
+
+
+def run_oracle(opt, params, vid, train_mode):
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    tap, c3d, lda = (torch.from_numpy(vid[k]) for k in ('tap', 'c3d', 'lda'))
+    labels = torch.from_numpy(vid['labels'])
+    masks = torch.from_numpy(vid['masks'])
+    drop = oracle_drop(opt) if train_mode else None
+    pred = O.caption_forward(P, tap, c3d, lda, labels, vid['ind'], vid['soi'], 'train', drop, opt.n_head)
+    loss = O.lm_criterion(pred, labels[:, 1:], masks[:, 1:])
+    loss.backward()
+    grads = {k: (p.grad.numpy().copy() if p.grad is not None else None) for k, p in P.items()}
+    return pred.detach().numpy(), float(loss), grads
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def do_case(name):
+    opt, params, vid = synth.make_case(name)
+    full = name == 'tiny'
+    out = {}
+    m = build_ref(opt, params)
+    for mode in ('eval', 'train'):
+        t0 = time.time()
+        pred, loss, grads = run_ref(m, vid, mode == 'train', opt)
+        t_ref = time.time() - t0
+        opred, oloss, ograds = run_oracle(opt, params, vid, mode == 'train')
+        dev = max(rel(ograds[k], grads[k]) for k in grads if grads[k] is not None)
+        unused = sorted(k for k in grads if grads[k] is None)
+        assert unused == sorted(k for k in ograds if ograds[k] is None), (unused,)
+        print('[%s/%s] ref %.2fs loss %.6f | oracle-vs-ref: max|dlogp| %.2e  dloss %.2e  max rel grad %.2e | unused %s'
+              % (name, mode, t_ref, loss, np.abs(opred - pred).max(), abs(oloss - loss), dev, unused))
+        assert np.abs(opred - pred).max() < 2e-5 and abs(oloss - loss) < 1e-5 and dev < 1e-4
+        out[mode + '|loss'] = np.float64(loss)
+        if full:
+            out[mode + '|logp'] = pred
+            for k, g in grads.items():
+                if g is not None:
+                    out[mode + '|grad|' + k] = g
+        else:
+            for k, v in SM.summarize_logp(pred).items():
+                out[mode + '|logp|' + k] = v
+            for k, v in SM.summarize_grads(grads).items():
+                out[mode + '|grad|' + k] = v
+    # greedy sampling (eval mode), index output bit-exact
+    m.eval()
+    tap, c3d, lda = (torch.from_numpy(vid[k]) for k in ('tap', 'c3d', 'lda'))
+    import io
+    import contextlib
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        seq, slp = m(tap, c3d, lda, [], vid['ind'], vid['soi'].tolist(), mode='eval')
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        oseq, oslp = O.caption_forward(P, tap, c3d, lda, None, vid['ind'], vid['soi'], 'eval', None, opt.n_head,
+                                       opt.CG_seq_length)
+    assert torch.equal(seq, oseq), 'oracle greedy seq differs'
+    print('[%s/sample] seq %s  oracle max|dlogp| %.2e' % (name, tuple(seq.shape), float((slp - oslp).abs().max())))
+    out['sample|seq'] = seq.numpy().astype(np.int64)
+    out['sample|logp'] = slp.numpy()
+    # event context / TSRM output in eval mode
+    with torch.no_grad():
+        ev = m.get_event_context(tap, c3d, lda, vid['ind'], vid['soi'].tolist())
+    out['event_context'] = ev.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'case_%s.npz' % name), **out)
+    print('  wrote case_%s.npz (%d arrays)' % (name, len(out)))
+
+
+def do_position():
+    RefMA = models.MA_Attention8
+    out = {}
+    sois = {'a': np.array([[0, 9], [4, 16], [2, 3], [10, 138]]),
+            'b': synth.make_video(12, 40, 5, 10, seed=5)['soi']}
+    for k, soi in sois.items():
+        pm = RefMA.extract_position_matrix(np.array(soi.tolist()), len(soi))
+        pe = RefMA.extract_position_embedding(pm, 512)
+        assert np.array_equal(pm, O.position_matrix(soi)) and np.array_equal(pe, O.position_embedding(pm, 512))
+        out[k + '|soi'] = soi
+        out[k + '|pos_matrix'] = pm
+        out[k + '|pos_emb_f32'] = pe.astype(np.float32)
+        pe32 = RefMA.extract_position_embedding(pm, 32)
+        out[k + '|pos_emb32_f32'] = pe32.astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, 'position.npz'), **out)
+    print('wrote position.npz')
+
+
+def do_adam():
+    """clip_gradient(+-clip) + torch.optim.Adam exactly as train.py:209,315-317 wires them."""
+    rs = np.random.RandomState(3)
+    p0 = rs.standard_normal(4097).astype(np.float32)
+    gs = [(rs.standard_normal(4097) * (150.0 if i == 1 else 1.0)).astype(np.float32) for i in range(4)]
+    p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([p], lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
+    out = {'p0': p0}
+    for i, g in enumerate(gs):
+        p.grad = torch.from_numpy(g.copy())
+        ref_utils.clip_gradient(opt, 100.0)
+        opt.step()
+        out['g%d' % i] = g
+        out['p%d' % (i + 1)] = p.detach().numpy().copy()
+    st = opt.state[p]
+    out['exp_avg'] = st['exp_avg'].numpy().copy()
+    out['exp_avg_sq'] = st['exp_avg_sq'].numpy().copy()
+    # oracle check
+    po, mo, vo = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for i, g in enumerate(gs):
+        O.clamp_adam_step(po, g.copy(), mo, vo, i + 1, 5e-5)
+    print('[adam] oracle-vs-torch max|dp| %.2e' % np.abs(po - out['p4']).max())
+    assert np.abs(po - out['p4']).max() < 1e-6
+    np.savez_compressed(os.path.join(GOLD, 'adam.npz'), **out)
+    print('wrote adam.npz')
+
+
+def do_proposals():
+    """gettop1000 index outputs for seeded score grids (eval_utils.py:259-287)."""
+    out = {}
+    for i, (T, K, topN) in enumerate(((40, 16, 50), (96, 64, 100), (30, 64, 1000))):
+        rs = np.random.RandomState(100 + i)
+        scores = rs.uniform(0, 1, size=(T, K)).astype(np.float32)
+        tmask = np.tril(np.ones((T, K), np.float32))[:, :K] if T >= K else np.ones((T, K), np.float32)
+        tmask = (np.arange(T)[:, None] >= np.arange(K)[None, :]).astype(np.float32)
+        ind, feat, _, _, conf = ref_eval.gettop1000(scores, tmask, [], 100.0, lambda s, e, n, d: [s, e], topN=topN)
+        oind, ofeat, oconf = O.top_proposals(scores, tmask, topN)
+        assert ind == oind and feat == ofeat and np.allclose(conf, oconf)
+        out['g%d|scores' % i] = scores
+        out['g%d|mask' % i] = tmask
+        out['g%d|topN' % i] = np.int64(topN)
+        out['g%d|ind' % i] = np.array(ind, np.int64)
+        out['g%d|feat' % i] = np.array(feat, np.int64)
+    np.savez_compressed(os.path.join(GOLD, 'proposals.npz'), **out)
+    print('wrote proposals.npz')
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', nargs='*', default=['tiny', 'c1', 'c2', 'c2full'])
+    ap.add_argument('--skip-aux', action='store_true')
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    if not a.skip_aux:
+        do_position()
+        do_adam()
+        do_proposals()
+    for c in a.cases:
+        do_case(c)
