@@ -1,0 +1,77 @@
+"""CaptionGenerator -- drop-in for the reference's CaptionGenerator.py (:7-167) on MI355X.
+
+Same constructor side effects on `opt` (video/event/clip_context_dim, :56-84), same `forward`
+signature and live modes ('train' -> log-probs [N,S,V+1]; 'eval' -> (seq, logp)), same sub-module
+names (`fusion_model`, `lm_model`) and state_dict keys.  The three context levels are built without
+python loops over events: index lists are uploaded once as int32 (start, length, anchor) vectors and
+every kernel addresses the video features through them.
+"""
+import torch
+from torch import nn
+
+from . import functional as EF
+from . import models
+from .models.OldModel_NEW import ClipView
+
+
+class CaptionGenerator(nn.Module):
+    def __init__(self, opt):
+        super(CaptionGenerator, self).__init__()
+        self.opt = opt
+        self.change_context_dim()
+        if 'TSRM' in opt.fusion_model and 'ER' in opt.event_context_type:
+            self.fusion_model = models.setup_fusion(opt)
+        self.lm_model = models.setup_lm(opt)
+        if opt.video_context_type != 'VL' or opt.event_context_type != 'ER3' or opt.clip_context_type != 'CC':
+            raise NotImplementedError('the HIP path implements the ECHR recipe: video_context_type=VL, event_context_type=ER3, '
+                                      'clip_context_type=CC (experiments/train_ECHR.sh)')
+
+    def set_dropout_state(self, seed, calls=0):
+        """Pin the counter-based dropout stream (tests / reproducible runs)."""
+        self.lm_model._drop_seed = int(seed)
+        self.lm_model._drop_calls = int(calls)
+
+    def forward(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, mode='train'):
+        if mode not in ('train', 'eval'):
+            raise NotImplementedError("mode=%r: only 'train' and 'eval' are live in the reference as shipped (SURVEY section 2 row 12)" % (mode,))
+        if not c3d_feats.is_cuda:
+            raise EF.L.EchrHipError('CaptionGenerator runs on the GPU only: move the module and its inputs with .cuda()')
+        ev = EF.event_index_tensors(soi_select_list, ind_select_list, c3d_feats.device, min(c3d_feats.shape[0], tap_feats.shape[0]))
+        drop = self.lm_model.next_drop_state(self.fusion_model.enc_attn.dropout.p if hasattr(self, 'fusion_model') else 0.0)
+        drop.training = self.training
+        video = self.get_video_context(tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list)
+        event = self.get_event_context(tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=ev, _drop=drop)
+        clip, clip_mask = self.get_clip_context(tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=ev)
+        if mode == 'train':
+            return self.lm_model(video, event, clip, clip_mask, lm_labels, drop=drop)
+        return self.lm_model.sample(video, event, clip, clip_mask)
+
+    def change_context_dim(self):
+        opt = self.opt
+        vt, et, ct = opt.video_context_type, opt.event_context_type, opt.clip_context_type
+        opt.video_context_dim = (opt.lda_dim if 'VL' in vt else 0) + (opt.video_dim if 'VC' in vt else 0) + \
+                                (opt.hidden_dim if 'VH' in vt else 0)
+        if 'ER' in et:
+            opt.event_context_dim = opt.d_o
+        else:
+            opt.event_context_dim = (opt.video_dim if 'EC' in et else 0) + (opt.hidden_dim if 'EH' in et else 0)
+        opt.clip_context_dim = (opt.video_dim if 'CC' in ct else 0) + (opt.hidden_dim if 'CH' in ct else 0)
+
+    def get_video_context(self, tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list):
+        """'VL': the LDA topic vector as is (CaptionGenerator.py:87-104)."""
+        return lda_feats
+
+    def get_event_context(self, tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=None, _drop=None):
+        """'ER3': TSRM over cat(mean-pooled C3D, SST state at the anchor) (CaptionGenerator.py:106-130)."""
+        ev_start, ev_len, ind, _ = _ev if _ev is not None else EF.event_index_tensors(soi_select_list, ind_select_list, c3d_feats.device)
+        ech = EF.EventPoolGather.apply(c3d_feats, tap_feats, ev_start, ev_len, ind)
+        return self.fusion_model(ech, soi_select_list, ev_tensors=(ev_start, ev_len), drop=_drop)
+
+    def get_clip_context(self, tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=None):
+        """'CC' frame-level context.  Internal callers get a zero-copy ClipView (+ None mask); external callers
+        (no `_ev`) get the reference's padded [N,A,D] tensor and [N,A] mask (CaptionGenerator.py:140-167)."""
+        if _ev is not None:
+            ev_start, ev_len, _, A = _ev
+            return ClipView(c3d_feats, ev_start, ev_len, A), None
+        ev_start, ev_len, _, A = EF.event_index_tensors(soi_select_list, ind_select_list, c3d_feats.device)
+        return ClipView(c3d_feats, ev_start, ev_len, A).materialize()

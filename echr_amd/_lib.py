@@ -1,0 +1,139 @@
+"""ctypes binding of libechr_hip.so (C ABI declared in include/echr_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libechr_hip.so')
+
+c_f = C.c_void_p   # device pointers travel as void*
+i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('A', c_f), ('B', c_f), ('C', c_f), ('M', i32), ('N', i32), ('K', i32),
+                ('sam', i64), ('sak', i64), ('sbk', i64), ('sbn', i64), ('ldc', i64),
+                ('batch', i32), ('bsa', i64), ('bsb', i64), ('bsc', i64), ('alpha', f32), ('beta', f32),
+                ('bias', c_f), ('bs_bias', i64), ('bias2', c_f), ('addend', c_f), ('add_mod', i32), ('ld_add', i64),
+                ('act', i32), ('aux', c_f), ('ld_aux', i64), ('rowmap_mod', i32), ('rowmap_mul', i32), ('split_k', i32)]
+
+
+class Dropout(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('offset', C.c_uint32), ('training', i32),
+                ('p_tsrm', f32), ('p_h', f32), ('p_out', f32)]
+
+
+class TsrmArgs(C.Structure):
+    _fields_ = [('N', i32), ('Din', i32), ('Df', i32), ('Do', i32), ('G', i32),
+                ('w_emb', c_f), ('b_emb', c_f), ('w_fc1', c_f), ('b_fc1', c_f), ('w_fc2', c_f), ('b_fc2', c_f),
+                ('w_q', c_f), ('b_q', c_f), ('w_k', c_f), ('b_k', c_f), ('w_out', c_f), ('b_out', c_f),
+                ('ech', c_f), ('ev_start', c_f), ('ev_len', c_f), ('ws', c_f), ('out', c_f)]
+
+
+class TsrmGrads(C.Structure):
+    _fields_ = [('g_w_emb', c_f), ('g_b_emb', c_f), ('g_w_fc1', c_f), ('g_b_fc1', c_f), ('g_w_fc2', c_f), ('g_b_fc2', c_f),
+                ('g_w_q', c_f), ('g_b_q', c_f), ('g_w_k', c_f), ('g_b_k', c_f), ('g_w_out', c_f), ('g_b_out', c_f),
+                ('g_ech', c_f), ('g_out', c_f), ('ws_bwd', c_f)]
+
+
+class DecArgs(C.Structure):
+    _fields_ = [('N', i32), ('A', i32), ('Tv', i32), ('D', i32), ('H', i32), ('E', i32), ('Ha', i32), ('De', i32),
+                ('Dv', i32), ('V1', i32), ('S', i32),
+                ('embed', c_f), ('w_logit', c_f), ('b_logit', c_f),
+                ('w_ih', c_f * 3), ('w_hh', c_f * 3), ('b_ih', c_f * 3), ('b_hh', c_f * 3),
+                ('w_c2a', c_f), ('b_c2a', c_f), ('w_h2a', c_f), ('b_h2a', c_f), ('w_alpha', c_f), ('b_alpha', c_f),
+                ('c3d', c_f), ('ev_start', c_f), ('ev_len', c_f), ('event', c_f), ('video', c_f), ('tokens', c_f),
+                ('ws', c_f), ('logp', c_f)]
+
+
+class DecGrads(C.Structure):
+    _fields_ = [('g_embed', c_f), ('g_w_logit', c_f), ('g_b_logit', c_f),
+                ('g_w_ih', c_f * 3), ('g_w_hh', c_f * 3), ('g_b_ih', c_f * 3), ('g_b_hh', c_f * 3),
+                ('g_w_c2a', c_f), ('g_b_c2a', c_f), ('g_w_h2a', c_f), ('g_b_h2a', c_f), ('g_w_alpha', c_f), ('g_b_alpha', c_f),
+                ('g_event', c_f), ('g_video', c_f), ('g_logp', c_f),
+                ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f)]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [('dec', DecArgs), ('seq_len', i32), ('seq', c_f), ('seq_logp', c_f), ('n_unfinished', c_f),
+                ('ws_sample', c_f)]
+
+
+# every symbol include/echr_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ('echr_version', i32, []),
+    ('echr_last_error', C.c_char_p, []),
+    ('echr_gemm_f32', i32, [C.POINTER(GemmDesc), C.c_void_p]),
+    ('echr_event_pool_gather_fwd', i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
+    ('echr_event_pool_gather_bwd', i32, [c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
+    ('echr_tsrm_ws_floats', i64, [i32, i32, i32, i32, i32]),
+    ('echr_tsrm_ws_bwd_floats', i64, [i32, i32, i32, i32, i32]),
+    ('echr_tsrm_fwd', i32, [C.POINTER(TsrmArgs), C.POINTER(Dropout), C.c_void_p]),
+    ('echr_tsrm_bwd', i32, [C.POINTER(TsrmArgs), C.POINTER(TsrmGrads), C.POINTER(Dropout), C.c_void_p]),
+    ('echr_tsrm_posemb', i32, [c_f, c_f, c_f, i32, i32, C.c_void_p]),
+    ('echr_decoder_ws_floats', i64, [C.POINTER(DecArgs)]),
+    ('echr_decoder_ws_bwd_floats', i64, [C.POINTER(DecArgs)]),
+    ('echr_decoder_fwd', i32, [C.POINTER(DecArgs), C.POINTER(Dropout), C.c_void_p]),
+    ('echr_decoder_bwd', i32, [C.POINTER(DecArgs), C.POINTER(DecGrads), C.POINTER(Dropout), C.c_void_p]),
+    ('echr_nll_loss_fwd', i32, [c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
+    ('echr_sampler_ws_floats', i64, [C.POINTER(DecArgs)]),
+    ('echr_decoder_sample', i32, [C.POINTER(SampleArgs), C.c_void_p]),
+    ('echr_clamp', i32, [c_f, i64, f32, C.c_void_p]),
+    ('echr_clamp_adam', i32, [c_f, c_f, c_f, c_f, i64, i32, f32, f32, f32, f32, f32, C.c_void_p]),
+]
+
+_lib = None
+
+
+class EchrHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libechr_hip.so (built in-tree by `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EchrHipError('libechr_hip.so not found at %s -- build it first (python __graft_entry__.py build); '
+                           'echr_amd has no CPU or PyTorch fallback path' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)       # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.echr_version() != 1:
+        raise EchrHipError('libechr_hip.so ABI version %d != 1' % lib.echr_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().echr_last_error()
+        raise EchrHipError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32, name='tensor'):
+    """Raw device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EchrHipError('%s must live on the GPU (got %s); echr_amd has no CPU path' % (name, t.device))
+    if t.dtype != dtype:
+        raise EchrHipError('%s must be %s (got %s)' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise EchrHipError('%s must be contiguous' % name)
+    return t.data_ptr()
+
+
+def ptr3(ts, name):
+    return (c_f * 3)(*[ptr(t, name=name) for t in ts])

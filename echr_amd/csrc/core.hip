@@ -1,0 +1,365 @@
+// Error plumbing + the small bandwidth-bound kernels of the ECHR hot path (reductions, embedding
+// gather/scatter, row log-softmax and its backward, masked NLL, event pooling, greedy arg-max,
+// fused clamp+Adam).  All wave64; row kernels use one 256-thread workgroup per row with
+// cross-lane shuffle reductions.
+#include <cstdarg>
+#include <cstdio>
+#include "echr_common.h"
+#include "echr_internal.h"
+
+namespace echr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return -5;  // -EIO
+    }
+    return 0;
+}
+
+// ---- block reductions ----------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < nw; ++w) r += red[w];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < nw; ++w) r = fmaxf(r, red[w]);
+    return r;
+}
+
+// ---- fill / colsum / sum over time ----------------------------------------------------------------
+int fill_zero(float* p, long n, hipStream_t st);
+__global__ void fill_zero_kernel(float* p, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = 0.f;
+}
+__global__ void fill_zero_2d_kernel(float* p, int rows, int cols, long ld) {
+    const long tot = (long)rows * cols;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) p[(i / cols) * ld + (i % cols)] = 0.f;
+}
+int fill_zero_2d(float* p, int rows, int cols, long ld, hipStream_t st) {
+    if (ld == cols) return fill_zero(p, (long)rows * cols, st);
+    const long tot = (long)rows * cols;
+    int grid = (int)min((tot + 255) / 256, 2048L);
+    hipLaunchKernelGGL(fill_zero_2d_kernel, dim3(grid), dim3(256), 0, st, p, rows, cols, ld);
+    return check_launch("fill_zero_2d");
+}
+int fill_zero(float* p, long n, hipStream_t st) {
+    if (n <= 0) return 0;
+    int grid = (int)min((n + 255) / 256, 2048L);
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(grid), dim3(256), 0, st, p, n);
+    return check_launch("fill_zero");
+}
+
+// one lane per column (coalesced 256 B per wave-row), 4 waves stride the rows, LDS combine
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, int rows, int cols,
+                                                     float* __restrict__ out, int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (col < cols)
+        for (int r = wave; r < rows; r += 4) s += X[(long)r * ld + col];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < cols) {
+        float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        out[col] = accumulate ? out[col] + t : t;
+    }
+}
+int colsum(const float* X, long ld, int rows, int cols, float* out, bool accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, X, ld, rows, cols, out, accumulate ? 1 : 0);
+    return check_launch("colsum");
+}
+
+__global__ void sum_over_time_kernel(const float* __restrict__ X, long ld, int S, int N, int cols,
+                                     float* __restrict__ out, long ld_out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * cols) return;
+    const int n = (int)(idx / cols), j = (int)(idx % cols);
+    float s = 0.f;
+    for (int t = 0; t < S; ++t) s += X[((long)t * N + n) * ld + j];
+    out[(long)n * ld_out + j] = s;
+}
+int sum_over_time(const float* X, long ld, int S, int N, int cols, float* out, long ld_out, hipStream_t st) {
+    const long tot = (long)N * cols;
+    hipLaunchKernelGGL(sum_over_time_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, ld, S, N, cols, out, ld_out);
+    return check_launch("sum_over_time");
+}
+
+// ---- embedding gather / scatter-add ----------------------------------------------------------------
+__global__ void embed_gather_kernel(const float* __restrict__ W, const int* __restrict__ tok, float* __restrict__ out,
+                                    int rows, int E, int V1) {
+    const int row = blockIdx.x;
+    int t = tok[row];
+    t = min(max(t, 0), V1 - 1);
+    for (int j = threadIdx.x; j < E; j += blockDim.x) out[(long)row * E + j] = W[(long)t * E + j];
+}
+int embed_gather(const float* W, const int* tok, float* out, int rows, int E, int V1, hipStream_t st) {
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(rows), dim3(128), 0, st, W, tok, out, rows, E, V1);
+    return check_launch("embed_gather");
+}
+__global__ void embed_scatter_add_kernel(const float* __restrict__ dX, const int* __restrict__ tok, float* __restrict__ gW,
+                                         int rows, int E, int V1) {
+    const int row = blockIdx.x;
+    int t = tok[row];
+    t = min(max(t, 0), V1 - 1);
+    for (int j = threadIdx.x; j < E; j += blockDim.x) atomicAdd(&gW[(long)t * E + j], dX[(long)row * E + j]);
+}
+int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st) {
+    hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(rows), dim3(128), 0, st, dX, tok, gW, rows, E, V1);
+    return check_launch("embed_scatter_add");
+}
+
+// ---- row log-softmax (in place) ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logsoftmax_rows_kernel(float* __restrict__ X, long ld, int cols) {
+    __shared__ float red[4];
+    float* x = X + (long)blockIdx.x * ld;
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < cols; j += 256) m = fmaxf(m, x[j]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < cols; j += 256) s += expf(x[j] - m);
+    s = block_sum(s, red);
+    const float lse = m + logf(s);
+    for (int j = threadIdx.x; j < cols; j += 256) x[j] = x[j] - lse;
+}
+int logsoftmax_rows(float* X, long ld, int rows, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(logsoftmax_rows_kernel, dim3(rows), dim3(256), 0, st, X, ld, cols);
+    return check_launch("logsoftmax_rows");
+}
+
+// d logits (time-major rows t*N+n, leading dim ldo, zero padded) from log-probs [N,S,V1] and either a
+// dense upstream gradient G [N,S,V1] or the fused masked-NLL gradient (target/mask/g_loss/inv_den).
+__global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __restrict__ logp, const float* __restrict__ G,
+                                                             const int* __restrict__ target, const float* __restrict__ mask,
+                                                             const float* __restrict__ g_loss, const float* __restrict__ mask_sum,
+                                                             float* __restrict__ out, long ldo, int N, int S, int V1) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;             // time-major row = t*N + n
+    const int t = row / N, n = row % N;
+    const long src = ((long)n * S + t) * V1;
+    float* o = out + (long)row * ldo;
+    if (G) {
+        float s = 0.f;
+        for (int j = threadIdx.x; j < V1; j += 256) s += G[src + j];
+        s = block_sum(s, red);
+        for (int j = threadIdx.x; j < V1; j += 256) o[j] = G[src + j] - expf(logp[src + j]) * s;
+    } else {
+        // loss = -sum(logp[target]*mask)/(sum(mask)+1e-6)  =>  g[target] = -mask/(den) * g_loss, other entries 0
+        const float gv = -mask[n * S + t] / (mask_sum[0] + 1e-6f) * g_loss[0];
+        const int tg = target[n * S + t];
+        for (int j = threadIdx.x; j < V1; j += 256) o[j] = (j == tg ? gv : 0.f) - expf(logp[src + j]) * gv;
+    }
+    for (int j = V1 + threadIdx.x; j < ldo; j += 256) o[j] = 0.f;
+}
+int logsoftmax_bwd(const float* logp, const float* G, const int* target, const float* mask, const float* g_loss,
+                   const float* mask_sum, float* out, long ldo, int N, int S, int V1, hipStream_t st) {
+    hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(N * S), dim3(256), 0, st, logp, G, target, mask, g_loss, mask_sum, out, ldo, N, S, V1);
+    return check_launch("logsoftmax_bwd");
+}
+
+// masked NLL (misc/utils.py:66-75): out[0] = loss, out[1] = sum(mask)
+__global__ __launch_bounds__(256) void nll_loss_kernel(const float* __restrict__ logp, const int* __restrict__ target,
+                                                       const float* __restrict__ mask, float* __restrict__ out, int NS, int V1) {
+    __shared__ float red[4];
+    float s = 0.f, ms = 0.f;
+    for (int i = threadIdx.x; i < NS; i += 256) {
+        const float mk = mask[i];
+        int tg = min(max(target[i], 0), V1 - 1);
+        s -= logp[(long)i * V1 + tg] * mk;
+        ms += mk;
+    }
+    s = block_sum(s, red);
+    ms = block_sum(ms, red);
+    if (threadIdx.x == 0) { out[0] = s / (ms + 1e-6f); out[1] = ms; }
+}
+
+// ---- event pooling + anchor gather (CaptionGenerator.py:111-114,121,128) -----------------------------
+__global__ void event_pool_gather_kernel(const float* __restrict__ c3d, const float* __restrict__ tap, const int* __restrict__ ev_start,
+                                         const int* __restrict__ ev_len, const int* __restrict__ ind, float* __restrict__ ech,
+                                         int D, int Ht) {
+    const int n = blockIdx.x;
+    const int s = ev_start[n], len = ev_len[n];
+    float* o = ech + (long)n * (D + Ht);
+    for (int j = threadIdx.x; j < D; j += blockDim.x) {
+        float acc = 0.f;
+        for (int a = 0; a < len; ++a) acc += c3d[(long)(s + a) * D + j];
+        o[j] = acc / (float)len;
+    }
+    const long trow = ind[n];
+    for (int j = threadIdx.x; j < Ht; j += blockDim.x) o[D + j] = tap[trow * Ht + j];
+}
+__global__ void event_gather_bwd_kernel(const float* __restrict__ d_ech, const int* __restrict__ ind, float* __restrict__ d_tap,
+                                        int D, int Ht) {
+    const int n = blockIdx.x;
+    const long trow = ind[n];
+    for (int j = threadIdx.x; j < Ht; j += blockDim.x) atomicAdd(&d_tap[trow * Ht + j], d_ech[(long)n * (D + Ht) + D + j]);
+}
+
+// ---- greedy arg-max over logits rows: lowest index on ties (torch.max semantics, OldModel_NEW.py:158) ---
+// Updates the sampler state: it_next[n] (int32), unfinished[n], seq/seq_logp column, n_unfinished counter.
+__global__ __launch_bounds__(256) void greedy_step_kernel(const float* __restrict__ logits, long ld, int V1, int t, int seq_len,
+                                                          int* __restrict__ it_next, int* __restrict__ unfinished,
+                                                          long long* __restrict__ seq, float* __restrict__ seq_logp,
+                                                          int* __restrict__ n_unfinished) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const int n = blockIdx.x;
+    const float* x = logits + (long)n * ld;
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int j = threadIdx.x; j < V1; j += 256) {
+        const float v = x[j];
+        if (v > m) { m = v; mi = j; }   // ascending j per thread: first maximum kept
+    }
+    // wave arg-max with (value, lowest index) ordering
+    for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_xor(m, off, 64);
+        const int oi = __shfl_xor(mi, off, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[wave] = m; redi[wave] = mi; }
+    __syncthreads();
+    float bm = red[0];
+    int bi = redi[0];
+    for (int w = 1; w < 4; ++w)
+        if (red[w] > bm || (red[w] == bm && redi[w] < bi)) { bm = red[w]; bi = redi[w]; }
+    float s = 0.f;
+    for (int j = threadIdx.x; j < V1; j += 256) s += expf(x[j] - bm);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        // step t produced logits(t); the token fed at step t+1 is argmax -> sample position t (0-based)
+        const float lp = -logf(s);              // log-softmax value at the maximum
+        int un = (t == 0) ? 1 : unfinished[n];
+        un = un && (bi > 0);
+        unfinished[n] = un;
+        const int tok = un ? bi : 0;
+        it_next[n] = bi;   // the network keeps consuming the raw arg-max; only the emitted seq is masked (:181 runs after :171)
+        if (t < seq_len) {
+            seq[(long)n * seq_len + t] = tok;
+            seq_logp[(long)n * seq_len + t] = lp;
+        }
+        if (un) atomicAdd(&n_unfinished[t + 1], 1);
+    }
+}
+
+// ---- fused clamp + Adam (misc/utils.py:107-111 + torch.optim.Adam) ------------------------------------
+__global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
+                                                         float b1, float b2, float eps, float clip) {
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        float4 G = reinterpret_cast<const float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i];
+        float4 V = reinterpret_cast<float4*>(v)[i];
+        float* pp = &P.x; float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gk = fminf(fmaxf(gg[k], -clip), clip);
+            mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+            const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
+            pp[k] -= lr_over_bc1 * (mm[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(m)[i] = M;
+        reinterpret_cast<float4*>(v)[i] = V;
+    }
+    // tail
+    const long base = n4 << 2;
+    const long i = base + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float gk = fminf(fmaxf(g[i], -clip), clip);
+        float mk = b1 * m[i] + (1.f - b1) * gk;
+        float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+        m[i] = mk; v[i] = vk;
+        p[i] -= lr_over_bc1 * (mk / (sqrtf(vk) * inv_sqrt_bc2 + eps));
+    }
+}
+
+__global__ void clamp_kernel(float* g, long n, float clip) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = fminf(fmaxf(g[i], -clip), clip);
+}
+
+int greedy_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
+                long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st) {
+    hipLaunchKernelGGL(greedy_step_kernel, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq, seq_logp, n_unfinished);
+    return check_launch("greedy_step");
+}
+
+}  // namespace echr
+
+using namespace echr;
+
+extern "C" int echr_version(void) { return ECHR_ABI_VERSION; }
+extern "C" const char* echr_last_error(void) { return g_err; }
+
+extern "C" int echr_event_pool_gather_fwd(const float* c3d, const float* tap, const int32_t* ev_start, const int32_t* ev_len,
+                                          const int32_t* ind, float* ech, int32_t N, int32_t D, int32_t Ht, void* stream) {
+    ECHR_REQUIRE(c3d && tap && ev_start && ev_len && ind && ech && N > 0 && D > 0 && Ht > 0, "event_pool_gather_fwd: bad arguments");
+    hipLaunchKernelGGL(event_pool_gather_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, c3d, tap, ev_start, ev_len, ind, ech, D, Ht);
+    return check_launch("event_pool_gather_fwd");
+}
+extern "C" int echr_event_pool_gather_bwd(const float* d_ech, const int32_t* ind, float* d_tap, int32_t N, int32_t D, int32_t Ht,
+                                          void* stream) {
+    ECHR_REQUIRE(d_ech && ind && d_tap && N > 0, "event_pool_gather_bwd: bad arguments");
+    hipLaunchKernelGGL(event_gather_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, d_ech, ind, d_tap, D, Ht);
+    return check_launch("event_pool_gather_bwd");
+}
+
+extern "C" int echr_nll_loss_fwd(const float* logp, const int32_t* target, const float* mask, float* loss, int32_t N, int32_t S,
+                                 int32_t V1, void* stream) {
+    ECHR_REQUIRE(logp && target && mask && loss && N > 0 && S > 0 && V1 > 0, "nll_loss_fwd: bad arguments");
+    hipLaunchKernelGGL(nll_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, target, mask, loss, N * S, V1);
+    return check_launch("nll_loss_fwd");
+}
+
+extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1,
+                               float beta2, float eps, float clip, void* stream) {
+    ECHR_REQUIRE(p && g && m && v && n > 0 && step >= 1, "clamp_adam: bad arguments");
+    ECHR_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                 "clamp_adam: buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const long n4 = n >> 2;
+    int grid = (int)min(max((n4 + 255) / 256, 1L), 4096L);
+    hipLaunchKernelGGL(clamp_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, (float)(lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, clip);
+    return check_launch("clamp_adam");
+}
+
+extern "C" int echr_clamp(float* g, int64_t n, float clip, void* stream) {
+    ECHR_REQUIRE(g && n > 0, "clamp: bad arguments");
+    int grid = (int)min(((long)n + 255) / 256, 4096L);
+    hipLaunchKernelGGL(clamp_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, (long)n, clip);
+    return check_launch("clamp");
+}

@@ -1,0 +1,706 @@
+// Three-stream attention caption decoder on gfx950: the per-timestep kernels (frame-level additive
+// attention score -> softmax -> context, LSTM-cell gate math with counter-based dropout) and the
+// host-side sequence drivers that string them together with the MFMA projections of gemm.hip.
+//
+// Reference semantics: models/OldModel_NEW.py:98-137 (teacher-forced loop, get_logprobs_state),
+// :376-401 (Attention), :801-823 (ThreeStream_Core), :139-187 (greedy sample).
+//
+// Data layout decisions:
+//  * The clip context is never materialised as [N,A,D]: event n's slot a is row ev_start[n]+a of
+//    c3d[Tv,D] (CaptionGenerator.py:147-151 builds a zero-padded copy instead).  ctx2att is applied ONCE
+//    per forward to the Tv video rows (P_all[Tv,Ha]) instead of to N*A rows every timestep (:381).
+//  * Padding slots are skipped: softmax over all A slots, x mask, / sum (:394-397) equals the softmax
+//    over the valid slots (the padded terms cancel in the renormalisation).
+//  * Time-major internal buffers [S, N, .]; only the log-prob output is written [N, S, V1].
+//  * Because ss_prob == 0 (:36), the token/context halves of every W_ih product are batched over all
+//    S*N rows before the recurrence; only W_hh.h and the attended-context columns are sequential.
+#include "echr_common.h"
+#include "echr_internal.h"
+
+namespace echr {
+
+enum { SITE_TSRM = 0, SITE_H0 = 1, SITE_H1 = 2, SITE_H2 = 3, SITE_OUT = 4 };
+
+static inline unsigned drop_thresh(float p) {
+    if (p >= 1.f) return 0xFFFFFFFFu;
+    double t = floor((double)p * 4294967296.0);
+    return (unsigned)((unsigned long long)t & 0xFFFFFFFFull);
+}
+DropCfg make_drop(const echr_dropout* d, float p) {
+    DropCfg c;
+    c.k0 = (unsigned)(d ? (d->seed & 0xFFFFFFFFull) : 0);
+    c.k1 = (unsigned)(d ? (d->seed >> 32) : 0);
+    c.offset = d ? d->offset : 0;
+    c.thresh = drop_thresh(p);
+    c.scale = 1.0f / (1.0f - p);
+    c.active = (d && d->training && p > 0.f) ? 1 : 0;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Frame-level attention, forward.
+// score kernel: grid (N, ceil(A/32)); a workgroup scores 32 slots of one event, one wave per 8 slots, lanes
+// across the Ha axis (float4), wave-shuffle reduction.  q[n,:] and alpha live in LDS.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict__ PALL, const float* __restrict__ Q,
+                                                        const float* __restrict__ alpha, const float* __restrict__ b_alpha,
+                                                        const int* __restrict__ ev_start, const int* __restrict__ ev_len,
+                                                        float* __restrict__ SC, int A, int Ha) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sq = sm;          // [Ha]
+    float* sa = sm + Ha;     // [Ha]
+    const int n = blockIdx.x, a0 = blockIdx.y * 32;
+    const int len = ev_len[n];
+    if (a0 >= len) return;
+    for (int j = threadIdx.x; j < Ha; j += 256) { sq[j] = Q[(long)n * Ha + j]; sa[j] = alpha[j]; }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row0 = ev_start[n];
+    const float ba = b_alpha[0];
+    for (int i = 0; i < 8; ++i) {
+        const int a = a0 + wave * 8 + i;
+        if (a >= len) break;
+        const float* prow = PALL + (row0 + a) * Ha;
+        float acc = 0.f;
+        for (int j = lane * 4; j < Ha; j += 256) {
+            const float4 p4 = *reinterpret_cast<const float4*>(prow + j);
+            const float4 q4 = *reinterpret_cast<const float4*>(sq + j);
+            const float4 a4 = *reinterpret_cast<const float4*>(sa + j);
+            acc += a4.x * fast_tanh(p4.x + q4.x) + a4.y * fast_tanh(p4.y + q4.y) + a4.z * fast_tanh(p4.z + q4.z) +
+                   a4.w * fast_tanh(p4.w + q4.w);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) SC[(long)n * A + a] = acc + ba;
+    }
+}
+
+// context kernel: grid (N, ceil(D/128)); softmax over the event's valid slots, then ctx[n, d-chunk] =
+// sum_a w_a * c3d[start+a, d-chunk]; 32 float4 lanes across the chunk x 8 row groups, LDS combine.
+__global__ __launch_bounds__(256) void att_context_kernel(const float* __restrict__ C3D, const float* __restrict__ SC,
+                                                          const int* __restrict__ ev_start, const int* __restrict__ ev_len,
+                                                          float* __restrict__ WT, float* __restrict__ ATT, int A, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* w = sm;                       // [A]
+    float* red = sm + ((A + 3) & ~3);    // [8][128]
+    __shared__ float r4[4];
+    const int n = blockIdx.x, d0 = blockIdx.y * 128;
+    const int len = ev_len[n];
+    const long row0 = ev_start[n];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float m = -INFINITY;
+    for (int a = threadIdx.x; a < len; a += 256) m = fmaxf(m, SC[(long)n * A + a]);
+    m = wave_max(m);
+    if (lane == 0) r4[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(r4[0], r4[1]), fmaxf(r4[2], r4[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int a = threadIdx.x; a < len; a += 256) { const float e = __expf(SC[(long)n * A + a] - m); w[a] = e; s += e; }
+    s = wave_sum(s);
+    if (lane == 0) r4[wave] = s;
+    __syncthreads();
+    const float inv = 1.0f / (r4[0] + r4[1] + r4[2] + r4[3]);
+    for (int a = threadIdx.x; a < A; a += 256) {
+        const float wa = a < len ? w[a] * inv : 0.f;
+        if (a < len) w[a] = wa;
+        if (blockIdx.y == 0) WT[(long)n * A + a] = wa;
+    }
+    __syncthreads();
+    const int dl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int d = d0 + dl * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d < D) {
+        for (int a = rg; a < len; a += 8) {
+            const float wa = w[a];
+            const float4 c = *reinterpret_cast<const float4*>(C3D + (row0 + a) * D + d);
+            acc.x += wa * c.x; acc.y += wa * c.y; acc.z += wa * c.z; acc.w += wa * c.w;
+        }
+    }
+    *reinterpret_cast<float4*>(red + rg * 128 + dl * 4) = acc;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int dd = d0 + threadIdx.x;
+        if (dd < D) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += red[g * 128 + threadIdx.x];
+            ATT[(long)n * D + dd] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Frame-level attention, backward for one timestep.  grid (N, ceil(A/32)).
+//   dscore_a = w_a * (clip_a . dATT - ATT . dATT);  dq += sum_a dscore_a * alpha * (1 - tanh^2(P_a + q))
+// DSC keeps dscore for the post-recurrence pass that accumulates d P_all and d alpha over all timesteps
+// (that pass recomputes tanh instead of reading+writing an [N,A,Ha] accumulator every step).
+// ------------------------------------------------------------------------------------------------------
+constexpr int MAXR = 4;   // Ha <= 256 * MAXR
+
+__global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ PALL, const float* __restrict__ C3D,
+                                                      const float* __restrict__ Q, const float* __restrict__ alpha,
+                                                      const float* __restrict__ WT, const float* __restrict__ ATT,
+                                                      const float* __restrict__ DATT, const int* __restrict__ ev_start,
+                                                      const int* __restrict__ ev_len, float* __restrict__ DSC,
+                                                      float* __restrict__ DQ, int A, int Ha, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sq = sm;                 // [Ha]
+    float* sa = sq + Ha;            // [Ha]
+    float* sd = sa + Ha;            // [D4] dATT row
+    const int D4 = (D + 3) & ~3;
+    float* red = sd + D4;           // [4][Ha]
+    __shared__ float r4[4];
+    const int n = blockIdx.x, a0 = blockIdx.y * 32;
+    const int len = ev_len[n];
+    if (a0 >= len) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float s0 = 0.f;
+    for (int j = threadIdx.x; j < Ha; j += 256) { sq[j] = Q[(long)n * Ha + j]; sa[j] = alpha[j]; }
+    for (int j = threadIdx.x; j < D4; j += 256) {
+        const float dv = j < D ? DATT[(long)n * D + j] : 0.f;
+        sd[j] = dv;
+        if (j < D) s0 += dv * ATT[(long)n * D + j];
+    }
+    s0 = wave_sum(s0);
+    if (lane == 0) r4[wave] = s0;
+    __syncthreads();
+    s0 = r4[0] + r4[1] + r4[2] + r4[3];
+    const long row0 = ev_start[n];
+    float dq[MAXR * 4];
+#pragma unroll
+    for (int r = 0; r < MAXR * 4; ++r) dq[r] = 0.f;
+    for (int i = 0; i < 8; ++i) {
+        const int a = a0 + wave * 8 + i;
+        if (a >= len) break;
+        const float* crow = C3D + (row0 + a) * D;
+        float dw = 0.f;
+        for (int j = lane * 4; j < D; j += 256) {
+            const float4 c = *reinterpret_cast<const float4*>(crow + j);
+            const float4 g = *reinterpret_cast<const float4*>(sd + j);
+            dw += c.x * g.x + c.y * g.y + c.z * g.z + c.w * g.w;
+        }
+        dw = wave_sum(dw);
+        const float dsc = WT[(long)n * A + a] * (dw - s0);
+        if (lane == 0) DSC[(long)n * A + a] = dsc;
+        const float* prow = PALL + (row0 + a) * Ha;
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const int j = lane * 4 + r * 256;
+            if (j < Ha) {
+                const float4 p4 = *reinterpret_cast<const float4*>(prow + j);
+                const float4 q4 = *reinterpret_cast<const float4*>(sq + j);
+                const float4 a4 = *reinterpret_cast<const float4*>(sa + j);
+                float t;
+                t = fast_tanh(p4.x + q4.x); dq[r * 4 + 0] += dsc * a4.x * (1.f - t * t);
+                t = fast_tanh(p4.y + q4.y); dq[r * 4 + 1] += dsc * a4.y * (1.f - t * t);
+                t = fast_tanh(p4.z + q4.z); dq[r * 4 + 2] += dsc * a4.z * (1.f - t * t);
+                t = fast_tanh(p4.w + q4.w); dq[r * 4 + 3] += dsc * a4.w * (1.f - t * t);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int j = lane * 4 + r * 256;
+        if (j < Ha) *reinterpret_cast<float4*>(red + wave * Ha + j) = make_float4(dq[r * 4], dq[r * 4 + 1], dq[r * 4 + 2], dq[r * 4 + 3]);
+    }
+    __syncthreads();
+    // waves past the event's end never ran the slot loop: their partial is the zero they just stored
+    for (int j = threadIdx.x; j < Ha; j += 256)
+        atomicAdd(&DQ[(long)n * Ha + j], red[j] + red[Ha + j] + red[2 * Ha + j] + red[3 * Ha + j]);
+}
+
+// Post-recurrence pass: d P_all[row,:] += sum_t dsc_t * alpha * (1 - tanh^2(P_row + q_t)),
+//                       d alpha      += sum_{t,n,a} dsc_t * tanh(P_row + q_t),  d b_alpha += sum dsc.
+// grid (N, ceil(A/32)); q_t[n,:] for a tile of TT timesteps is staged in LDS.
+constexpr int TT = 16;
+__global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__ PALL, const float* __restrict__ QS,
+                                                       const float* __restrict__ alpha, const float* __restrict__ DSC,
+                                                       const int* __restrict__ ev_start, const int* __restrict__ ev_len,
+                                                       float* __restrict__ DPALL, float* __restrict__ g_alpha,
+                                                       float* __restrict__ g_balpha, int S, int N, int A, int Ha) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sqt = sm;                   // [TT][Ha]
+    float* sa = sqt + TT * Ha;         // [Ha]
+    float* sds = sa + Ha;              // [TT][32] dscore tile
+    float* red = sds + TT * 32;        // [4][Ha]
+    const int n = blockIdx.x, a0 = blockIdx.y * 32;
+    const int len = ev_len[n];
+    if (a0 >= len) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row0 = ev_start[n];
+    for (int j = threadIdx.x; j < Ha; j += 256) sa[j] = alpha[j];
+    float dal[MAXR * 4];
+    float dp[8][MAXR * 4];             // one accumulator row per slot of this wave (kept across t-tiles)
+#pragma unroll
+    for (int r = 0; r < MAXR * 4; ++r) dal[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < MAXR * 4; ++r) dp[i][r] = 0.f;
+    float dsum = 0.f;
+    for (int t0 = 0; t0 < S; t0 += TT) {
+        const int nt = min(TT, S - t0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nt * Ha; idx += 256) {
+            const int tt = idx / Ha, j = idx % Ha;
+            sqt[tt * Ha + j] = QS[((long)(t0 + tt) * N + n) * Ha + j];
+        }
+        for (int idx = threadIdx.x; idx < nt * 32; idx += 256) {
+            const int tt = idx / 32, i = idx % 32;
+            sds[tt * 32 + i] = (a0 + i < len) ? DSC[((long)(t0 + tt) * N + n) * A + a0 + i] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int a = a0 + wave * 8 + i;
+            if (a < len) {
+                const float* prow = PALL + (row0 + a) * Ha;
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r) {
+                    const int j = lane * 4 + r * 256;
+                    if (j < Ha) {
+                        const float4 p4 = *reinterpret_cast<const float4*>(prow + j);
+                        const float4 a4 = *reinterpret_cast<const float4*>(sa + j);
+                        for (int tt = 0; tt < nt; ++tt) {
+                            const float dsc = sds[tt * 32 + wave * 8 + i];
+                            const float4 q4 = *reinterpret_cast<const float4*>(sqt + tt * Ha + j);
+                            float t;
+                            t = fast_tanh(p4.x + q4.x); dp[i][r * 4 + 0] += dsc * a4.x * (1.f - t * t); dal[r * 4 + 0] += dsc * t;
+                            t = fast_tanh(p4.y + q4.y); dp[i][r * 4 + 1] += dsc * a4.y * (1.f - t * t); dal[r * 4 + 1] += dsc * t;
+                            t = fast_tanh(p4.z + q4.z); dp[i][r * 4 + 2] += dsc * a4.z * (1.f - t * t); dal[r * 4 + 2] += dsc * t;
+                            t = fast_tanh(p4.w + q4.w); dp[i][r * 4 + 3] += dsc * a4.w * (1.f - t * t); dal[r * 4 + 3] += dsc * t;
+                        }
+                    }
+                }
+                if (lane == 0)
+                    for (int tt = 0; tt < nt; ++tt) dsum += sds[tt * 32 + wave * 8 + i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int a = a0 + wave * 8 + i;
+        if (a < len) {
+            float* drow = DPALL + (row0 + a) * Ha;
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                const int j = lane * 4 + r * 256;
+                if (j < Ha) {
+                    atomicAdd(drow + j + 0, dp[i][r * 4 + 0]);
+                    atomicAdd(drow + j + 1, dp[i][r * 4 + 1]);
+                    atomicAdd(drow + j + 2, dp[i][r * 4 + 2]);
+                    atomicAdd(drow + j + 3, dp[i][r * 4 + 3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int j = lane * 4 + r * 256;
+        if (j < Ha) *reinterpret_cast<float4*>(red + wave * Ha + j) = make_float4(dal[r * 4], dal[r * 4 + 1], dal[r * 4 + 2], dal[r * 4 + 3]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Ha; j += 256)
+        atomicAdd(&g_alpha[j], red[j] + red[Ha + j] + red[2 * Ha + j] + red[3 * Ha + j]);
+    if (lane == 0 && dsum != 0.f) atomicAdd(g_balpha, dsum);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// LSTM cell gate math for the three streams of one timestep (nn.LSTMCell order i,f,g,o).
+// GATES holds the complete pre-activations on entry and the activations on exit (saved for backward).
+// h is dropped once for the recurrence/state (OldModel_NEW.py:810,814,818) and once more for the
+// late-fusion input (:136).
+// ------------------------------------------------------------------------------------------------------
+struct LstmPtrs {
+    float* gates[3];      // [N,4H] slice of timestep t
+    const float* c_prev[3];
+    float* c_new[3];
+};
+
+__global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(LstmPtrs P, float* __restrict__ h_out, float* __restrict__ outd,
+                                                                 int N, int H, int t, DropCfg dh, DropCfg dout) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * H) return;
+    const int k = blockIdx.y;
+    const int n = idx / H, j = idx % H;
+    float* g = P.gates[k] + (long)n * 4 * H;
+    const float gi = fast_sigmoid(g[j]);
+    const float gf = fast_sigmoid(g[H + j]);
+    const float gg = tanhf(g[2 * H + j]);
+    const float go = fast_sigmoid(g[3 * H + j]);
+    const float c = gf * P.c_prev[k][idx] + gi * gg;
+    g[j] = gi; g[H + j] = gf; g[2 * H + j] = gg; g[3 * H + j] = go;
+    P.c_new[k][idx] = c;
+    const float h = go * tanhf(c) * drop_mult(dh, (unsigned)idx, (unsigned)t, (unsigned)(SITE_H0 + k));
+    const long o = (long)n * 3 * H + k * H + j;
+    h_out[o] = h;
+    outd[o] = h * drop_mult(dout, (unsigned)o, (unsigned)t, SITE_OUT);
+}
+
+struct LstmBwdPtrs {
+    const float* gates[3];   // activations of timestep t
+    const float* c_prev[3];
+    const float* c_new[3];
+    float* dgates[3];        // [N,4H] slice of timestep t
+};
+
+// dh = dOUTD * m_out + dHREC (recurrent part from step t+1);  dC carries c-gradients between steps.
+__global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdPtrs P, const float* __restrict__ doutd,
+                                                                 const float* __restrict__ dhrec, float* __restrict__ dc,
+                                                                 int N, int H, int t, DropCfg dh, DropCfg dout) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * H) return;
+    const int k = blockIdx.y;
+    const int n = idx / H, j = idx % H;
+    const long o = (long)n * 3 * H + k * H + j;
+    float dhv = doutd[o] * drop_mult(dout, (unsigned)o, (unsigned)t, SITE_OUT) + (dhrec ? dhrec[o] : 0.f);
+    dhv *= drop_mult(dh, (unsigned)idx, (unsigned)t, (unsigned)(SITE_H0 + k));
+    const float* g = P.gates[k] + (long)n * 4 * H;
+    const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+    const float tc = tanhf(P.c_new[k][idx]);
+    const float dcv = dhv * go * (1.f - tc * tc) + dc[o];
+    float* dg = P.dgates[k] + (long)n * 4 * H;
+    dg[j] = dcv * gg * gi * (1.f - gi);
+    dg[H + j] = dcv * P.c_prev[k][idx] * gf * (1.f - gf);
+    dg[2 * H + j] = dcv * gi * (1.f - gg * gg);
+    dg[3 * H + j] = dhv * tc * go * (1.f - go);
+    dc[o] = dcv * gf;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// workspace carving
+// ------------------------------------------------------------------------------------------------------
+static inline long rup(long x, long a) { return (x + a - 1) / a * a; }
+
+struct DecWs {
+    float *XT, *GATES[3], *CS[3], *HS, *OUTD, *PALL, *QS, *SC, *WT, *ATT, *EVB0, *VIDB;
+    long total;
+};
+static DecWs carve_ws(const echr_dec_args* a, float* base) {
+    DecWs w;
+    long off = 0;
+    const long N = a->N, S = a->S, H = a->H;
+    auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
+    w.XT = take(S * N * a->E);
+    for (int k = 0; k < 3; ++k) w.GATES[k] = take(S * N * 4 * H);
+    for (int k = 0; k < 3; ++k) w.CS[k] = take((S + 1) * N * H);
+    w.HS = take((S + 1) * N * 3 * H);
+    w.OUTD = take(S * N * 3 * H);
+    w.PALL = take((long)a->Tv * a->Ha);
+    w.QS = take(S * N * a->Ha);
+    w.SC = take(S * N * a->A);
+    w.WT = take(S * N * a->A);
+    w.ATT = take(S * N * a->D);
+    w.EVB0 = take(N * 4 * H);
+    w.VIDB = take(4 * H);
+    w.total = off;
+    return w;
+}
+
+struct DecWsBwd {
+    float *DLG, *DOUT, *DG[3], *DHREC, *DC, *DATT, *DSC, *DQ, *DPALL, *DGSUM[3], *DGCOL[3], *DXT, *MSUM;
+    long ldg, total;
+};
+static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
+    DecWsBwd w;
+    long off = 0;
+    const long N = a->N, S = a->S, H = a->H;
+    auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
+    w.ldg = rup(a->V1, 4);
+    w.DLG = take(S * N * w.ldg);
+    w.DOUT = take(S * N * 3 * H);
+    for (int k = 0; k < 3; ++k) w.DG[k] = take(S * N * 4 * H);
+    w.DHREC = take(S * N * 3 * H);
+    w.DC = take(N * 3 * H);
+    w.DATT = take(S * N * a->D);
+    w.DSC = take(S * N * a->A);
+    w.DQ = take(S * N * a->Ha);
+    w.DPALL = take((long)a->Tv * a->Ha);
+    for (int k = 0; k < 3; ++k) w.DGSUM[k] = take(N * 4 * H);
+    for (int k = 0; k < 3; ++k) w.DGCOL[k] = take(4 * H);
+    w.DXT = take(S * N * a->E);
+    w.MSUM = take(64);
+    w.total = off;
+    return w;
+}
+
+static int check_dims(const echr_dec_args* a, const char* who) {
+    ECHR_REQUIRE(a, "%s: null args", who);
+    ECHR_REQUIRE(a->N > 0 && a->A > 0 && a->Tv > 0 && a->S >= 0, "%s: bad N/A/Tv/S", who);
+    ECHR_REQUIRE(a->D % 4 == 0 && a->Ha % 4 == 0 && a->Ha <= 256 * MAXR, "%s: need D%%4==0, Ha%%4==0, Ha<=%d (D=%d Ha=%d)", who, 256 * MAXR, a->D, a->Ha);
+    ECHR_REQUIRE(a->H > 0 && a->E > 0 && a->De > 0 && a->Dv > 0 && a->V1 > 1, "%s: bad widths", who);
+    return 0;
+}
+
+#define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+// P_all = c3d . W_c^T + b_c over the Tv video rows; EVB0 = event . W_ih0[:,E:]^T + b_ih0 + b_hh0;
+// VIDB = W_ih2[:,E:] . video + b_ih2 + b_hh2   (all time-invariant)
+static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t st) {
+    const int H = a->H, E = a->E;
+    echr_gemm_desc d = desc_nt(a->c3d, a->D, a->w_c2a, a->D, w.PALL, a->Ha, a->Tv, a->Ha, a->D);
+    d.bias = a->b_c2a; d.split_k = -1;
+    RC(gemm(d, st));
+    d = desc_nt(a->event, a->De, a->w_ih[0] + E, E + a->De, w.EVB0, 4 * H, a->N, 4 * H, a->De);
+    d.bias = a->b_ih[0]; d.bias2 = a->b_hh[0]; d.split_k = -1;
+    RC(gemm(d, st));
+    d = desc_nt(a->video, a->Dv, a->w_ih[2] + E, E + a->Dv, w.VIDB, 4 * H, 1, 4 * H, a->Dv);
+    d.bias = a->b_ih[2]; d.bias2 = a->b_hh[2];
+    RC(gemm(d, st));
+    return 0;
+}
+
+// one decoder timestep given the input-side gate pre-activations already in GATES[k][t]
+static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg& dh, const DropCfg& dout, hipStream_t st) {
+    const int N = a->N, H = a->H, Ha = a->Ha, A = a->A, D = a->D, E = a->E;
+    const float* hprev = w.HS + (long)t * N * 3 * H;          // [N,3H] dropped h of step t-1 (zeros at t=0)
+    float* q = w.QS + (long)t * N * Ha;
+    // q = h1_prev . W_h^T + b_h
+    echr_gemm_desc d = desc_nt(hprev + H, 3 * H, a->w_h2a, H, q, Ha, N, Ha, H);
+    d.bias = a->b_h2a; d.split_k = -1;
+    RC(gemm(d, st));
+    float* sc = w.SC + (long)t * N * A;
+    float* wt = w.WT + (long)t * N * A;
+    float* att = w.ATT + (long)t * N * D;
+    hipLaunchKernelGGL(att_score_kernel, dim3(N, (A + 31) / 32), dim3(256), 2 * Ha * sizeof(float), st, w.PALL, q, a->w_alpha,
+                       a->b_alpha, a->ev_start, a->ev_len, sc, A, Ha);
+    RC(check_launch("att_score"));
+    hipLaunchKernelGGL(att_context_kernel, dim3(N, (D + 127) / 128), dim3(256), (((A + 3) & ~3) + 8 * 128) * sizeof(float), st, a->c3d, sc,
+                       a->ev_start, a->ev_len, wt, att, A, D);
+    RC(check_launch("att_context"));
+    // recurrent halves: GATES_k[t] += h_k_prev . W_hh_k^T ; stream 1 also += att . W_ih1[:,E:]^T
+    LstmPtrs P;
+    for (int k = 0; k < 3; ++k) {
+        float* g = w.GATES[k] + (long)t * N * 4 * H;
+        d = desc_nt(hprev + k * H, 3 * H, a->w_hh[k], H, g, 4 * H, N, 4 * H, H);
+        d.beta = 1.f; d.split_k = -1;
+        if (t > 0) RC(gemm(d, st));                              // h_prev == 0 at t == 0
+        if (k == 1) {
+            d = desc_nt(att, D, a->w_ih[1] + E, E + D, g, 4 * H, N, 4 * H, D);
+            d.beta = 1.f; d.split_k = -1;
+            RC(gemm(d, st));
+        }
+        P.gates[k] = g;
+        P.c_prev[k] = w.CS[k] + (long)t * N * H;
+        P.c_new[k] = w.CS[k] + (long)(t + 1) * N * H;
+    }
+    hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3((N * H + 255) / 256, 3), dim3(256), 0, st, P,
+                       w.HS + (long)(t + 1) * N * 3 * H, w.OUTD + (long)t * N * 3 * H, N, H, t, dh, dout);
+    return check_launch("lstm_pointwise_fwd");
+}
+
+// input-side gate pre-activations for `rows` = nt*N token rows starting at timestep t0
+static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, int t0, int nt, hipStream_t st) {
+    const int N = a->N, H = a->H, E = a->E;
+    const int rows = nt * N;
+    const int cin[3] = {E + a->De, E + a->D, E + a->Dv};
+    for (int k = 0; k < 3; ++k) {
+        float* g = w.GATES[k] + (long)t0 * N * 4 * H;
+        echr_gemm_desc d = desc_nt(xt, E, a->w_ih[k], cin[k], g, 4 * H, rows, 4 * H, E);
+        if (k == 0) { d.addend = w.EVB0; d.add_mod = N; d.ld_add = 4 * H; }
+        else if (k == 1) { d.bias = a->b_ih[1]; d.bias2 = a->b_hh[1]; }
+        else { d.bias = w.VIDB; }
+        d.split_k = -1;
+        RC(gemm(d, st));
+    }
+    return 0;
+}
+
+}  // namespace echr
+
+using namespace echr;
+
+extern "C" int64_t echr_decoder_ws_floats(const echr_dec_args* a) { return a ? carve_ws(a, nullptr).total : -1; }
+extern "C" int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a) { return a ? carve_ws_bwd(a, nullptr).total : -1; }
+
+extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream) {
+    RC(check_dims(a, "decoder_fwd"));
+    ECHR_REQUIRE(a->S > 0 && a->ws && a->logp && a->tokens, "decoder_fwd: missing buffers");
+    hipStream_t st = (hipStream_t)stream;
+    const int N = a->N, S = a->S, H = a->H, E = a->E;
+    DecWs w = carve_ws(a, a->ws);
+    const DropCfg dh = make_drop(drop, drop ? drop->p_h : 0.f), dout = make_drop(drop, drop ? drop->p_out : 0.f);
+    RC(fill_zero(w.HS, (long)N * 3 * H, st));                       // h(-1) = 0   (init_hidden, :75-78)
+    for (int k = 0; k < 3; ++k) RC(fill_zero(w.CS[k], (long)N * H, st));
+    RC(precompute_static(a, w, st));
+    RC(embed_gather(a->embed, a->tokens, w.XT, S * N, E, a->V1, st));
+    RC(input_gates(a, w, w.XT, 0, S, st));
+    for (int t = 0; t < S; ++t) RC(step_fwd(a, w, t, dh, dout, st));
+    // late fusion: logits = OUTD . W_logit^T + b, written [N,S,V1]; then row log-softmax in place
+    echr_gemm_desc d = desc_nt(w.OUTD, 3 * H, a->w_logit, 3 * H, a->logp, a->V1, S * N, a->V1, 3 * H);
+    d.bias = a->b_logit; d.rowmap_mod = N; d.rowmap_mul = S;
+    RC(gemm(d, st));
+    RC(logsoftmax_rows(a->logp, a->V1, N * S, a->V1, st));
+    return 0;
+}
+
+extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream) {
+    RC(check_dims(a, "decoder_bwd"));
+    ECHR_REQUIRE(g && a->ws && g->ws_bwd && a->logp, "decoder_bwd: missing buffers");
+    ECHR_REQUIRE(g->g_logp || (g->nll_target && g->nll_mask && g->g_loss), "decoder_bwd: need g_logp or the fused NLL inputs");
+    hipStream_t st = (hipStream_t)stream;
+    const int N = a->N, S = a->S, H = a->H, E = a->E, Ha = a->Ha, A = a->A, D = a->D, V1 = a->V1;
+    const int SN = S * N;
+    DecWs w = carve_ws(a, a->ws);
+    DecWsBwd b = carve_ws_bwd(a, g->ws_bwd);
+    const DropCfg dh = make_drop(drop, drop ? drop->p_h : 0.f), dout = make_drop(drop, drop ? drop->p_out : 0.f);
+    const int cin[3] = {E + a->De, E + D, E + a->Dv};
+
+    // 1. d logits (time-major, padded leading dimension)
+    if (!g->g_logp) RC(colsum(g->nll_mask, 1, N * S, 1, b.MSUM, false, st));
+    RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_mask, g->g_loss, b.MSUM, b.DLG, b.ldg, N, S, V1, st));
+    // 2. late fusion gradients
+    echr_gemm_desc d = desc_tn(b.DLG, b.ldg, w.OUTD, 3 * H, g->g_w_logit, 3 * H, V1, 3 * H, SN);
+    d.split_k = -1;
+    RC(gemm(d, st));
+    RC(colsum(b.DLG, b.ldg, SN, V1, g->g_b_logit, false, st));
+    d = desc_nn(b.DLG, b.ldg, a->w_logit, 3 * H, b.DOUT, 3 * H, SN, 3 * H, V1);
+    d.split_k = -1;
+    RC(gemm(d, st));
+    // 3. reverse recurrence
+    RC(fill_zero(b.DHREC, (long)SN * 3 * H, st));
+    RC(fill_zero(b.DC, (long)N * 3 * H, st));
+    RC(fill_zero(b.DATT, (long)SN * D, st));
+    RC(fill_zero(b.DQ, (long)SN * Ha, st));
+    for (int t = S - 1; t >= 0; --t) {
+        LstmBwdPtrs P;
+        for (int k = 0; k < 3; ++k) {
+            P.gates[k] = w.GATES[k] + (long)t * N * 4 * H;
+            P.c_prev[k] = w.CS[k] + (long)t * N * H;
+            P.c_new[k] = w.CS[k] + (long)(t + 1) * N * H;
+            P.dgates[k] = b.DG[k] + (long)t * N * 4 * H;
+        }
+        const float* dhrec = (t == S - 1) ? nullptr : b.DHREC + (long)(t + 1) * N * 3 * H;   // written while processing step t+1
+        hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((N * H + 255) / 256, 3), dim3(256), 0, st, P,
+                           b.DOUT + (long)t * N * 3 * H, dhrec, b.DC, N, H, t, dh, dout);
+        RC(check_launch("lstm_pointwise_bwd"));
+        float* dhr = b.DHREC + (long)t * N * 3 * H;      // d h(t-1), consumed by step t-1
+        if (t > 0) {
+            for (int k = 0; k < 3; ++k) {
+                d = desc_nn(P.dgates[k], 4 * H, a->w_hh[k], H, dhr + k * H, 3 * H, N, H, 4 * H);
+                d.beta = 1.f; d.split_k = -1;
+                RC(gemm(d, st));
+            }
+        }
+        // attended-context gradient and attention backward (needed at every t: feeds d P_all, d alpha, d W_h)
+        float* datt = b.DATT + (long)t * N * D;
+        d = desc_nn(P.dgates[1], 4 * H, a->w_ih[1] + E, cin[1], datt, D, N, D, 4 * H);
+        d.beta = 1.f; d.split_k = -1;
+        RC(gemm(d, st));
+        float* dq = b.DQ + (long)t * N * Ha;
+        const int D4 = (D + 3) & ~3;
+        hipLaunchKernelGGL(att_bwd_kernel, dim3(N, (A + 31) / 32), dim3(256), (6 * Ha + D4) * sizeof(float), st, w.PALL, a->c3d,
+                           w.QS + (long)t * N * Ha, a->w_alpha, w.WT + (long)t * N * A, w.ATT + (long)t * N * D, datt,
+                           a->ev_start, a->ev_len, b.DSC + (long)t * N * A, dq, A, Ha, D);
+        RC(check_launch("att_bwd"));
+        if (t > 0) {
+            d = desc_nn(dq, Ha, a->w_h2a, H, dhr + H, 3 * H, N, H, Ha);
+            d.beta = 1.f; d.split_k = -1;
+            RC(gemm(d, st));
+        }
+    }
+    // 4. batched parameter gradients
+    //    attention: d P_all / d alpha over all timesteps, then ctx2att and h2att weights
+    RC(fill_zero(b.DPALL, (long)a->Tv * Ha, st));
+    RC(fill_zero(g->g_w_alpha, Ha, st));
+    RC(fill_zero(g->g_b_alpha, 1, st));
+    hipLaunchKernelGGL(att_post_kernel, dim3(N, (A + 31) / 32), dim3(256), (TT * Ha + Ha + TT * 32 + 4 * Ha) * sizeof(float), st,
+                       w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, g->g_w_alpha, g->g_b_alpha, S, N, A, Ha);
+    RC(check_launch("att_post"));
+    d = desc_tn(b.DPALL, Ha, a->c3d, D, g->g_w_c2a, D, Ha, D, a->Tv);
+    d.split_k = -1;
+    RC(gemm(d, st));
+    RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, false, st));
+    d = desc_tn(b.DQ, Ha, w.HS + H, 3 * H, g->g_w_h2a, H, Ha, H, SN);       // HS[t] = h(t-1): rows 0..SN-1
+    d.split_k = -1;
+    RC(gemm(d, st));
+    RC(colsum(b.DQ, Ha, SN, Ha, g->g_b_h2a, false, st));
+    //    LSTM weights
+    for (int k = 0; k < 3; ++k) {
+        d = desc_tn(b.DG[k], 4 * H, w.HS + k * H, 3 * H, g->g_w_hh[k], H, 4 * H, H, SN);
+        d.split_k = -1;
+        RC(gemm(d, st));
+        d = desc_tn(b.DG[k], 4 * H, w.XT, E, g->g_w_ih[k], cin[k], 4 * H, E, SN);
+        d.split_k = -1;
+        RC(gemm(d, st));
+        RC(sum_over_time(b.DG[k], 4 * H, S, N, 4 * H, b.DGSUM[k], 4 * H, st));
+        RC(colsum(b.DGSUM[k], 4 * H, N, 4 * H, b.DGCOL[k], false, st));
+        RC(hipMemcpyAsync(g->g_b_ih[k], b.DGCOL[k], sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : -5);
+        RC(hipMemcpyAsync(g->g_b_hh[k], b.DGCOL[k], sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : -5);
+    }
+    //    context halves of W_ih: event (stream 0), attended clip (stream 1), video (stream 2)
+    d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);
+    d.split_k = -1;
+    RC(gemm(d, st));
+    d = desc_nn(b.DGSUM[0], 4 * H, a->w_ih[0] + E, cin[0], g->g_event, a->De, N, a->De, 4 * H);
+    d.split_k = -1;
+    RC(gemm(d, st));
+    d = desc_tn(b.DG[1], 4 * H, w.ATT, D, g->g_w_ih[1] + E, cin[1], 4 * H, D, SN);
+    d.split_k = -1;
+    RC(gemm(d, st));
+    d = desc_tn(b.DGCOL[2], 4 * H, a->video, a->Dv, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, 1);
+    RC(gemm(d, st));
+    if (g->g_video) {
+        d = desc_nn(b.DGCOL[2], 4 * H, a->w_ih[2] + E, cin[2], g->g_video, a->Dv, 1, a->Dv, 4 * H);
+        d.split_k = -1;
+        RC(gemm(d, st));
+    }
+    //    token embedding: dXT = sum_k DG_k . W_ih_k[:, :E], scatter-added into the (caller-zeroed) table gradient
+    for (int k = 0; k < 3; ++k) {
+        d = desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], b.DXT, E, SN, E, 4 * H);
+        d.beta = k == 0 ? 0.f : 1.f; d.split_k = -1;
+        RC(gemm(d, st));
+    }
+    RC(embed_scatter_add(b.DXT, a->tokens, g->g_embed, SN, E, V1, st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// greedy sampler (OldModel_NEW.py:139-187, sample_max = 1, eval mode): every step on device
+// ------------------------------------------------------------------------------------------------------
+struct SampWs { float* XT; float* LOGITS; int *IT, *UNF; long total; };
+static SampWs carve_samp(const echr_dec_args* a, float* base) {
+    SampWs s;
+    long off = 0;
+    auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
+    s.XT = take((long)a->N * a->E);
+    s.LOGITS = take((long)a->N * a->V1);
+    s.IT = reinterpret_cast<int*>(take(a->N));
+    s.UNF = reinterpret_cast<int*>(take(a->N));
+    s.total = off;
+    return s;
+}
+extern "C" int64_t echr_sampler_ws_floats(const echr_dec_args* a) { return a ? carve_samp(a, nullptr).total : -1; }
+
+extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
+    ECHR_REQUIRE(sa, "decoder_sample: null args");
+    echr_dec_args a = sa->dec;
+    const int L = sa->seq_len;
+    ECHR_REQUIRE(L > 0 && sa->seq && sa->seq_logp && sa->n_unfinished && sa->ws_sample && a.ws, "decoder_sample: missing buffers");
+    a.S = L;                                   // workspace is carved for seq_len steps
+    RC(check_dims(&a, "decoder_sample"));
+    hipStream_t st = (hipStream_t)stream;
+    const int N = a.N, H = a.H, E = a.E;
+    DecWs w = carve_ws(&a, a.ws);
+    SampWs s = carve_samp(&a, sa->ws_sample);
+    const DropCfg off = make_drop(nullptr, 0.f);
+    RC(fill_zero(w.HS, (long)N * 3 * H, st));
+    for (int k = 0; k < 3; ++k) RC(fill_zero(w.CS[k], (long)N * H, st));
+    RC(fill_zero(reinterpret_cast<float*>(s.IT), N, st));           // <bos> = 0
+    RC(fill_zero(reinterpret_cast<float*>(sa->n_unfinished), L + 1, st));
+    RC(fill_zero(reinterpret_cast<float*>(sa->seq), 2L * N * L, st));
+    RC(fill_zero(sa->seq_logp, (long)N * L, st));
+    RC(precompute_static(&a, w, st));
+    for (int t = 0; t < L; ++t) {
+        RC(embed_gather(a.embed, s.IT, s.XT, N, E, a.V1, st));
+        RC(input_gates(&a, w, s.XT, t, 1, st));
+        RC(step_fwd(&a, w, t, off, off, st));
+        echr_gemm_desc d = desc_nt(w.OUTD + (long)t * N * 3 * H, 3 * H, a.w_logit, 3 * H, s.LOGITS, a.V1, N, a.V1, 3 * H);
+        d.bias = a.b_logit; d.split_k = -1;
+        RC(gemm(d, st));
+        RC(greedy_step(s.LOGITS, a.V1, N, a.V1, t, L, s.IT, s.UNF, reinterpret_cast<long long*>(sa->seq), sa->seq_logp,
+                       sa->n_unfinished, st));
+    }
+    return 0;
+}

@@ -1,0 +1,45 @@
+// Internal (C++) interfaces between the translation units of libechr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/echr_hip.h"
+
+namespace echr {
+
+int gemm(const echr_gemm_desc& d, hipStream_t st);
+
+// C[M,N] = A[M,K] . W[N,K]^T  (nn.Linear forward; row-major operands with leading dimensions)
+inline echr_gemm_desc desc_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K) {
+    echr_gemm_desc d{};
+    d.A = A; d.B = W; d.C = C; d.M = M; d.N = N; d.K = K;
+    d.sam = lda; d.sak = 1; d.sbk = 1; d.sbn = ldw; d.ldc = ldc;
+    d.batch = 1; d.alpha = 1.f; d.beta = 0.f; d.split_k = 1;
+    return d;
+}
+// C[M,N] = A[M,K] . B[K,N]   (data gradient dX = dY . W)
+inline echr_gemm_desc desc_nn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K) {
+    echr_gemm_desc d = desc_nt(A, lda, B, 1, C, ldc, M, N, K);
+    d.sbk = ldb; d.sbn = 1;
+    return d;
+}
+// C[M,N] = A[K,M]^T . B[K,N] (weight gradient dW = dY^T . X)
+inline echr_gemm_desc desc_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K) {
+    echr_gemm_desc d = desc_nn(A, 1, B, ldb, C, ldc, M, N, K);
+    d.sam = 1; d.sak = lda;
+    return d;
+}
+
+// column sums: out[j] (+)= sum_i X[i*ld + j], i < rows
+int colsum(const float* X, long ld, int rows, int cols, float* out, bool accumulate, hipStream_t st);
+// out[n*ld_out + j] = sum_t X[(t*N + n)*ld + j]
+int sum_over_time(const float* X, long ld, int S, int N, int cols, float* out, long ld_out, hipStream_t st);
+int fill_zero(float* p, long n, hipStream_t st);
+int fill_zero_2d(float* p, int rows, int cols, long ld, hipStream_t st);
+int embed_gather(const float* W, const int* tok, float* out, int rows, int E, int V1, hipStream_t st);
+int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st);
+int logsoftmax_rows(float* X, long ld, int rows, int cols, hipStream_t st);
+int logsoftmax_bwd(const float* logp, const float* G, const int* target, const float* mask, const float* g_loss,
+                   const float* mask_sum, float* out, long ldo, int N, int S, int V1, hipStream_t st);
+int greedy_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
+                long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st);
+
+}  // namespace echr

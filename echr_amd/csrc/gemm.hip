@@ -1,0 +1,294 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), wave64, LDS-tiled.
+//
+// One kernel template serves every dense projection of the ECHR hot path: NT (x . W^T,
+// nn.Linear forward), NN (dY . W, data gradients) and TN (dY^T . X, weight gradients) through
+// per-operand (row, k) strides, plus strided batches (the 16 TSRM heads), split-K with fp32 atomics
+// for skinny/deep shapes, and a fused epilogue (two biases, a row-broadcast addend, tanh,
+// tanh-derivative multiply, output row remap for the [t,n] -> [n,t] log-prob layout).
+//
+// MFMA 32x32x2 f32 operand maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; accumulator reg r of lane l is C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+// LDS tiles are stored k-major ([BK][BM+pad]) so the 32 lanes of a half-wave read 32 consecutive
+// floats (conflict-free ds_read_b32); pad = 1 when the tile is filled by transposing float4 loads
+// along k (scatter of b32 writes, conflict-free at stride BM+1), pad = 4 when filled along m (b128 writes).
+#include "echr_common.h"
+#include "echr_internal.h"
+
+namespace echr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+
+struct GemmParams {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long sam, sak, sbk, sbn, ldc;
+    long bsa, bsb, bsc;
+    float alpha, beta;
+    const float* bias; long bs_bias; const float* bias2;
+    const float* addend; int add_mod; long ld_add;
+    int act; const float* aux; long ld_aux;
+    int rowmap_mod, rowmap_mul;
+    int split_k, k_tiles_per_split;
+    int tiles_m, tiles_n;
+    int vecA, vecB;
+};
+
+// Fill registers with one [BMN x BK] operand tile.  KC: k is the contiguous axis of the source.
+template <int BMN, bool KC>
+__device__ __forceinline__ void load_tile(float4 (&r)[BMN / 32], const float* __restrict__ P, long s_mn, long s_k,
+                                          int mn0, int k0, int MN, int K, int kend, bool vec, int tid) {
+#pragma unroll
+    for (int p = 0; p < BMN / 32; ++p) {
+        int f = tid + p * 256;
+        int mn, k;
+        if (KC) { mn = mn0 + f / (BK / 4); k = k0 + 4 * (f % (BK / 4)); }
+        else    { k = k0 + f / (BMN / 4); mn = mn0 + 4 * (f % (BMN / 4)); }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KC) {
+            if (mn < MN) {
+                const float* src = P + (long)mn * s_mn + k;
+                if (vec && k + 3 < kend) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (k < kend) v.x = src[0];
+                    if (k + 1 < kend) v.y = src[1];
+                    if (k + 2 < kend) v.z = src[2];
+                    if (k + 3 < kend) v.w = src[3];
+                }
+            }
+        } else {
+            if (k < kend) {
+                const float* src = P + (long)k * s_k + mn;
+                if (vec && mn + 3 < MN) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (mn < MN) v.x = src[0];
+                    if (mn + 1 < MN) v.y = src[1];
+                    if (mn + 2 < MN) v.z = src[2];
+                    if (mn + 3 < MN) v.w = src[3];
+                }
+            }
+        }
+        r[p] = v;
+    }
+}
+
+template <int BMN, bool KC>
+__device__ __forceinline__ void store_tile(const float4 (&r)[BMN / 32], float* __restrict__ S, int tid) {
+    constexpr int LD = BMN + (KC ? 1 : 4);
+#pragma unroll
+    for (int p = 0; p < BMN / 32; ++p) {
+        int f = tid + p * 256;
+        if (KC) {
+            int mn = f / (BK / 4), k = 4 * (f % (BK / 4));
+            S[(k + 0) * LD + mn] = r[p].x;
+            S[(k + 1) * LD + mn] = r[p].y;
+            S[(k + 2) * LD + mn] = r[p].z;
+            S[(k + 3) * LD + mn] = r[p].w;
+        } else {
+            int k = f / (BMN / 4), mn = 4 * (f % (BMN / 4));
+            *reinterpret_cast<float4*>(&S[k * LD + mn]) = r[p];
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    constexpr int LDA = BM + (AKC ? 1 : 4);
+    constexpr int LDB = BN + (BKC ? 1 : 4);
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
+    float* As = smem;
+    float* Bs = smem + BK * LDA;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = (wave / WAVES_N) * WM;
+    const int wn = (wave % WAVES_N) * WN;
+
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+    // contiguous run of tiles (neighbouring tiles share an A panel -> L2 hits).  Bijective for any grid.
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int m0 = (bid / p.tiles_n) * BM;
+    const int n0 = (bid % p.tiles_n) * BN;
+    const int z = blockIdx.z;
+    const int b = z / p.split_k;
+    const int ks = z % p.split_k;
+
+    const float* A = p.A + (long)b * p.bsa;
+    const float* B = p.B + (long)b * p.bsb;
+    float* C = p.C + (long)b * p.bsc;
+
+    const int kt_total = (p.K + BK - 1) / BK;
+    const int kt0 = ks * p.k_tiles_per_split;
+    const int kt1 = min(kt_total, kt0 + p.k_tiles_per_split);
+    const int kend = min(p.K, kt1 * BK);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[BM / 32], rb[BN / 32];
+    if (kt0 < kt1) {
+        load_tile<BM, AKC>(ra, A, p.sam, p.sak, m0, kt0 * BK, p.M, p.K, kend, p.vecA, tid);
+        load_tile<BN, BKC>(rb, B, p.sbn, p.sbk, n0, kt0 * BK, p.N, p.K, kend, p.vecB, tid);
+    }
+    const int khalf = lane >> 5, l31 = lane & 31;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        store_tile<BM, AKC>(ra, As, tid);
+        store_tile<BN, BKC>(rb, Bs, tid);
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            load_tile<BM, AKC>(ra, A, p.sam, p.sak, m0, (kt + 1) * BK, p.M, p.K, kend, p.vecA, tid);
+            load_tile<BN, BKC>(rb, B, p.sbn, p.sbk, n0, (kt + 1) * BK, p.N, p.K, kend, p.vecB, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], bb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + khalf) * LDA + wm + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bb[j] = Bs[(2 * kk + khalf) * LDB + wn + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    const bool first_split = (ks == 0);
+    const float* bias = p.bias ? p.bias + (long)b * p.bs_bias : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn + j * 32 + l31;
+            if (col >= p.N) continue;
+            float cb = 0.f;
+            if (first_split) {
+                if (bias) cb += bias[col];
+                if (p.bias2) cb += p.bias2[col];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (row >= p.M) continue;
+                float v = p.alpha * acc[i][j][r];
+                int orow = row;
+                if (p.rowmap_mod > 0) orow = (row % p.rowmap_mod) * p.rowmap_mul + row / p.rowmap_mod;
+                float* dst = C + (long)orow * p.ldc + col;
+                if (p.split_k > 1) {
+                    if (first_split) {
+                        v += cb;
+                        if (p.addend) v += p.addend[(long)(row % p.add_mod) * p.ld_add + col];
+                    }
+                    atomicAdd(dst, v);
+                } else {
+                    v += cb;
+                    if (p.addend) v += p.addend[(long)(row % p.add_mod) * p.ld_add + col];
+                    if (p.beta != 0.f) v += p.beta * *dst;
+                    if (p.act == ECHR_ACT_TANH) v = tanhf(v);
+                    else if (p.act == ECHR_ACT_MUL_DTANH) {
+                        float t = p.aux[(long)row * p.ld_aux + col];
+                        v *= (1.f - t * t);
+                    }
+                    *dst = v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(const GemmParams& p, bool akc, bool bkc, dim3 grid, hipStream_t st) {
+    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, p);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, p);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, p);
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int gemm(const echr_gemm_desc& d, hipStream_t st) {
+    ECHR_REQUIRE(d.A && d.B && d.C, "gemm: null operand");
+    ECHR_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch >= 1, "gemm: bad shape M=%d N=%d K=%d batch=%d", d.M, d.N, d.K, d.batch);
+    ECHR_REQUIRE(d.sam == 1 || d.sak == 1, "gemm: A needs a unit stride (sam=%ld sak=%ld)", (long)d.sam, (long)d.sak);
+    ECHR_REQUIRE(d.sbk == 1 || d.sbn == 1, "gemm: B needs a unit stride (sbk=%ld sbn=%ld)", (long)d.sbk, (long)d.sbn);
+    ECHR_REQUIRE(d.act == ECHR_ACT_NONE || d.split_k <= 1, "gemm: split-K cannot carry an activation");
+    ECHR_REQUIRE(d.act != ECHR_ACT_MUL_DTANH || d.aux, "gemm: MUL_DTANH needs aux");
+    ECHR_REQUIRE(!d.addend || d.add_mod > 0, "gemm: addend needs add_mod");
+    GemmParams p;
+    p.A = d.A; p.B = d.B; p.C = d.C; p.M = d.M; p.N = d.N; p.K = d.K;
+    p.sam = d.sam; p.sak = d.sak; p.sbk = d.sbk; p.sbn = d.sbn; p.ldc = d.ldc;
+    p.bsa = d.bsa; p.bsb = d.bsb; p.bsc = d.bsc;
+    p.alpha = d.alpha; p.beta = d.beta;
+    p.bias = d.bias; p.bs_bias = d.bs_bias; p.bias2 = d.bias2;
+    p.addend = d.addend; p.add_mod = d.add_mod; p.ld_add = d.ld_add;
+    p.act = d.act; p.aux = d.aux; p.ld_aux = d.ld_aux;
+    p.rowmap_mod = d.rowmap_mod; p.rowmap_mul = d.rowmap_mul;
+    const bool akc = (d.sak == 1);
+    const bool bkc = (d.sbk == 1);
+    p.vecA = akc ? (d.sam % 4 == 0 && aligned16(d.A) && d.bsa % 4 == 0) : (d.sak % 4 == 0 && aligned16(d.A) && d.bsa % 4 == 0);
+    p.vecB = bkc ? (d.sbn % 4 == 0 && aligned16(d.B) && d.bsb % 4 == 0) : (d.sbk % 4 == 0 && aligned16(d.B) && d.bsb % 4 == 0);
+
+    // tile choice: big tiles when there is enough work to fill the 256 CUs with them, else 64x64
+    const long wg128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
+    int BMs = 64, BNs = 64;
+    if (wg128 >= 192) { BMs = 128; BNs = 128; }
+    else if (d.M <= 64 && d.N >= 256) { BMs = 64; BNs = 64; }
+    p.tiles_m = (d.M + BMs - 1) / BMs;
+    p.tiles_n = (d.N + BNs - 1) / BNs;
+    const int kt_total = (d.K + BK - 1) / BK;
+    int split = d.split_k;
+    const bool accumulate = (d.split_k > 1 || d.split_k < 0);   // caller promises C already holds its base value
+    if (split < 0) {  // auto: fill ~2 waves of workgroups over the chip when the output grid is small
+        long wgs = (long)p.tiles_m * p.tiles_n * d.batch;
+        split = 1;
+        if (d.act == ECHR_ACT_NONE && wgs < 256 && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
+            split = (int)min((long)kt_total, max(1L, 512 / max(wgs, 1L)));
+            if (split > 1 && kt_total / split < 2) split = max(1, kt_total / 2);
+        }
+    }
+    if (split < 1) split = 1;
+    if (split > kt_total) split = kt_total;
+    p.k_tiles_per_split = (kt_total + split - 1) / split;
+    split = (kt_total + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
+    p.split_k = split;
+    if (d.split_k < 0) {
+        // auto mode: beta == 0 -> the library zero-fills C itself before splitting; beta == 1 -> accumulate
+        ECHR_REQUIRE(d.beta == 0.f || d.beta == 1.f, "gemm: auto split needs beta in {0,1}");
+        if (split > 1 && d.beta == 0.f) {
+            ECHR_REQUIRE(d.rowmap_mod == 0, "gemm: auto split cannot zero a row-remapped output");
+            for (int bb = 0; bb < d.batch; ++bb) {
+                int rc = fill_zero_2d(d.C + (long)bb * d.bsc, d.M, d.N, d.ldc, st);
+                if (rc) return rc;
+            }
+        }
+        if (split == 1) p.beta = d.beta;
+    } else if (accumulate && split == 1) p.beta = 1.f;
+    dim3 grid(p.tiles_m * p.tiles_n, 1, d.batch * split);
+    if (BMs == 128) launch_cfg<128, 128, 64, 64>(p, akc, bkc, grid, st);
+    else launch_cfg<64, 64, 32, 32>(p, akc, bkc, grid, st);
+    return check_launch("gemm_f32");
+}
+
+}  // namespace echr
+
+extern "C" int echr_gemm_f32(const echr_gemm_desc* d, void* stream) {
+    if (!d) { echr::set_error("echr_gemm_f32: null descriptor"); return -22; }
+    return echr::gemm(*d, static_cast<hipStream_t>(stream));
+}

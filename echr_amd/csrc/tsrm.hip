@@ -1,0 +1,244 @@
+// TSRM event-relation encoder on gfx950 (reference: models/MA_attention_8_NEW.py:35-49, :51-79, :101-177;
+// fST0, use_posit=1).  The dense parts (event_emb, pair_pos_fc1/fc2, query/key, per-head products) run on
+// the fp32 MFMA GEMM of gemm.hip as plain or head-batched problems; this file adds the on-device
+// position-embedding generator (float64 math like the reference's numpy), the gated softmax over
+// events with dropout, and its backward.
+//
+// Re-association used (documented in DESIGN.md): the reference multiplies softmax weights with the
+// un-projected 512-d event features per head and then applies a grouped 1x1 conv (:169-173); here the conv
+// weight is applied to the features first (XW = X . Wout^T, one [N,Df]x[Df,Do] GEMM) and each head then
+// mixes its own dgo-column slice of XW -- same math, 1/G of the flops, fp32 rounding differs at 1e-7.
+#include <cmath>
+#include "echr_common.h"
+#include "echr_internal.h"
+
+namespace echr {
+
+DropCfg make_drop(const echr_dropout* d, float p);
+enum { SITE_TSRM = 0 };
+
+// pos[i,j,:] for the event pair (i,j): [sin(dc*f_k), cos(dc*f_k), sin(dl*f_k), cos(dl*f_k)], k < Df/4, where
+// dc = max(|c_i - c_j| / l_i, 1e-3) (float64), dl = log(l_j / l_i) evaluated in float32 as the reference does
+// (lengths are cast to float32, MA_attention_8_NEW.py:70), arguments scaled by 100 / 10000^(4k/Df).
+__global__ void posemb_kernel(const int* __restrict__ ev_start, const int* __restrict__ ev_len, float* __restrict__ pos,
+                              int N, int Df) {
+    const int F4 = Df / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * N * F4) return;
+    const int k = (int)(idx % F4);
+    const long ij = idx / F4;
+    const int j = (int)(ij % N), i = (int)(ij / N);
+    const double ci = 0.5 * ((double)ev_start[i] + (double)(ev_start[i] + ev_len[i]));
+    const double cj = 0.5 * ((double)ev_start[j] + (double)(ev_start[j] + ev_len[j]));
+    const float li = (float)ev_len[i], lj = (float)ev_len[j];
+    double dc = fabs((ci - cj) / (double)li);
+    dc = dc > 1e-3 ? dc : 1e-3;
+    const float ratio = __fdiv_rn(lj, li);
+    const double dl = (double)(float)log((double)ratio);
+    const double dim = pow(10000.0, (4.0 / (double)Df) * (double)k);
+    const double ac = 100.0 * dc / dim, al = 100.0 * dl / dim;
+    float* o = pos + ij * Df;
+    o[k] = (float)sin(ac);
+    o[F4 + k] = (float)cos(ac);
+    o[2 * F4 + k] = (float)sin(al);
+    o[3 * F4 + k] = (float)cos(al);
+}
+
+// one wave per (event n, head g): w[m] = softmax_m(gate[n,m,g] * aff[g,n,m]); wd = w * dropout
+__global__ __launch_bounds__(64) void tsrm_softmax_fwd_kernel(const float* __restrict__ GATE, const float* __restrict__ AFF,
+                                                              float* __restrict__ WSM, float* __restrict__ WD, int N, int G, DropCfg dc) {
+    const int n = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const float* aff = AFF + ((long)g * N + n) * N;
+    float m = -INFINITY;
+    for (int j = lane; j < N; j += 64) m = fmaxf(m, GATE[((long)n * N + j) * G + g] * aff[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s += expf(GATE[((long)n * N + j) * G + g] * aff[j] - m);
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int j = lane; j < N; j += 64) {
+        const float w = expf(GATE[((long)n * N + j) * G + g] * aff[j] - m) * inv;
+        const long o = ((long)g * N + n) * N + j;
+        WSM[o] = w;
+        WD[o] = w * drop_mult(dc, (unsigned)(((long)n * G + g) * N + j), 0u, SITE_TSRM);
+    }
+}
+
+// ds = w * (dw - sum_m w dw), dw = dWD * dropout;  dGATE[n,m,g] = ds * aff, dAFF[g,n,m] = ds * gate
+__global__ __launch_bounds__(64) void tsrm_softmax_bwd_kernel(const float* __restrict__ GATE, const float* __restrict__ AFF,
+                                                              const float* __restrict__ WSM, const float* __restrict__ DWD,
+                                                              float* __restrict__ DGATE, float* __restrict__ DAFF, int N, int G, DropCfg dc) {
+    const int n = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const long base = ((long)g * N + n) * N;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64)
+        s += WSM[base + j] * DWD[base + j] * drop_mult(dc, (unsigned)(((long)n * G + g) * N + j), 0u, SITE_TSRM);
+    s = wave_sum(s);
+    for (int j = lane; j < N; j += 64) {
+        const float dw = DWD[base + j] * drop_mult(dc, (unsigned)(((long)n * G + g) * N + j), 0u, SITE_TSRM);
+        const float ds = WSM[base + j] * (dw - s);
+        const long go = ((long)n * N + j) * G + g;
+        DGATE[go] = ds * AFF[base + j];
+        DAFF[base + j] = ds * GATE[go];
+    }
+}
+
+static inline long rup(long x, long a) { return (x + a - 1) / a * a; }
+
+struct TsrmWs { float *X, *POS, *P1, *GATE, *Q, *K, *XW, *AFF, *WSM, *WD; long total; };
+static TsrmWs carve(int N, int Din, int Df, int Do, int G, float* base) {
+    TsrmWs w;
+    long off = 0;
+    auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
+    const long NN = (long)N * N;
+    w.X = take((long)N * Df); w.POS = take(NN * Df); w.P1 = take(NN * Df); w.GATE = take(NN * G);
+    w.Q = take((long)N * Df); w.K = take((long)N * Df); w.XW = take((long)N * Do);
+    w.AFF = take(NN * G); w.WSM = take(NN * G); w.WD = take(NN * G);
+    w.total = off;
+    return w;
+}
+struct TsrmWsB { float *DWD, *DGATE, *DAFF, *DQ, *DK, *DXW, *DX, *DP1; long total; };
+static TsrmWsB carve_b(int N, int Din, int Df, int Do, int G, float* base) {
+    TsrmWsB w;
+    long off = 0;
+    auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
+    const long NN = (long)N * N;
+    w.DWD = take(NN * G); w.DGATE = take(NN * G); w.DAFF = take(NN * G);
+    w.DQ = take((long)N * Df); w.DK = take((long)N * Df); w.DXW = take((long)N * Do); w.DX = take((long)N * Df);
+    w.DP1 = take(NN * Df);
+    w.total = off;
+    return w;
+}
+
+static int check(const echr_tsrm_args* a, const char* who) {
+    ECHR_REQUIRE(a, "%s: null args", who);
+    ECHR_REQUIRE(a->N > 0 && a->Din > 0 && a->Df > 0 && a->Do > 0 && a->G > 0, "%s: bad dims", who);
+    ECHR_REQUIRE(a->Df % a->G == 0 && a->Do % a->G == 0 && a->Df % 4 == 0, "%s: need Df%%G==0, Do%%G==0, Df%%4==0", who);
+    ECHR_REQUIRE(a->ws && a->out && a->ech && a->ev_start && a->ev_len, "%s: missing buffers", who);
+    return 0;
+}
+
+#define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+int posemb(const int* ev_start, const int* ev_len, float* pos, int N, int Df, hipStream_t st) {
+    const long tot = (long)N * N * (Df / 4);
+    hipLaunchKernelGGL(posemb_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ev_start, ev_len, pos, N, Df);
+    return check_launch("posemb");
+}
+
+}  // namespace echr
+
+using namespace echr;
+
+extern "C" int64_t echr_tsrm_ws_floats(int32_t N, int32_t Din, int32_t Df, int32_t Do, int32_t G) {
+    return carve(N, Din, Df, Do, G, nullptr).total;
+}
+extern "C" int64_t echr_tsrm_ws_bwd_floats(int32_t N, int32_t Din, int32_t Df, int32_t Do, int32_t G) {
+    return carve_b(N, Din, Df, Do, G, nullptr).total;
+}
+
+extern "C" int echr_tsrm_posemb(const int32_t* ev_start, const int32_t* ev_len, float* pos, int32_t N, int32_t Df, void* stream) {
+    ECHR_REQUIRE(ev_start && ev_len && pos && N > 0 && Df > 0 && Df % 4 == 0, "tsrm_posemb: bad arguments");
+    return posemb(ev_start, ev_len, pos, N, Df, (hipStream_t)stream);
+}
+
+extern "C" int echr_tsrm_fwd(const echr_tsrm_args* a, const echr_dropout* drop, void* stream) {
+    RC(check(a, "tsrm_fwd"));
+    hipStream_t st = (hipStream_t)stream;
+    const int N = a->N, Din = a->Din, Df = a->Df, Do = a->Do, G = a->G;
+    const int NN = N * N, dgq = Df / G, dgo = Do / G;
+    TsrmWs w = carve(N, Din, Df, Do, G, a->ws);
+    echr_gemm_desc d;
+    // event embedding (:44)
+    d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1;
+    RC(gemm(d, st));
+    // pairwise position features -> per-head gates (:39-41, :108-116)
+    RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, st));
+    d = desc_nt(w.POS, Df, a->w_fc1, Df, w.P1, Df, NN, Df, Df); d.bias = a->b_fc1; d.act = ECHR_ACT_TANH;
+    RC(gemm(d, st));
+    d = desc_nt(w.P1, Df, a->w_fc2, Df, w.GATE, G, NN, G, Df); d.bias = a->b_fc2; d.split_k = -1;
+    RC(gemm(d, st));
+    // query / key / (pre-applied) output projection
+    d = desc_nt(w.X, Df, a->w_q, Df, w.Q, Df, N, Df, Df); d.bias = a->b_q; d.split_k = -1;
+    RC(gemm(d, st));
+    d = desc_nt(w.X, Df, a->w_k, Df, w.K, Df, N, Df, Df); d.bias = a->b_k; d.split_k = -1;
+    RC(gemm(d, st));
+    d = desc_nt(w.X, Df, a->w_out, Df, w.XW, Do, N, Do, Df); d.split_k = -1;
+    RC(gemm(d, st));
+    // per-head scaled affinities AFF[g] = Q_g . K_g^T / sqrt(dgq)   (:138-140)
+    d = desc_nt(w.Q, Df, w.K, Df, w.AFF, N, N, N, dgq);
+    d.batch = G; d.bsa = dgq; d.bsb = dgq; d.bsc = (long)NN; d.alpha = 1.0f / sqrtf((float)dgq);
+    RC(gemm(d, st));
+    const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
+    hipLaunchKernelGGL(tsrm_softmax_fwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, w.WD, N, G, dc);
+    RC(check_launch("tsrm_softmax_fwd"));
+    // OUT[:, g] = WD_g . XW_g + b_out_g
+    d = desc_nn(w.WD, N, w.XW, Do, a->out, Do, N, dgo, N);
+    d.batch = G; d.bsa = (long)NN; d.bsb = dgo; d.bsc = dgo; d.bias = a->b_out; d.bs_bias = dgo;
+    RC(gemm(d, st));
+    return 0;
+}
+
+extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr_dropout* drop, void* stream) {
+    RC(check(a, "tsrm_bwd"));
+    ECHR_REQUIRE(g && g->g_out && g->ws_bwd, "tsrm_bwd: missing buffers");
+    hipStream_t st = (hipStream_t)stream;
+    const int N = a->N, Din = a->Din, Df = a->Df, Do = a->Do, G = a->G;
+    const int NN = N * N, dgq = Df / G, dgo = Do / G;
+    const float scale = 1.0f / sqrtf((float)dgq);
+    TsrmWs w = carve(N, Din, Df, Do, G, a->ws);
+    TsrmWsB b = carve_b(N, Din, Df, Do, G, g->ws_bwd);
+    echr_gemm_desc d;
+    RC(colsum(g->g_out, Do, N, Do, g->g_b_out, false, st));
+    // dWD_g = dOUT_g . XW_g^T ; dXW_g = WD_g^T . dOUT_g
+    d = desc_nt(g->g_out, Do, w.XW, Do, b.DWD, N, N, N, dgo);
+    d.batch = G; d.bsa = dgo; d.bsb = dgo; d.bsc = (long)NN;
+    RC(gemm(d, st));
+    d = desc_tn(w.WD, N, g->g_out, Do, b.DXW, Do, N, dgo, N);
+    d.batch = G; d.bsa = (long)NN; d.bsb = dgo; d.bsc = dgo;
+    RC(gemm(d, st));
+    const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
+    hipLaunchKernelGGL(tsrm_softmax_bwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, b.DWD, b.DGATE, b.DAFF, N, G, dc);
+    RC(check_launch("tsrm_softmax_bwd"));
+    // dQ_g = scale * dAFF_g . K_g ; dK_g = scale * dAFF_g^T . Q_g
+    d = desc_nn(b.DAFF, N, w.K, Df, b.DQ, Df, N, dgq, N);
+    d.batch = G; d.bsa = (long)NN; d.bsb = dgq; d.bsc = dgq; d.alpha = scale;
+    RC(gemm(d, st));
+    d = desc_tn(b.DAFF, N, w.Q, Df, b.DK, Df, N, dgq, N);
+    d.batch = G; d.bsa = (long)NN; d.bsb = dgq; d.bsc = dgq; d.alpha = scale;
+    RC(gemm(d, st));
+    // dX = dQ . Wq + dK . Wk + dXW . Wout
+    d = desc_nn(b.DQ, Df, a->w_q, Df, b.DX, Df, N, Df, Df); d.split_k = -1;
+    RC(gemm(d, st));
+    d = desc_nn(b.DK, Df, a->w_k, Df, b.DX, Df, N, Df, Df); d.beta = 1.f; d.split_k = -1;
+    RC(gemm(d, st));
+    d = desc_nn(b.DXW, Do, a->w_out, Df, b.DX, Df, N, Df, Do); d.beta = 1.f; d.split_k = -1;
+    RC(gemm(d, st));
+    // projection weights
+    d = desc_tn(b.DQ, Df, w.X, Df, g->g_w_q, Df, Df, Df, N); d.split_k = -1;
+    RC(gemm(d, st));
+    RC(colsum(b.DQ, Df, N, Df, g->g_b_q, false, st));
+    d = desc_tn(b.DK, Df, w.X, Df, g->g_w_k, Df, Df, Df, N); d.split_k = -1;
+    RC(gemm(d, st));
+    RC(colsum(b.DK, Df, N, Df, g->g_b_k, false, st));
+    d = desc_tn(b.DXW, Do, w.X, Df, g->g_w_out, Df, Do, Df, N); d.split_k = -1;
+    RC(gemm(d, st));
+    // position MLP
+    d = desc_tn(b.DGATE, G, w.P1, Df, g->g_w_fc2, Df, G, Df, NN); d.split_k = -1;
+    RC(gemm(d, st));
+    RC(colsum(b.DGATE, G, NN, G, g->g_b_fc2, false, st));
+    d = desc_nn(b.DGATE, G, a->w_fc2, Df, b.DP1, Df, NN, Df, G); d.act = ECHR_ACT_MUL_DTANH; d.aux = w.P1; d.ld_aux = Df;
+    RC(gemm(d, st));
+    d = desc_tn(b.DP1, Df, w.POS, Df, g->g_w_fc1, Df, Df, Df, NN); d.split_k = -1;
+    RC(gemm(d, st));
+    RC(colsum(b.DP1, Df, NN, Df, g->g_b_fc1, false, st));
+    // event embedding
+    d = desc_tn(b.DX, Df, a->ech, Din, g->g_w_emb, Din, Df, Din, N); d.split_k = -1;
+    RC(gemm(d, st));
+    RC(colsum(b.DX, Df, N, Df, g->g_b_emb, false, st));
+    if (g->g_ech) {
+        d = desc_nn(b.DX, Df, a->w_emb, Din, g->g_ech, Din, N, Din, Df); d.split_k = -1;
+        RC(gemm(d, st));
+    }
+    return 0;
+}

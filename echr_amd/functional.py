@@ -1,0 +1,281 @@
+"""torch.autograd bindings of the HIP hot path (one Function per fused region).
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd graph edges; all arithmetic
+happens in libechr_hip.so (include/echr_hip.h).  Every call fails loudly when the library or the GPU
+is missing -- there is no eager/PyTorch fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class DropState:
+    """Dropout configuration of one forward call (counter-based; see echr_amd/philox.py)."""
+
+    def __init__(self, seed=0, offset=0, training=False, p_tsrm=0.3, p_h=0.5, p_out=0.5):
+        self.seed, self.offset, self.training = int(seed), int(offset), bool(training)
+        self.p_tsrm, self.p_h, self.p_out = float(p_tsrm), float(p_h), float(p_out)
+
+    def c(self):
+        return L.Dropout(self.seed & 0xFFFFFFFFFFFFFFFF, self.offset & 0xFFFFFFFF, 1 if self.training else 0,
+                         self.p_tsrm, self.p_h, self.p_out)
+
+
+def event_index_tensors(soi_select_list, ind_select_list, device, n_rows=None):
+    """(ev_start, ev_len, ind) int32 device tensors + max length A from the reference's list inputs
+    (numpy int arrays or python lists; CaptionGenerator.py:17, train.py:265-271)."""
+    soi = np.asarray(soi_select_list, dtype=np.int64).reshape(-1, 2)
+    ind = np.asarray(ind_select_list, dtype=np.int64).reshape(-1)
+    lens = soi[:, 1] - soi[:, 0]
+    if len(soi) == 0 or lens.min() <= 0:
+        raise ValueError('every event needs at least one segment (soi=%s)' % (soi.tolist(),))
+    if len(ind) != len(soi):
+        raise ValueError('ind_select_list and soi_select_list differ in length (%d vs %d)' % (len(ind), len(soi)))
+    if n_rows is not None and (soi.min() < 0 or soi[:, 1].max() > n_rows or ind.min() < 0 or ind.max() >= n_rows):
+        raise ValueError('event intervals / anchors fall outside the %d feature rows' % n_rows)
+    packed = np.stack([soi[:, 0], lens, ind]).astype(np.int32)
+    t = torch.from_numpy(packed).to(device, non_blocking=True)
+    return t[0].contiguous(), t[1].contiguous(), t[2].contiguous(), int(lens.max())
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+class EventPoolGather(torch.autograd.Function):
+    """ech = [mean-pooled C3D rows | tap[ind]]  (CaptionGenerator.py:111-114,121,128)."""
+
+    @staticmethod
+    def forward(ctx, c3d, tap, ev_start, ev_len, ind):
+        lib = L.load()
+        c3d, tap = _f32c(c3d), _f32c(tap)
+        N, D, Ht = ev_start.numel(), c3d.shape[1], tap.shape[1]
+        ech = torch.empty(N, D + Ht, device=c3d.device, dtype=torch.float32)
+        L.check(lib.echr_event_pool_gather_fwd(L.ptr(c3d), L.ptr(tap), L.ptr(ev_start, torch.int32), L.ptr(ev_len, torch.int32),
+                                               L.ptr(ind, torch.int32), L.ptr(ech), N, D, Ht, L.stream_ptr()), 'event_pool_gather_fwd')
+        ctx.save_for_backward(ind)
+        ctx.shape = (tap.shape, D, Ht, N)
+        return ech
+
+    @staticmethod
+    def backward(ctx, g_ech):
+        lib = L.load()
+        (ind,) = ctx.saved_tensors
+        tap_shape, D, Ht, N = ctx.shape
+        g_tap = None
+        if ctx.needs_input_grad[1]:
+            g_tap = torch.zeros(tap_shape, device=g_ech.device, dtype=torch.float32)
+            L.check(lib.echr_event_pool_gather_bwd(L.ptr(_f32c(g_ech)), L.ptr(ind, torch.int32), L.ptr(g_tap), N, D, Ht,
+                                                   L.stream_ptr()), 'event_pool_gather_bwd')
+        return None, g_tap, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+TSRM_PARAMS = ('w_emb', 'b_emb', 'w_fc1', 'b_fc1', 'w_fc2', 'b_fc2', 'w_q', 'b_q', 'w_k', 'b_k', 'w_out', 'b_out')
+
+
+class TSRMFunction(torch.autograd.Function):
+    """MA_Attention8.forward (MA_attention_8_NEW.py:35-49, :101-177)."""
+
+    @staticmethod
+    def forward(ctx, ech, ev_start, ev_len, n_head, drop, *params):
+        lib = L.load()
+        ech = _f32c(ech)
+        ps = [_f32c(p) for p in params]
+        N, Din = ech.shape
+        Df, Do = ps[0].shape[0], ps[10].shape[0]
+        ws = torch.empty(lib.echr_tsrm_ws_floats(N, Din, Df, Do, n_head), device=ech.device, dtype=torch.float32)
+        out = torch.empty(N, Do, device=ech.device, dtype=torch.float32)
+        a = L.TsrmArgs(N, Din, Df, Do, n_head, *[L.ptr(p) for p in ps], L.ptr(ech), L.ptr(ev_start, torch.int32),
+                       L.ptr(ev_len, torch.int32), L.ptr(ws), L.ptr(out))
+        d = drop.c()
+        L.check(lib.echr_tsrm_fwd(C.byref(a), C.byref(d), L.stream_ptr()), 'tsrm_fwd')
+        ctx.save_for_backward(ech, ev_start, ev_len, ws, out, *ps)
+        ctx.meta = (N, Din, Df, Do, n_head, drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = L.load()
+        ech, ev_start, ev_len, ws, out, *ps = ctx.saved_tensors
+        N, Din, Df, Do, G, drop = ctx.meta
+        g_out = _f32c(g_out)
+        grads = [torch.empty_like(p) for p in ps]
+        g_ech = torch.empty_like(ech)
+        wsb = torch.empty(lib.echr_tsrm_ws_bwd_floats(N, Din, Df, Do, G), device=ech.device, dtype=torch.float32)
+        a = L.TsrmArgs(N, Din, Df, Do, G, *[L.ptr(p) for p in ps], L.ptr(ech), L.ptr(ev_start, torch.int32),
+                       L.ptr(ev_len, torch.int32), L.ptr(ws), L.ptr(out))
+        g = L.TsrmGrads(*[L.ptr(x) for x in grads], L.ptr(g_ech), L.ptr(g_out), L.ptr(wsb))
+        d = drop.c()
+        L.check(lib.echr_tsrm_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'tsrm_bwd')
+        return (g_ech, None, None, None, None) + tuple(grads)
+
+
+def position_embedding(ev_start, ev_len, d_pos):
+    """[N,N,d_pos] fp32 pairwise position embedding generated on device (MA_attention_8_NEW.py:39-41)."""
+    lib = L.load()
+    N = ev_start.numel()
+    pos = torch.empty(N, N, d_pos, device=ev_start.device, dtype=torch.float32)
+    L.check(lib.echr_tsrm_posemb(L.ptr(ev_start, torch.int32), L.ptr(ev_len, torch.int32), L.ptr(pos), N, d_pos, L.stream_ptr()),
+            'tsrm_posemb')
+    return pos
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter order of the decoder Functions
+DEC_PARAMS = ('embed', 'w_logit', 'b_logit',
+              'w_ih0', 'w_ih1', 'w_ih2', 'w_hh0', 'w_hh1', 'w_hh2', 'b_ih0', 'b_ih1', 'b_ih2', 'b_hh0', 'b_hh1', 'b_hh2',
+              'w_c2a', 'b_c2a', 'w_h2a', 'b_h2a', 'w_alpha', 'b_alpha')
+
+
+def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp):
+    (embed, w_logit, b_logit, wi0, wi1, wi2, wh0, wh1, wh2, bi0, bi1, bi2, bh0, bh1, bh2, w_c2a, b_c2a, w_h2a, b_h2a,
+     w_alpha, b_alpha) = ps
+    N, De = event.shape
+    Tv, D = c3d.shape
+    H = wh0.shape[1]
+    E = embed.shape[1]
+    Ha = w_c2a.shape[0]
+    Dv = video.numel()
+    V1 = embed.shape[0]
+    assert wi0.shape[1] == E + De and wi1.shape[1] == E + D and wi2.shape[1] == E + Dv, 'LSTM input widths do not match the contexts'
+    return L.DecArgs(N, A, Tv, D, H, E, Ha, De, Dv, V1, S,
+                     L.ptr(embed), L.ptr(w_logit), L.ptr(b_logit),
+                     L.ptr3((wi0, wi1, wi2), 'w_ih'), L.ptr3((wh0, wh1, wh2), 'w_hh'), L.ptr3((bi0, bi1, bi2), 'b_ih'),
+                     L.ptr3((bh0, bh1, bh2), 'b_hh'),
+                     L.ptr(w_c2a), L.ptr(b_c2a), L.ptr(w_h2a), L.ptr(b_h2a), L.ptr(w_alpha), L.ptr(b_alpha),
+                     L.ptr(c3d), L.ptr(ev_start, torch.int32), L.ptr(ev_len, torch.int32), L.ptr(event), L.ptr(video),
+                     L.ptr(tokens, torch.int32) if tokens is not None else None, L.ptr(ws), L.ptr(logp) if logp is not None else None)
+
+
+class DecoderFunction(torch.autograd.Function):
+    """OldModel.forward with the ThreeStream core (OldModel_NEW.py:98-137, :376-401, :801-823): log-probs [N,S,V1]."""
+
+    @staticmethod
+    def forward(ctx, video, event, c3d, ev_start, ev_len, tokens, A, drop, *params):
+        lib = L.load()
+        video, event, c3d = _f32c(video), _f32c(event), _f32c(c3d)
+        ps = [_f32c(p) for p in params]
+        S, N = tokens.shape
+        V1 = ps[0].shape[0]
+        logp = torch.empty(N, S, V1, device=event.device, dtype=torch.float32)
+        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, None, logp)
+        ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=event.device, dtype=torch.float32)
+        a.ws = L.ptr(ws)
+        d = drop.c()
+        L.check(lib.echr_decoder_fwd(C.byref(a), C.byref(d), L.stream_ptr()), 'decoder_fwd')
+        ctx.save_for_backward(video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps)
+        ctx.meta = (A, S, drop)
+        return logp
+
+    @staticmethod
+    def backward(ctx, g_logp):
+        lib = L.load()
+        video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps = ctx.saved_tensors
+        A, S, drop = ctx.meta
+        g_logp = _f32c(g_logp)
+        grads = [torch.empty_like(p) for p in ps]
+        grads[0].zero_()                                     # embedding table gradient is scatter-added
+        g_event = torch.empty_like(event)
+        g_video = torch.empty_like(video) if ctx.needs_input_grad[0] else None
+        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp)
+        wsb = torch.empty(lib.echr_decoder_ws_bwd_floats(C.byref(a)), device=event.device, dtype=torch.float32)
+        gp = [L.ptr(x) for x in grads]
+        g = L.DecGrads(gp[0], gp[1], gp[2], (L.c_f * 3)(*gp[3:6]), (L.c_f * 3)(*gp[6:9]), (L.c_f * 3)(*gp[9:12]),
+                       (L.c_f * 3)(*gp[12:15]), gp[15], gp[16], gp[17], gp[18], gp[19], gp[20],
+                       L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp), None, None, None, L.ptr(wsb))
+        d = drop.c()
+        L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
+        return (g_video, g_event, None, None, None, None, None, None) + tuple(grads)
+
+
+def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params):
+    """Greedy OldModel.sample (OldModel_NEW.py:139-187) with every step on device; one host sync at the end.
+
+    Returns (seq int64 [N,T], logp fp32 [N,T]) with T <= seq_length, or ([], []) when nothing was generated."""
+    lib = L.load()
+    video, event, c3d = _f32c(video), _f32c(event), _f32c(c3d)
+    ps = [_f32c(p) for p in params]
+    N = event.shape[0]
+    dev = event.device
+    a = _dec_args(ps, c3d, ev_start, ev_len, event, video, None, A, seq_length, None, None)
+    ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=dev, dtype=torch.float32)
+    a.ws = L.ptr(ws)
+    wss = torch.empty(lib.echr_sampler_ws_floats(C.byref(a)), device=dev, dtype=torch.float32)
+    seq = torch.empty(N, seq_length, device=dev, dtype=torch.int64)
+    slp = torch.empty(N, seq_length, device=dev, dtype=torch.float32)
+    nun = torch.empty(seq_length + 1, device=dev, dtype=torch.int32)
+    sa = L.SampleArgs(a, seq_length, L.ptr(seq, torch.int64), L.ptr(slp), L.ptr(nun, torch.int32), L.ptr(wss))
+    L.check(lib.echr_decoder_sample(C.byref(sa), L.stream_ptr()), 'decoder_sample')
+    counts = nun.cpu().numpy()                 # the only device->host sync of the whole decode
+    T = seq_length
+    for t in range(1, seq_length + 1):        # OldModel_NEW.py:179-180: stop at the first step with nobody unfinished
+        if counts[t] == 0:
+            T = t - 1
+            break
+    if T == 0:
+        return [], []
+    return seq[:, :T].contiguous(), slp[:, :T].contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+class MaskedNLL(torch.autograd.Function):
+    """LanguageModelCriterion.forward (misc/utils.py:66-75) on device."""
+
+    @staticmethod
+    def forward(ctx, logp, target, mask):
+        lib = L.load()
+        N, S, V1 = logp.shape
+        logp = logp.contiguous()
+        tgt = target[:, :S].to(torch.int32).contiguous()
+        msk = mask[:, :S].to(torch.float32).contiguous()
+        out = torch.empty(2, device=logp.device, dtype=torch.float32)
+        L.check(lib.echr_nll_loss_fwd(L.ptr(logp), L.ptr(tgt, torch.int32), L.ptr(msk), L.ptr(out), N, S, V1, L.stream_ptr()),
+                'nll_loss_fwd')
+        ctx.save_for_backward(tgt, msk, out)
+        ctx.shape = (N, S, V1)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        tgt, msk, out = ctx.saved_tensors
+        N, S, V1 = ctx.shape
+        coef = (-g / (out[1] + 1e-6)) * msk                       # [N,S]
+        g_logp = torch.zeros(N, S, V1, device=msk.device, dtype=torch.float32)
+        g_logp.scatter_(2, tgt.long().clamp_(0, V1 - 1).unsqueeze(2), coef.unsqueeze(2))
+        return g_logp, None, None
+
+
+def clamp_adam_(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip=100.0):
+    """In-place fused clamp(+-clip) + Adam over flat fp32 buffers (misc/utils.py:107-111 + optim.Adam)."""
+    lib = L.load()
+    L.check(lib.echr_clamp_adam(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), int(step), float(lr), float(beta1),
+                                float(beta2), float(eps), float(clip), L.stream_ptr()), 'clamp_adam')
+
+
+def clamp_(g, clip):
+    lib = L.load()
+    L.check(lib.echr_clamp(L.ptr(g), g.numel(), float(clip), L.stream_ptr()), 'clamp')
+    return g
+
+
+def gemm(A, B, trans_b=True, bias=None):
+    """C = A @ B^T (trans_b) or A @ B on the fp32 MFMA path; exposed for kernel-level parity tests."""
+    lib = L.load()
+    M, K = A.shape
+    Nn = B.shape[0] if trans_b else B.shape[1]
+    Cc = torch.empty(M, Nn, device=A.device, dtype=torch.float32)
+    d = L.GemmDesc()
+    d.A, d.B, d.C = L.ptr(A), L.ptr(B), L.ptr(Cc)
+    d.M, d.N, d.K = M, Nn, K
+    d.sam, d.sak = K, 1
+    d.sbk, d.sbn = (1, K) if trans_b else (Nn, 1)
+    d.ldc = Nn
+    d.batch, d.alpha, d.beta, d.split_k = 1, 1.0, 0.0, -1
+    d.bias = L.ptr(bias) if bias is not None else None
+    L.check(lib.echr_gemm_f32(C.byref(d), L.stream_ptr()), 'gemm_f32')
+    return Cc

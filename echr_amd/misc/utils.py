@@ -1,0 +1,71 @@
+"""Criteria and optimiser helpers with the reference's names (misc/utils.py:15-122)."""
+import torch
+import torch.nn as nn
+
+from .. import functional as EF
+
+
+def if_use_att(caption_model):
+    return not (caption_model in ('show_tell', 'all_img', 'fc') or 'allimg' in caption_model)
+
+
+def decode_sequence(ix_to_word, seq):
+    """Index rows -> strings; 0 terminates a row (misc/utils.py:24-38)."""
+    rows = seq.tolist() if hasattr(seq, 'tolist') else seq
+    out = []
+    for row in rows:
+        words = []
+        for ix in row:
+            if ix <= 0:
+                break
+            words.append(ix_to_word[str(int(ix))])
+        out.append(' '.join(words))
+    return out
+
+
+class LanguageModelCriterion(nn.Module):
+    """Masked NLL over log-probs [N,S,V+1] (misc/utils.py:62-75), evaluated by echr_nll_loss_fwd."""
+
+    def forward(self, input, target, mask):
+        return EF.MaskedNLL.apply(input, target.to(input.device), mask.to(input.device))
+
+
+class TAPModelCriterion(nn.Module):
+    """Weighted BCE of the proposal head (misc/utils.py:78-99).  Belongs to the SST producer: stock ops."""
+
+    def forward(self, scores, masks, labels, w1):
+        w0 = 1. - w1
+        labels = labels * masks
+        weights = (labels * w0.expand_as(labels) + (1. - labels) * w1.expand_as(labels)).view(-1)
+        loss = nn.functional.binary_cross_entropy((scores.view(-1) * masks.view(-1)), labels.view(-1), weight=weights)
+        return loss * w0.shape[0]
+
+
+def set_lr(optimizer, lr):
+    for group in optimizer.param_groups:
+        group['lr'] = lr
+
+
+def clip_gradient(optimizer, grad_clip):
+    """Element-wise clamp of every gradient to +-grad_clip (misc/utils.py:107-111).
+
+    With echr_amd.optim.ClampAdam the clamp is folded into the fused step kernel (it is recorded here and
+    applied inside `step()`); for any other optimiser the clamp runs as its own HIP kernel per tensor."""
+    from ..optim import ClampAdam
+    if isinstance(optimizer, ClampAdam):
+        optimizer.pending_clip = float(grad_clip)
+        return
+    for group in optimizer.param_groups:
+        for p in group['params']:
+            if p.grad is not None:
+                EF.clamp_(p.grad.data, grad_clip)
+
+
+def fix_model_parameters(model):
+    for p in model.parameters():
+        p.requires_grad = False
+
+
+def unfix_model_parameters(model):
+    for p in model.parameters():
+        p.requires_grad = True

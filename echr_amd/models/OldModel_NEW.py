@@ -1,0 +1,215 @@
+"""Three-stream attention caption decoder -- drop-in for the reference's models/OldModel_NEW.py
+(the `three_stream` branch that models.setup_lm can return: OldModel :18-187, Attention :366-401,
+ThreeStream_Core :762-823, ThreestreamModel :1040-1043).
+
+Module/parameter names and shapes match the reference so `state_dict()`s are interchangeable.  The
+sub-modules (nn.Embedding, nn.Linear, nn.LSTMCell) are parameter containers only: `forward` and
+`sample` run the whole sequence through libechr_hip.so (echr_decoder_fwd/bwd, echr_decoder_sample).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import functional as EF
+
+
+class ClipView(object):
+    """The frame-level ('CC') context without the zero-padded copy: event n's slot a is row
+    ev_start[n] + a of `feats` [T,D] (CaptionGenerator.py:140-167 materialises [N,A,D] + mask instead)."""
+
+    def __init__(self, feats, ev_start, ev_len, max_len):
+        self.feats, self.ev_start, self.ev_len, self.max_len = feats, ev_start, ev_len, int(max_len)
+
+    @property
+    def shape(self):
+        return (self.ev_start.numel(), self.max_len, self.feats.shape[1])
+
+    def materialize(self):
+        """(clip [N,A,D], mask [N,A]) exactly as the reference builds them (pure data movement)."""
+        N, A, D = self.shape
+        a = torch.arange(A, device=self.feats.device)
+        mask = (a[None, :] < self.ev_len[:, None].long())
+        rows = (self.ev_start[:, None].long() + a[None, :]).clamp_(max=self.feats.shape[0] - 1)
+        clip = self.feats[rows] * mask[:, :, None].to(self.feats.dtype)
+        return clip, mask.to(self.feats.dtype)
+
+    @staticmethod
+    def from_padded(clip, clip_mask):
+        """Wrap a reference-style padded clip tensor [N,A,D] + prefix mask [N,A] (one small D2H sync for the lengths)."""
+        N, A, D = clip.shape
+        lens = clip_mask.reshape(N, A).sum(1).round().to(torch.int32)
+        if int(lens.min()) <= 0:
+            raise ValueError('clip_mask has an empty row')
+        starts = (torch.arange(N, device=clip.device, dtype=torch.int32) * A)
+        return ClipView(clip.reshape(N * A, D).contiguous(), starts.contiguous(), lens.contiguous(), A)
+
+
+def n_decoder_steps(seq):
+    """Iterations of the teacher-forced loop incl. its early break on an all-zero label column
+    (OldModel_NEW.py:105,122), computed once on the host instead of one device sync per step."""
+    if isinstance(seq, torch.Tensor):
+        nz = (seq != 0).any(0).cpu().numpy()
+    else:
+        nz = (np.asarray(seq) != 0).any(0)
+    L = len(nz)
+    S = 0
+    for i in range(L - 1):
+        if i >= 1 and not nz[i]:
+            break
+        S += 1
+    return S
+
+
+class OldModel(nn.Module):
+    def __init__(self, opt):
+        super(OldModel, self).__init__()
+        self.CG_init_feats_type = opt.CG_init_feats_type
+        self.opt = opt
+        self.vocab_size = opt.CG_vocab_size
+        self.input_encoding_size = opt.CG_input_encoding_size
+        self.rnn_type = opt.CG_rnn_type
+        self.rnn_size = opt.CG_rnn_size
+        self.num_layers = opt.CG_num_layers
+        self.drop_prob_lm = opt.CG_drop_prob
+        self.seq_length = opt.CG_seq_length
+        self.CG_init_feats_dim = self.decide_init_feats_dim()
+        self.ss_prob = 0.0
+        if self.CG_init_feats_dim:
+            raise NotImplementedError('CG_init_feats_type=%r: the HIP path implements the ECHR recipe (zero initial state, '
+                                      'train_ECHR.sh)' % (opt.CG_init_feats_type,))
+        self.embed = nn.Embedding(self.vocab_size + 1, self.input_encoding_size)
+        if 'three_stream' not in opt.caption_model or 'three_stream_2stream' in opt.caption_model:
+            raise NotImplementedError('caption_model=%r: only the three_stream decoder is on the HIP path' % (opt.caption_model,))
+        self.logit = nn.Linear(3 * self.rnn_size, self.vocab_size + 1)
+        self.dropout = nn.Dropout(self.drop_prob_lm)
+        self.init_weights()
+        self._drop_seed = None
+        self._drop_calls = 0
+
+    def decide_init_feats_dim(self):
+        t, o = self.CG_init_feats_type, self.opt
+        return (o.video_context_dim if 'V' in t else 0) + (o.event_context_dim if 'E' in t else 0) + \
+               (o.clip_context_dim if 'C' in t else 0)
+
+    def init_weights(self):
+        r = 0.1                                            # OldModel_NEW.py:66-70
+        with torch.no_grad():
+            self.embed.weight.uniform_(-r, r)
+            self.logit.bias.zero_()
+            self.logit.weight.uniform_(-r, r)
+
+    # ---- dropout bookkeeping ----------------------------------------------------------------------
+    def next_drop_state(self, p_tsrm=0.3):
+        """Dropout configuration for the next forward: fresh Philox offset per training-mode call."""
+        if self._drop_seed is None:
+            self._drop_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        c = self.core
+        st = EF.DropState(self._drop_seed, self._drop_calls, self.training, p_tsrm, c.dropout0.p, self.dropout.p)
+        if self.training:
+            self._drop_calls += 1
+        return st
+
+    def native_params(self):
+        c = self.core
+        a = c.attention
+        return (self.embed.weight, self.logit.weight, self.logit.bias,
+                c.layer0.weight_ih, c.layer1.weight_ih, c.layer2.weight_ih,
+                c.layer0.weight_hh, c.layer1.weight_hh, c.layer2.weight_hh,
+                c.layer0.bias_ih, c.layer1.bias_ih, c.layer2.bias_ih,
+                c.layer0.bias_hh, c.layer1.bias_hh, c.layer2.bias_hh,
+                a.ctx2att.weight, a.ctx2att.bias, a.h2att.weight, a.h2att.bias, a.alpha_net.weight, a.alpha_net.bias)
+
+    @staticmethod
+    def _clip_view(clip, clip_mask):
+        return clip if isinstance(clip, ClipView) else ClipView.from_padded(clip, clip_mask)
+
+    def forward(self, video, event, clip, clip_mask, seq, drop=None):
+        """Teacher-forced log-probs [N,S,V+1] (OldModel_NEW.py:98-130)."""
+        if self.training and self.ss_prob > 0.0:
+            raise NotImplementedError('scheduled sampling (ss_prob > 0) is never enabled by the reference and is not on the HIP path')
+        cv = self._clip_view(clip, clip_mask)
+        S = n_decoder_steps(seq)
+        if S == 0:
+            raise ValueError('label tensor needs at least two columns')
+        dev = event.device
+        seq_t = torch.as_tensor(np.asarray(seq) if not isinstance(seq, torch.Tensor) else seq)
+        tokens = seq_t[:, :S].t().to(device=dev, dtype=torch.int32).contiguous()          # [S,N] time-major
+        if drop is None:
+            drop = self.next_drop_state()
+        return EF.DecoderFunction.apply(video, event, cv.feats, cv.ev_start, cv.ev_len, tokens, cv.max_len, drop,
+                                        *self.native_params())
+
+    def get_logprobs_state(self, it, video, event, clip, clip_mask, state):
+        raise NotImplementedError('single-step API: use forward() (teacher forcing) or sample() (greedy), which run the whole '
+                                  'sequence inside libechr_hip.so')
+
+    def sample(self, video, event, clip, clip_mask, opt={}):
+        """Greedy decoding (OldModel_NEW.py:139-187 with sample_max=1, beam_size=1)."""
+        if opt.get('sample_max', 1) != 1 or opt.get('beam_size', 1) != 1:
+            raise NotImplementedError('only greedy decoding (sample_max=1, beam_size=1) is on the HIP path')
+        cv = self._clip_view(clip, clip_mask)
+        with torch.no_grad():
+            return EF.greedy_sample(video, event, cv.feats, cv.ev_start, cv.ev_len, cv.max_len, self.seq_length,
+                                    self.native_params())
+
+
+class Attention(nn.Module):
+    """Additive attention parameters (OldModel_NEW.py:366-375); arithmetic fused into the decoder kernels."""
+
+    def __init__(self, opt):
+        super(Attention, self).__init__()
+        self.rnn_size = opt.CG_rnn_size
+        self.att_hid_size = opt.CG_att_hid_size
+        self.att_feat_size = opt.clip_context_dim
+        self.ctx2att = nn.Linear(self.att_feat_size, self.att_hid_size)
+        self.h2att = nn.Linear(self.rnn_size, self.att_hid_size)
+        self.alpha_net = nn.Linear(self.att_hid_size, 1)
+
+
+class ThreeStream_Core(nn.Module):
+    """Three independent LSTM-cell streams (event / attended clip / scene) + late fusion (OldModel_NEW.py:762-799)."""
+
+    def __init__(self, opt):
+        super(ThreeStream_Core, self).__init__()
+        self.opt = opt
+        self.input_encoding_size = opt.CG_input_encoding_size
+        self.rnn_type = opt.CG_rnn_type
+        self.rnn_size = opt.CG_rnn_size
+        self.drop_prob_lm = opt.CG_drop_prob
+        self.fc_feat_size = opt.CG_fc_feat_size
+        self.att_feat_size = opt.clip_context_dim
+        self.att_hid_size = opt.CG_att_hid_size
+        self.CG_input_feats_type = opt.CG_input_feats_type
+        if self.CG_input_feats_type:
+            raise NotImplementedError('CG_input_feats_type=%r is not part of the ECHR recipe' % (self.CG_input_feats_type,))
+        self.CG_input_dim = 0
+        E = self.input_encoding_size
+        self.layer0 = nn.LSTMCell(opt.event_context_dim + E, self.rnn_size)
+        self.layer1 = nn.LSTMCell(opt.clip_context_dim + E, self.rnn_size)
+        self.layer2 = nn.LSTMCell(opt.video_context_dim + E, self.rnn_size)
+        self.fusion_layer = nn.Linear(self.rnn_size * 3, self.rnn_size)      # registered, never used (:783)
+        self.attention = Attention(opt)
+        self.dropout0 = nn.Dropout(0.5)
+        self.dropout1 = nn.Dropout(0.5)
+        self.dropout2 = nn.Dropout(0.5)
+
+
+class ThreestreamModel(OldModel):
+    def __init__(self, opt):
+        super(ThreestreamModel, self).__init__(opt)
+        self.core = ThreeStream_Core(opt)
+
+
+def _ablation(name):
+    class _Unsupported(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError('%s is an ablation variant outside the ECHR hot path (SURVEY section 2 row 4)' % name)
+    _Unsupported.__name__ = name
+    return _Unsupported
+
+
+# names the reference's models/__init__.py imports (models/__init__.py:1); only ThreestreamModel is live
+for _n in ('ShowAttendTellModel', 'AllImgModel', 'H3Model', 'TwostreamModel', 'Twostream_jump_Model', 'TwostreamModel_3LSTM',
+           'H3denseModel', 'H3denaddModel', 'ThreestreamModel_2stream', 'ThreestreamModel_2stream_LDA',
+           'ThreestreamModel_2stream_CC'):
+    globals()[_n] = _ablation(_n)

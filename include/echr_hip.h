@@ -1,0 +1,218 @@
+/*
+ * echr_hip.h -- C ABI of libechr_hip.so: the MI355X (gfx950) implementation of ECHR's
+ * hierarchical-encoder + attention caption-decoder hot path.
+ *
+ * The reference (ttengwang/ECHR) has no FFI layer of its own: its boundary is the Python module API
+ * (CaptionGenerator.py:17, models/__init__.py:6-29).  echr_amd/ keeps that Python API and calls the
+ * entry points below through ctypes; each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - every pointer is a BORROWED device pointer (PyTorch owns all memory; the library never
+ *    allocates or frees user-visible buffers); tensors are row-major contiguous fp32 unless a
+ *    leading dimension is given; index tensors are int32.
+ *  - `stream` is a hipStream_t passed as void*; calls are asynchronous w.r.t. the host, re-entrant,
+ *    never synchronise, and are legal inside hipGraph stream capture.
+ *  - return 0 on success, negative errno-style code on failure; echr_last_error() returns the
+ *    calling thread's last message.
+ */
+#ifndef ECHR_HIP_H
+#define ECHR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECHR_ABI_VERSION 1
+
+int echr_version(void);
+const char* echr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense fp32 projection on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+ * Replaces every nn.Linear / torch.bmm / addmm site of the path.
+ *   C[b][rowmap(i)][j] = act( alpha * sum_k A[b](i,k) * B[b](k,j) + beta * C_old + bias[j] + bias2[j]
+ *                             + addend[(i % add_mod)][j] )
+ * A(i,k) = A[i*sam + k*sak], B(k,j) = B[k*sbk + j*sbn]; in each pair one stride must be 1.
+ * split_k > 1: partial sums are atomically added into C (which must already hold its base value);
+ *              act must be ECHR_ACT_NONE and beta is ignored.
+ * ---------------------------------------------------------------------------------------------- */
+enum { ECHR_ACT_NONE = 0, ECHR_ACT_TANH = 1, ECHR_ACT_MUL_DTANH = 2 /* acc * (1 - aux^2) */ };
+
+typedef struct {
+    const float* A;
+    const float* B;
+    float* C;
+    int32_t M, N, K;
+    int64_t sam, sak, sbk, sbn, ldc;
+    int32_t batch;
+    int64_t bsa, bsb, bsc;
+    float alpha, beta;
+    const float* bias;
+    int64_t bs_bias;
+    const float* bias2;
+    const float* addend;
+    int32_t add_mod;
+    int64_t ld_add;
+    int32_t act;
+    const float* aux;
+    int64_t ld_aux;
+    int32_t rowmap_mod, rowmap_mul; /* out row = (i % mod) * mul + i / mod ; mod = 0 -> identity */
+    int32_t split_k;
+} echr_gemm_desc;
+
+int echr_gemm_f32(const echr_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dropout configuration shared by all training-mode entry points (counter-based Philox-4x32-10;
+ * bit-identical host implementation: echr_amd/philox.py).  Sites: reference nn.Dropout instances at
+ * models/MA_attention_8_NEW.py:162 (p=0.3), models/OldModel_NEW.py:810,814,818 (p=0.5), :136 (CG_drop_prob).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t seed;
+    uint32_t offset;   /* forward-call counter */
+    int32_t training;  /* 0: every dropout is the identity */
+    float p_tsrm, p_h, p_out;
+} echr_dropout;
+
+/* ------------------------------------------------------------------------------------------------
+ * Event-level context inputs: mean-pool of each event's C3D rows + gather of the proposal-LSTM
+ * state at the event's anchor.  Replaces CaptionGenerator.py:111-114,121,128.
+ *   ech[n, 0:D]     = mean(c3d[ev_start[n] : ev_start[n]+ev_len[n], :])
+ *   ech[n, D:D+Ht]  = tap[ind[n], :]
+ * bwd scatters d_ech[:, D:] into d_tap rows (atomic add; d_tap pre-zeroed) -- gradients to c3d are
+ * not produced (features are data).
+ * ---------------------------------------------------------------------------------------------- */
+int echr_event_pool_gather_fwd(const float* c3d, const float* tap, const int32_t* ev_start, const int32_t* ev_len,
+                               const int32_t* ind, float* ech, int32_t N, int32_t D, int32_t Ht, void* stream);
+int echr_event_pool_gather_bwd(const float* d_ech, const int32_t* ind, float* d_tap, int32_t N, int32_t D, int32_t Ht,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * TSRM event-relation encoder.  Replaces MA_Attention8.forward (MA_attention_8_NEW.py:35-49) and
+ * attention_module_multi_head.forward (:101-177), fST0 / use_posit=1.
+ * Parameter pointers use the reference state_dict names (fusion_model.*).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t N, Din, Df, Do, G;
+    /* parameters */
+    const float *w_emb, *b_emb;      /* event_emb      [Df,Din],[Df] */
+    const float *w_fc1, *b_fc1;      /* pair_pos_fc1   [Df,Df],[Df]  */
+    const float *w_fc2, *b_fc2;      /* pair_pos_fc2   [G,Df],[G]    */
+    const float *w_q, *b_q;          /* query_1        [Df,Df],[Df]  */
+    const float *w_k, *b_k;          /* key_1          [Df,Df],[Df]  */
+    const float *w_out, *b_out;      /* linear_out_1   [Do,Df(,1,1)],[Do] */
+    /* inputs */
+    const float* ech;                /* [N,Din] */
+    const int32_t *ev_start, *ev_len;
+    /* saved activations (caller-allocated; sizes via echr_tsrm_ws_floats) */
+    float* ws;
+    /* output */
+    float* out;                      /* [N,Do] */
+} echr_tsrm_args;
+
+typedef struct {
+    /* parameter gradients (written, not accumulated) */
+    float *g_w_emb, *g_b_emb, *g_w_fc1, *g_b_fc1, *g_w_fc2, *g_b_fc2, *g_w_q, *g_b_q, *g_w_k, *g_b_k, *g_w_out, *g_b_out;
+    float* g_ech;                    /* [N,Din] */
+    const float* g_out;              /* [N,Do] */
+    float* ws_bwd;                   /* scratch, echr_tsrm_ws_bwd_floats */
+} echr_tsrm_grads;
+
+int64_t echr_tsrm_ws_floats(int32_t N, int32_t Din, int32_t Df, int32_t Do, int32_t G);
+int64_t echr_tsrm_ws_bwd_floats(int32_t N, int32_t Din, int32_t Df, int32_t Do, int32_t G);
+int echr_tsrm_fwd(const echr_tsrm_args* a, const echr_dropout* drop, void* stream);
+int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr_dropout* drop, void* stream);
+/* position embedding alone (float64 math on device, fp32 result [N,N,Df]); replaces the numpy
+ * extract_position_matrix / extract_position_embedding (:51-79) + the host->device copy at :41 */
+int echr_tsrm_posemb(const int32_t* ev_start, const int32_t* ev_len, float* pos, int32_t N, int32_t Df, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Three-stream attention caption decoder.  Replaces OldModel.forward (teacher forcing,
+ * models/OldModel_NEW.py:98-130), get_logprobs_state (:133-137), ThreeStream_Core.forward (:801-823),
+ * Attention.forward (:376-401), the greedy branch of OldModel.sample (:139-187), and, optionally
+ * fused, LanguageModelCriterion (misc/utils.py:66-75).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t N, A, Tv, D, H, E, Ha, De, Dv, V1, S;
+    /* parameters (reference state_dict names under lm_model.) */
+    const float* embed;                        /* embed.weight [V1,E] */
+    const float *w_logit, *b_logit;            /* logit [V1,3H],[V1] */
+    const float* w_ih[3];                      /* core.layer{k}.weight_ih [4H, E+ctx_k] */
+    const float* w_hh[3];                      /* [4H,H] */
+    const float* b_ih[3];
+    const float* b_hh[3];
+    const float *w_c2a, *b_c2a;                /* core.attention.ctx2att [Ha,D],[Ha] */
+    const float *w_h2a, *b_h2a;                /* h2att [Ha,H],[Ha] */
+    const float *w_alpha, *b_alpha;            /* alpha_net [1,Ha],[1] */
+    /* inputs */
+    const float* c3d;                          /* [Tv,D] */
+    const int32_t *ev_start, *ev_len;          /* [N] (clip context = rows ev_start..ev_start+ev_len) */
+    const float* event;                        /* [N,De] */
+    const float* video;                        /* [Dv]   */
+    const int32_t* tokens;                     /* [S,N] time-major input tokens (labels[:, t]) */
+    /* workspace (saved for backward), echr_decoder_ws_floats */
+    float* ws;
+    /* output: log-probs [N,S,V1] */
+    float* logp;
+} echr_dec_args;
+
+typedef struct {
+    float* g_embed;                            /* [V1,E] must be zeroed by the caller (scatter-add) */
+    float *g_w_logit, *g_b_logit;
+    float* g_w_ih[3];
+    float* g_w_hh[3];
+    float* g_b_ih[3];
+    float* g_b_hh[3];
+    float *g_w_c2a, *g_b_c2a, *g_w_h2a, *g_b_h2a, *g_w_alpha, *g_b_alpha;
+    float* g_event;                            /* [N,De] */
+    float* g_video;                            /* [Dv] or NULL */
+    const float* g_logp;                       /* [N,S,V1] upstream gradient, or NULL when nll_* are set */
+    /* fused criterion path: d loss / d logp = -mask/(sum(mask)+1e-6) * g_loss at the target entries */
+    const int32_t* nll_target;                 /* [N,S] or NULL */
+    const float* nll_mask;                     /* [N,S] */
+    const float* g_loss;                       /* device scalar */
+    float* ws_bwd;                             /* scratch, echr_decoder_ws_bwd_floats */
+} echr_dec_grads;
+
+int64_t echr_decoder_ws_floats(const echr_dec_args* a);
+int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a);
+int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream);
+int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream);
+
+/* masked NLL of LanguageModelCriterion on log-probs [N,S,V1]: loss (device scalar) */
+int echr_nll_loss_fwd(const float* logp, const int32_t* target, const float* mask, float* loss, int32_t N, int32_t S,
+                      int32_t V1, void* stream);
+
+/* greedy sampler: runs seq_len+1 decoder steps on device without host syncs.
+ * seq [N,seq_len] int64 (zero after a row finished), seq_logp [N,seq_len] fp32,
+ * n_unfinished [seq_len+1] int32: number of unfinished rows after step t (the host trims the output
+ * at the first t >= 1 with n_unfinished[t] == 0, as OldModel.sample's break does). */
+typedef struct {
+    echr_dec_args dec;       /* S, tokens, logp unused */
+    int32_t seq_len;
+    int64_t* seq;
+    float* seq_logp;
+    int32_t* n_unfinished;
+    float* ws_sample;        /* echr_sampler_ws_floats */
+} echr_sample_args;
+int64_t echr_sampler_ws_floats(const echr_dec_args* a);
+int echr_decoder_sample(const echr_sample_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused element-wise clamp(+-clip) + Adam (betas, eps, no weight decay, no amsgrad) over a flat
+ * buffer.  Replaces misc/utils.py:107-111 + torch.optim.Adam.step as wired at train.py:209,315-317.
+ * `step` is the 1-based step count.  `skip_nonfinite`=0 keeps torch semantics.
+ * ---------------------------------------------------------------------------------------------- */
+int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1,
+                    float beta2, float eps, float clip, void* stream);
+
+/* stand-alone element-wise clamp (misc/utils.py:107-111) for optimisers other than the fused one */
+int echr_clamp(float* g, int64_t n, float clip, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECHR_HIP_H */

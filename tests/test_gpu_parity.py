@@ -1,0 +1,223 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs and against the golden fixtures generated from the reference (tests/golden, tools/make_golden.py).
+
+Tolerances (north_star): log-probs / losses within 1e-4 relative of the reference's PyTorch-CPU path; index
+outputs bit-exact.  Gradients: 1e-3 of each tensor's max-norm (fp32 atomics reorder sums; measured ~1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from echr_amd import synth
+from oracle import summary as SM
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOGP = 1e-4     # absolute on log-probs of magnitude ~8.5 => ~1e-5 relative
+TOL_LOSS = 1e-4     # relative
+TOL_GRAD = 1e-3     # relative to the tensor's max-norm
+
+
+def test_library_loaded_on_gpu():
+    from echr_amd import _lib
+    lib = _lib.load()
+    assert lib.echr_version() == 1
+
+
+@pytest.mark.parametrize('M,N,K,trans_b', [(64, 64, 32, True), (130, 70, 100, True), (1280, 513, 1536, True),
+                                           (64, 2048, 512, True), (200, 96, 500, False), (5, 7, 3, True),
+                                           (257, 5001, 64, True), (64, 500, 2048, False)])
+def test_gemm_f32(M, N, K, trans_b):
+    from echr_amd import functional as EF
+    rs = np.random.RandomState(M * 7 + N)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    B = rs.standard_normal((N, K) if trans_b else (K, N)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    ref = A.astype(np.float64) @ (B.T if trans_b else B).astype(np.float64) + bias
+    out = EF.gemm(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), trans_b, torch.from_numpy(bias).cuda()).cpu().numpy()
+    scale = np.abs(A).astype(np.float64) @ np.abs(B.T if trans_b else B).astype(np.float64) + 1.0
+    assert np.max(np.abs(out - ref) / scale) < 1e-6, np.max(np.abs(out - ref) / scale)
+
+
+def test_position_embedding_matches_reference_numpy():
+    from echr_amd import functional as EF
+    g = U.gold('position.npz')
+    for k in ('a', 'b'):
+        soi = g[k + '|soi']
+        st = torch.from_numpy(soi[:, 0].astype(np.int32)).cuda()
+        ln = torch.from_numpy((soi[:, 1] - soi[:, 0]).astype(np.int32)).cuda()
+        for d, key in ((512, '|pos_emb_f32'), (32, '|pos_emb32_f32')):
+            pos = EF.position_embedding(st, ln, d).cpu().numpy()
+            err = np.abs(pos - g[k + key]).max()
+            assert err < 2e-6, (k, d, err)      # float64 math on device; log(l_j/l_i) in float32 like the reference
+
+
+def test_event_pool_gather():
+    from echr_amd import functional as EF
+    from oracle import echr_ref_cpu as O
+    opt, params, vid = synth.make_case('c2')
+    c3d, tap = torch.from_numpy(vid['c3d']), torch.from_numpy(vid['tap'])
+    ev = EF.event_index_tensors(vid['soi'], vid['ind'], torch.device('cuda'))
+    ech = EF.EventPoolGather.apply(c3d.cuda(), tap.cuda(), ev[0], ev[1], ev[2]).cpu()
+    ref = torch.cat((O.event_pool(c3d, vid['soi']), tap[torch.from_numpy(vid['ind'])]), 1)
+    assert float((ech - ref).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2'])
+@pytest.mark.parametrize('train_mode', [False, True])
+def test_event_context_tsrm(case, train_mode):
+    """fusion_model (TSRM) forward + backward against the oracle, eval and train (dropout) mode."""
+    from echr_amd import functional as EF
+    from oracle import echr_ref_cpu as O
+    opt, params, vid = synth.make_case(case)
+    m = U.build_gpu_model(opt, params, train_mode)
+    dev = torch.device('cuda')
+    N = len(vid['soi'])
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    dm = U.oracle_drop(opt)('tsrm', 0, (N, opt.n_head, N)) if train_mode else None
+    ref = O.event_context(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), vid['ind'], vid['soi'], opt.n_head, dm)
+    ev = EF.event_index_tensors(vid['soi'], vid['ind'], dev)
+    drop = EF.DropState(U.SEED, U.OFFSET, train_mode)
+    out = m.get_event_context(torch.from_numpy(vid['tap']).to(dev), torch.from_numpy(vid['c3d']).to(dev), None, vid['ind'], vid['soi'],
+                              _ev=ev, _drop=drop)
+    assert U.relerr(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    if not train_mode:
+        gold = U.gold('case_%s.npz' % case)['event_context']
+        assert U.relerr(out.detach().cpu().numpy(), gold) < 1e-5
+    w = torch.from_numpy(np.random.RandomState(1).standard_normal(tuple(ref.shape)).astype(np.float32))
+    (ref * w).sum().backward()
+    (out * w.to(dev)).sum().backward()
+    for k, p in m.named_parameters():
+        if not k.startswith('fusion_model.') or P[k].grad is None:
+            continue
+        assert U.relerr(p.grad.cpu().numpy(), P[k].grad.numpy()) < TOL_GRAD, k
+
+
+@pytest.mark.parametrize('case', ['tiny', 'c1'])
+@pytest.mark.parametrize('train_mode', [False, True])
+def test_full_path_vs_oracle(case, train_mode):
+    """CaptionGenerator forward + criterion + backward against the oracle run on the host with identical dropout masks."""
+    opt, params, vid = synth.make_case(case)
+    pred, loss, grads, _ = U.run_gpu(opt, params, vid, train_mode)
+    rpred, rloss, rgrads = U.run_oracle(opt, params, vid, train_mode)
+    assert pred.shape == rpred.shape
+    assert np.abs(pred - rpred).max() < TOL_LOGP, np.abs(pred - rpred).max()
+    assert abs(loss - rloss) < TOL_LOSS * abs(rloss)
+    for k, g in rgrads.items():
+        if g is None:
+            assert grads[k] is None, k
+        else:
+            assert U.relerr(grads[k], g) < TOL_GRAD, (k, U.relerr(grads[k], g))
+
+
+@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full'])
+@pytest.mark.parametrize('train_mode', [False, True])
+def test_full_path_vs_reference_golden(case, train_mode):
+    """Same, against the fixtures the reference itself produced (full tensors for 'tiny', summaries otherwise)."""
+    opt, params, vid = synth.make_case(case)
+    g = U.gold('case_%s.npz' % case)
+    mode = 'train' if train_mode else 'eval'
+    pred, loss, grads, _ = U.run_gpu(opt, params, vid, train_mode)
+    assert abs(loss - float(g[mode + '|loss'])) < TOL_LOSS * abs(float(g[mode + '|loss']))
+    if case == 'tiny':
+        assert np.abs(pred - g[mode + '|logp']).max() < TOL_LOGP
+        for k, v in grads.items():
+            key = mode + '|grad|' + k
+            if v is None:
+                assert key not in g
+            else:
+                assert U.relerr(v, g[key]) < TOL_GRAD, (k, U.relerr(v, g[key]))
+        return
+    s = SM.summarize_logp(pred)
+    assert np.abs(s['slice'] - g[mode + '|logp|slice']).max() < TOL_LOGP
+    assert np.abs(s['top1'] - g[mode + '|logp|top1']).max() < TOL_LOGP
+    assert np.abs(s['prob_sum'] - 1.0).max() < 1e-4
+    safe = g[mode + '|logp|margin'] > 1e-4                # arg-max must agree wherever the reference's own margin is resolvable
+    assert np.array_equal(s['argmax'][safe], g[mode + '|logp|argmax'][safe])
+    gs = SM.summarize_grads(grads)
+    for key, v in gs.items():
+        ref = g[mode + '|grad|' + key]
+        name = key.split('|')[0]
+        scale = float(g[mode + '|grad|' + name + '|linf']) + 1e-30
+        if key.endswith('|l2') or key.endswith('|linf'):
+            assert abs(float(v) - float(ref)) < TOL_GRAD * max(abs(float(ref)), 1e-30), (key, float(v), float(ref))
+        else:
+            assert np.abs(v - ref).max() < TOL_GRAD * scale, (key, np.abs(v - ref).max() / scale)
+
+
+@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full'])
+def test_greedy_sample_bit_exact(case):
+    """mode='eval': the index output must equal the reference's greedy sequence exactly; log-probs within 1e-4."""
+    opt, params, vid = synth.make_case(case)
+    g = U.gold('case_%s.npz' % case)
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    with torch.no_grad():
+        seq, lp = m(torch.from_numpy(vid['tap']).to(dev), torch.from_numpy(vid['c3d']).to(dev), torch.from_numpy(vid['lda']).to(dev),
+                    [], vid['ind'], vid['soi'], mode='eval')
+    assert seq.dtype == torch.int64
+    assert tuple(seq.shape) == tuple(g['sample|seq'].shape)
+    assert np.array_equal(seq.cpu().numpy(), g['sample|seq'])
+    assert np.abs(lp.cpu().numpy() - g['sample|logp']).max() < TOL_LOGP
+
+
+def test_clamp_adam_matches_torch_adam():
+    from echr_amd import functional as EF
+    g = U.gold('adam.npz')
+    p = torch.from_numpy(g['p0'].copy()).cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i in range(4):
+        EF.clamp_adam_(p, torch.from_numpy(g['g%d' % i]).cuda(), m, v, i + 1, 5e-5, 0.9, 0.999, 1e-8, 100.0)
+        assert np.abs(p.cpu().numpy() - g['p%d' % (i + 1)]).max() < 2e-7, i
+    assert U.relerr(m.cpu().numpy(), g['exp_avg']) < 1e-6
+    assert U.relerr(v.cpu().numpy(), g['exp_avg_sq']) < 1e-6
+
+
+def test_optimizer_step_on_model():
+    """clip_gradient + ClampAdam.step() == reference's clip_gradient + torch.optim.Adam on the same gradients."""
+    from echr_amd.misc.utils import clip_gradient
+    from echr_amd.optim import ClampAdam
+    opt, params, vid = synth.make_case('tiny')
+    _, _, grads, m = U.run_gpu(opt, params, vid, False)
+    ref_p = {k: torch.nn.Parameter(torch.from_numpy(v.copy())) for k, v in params.items()}
+    for k, p in ref_p.items():
+        p.grad = torch.from_numpy(grads[k].copy()) if grads[k] is not None else None
+    ropt = torch.optim.Adam(list(ref_p.values()), lr=1e-3)
+    for p in ref_p.values():
+        if p.grad is not None:
+            p.grad.clamp_(-0.01, 0.01)
+    ropt.step()
+    o = ClampAdam(m.parameters(), lr=1e-3)
+    clip_gradient(o, 0.01)
+    o.step()
+    for k, p in m.named_parameters():
+        assert np.abs(p.detach().cpu().numpy() - ref_p[k].detach().numpy()).max() < 1e-6, k
+
+
+def test_padded_clip_tensor_api():
+    """lm_model accepts the reference-style padded clip tensor + mask (external callers of lm_model.forward)."""
+    from echr_amd import functional as EF
+    opt, params, vid = synth.make_case('tiny')
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels = torch.from_numpy(vid['labels'])
+    a = m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+    clip, mask = m.get_clip_context(tap, c3d, lda, vid['ind'], vid['soi'])
+    from oracle import echr_ref_cpu as O
+    rc, rm = O.clip_context(torch.from_numpy(vid['c3d']), vid['soi'])
+    assert torch.equal(clip.cpu(), rc) and torch.equal(mask.cpu(), rm)
+    ev = EF.event_index_tensors(vid['soi'], vid['ind'], dev)
+    event = m.get_event_context(tap, c3d, lda, vid['ind'], vid['soi'], _ev=ev, _drop=EF.DropState())
+    b = m.lm_model(lda, event, clip, mask, labels)
+    assert float((a - b).abs().max()) < 1e-5
+
+
+def test_cpu_tensors_fail_loudly():
+    import echr_amd
+    from echr_amd._lib import EchrHipError
+    opt, params, vid = synth.make_case('tiny')
+    m = echr_amd.CaptionGenerator(opt)
+    with pytest.raises(EchrHipError):
+        m(torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), torch.from_numpy(vid['labels']),
+          vid['ind'], vid['soi'], mode='train')

@@ -1,0 +1,120 @@
+"""CPU: host-side mirror of the reference interface + the C-ABI library's exports (no compute calls)."""
+import copy
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import echr_amd
+from echr_amd import philox, synth
+from tests import util as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_contract_and_opt_side_effects():
+    opt = synth.default_opt()
+    m = echr_amd.CaptionGenerator(opt)
+    want = synth.state_dict_shapes(opt)
+    sd = m.state_dict()
+    assert set(sd) == set(want)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(want[k]), k
+    assert (opt.video_context_dim, opt.event_context_dim, opt.clip_context_dim) == (100, 512, 500)   # CaptionGenerator.py:82-84
+    assert (opt.TSRM_input_dim, opt.d_pos_vec) == (1012, 512)                                         # MA_attention_8_NEW.py:14-22
+    assert sum(v.numel() for v in sd.values()) == 11465343 + 2049 * 5001
+    assert m.lm_model.seq_length == opt.CG_seq_length and m.lm_model.vocab_size == opt.CG_vocab_size and m.lm_model.ss_prob == 0.0
+    assert float(m.lm_model.logit.bias.detach().abs().max()) == 0.0 and float(m.lm_model.embed.weight.detach().abs().max()) <= 0.1
+
+
+def test_loads_reference_shaped_state_dict():
+    opt, params, _ = synth.make_case('tiny')
+    m = echr_amd.CaptionGenerator(opt)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    assert torch.equal(m.fusion_model.enc_attn.linear_out_1.weight, torch.from_numpy(params['fusion_model.enc_attn.linear_out_1.weight']))
+
+
+def test_factories_and_unsupported_variants():
+    from echr_amd import models
+    opt = synth.default_opt()
+    echr_amd.CaptionGenerator(copy.copy(opt))
+    bad = synth.default_opt(caption_model='show_attend_tell')
+    with pytest.raises(NotImplementedError):
+        models.setup_lm(bad)
+    with pytest.raises(Exception):
+        models.setup_fusion(synth.default_opt(fusion_model='nope'))
+    sst = models.setup_tap(opt)
+    assert sst.rnn.hidden_size == 512 and sst.scores.out_features == 256
+
+
+def test_library_exports_every_declared_symbol():
+    from echr_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, 'include', 'echr_hip.h')).read()
+    declared = set(re.findall(r'\b(echr_[a-z0-9_]+)\s*\(', hdr))
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.echr_version() == 1
+
+
+def test_philox_known_answer_and_mask_rate():
+    # Random123 known-answer vectors for philox4x32-10
+    out = philox.philox4x32_10(np.array([0]), 0, 0, 0, 0, 0)
+    assert [int(x[0]) for x in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    out = philox.philox4x32_10(np.array([0xffffffff], dtype=np.uint64), 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)
+    assert [int(x[0]) for x in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    m = philox.scale_mask((64, 512), 0.5, 1, 2, philox.SITE_H1, 3)
+    assert set(np.unique(m)) == {0.0, 2.0} and abs((m > 0).mean() - 0.5) < 0.02
+    m3 = philox.scale_mask((64, 16, 64), 0.3, 1, 2, philox.SITE_TSRM, 0)
+    assert abs((m3 > 0).mean() - 0.7) < 0.02 and abs(m3.max() - 1 / 0.7) < 1e-6
+
+
+def test_static_position_helpers_match_reference_numpy():
+    from echr_amd.models.MA_attention_8_NEW import MA_Attention8
+    g = U.gold('position.npz')
+    for k in ('a', 'b'):
+        pm = MA_Attention8.extract_position_matrix(g[k + '|soi'], len(g[k + '|soi']))
+        assert np.array_equal(pm, g[k + '|pos_matrix'])
+        pe = MA_Attention8.extract_position_embedding(pm, 512)
+        assert pe.dtype == np.float64 and np.array_equal(pe.astype(np.float32), g[k + '|pos_emb_f32'])
+
+
+def test_decoder_step_count_and_clip_view():
+    from echr_amd.models.OldModel_NEW import ClipView, n_decoder_steps
+    from oracle import echr_ref_cpu as O
+    lab = np.array([[0, 5, 6, 0, 0, 0], [0, 7, 0, 0, 0, 0]])
+    assert n_decoder_steps(lab) == O.n_decoder_steps(lab) == 3
+    assert n_decoder_steps(torch.from_numpy(lab)) == 3
+    lab2 = np.array([[0, 5, 6, 1, 2, 0]])
+    assert n_decoder_steps(lab2) == O.n_decoder_steps(lab2) == 5
+    _, _, vid = synth.make_case('tiny')
+    c3d = torch.from_numpy(vid['c3d'])
+    soi = vid['soi']
+    cv = ClipView(c3d, torch.from_numpy(soi[:, 0].astype(np.int32)), torch.from_numpy((soi[:, 1] - soi[:, 0]).astype(np.int32)),
+                  int((soi[:, 1] - soi[:, 0]).max()))
+    clip, mask = cv.materialize()
+    rc, rm = O.clip_context(c3d, soi)
+    assert torch.equal(clip, rc) and torch.equal(mask, rm)
+    back = ClipView.from_padded(clip, mask)
+    assert torch.equal(back.ev_len, cv.ev_len)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'echr_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+\.*oracle', src, re.M), os.path.join(dirpath, f)
+
+
+def test_cpu_call_fails_loudly():
+    from echr_amd._lib import EchrHipError
+    opt, params, vid = synth.make_case('tiny')
+    m = echr_amd.CaptionGenerator(opt)
+    with pytest.raises(EchrHipError):
+        m(torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), torch.from_numpy(vid['labels']),
+          vid['ind'], vid['soi'], mode='train')

@@ -1,0 +1,75 @@
+"""CPU: the oracle against the fixtures the reference itself produced (tools/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from echr_amd import synth
+from oracle import echr_ref_cpu as O
+from oracle import summary as SM
+from tests import util as U
+
+
+def test_position_matrix_and_embedding():
+    g = U.gold('position.npz')
+    for k in ('a', 'b'):
+        pm = O.position_matrix(g[k + '|soi'])
+        assert np.array_equal(pm, g[k + '|pos_matrix'])
+        assert np.array_equal(O.position_embedding(pm, 512).astype(np.float32), g[k + '|pos_emb_f32'])
+        assert np.array_equal(O.position_embedding(pm, 32).astype(np.float32), g[k + '|pos_emb32_f32'])
+
+
+@pytest.mark.parametrize('train_mode', [False, True])
+def test_tiny_full_tensors(train_mode):
+    opt, params, vid = synth.make_case('tiny')
+    g = U.gold('case_tiny.npz')
+    mode = 'train' if train_mode else 'eval'
+    pred, loss, grads = U.run_oracle(opt, params, vid, train_mode)
+    assert np.abs(pred - g[mode + '|logp']).max() < 1e-6
+    assert abs(loss - float(g[mode + '|loss'])) < 1e-6
+    for k, v in grads.items():
+        if v is None:
+            assert (mode + '|grad|' + k) not in g          # the two never-used parameter groups
+        else:
+            assert U.relerr(v, g[mode + '|grad|' + k]) < 1e-5, k
+
+
+@pytest.mark.parametrize('case', ['c1', 'c2'])
+def test_config_summaries(case):
+    opt, params, vid = synth.make_case(case)
+    g = U.gold('case_%s.npz' % case)
+    pred, loss, grads = U.run_oracle(opt, params, vid, True)
+    assert abs(loss - float(g['train|loss'])) < 1e-5
+    s = SM.summarize_logp(pred)
+    assert np.abs(s['slice'] - g['train|logp|slice']).max() < 1e-5
+    assert np.array_equal(s['argmax'], g['train|logp|argmax'])
+    for key, v in SM.summarize_grads(grads).items():
+        ref = g['train|grad|' + key]
+        assert np.allclose(v, ref, rtol=1e-4, atol=1e-7 * (1 + np.abs(ref).max())), key
+
+
+@pytest.mark.parametrize('case', ['tiny', 'c1'])
+def test_greedy_sample(case):
+    opt, params, vid = synth.make_case(case)
+    g = U.gold('case_%s.npz' % case)
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        seq, lp = O.caption_forward(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), None,
+                                    vid['ind'], vid['soi'], 'eval', None, opt.n_head, opt.CG_seq_length)
+    assert np.array_equal(seq.numpy(), g['sample|seq'])
+    assert np.abs(lp.numpy() - g['sample|logp']).max() < 1e-5
+
+
+def test_adam_restatement():
+    g = U.gold('adam.npz')
+    p, m, v = g['p0'].copy(), np.zeros_like(g['p0']), np.zeros_like(g['p0'])
+    for i in range(4):
+        O.clamp_adam_step(p, g['g%d' % i].copy(), m, v, i + 1, 5e-5)
+        assert np.abs(p - g['p%d' % (i + 1)]).max() < 1e-6
+
+
+def test_proposal_selection_indices():
+    g = U.gold('proposals.npz')
+    for i in range(3):
+        ind, feat, _ = O.top_proposals(g['g%d|scores' % i], g['g%d|mask' % i], int(g['g%d|topN' % i]))
+        assert np.array_equal(np.array(ind, np.int64), g['g%d|ind' % i])
+        assert np.array_equal(np.array(feat, np.int64).reshape(-1, 2), g['g%d|feat' % i].reshape(-1, 2))
