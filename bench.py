@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- caption-decoder timesteps/sec (fwd+bwd+clamp+Adam) on N MI355X, with roofline and CPU baseline.
+
+One "step" = one training iteration of the caption hot path over one video batch:
+  CaptionGenerator.forward(mode='train') -> LanguageModelCriterion -> backward -> [all-reduce SUM] -> clip_gradient + Adam.
+Workload (BASELINE.json configs[2], "c3"): N=64 events x A=128 segments x 500-d C3D features, S=20 decoder timesteps,
+V1=5001 (the reference does not fix the vocabulary; stated here), fp32, synthetic N(0,1) features, random-init weights.
+The 64 events are laid out disjointly on a T_v = 8192 video so that all 64x128 feature rows are distinct
+(--overlap uses SURVEY 8-d's T_v = 160 one-video layout instead, where events share rows).
+metric = decoder timesteps/s = (iterations x S x n_gpus) / wall time; every rank works on its own video (weak scaling).
+
+usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--overlap] [--no-cpu] [--no-roofline]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+S_STEPS, N_EV, A_SEG, V1 = 20, 64, 128, 5001
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA peak
+
+
+def make_workload(rank, overlap):
+    from echr_amd import synth
+    opt = synth.default_opt(vocab_size=V1 - 1, seq_length=S_STEPS - 1)
+    params = synth.make_params(opt, 0)
+    vid = synth.make_video(N_EV, A_SEG, S_STEPS + 1, V1, seed=1234 + rank, full_len=True, disjoint=not overlap,
+                           T_v=None if not overlap else 160)
+    return opt, params, vid
+
+
+def gpu_leg(args, rank, world, local_rank):
+    import echr_amd
+    from echr_amd import _lib, parallel
+    from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+    from echr_amd.optim import ClampAdam
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    opt, params, vid = make_workload(rank, args.overlap)
+    model = echr_amd.CaptionGenerator(opt)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    model = model.to(dev).train()
+    crit = LanguageModelCriterion()
+    optim = ClampAdam(model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon)
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels = torch.from_numpy(vid['labels'])                       # host copy: step count needs no device sync
+    tgt = labels[:, 1:].to(dev)
+    msk = torch.from_numpy(vid['masks'])[:, 1:].to(dev)
+
+    def iteration():
+        optim.zero_grad()
+        pred = model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+        loss = crit(pred, tgt, msk)
+        loss.backward()
+        if world > 1:
+            parallel.allreduce_gradients(model)                    # SUM over ranks == reference m_batch accumulation
+        clip_gradient(optim, opt.grad_clip)
+        optim.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def say(msg):
+        if rank == 0:
+            print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+    say('model ready; warm-up')
+    for i in range(args.warmup):
+        loss = iteration()
+        torch.cuda.synchronize()
+        say('warm-up %d done' % i)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = iteration()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+    say('timed region done: %.3f s for %d steps' % (dt, args.steps))
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # second, instrumented pass over the same iterations: HIP events around every launch of each kernel class
+        lib = _lib.load()
+        lib.echr_prof_enable(1)
+        for _ in range(max(2, min(args.steps, 5))):
+            iteration()
+        torch.cuda.synchronize()
+        kinds = ['gemm_f32_mfma', 'att_fwd', 'att_bwd', 'att_post']
+        stats = {}
+        for k, name in enumerate(kinds):
+            ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+            lib.echr_prof_read(k, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n))
+            stats[name] = dict(ms=ms.value, flops=fl.value, bytes=by.value, launches=n.value)
+        lib.echr_prof_enable(0)
+        dom = max(stats, key=lambda k: stats[k]['ms'])
+        st = stats[dom]
+        if dom == 'gemm_f32_mfma':
+            ach = st['flops'] / (st['ms'] * 1e-3) / 1e12
+            roof = dict(bound='mfma', kernel=dom, achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None)
+        else:
+            ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
+            roof = dict(bound='hbm', kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(ach / HBM_PEAK_GBS, 4), traffic=None)
+        roof['avg_launch_us'] = round(1e3 * st['ms'] / max(st['launches'], 1), 2)
+        roof['launches_per_step'] = st['launches'] / max(2, min(args.steps, 5))
+        roof['classes_ms_per_step'] = {k: round(v['ms'] / max(2, min(args.steps, 5)), 3) for k, v in stats.items()}
+    return dt, final_loss, roof
+
+
+def cpu_leg(args):
+    """The oracle (a CPU port of the reference algorithm, kind='port') timed on this box's host cores on the SAME
+    workload: fwd + criterion + backward + clamp + Adam, all torch threads."""
+    from oracle import echr_ref_cpu as O
+    from echr_amd import synth
+    opt, params, vid = make_workload(0, args.overlap)
+    # host cores actually available to this process: the scheduler affinity, capped by the cgroup CPU quota when one is set
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            threads = max(1, min(threads, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    threads = min(threads, int(os.environ.get('ECHR_CPU_THREADS', '16')))     # a one-GPU box's CPU share is 16 cores
+    torch.set_num_threads(threads)
+    print('[bench] cpu baseline: %d threads (cpu_count=%s)' % (threads, os.cpu_count()), file=sys.stderr, flush=True)
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    ms = {k: torch.zeros_like(v) for k, v in P.items()}
+    vs = {k: torch.zeros_like(v) for k, v in P.items()}
+    tap, c3d, lda = (torch.from_numpy(vid[k]) for k in ('tap', 'c3d', 'lda'))
+    labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    rs = np.random.RandomState(0)
+
+    def drop(site, step, shape):
+        p = 0.3 if site == 'tsrm' else 0.5
+        return torch.from_numpy(((rs.random_sample(shape) >= p) / (1 - p)).astype(np.float32))
+
+    def iteration(step):
+        for v in P.values():
+            v.grad = None
+        pred = O.caption_forward(P, tap, c3d, lda, labels, vid['ind'], vid['soi'], 'train', drop, opt.n_head)
+        loss = O.lm_criterion(pred, labels[:, 1:], masks[:, 1:])
+        loss.backward()
+        with torch.no_grad():
+            for k, v in P.items():
+                if v.grad is not None:
+                    O.clamp_adam_step(v, v.grad, ms[k], vs[k], step, opt.lr, clip=opt.grad_clip)
+
+    print('[bench] cpu baseline: warm-up', file=sys.stderr, flush=True)
+    iteration(1)
+    print('[bench] cpu baseline: timing', file=sys.stderr, flush=True)
+    times = []
+    t_all = time.perf_counter()
+    i = 2
+    while len(times) < 5 and time.perf_counter() - t_all < 25.0:
+        t0 = time.perf_counter()
+        iteration(i)
+        times.append(time.perf_counter() - t0)
+        i += 1
+    best = min(times)
+    return dict(value=round(S_STEPS / best, 2), unit='timesteps/s', cores=threads, kind='port',
+                sample='%d fwd+bwd+Adam iterations of the same N=64 x A=128 x S=20 workload (min of %d, 1 warm-up), torch %s CPU fp32'
+                       % (len(times), len(times), torch.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--overlap', action='store_true', help='SURVEY 8-d one-video layout (T_v=160, events share rows)')
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    dt, loss, roof = gpu_leg(args, rank, world, local_rank)
+    if rank == 0:
+        value = args.steps * S_STEPS * world / dt
+        out = {
+            'metric': 'caption-decoder timesteps/sec (fwd+bwd)', 'value': round(value, 1), 'unit': 'timesteps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'c3: %d events x %d seg x 500-d C3D (%s), S=%d decoder timesteps, V1=%d, fwd+bwd+clamp+Adam, '
+                                   'one video per GPU' % (N_EV, A_SEG, 'T_v=160 overlapping' if args.overlap else 'disjoint rows, T_v=8192',
+                                                          S_STEPS, V1),
+                       'global_events': N_EV * world, 'timesteps_per_step': S_STEPS, 'parallelism': 'dp%d' % world,
+                       'final_loss': round(loss, 5)},
+        }
+        if roof is not None:
+            out['roofline'] = roof
+        if world == 1 and not args.no_cpu:
+            out['cpu_baseline'] = cpu_leg(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

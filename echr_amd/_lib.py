@@ -82,8 +82,10 @@ SYMBOLS = [
     ('echr_nll_loss_fwd', i32, [c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_sampler_ws_floats', i64, [C.POINTER(DecArgs)]),
     ('echr_decoder_sample', i32, [C.POINTER(SampleArgs), C.c_void_p]),
+    ('echr_prof_enable', i32, [i32]),
+    ('echr_prof_read', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     ('echr_clamp', i32, [c_f, i64, f32, C.c_void_p]),
-    ('echr_clamp_adam', i32, [c_f, c_f, c_f, c_f, i64, i32, f32, f32, f32, f32, f32, C.c_void_p]),
+    ('echr_clamp_adam', i32, [c_f, c_f, c_f, c_f, i64, i32, C.c_double, C.c_double, C.c_double, C.c_double, f32, C.c_void_p]),
 ]
 
 _lib = None

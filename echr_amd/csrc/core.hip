@@ -4,6 +4,7 @@
 // cross-lane shuffle reductions.
 #include <cstdarg>
 #include <cstdio>
+#include <vector>
 #include "echr_common.h"
 #include "echr_internal.h"
 
@@ -25,6 +26,41 @@ int check_launch(const char* what) {
         return -5;  // -EIO
     }
     return 0;
+}
+
+// ---- optional HIP-event profiling --------------------------------------------------------------------
+struct ProfRec { hipEvent_t e0, e1; int kind; double flops, bytes; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static double g_prof_ms[PROF_KINDS], g_prof_flops[PROF_KINDS], g_prof_bytes[PROF_KINDS];
+static long long g_prof_n[PROF_KINDS];
+
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+ProfScope::ProfScope(int k, double f, double b, hipStream_t s) : st(s), kind(k), flops(f), bytes(b) {
+    if (!g_prof_on) return;
+    e0 = prof_event(); e1 = prof_event();
+    (void)hipEventRecord(e0, st);
+}
+ProfScope::~ProfScope() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, st);
+    g_prof_recs.push_back({e0, e1, kind, flops, bytes});
+}
+static void prof_resolve() {
+    for (auto& r : g_prof_recs) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.e1);
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        g_prof_ms[r.kind] += ms; g_prof_flops[r.kind] += r.flops; g_prof_bytes[r.kind] += r.bytes; g_prof_n[r.kind] += 1;
+        g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1);
+    }
+    g_prof_recs.clear();
 }
 
 // ---- block reductions ----------------------------------------------------------------------------
@@ -272,7 +308,7 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const float* __restric
 // ---- fused clamp + Adam (misc/utils.py:107-111 + torch.optim.Adam) ------------------------------------
 __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
-                                                         float b1, float b2, float eps, float clip) {
+                                                         float omb1, float b2, float omb2, float eps, float clip) {
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -284,8 +320,8 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float gk = fminf(fmaxf(gg[k], -clip), clip);
-            mm[k] = b1 * mm[k] + (1.f - b1) * gk;
-            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+            mm[k] = mm[k] + (gk - mm[k]) * omb1;            // torch: exp_avg.lerp_(grad, 1 - beta1)
+            vv[k] = b2 * vv[k] + omb2 * gk * gk;            // torch: exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
             const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
             pp[k] -= lr_over_bc1 * (mm[k] / denom);
         }
@@ -298,8 +334,8 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
     const long i = base + (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         float gk = fminf(fmaxf(g[i], -clip), clip);
-        float mk = b1 * m[i] + (1.f - b1) * gk;
-        float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+        float mk = m[i] + (gk - m[i]) * omb1;
+        float vk = b2 * v[i] + omb2 * gk * gk;
         m[i] = mk; v[i] = vk;
         p[i] -= lr_over_bc1 * (mk / (sqrtf(vk) * inv_sqrt_bc2 + eps));
     }
@@ -343,17 +379,17 @@ extern "C" int echr_nll_loss_fwd(const float* logp, const int32_t* target, const
     return check_launch("nll_loss_fwd");
 }
 
-extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1,
-                               float beta2, float eps, float clip, void* stream) {
+extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
+                               double beta2, double eps, float clip, void* stream) {
     ECHR_REQUIRE(p && g && m && v && n > 0 && step >= 1, "clamp_adam: bad arguments");
     ECHR_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                  "clamp_adam: buffers must be 16-byte aligned");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     const long n4 = n >> 2;
     int grid = (int)min(max((n4 + 255) / 256, 1L), 4096L);
     hipLaunchKernelGGL(clamp_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, (float)(lr / bc1),
-                       (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, clip);
+                       (float)(1.0 / sqrt(bc2)), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, clip);
     return check_launch("clamp_adam");
 }
 
@@ -362,4 +398,17 @@ extern "C" int echr_clamp(float* g, int64_t n, float clip, void* stream) {
     int grid = (int)min(((long)n + 255) / 256, 4096L);
     hipLaunchKernelGGL(clamp_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, (long)n, clip);
     return check_launch("clamp");
+}
+
+extern "C" int echr_prof_enable(int on) {
+    prof_resolve();
+    g_prof_on = on != 0;
+    if (on) for (int k = 0; k < PROF_KINDS; ++k) { g_prof_ms[k] = g_prof_flops[k] = g_prof_bytes[k] = 0.0; g_prof_n[k] = 0; }
+    return 0;
+}
+extern "C" int echr_prof_read(int kind, double* ms, double* flops, double* bytes, int64_t* launches) {
+    ECHR_REQUIRE(kind >= 0 && kind < PROF_KINDS && ms && flops && bytes && launches, "prof_read: bad arguments");
+    prof_resolve();
+    *ms = g_prof_ms[kind]; *flops = g_prof_flops[kind]; *bytes = g_prof_bytes[kind]; *launches = g_prof_n[kind];
+    return 0;
 }

@@ -463,12 +463,17 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
     float* sc = w.SC + (long)t * N * A;
     float* wt = w.WT + (long)t * N * A;
     float* att = w.ATT + (long)t * N * D;
+    {
+    // algorithmic bytes of one attention step: p_att rows + clip rows + scores/weights/context
+    const double rows = (double)N * A;
+    ProfScope prof(PROF_ATT_FWD, 2.0 * rows * (Ha + D) , 4.0 * (rows * (Ha + D + 2) + (double)N * (Ha + D)), st);
     hipLaunchKernelGGL(att_score_kernel, dim3(N, (A + 31) / 32), dim3(256), 2 * Ha * sizeof(float), st, w.PALL, q, a->w_alpha,
                        a->b_alpha, a->ev_start, a->ev_len, sc, A, Ha);
     RC(check_launch("att_score"));
     hipLaunchKernelGGL(att_context_kernel, dim3(N, (D + 127) / 128), dim3(256), (((A + 3) & ~3) + 8 * 128) * sizeof(float), st, a->c3d, sc,
                        a->ev_start, a->ev_len, wt, att, A, D);
     RC(check_launch("att_context"));
+    }
     // recurrent halves: GATES_k[t] += h_k_prev . W_hh_k^T ; stream 1 also += att . W_ih1[:,E:]^T
     LstmPtrs P;
     for (int k = 0; k < 3; ++k) {
@@ -590,9 +595,11 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         RC(gemm(d, st));
         float* dq = b.DQ + (long)t * N * Ha;
         const int D4 = (D + 3) & ~3;
+        ProfScope* prof = new ProfScope(PROF_ATT_BWD, 4.0 * N * A * (Ha + D), 4.0 * ((double)N * A * (Ha + D + 2) + (double)N * (2 * Ha + 2 * D)), st);
         hipLaunchKernelGGL(att_bwd_kernel, dim3(N, (A + 31) / 32), dim3(256), (6 * Ha + D4) * sizeof(float), st, w.PALL, a->c3d,
                            w.QS + (long)t * N * Ha, a->w_alpha, w.WT + (long)t * N * A, w.ATT + (long)t * N * D, datt,
                            a->ev_start, a->ev_len, b.DSC + (long)t * N * A, dq, A, Ha, D);
+        delete prof;
         RC(check_launch("att_bwd"));
         if (t > 0) {
             d = desc_nn(dq, Ha, a->w_h2a, H, dhr + H, 3 * H, N, H, Ha);
@@ -605,8 +612,11 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     RC(fill_zero(b.DPALL, (long)a->Tv * Ha, st));
     RC(fill_zero(g->g_w_alpha, Ha, st));
     RC(fill_zero(g->g_b_alpha, 1, st));
+    {
+    ProfScope prof(PROF_ATT_POST, 6.0 * N * A * Ha * S, 4.0 * ((double)N * A * Ha * 2 + (double)S * N * (Ha + A)), st);
     hipLaunchKernelGGL(att_post_kernel, dim3(N, (A + 31) / 32), dim3(256), (TT * Ha + Ha + TT * 32 + 4 * Ha) * sizeof(float), st,
                        w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, g->g_w_alpha, g->g_b_alpha, S, N, A, Ha);
+    }
     RC(check_launch("att_post"));
     d = desc_tn(b.DPALL, Ha, a->c3d, D, g->g_w_c2a, D, Ha, D, a->Tv);
     d.split_k = -1;

@@ -5,6 +5,17 @@
 
 namespace echr {
 
+// Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
+// Disabled by default: ProfScope is then a no-op.  Events are resolved in echr_prof_read after a stream sync.
+enum ProfKind { PROF_GEMM = 0, PROF_ATT_FWD = 1, PROF_ATT_BWD = 2, PROF_ATT_POST = 3, PROF_LSTM = 4, PROF_OTHER = 5, PROF_KINDS = 6 };
+struct ProfScope {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st;
+    ProfScope(int kind, double flops, double bytes, hipStream_t st);
+    ~ProfScope();
+    int kind; double flops, bytes;
+};
+
 int gemm(const echr_gemm_desc& d, hipStream_t st);
 
 // C[M,N] = A[M,K] . W[N,K]^T  (nn.Linear forward; row-major operands with leading dimensions)

@@ -281,6 +281,8 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
         if (split == 1) p.beta = d.beta;
     } else if (accumulate && split == 1) p.beta = 1.f;
     dim3 grid(p.tiles_m * p.tiles_n, 1, d.batch * split);
+    // algorithmic work of this launch: 2MNK flops; one read of A and B, one write of C
+    ProfScope prof(PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch, st);
     if (BMs == 128) launch_cfg<128, 128, 64, 64>(p, akc, bkc, grid, st);
     else launch_cfg<64, 64, 32, 32>(p, akc, bkc, grid, st);
     return check_launch("gemm_f32");

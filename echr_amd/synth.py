@@ -93,20 +93,25 @@ def make_params(opt, seed=0):
     return out
 
 
-def make_video(N, A, L, V1, seed=1234, T_v=None, full_len=False, min_len=4, video_dim=500, hidden_dim=512, lda_dim=100):
+def make_video(N, A, L, V1, seed=1234, T_v=None, full_len=False, min_len=4, video_dim=500, hidden_dim=512, lda_dim=100, disjoint=False):
     """One synthetic video: features, N events (half-open [s,e) segment intervals), captions.
 
     full_len=True makes every event exactly A segments long (the dense N x A x D case BASELINE
     quotes); otherwise lengths are uniform in [min_len, A] with at least one event of length A
     (SURVEY 8-d config 2).  Captions: column 0 = BOS (0), tokens in [1, V1), zero padded; at least
-    one caption uses all L-2 token slots so the decoder runs the full L-1 steps.  The mask follows
+    one caption uses all L-2 token slots so the decoder runs the full L-1 steps.  disjoint=True lays the events out
+    back to back on a T_v = N*A video (every event owns its own A feature rows: the dense [N x A x D] block).  The mask follows
     dataloader.py:437-439 (`nonzeros + 2` ones)."""
     rs = np.random.RandomState(seed)
+    if disjoint:                      # N non-overlapping events of A segments: N*A distinct feature rows
+        full_len, T_v = True, N * A
     if T_v is None:
         T_v = A + max(8, A // 4)
     lens = np.full(N, A, dtype=np.int64) if full_len else rs.randint(min(min_len, A), A + 1, size=N)
     lens[rs.randint(0, N)] = A
     starts = np.array([rs.randint(0, T_v - l + 1) for l in lens], dtype=np.int64)
+    if disjoint:
+        starts = np.arange(N, dtype=np.int64) * A
     soi = np.stack([starts, starts + lens], axis=1)
     ind = soi[:, 1] - 1                                   # proposal anchored at its last segment
     c3d = rs.standard_normal((T_v, video_dim)).astype(np.float32)

@@ -204,10 +204,21 @@ int echr_decoder_sample(const echr_sample_args* a, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Fused element-wise clamp(+-clip) + Adam (betas, eps, no weight decay, no amsgrad) over a flat
  * buffer.  Replaces misc/utils.py:107-111 + torch.optim.Adam.step as wired at train.py:209,315-317.
- * `step` is the 1-based step count.  `skip_nonfinite`=0 keeps torch semantics.
+ * `step` is the 1-based step count; lr/betas/eps are doubles because torch derives 1-beta and the bias corrections
+ * from the Python doubles (1 - 0.999f != 0.001).
  * ---------------------------------------------------------------------------------------------- */
-int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr, float beta1,
-                    float beta2, float eps, float clip, void* stream);
+int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
+                    double beta2, double eps, float clip, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optional per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
+ * class) for bench.py's roofline leg.  kind: 0 fp32 MFMA GEMM, 1 attention fwd, 2 attention bwd,
+ * 3 attention post-pass, 4 LSTM gate math, 5 other.  echr_prof_read synchronises the recorded events and
+ * returns the totals since echr_prof_enable(1): elapsed ms, algorithmic flops / bytes, launches.
+ * Not thread-safe; never enabled on the product path.
+ * ---------------------------------------------------------------------------------------------- */
+int echr_prof_enable(int on);
+int echr_prof_read(int kind, double* ms, double* flops, double* bytes, int64_t* launches);
 
 /* stand-alone element-wise clamp (misc/utils.py:107-111) for optimisers other than the fused one */
 int echr_clamp(float* g, int64_t n, float clip, void* stream);

@@ -49,7 +49,10 @@ def test_position_embedding_matches_reference_numpy():
         for d, key in ((512, '|pos_emb_f32'), (32, '|pos_emb32_f32')):
             pos = EF.position_embedding(st, ln, d).cpu().numpy()
             err = np.abs(pos - g[k + key]).max()
-            assert err < 2e-6, (k, d, err)      # float64 math on device; log(l_j/l_i) in float32 like the reference
+            # float64 math on device.  log(l_j/l_i) is float32 in the reference (numpy's SIMD logf, <= 1 ulp); the device
+            # rounds the float64 log to float32 (correctly rounded), so the two can differ by one float32 ulp of a value
+            # <= ~5, i.e. <= 4.8e-7 * 100 in the sin/cos argument.
+            assert err < 5e-5, (k, d, err)
 
 
 def test_event_pool_gather():
@@ -107,7 +110,7 @@ def test_full_path_vs_oracle(case, train_mode):
         if g is None:
             assert grads[k] is None, k
         else:
-            assert U.relerr(grads[k], g) < TOL_GRAD, (k, U.relerr(grads[k], g))
+            assert U.relerr(grads[k], g, U.GRAD_FLOOR) < TOL_GRAD, (k, U.relerr(grads[k], g))
 
 
 @pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full'])
@@ -126,7 +129,7 @@ def test_full_path_vs_reference_golden(case, train_mode):
             if v is None:
                 assert key not in g
             else:
-                assert U.relerr(v, g[key]) < TOL_GRAD, (k, U.relerr(v, g[key]))
+                assert U.relerr(v, g[key], U.GRAD_FLOOR) < TOL_GRAD, (k, U.relerr(v, g[key]))
         return
     s = SM.summarize_logp(pred)
     assert np.abs(s['slice'] - g[mode + '|logp|slice']).max() < TOL_LOGP
@@ -138,9 +141,9 @@ def test_full_path_vs_reference_golden(case, train_mode):
     for key, v in gs.items():
         ref = g[mode + '|grad|' + key]
         name = key.split('|')[0]
-        scale = float(g[mode + '|grad|' + name + '|linf']) + 1e-30
+        scale = max(float(g[mode + '|grad|' + name + '|linf']), U.GRAD_FLOOR)
         if key.endswith('|l2') or key.endswith('|linf'):
-            assert abs(float(v) - float(ref)) < TOL_GRAD * max(abs(float(ref)), 1e-30), (key, float(v), float(ref))
+            assert abs(float(v) - float(ref)) < TOL_GRAD * max(abs(float(ref)), U.GRAD_FLOOR), (key, float(v), float(ref))
         else:
             assert np.abs(v - ref).max() < TOL_GRAD * scale, (key, np.abs(v - ref).max() / scale)
 
