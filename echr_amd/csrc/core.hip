@@ -111,24 +111,31 @@ int fill_zero(float* p, long n, hipStream_t st) {
     return check_launch("fill_zero");
 }
 
-// one lane per column (coalesced 256 B per wave-row), 4 waves stride the rows, LDS combine
+// one lane per column (coalesced 256 B per wave-row), 4 waves stride the rows of one 256-row chunk, LDS combine;
+// several row chunks (grid.y) add their partial sums atomically into the zero-initialised output.
+constexpr int CS_ROWS = 256;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, int rows, int cols,
-                                                     float* __restrict__ out, int accumulate) {
+                                                     float* __restrict__ out, int mode) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
     float s = 0.f;
     if (col < cols)
-        for (int r = wave; r < rows; r += 4) s += X[(long)r * ld + col];
+        for (int r = r0 + wave; r < r1; r += 4) s += X[(long)r * ld + col];
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && col < cols) {
-        float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-        out[col] = accumulate ? out[col] + t : t;
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (mode == 0) out[col] = t;            // single chunk, overwrite
+        else atomicAdd(&out[col], t);           // accumulate / multi-chunk
     }
 }
 int colsum(const float* X, long ld, int rows, int cols, float* out, bool accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, X, ld, rows, cols, out, accumulate ? 1 : 0);
+    const int chunks = (rows + CS_ROWS - 1) / CS_ROWS;
+    int mode = (accumulate || chunks > 1) ? 1 : 0;
+    if (!accumulate && chunks > 1) { int rc = fill_zero(out, cols, st); if (rc) return rc; }
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, st, X, ld, rows, cols, out, mode);
     return check_launch("colsum");
 }
 
@@ -236,19 +243,42 @@ __global__ __launch_bounds__(256) void nll_loss_kernel(const float* __restrict__
 }
 
 // ---- event pooling + anchor gather (CaptionGenerator.py:111-114,121,128) -----------------------------
-__global__ void event_pool_gather_kernel(const float* __restrict__ c3d, const float* __restrict__ tap, const int* __restrict__ ev_start,
-                                         const int* __restrict__ ev_len, const int* __restrict__ ind, float* __restrict__ ech,
-                                         int D, int Ht) {
+__global__ __launch_bounds__(256) void event_pool_gather_kernel(const float* __restrict__ c3d, const float* __restrict__ tap,
+                                                                const int* __restrict__ ev_start, const int* __restrict__ ev_len,
+                                                                const int* __restrict__ ind, float* __restrict__ ech, int D, int Ht, int vec) {
+    extern __shared__ __attribute__((aligned(16))) float red[];            // [groups][D]
     const int n = blockIdx.x;
     const int s = ev_start[n], len = ev_len[n];
     float* o = ech + (long)n * (D + Ht);
-    for (int j = threadIdx.x; j < D; j += blockDim.x) {
-        float acc = 0.f;
-        for (int a = 0; a < len; ++a) acc += c3d[(long)(s + a) * D + j];
-        o[j] = acc / (float)len;
+    const int C4 = D >> 2;
+    if (vec && C4 <= 256) {
+        // float4 lanes across the feature axis (coalesced rows), row groups across the remaining threads, LDS combine
+        const int groups = 256 / C4;
+        const int c = threadIdx.x % C4, rg = threadIdx.x / C4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rg < groups) {
+            for (int a = rg; a < len; a += groups) {
+                const float4 v = *reinterpret_cast<const float4*>(c3d + (long)(s + a) * D + 4 * c);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            *reinterpret_cast<float4*>(red + (long)rg * D + 4 * c) = acc;
+        }
+        __syncthreads();
+        const float inv = 1.0f / (float)len;
+        for (int j = threadIdx.x; j < D; j += 256) {
+            float t = 0.f;
+            for (int g = 0; g < groups; ++g) t += red[(long)g * D + j];
+            o[j] = t * inv;
+        }
+    } else {
+        for (int j = threadIdx.x; j < D; j += 256) {
+            float acc = 0.f;
+            for (int a = 0; a < len; ++a) acc += c3d[(long)(s + a) * D + j];
+            o[j] = acc / (float)len;
+        }
     }
     const long trow = ind[n];
-    for (int j = threadIdx.x; j < Ht; j += blockDim.x) o[D + j] = tap[trow * Ht + j];
+    for (int j = threadIdx.x; j < Ht; j += 256) o[D + j] = tap[trow * Ht + j];
 }
 __global__ void event_gather_bwd_kernel(const float* __restrict__ d_ech, const int* __restrict__ ind, float* __restrict__ d_tap,
                                         int D, int Ht) {
@@ -362,7 +392,10 @@ extern "C" const char* echr_last_error(void) { return g_err; }
 extern "C" int echr_event_pool_gather_fwd(const float* c3d, const float* tap, const int32_t* ev_start, const int32_t* ev_len,
                                           const int32_t* ind, float* ech, int32_t N, int32_t D, int32_t Ht, void* stream) {
     ECHR_REQUIRE(c3d && tap && ev_start && ev_len && ind && ech && N > 0 && D > 0 && Ht > 0, "event_pool_gather_fwd: bad arguments");
-    hipLaunchKernelGGL(event_pool_gather_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, c3d, tap, ev_start, ev_len, ind, ech, D, Ht);
+    const int vec = (D % 4 == 0) && ((uintptr_t)c3d % 16 == 0) && D >= 4;
+    const int groups = vec && D / 4 <= 256 ? 256 / (D / 4) : 1;
+    hipLaunchKernelGGL(event_pool_gather_kernel, dim3(N), dim3(256), (size_t)groups * D * sizeof(float), (hipStream_t)stream, c3d, tap,
+                       ev_start, ev_len, ind, ech, D, Ht, vec);
     return check_launch("event_pool_gather_fwd");
 }
 extern "C" int echr_event_pool_gather_bwd(const float* d_ech, const int32_t* ind, float* d_tap, int32_t N, int32_t D, int32_t Ht,

@@ -42,7 +42,8 @@ DropCfg make_drop(const echr_dropout* d, float p) {
 // score kernel: grid (N, ceil(A/32)); a workgroup scores 32 slots of one event, one wave per 8 slots, lanes
 // across the Ha axis (float4), wave-shuffle reduction.  q[n,:] and alpha live in LDS.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict__ PALL, const float* __restrict__ Q,
+__global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict__ PALL, const float* __restrict__ QSL, int nslab,
+                                                        long slab_stride, const float* __restrict__ b_q, float* __restrict__ QS,
                                                         const float* __restrict__ alpha, const float* __restrict__ b_alpha,
                                                         const int* __restrict__ ev_start, const int* __restrict__ ev_len,
                                                         float* __restrict__ SC, int A, int Ha) {
@@ -52,7 +53,13 @@ __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict_
     const int n = blockIdx.x, a0 = blockIdx.y * 32;
     const int len = ev_len[n];
     if (a0 >= len) return;
-    for (int j = threadIdx.x; j < Ha; j += 256) { sq[j] = Q[(long)n * Ha + j]; sa[j] = alpha[j]; }
+    // q[n,:] = b_h2a + sum of the split-K partial slabs of h1_prev . W_h^T (rec_gemm); kept in QS for backward
+    for (int j = threadIdx.x; j < Ha; j += 256) {
+        float q = b_q[j];
+        for (int s = 0; s < nslab; ++s) q += QSL[s * slab_stride + (long)n * Ha + j];
+        sq[j] = q; sa[j] = alpha[j];
+        if (blockIdx.y == 0) QS[(long)n * Ha + j] = q;
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long row0 = ev_start[n];
@@ -140,7 +147,8 @@ constexpr int MAXR = 4;   // Ha <= 256 * MAXR
 __global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ PALL, const float* __restrict__ C3D,
                                                       const float* __restrict__ Q, const float* __restrict__ alpha,
                                                       const float* __restrict__ WT, const float* __restrict__ ATT,
-                                                      const float* __restrict__ DATT, const int* __restrict__ ev_start,
+                                                      const float* __restrict__ DAS, int nslab, long slab_stride,
+                                                      const int* __restrict__ ev_start,
                                                       const int* __restrict__ ev_len, float* __restrict__ DSC,
                                                       float* __restrict__ DQ, int A, int Ha, int D) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -157,7 +165,9 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ 
     float s0 = 0.f;
     for (int j = threadIdx.x; j < Ha; j += 256) { sq[j] = Q[(long)n * Ha + j]; sa[j] = alpha[j]; }
     for (int j = threadIdx.x; j < D4; j += 256) {
-        const float dv = j < D ? DATT[(long)n * D + j] : 0.f;
+        float dv = 0.f;
+        if (j < D)
+            for (int s = 0; s < nslab; ++s) dv += DAS[s * slab_stride + (long)n * D + j];
         sd[j] = dv;
         if (j < D) s0 += dv * ATT[(long)n * D + j];
     }
@@ -307,13 +317,126 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Grouped skinny NT GEMM for the recurrence: P[ks] = A[M, kslice] . B[Nout, kslice]^T, M = events (<= a few
+// hundred), several independent problems ("jobs") per launch, K split over workgroups.  Partial sums go to
+// per-slice slabs that the CONSUMER kernel adds up (LSTM gate math / attention) -- no atomics, no extra
+// reduction launch, bitwise reproducible.
+//   grid (ceil(Nout/64), ksplit, jobs * ceil(M/64)); 256 threads = 2x2 waves of 32x32 MFMA tiles.
+//   A and B k-slices are staged once into LDS with full-row coalesced float4 loads ([64][128+4] floats each,
+//   conflict-free ds_read_b128 fragment reads); 2 workgroups per CU overlap one's loads with the other's MFMAs.
+//   Lane l feeds MFMA j of an 8-wide k chunk with element j of its float4 (k = 8c + 4(l>>5) + j): A and B use
+//   the same k pairing, so the products are exact fp32 sums over the slice.
+// ------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int RK = 128;              // k-slice staged per workgroup
+constexpr int RLD = RK + 4;          // LDS row stride (floats): 16-byte aligned rows, conflict-free b128 reads
+constexpr int MAXJOBS = 8;
+
+struct RecJob {
+    const float* A; long lda; int K;
+    const float* B; long ldb; int Nout;
+    float* P; long slab_stride; long ldp;
+};
+struct RecArgs { RecJob job[MAXJOBS]; int njobs; int M; };
+
+__global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
+    __shared__ __attribute__((aligned(16))) float As[64 * RLD];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * RLD];
+    const int jz = blockIdx.z % args.njobs, rb = blockIdx.z / args.njobs;
+    const RecJob J = args.job[jz];
+    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * RK, m0 = rb * 64;
+    if (n0 >= J.Nout || k0 >= J.K) return;
+    const int k1 = min(J.K, k0 + RK);
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int f = tid + p * 256;
+        const int row = f >> 5, kq = (f & 31) * 4;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        if (k0 + kq < k1) {
+            if (m0 + row < args.M) va = *reinterpret_cast<const float4*>(J.A + (long)(m0 + row) * J.lda + k0 + kq);
+            if (n0 + row < J.Nout) vb = *reinterpret_cast<const float4*>(J.B + (long)(n0 + row) * J.ldb + k0 + kq);
+        }
+        *reinterpret_cast<float4*>(&As[row * RLD + kq]) = va;
+        *reinterpret_cast<float4*>(&Bs[row * RLD + kq]) = vb;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunk = (k1 - k0 + 7) >> 3;
+    const float* ap = &As[(wm + l31) * RLD + 4 * h];
+    const float* bp = &Bs[(wn + l31) * RLD + 4 * h];
+#pragma unroll 4
+    for (int c = 0; c < nchunk; ++c) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * c);
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * c);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+    float* P = J.P + (long)blockIdx.y * J.slab_stride;
+    const int col = n0 + wn + l31;
+    if (col < J.Nout) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < args.M) P[(long)row * J.ldp + col] = acc[r];
+        }
+    }
+}
+
+static inline int ksplit_of(int K) { return (K + RK - 1) / RK; }
+
+static int rec_gemm(const RecArgs& a, hipStream_t st) {
+    int maxn = 0, maxk = 0;
+    double fl = 0, by = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        const RecJob& J = a.job[j];
+        ECHR_REQUIRE(J.K % 4 == 0 && J.lda % 4 == 0 && J.ldb % 4 == 0 && ((uintptr_t)J.A % 16 == 0) && ((uintptr_t)J.B % 16 == 0),
+                     "rec_gemm: operands must be 16-byte aligned with K, lda, ldb multiples of 4 (job %d)", j);
+        maxn = max(maxn, (J.Nout + 63) / 64);
+        maxk = max(maxk, ksplit_of(J.K));
+        fl += 2.0 * a.M * J.Nout * J.K;
+        by += 4.0 * ((double)a.M * J.K + (double)J.Nout * J.K + (double)a.M * J.Nout * ksplit_of(J.K));
+    }
+    ProfScope prof(PROF_LSTM, fl, by, st);
+    hipLaunchKernelGGL(rec_gemm_kernel, dim3(maxn, maxk, a.njobs * ((a.M + 63) / 64)), dim3(256), 0, st, a);
+    return check_launch("rec_gemm");
+}
+
+// 32x32 LDS-tiled transpose: out[c, r] = in[r, c]  (weights for the backward recurrence, once per backward)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long ld_in, float* __restrict__ out, long ld_out,
+                                                        int rows, int cols) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) t[i][tx] = in[(long)(r0 + i) * ld_in + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
+}
+static int transpose(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, ld_in, out, ld_out, rows, cols);
+    return check_launch("transpose");
+}
+
+// ------------------------------------------------------------------------------------------------------
 // LSTM cell gate math for the three streams of one timestep (nn.LSTMCell order i,f,g,o).
-// GATES holds the complete pre-activations on entry and the activations on exit (saved for backward).
-// h is dropped once for the recurrence/state (OldModel_NEW.py:810,814,818) and once more for the
-// late-fusion input (:136).
+// Pre-activation = input-side part (GATES, batched GEMM before the recurrence) + the recurrent split-K slabs.
+// GATES is overwritten with the activations (saved for backward).  h is dropped once for the recurrence/state
+// (OldModel_NEW.py:810,814,818) and once more for the late-fusion input (:136).
 // ------------------------------------------------------------------------------------------------------
 struct LstmPtrs {
-    float* gates[3];      // [N,4H] slice of timestep t
+    float* gates[3];          // [N,4H] slice of timestep t
+    const float* slab[3];     // recurrent partial sums: slab[k] + s*slab_stride, s < nslab[k]
+    int nslab[3];
+    long slab_stride;
     const float* c_prev[3];
     float* c_new[3];
 };
@@ -325,10 +448,13 @@ __global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(LstmPtrs P, flo
     const int k = blockIdx.y;
     const int n = idx / H, j = idx % H;
     float* g = P.gates[k] + (long)n * 4 * H;
-    const float gi = fast_sigmoid(g[j]);
-    const float gf = fast_sigmoid(g[H + j]);
-    const float gg = tanhf(g[2 * H + j]);
-    const float go = fast_sigmoid(g[3 * H + j]);
+    float pi = g[j], pf = g[H + j], pg = g[2 * H + j], po = g[3 * H + j];
+    const float* sl = P.slab[k] + (long)n * 4 * H;
+    for (int s = 0; s < P.nslab[k]; ++s) {
+        const float* q = sl + s * P.slab_stride;
+        pi += q[j]; pf += q[H + j]; pg += q[2 * H + j]; po += q[3 * H + j];
+    }
+    const float gi = fast_sigmoid(pi), gf = fast_sigmoid(pf), gg = tanhf(pg), go = fast_sigmoid(po);
     const float c = gf * P.c_prev[k][idx] + gi * gg;
     g[j] = gi; g[H + j] = gf; g[2 * H + j] = gg; g[3 * H + j] = go;
     P.c_new[k][idx] = c;
@@ -339,22 +465,25 @@ __global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(LstmPtrs P, flo
 }
 
 struct LstmBwdPtrs {
-    const float* gates[3];   // activations of timestep t
+    const float* gates[3];    // activations of timestep t
     const float* c_prev[3];
     const float* c_new[3];
-    float* dgates[3];        // [N,4H] slice of timestep t
+    float* dgates[3];         // [N,4H] slice of timestep t
+    const float* dh_slab[3];  // partial sums of d h(t) from step t+1: [N,H] slabs
+    int nslab[3];
+    long slab_stride;
 };
 
-// dh = dOUTD * m_out + dHREC (recurrent part from step t+1);  dC carries c-gradients between steps.
-__global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdPtrs P, const float* __restrict__ doutd,
-                                                                 const float* __restrict__ dhrec, float* __restrict__ dc,
+// dh = dOUTD * m_out + sum of the recurrent slabs written while processing step t+1;  dC carries c-gradients.
+__global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdPtrs P, const float* __restrict__ doutd, float* __restrict__ dc,
                                                                  int N, int H, int t, DropCfg dh, DropCfg dout) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= N * H) return;
     const int k = blockIdx.y;
     const int n = idx / H, j = idx % H;
     const long o = (long)n * 3 * H + k * H + j;
-    float dhv = doutd[o] * drop_mult(dout, (unsigned)o, (unsigned)t, SITE_OUT) + (dhrec ? dhrec[o] : 0.f);
+    float dhv = doutd[o] * drop_mult(dout, (unsigned)o, (unsigned)t, SITE_OUT);
+    for (int s = 0; s < P.nslab[k]; ++s) dhv += P.dh_slab[k][s * P.slab_stride + idx];
     dhv *= drop_mult(dh, (unsigned)idx, (unsigned)t, (unsigned)(SITE_H0 + k));
     const float* g = P.gates[k] + (long)n * 4 * H;
     const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
@@ -375,6 +504,8 @@ static inline long rup(long x, long a) { return (x + a - 1) / a * a; }
 
 struct DecWs {
     float *XT, *GATES[3], *CS[3], *HS, *OUTD, *PALL, *QS, *SC, *WT, *ATT, *EVB0, *VIDB;
+    float *QSL, *GSL[3];         // split-K slabs of the current timestep (q and the three gate blocks)
+    int nq, ng[3];
     long total;
 };
 static DecWs carve_ws(const echr_dec_args* a, float* base) {
@@ -394,12 +525,20 @@ static DecWs carve_ws(const echr_dec_args* a, float* base) {
     w.ATT = take(S * N * a->D);
     w.EVB0 = take(N * 4 * H);
     w.VIDB = take(4 * H);
+    w.nq = ksplit_of(a->H);
+    w.QSL = take((long)w.nq * N * a->Ha);
+    w.ng[0] = w.ng[2] = ksplit_of(a->H);
+    w.ng[1] = ksplit_of(a->H) + ksplit_of(a->D);
+    for (int k = 0; k < 3; ++k) w.GSL[k] = take((long)w.ng[k] * N * 4 * H);
     w.total = off;
     return w;
 }
 
 struct DecWsBwd {
-    float *DLG, *DOUT, *DG[3], *DHREC, *DC, *DATT, *DSC, *DQ, *DPALL, *DGSUM[3], *DGCOL[3], *DXT, *MSUM;
+    float *DLG, *DOUT, *DG[3], *DC, *DSC, *DQ, *DPALL, *DGSUM[3], *DGCOL[3], *DXT, *MSUM;
+    float *WT_HH[3], *WT_ATT, *WT_H2A;      // transposed weights: the backward recurrence runs as NT products too
+    float *DHSL[3], *DASL;                   // split-K slabs: d h(t-1) per stream, d ATT
+    int ndh[3], nda;
     long ldg, total;
 };
 static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
@@ -411,9 +550,7 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     w.DLG = take(S * N * w.ldg);
     w.DOUT = take(S * N * 3 * H);
     for (int k = 0; k < 3; ++k) w.DG[k] = take(S * N * 4 * H);
-    w.DHREC = take(S * N * 3 * H);
     w.DC = take(N * 3 * H);
-    w.DATT = take(S * N * a->D);
     w.DSC = take(S * N * a->A);
     w.DQ = take(S * N * a->Ha);
     w.DPALL = take((long)a->Tv * a->Ha);
@@ -421,6 +558,14 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     for (int k = 0; k < 3; ++k) w.DGCOL[k] = take(4 * H);
     w.DXT = take(S * N * a->E);
     w.MSUM = take(64);
+    for (int k = 0; k < 3; ++k) w.WT_HH[k] = take(H * 4 * H);
+    w.WT_ATT = take((long)a->D * 4 * H);
+    w.WT_H2A = take(H * (long)a->Ha);
+    w.ndh[0] = w.ndh[2] = ksplit_of(4 * a->H);
+    w.ndh[1] = ksplit_of(4 * a->H) + ksplit_of(a->Ha);
+    w.nda = ksplit_of(4 * a->H);
+    for (int k = 0; k < 3; ++k) w.DHSL[k] = take((long)w.ndh[k] * N * H);
+    w.DASL = take((long)w.nda * N * a->D);
     w.total = off;
     return w;
 }
@@ -430,10 +575,16 @@ static int check_dims(const echr_dec_args* a, const char* who) {
     ECHR_REQUIRE(a->N > 0 && a->A > 0 && a->Tv > 0 && a->S >= 0, "%s: bad N/A/Tv/S", who);
     ECHR_REQUIRE(a->D % 4 == 0 && a->Ha % 4 == 0 && a->Ha <= 256 * MAXR, "%s: need D%%4==0, Ha%%4==0, Ha<=%d (D=%d Ha=%d)", who, 256 * MAXR, a->D, a->Ha);
     ECHR_REQUIRE(a->H > 0 && a->E > 0 && a->De > 0 && a->Dv > 0 && a->V1 > 1, "%s: bad widths", who);
+    ECHR_REQUIRE(a->H % 4 == 0 && a->E % 4 == 0, "%s: need H%%4==0 and E%%4==0 (H=%d E=%d)", who, a->H, a->E);
     return 0;
 }
 
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+static RecJob mkjob(const float* A, long lda, int K, const float* B, long ldb, int Nout, float* P, long slab_stride, long ldp) {
+    RecJob j; j.A = A; j.lda = lda; j.K = K; j.B = B; j.ldb = ldb; j.Nout = Nout; j.P = P; j.slab_stride = slab_stride; j.ldp = ldp;
+    return j;
+}
 
 // P_all = c3d . W_c^T + b_c over the Tv video rows; EVB0 = event . W_ih0[:,E:]^T + b_ih0 + b_hh0;
 // VIDB = W_ih2[:,E:] . video + b_ih2 + b_hh2   (all time-invariant)
@@ -452,14 +603,21 @@ static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t
 }
 
 // one decoder timestep given the input-side gate pre-activations already in GATES[k][t]
+//   launch 1: q and the three W_hh . h(t-1) products (all depend only on h(t-1))      -> slabs
+//   launch 2,3: attention scores, softmax + context
+//   launch 4: attended-context columns of stream 1's W_ih                              -> slabs
+//   launch 5: gate math for the three streams (adds the slabs)
 static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg& dh, const DropCfg& dout, hipStream_t st) {
     const int N = a->N, H = a->H, Ha = a->Ha, A = a->A, D = a->D, E = a->E;
     const float* hprev = w.HS + (long)t * N * 3 * H;          // [N,3H] dropped h of step t-1 (zeros at t=0)
+    const long gs = (long)N * 4 * H, qs = (long)N * Ha;
+    const int nh = ksplit_of(H);
+    RecArgs ra;
+    ra.M = N; ra.njobs = 4;
+    ra.job[0] = mkjob(hprev + H, 3 * H, H, a->w_h2a, H, Ha, w.QSL, qs, Ha);
+    for (int k = 0; k < 3; ++k) ra.job[1 + k] = mkjob(hprev + k * H, 3 * H, H, a->w_hh[k], H, 4 * H, w.GSL[k], gs, 4 * H);
+    RC(rec_gemm(ra, st));
     float* q = w.QS + (long)t * N * Ha;
-    // q = h1_prev . W_h^T + b_h
-    echr_gemm_desc d = desc_nt(hprev + H, 3 * H, a->w_h2a, H, q, Ha, N, Ha, H);
-    d.bias = a->b_h2a; d.split_k = -1;
-    RC(gemm(d, st));
     float* sc = w.SC + (long)t * N * A;
     float* wt = w.WT + (long)t * N * A;
     float* att = w.ATT + (long)t * N * D;
@@ -467,29 +625,25 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
     // algorithmic bytes of one attention step: p_att rows + clip rows + scores/weights/context
     const double rows = (double)N * A;
     ProfScope prof(PROF_ATT_FWD, 2.0 * rows * (Ha + D) , 4.0 * (rows * (Ha + D + 2) + (double)N * (Ha + D)), st);
-    hipLaunchKernelGGL(att_score_kernel, dim3(N, (A + 31) / 32), dim3(256), 2 * Ha * sizeof(float), st, w.PALL, q, a->w_alpha,
-                       a->b_alpha, a->ev_start, a->ev_len, sc, A, Ha);
+    hipLaunchKernelGGL(att_score_kernel, dim3(N, (A + 31) / 32), dim3(256), 2 * Ha * sizeof(float), st, w.PALL, w.QSL, w.nq, qs,
+                       a->b_h2a, q, a->w_alpha, a->b_alpha, a->ev_start, a->ev_len, sc, A, Ha);
     RC(check_launch("att_score"));
     hipLaunchKernelGGL(att_context_kernel, dim3(N, (D + 127) / 128), dim3(256), (((A + 3) & ~3) + 8 * 128) * sizeof(float), st, a->c3d, sc,
                        a->ev_start, a->ev_len, wt, att, A, D);
     RC(check_launch("att_context"));
     }
-    // recurrent halves: GATES_k[t] += h_k_prev . W_hh_k^T ; stream 1 also += att . W_ih1[:,E:]^T
+    ra.njobs = 1;
+    ra.job[0] = mkjob(att, D, D, a->w_ih[1] + E, E + D, 4 * H, w.GSL[1] + nh * gs, gs, 4 * H);
+    RC(rec_gemm(ra, st));
     LstmPtrs P;
     for (int k = 0; k < 3; ++k) {
-        float* g = w.GATES[k] + (long)t * N * 4 * H;
-        d = desc_nt(hprev + k * H, 3 * H, a->w_hh[k], H, g, 4 * H, N, 4 * H, H);
-        d.beta = 1.f; d.split_k = -1;
-        if (t > 0) RC(gemm(d, st));                              // h_prev == 0 at t == 0
-        if (k == 1) {
-            d = desc_nt(att, D, a->w_ih[1] + E, E + D, g, 4 * H, N, 4 * H, D);
-            d.beta = 1.f; d.split_k = -1;
-            RC(gemm(d, st));
-        }
-        P.gates[k] = g;
+        P.gates[k] = w.GATES[k] + (long)t * N * 4 * H;
+        P.slab[k] = w.GSL[k];
+        P.nslab[k] = w.ng[k];
         P.c_prev[k] = w.CS[k] + (long)t * N * H;
         P.c_new[k] = w.CS[k] + (long)(t + 1) * N * H;
     }
+    P.slab_stride = gs;
     hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3((N * H + 255) / 256, 3), dim3(256), 0, st, P,
                        w.HS + (long)(t + 1) * N * 3 * H, w.OUTD + (long)t * N * 3 * H, N, H, t, dh, dout);
     return check_launch("lstm_pointwise_fwd");
@@ -563,11 +717,14 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     d = desc_nn(b.DLG, b.ldg, a->w_logit, 3 * H, b.DOUT, 3 * H, SN, 3 * H, V1);
     d.split_k = -1;
     RC(gemm(d, st));
-    // 3. reverse recurrence
-    RC(fill_zero(b.DHREC, (long)SN * 3 * H, st));
+    // 3. reverse recurrence.  Transposed weights turn every d h / d ATT product into the same NT form as forward.
+    for (int k = 0; k < 3; ++k) RC(transpose(a->w_hh[k], H, b.WT_HH[k], 4 * H, 4 * H, H, st));
+    RC(transpose(a->w_ih[1] + E, cin[1], b.WT_ATT, 4 * H, 4 * H, D, st));
+    RC(transpose(a->w_h2a, H, b.WT_H2A, Ha, Ha, H, st));
     RC(fill_zero(b.DC, (long)N * 3 * H, st));
-    RC(fill_zero(b.DATT, (long)SN * D, st));
     RC(fill_zero(b.DQ, (long)SN * Ha, st));
+    const long hs = (long)N * H, as = (long)N * D;
+    const int n4h = ksplit_of(4 * H);
     for (int t = S - 1; t >= 0; --t) {
         LstmBwdPtrs P;
         for (int k = 0; k < 3; ++k) {
@@ -575,36 +732,33 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
             P.c_prev[k] = w.CS[k] + (long)t * N * H;
             P.c_new[k] = w.CS[k] + (long)(t + 1) * N * H;
             P.dgates[k] = b.DG[k] + (long)t * N * 4 * H;
+            P.dh_slab[k] = b.DHSL[k];
+            P.nslab[k] = (t == S - 1) ? 0 : b.ndh[k];           // slabs hold d h(t), written while processing step t+1
         }
-        const float* dhrec = (t == S - 1) ? nullptr : b.DHREC + (long)(t + 1) * N * 3 * H;   // written while processing step t+1
+        P.slab_stride = hs;
         hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((N * H + 255) / 256, 3), dim3(256), 0, st, P,
-                           b.DOUT + (long)t * N * 3 * H, dhrec, b.DC, N, H, t, dh, dout);
+                           b.DOUT + (long)t * N * 3 * H, b.DC, N, H, t, dh, dout);
         RC(check_launch("lstm_pointwise_bwd"));
-        float* dhr = b.DHREC + (long)t * N * 3 * H;      // d h(t-1), consumed by step t-1
-        if (t > 0) {
-            for (int k = 0; k < 3; ++k) {
-                d = desc_nn(P.dgates[k], 4 * H, a->w_hh[k], H, dhr + k * H, 3 * H, N, H, 4 * H);
-                d.beta = 1.f; d.split_k = -1;
-                RC(gemm(d, st));
-            }
-        }
-        // attended-context gradient and attention backward (needed at every t: feeds d P_all, d alpha, d W_h)
-        float* datt = b.DATT + (long)t * N * D;
-        d = desc_nn(P.dgates[1], 4 * H, a->w_ih[1] + E, cin[1], datt, D, N, D, 4 * H);
-        d.beta = 1.f; d.split_k = -1;
-        RC(gemm(d, st));
+        // d h(t-1) = dG_k(t) . W_hh_k  (skipped at t = 0: h(-1) is the constant zero state);  d ATT = dG_1(t) . W_ih1[:,E:]
+        RecArgs ra;
+        ra.M = N; ra.njobs = 0;
+        ra.job[ra.njobs++] = mkjob(P.dgates[1], 4 * H, 4 * H, b.WT_ATT, 4 * H, D, b.DASL, as, D);
+        if (t > 0)
+            for (int k = 0; k < 3; ++k) ra.job[ra.njobs++] = mkjob(P.dgates[k], 4 * H, 4 * H, b.WT_HH[k], 4 * H, H, b.DHSL[k], hs, H);
+        RC(rec_gemm(ra, st));
+        // attention backward (needed at every t: feeds d P_all, d alpha, d W_h)
         float* dq = b.DQ + (long)t * N * Ha;
         const int D4 = (D + 3) & ~3;
         ProfScope* prof = new ProfScope(PROF_ATT_BWD, 4.0 * N * A * (Ha + D), 4.0 * ((double)N * A * (Ha + D + 2) + (double)N * (2 * Ha + 2 * D)), st);
         hipLaunchKernelGGL(att_bwd_kernel, dim3(N, (A + 31) / 32), dim3(256), (6 * Ha + D4) * sizeof(float), st, w.PALL, a->c3d,
-                           w.QS + (long)t * N * Ha, a->w_alpha, w.WT + (long)t * N * A, w.ATT + (long)t * N * D, datt,
+                           w.QS + (long)t * N * Ha, a->w_alpha, w.WT + (long)t * N * A, w.ATT + (long)t * N * D, b.DASL, b.nda, as,
                            a->ev_start, a->ev_len, b.DSC + (long)t * N * A, dq, A, Ha, D);
         delete prof;
         RC(check_launch("att_bwd"));
-        if (t > 0) {
-            d = desc_nn(dq, Ha, a->w_h2a, H, dhr + H, 3 * H, N, H, Ha);
-            d.beta = 1.f; d.split_k = -1;
-            RC(gemm(d, st));
+        if (t > 0) {   // d h1(t-1) += dq . W_h : extra slabs behind stream 1's W_hh slabs
+            ra.njobs = 1;
+            ra.job[0] = mkjob(dq, Ha, Ha, b.WT_H2A, Ha, H, b.DHSL[1] + n4h * hs, hs, H);
+            RC(rec_gemm(ra, st));
         }
     }
     // 4. batched parameter gradients
