@@ -38,10 +38,17 @@ DropCfg make_drop(const echr_dropout* d, float p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Frame-level attention, forward.
-// score kernel: grid (N, ceil(A/32)); a workgroup scores 32 slots of one event, one wave per 8 slots, lanes
-// across the Ha axis (float4), wave-shuffle reduction.  q[n,:] and alpha live in LDS.
+// Frame-level attention.  All kernels index the video through (ev_start, ev_len); a workgroup = 4 waves, lanes across
+// the feature axis in float4, one wave per group of slots.  Loads are branch-free (clamped addresses, masked
+// contributions) and issued for ALL of a wave's slots before the first use, so each wave keeps 8-16 KB in flight.
+// R  = float4 per lane per P_all row (ceil(Ha/256)), RD = float4 per lane per clip row (ceil(D/256)).
 // ------------------------------------------------------------------------------------------------------
+constexpr int MAXR = 4;   // Ha, D <= 1024
+constexpr int SLOTS = 8;  // slots per wave
+
+// score kernel: grid (N, ceil(A/32)): e[n,a] = alpha . tanh(P_all[start+a] + q[n]) + b_alpha.
+// q[n,:] = b_h2a + sum of the split-K partial slabs of h1_prev . W_h^T (rec_gemm); block y==0 keeps it in QS for backward.
+template <int R>
 __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict__ PALL, const float* __restrict__ QSL, int nslab,
                                                         long slab_stride, const float* __restrict__ b_q, float* __restrict__ QS,
                                                         const float* __restrict__ alpha, const float* __restrict__ b_alpha,
@@ -53,7 +60,16 @@ __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict_
     const int n = blockIdx.x, a0 = blockIdx.y * 32;
     const int len = ev_len[n];
     if (a0 >= len) return;
-    // q[n,:] = b_h2a + sum of the split-K partial slabs of h1_prev . W_h^T (rec_gemm); kept in QS for backward
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row0 = ev_start[n];
+    float4 p[SLOTS][R];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int a = min(a0 + wave * SLOTS + i, len - 1);
+        const float* prow = PALL + (row0 + a) * Ha;
+#pragma unroll
+        for (int r = 0; r < R; ++r) p[i][r] = *reinterpret_cast<const float4*>(prow + min(lane * 4 + r * 256, Ha - 4));
+    }
     for (int j = threadIdx.x; j < Ha; j += 256) {
         float q = b_q[j];
         for (int s = 0; s < nslab; ++s) q += QSL[s * slab_stride + (long)n * Ha + j];
@@ -61,23 +77,27 @@ __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict_
         if (blockIdx.y == 0) QS[(long)n * Ha + j] = q;
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long row0 = ev_start[n];
+    float4 q4[R], a4[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = lane * 4 + r * 256;
+        const bool in = j < Ha;
+        q4[r] = *reinterpret_cast<const float4*>(sq + min(j, Ha - 4));
+        a4[r] = *reinterpret_cast<const float4*>(sa + min(j, Ha - 4));
+        if (!in) a4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float ba = b_alpha[0];
-    for (int i = 0; i < 8; ++i) {
-        const int a = a0 + wave * 8 + i;
-        if (a >= len) break;
-        const float* prow = PALL + (row0 + a) * Ha;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
         float acc = 0.f;
-        for (int j = lane * 4; j < Ha; j += 256) {
-            const float4 p4 = *reinterpret_cast<const float4*>(prow + j);
-            const float4 q4 = *reinterpret_cast<const float4*>(sq + j);
-            const float4 a4 = *reinterpret_cast<const float4*>(sa + j);
-            acc += a4.x * fast_tanh(p4.x + q4.x) + a4.y * fast_tanh(p4.y + q4.y) + a4.z * fast_tanh(p4.z + q4.z) +
-                   a4.w * fast_tanh(p4.w + q4.w);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc += a4[r].x * fast_tanh(p[i][r].x + q4[r].x) + a4[r].y * fast_tanh(p[i][r].y + q4[r].y) +
+                   a4[r].z * fast_tanh(p[i][r].z + q4[r].z) + a4[r].w * fast_tanh(p[i][r].w + q4[r].w);
         }
         acc = wave_sum(acc);
-        if (lane == 0) SC[(long)n * A + a] = acc + ba;
+        const int a = a0 + wave * SLOTS + i;
+        if (lane == 0 && a < len) SC[(long)n * A + a] = acc + ba;
     }
 }
 
@@ -87,8 +107,9 @@ __global__ __launch_bounds__(256) void att_context_kernel(const float* __restric
                                                           const int* __restrict__ ev_start, const int* __restrict__ ev_len,
                                                           float* __restrict__ WT, float* __restrict__ ATT, int A, int D) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* w = sm;                       // [A]
-    float* red = sm + ((A + 3) & ~3);    // [8][128]
+    const int A32 = (A + 31) & ~31;
+    float* w = sm;                       // [A32] (zero beyond len)
+    float* red = sm + A32;               // [8][128]
     __shared__ float r4[4];
     const int n = blockIdx.x, d0 = blockIdx.y * 128;
     const int len = ev_len[n];
@@ -102,26 +123,34 @@ __global__ __launch_bounds__(256) void att_context_kernel(const float* __restric
     m = fmaxf(fmaxf(r4[0], r4[1]), fmaxf(r4[2], r4[3]));
     __syncthreads();
     float s = 0.f;
-    for (int a = threadIdx.x; a < len; a += 256) { const float e = __expf(SC[(long)n * A + a] - m); w[a] = e; s += e; }
+    for (int a = threadIdx.x; a < A32; a += 256) {
+        const float e = a < len ? __expf(SC[(long)n * A + a] - m) : 0.f;
+        w[a] = e; s += e;
+    }
     s = wave_sum(s);
     if (lane == 0) r4[wave] = s;
     __syncthreads();
     const float inv = 1.0f / (r4[0] + r4[1] + r4[2] + r4[3]);
-    for (int a = threadIdx.x; a < A; a += 256) {
-        const float wa = a < len ? w[a] * inv : 0.f;
-        if (a < len) w[a] = wa;
-        if (blockIdx.y == 0) WT[(long)n * A + a] = wa;
+    for (int a = threadIdx.x; a < A32; a += 256) {
+        const float wa = w[a] * inv;
+        w[a] = wa;
+        if (blockIdx.y == 0 && a < A) WT[(long)n * A + a] = wa;
     }
     __syncthreads();
     const int dl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int d = d0 + dl * 4;
+    const int d = min(d0 + dl * 4, D - 4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d < D) {
-        for (int a = rg; a < len; a += 8) {
-            const float wa = w[a];
-            const float4 c = *reinterpret_cast<const float4*>(C3D + (row0 + a) * D + d);
-            acc.x += wa * c.x; acc.y += wa * c.y; acc.z += wa * c.z; acc.w += wa * c.w;
+    for (int ab = 0; ab < len; ab += 32) {          // 4 rows per thread in flight
+        float4 c[4];
+        float wa[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = ab + rg + 8 * u;
+            wa[u] = w[a];                             // zero past the event's end
+            c[u] = *reinterpret_cast<const float4*>(C3D + (row0 + min(a, len - 1)) * D + d);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += wa[u] * c[u].x; acc.y += wa[u] * c[u].y; acc.z += wa[u] * c[u].z; acc.w += wa[u] * c[u].w; }
     }
     *reinterpret_cast<float4*>(red + rg * 128 + dl * 4) = acc;
     __syncthreads();
@@ -136,32 +165,40 @@ __global__ __launch_bounds__(256) void att_context_kernel(const float* __restric
     }
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Frame-level attention, backward for one timestep.  grid (N, ceil(A/32)).
+// backward for one timestep.  grid (N, ceil(A/32)).
 //   dscore_a = w_a * (clip_a . dATT - ATT . dATT);  dq += sum_a dscore_a * alpha * (1 - tanh^2(P_a + q))
-// DSC keeps dscore for the post-recurrence pass that accumulates d P_all and d alpha over all timesteps
-// (that pass recomputes tanh instead of reading+writing an [N,A,Ha] accumulator every step).
-// ------------------------------------------------------------------------------------------------------
-constexpr int MAXR = 4;   // Ha <= 256 * MAXR
-
+// dATT arrives as split-K slabs (rec_gemm).  DSC keeps dscore for the post-recurrence pass that accumulates d P_all and
+// d alpha over all timesteps (that pass recomputes tanh instead of updating an [N,A,Ha] accumulator every step).
+template <int R, int RD>
 __global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ PALL, const float* __restrict__ C3D,
                                                       const float* __restrict__ Q, const float* __restrict__ alpha,
                                                       const float* __restrict__ WT, const float* __restrict__ ATT,
                                                       const float* __restrict__ DAS, int nslab, long slab_stride,
-                                                      const int* __restrict__ ev_start,
-                                                      const int* __restrict__ ev_len, float* __restrict__ DSC,
-                                                      float* __restrict__ DQ, int A, int Ha, int D) {
+                                                      const int* __restrict__ ev_start, const int* __restrict__ ev_len,
+                                                      float* __restrict__ DSC, float* __restrict__ DQ, int A, int Ha, int D) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sq = sm;                 // [Ha]
     float* sa = sq + Ha;            // [Ha]
-    float* sd = sa + Ha;            // [D4] dATT row
     const int D4 = (D + 3) & ~3;
+    float* sd = sa + Ha;            // [D4] dATT row
     float* red = sd + D4;           // [4][Ha]
     __shared__ float r4[4];
     const int n = blockIdx.x, a0 = blockIdx.y * 32;
     const int len = ev_len[n];
     if (a0 >= len) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row0 = ev_start[n];
+    float4 p[SLOTS][R], c[SLOTS][RD];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int a = min(a0 + wave * SLOTS + i, len - 1);
+        const float* crow = C3D + (row0 + a) * D;
+        const float* prow = PALL + (row0 + a) * Ha;
+#pragma unroll
+        for (int r = 0; r < RD; ++r) c[i][r] = *reinterpret_cast<const float4*>(crow + min(lane * 4 + r * 256, D - 4));
+#pragma unroll
+        for (int r = 0; r < R; ++r) p[i][r] = *reinterpret_cast<const float4*>(prow + min(lane * 4 + r * 256, Ha - 4));
+    }
     float s0 = 0.f;
     for (int j = threadIdx.x; j < Ha; j += 256) { sq[j] = Q[(long)n * Ha + j]; sa[j] = alpha[j]; }
     for (int j = threadIdx.x; j < D4; j += 256) {
@@ -175,54 +212,55 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ 
     if (lane == 0) r4[wave] = s0;
     __syncthreads();
     s0 = r4[0] + r4[1] + r4[2] + r4[3];
-    const long row0 = ev_start[n];
-    float dq[MAXR * 4];
+    float dsc[SLOTS];
 #pragma unroll
-    for (int r = 0; r < MAXR * 4; ++r) dq[r] = 0.f;
-    for (int i = 0; i < 8; ++i) {
-        const int a = a0 + wave * 8 + i;
-        if (a >= len) break;
-        const float* crow = C3D + (row0 + a) * D;
+    for (int i = 0; i < SLOTS; ++i) {
         float dw = 0.f;
-        for (int j = lane * 4; j < D; j += 256) {
-            const float4 c = *reinterpret_cast<const float4*>(crow + j);
-            const float4 g = *reinterpret_cast<const float4*>(sd + j);
-            dw += c.x * g.x + c.y * g.y + c.z * g.z + c.w * g.w;
-        }
-        dw = wave_sum(dw);
-        const float dsc = WT[(long)n * A + a] * (dw - s0);
-        if (lane == 0) DSC[(long)n * A + a] = dsc;
-        const float* prow = PALL + (row0 + a) * Ha;
 #pragma unroll
-        for (int r = 0; r < MAXR; ++r) {
+        for (int r = 0; r < RD; ++r) {
             const int j = lane * 4 + r * 256;
-            if (j < Ha) {
-                const float4 p4 = *reinterpret_cast<const float4*>(prow + j);
-                const float4 q4 = *reinterpret_cast<const float4*>(sq + j);
-                const float4 a4 = *reinterpret_cast<const float4*>(sa + j);
-                float t;
-                t = fast_tanh(p4.x + q4.x); dq[r * 4 + 0] += dsc * a4.x * (1.f - t * t);
-                t = fast_tanh(p4.y + q4.y); dq[r * 4 + 1] += dsc * a4.y * (1.f - t * t);
-                t = fast_tanh(p4.z + q4.z); dq[r * 4 + 2] += dsc * a4.z * (1.f - t * t);
-                t = fast_tanh(p4.w + q4.w); dq[r * 4 + 3] += dsc * a4.w * (1.f - t * t);
+            if (j < D) {
+                const float4 g = *reinterpret_cast<const float4*>(sd + j);
+                dw += c[i][r].x * g.x + c[i][r].y * g.y + c[i][r].z * g.z + c[i][r].w * g.w;
             }
         }
+        dw = wave_sum(dw);
+        const int a = a0 + wave * SLOTS + i;
+        dsc[i] = a < len ? WT[(long)n * A + min(a, A - 1)] * (dw - s0) : 0.f;
+        if (lane == 0 && a < len) DSC[(long)n * A + a] = dsc[i];
+    }
+    float4 dq[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        dq[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int j = min(lane * 4 + r * 256, Ha - 4);
+        const float4 q4 = *reinterpret_cast<const float4*>(sq + j);
+        const float4 a4 = *reinterpret_cast<const float4*>(sa + j);
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            float t;
+            t = fast_tanh(p[i][r].x + q4.x); dq[r].x += dsc[i] * a4.x * (1.f - t * t);
+            t = fast_tanh(p[i][r].y + q4.y); dq[r].y += dsc[i] * a4.y * (1.f - t * t);
+            t = fast_tanh(p[i][r].z + q4.z); dq[r].z += dsc[i] * a4.z * (1.f - t * t);
+            t = fast_tanh(p[i][r].w + q4.w); dq[r].w += dsc[i] * a4.w * (1.f - t * t);
+        }
     }
 #pragma unroll
-    for (int r = 0; r < MAXR; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int j = lane * 4 + r * 256;
-        if (j < Ha) *reinterpret_cast<float4*>(red + wave * Ha + j) = make_float4(dq[r * 4], dq[r * 4 + 1], dq[r * 4 + 2], dq[r * 4 + 3]);
+        if (j < Ha) *reinterpret_cast<float4*>(red + wave * Ha + j) = dq[r];
     }
     __syncthreads();
-    // waves past the event's end never ran the slot loop: their partial is the zero they just stored
     for (int j = threadIdx.x; j < Ha; j += 256)
         atomicAdd(&DQ[(long)n * Ha + j], red[j] + red[Ha + j] + red[2 * Ha + j] + red[3 * Ha + j]);
 }
 
 // Post-recurrence pass: d P_all[row,:] += sum_t dsc_t * alpha * (1 - tanh^2(P_row + q_t)),
 //                       d alpha      += sum_{t,n,a} dsc_t * tanh(P_row + q_t),  d b_alpha += sum dsc.
-// grid (N, ceil(A/32)); q_t[n,:] for a tile of TT timesteps is staged in LDS.
-constexpr int TT = 16;
+// grid (N, ceil(A/8)): 4 waves x 2 slots; q_t[n,:] for a tile of TT timesteps is staged in LDS (4 workgroups per CU).
+constexpr int TT = 20;
+constexpr int PSLOTS = 2;
+template <int R>
 __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__ PALL, const float* __restrict__ QS,
                                                        const float* __restrict__ alpha, const float* __restrict__ DSC,
                                                        const int* __restrict__ ev_start, const int* __restrict__ ev_len,
@@ -230,90 +268,132 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
                                                        float* __restrict__ g_balpha, int S, int N, int A, int Ha) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sqt = sm;                   // [TT][Ha]
-    float* sa = sqt + TT * Ha;         // [Ha]
-    float* sds = sa + Ha;              // [TT][32] dscore tile
-    float* red = sds + TT * 32;        // [4][Ha]
-    const int n = blockIdx.x, a0 = blockIdx.y * 32;
+    float* sds = sqt + TT * Ha;        // [TT][8] dscore tile
+    float* red = sds + TT * 8;         // [4][Ha]
+    const int n = blockIdx.x, a0 = blockIdx.y * 8;
     const int len = ev_len[n];
     if (a0 >= len) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long row0 = ev_start[n];
-    for (int j = threadIdx.x; j < Ha; j += 256) sa[j] = alpha[j];
-    float dal[MAXR * 4];
-    float dp[8][MAXR * 4];             // one accumulator row per slot of this wave (kept across t-tiles)
+    float4 p[PSLOTS][R], a4[R], dal[R];
 #pragma unroll
-    for (int r = 0; r < MAXR * 4; ++r) dal[r] = 0.f;
+    for (int i = 0; i < PSLOTS; ++i) {
+        const int a = min(a0 + wave * PSLOTS + i, len - 1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int r = 0; r < R; ++r) p[i][r] = *reinterpret_cast<const float4*>(PALL + (row0 + a) * Ha + min(lane * 4 + r * 256, Ha - 4));
+    }
 #pragma unroll
-        for (int r = 0; r < MAXR * 4; ++r) dp[i][r] = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const int j = lane * 4 + r * 256;
+        a4[r] = j < Ha ? *reinterpret_cast<const float4*>(alpha + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dal[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 dp[PSLOTS][R];
+#pragma unroll
+    for (int i = 0; i < PSLOTS; ++i)
+#pragma unroll
+        for (int r = 0; r < R; ++r) dp[i][r] = make_float4(0.f, 0.f, 0.f, 0.f);
     float dsum = 0.f;
     for (int t0 = 0; t0 < S; t0 += TT) {
         const int nt = min(TT, S - t0);
         __syncthreads();
-        for (int idx = threadIdx.x; idx < nt * Ha; idx += 256) {
-            const int tt = idx / Ha, j = idx % Ha;
-            sqt[tt * Ha + j] = QS[((long)(t0 + tt) * N + n) * Ha + j];
+        for (int idx = threadIdx.x; idx < nt * (Ha >> 2); idx += 256) {
+            const int tt = idx / (Ha >> 2), j4 = idx % (Ha >> 2);
+            *reinterpret_cast<float4*>(sqt + tt * Ha + 4 * j4) = *reinterpret_cast<const float4*>(QS + ((long)(t0 + tt) * N + n) * Ha + 4 * j4);
         }
-        for (int idx = threadIdx.x; idx < nt * 32; idx += 256) {
-            const int tt = idx / 32, i = idx % 32;
-            sds[tt * 32 + i] = (a0 + i < len) ? DSC[((long)(t0 + tt) * N + n) * A + a0 + i] : 0.f;
+        for (int idx = threadIdx.x; idx < nt * 8; idx += 256) {
+            const int tt = idx >> 3, i = idx & 7;
+            sds[idx] = (a0 + i < len) ? DSC[((long)(t0 + tt) * N + n) * A + a0 + i] : 0.f;
         }
         __syncthreads();
+        for (int tt = 0; tt < nt; ++tt) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int a = a0 + wave * 8 + i;
-            if (a < len) {
-                const float* prow = PALL + (row0 + a) * Ha;
+            for (int i = 0; i < PSLOTS; ++i) {
+                const float dsc = sds[tt * 8 + wave * PSLOTS + i];
+                if (lane == 0) dsum += dsc;
 #pragma unroll
-                for (int r = 0; r < MAXR; ++r) {
-                    const int j = lane * 4 + r * 256;
-                    if (j < Ha) {
-                        const float4 p4 = *reinterpret_cast<const float4*>(prow + j);
-                        const float4 a4 = *reinterpret_cast<const float4*>(sa + j);
-                        for (int tt = 0; tt < nt; ++tt) {
-                            const float dsc = sds[tt * 32 + wave * 8 + i];
-                            const float4 q4 = *reinterpret_cast<const float4*>(sqt + tt * Ha + j);
-                            float t;
-                            t = fast_tanh(p4.x + q4.x); dp[i][r * 4 + 0] += dsc * a4.x * (1.f - t * t); dal[r * 4 + 0] += dsc * t;
-                            t = fast_tanh(p4.y + q4.y); dp[i][r * 4 + 1] += dsc * a4.y * (1.f - t * t); dal[r * 4 + 1] += dsc * t;
-                            t = fast_tanh(p4.z + q4.z); dp[i][r * 4 + 2] += dsc * a4.z * (1.f - t * t); dal[r * 4 + 2] += dsc * t;
-                            t = fast_tanh(p4.w + q4.w); dp[i][r * 4 + 3] += dsc * a4.w * (1.f - t * t); dal[r * 4 + 3] += dsc * t;
-                        }
-                    }
+                for (int r = 0; r < R; ++r) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(sqt + tt * Ha + min(lane * 4 + r * 256, Ha - 4));
+                    float t;
+                    t = fast_tanh(p[i][r].x + q4.x); dp[i][r].x += dsc * (1.f - t * t); dal[r].x += dsc * t;
+                    t = fast_tanh(p[i][r].y + q4.y); dp[i][r].y += dsc * (1.f - t * t); dal[r].y += dsc * t;
+                    t = fast_tanh(p[i][r].z + q4.z); dp[i][r].z += dsc * (1.f - t * t); dal[r].z += dsc * t;
+                    t = fast_tanh(p[i][r].w + q4.w); dp[i][r].w += dsc * (1.f - t * t); dal[r].w += dsc * t;
                 }
-                if (lane == 0)
-                    for (int tt = 0; tt < nt; ++tt) dsum += sds[tt * 32 + wave * 8 + i];
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int a = a0 + wave * 8 + i;
+    for (int i = 0; i < PSLOTS; ++i) {
+        const int a = a0 + wave * PSLOTS + i;
         if (a < len) {
             float* drow = DPALL + (row0 + a) * Ha;
 #pragma unroll
-            for (int r = 0; r < MAXR; ++r) {
+            for (int r = 0; r < R; ++r) {
                 const int j = lane * 4 + r * 256;
                 if (j < Ha) {
-                    atomicAdd(drow + j + 0, dp[i][r * 4 + 0]);
-                    atomicAdd(drow + j + 1, dp[i][r * 4 + 1]);
-                    atomicAdd(drow + j + 2, dp[i][r * 4 + 2]);
-                    atomicAdd(drow + j + 3, dp[i][r * 4 + 3]);
+                    atomicAdd(drow + j + 0, dp[i][r].x * a4[r].x);
+                    atomicAdd(drow + j + 1, dp[i][r].y * a4[r].y);
+                    atomicAdd(drow + j + 2, dp[i][r].z * a4[r].z);
+                    atomicAdd(drow + j + 3, dp[i][r].w * a4[r].w);
                 }
             }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < MAXR; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int j = lane * 4 + r * 256;
-        if (j < Ha) *reinterpret_cast<float4*>(red + wave * Ha + j) = make_float4(dal[r * 4], dal[r * 4 + 1], dal[r * 4 + 2], dal[r * 4 + 3]);
+        if (j < Ha) *reinterpret_cast<float4*>(red + wave * Ha + j) = dal[r];
     }
     __syncthreads();
     for (int j = threadIdx.x; j < Ha; j += 256)
         atomicAdd(&g_alpha[j], red[j] + red[Ha + j] + red[2 * Ha + j] + red[3 * Ha + j]);
     if (lane == 0 && dsum != 0.f) atomicAdd(g_balpha, dsum);
+}
+
+// ---- launch helpers (dispatch on the per-lane row widths) ------------------------------------------------
+struct AttDims { int N, A, Ha, D; };
+
+static int launch_att_score(const AttDims& d, const float* PALL, const float* QSL, int nslab, long slab_stride, const float* b_q,
+                            float* QS, const float* alpha, const float* b_alpha, const int* ev_start, const int* ev_len, float* SC,
+                            hipStream_t st) {
+    const dim3 grid(d.N, (d.A + 31) / 32), blk(256);
+    const size_t sm = 2 * d.Ha * sizeof(float);
+    switch ((d.Ha + 255) / 256) {
+#define ECHR_CASE(R) case R: hipLaunchKernelGGL((att_score_kernel<R>), grid, blk, sm, st, PALL, QSL, nslab, slab_stride, b_q, QS, alpha, b_alpha, ev_start, ev_len, SC, d.A, d.Ha); break;
+        ECHR_CASE(1) ECHR_CASE(2) ECHR_CASE(3) ECHR_CASE(4)
+#undef ECHR_CASE
+        default: set_error("att_score: Ha too large"); return -22;
+    }
+    return check_launch("att_score");
+}
+
+static int launch_att_bwd(const AttDims& d, const float* PALL, const float* C3D, const float* Q, const float* alpha, const float* WT,
+                          const float* ATT, const float* DAS, int nslab, long slab_stride, const int* ev_start, const int* ev_len,
+                          float* DSC, float* DQ, hipStream_t st) {
+    const dim3 grid(d.N, (d.A + 31) / 32), blk(256);
+    const size_t sm = (6 * d.Ha + ((d.D + 3) & ~3)) * sizeof(float);
+    const int R = (d.Ha + 255) / 256, RD = (d.D + 255) / 256;
+#define ECHR_CASE(RR, RRD) if (R == RR && RD == RRD) { hipLaunchKernelGGL((att_bwd_kernel<RR, RRD>), grid, blk, sm, st, PALL, C3D, Q, alpha, WT, ATT, DAS, nslab, slab_stride, ev_start, ev_len, DSC, DQ, d.A, d.Ha, d.D); return check_launch("att_bwd"); }
+    ECHR_CASE(1, 1) ECHR_CASE(1, 2) ECHR_CASE(2, 1) ECHR_CASE(2, 2) ECHR_CASE(2, 3) ECHR_CASE(2, 4) ECHR_CASE(3, 2) ECHR_CASE(4, 2)
+    ECHR_CASE(1, 3) ECHR_CASE(1, 4) ECHR_CASE(3, 1) ECHR_CASE(3, 3) ECHR_CASE(3, 4) ECHR_CASE(4, 1) ECHR_CASE(4, 3) ECHR_CASE(4, 4)
+#undef ECHR_CASE
+    set_error("att_bwd: Ha or D too large");
+    return -22;
+}
+
+static int launch_att_post(const AttDims& d, const float* PALL, const float* QS, const float* alpha, const float* DSC, const int* ev_start,
+                           const int* ev_len, float* DPALL, float* g_alpha, float* g_balpha, int S, hipStream_t st) {
+    const dim3 grid(d.N, (d.A + 7) / 8), blk(256);
+    const size_t sm = ((size_t)TT * d.Ha + TT * 8 + 4 * d.Ha) * sizeof(float);
+    switch ((d.Ha + 255) / 256) {
+#define ECHR_CASE(R) case R: hipLaunchKernelGGL((att_post_kernel<R>), grid, blk, sm, st, PALL, QS, alpha, DSC, ev_start, ev_len, DPALL, g_alpha, g_balpha, S, d.N, d.A, d.Ha); break;
+        ECHR_CASE(1) ECHR_CASE(2) ECHR_CASE(3) ECHR_CASE(4)
+#undef ECHR_CASE
+        default: set_error("att_post: Ha too large"); return -22;
+    }
+    return check_launch("att_post");
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -348,17 +428,30 @@ __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
     if (n0 >= J.Nout || k0 >= J.K) return;
     const int k1 = min(J.K, k0 + RK);
     const int tid = threadIdx.x;
+    // branch-free staging: every lane loads from a clamped (always valid) address and zeroes what lies outside the
+    // problem, so all 16 global loads of a thread are in flight together before the first LDS write
+    float4 va[8], vb[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int f = tid + p * 256;
         const int row = f >> 5, kq = (f & 31) * 4;
-        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-        if (k0 + kq < k1) {
-            if (m0 + row < args.M) va = *reinterpret_cast<const float4*>(J.A + (long)(m0 + row) * J.lda + k0 + kq);
-            if (n0 + row < J.Nout) vb = *reinterpret_cast<const float4*>(J.B + (long)(n0 + row) * J.ldb + k0 + kq);
-        }
-        *reinterpret_cast<float4*>(&As[row * RLD + kq]) = va;
-        *reinterpret_cast<float4*>(&Bs[row * RLD + kq]) = vb;
+        const int kk = min(k0 + kq, J.K - 4);
+        const int ra = min(m0 + row, args.M - 1), rbn = min(n0 + row, J.Nout - 1);
+        va[p] = *reinterpret_cast<const float4*>(J.A + (long)ra * J.lda + kk);
+        vb[p] = *reinterpret_cast<const float4*>(J.B + (long)rbn * J.ldb + kk);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int f = tid + p * 256;
+        const int row = f >> 5, kq = (f & 31) * 4;
+        const bool kin = (k0 + kq) < k1;
+        const float ma = (kin && (m0 + row) < args.M) ? 1.f : 0.f;
+        const float mb = (kin && (n0 + row) < J.Nout) ? 1.f : 0.f;
+        float4 a = va[p], b = vb[p];
+        a.x *= ma; a.y *= ma; a.z *= ma; a.w *= ma;
+        b.x *= mb; b.y *= mb; b.z *= mb; b.w *= mb;
+        *reinterpret_cast<float4*>(&As[row * RLD + kq]) = a;
+        *reinterpret_cast<float4*>(&Bs[row * RLD + kq]) = b;
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -367,11 +460,12 @@ __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int nchunk = (k1 - k0 + 7) >> 3;
     const float* ap = &As[(wm + l31) * RLD + 4 * h];
     const float* bp = &Bs[(wn + l31) * RLD + 4 * h];
-#pragma unroll 4
-    for (int c = 0; c < nchunk; ++c) {
+    // the whole 128-wide slice is always multiplied (tails are zero-filled): a fixed trip count lets the compiler
+    // hoist the LDS fragment reads ahead of the MFMA chain
+#pragma unroll
+    for (int c = 0; c < RK / 8; ++c) {
         const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * c);
         const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * c);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
@@ -573,7 +667,8 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
 static int check_dims(const echr_dec_args* a, const char* who) {
     ECHR_REQUIRE(a, "%s: null args", who);
     ECHR_REQUIRE(a->N > 0 && a->A > 0 && a->Tv > 0 && a->S >= 0, "%s: bad N/A/Tv/S", who);
-    ECHR_REQUIRE(a->D % 4 == 0 && a->Ha % 4 == 0 && a->Ha <= 256 * MAXR, "%s: need D%%4==0, Ha%%4==0, Ha<=%d (D=%d Ha=%d)", who, 256 * MAXR, a->D, a->Ha);
+    ECHR_REQUIRE(a->D % 4 == 0 && a->Ha % 4 == 0 && a->Ha <= 256 * MAXR && a->D <= 256 * MAXR && a->D >= 4 && a->Ha >= 4,
+                 "%s: need D%%4==0, Ha%%4==0, 4 <= D,Ha <= %d (D=%d Ha=%d)", who, 256 * MAXR, a->D, a->Ha);
     ECHR_REQUIRE(a->H > 0 && a->E > 0 && a->De > 0 && a->Dv > 0 && a->V1 > 1, "%s: bad widths", who);
     ECHR_REQUIRE(a->H % 4 == 0 && a->E % 4 == 0, "%s: need H%%4==0 and E%%4==0 (H=%d E=%d)", who, a->H, a->E);
     return 0;
@@ -625,10 +720,9 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
     // algorithmic bytes of one attention step: p_att rows + clip rows + scores/weights/context
     const double rows = (double)N * A;
     ProfScope prof(PROF_ATT_FWD, 2.0 * rows * (Ha + D) , 4.0 * (rows * (Ha + D + 2) + (double)N * (Ha + D)), st);
-    hipLaunchKernelGGL(att_score_kernel, dim3(N, (A + 31) / 32), dim3(256), 2 * Ha * sizeof(float), st, w.PALL, w.QSL, w.nq, qs,
-                       a->b_h2a, q, a->w_alpha, a->b_alpha, a->ev_start, a->ev_len, sc, A, Ha);
-    RC(check_launch("att_score"));
-    hipLaunchKernelGGL(att_context_kernel, dim3(N, (D + 127) / 128), dim3(256), (((A + 3) & ~3) + 8 * 128) * sizeof(float), st, a->c3d, sc,
+    const AttDims ad{N, A, Ha, D};
+    RC(launch_att_score(ad, w.PALL, w.QSL, w.nq, qs, a->b_h2a, q, a->w_alpha, a->b_alpha, a->ev_start, a->ev_len, sc, st));
+    hipLaunchKernelGGL(att_context_kernel, dim3(N, (D + 127) / 128), dim3(256), (((A + 31) & ~31) + 8 * 128) * sizeof(float), st, a->c3d, sc,
                        a->ev_start, a->ev_len, wt, att, A, D);
     RC(check_launch("att_context"));
     }
@@ -748,13 +842,12 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         RC(rec_gemm(ra, st));
         // attention backward (needed at every t: feeds d P_all, d alpha, d W_h)
         float* dq = b.DQ + (long)t * N * Ha;
-        const int D4 = (D + 3) & ~3;
-        ProfScope* prof = new ProfScope(PROF_ATT_BWD, 4.0 * N * A * (Ha + D), 4.0 * ((double)N * A * (Ha + D + 2) + (double)N * (2 * Ha + 2 * D)), st);
-        hipLaunchKernelGGL(att_bwd_kernel, dim3(N, (A + 31) / 32), dim3(256), (6 * Ha + D4) * sizeof(float), st, w.PALL, a->c3d,
-                           w.QS + (long)t * N * Ha, a->w_alpha, w.WT + (long)t * N * A, w.ATT + (long)t * N * D, b.DASL, b.nda, as,
-                           a->ev_start, a->ev_len, b.DSC + (long)t * N * A, dq, A, Ha, D);
-        delete prof;
-        RC(check_launch("att_bwd"));
+        {
+        ProfScope prof(PROF_ATT_BWD, 4.0 * N * A * (Ha + D), 4.0 * ((double)N * A * (Ha + D + 2) + (double)N * (2 * Ha + 2 * D)), st);
+        const AttDims ad{N, A, Ha, D};
+        RC(launch_att_bwd(ad, w.PALL, a->c3d, w.QS + (long)t * N * Ha, a->w_alpha, w.WT + (long)t * N * A, w.ATT + (long)t * N * D,
+                          b.DASL, b.nda, as, a->ev_start, a->ev_len, b.DSC + (long)t * N * A, dq, st));
+        }
         if (t > 0) {   // d h1(t-1) += dq . W_h : extra slabs behind stream 1's W_hh slabs
             ra.njobs = 1;
             ra.job[0] = mkjob(dq, Ha, Ha, b.WT_H2A, Ha, H, b.DHSL[1] + n4h * hs, hs, H);
@@ -768,10 +861,9 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     RC(fill_zero(g->g_b_alpha, 1, st));
     {
     ProfScope prof(PROF_ATT_POST, 6.0 * N * A * Ha * S, 4.0 * ((double)N * A * Ha * 2 + (double)S * N * (Ha + A)), st);
-    hipLaunchKernelGGL(att_post_kernel, dim3(N, (A + 31) / 32), dim3(256), (TT * Ha + Ha + TT * 32 + 4 * Ha) * sizeof(float), st,
-                       w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, g->g_w_alpha, g->g_b_alpha, S, N, A, Ha);
+    const AttDims ad{N, A, Ha, D};
+    RC(launch_att_post(ad, w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, g->g_w_alpha, g->g_b_alpha, S, st));
     }
-    RC(check_launch("att_post"));
     d = desc_tn(b.DPALL, Ha, a->c3d, D, g->g_w_c2a, D, Ha, D, a->Tv);
     d.split_k = -1;
     RC(gemm(d, st));
