@@ -51,7 +51,8 @@ def gpu_leg(args, rank, world, local_rank):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.to(dev).train()
     crit = LanguageModelCriterion()
-    optim = ClampAdam(model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon)
+    arena = None if args.no_arena else model.build_arena()      # flat parameter/gradient buffers: 1-launch Adam, 1-bucket all-reduce
+    optim = ClampAdam(model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon, arena=arena)
     tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
     labels = torch.from_numpy(vid['labels'])                       # host copy: step count needs no device sync
     tgt = labels[:, 1:].to(dev)
@@ -188,6 +189,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--overlap', action='store_true', help='SURVEY 8-d one-video layout (T_v=160, events share rows)')
+    ap.add_argument('--no-arena', action='store_true', help='per-tensor gradients/optimiser instead of the flat arena')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()

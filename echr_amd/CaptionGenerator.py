@@ -26,6 +26,16 @@ class CaptionGenerator(nn.Module):
             raise NotImplementedError('the HIP path implements the ECHR recipe: video_context_type=VL, event_context_type=ER3, '
                                       'clip_context_type=CC (experiments/train_ECHR.sh)')
 
+    def build_arena(self):
+        """Pack parameters and gradients into flat device buffers (echr_amd/arena.py).  Call after .cuda(); enables the
+        single-launch fused optimiser step and the single-bucket gradient all-reduce."""
+        from .arena import ParamArena
+        arena = ParamArena(self)
+        self.lm_model._echr_arena_ref = arena
+        if hasattr(self, 'fusion_model'):
+            self.fusion_model._echr_arena_ref = arena
+        return arena
+
     def set_dropout_state(self, seed, calls=0):
         """Pin the counter-based dropout stream (tests / reproducible runs)."""
         self.lm_model._drop_seed = int(seed)

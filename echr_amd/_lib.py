@@ -37,7 +37,7 @@ class TsrmArgs(C.Structure):
 class TsrmGrads(C.Structure):
     _fields_ = [('g_w_emb', c_f), ('g_b_emb', c_f), ('g_w_fc1', c_f), ('g_b_fc1', c_f), ('g_w_fc2', c_f), ('g_b_fc2', c_f),
                 ('g_w_q', c_f), ('g_b_q', c_f), ('g_w_k', c_f), ('g_b_k', c_f), ('g_w_out', c_f), ('g_b_out', c_f),
-                ('g_ech', c_f), ('g_out', c_f), ('ws_bwd', c_f)]
+                ('g_ech', c_f), ('g_out', c_f), ('ws_bwd', c_f), ('zeroed', i32)]
 
 
 class DecArgs(C.Structure):
@@ -55,7 +55,7 @@ class DecGrads(C.Structure):
                 ('g_w_ih', c_f * 3), ('g_w_hh', c_f * 3), ('g_b_ih', c_f * 3), ('g_b_hh', c_f * 3),
                 ('g_w_c2a', c_f), ('g_b_c2a', c_f), ('g_w_h2a', c_f), ('g_b_h2a', c_f), ('g_w_alpha', c_f), ('g_b_alpha', c_f),
                 ('g_event', c_f), ('g_video', c_f), ('g_logp', c_f),
-                ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f)]
+                ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f), ('zeroed', i32)]
 
 
 class SampleArgs(C.Structure):

@@ -1,0 +1,76 @@
+"""Flat parameter / gradient arena.
+
+Packs every parameter of a module into ONE fp32 device buffer (64-float aligned slots) and gives the backward
+Functions matching views of ONE flat gradient buffer.  What it buys on MI355X:
+  * a single fused clamp+Adam launch over the whole model (echr_clamp_adam streams 7 x 4 B per parameter once)
+    instead of one launch per tensor,
+  * one zero-fill per backward group instead of one per split-K product,
+  * a single-bucket RCCL all-reduce straight on the gradient buffer (no pack/unpack copies).
+Parameter tensors stay ordinary nn.Parameters (state_dict / load_state_dict unchanged); only their storage moves.
+"""
+import torch
+
+ALIGN = 64
+
+
+class ParamArena(object):
+    def __init__(self, module):
+        self.params = [p for p in module.parameters()]
+        if not self.params:
+            raise ValueError('module has no parameters')
+        dev = self.params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self.params):
+            raise ValueError('arena needs all parameters in fp32 on one device (move the module first, then build the arena)')
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.index = {}
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                v = self.flat_p[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v                                     # the Parameter object (and its name) is unchanged
+                p.grad = None
+                self.index[id(p)] = i
+        module._echr_arena = self
+
+    def slot(self, p):
+        return self.index.get(id(p))
+
+    def grad_view(self, i):
+        """A FRESH view tensor of slot i (autograd adopts it as .grad without copying when .grad is None)."""
+        p, o = self.params[i], self.offsets[i]
+        return self.flat_g[o:o + p.numel()].view(p.shape)
+
+    def span(self, idxs):
+        """[start, end) float range from the first to the last of the given slots.  Slots in between that are not listed
+        belong to parameters that never receive a gradient (core.fusion_layer); zero is the right content for them."""
+        lo, hi = min(idxs), max(idxs)
+        end = self.offsets[hi + 1] if hi + 1 < len(self.offsets) else self.total
+        return self.offsets[lo], end
+
+    def grads_in_arena(self):
+        """True when every existing .grad aliases its arena slot (then flat_g IS the model's gradient)."""
+        base = self.flat_g.data_ptr()
+        ok = False
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None:
+                continue
+            if p.grad.data_ptr() != base + 4 * o or not p.grad.is_contiguous():
+                return False
+            ok = True
+        return ok
+
+    def params_in_arena(self):
+        base = self.flat_p.data_ptr()
+        return all(p.data.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
+
+    def zero_unused_grads(self):
+        """Slots whose parameter received no gradient this step must not carry stale values into a flat update."""
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None:
+                self.flat_g[o:o + p.numel()].zero_()

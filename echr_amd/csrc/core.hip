@@ -179,9 +179,10 @@ int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int 
 }
 
 // ---- row log-softmax (in place) ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void logsoftmax_rows_kernel(float* __restrict__ X, long ld, int cols) {
+// rows are (n, t) pairs of a [N,S,cols] tensor restricted to timesteps [t0, t0+nt): block b -> n = b / nt, t = t0 + b % nt
+__global__ __launch_bounds__(256) void logsoftmax_rows_kernel(float* __restrict__ X, long ld, int S, int t0, int nt, int cols) {
     __shared__ float red[4];
-    float* x = X + (long)blockIdx.x * ld;
+    float* x = X + ((long)(blockIdx.x / nt) * S + t0 + blockIdx.x % nt) * ld;
     float m = -INFINITY;
     for (int j = threadIdx.x; j < cols; j += 256) m = fmaxf(m, x[j]);
     m = block_max(m, red);
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(256) void logsoftmax_rows_kernel(float* __restrict_
     const float lse = m + logf(s);
     for (int j = threadIdx.x; j < cols; j += 256) x[j] = x[j] - lse;
 }
-int logsoftmax_rows(float* X, long ld, int rows, int cols, hipStream_t st) {
-    hipLaunchKernelGGL(logsoftmax_rows_kernel, dim3(rows), dim3(256), 0, st, X, ld, cols);
+int logsoftmax_rows(float* X, long ld, int N, int S, int t0, int nt, int cols, hipStream_t st) {
+    hipLaunchKernelGGL(logsoftmax_rows_kernel, dim3(N * nt), dim3(256), 0, st, X, ld, S, t0, nt, cols);
     return check_launch("logsoftmax_rows");
 }
 

@@ -14,6 +14,7 @@
 //  * Time-major internal buffers [S, N, .]; only the log-prob output is written [N, S, V1].
 //  * Because ss_prob == 0 (:36), the token/context halves of every W_ih product are batched over all
 //    S*N rows before the recurrence; only W_hh.h and the attended-context columns are sequential.
+#include <cstdlib>
 #include "echr_common.h"
 #include "echr_internal.h"
 
@@ -35,6 +36,45 @@ DropCfg make_drop(const echr_dropout* d, float p) {
     c.scale = 1.0f / (1.0f - p);
     c.active = (d && d->training && p > 0.f) ? 1 : 0;
     return c;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Side stream: the recurrence is a chain of short, latency-bound launches that leaves most CUs idle, while the
+// late-fusion and weight-gradient products are throughput GEMMs with no dependence on it.  They run on a
+// library-owned low-priority HIP stream, forked from / joined to the caller's stream with events (legal under
+// hipGraph capture).  One process drives one GPU (torch.distributed layout), so a process-wide singleton suffices.
+// ------------------------------------------------------------------------------------------------------
+struct Side {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, half = nullptr, join = nullptr;
+    bool ok = false;
+};
+static Side& side() {
+    static Side sd;
+    if (!sd.s) {
+        int lo = 0, hi = 0;
+        bool good = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+        good = good && hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, lo) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&sd.half, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess;
+        sd.ok = good;
+    }
+    return sd;
+}
+static bool overlap_enabled() {
+    static int v = -1;
+    // measured neutral on the c3 workload (the recurrent GEMM's two 67 KB-LDS workgroups per CU leave no room for a
+    // co-resident throughput GEMM, so the overlap only trades places): opt-in with ECHR_OVERLAP=1
+    if (v < 0) { const char* e = getenv("ECHR_OVERLAP"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1 && side().ok;
+}
+static int hop(hipStream_t from, hipEvent_t ev, hipStream_t to) {      // `to` continues after everything queued on `from`
+    if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
+        set_error("stream fork/join failed");
+        return -5;
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -779,12 +819,26 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
     RC(precompute_static(a, w, st));
     RC(embed_gather(a->embed, a->tokens, w.XT, S * N, E, a->V1, st));
     RC(input_gates(a, w, w.XT, 0, S, st));
-    for (int t = 0; t < S; ++t) RC(step_fwd(a, w, t, dh, dout, st));
-    // late fusion: logits = OUTD . W_logit^T + b, written [N,S,V1]; then row log-softmax in place
-    echr_gemm_desc d = desc_nt(w.OUTD, 3 * H, a->w_logit, 3 * H, a->logp, a->V1, S * N, a->V1, 3 * H);
-    d.bias = a->b_logit; d.rowmap_mod = N; d.rowmap_mul = S;
-    RC(gemm(d, st));
-    RC(logsoftmax_rows(a->logp, a->V1, N * S, a->V1, st));
+    // late fusion: logits = OUTD . W_logit^T + b, written [N,S,V1], then row log-softmax in place.  Timesteps [0,th) are
+    // projected on the side stream while the recurrence of [th,S) is still running.
+    auto logits_chunk = [&](int t0, int t1, hipStream_t q) -> int {
+        echr_gemm_desc d = desc_nt(w.OUTD + (long)t0 * N * 3 * H, 3 * H, a->w_logit, 3 * H, a->logp + (long)t0 * a->V1, a->V1,
+                                   (t1 - t0) * N, a->V1, 3 * H);
+        d.bias = a->b_logit; d.rowmap_mod = N; d.rowmap_mul = S;
+        RC(gemm(d, q));
+        return logsoftmax_rows(a->logp, a->V1, N, S, t0, t1 - t0, a->V1, q);
+    };
+    const bool ov = overlap_enabled() && S >= 4;
+    const int th = ov ? S / 2 : 0;
+    for (int t = 0; t < S; ++t) {
+        RC(step_fwd(a, w, t, dh, dout, st));
+        if (ov && t == th - 1) {
+            RC(hop(st, side().fork, side().s));
+            RC(logits_chunk(0, th, side().s));
+        }
+    }
+    RC(logits_chunk(th, S, st));
+    if (ov) RC(hop(side().s, side().join, st));
     return 0;
 }
 
@@ -799,15 +853,20 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     DecWsBwd b = carve_ws_bwd(a, g->ws_bwd);
     const DropCfg dh = make_drop(drop, drop ? drop->p_h : 0.f), dout = make_drop(drop, drop ? drop->p_out : 0.f);
     const int cin[3] = {E + a->De, E + D, E + a->Dv};
+    const bool z = g->zeroed != 0;             // gradient buffers pre-zeroed by the caller: accumulate, no fills
+    const float zb = z ? 1.f : 0.f;
 
     // 1. d logits (time-major, padded leading dimension)
     if (!g->g_logp) RC(colsum(g->nll_mask, 1, N * S, 1, b.MSUM, false, st));
     RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_mask, g->g_loss, b.MSUM, b.DLG, b.ldg, N, S, V1, st));
-    // 2. late fusion gradients
+    // 2. late fusion gradients: the weight/bias gradients do not feed the recurrence -> side stream
+    const bool ov = overlap_enabled() && S >= 4;
+    hipStream_t sq = ov ? side().s : st;
+    if (ov) RC(hop(st, side().fork, sq));
     echr_gemm_desc d = desc_tn(b.DLG, b.ldg, w.OUTD, 3 * H, g->g_w_logit, 3 * H, V1, 3 * H, SN);
-    d.split_k = -1;
-    RC(gemm(d, st));
-    RC(colsum(b.DLG, b.ldg, SN, V1, g->g_b_logit, false, st));
+    d.beta = zb; d.split_k = -1;
+    RC(gemm(d, sq));
+    RC(colsum(b.DLG, b.ldg, SN, V1, g->g_b_logit, z, sq));
     d = desc_nn(b.DLG, b.ldg, a->w_logit, 3 * H, b.DOUT, 3 * H, SN, 3 * H, V1);
     d.split_k = -1;
     RC(gemm(d, st));
@@ -819,6 +878,29 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     RC(fill_zero(b.DQ, (long)SN * Ha, st));
     const long hs = (long)N * H, as = (long)N * D;
     const int n4h = ksplit_of(4 * H);
+    // weight gradients that are sums over timesteps [t0,t1): W_hh_k, W_ih_k[:, :E], W_ih1[:, E:], W_h2a.
+    // beta = 0 writes, beta = 1 accumulates.  HS[t] holds h(t-1), so rows t*N.. pair with DG[t].
+    auto wgrad_chunk = [&](int t0, int t1, float beta, hipStream_t q) -> int {
+        if (t1 <= t0) return 0;
+        const long r0 = (long)t0 * N;
+        const int rows = (t1 - t0) * N;
+        echr_gemm_desc e;
+        for (int k = 0; k < 3; ++k) {
+            e = desc_tn(b.DG[k] + r0 * 4 * H, 4 * H, w.HS + r0 * 3 * H + k * H, 3 * H, g->g_w_hh[k], H, 4 * H, H, rows);
+            e.beta = beta; e.split_k = -1;
+            RC(gemm(e, q));
+            e = desc_tn(b.DG[k] + r0 * 4 * H, 4 * H, w.XT + r0 * E, E, g->g_w_ih[k], cin[k], 4 * H, E, rows);
+            e.beta = beta; e.split_k = -1;
+            RC(gemm(e, q));
+        }
+        e = desc_tn(b.DG[1] + r0 * 4 * H, 4 * H, w.ATT + r0 * D, D, g->g_w_ih[1] + E, cin[1], 4 * H, D, rows);
+        e.beta = beta; e.split_k = -1;
+        RC(gemm(e, q));
+        e = desc_tn(b.DQ + r0 * Ha, Ha, w.HS + r0 * 3 * H + H, 3 * H, g->g_w_h2a, H, Ha, H, rows);
+        e.beta = beta; e.split_k = -1;
+        return gemm(e, q);
+    };
+    const int th_b = ov ? S / 2 : S;       // timesteps [th_b, S) get their weight gradients on the side stream
     for (int t = S - 1; t >= 0; --t) {
         LstmBwdPtrs P;
         for (int k = 0; k < 3; ++k) {
@@ -853,33 +935,32 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
             ra.job[0] = mkjob(dq, Ha, Ha, b.WT_H2A, Ha, H, b.DHSL[1] + n4h * hs, hs, H);
             RC(rec_gemm(ra, st));
         }
+        if (ov && t == th_b) {     // DG / DQ of timesteps [th_b, S) are final: their weight gradients overlap the rest
+            RC(hop(st, side().half, sq));
+            RC(wgrad_chunk(th_b, S, zb, sq));
+        }
     }
     // 4. batched parameter gradients
     //    attention: d P_all / d alpha over all timesteps, then ctx2att and h2att weights
     RC(fill_zero(b.DPALL, (long)a->Tv * Ha, st));
-    RC(fill_zero(g->g_w_alpha, Ha, st));
-    RC(fill_zero(g->g_b_alpha, 1, st));
+    if (!z) {
+        RC(fill_zero(g->g_w_alpha, Ha, st));
+        RC(fill_zero(g->g_b_alpha, 1, st));
+    }
     {
     ProfScope prof(PROF_ATT_POST, 6.0 * N * A * Ha * S, 4.0 * ((double)N * A * Ha * 2 + (double)S * N * (Ha + A)), st);
     const AttDims ad{N, A, Ha, D};
     RC(launch_att_post(ad, w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, g->g_w_alpha, g->g_b_alpha, S, st));
     }
     d = desc_tn(b.DPALL, Ha, a->c3d, D, g->g_w_c2a, D, Ha, D, a->Tv);
-    d.split_k = -1;
+    d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
-    RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, false, st));
-    d = desc_tn(b.DQ, Ha, w.HS + H, 3 * H, g->g_w_h2a, H, Ha, H, SN);       // HS[t] = h(t-1): rows 0..SN-1
-    d.split_k = -1;
-    RC(gemm(d, st));
-    RC(colsum(b.DQ, Ha, SN, Ha, g->g_b_h2a, false, st));
-    //    LSTM weights
+    RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
+    //    LSTM / h2att weights: sums over timesteps, done in two chunks (see wgrad_chunk)
+    if (ov) RC(hop(sq, side().join, st));                     // chunk [th,S) and the logit gradients are complete
+    RC(wgrad_chunk(0, th_b, (ov || z) ? 1.f : 0.f, st));
+    RC(colsum(b.DQ, Ha, SN, Ha, g->g_b_h2a, z, st));
     for (int k = 0; k < 3; ++k) {
-        d = desc_tn(b.DG[k], 4 * H, w.HS + k * H, 3 * H, g->g_w_hh[k], H, 4 * H, H, SN);
-        d.split_k = -1;
-        RC(gemm(d, st));
-        d = desc_tn(b.DG[k], 4 * H, w.XT, E, g->g_w_ih[k], cin[k], 4 * H, E, SN);
-        d.split_k = -1;
-        RC(gemm(d, st));
         RC(sum_over_time(b.DG[k], 4 * H, S, N, 4 * H, b.DGSUM[k], 4 * H, st));
         RC(colsum(b.DGSUM[k], 4 * H, N, 4 * H, b.DGCOL[k], false, st));
         RC(hipMemcpyAsync(g->g_b_ih[k], b.DGCOL[k], sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : -5);
@@ -887,12 +968,9 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     }
     //    context halves of W_ih: event (stream 0), attended clip (stream 1), video (stream 2)
     d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);
-    d.split_k = -1;
+    d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
     d = desc_nn(b.DGSUM[0], 4 * H, a->w_ih[0] + E, cin[0], g->g_event, a->De, N, a->De, 4 * H);
-    d.split_k = -1;
-    RC(gemm(d, st));
-    d = desc_tn(b.DG[1], 4 * H, w.ATT, D, g->g_w_ih[1] + E, cin[1], 4 * H, D, SN);
     d.split_k = -1;
     RC(gemm(d, st));
     d = desc_tn(b.DGCOL[2], 4 * H, a->video, a->Dv, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, 1);

@@ -47,7 +47,7 @@ int fill_zero(float* p, long n, hipStream_t st);
 int fill_zero_2d(float* p, int rows, int cols, long ld, hipStream_t st);
 int embed_gather(const float* W, const int* tok, float* out, int rows, int E, int V1, hipStream_t st);
 int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st);
-int logsoftmax_rows(float* X, long ld, int rows, int cols, hipStream_t st);
+int logsoftmax_rows(float* X, long ld, int N, int S, int t0, int nt, int cols, hipStream_t st);
 int logsoftmax_bwd(const float* logp, const float* G, const int* target, const float* mask, const float* g_loss,
                    const float* mask_sum, float* out, long ldo, int N, int S, int V1, hipStream_t st);
 int greedy_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,

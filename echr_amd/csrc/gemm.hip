@@ -39,6 +39,15 @@ struct GemmParams {
 template <int BMN, bool KC>
 __device__ __forceinline__ void load_tile(float4 (&r)[BMN / 32], const float* __restrict__ P, long s_mn, long s_k,
                                           int mn0, int k0, int MN, int K, int kend, bool vec, int tid) {
+    if (vec && mn0 + BMN <= MN && k0 + BK <= kend) {      // interior tile: unconditional 16-byte loads, all in flight together
+#pragma unroll
+        for (int p = 0; p < BMN / 32; ++p) {
+            const int f = tid + p * 256;
+            if (KC) r[p] = *reinterpret_cast<const float4*>(P + (long)(mn0 + f / (BK / 4)) * s_mn + k0 + 4 * (f % (BK / 4)));
+            else    r[p] = *reinterpret_cast<const float4*>(P + (long)(k0 + f / (BMN / 4)) * s_k + mn0 + 4 * (f % (BMN / 4)));
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < BMN / 32; ++p) {
         int f = tid + p * 256;
@@ -140,20 +149,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[BM / 32], rb[BN / 32];
+    // two register sets: the tile written to LDS at step kt was requested two compute phases earlier
+    float4 ra0[BM / 32], rb0[BN / 32], ra1[BM / 32], rb1[BN / 32];
     if (kt0 < kt1) {
-        load_tile<BM, AKC>(ra, A, p.sam, p.sak, m0, kt0 * BK, p.M, p.K, kend, p.vecA, tid);
-        load_tile<BN, BKC>(rb, B, p.sbn, p.sbk, n0, kt0 * BK, p.N, p.K, kend, p.vecB, tid);
+        load_tile<BM, AKC>(ra0, A, p.sam, p.sak, m0, kt0 * BK, p.M, p.K, kend, p.vecA, tid);
+        load_tile<BN, BKC>(rb0, B, p.sbn, p.sbk, n0, kt0 * BK, p.N, p.K, kend, p.vecB, tid);
+    }
+    if (kt0 + 1 < kt1) {
+        load_tile<BM, AKC>(ra1, A, p.sam, p.sak, m0, (kt0 + 1) * BK, p.M, p.K, kend, p.vecA, tid);
+        load_tile<BN, BKC>(rb1, B, p.sbn, p.sbk, n0, (kt0 + 1) * BK, p.N, p.K, kend, p.vecB, tid);
     }
     const int khalf = lane >> 5, l31 = lane & 31;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        store_tile<BM, AKC>(ra, As, tid);
-        store_tile<BN, BKC>(rb, Bs, tid);
-        __syncthreads();
-        if (kt + 1 < kt1) {
-            load_tile<BM, AKC>(ra, A, p.sam, p.sak, m0, (kt + 1) * BK, p.M, p.K, kend, p.vecA, tid);
-            load_tile<BN, BKC>(rb, B, p.sbn, p.sbk, n0, (kt + 1) * BK, p.N, p.K, kend, p.vecB, tid);
-        }
+    auto compute = [&]() {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             float a[TM], bb[TN];
@@ -167,7 +174,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
+    };
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        store_tile<BM, AKC>(ra0, As, tid);
+        store_tile<BN, BKC>(rb0, Bs, tid);
         __syncthreads();
+        if (kt + 2 < kt1) {
+            load_tile<BM, AKC>(ra0, A, p.sam, p.sak, m0, (kt + 2) * BK, p.M, p.K, kend, p.vecA, tid);
+            load_tile<BN, BKC>(rb0, B, p.sbn, p.sbk, n0, (kt + 2) * BK, p.N, p.K, kend, p.vecB, tid);
+        }
+        compute();
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            store_tile<BM, AKC>(ra1, As, tid);
+            store_tile<BN, BKC>(rb1, Bs, tid);
+            __syncthreads();
+            if (kt + 3 < kt1) {
+                load_tile<BM, AKC>(ra1, A, p.sam, p.sak, m0, (kt + 3) * BK, p.M, p.K, kend, p.vecA, tid);
+                load_tile<BN, BKC>(rb1, B, p.sbn, p.sbk, n0, (kt + 3) * BK, p.N, p.K, kend, p.vecB, tid);
+            }
+            compute();
+            __syncthreads();
+        }
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
@@ -258,9 +286,11 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     if (split < 0) {  // auto: fill ~2 waves of workgroups over the chip when the output grid is small
         long wgs = (long)p.tiles_m * p.tiles_n * d.batch;
         split = 1;
-        if (d.act == ECHR_ACT_NONE && wgs < 256 && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
-            split = (int)min((long)kt_total, max(1L, 512 / max(wgs, 1L)));
-            if (split > 1 && kt_total / split < 2) split = max(1, kt_total / 2);
+        // latency-bound regime: fewer than ~3 workgroups per CU.  Split K so that ~768 workgroups overlap each other's
+        // load latency, keeping at least 4 k-tiles (128 deep) per split.
+        if (d.act == ECHR_ACT_NONE && wgs < 640 && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
+            split = (int)min((long)kt_total, max(1L, (768 + wgs - 1) / max(wgs, 1L)));
+            if (split > 1 && kt_total / split < 4) split = max(1, kt_total / 4);
         }
     }
     if (split < 1) split = 1;

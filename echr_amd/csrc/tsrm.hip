@@ -189,7 +189,9 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     TsrmWs w = carve(N, Din, Df, Do, G, a->ws);
     TsrmWsB b = carve_b(N, Din, Df, Do, G, g->ws_bwd);
     echr_gemm_desc d;
-    RC(colsum(g->g_out, Do, N, Do, g->g_b_out, false, st));
+    const bool z = g->zeroed != 0;             // gradient buffers pre-zeroed by the caller: accumulate, no fills
+    const float zb = z ? 1.f : 0.f;
+    RC(colsum(g->g_out, Do, N, Do, g->g_b_out, z, st));
     // dWD_g = dOUT_g . XW_g^T ; dXW_g = WD_g^T . dOUT_g
     d = desc_nt(g->g_out, Do, w.XW, Do, b.DWD, N, N, N, dgo);
     d.batch = G; d.bsa = dgo; d.bsb = dgo; d.bsc = (long)NN;
@@ -215,27 +217,27 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     d = desc_nn(b.DXW, Do, a->w_out, Df, b.DX, Df, N, Df, Do); d.beta = 1.f; d.split_k = -1;
     RC(gemm(d, st));
     // projection weights
-    d = desc_tn(b.DQ, Df, w.X, Df, g->g_w_q, Df, Df, Df, N); d.split_k = -1;
+    d = desc_tn(b.DQ, Df, w.X, Df, g->g_w_q, Df, Df, Df, N); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
-    RC(colsum(b.DQ, Df, N, Df, g->g_b_q, false, st));
-    d = desc_tn(b.DK, Df, w.X, Df, g->g_w_k, Df, Df, Df, N); d.split_k = -1;
+    RC(colsum(b.DQ, Df, N, Df, g->g_b_q, z, st));
+    d = desc_tn(b.DK, Df, w.X, Df, g->g_w_k, Df, Df, Df, N); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
-    RC(colsum(b.DK, Df, N, Df, g->g_b_k, false, st));
-    d = desc_tn(b.DXW, Do, w.X, Df, g->g_w_out, Df, Do, Df, N); d.split_k = -1;
+    RC(colsum(b.DK, Df, N, Df, g->g_b_k, z, st));
+    d = desc_tn(b.DXW, Do, w.X, Df, g->g_w_out, Df, Do, Df, N); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
     // position MLP
-    d = desc_tn(b.DGATE, G, w.P1, Df, g->g_w_fc2, Df, G, Df, NN); d.split_k = -1;
+    d = desc_tn(b.DGATE, G, w.P1, Df, g->g_w_fc2, Df, G, Df, NN); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
-    RC(colsum(b.DGATE, G, NN, G, g->g_b_fc2, false, st));
+    RC(colsum(b.DGATE, G, NN, G, g->g_b_fc2, z, st));
     d = desc_nn(b.DGATE, G, a->w_fc2, Df, b.DP1, Df, NN, Df, G); d.act = ECHR_ACT_MUL_DTANH; d.aux = w.P1; d.ld_aux = Df;
     RC(gemm(d, st));
-    d = desc_tn(b.DP1, Df, w.POS, Df, g->g_w_fc1, Df, Df, Df, NN); d.split_k = -1;
+    d = desc_tn(b.DP1, Df, w.POS, Df, g->g_w_fc1, Df, Df, Df, NN); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
-    RC(colsum(b.DP1, Df, NN, Df, g->g_b_fc1, false, st));
+    RC(colsum(b.DP1, Df, NN, Df, g->g_b_fc1, z, st));
     // event embedding
-    d = desc_tn(b.DX, Df, a->ech, Din, g->g_w_emb, Din, Df, Din, N); d.split_k = -1;
+    d = desc_tn(b.DX, Df, a->ech, Din, g->g_w_emb, Din, Df, Din, N); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
-    RC(colsum(b.DX, Df, N, Df, g->g_b_emb, false, st));
+    RC(colsum(b.DX, Df, N, Df, g->g_b_emb, z, st));
     if (g->g_ech) {
         d = desc_nn(b.DX, Df, a->w_emb, Din, g->g_ech, Din, N, Din, Df); d.split_k = -1;
         RC(gemm(d, st));

@@ -45,6 +45,27 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+class GradSink(object):
+    """Where a backward Function should write its parameter gradients: the module's flat arena (echr_amd/arena.py).
+
+    Used only when EVERY parameter of the group currently has .grad None -- then the Function zero-fills the group's span
+    once, lets the library accumulate into it (`zeroed` = 1) and returns fresh arena views that autograd adopts as .grad
+    without a copy.  If any .grad already exists (gradient accumulation) the Function falls back to private buffers so
+    that autograd's `grad += new` sees two distinct tensors."""
+
+    def __init__(self, arena, params):
+        self.arena, self.params = arena, list(params)
+        self.slots = [arena.slot(p) for p in self.params]
+
+    def usable(self):
+        return all(s is not None for s in self.slots) and all(p.grad is None for p in self.params)
+
+    def take(self):
+        lo, hi = self.arena.span(self.slots)
+        self.arena.flat_g[lo:hi].zero_()
+        return [self.arena.grad_view(s) for s in self.slots]
+
+
 # --------------------------------------------------------------------------------------------------
 class EventPoolGather(torch.autograd.Function):
     """ech = [mean-pooled C3D rows | tap[ind]]  (CaptionGenerator.py:111-114,121,128)."""
@@ -82,8 +103,9 @@ class TSRMFunction(torch.autograd.Function):
     """MA_Attention8.forward (MA_attention_8_NEW.py:35-49, :101-177)."""
 
     @staticmethod
-    def forward(ctx, ech, ev_start, ev_len, n_head, drop, *params):
+    def forward(ctx, ech, ev_start, ev_len, n_head, drop, sink, *params):
         lib = L.load()
+        ctx.sink = sink
         ech = _f32c(ech)
         ps = [_f32c(p) for p in params]
         N, Din = ech.shape
@@ -104,15 +126,18 @@ class TSRMFunction(torch.autograd.Function):
         ech, ev_start, ev_len, ws, out, *ps = ctx.saved_tensors
         N, Din, Df, Do, G, drop = ctx.meta
         g_out = _f32c(g_out)
-        grads = [torch.empty_like(p) for p in ps]
+        zeroed = 1 if (ctx.sink is not None and ctx.sink.usable()) else 0
+        grads = ctx.sink.take() if zeroed else [torch.empty_like(p) for p in ps]
+        if zeroed:
+            grads[10] = grads[10].view(ps[10].shape)              # linear_out_1.weight [d_o, d_feats, 1, 1] -> [d_o, d_feats]
         g_ech = torch.empty_like(ech)
         wsb = torch.empty(lib.echr_tsrm_ws_bwd_floats(N, Din, Df, Do, G), device=ech.device, dtype=torch.float32)
         a = L.TsrmArgs(N, Din, Df, Do, G, *[L.ptr(p) for p in ps], L.ptr(ech), L.ptr(ev_start, torch.int32),
                        L.ptr(ev_len, torch.int32), L.ptr(ws), L.ptr(out))
-        g = L.TsrmGrads(*[L.ptr(x) for x in grads], L.ptr(g_ech), L.ptr(g_out), L.ptr(wsb))
+        g = L.TsrmGrads(*[L.ptr(x) for x in grads], L.ptr(g_ech), L.ptr(g_out), L.ptr(wsb), zeroed)
         d = drop.c()
         L.check(lib.echr_tsrm_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'tsrm_bwd')
-        return (g_ech, None, None, None, None) + tuple(grads)
+        return (g_ech, None, None, None, None, None) + tuple(grads)
 
 
 def position_embedding(ev_start, ev_len, d_pos):
@@ -156,8 +181,9 @@ class DecoderFunction(torch.autograd.Function):
     """OldModel.forward with the ThreeStream core (OldModel_NEW.py:98-137, :376-401, :801-823): log-probs [N,S,V1]."""
 
     @staticmethod
-    def forward(ctx, video, event, c3d, ev_start, ev_len, tokens, A, drop, *params):
+    def forward(ctx, video, event, c3d, ev_start, ev_len, tokens, A, drop, sink, *params):
         lib = L.load()
+        ctx.sink = sink
         video, event, c3d = _f32c(video), _f32c(event), _f32c(c3d)
         ps = [_f32c(p) for p in params]
         S, N = tokens.shape
@@ -178,8 +204,12 @@ class DecoderFunction(torch.autograd.Function):
         video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps = ctx.saved_tensors
         A, S, drop = ctx.meta
         g_logp = _f32c(g_logp)
-        grads = [torch.empty_like(p) for p in ps]
-        grads[0].zero_()                                     # embedding table gradient is scatter-added
+        zeroed = 1 if (ctx.sink is not None and ctx.sink.usable()) else 0
+        if zeroed:
+            grads = ctx.sink.take()
+        else:
+            grads = [torch.empty_like(p) for p in ps]
+            grads[0].zero_()                                 # embedding table gradient is scatter-added
         g_event = torch.empty_like(event)
         g_video = torch.empty_like(video) if ctx.needs_input_grad[0] else None
         a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp)
@@ -187,10 +217,10 @@ class DecoderFunction(torch.autograd.Function):
         gp = [L.ptr(x) for x in grads]
         g = L.DecGrads(gp[0], gp[1], gp[2], (L.c_f * 3)(*gp[3:6]), (L.c_f * 3)(*gp[6:9]), (L.c_f * 3)(*gp[9:12]),
                        (L.c_f * 3)(*gp[12:15]), gp[15], gp[16], gp[17], gp[18], gp[19], gp[20],
-                       L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp), None, None, None, L.ptr(wsb))
+                       L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp), None, None, None, L.ptr(wsb), zeroed)
         d = drop.c()
         L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
-        return (g_video, g_event, None, None, None, None, None, None) + tuple(grads)
+        return (g_video, g_event, None, None, None, None, None, None, None) + tuple(grads)
 
 
 def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params):

@@ -55,7 +55,16 @@ class MA_Attention8(nn.Module):
             ev_start, ev_len = ev_tensors
         if drop is None:
             drop = EF.DropState(training=False)
-        return EF.TSRMFunction.apply(feats, ev_start, ev_len, self.enc_attn.group, drop, *self.native_params())
+        return EF.TSRMFunction.apply(feats, ev_start, ev_len, self.enc_attn.group, drop, self._grad_sink(), *self.native_params())
+
+    def _grad_sink(self):
+        arena = getattr(self, '_echr_arena_ref', None)
+        if arena is None:
+            return None
+        e = self.enc_attn
+        return EF.GradSink(arena, (self.event_emb.weight, self.event_emb.bias, e.pair_pos_fc1.weight, e.pair_pos_fc1.bias,
+                                   e.pair_pos_fc2.weight, e.pair_pos_fc2.bias, e.query_1.weight, e.query_1.bias,
+                                   e.key_1.weight, e.key_1.bias, e.linear_out_1.weight, e.linear_out_1.bias))
 
     @staticmethod
     def extract_position_matrix(bbox, nongt_dim):

@@ -136,7 +136,9 @@ class OldModel(nn.Module):
         tokens = seq_t[:, :S].t().to(device=dev, dtype=torch.int32).contiguous()          # [S,N] time-major
         if drop is None:
             drop = self.next_drop_state()
-        return EF.DecoderFunction.apply(video, event, cv.feats, cv.ev_start, cv.ev_len, tokens, cv.max_len, drop,
+        arena = getattr(self, '_echr_arena_ref', None)
+        sink = EF.GradSink(arena, self.native_params()) if arena is not None else None
+        return EF.DecoderFunction.apply(video, event, cv.feats, cv.ev_start, cv.ev_len, tokens, cv.max_len, drop, sink,
                                         *self.native_params())
 
     def get_logprobs_state(self, it, video, event, clip, clip_mask, state):

@@ -11,18 +11,43 @@ class ClampAdam(torch.optim.Optimizer):
     Parameters whose .grad is None are skipped like torch.optim.Adam does (the reference model has two
     never-used parameter groups: core.fusion_layer and fusion_model.h2a_layer)."""
 
-    def __init__(self, params, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_clip=None):
+    def __init__(self, params, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_clip=None, arena=None):
         if weight_decay != 0:
             raise NotImplementedError('the ECHR recipe uses weight_decay=0 (opts.py:215)')
         super(ClampAdam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_clip = grad_clip
         self.pending_clip = None
+        self.arena = arena            # echr_amd.arena.ParamArena: one launch over the whole model when gradients live there
+        self._flat = None
+
+    def _flat_step(self, clip):
+        """Whole-model update in ONE kernel launch; valid when all parameters and all live gradients alias the arena."""
+        ar = self.arena
+        if ar is None or len(self.param_groups) != 1 or not ar.params_in_arena() or not ar.grads_in_arena():
+            return False
+        if {id(p) for p in self.param_groups[0]['params']} != {id(p) for p in ar.params}:
+            return False
+        group = self.param_groups[0]
+        if self._flat is None:
+            if any(self.state[p] for p in ar.params):
+                return False                  # per-tensor state already exists (resumed run): keep the per-tensor path
+            self._flat = dict(step=0, m=torch.zeros_like(ar.flat_p), v=torch.zeros_like(ar.flat_p))
+        ar.zero_unused_grads()                # never-used parameters: g = 0 -> m = v = 0 -> no update (== Adam skipping them)
+        st = self._flat
+        st['step'] += 1
+        b1, b2 = group['betas']
+        EF.clamp_adam_(ar.flat_p, ar.flat_g, st['m'], st['v'], st['step'], group['lr'], b1, b2, group['eps'], clip)
+        return True
 
     @torch.no_grad()
     def step(self, closure=None):
         clip = self.pending_clip if self.pending_clip is not None else self.grad_clip
         self.pending_clip = None
         clip = float('inf') if clip is None else float(clip)
+        if self._flat_step(clip):
+            return None
+        if self._flat is not None:
+            raise RuntimeError('ClampAdam: gradients left the flat arena after flat optimiser state was created')
         for group in self.param_groups:
             b1, b2 = group['betas']
             for p in group['params']:

@@ -20,6 +20,12 @@ def allreduce_gradients(module, group=None, bucket_bytes=64 << 20):
     """Sum the gradients over ranks in a few large flat buckets (xGMI is point-to-point: few large messages)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0
+    arena = getattr(module, '_echr_arena', None)
+    if arena is not None and arena.grads_in_arena():
+        # the flat gradient buffer IS the bucket: one collective, no pack/unpack copies
+        arena.zero_unused_grads()
+        dist.all_reduce(arena.flat_g, op=dist.ReduceOp.SUM, group=group)
+        return 1
     params = live_grads(module)
     buckets, cur, cur_bytes = [], [], 0
     for p in params:

@@ -114,11 +114,13 @@ typedef struct {
 } echr_tsrm_args;
 
 typedef struct {
-    /* parameter gradients (written, not accumulated) */
+    /* parameter gradients (written, not accumulated, unless `zeroed`) */
     float *g_w_emb, *g_b_emb, *g_w_fc1, *g_b_fc1, *g_w_fc2, *g_b_fc2, *g_w_q, *g_b_q, *g_w_k, *g_b_k, *g_w_out, *g_b_out;
     float* g_ech;                    /* [N,Din] */
     const float* g_out;              /* [N,Do] */
     float* ws_bwd;                   /* scratch, echr_tsrm_ws_bwd_floats */
+    int32_t zeroed;                  /* 1: the caller zero-filled every parameter-gradient buffer (flat arena): the
+                                        library accumulates into them and skips its own zero fills */
 } echr_tsrm_grads;
 
 int64_t echr_tsrm_ws_floats(int32_t N, int32_t Din, int32_t Df, int32_t Do, int32_t G);
@@ -175,6 +177,7 @@ typedef struct {
     const float* nll_mask;                     /* [N,S] */
     const float* g_loss;                       /* device scalar */
     float* ws_bwd;                             /* scratch, echr_decoder_ws_bwd_floats */
+    int32_t zeroed;                            /* 1: parameter-gradient buffers arrive zero-filled (see echr_tsrm_grads) */
 } echr_dec_grads;
 
 int64_t echr_decoder_ws_floats(const echr_dec_args* a);

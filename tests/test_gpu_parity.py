@@ -224,3 +224,50 @@ def test_cpu_tensors_fail_loudly():
     with pytest.raises(EchrHipError):
         m(torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), torch.from_numpy(vid['labels']),
           vid['ind'], vid['soi'], mode='train')
+
+
+@pytest.mark.parametrize('case', ['tiny', 'c1'])
+def test_flat_arena_path_matches_per_tensor_path(case):
+    """build_arena(): gradients land in the flat buffer (adopted as .grad without copies) and equal the per-tensor path's;
+    the single-launch fused optimiser step equals the per-tensor one on identical gradients; a second backward without
+    zero_grad accumulates instead of aliasing."""
+    from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+    from echr_amd.optim import ClampAdam
+    opt, params, vid = synth.make_case(case)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels = torch.from_numpy(vid['labels'])
+    tgt, msk = labels[:, 1:].to(dev), torch.from_numpy(vid['masks'])[:, 1:].to(dev)
+
+    def backward(m, off):
+        m.set_dropout_state(U.SEED, off)
+        LanguageModelCriterion()(m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), tgt, msk).backward()
+
+    ma, mb = U.build_gpu_model(opt, params, True), U.build_gpu_model(opt, params, True)
+    arena = ma.build_arena()
+    for k, v in ma.state_dict().items():
+        assert torch.equal(v.cpu(), torch.from_numpy(params[k])), k          # packing kept every value
+    oa = ClampAdam(ma.parameters(), lr=1e-3, arena=arena)
+    ob = ClampAdam(mb.parameters(), lr=1e-3)
+    for it in range(2):
+        oa.zero_grad(); ob.zero_grad()
+        backward(ma, U.OFFSET + it); backward(mb, U.OFFSET + it)
+        assert arena.grads_in_arena()
+        for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert (pa.grad is None) == (pb.grad is None), k
+            if pa.grad is not None:
+                assert U.grad_close(k, pa.grad.cpu().numpy(), pb.grad.cpu().numpy(), 1e-4), k
+                pb.grad.copy_(pa.grad)                                       # identical inputs for the optimiser comparison
+        clip_gradient(oa, 0.05); clip_gradient(ob, 0.05)
+        oa.step(); ob.step()
+        for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert float((pa.detach() - pb.detach()).abs().max()) < 1e-7, k
+    assert oa._flat is not None and oa._flat['step'] == 2 and ob._flat is None and ob.state[mb.lm_model.embed.weight]['step'] == 2
+    # gradient accumulation: two backward passes without zero_grad == twice the single gradient
+    oa.zero_grad()
+    backward(ma, U.OFFSET + 9)
+    g1 = {k: p.grad.detach().clone() for k, p in ma.named_parameters() if p.grad is not None}
+    backward(ma, U.OFFSET + 9)
+    for k, p in ma.named_parameters():
+        if p.grad is not None:
+            assert U.grad_close(k, p.grad.cpu().numpy(), 2 * g1[k].cpu().numpy(), 1e-4), k
