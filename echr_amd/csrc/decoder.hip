@@ -84,11 +84,10 @@ static int hop(hipStream_t from, hipEvent_t ev, hipStream_t to) {      // `to` c
 // R  = float4 per lane per P_all row (ceil(Ha/256)), RD = float4 per lane per clip row (ceil(D/256)).
 // ------------------------------------------------------------------------------------------------------
 constexpr int MAXR = 4;   // Ha, D <= 1024
-constexpr int SLOTS = 8;  // slots per wave
 
 // score kernel: grid (N, ceil(A/32)): e[n,a] = alpha . tanh(P_all[start+a] + q[n]) + b_alpha.
 // q[n,:] = b_h2a + sum of the split-K partial slabs of h1_prev . W_h^T (rec_gemm); block y==0 keeps it in QS for backward.
-template <int R>
+template <int R, int SLOTS>
 __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict__ PALL, const float* __restrict__ QSL, int nslab,
                                                         long slab_stride, const float* __restrict__ b_q, float* __restrict__ QS,
                                                         const float* __restrict__ alpha, const float* __restrict__ b_alpha,
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(256) void att_score_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sq = sm;          // [Ha]
     float* sa = sm + Ha;     // [Ha]
-    const int n = blockIdx.x, a0 = blockIdx.y * 32;
+    const int n = blockIdx.x, a0 = blockIdx.y * (4 * SLOTS);
     const int len = ev_len[n];
     if (a0 >= len) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(256) void att_context_kernel(const float* __restric
 //   dscore_a = w_a * (clip_a . dATT - ATT . dATT);  dq += sum_a dscore_a * alpha * (1 - tanh^2(P_a + q))
 // dATT arrives as split-K slabs (rec_gemm).  DSC keeps dscore for the post-recurrence pass that accumulates d P_all and
 // d alpha over all timesteps (that pass recomputes tanh instead of updating an [N,A,Ha] accumulator every step).
-template <int R, int RD>
+template <int R, int RD, int SLOTS>
 __global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ PALL, const float* __restrict__ C3D,
                                                       const float* __restrict__ Q, const float* __restrict__ alpha,
                                                       const float* __restrict__ WT, const float* __restrict__ ATT,
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ 
     float* sd = sa + Ha;            // [D4] dATT row
     float* red = sd + D4;           // [4][Ha]
     __shared__ float r4[4];
-    const int n = blockIdx.x, a0 = blockIdx.y * 32;
+    const int n = blockIdx.x, a0 = blockIdx.y * (4 * SLOTS);
     const int len = ev_len[n];
     if (a0 >= len) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -395,30 +394,41 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
 // ---- launch helpers (dispatch on the per-lane row widths) ------------------------------------------------
 struct AttDims { int N, A, Ha, D; };
 
+static int att_slots() {     // slots per wave (2, 4 or 8): tuning knob, default chosen from measurements on the c3 workload
+    static int v = 0;
+    if (!v) { const char* e = getenv("ECHR_ATT_SLOTS"); v = e ? atoi(e) : 2; if (v != 2 && v != 4 && v != 8) v = 2; }
+    return v;
+}
+
 static int launch_att_score(const AttDims& d, const float* PALL, const float* QSL, int nslab, long slab_stride, const float* b_q,
                             float* QS, const float* alpha, const float* b_alpha, const int* ev_start, const int* ev_len, float* SC,
                             hipStream_t st) {
-    const dim3 grid(d.N, (d.A + 31) / 32), blk(256);
+    const int SL = att_slots();
+    const dim3 grid(d.N, (d.A + 4 * SL - 1) / (4 * SL)), blk(256);
     const size_t sm = 2 * d.Ha * sizeof(float);
-    switch ((d.Ha + 255) / 256) {
-#define ECHR_CASE(R) case R: hipLaunchKernelGGL((att_score_kernel<R>), grid, blk, sm, st, PALL, QSL, nslab, slab_stride, b_q, QS, alpha, b_alpha, ev_start, ev_len, SC, d.A, d.Ha); break;
-        ECHR_CASE(1) ECHR_CASE(2) ECHR_CASE(3) ECHR_CASE(4)
+    const int R = (d.Ha + 255) / 256;
+#define ECHR_CASE(RR, SS) if (R == RR && SL == SS) { hipLaunchKernelGGL((att_score_kernel<RR, SS>), grid, blk, sm, st, PALL, QSL, nslab, slab_stride, b_q, QS, alpha, b_alpha, ev_start, ev_len, SC, d.A, d.Ha); return check_launch("att_score"); }
+    ECHR_CASE(1, 2) ECHR_CASE(2, 2) ECHR_CASE(3, 2) ECHR_CASE(4, 2)
+    ECHR_CASE(1, 4) ECHR_CASE(2, 4) ECHR_CASE(3, 4) ECHR_CASE(4, 4)
+    ECHR_CASE(1, 8) ECHR_CASE(2, 8) ECHR_CASE(3, 8) ECHR_CASE(4, 8)
 #undef ECHR_CASE
-        default: set_error("att_score: Ha too large"); return -22;
-    }
-    return check_launch("att_score");
+    set_error("att_score: Ha too large");
+    return -22;
 }
 
 static int launch_att_bwd(const AttDims& d, const float* PALL, const float* C3D, const float* Q, const float* alpha, const float* WT,
                           const float* ATT, const float* DAS, int nslab, long slab_stride, const int* ev_start, const int* ev_len,
                           float* DSC, float* DQ, hipStream_t st) {
-    const dim3 grid(d.N, (d.A + 31) / 32), blk(256);
+    const int SL = att_slots();
+    const dim3 grid(d.N, (d.A + 4 * SL - 1) / (4 * SL)), blk(256);
     const size_t sm = (6 * d.Ha + ((d.D + 3) & ~3)) * sizeof(float);
     const int R = (d.Ha + 255) / 256, RD = (d.D + 255) / 256;
-#define ECHR_CASE(RR, RRD) if (R == RR && RD == RRD) { hipLaunchKernelGGL((att_bwd_kernel<RR, RRD>), grid, blk, sm, st, PALL, C3D, Q, alpha, WT, ATT, DAS, nslab, slab_stride, ev_start, ev_len, DSC, DQ, d.A, d.Ha, d.D); return check_launch("att_bwd"); }
+#define ECHR_CASE3(RR, RRD, SS) if (R == RR && RD == RRD && SL == SS) { hipLaunchKernelGGL((att_bwd_kernel<RR, RRD, SS>), grid, blk, sm, st, PALL, C3D, Q, alpha, WT, ATT, DAS, nslab, slab_stride, ev_start, ev_len, DSC, DQ, d.A, d.Ha, d.D); return check_launch("att_bwd"); }
+#define ECHR_CASE(RR, RRD) ECHR_CASE3(RR, RRD, 2) ECHR_CASE3(RR, RRD, 4) ECHR_CASE3(RR, RRD, 8)
     ECHR_CASE(1, 1) ECHR_CASE(1, 2) ECHR_CASE(2, 1) ECHR_CASE(2, 2) ECHR_CASE(2, 3) ECHR_CASE(2, 4) ECHR_CASE(3, 2) ECHR_CASE(4, 2)
     ECHR_CASE(1, 3) ECHR_CASE(1, 4) ECHR_CASE(3, 1) ECHR_CASE(3, 3) ECHR_CASE(3, 4) ECHR_CASE(4, 1) ECHR_CASE(4, 3) ECHR_CASE(4, 4)
 #undef ECHR_CASE
+#undef ECHR_CASE3
     set_error("att_bwd: Ha or D too large");
     return -22;
 }

@@ -11,6 +11,7 @@
 // LDS tiles are stored k-major ([BK][BM+pad]) so the 32 lanes of a half-wave read 32 consecutive
 // floats (conflict-free ds_read_b32); pad = 1 when the tile is filled by transposing float4 loads
 // along k (scatter of b32 writes, conflict-free at stride BM+1), pad = 4 when filled along m (b128 writes).
+#include <cstdlib>
 #include "echr_common.h"
 #include "echr_internal.h"
 
@@ -36,21 +37,21 @@ struct GemmParams {
 };
 
 // Fill registers with one [BMN x BK] operand tile.  KC: k is the contiguous axis of the source.
-template <int BMN, bool KC>
-__device__ __forceinline__ void load_tile(float4 (&r)[BMN / 32], const float* __restrict__ P, long s_mn, long s_k,
+template <int BMN, bool KC, int NT>
+__device__ __forceinline__ void load_tile(float4 (&r)[BMN * 8 / NT], const float* __restrict__ P, long s_mn, long s_k,
                                           int mn0, int k0, int MN, int K, int kend, bool vec, int tid) {
     if (vec && mn0 + BMN <= MN && k0 + BK <= kend) {      // interior tile: unconditional 16-byte loads, all in flight together
 #pragma unroll
-        for (int p = 0; p < BMN / 32; ++p) {
-            const int f = tid + p * 256;
+        for (int p = 0; p < BMN * 8 / NT; ++p) {
+            const int f = tid + p * NT;
             if (KC) r[p] = *reinterpret_cast<const float4*>(P + (long)(mn0 + f / (BK / 4)) * s_mn + k0 + 4 * (f % (BK / 4)));
             else    r[p] = *reinterpret_cast<const float4*>(P + (long)(k0 + f / (BMN / 4)) * s_k + mn0 + 4 * (f % (BMN / 4)));
         }
         return;
     }
 #pragma unroll
-    for (int p = 0; p < BMN / 32; ++p) {
-        int f = tid + p * 256;
+    for (int p = 0; p < BMN * 8 / NT; ++p) {
+        int f = tid + p * NT;
         int mn, k;
         if (KC) { mn = mn0 + f / (BK / 4); k = k0 + 4 * (f % (BK / 4)); }
         else    { k = k0 + f / (BMN / 4); mn = mn0 + 4 * (f % (BMN / 4)); }
@@ -82,12 +83,12 @@ __device__ __forceinline__ void load_tile(float4 (&r)[BMN / 32], const float* __
     }
 }
 
-template <int BMN, bool KC>
-__device__ __forceinline__ void store_tile(const float4 (&r)[BMN / 32], float* __restrict__ S, int tid) {
+template <int BMN, bool KC, int NT>
+__device__ __forceinline__ void store_tile(const float4 (&r)[BMN * 8 / NT], float* __restrict__ S, int tid) {
     constexpr int LD = BMN + (KC ? 1 : 4);
 #pragma unroll
-    for (int p = 0; p < BMN / 32; ++p) {
-        int f = tid + p * 256;
+    for (int p = 0; p < BMN * 8 / NT; ++p) {
+        int f = tid + p * NT;
         if (KC) {
             int mn = f / (BK / 4), k = 4 * (f % (BK / 4));
             S[(k + 0) * LD + mn] = r[p].x;
@@ -102,12 +103,13 @@ __device__ __forceinline__ void store_tile(const float4 (&r)[BMN / 32], float* _
 }
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(GemmParams p) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int LDA = BM + (AKC ? 1 : 4);
     constexpr int LDB = BN + (BKC ? 1 : 4);
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
     __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
     float* As = smem;
     float* Bs = smem + BK * LDA;
@@ -150,14 +152,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // two register sets: the tile written to LDS at step kt was requested two compute phases earlier
-    float4 ra0[BM / 32], rb0[BN / 32], ra1[BM / 32], rb1[BN / 32];
+    float4 ra0[BM * 8 / NT], rb0[BN * 8 / NT], ra1[BM * 8 / NT], rb1[BN * 8 / NT];
     if (kt0 < kt1) {
-        load_tile<BM, AKC>(ra0, A, p.sam, p.sak, m0, kt0 * BK, p.M, p.K, kend, p.vecA, tid);
-        load_tile<BN, BKC>(rb0, B, p.sbn, p.sbk, n0, kt0 * BK, p.N, p.K, kend, p.vecB, tid);
+        load_tile<BM, AKC, NT>(ra0, A, p.sam, p.sak, m0, kt0 * BK, p.M, p.K, kend, p.vecA, tid);
+        load_tile<BN, BKC, NT>(rb0, B, p.sbn, p.sbk, n0, kt0 * BK, p.N, p.K, kend, p.vecB, tid);
     }
     if (kt0 + 1 < kt1) {
-        load_tile<BM, AKC>(ra1, A, p.sam, p.sak, m0, (kt0 + 1) * BK, p.M, p.K, kend, p.vecA, tid);
-        load_tile<BN, BKC>(rb1, B, p.sbn, p.sbk, n0, (kt0 + 1) * BK, p.N, p.K, kend, p.vecB, tid);
+        load_tile<BM, AKC, NT>(ra1, A, p.sam, p.sak, m0, (kt0 + 1) * BK, p.M, p.K, kend, p.vecA, tid);
+        load_tile<BN, BKC, NT>(rb1, B, p.sbn, p.sbk, n0, (kt0 + 1) * BK, p.N, p.K, kend, p.vecB, tid);
     }
     const int khalf = lane >> 5, l31 = lane & 31;
     auto compute = [&]() {
@@ -176,22 +178,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
     };
     for (int kt = kt0; kt < kt1; kt += 2) {
-        store_tile<BM, AKC>(ra0, As, tid);
-        store_tile<BN, BKC>(rb0, Bs, tid);
+        store_tile<BM, AKC, NT>(ra0, As, tid);
+        store_tile<BN, BKC, NT>(rb0, Bs, tid);
         __syncthreads();
         if (kt + 2 < kt1) {
-            load_tile<BM, AKC>(ra0, A, p.sam, p.sak, m0, (kt + 2) * BK, p.M, p.K, kend, p.vecA, tid);
-            load_tile<BN, BKC>(rb0, B, p.sbn, p.sbk, n0, (kt + 2) * BK, p.N, p.K, kend, p.vecB, tid);
+            load_tile<BM, AKC, NT>(ra0, A, p.sam, p.sak, m0, (kt + 2) * BK, p.M, p.K, kend, p.vecA, tid);
+            load_tile<BN, BKC, NT>(rb0, B, p.sbn, p.sbk, n0, (kt + 2) * BK, p.N, p.K, kend, p.vecB, tid);
         }
         compute();
         __syncthreads();
         if (kt + 1 < kt1) {
-            store_tile<BM, AKC>(ra1, As, tid);
-            store_tile<BN, BKC>(rb1, Bs, tid);
+            store_tile<BM, AKC, NT>(ra1, As, tid);
+            store_tile<BN, BKC, NT>(rb1, Bs, tid);
             __syncthreads();
             if (kt + 3 < kt1) {
-                load_tile<BM, AKC>(ra1, A, p.sam, p.sak, m0, (kt + 3) * BK, p.M, p.K, kend, p.vecA, tid);
-                load_tile<BN, BKC>(rb1, B, p.sbn, p.sbk, n0, (kt + 3) * BK, p.N, p.K, kend, p.vecB, tid);
+                load_tile<BM, AKC, NT>(ra1, A, p.sam, p.sak, m0, (kt + 3) * BK, p.M, p.K, kend, p.vecA, tid);
+                load_tile<BN, BKC, NT>(rb1, B, p.sbn, p.sbk, n0, (kt + 3) * BK, p.N, p.K, kend, p.vecB, tid);
             }
             compute();
             __syncthreads();
@@ -243,10 +245,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmParams& p, bool akc, bool bkc, dim3 grid, hipStream_t st) {
-    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, p);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, p);
-    else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, p);
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(NT), 0, st, p);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(NT), 0, st, p);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(NT), 0, st, p);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -273,11 +276,16 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     p.vecA = akc ? (d.sam % 4 == 0 && aligned16(d.A) && d.bsa % 4 == 0) : (d.sak % 4 == 0 && aligned16(d.A) && d.bsa % 4 == 0);
     p.vecB = bkc ? (d.sbn % 4 == 0 && aligned16(d.B) && d.bsb % 4 == 0) : (d.sbk % 4 == 0 && aligned16(d.B) && d.bsb % 4 == 0);
 
-    // tile choice: big tiles when there is enough work to fill the 256 CUs with them, else 64x64
-    const long wg128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
+    // tile choice.  Measured on the c3 shapes (tools/gemm_bench.py): the 64x64 tile (7 waves/SIMD resident, latency hidden by
+    // occupancy) matches or beats 128x128 (2 waves/SIMD) everywhere at these sizes, including the 1280 x 5001 x 1536 logit
+    // products (tile quantisation: 400 big tiles on 256 CUs), so it is the default; 128x128 stays selectable for tuning.
     int BMs = 64, BNs = 64;
-    if (wg128 >= 192) { BMs = 128; BNs = 128; }
-    else if (d.M <= 64 && d.N >= 256) { BMs = 64; BNs = 64; }
+    bool w8 = false;
+    if (const char* e = getenv("ECHR_GEMM_TILE")) {          // tuning override (tools/gemm_bench.py); never set in production
+        if (e[0] == '1') { BMs = 128; BNs = 128; } else if (e[0] == '6') { BMs = 64; BNs = 64; }
+        else if (e[0] == 'a') { BMs = 128; BNs = 64; } else if (e[0] == 'b') { BMs = 64; BNs = 128; }
+        else if (e[0] == 'c') { BMs = 128; BNs = 128; w8 = true; }
+    }
     p.tiles_m = (d.M + BMs - 1) / BMs;
     p.tiles_n = (d.N + BNs - 1) / BNs;
     const int kt_total = (d.K + BK - 1) / BK;
@@ -286,13 +294,14 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     if (split < 0) {  // auto: fill ~2 waves of workgroups over the chip when the output grid is small
         long wgs = (long)p.tiles_m * p.tiles_n * d.batch;
         split = 1;
-        // latency-bound regime: fewer than ~3 workgroups per CU.  Split K so that ~768 workgroups overlap each other's
-        // load latency, keeping at least 4 k-tiles (128 deep) per split.
-        if (d.act == ECHR_ACT_NONE && wgs < 640 && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
-            split = (int)min((long)kt_total, max(1L, (768 + wgs - 1) / max(wgs, 1L)));
+        // latency-bound regime: fewer than 2 workgroups per CU.  Split K so that ~1024 workgroups overlap each other's
+        // load latency, keeping at least 4 k-tiles (128 deep) per split (measured optimum on the weight-gradient shapes).
+        if (d.act == ECHR_ACT_NONE && wgs < 512 && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
+            split = (int)min((long)kt_total, max(1L, (1024 + wgs - 1) / max(wgs, 1L)));
             if (split > 1 && kt_total / split < 4) split = max(1, kt_total / 4);
         }
     }
+    if (const char* e = getenv("ECHR_GEMM_SPLIT")) { if (d.split_k < 0 && atoi(e) > 0) split = atoi(e); }
     if (split < 1) split = 1;
     if (split > kt_total) split = kt_total;
     p.k_tiles_per_split = (kt_total + split - 1) / split;
@@ -313,7 +322,10 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     dim3 grid(p.tiles_m * p.tiles_n, 1, d.batch * split);
     // algorithmic work of this launch: 2MNK flops; one read of A and B, one write of C
     ProfScope prof(PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch, st);
-    if (BMs == 128) launch_cfg<128, 128, 64, 64>(p, akc, bkc, grid, st);
+    if (BMs == 128 && BNs == 128 && w8) launch_cfg<128, 128, 64, 32>(p, akc, bkc, grid, st);
+    else if (BMs == 128 && BNs == 128) launch_cfg<128, 128, 64, 64>(p, akc, bkc, grid, st);
+    else if (BMs == 128) launch_cfg<128, 64, 64, 32>(p, akc, bkc, grid, st);
+    else if (BNs == 128) launch_cfg<64, 128, 32, 64>(p, akc, bkc, grid, st);
     else launch_cfg<64, 64, 32, 32>(p, akc, bkc, grid, st);
     return check_launch("gemm_f32");
 }
