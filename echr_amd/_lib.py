@@ -19,7 +19,7 @@ class GemmDesc(C.Structure):
                 ('sam', i64), ('sak', i64), ('sbk', i64), ('sbn', i64), ('ldc', i64),
                 ('batch', i32), ('bsa', i64), ('bsb', i64), ('bsc', i64), ('alpha', f32), ('beta', f32),
                 ('bias', c_f), ('bs_bias', i64), ('bias2', c_f), ('addend', c_f), ('add_mod', i32), ('ld_add', i64),
-                ('act', i32), ('aux', c_f), ('ld_aux', i64), ('rowmap_mod', i32), ('rowmap_mul', i32), ('split_k', i32)]
+                ('act', i32), ('aux', c_f), ('ld_aux', i64), ('rowmap_mod', i32), ('rowmap_mul', i32), ('split_k', i32), ('algo', i32)]
 
 
 class Dropout(C.Structure):
@@ -82,6 +82,7 @@ SYMBOLS = [
     ('echr_nll_loss_fwd', i32, [c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_sampler_ws_floats', i64, [C.POINTER(DecArgs)]),
     ('echr_decoder_sample', i32, [C.POINTER(SampleArgs), C.c_void_p]),
+    ('echr_config_set', i32, [C.c_char_p, i32]),
     ('echr_prof_enable', i32, [i32]),
     ('echr_prof_read', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     ('echr_clamp', i32, [c_f, i64, f32, C.c_void_p]),

@@ -4,6 +4,8 @@
 // cross-lane shuffle reductions.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "echr_common.h"
 #include "echr_internal.h"
@@ -26,6 +28,31 @@ int check_launch(const char* what) {
         return -5;  // -EIO
     }
     return 0;
+}
+
+// ---- runtime configuration -------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+Config& config() {
+    static Config c = {env_int("ECHR_GEMM_BF16X3", 1), env_int("ECHR_OVERLAP", 0), env_int("ECHR_ATT_SLOTS", 2)};
+    return c;
+}
+
+// 32x32 LDS-tiled transpose with zero padding of the output rows' tail
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long ld_in, float* __restrict__ out, long ld_out,
+                                                        int rows, int cols, int rows_pad) {
+    __shared__ float t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        t[i][tx] = (r0 + i < rows && c0 + tx < cols) ? in[(long)(r0 + i) * ld_in + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows_pad) out[(long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
+}
+int transpose(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, int rows_pad, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows_pad + 31) / 32), dim3(256), 0, st, in, ld_in, out, ld_out, rows, cols,
+                       rows_pad);
+    return check_launch("transpose");
 }
 
 // ---- optional HIP-event profiling --------------------------------------------------------------------
@@ -444,5 +471,15 @@ extern "C" int echr_prof_read(int kind, double* ms, double* flops, double* bytes
     ECHR_REQUIRE(kind >= 0 && kind < PROF_KINDS && ms && flops && bytes && launches, "prof_read: bad arguments");
     prof_resolve();
     *ms = g_prof_ms[kind]; *flops = g_prof_flops[kind]; *bytes = g_prof_bytes[kind]; *launches = g_prof_n[kind];
+    return 0;
+}
+
+extern "C" int echr_config_set(const char* key, int32_t value) {
+    ECHR_REQUIRE(key, "config_set: null key");
+    Config& c = config();
+    if (!strcmp(key, "gemm_bf16x3")) c.gemm_bf16x3 = value;
+    else if (!strcmp(key, "overlap")) c.overlap = value;
+    else if (!strcmp(key, "att_slots")) { ECHR_REQUIRE(value == 2 || value == 4 || value == 8, "config_set: att_slots must be 2, 4 or 8"); c.att_slots = value; }
+    else { set_error("config_set: unknown key %s", key); return -22; }
     return 0;
 }

@@ -63,11 +63,9 @@ static Side& side() {
     return sd;
 }
 static bool overlap_enabled() {
-    static int v = -1;
     // measured neutral on the c3 workload (the recurrent GEMM's two 67 KB-LDS workgroups per CU leave no room for a
-    // co-resident throughput GEMM, so the overlap only trades places): opt-in with ECHR_OVERLAP=1
-    if (v < 0) { const char* e = getenv("ECHR_OVERLAP"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1 && side().ok;
+    // co-resident throughput GEMM, so the overlap only trades places): opt-in (ECHR_OVERLAP=1 / echr_config_set)
+    return config().overlap == 1 && side().ok;
 }
 static int hop(hipStream_t from, hipEvent_t ev, hipStream_t to) {      // `to` continues after everything queued on `from`
     if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
@@ -395,9 +393,8 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
 struct AttDims { int N, A, Ha, D; };
 
 static int att_slots() {     // slots per wave (2, 4 or 8): tuning knob, default chosen from measurements on the c3 workload
-    static int v = 0;
-    if (!v) { const char* e = getenv("ECHR_ATT_SLOTS"); v = e ? atoi(e) : 2; if (v != 2 && v != 4 && v != 8) v = 2; }
-    return v;
+    const int v = config().att_slots;
+    return (v == 2 || v == 4 || v == 8) ? v : 2;
 }
 
 static int launch_att_score(const AttDims& d, const float* PALL, const float* QSL, int nslab, long slab_stride, const float* b_q,
@@ -553,23 +550,6 @@ static int rec_gemm(const RecArgs& a, hipStream_t st) {
     return check_launch("rec_gemm");
 }
 
-// 32x32 LDS-tiled transpose: out[c, r] = in[r, c]  (weights for the backward recurrence, once per backward)
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long ld_in, float* __restrict__ out, long ld_out,
-                                                        int rows, int cols) {
-    __shared__ float t[32][33];
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8)
-        if (r0 + i < rows && c0 + tx < cols) t[i][tx] = in[(long)(r0 + i) * ld_in + c0 + tx];
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8)
-        if (c0 + i < cols && r0 + tx < rows) out[(long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
-}
-static int transpose(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, hipStream_t st) {
-    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, ld_in, out, ld_out, rows, cols);
-    return check_launch("transpose");
-}
-
 // ------------------------------------------------------------------------------------------------------
 // LSTM cell gate math for the three streams of one timestep (nn.LSTMCell order i,f,g,o).
 // Pre-activation = input-side part (GATES, batched GEMM before the recurrence) + the recurrent split-K slabs.
@@ -681,6 +661,8 @@ static DecWs carve_ws(const echr_dec_args* a, float* base) {
 struct DecWsBwd {
     float *DLG, *DOUT, *DG[3], *DC, *DSC, *DQ, *DPALL, *DGSUM[3], *DGCOL[3], *DXT, *MSUM;
     float *WT_HH[3], *WT_ATT, *WT_H2A;      // transposed weights: the backward recurrence runs as NT products too
+    float *WLT, *DLGT, *OUTDT;               // W_logit^T [3H, ldg], DLG^T [V1, snp], OUTD^T [3H, snp]: NT operands for the split GEMM
+    long snp;
     float *DHSL[3], *DASL;                   // split-K slabs: d h(t-1) per stream, d ATT
     int ndh[3], nda;
     long ldg, total;
@@ -705,6 +687,10 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     for (int k = 0; k < 3; ++k) w.WT_HH[k] = take(H * 4 * H);
     w.WT_ATT = take((long)a->D * 4 * H);
     w.WT_H2A = take(H * (long)a->Ha);
+    w.snp = rup(S * N, 4);
+    w.WLT = take(3 * H * w.ldg);
+    w.DLGT = take((long)a->V1 * w.snp);
+    w.OUTDT = take(3 * H * w.snp);
     w.ndh[0] = w.ndh[2] = ksplit_of(4 * a->H);
     w.ndh[1] = ksplit_of(4 * a->H) + ksplit_of(a->Ha);
     w.nda = ksplit_of(4 * a->H);
@@ -736,7 +722,7 @@ static RecJob mkjob(const float* A, long lda, int K, const float* B, long ldb, i
 static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t st) {
     const int H = a->H, E = a->E;
     echr_gemm_desc d = desc_nt(a->c3d, a->D, a->w_c2a, a->D, w.PALL, a->Ha, a->Tv, a->Ha, a->D);
-    d.bias = a->b_c2a; d.split_k = -1;
+    d.bias = a->b_c2a; d.split_k = -1; d.algo = ECHR_GEMM_BF16X3;
     RC(gemm(d, st));
     d = desc_nt(a->event, a->De, a->w_ih[0] + E, E + a->De, w.EVB0, 4 * H, a->N, 4 * H, a->De);
     d.bias = a->b_ih[0]; d.bias2 = a->b_hh[0]; d.split_k = -1;
@@ -834,7 +820,7 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
     auto logits_chunk = [&](int t0, int t1, hipStream_t q) -> int {
         echr_gemm_desc d = desc_nt(w.OUTD + (long)t0 * N * 3 * H, 3 * H, a->w_logit, 3 * H, a->logp + (long)t0 * a->V1, a->V1,
                                    (t1 - t0) * N, a->V1, 3 * H);
-        d.bias = a->b_logit; d.rowmap_mod = N; d.rowmap_mul = S;
+        d.bias = a->b_logit; d.rowmap_mod = N; d.rowmap_mul = S; d.algo = ECHR_GEMM_BF16X3;
         RC(gemm(d, q));
         return logsoftmax_rows(a->logp, a->V1, N, S, t0, t1 - t0, a->V1, q);
     };
@@ -873,17 +859,23 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     const bool ov = overlap_enabled() && S >= 4;
     hipStream_t sq = ov ? side().s : st;
     if (ov) RC(hop(st, side().fork, sq));
-    echr_gemm_desc d = desc_tn(b.DLG, b.ldg, w.OUTD, 3 * H, g->g_w_logit, 3 * H, V1, 3 * H, SN);
-    d.beta = zb; d.split_k = -1;
+    // Both late-fusion products run as NT problems on k-contiguous (transposed) operands so that they qualify for the
+    // bf16-split matrix-core path: d W_logit = DLG^T . OUTD  and  d OUTD = DLG . W_logit.
+    echr_gemm_desc d;
+    RC(transpose(b.DLG, b.ldg, b.DLGT, b.snp, SN, V1, (int)b.snp, sq));
+    RC(transpose(w.OUTD, 3 * H, b.OUTDT, b.snp, SN, 3 * H, (int)b.snp, sq));
+    d = desc_nt(b.DLGT, b.snp, b.OUTDT, b.snp, g->g_w_logit, 3 * H, V1, 3 * H, (int)b.snp);
+    d.beta = zb; d.split_k = -1; d.algo = ECHR_GEMM_BF16X3;
     RC(gemm(d, sq));
     RC(colsum(b.DLG, b.ldg, SN, V1, g->g_b_logit, z, sq));
-    d = desc_nn(b.DLG, b.ldg, a->w_logit, 3 * H, b.DOUT, 3 * H, SN, 3 * H, V1);
-    d.split_k = -1;
+    RC(transpose(a->w_logit, 3 * H, b.WLT, b.ldg, V1, 3 * H, (int)b.ldg, st));
+    d = desc_nt(b.DLG, b.ldg, b.WLT, b.ldg, b.DOUT, 3 * H, SN, 3 * H, (int)b.ldg);
+    d.split_k = -1; d.algo = ECHR_GEMM_BF16X3;
     RC(gemm(d, st));
     // 3. reverse recurrence.  Transposed weights turn every d h / d ATT product into the same NT form as forward.
-    for (int k = 0; k < 3; ++k) RC(transpose(a->w_hh[k], H, b.WT_HH[k], 4 * H, 4 * H, H, st));
-    RC(transpose(a->w_ih[1] + E, cin[1], b.WT_ATT, 4 * H, 4 * H, D, st));
-    RC(transpose(a->w_h2a, H, b.WT_H2A, Ha, Ha, H, st));
+    for (int k = 0; k < 3; ++k) RC(transpose(a->w_hh[k], H, b.WT_HH[k], 4 * H, 4 * H, H, 4 * H, st));
+    RC(transpose(a->w_ih[1] + E, cin[1], b.WT_ATT, 4 * H, 4 * H, D, 4 * H, st));
+    RC(transpose(a->w_h2a, H, b.WT_H2A, Ha, Ha, H, Ha, st));
     RC(fill_zero(b.DC, (long)N * 3 * H, st));
     RC(fill_zero(b.DQ, (long)SN * Ha, st));
     const long hs = (long)N * H, as = (long)N * D;

@@ -7,7 +7,7 @@ namespace echr {
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 // Disabled by default: ProfScope is then a no-op.  Events are resolved in echr_prof_read after a stream sync.
-enum ProfKind { PROF_GEMM = 0, PROF_ATT_FWD = 1, PROF_ATT_BWD = 2, PROF_ATT_POST = 3, PROF_LSTM = 4, PROF_OTHER = 5, PROF_KINDS = 6 };
+enum ProfKind { PROF_GEMM = 0, PROF_ATT_FWD = 1, PROF_ATT_BWD = 2, PROF_ATT_POST = 3, PROF_LSTM = 4, PROF_OTHER = 5, PROF_GEMM_SPLIT = 6, PROF_KINDS = 7 };
 struct ProfScope {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t st;
@@ -15,6 +15,10 @@ struct ProfScope {
     ~ProfScope();
     int kind; double flops, bytes;
 };
+
+// runtime switches (initial values from the environment, changeable through echr_config_set)
+struct Config { int gemm_bf16x3; int overlap; int att_slots; };
+Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);
 
@@ -45,6 +49,8 @@ int colsum(const float* X, long ld, int rows, int cols, float* out, bool accumul
 int sum_over_time(const float* X, long ld, int S, int N, int cols, float* out, long ld_out, hipStream_t st);
 int fill_zero(float* p, long n, hipStream_t st);
 int fill_zero_2d(float* p, int rows, int cols, long ld, hipStream_t st);
+// out[c, r] = in[r, c] for r < rows, c < cols; rows..rows_pad-1 of the output's row are zero-filled (k padding)
+int transpose(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, int rows_pad, hipStream_t st);
 int embed_gather(const float* W, const int* tok, float* out, int rows, int E, int V1, hipStream_t st);
 int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st);
 int logsoftmax_rows(float* X, long ld, int N, int S, int t0, int nt, int cols, hipStream_t st);

@@ -36,6 +36,53 @@ struct GemmParams {
     int vecA, vecB;
 };
 
+// Shared epilogue: C = act(alpha*acc + beta*C + biases + addend) with optional output row remap; split-K slices add atomically.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], float* __restrict__ C, int b, int ks, int m0,
+                                         int n0, int wm, int wn, int lane) {
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const bool first_split = (ks == 0);
+    const float* bias = p.bias ? p.bias + (long)b * p.bs_bias : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn + j * 32 + l31;
+            if (col >= p.N) continue;
+            float cb = 0.f;
+            if (first_split) {
+                if (bias) cb += bias[col];
+                if (p.bias2) cb += p.bias2[col];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (row >= p.M) continue;
+                float v = p.alpha * acc[i][j][r];
+                int orow = row;
+                if (p.rowmap_mod > 0) orow = (row % p.rowmap_mod) * p.rowmap_mul + row / p.rowmap_mod;
+                float* dst = C + (long)orow * p.ldc + col;
+                if (p.split_k > 1) {
+                    if (first_split) {
+                        v += cb;
+                        if (p.addend) v += p.addend[(long)(row % p.add_mod) * p.ld_add + col];
+                    }
+                    atomicAdd(dst, v);
+                } else {
+                    v += cb;
+                    if (p.addend) v += p.addend[(long)(row % p.add_mod) * p.ld_add + col];
+                    if (p.beta != 0.f) v += p.beta * *dst;
+                    if (p.act == ECHR_ACT_TANH) v = tanhf(v);
+                    else if (p.act == ECHR_ACT_MUL_DTANH) {
+                        float t = p.aux[(long)row * p.ld_aux + col];
+                        v *= (1.f - t * t);
+                    }
+                    *dst = v;
+                }
+            }
+        }
+}
+
 // Fill registers with one [BMN x BK] operand tile.  KC: k is the contiguous axis of the source.
 template <int BMN, bool KC, int NT>
 __device__ __forceinline__ void load_tile(float4 (&r)[BMN * 8 / NT], const float* __restrict__ P, long s_mn, long s_k,
@@ -200,47 +247,145 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
         }
     }
 
-    // ---- epilogue --------------------------------------------------------------------------------
-    const bool first_split = (ks == 0);
-    const float* bias = p.bias ? p.bias + (long)b * p.bs_bias : nullptr;
+    epilogue<TM, TN>(p, acc, C, b, ks, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fp32 GEMM through the bf16 matrix cores: each fp32 operand is split EXACTLY into three bf16 planes
+// (x = hi + mid + lo, 8 significand bits each, by truncation: every residual is exactly representable), and the six
+// largest of the nine plane products (hh, hm, mh, mm, hl, lh) are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
+// Every bf16 x bf16 product is exact in fp32; the three dropped products are below 2^-23 of |x.y|, i.e. at the level of
+// one fp32 rounding of the product -- the result is fp32-accurate (measured against float64 in tests/test_gpu_parity.py)
+// at 16/6 = 2.7x the rate of the native fp32 MFMA.
+// NT only (both operands k-contiguous, 16-byte aligned, K % 4 == 0): 128x128 tile, BK = 32, 4 waves x (2x2) 32x32 tiles.
+// LDS holds the three planes of both operands as [row][32 + 8 pad] bf16 (80-byte rows: conflict-free ds_read_b128
+// fragment reads, lane l reads row l&31, k = 8*(l>>5)..+7 -- the 32x32x16 A/B operand map).
+// ------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SLD = 40;     // bf16 elements per LDS row
+
+__device__ __forceinline__ void split_store(unsigned short* __restrict__ base, int plane_stride, int off, float4 v) {
+    // hi / mid / lo planes of 4 consecutive k values -> one 8-byte LDS store per plane.  Truncation split: every residual
+    // is exact.  (Non-finite inputs turn into NaN in the lower planes, i.e. a non-finite result, like the fp32 product.)
+    const unsigned x0 = __float_as_uint(v.x), x1 = __float_as_uint(v.y), x2 = __float_as_uint(v.z), x3 = __float_as_uint(v.w);
+    const uint2 h = make_uint2(__builtin_amdgcn_perm(x1, x0, 0x07060302u), __builtin_amdgcn_perm(x3, x2, 0x07060302u));
+    const float r0 = v.x - __uint_as_float(x0 & 0xFFFF0000u), r1 = v.y - __uint_as_float(x1 & 0xFFFF0000u);
+    const float r2 = v.z - __uint_as_float(x2 & 0xFFFF0000u), r3 = v.w - __uint_as_float(x3 & 0xFFFF0000u);
+    const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1), y2 = __float_as_uint(r2), y3 = __float_as_uint(r3);
+    const uint2 m = make_uint2(__builtin_amdgcn_perm(y1, y0, 0x07060302u), __builtin_amdgcn_perm(y3, y2, 0x07060302u));
+    const float s0 = r0 - __uint_as_float(y0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+    const float s2 = r2 - __uint_as_float(y2 & 0xFFFF0000u), s3 = r3 - __uint_as_float(y3 & 0xFFFF0000u);
+    const uint2 l = make_uint2(__builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u),
+                               __builtin_amdgcn_perm(__float_as_uint(s3), __float_as_uint(s2), 0x07060302u));
+    *reinterpret_cast<uint2*>(base + off) = h;
+    *reinterpret_cast<uint2*>(base + plane_stride + off) = m;
+    *reinterpret_cast<uint2*>(base + 2 * plane_stride + off) = l;
+}
+
+// one [128 x 32] fp32 tile: 2 float4 per thread (512 threads); interior tiles load unconditionally, edge tiles use
+// clamped addresses + masks (both branch-free per lane; the tile class is workgroup-uniform)
+__device__ __forceinline__ void split_load(float4 (&r)[2], const float* __restrict__ P, long ld, int mn0, int k0, int MN, int K,
+                                           int kend, int tid) {
+    if (mn0 + 128 <= MN && k0 + BK <= kend) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + i * 512;
+            r[i] = *reinterpret_cast<const float4*>(P + (long)(mn0 + (f >> 3)) * ld + k0 + 4 * (f & 7));
+        }
+        return;
+    }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn + j * 32 + l31;
-            if (col >= p.N) continue;
-            float cb = 0.f;
-            if (first_split) {
-                if (bias) cb += bias[col];
-                if (p.bias2) cb += p.bias2[col];
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 512;
+        const int row = mn0 + (f >> 3), k = k0 + 4 * (f & 7);
+        const float4 v = *reinterpret_cast<const float4*>(P + (long)min(row, MN - 1) * ld + min(k, K - 4));
+        const float msk = (row < MN && k < kend) ? 1.f : 0.f;
+        r[i] = make_float4(v.x * msk, v.y * msk, v.z * msk, v.w * msk);
+    }
+}
+
+// 8 waves (2 x 4) of 64x32 wave tiles; <= 128 VGPRs so that two workgroups (4 waves per SIMD) share a CU and one wave's
+// operand splitting (VALU) overlaps the other waves' MFMAs.
+__global__ __launch_bounds__(512, 4) void gemm_split_kernel(GemmParams p) {
+    constexpr int BM = 128, BN = 128, PS = 128 * SLD;                 // plane stride (bf16 elements)
+    __shared__ __attribute__((aligned(16))) unsigned short sm[6 * PS];   // A planes 0..2, B planes 0..2: 61,440 B
+    unsigned short* As = sm;
+    unsigned short* Bs = sm + 3 * PS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
+    const int z = blockIdx.z, b = z / p.split_k, ks = z % p.split_k;
+    const float* A = p.A + (long)b * p.bsa;
+    const float* B = p.B + (long)b * p.bsb;
+    float* C = p.C + (long)b * p.bsc;
+    const int kt_total = (p.K + BK - 1) / BK;
+    const int kt0 = ks * p.k_tiles_per_split, kt1 = min(kt_total, kt0 + p.k_tiles_per_split);
+    const int kend = min(p.K, kt1 * BK);
+
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    float4 ra0[2], rb0[2], ra1[2], rb1[2];
+    if (kt0 < kt1) { split_load(ra0, A, p.sam, m0, kt0 * BK, p.M, p.K, kend, tid); split_load(rb0, B, p.sbn, n0, kt0 * BK, p.N, p.K, kend, tid); }
+    if (kt0 + 1 < kt1) { split_load(ra1, A, p.sam, m0, (kt0 + 1) * BK, p.M, p.K, kend, tid); split_load(rb1, B, p.sbn, n0, (kt0 + 1) * BK, p.N, p.K, kend, tid); }
+
+    auto stage = [&](const float4 (&ra)[2], const float4 (&rb)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + i * 512;
+            const int off = (f >> 3) * SLD + 4 * (f & 7);
+            split_store(As, PS, off, ra[i]);
+            split_store(Bs, PS, off, rb[i]);
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[2][3], bb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[0][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PS + (wm + l31) * SLD + 16 * s + 8 * h);
+                a[1][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PS + (wm + 32 + l31) * SLD + 16 * s + 8 * h);
+                bb[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PS + (wn + l31) * SLD + 16 * s + 8 * h);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (row >= p.M) continue;
-                float v = p.alpha * acc[i][j][r];
-                int orow = row;
-                if (p.rowmap_mod > 0) orow = (row % p.rowmap_mod) * p.rowmap_mul + row / p.rowmap_mod;
-                float* dst = C + (long)orow * p.ldc + col;
-                if (p.split_k > 1) {
-                    if (first_split) {
-                        v += cb;
-                        if (p.addend) v += p.addend[(long)(row % p.add_mod) * p.ld_add + col];
-                    }
-                    atomicAdd(dst, v);
-                } else {
-                    v += cb;
-                    if (p.addend) v += p.addend[(long)(row % p.add_mod) * p.ld_add + col];
-                    if (p.beta != 0.f) v += p.beta * *dst;
-                    if (p.act == ECHR_ACT_TANH) v = tanhf(v);
-                    else if (p.act == ECHR_ACT_MUL_DTANH) {
-                        float t = p.aux[(long)row * p.ld_aux + col];
-                        v *= (1.f - t * t);
-                    }
-                    *dst = v;
-                }
+            for (int i = 0; i < 2; ++i) {
+                f32x16 c = acc[i][0];       // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[0], c, 0, 0, 0);
+                acc[i][0] = c;
             }
         }
+    };
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        stage(ra0, rb0);
+        __syncthreads();
+        if (kt + 2 < kt1) { split_load(ra0, A, p.sam, m0, (kt + 2) * BK, p.M, p.K, kend, tid); split_load(rb0, B, p.sbn, n0, (kt + 2) * BK, p.N, p.K, kend, tid); }
+        compute();
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            stage(ra1, rb1);
+            __syncthreads();
+            if (kt + 3 < kt1) { split_load(ra1, A, p.sam, m0, (kt + 3) * BK, p.M, p.K, kend, tid); split_load(rb1, B, p.sbn, n0, (kt + 3) * BK, p.N, p.K, kend, tid); }
+            compute();
+            __syncthreads();
+        }
+    }
+    epilogue<2, 1>(p, acc, C, b, ks, m0, n0, wm, wn, lane);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -273,6 +418,9 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     p.rowmap_mod = d.rowmap_mod; p.rowmap_mul = d.rowmap_mul;
     const bool akc = (d.sak == 1);
     const bool bkc = (d.sbk == 1);
+    const bool use_split = d.algo == ECHR_GEMM_BF16X3 && config().gemm_bf16x3 && akc && bkc && d.K % 4 == 0 && d.K >= 4 && d.sam % 4 == 0 &&
+                           d.sbn % 4 == 0 && aligned16(d.A) && aligned16(d.B) && d.bsa % 4 == 0 && d.bsb % 4 == 0 &&
+                           (long)d.M * d.N >= 128L * 128L;
     p.vecA = akc ? (d.sam % 4 == 0 && aligned16(d.A) && d.bsa % 4 == 0) : (d.sak % 4 == 0 && aligned16(d.A) && d.bsa % 4 == 0);
     p.vecB = bkc ? (d.sbn % 4 == 0 && aligned16(d.B) && d.bsb % 4 == 0) : (d.sbk % 4 == 0 && aligned16(d.B) && d.bsb % 4 == 0);
 
@@ -281,10 +429,12 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     // products (tile quantisation: 400 big tiles on 256 CUs), so it is the default; 128x128 stays selectable for tuning.
     int BMs = 64, BNs = 64;
     bool w8 = false;
+    if (use_split) { BMs = 128; BNs = 128; }
     if (const char* e = getenv("ECHR_GEMM_TILE")) {          // tuning override (tools/gemm_bench.py); never set in production
         if (e[0] == '1') { BMs = 128; BNs = 128; } else if (e[0] == '6') { BMs = 64; BNs = 64; }
         else if (e[0] == 'a') { BMs = 128; BNs = 64; } else if (e[0] == 'b') { BMs = 64; BNs = 128; }
         else if (e[0] == 'c') { BMs = 128; BNs = 128; w8 = true; }
+        if (use_split) { BMs = 128; BNs = 128; }
     }
     p.tiles_m = (d.M + BMs - 1) / BMs;
     p.tiles_n = (d.N + BNs - 1) / BNs;
@@ -296,8 +446,8 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
         split = 1;
         // latency-bound regime: fewer than 2 workgroups per CU.  Split K so that ~1024 workgroups overlap each other's
         // load latency, keeping at least 4 k-tiles (128 deep) per split (measured optimum on the weight-gradient shapes).
-        if (d.act == ECHR_ACT_NONE && wgs < 512 && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
-            split = (int)min((long)kt_total, max(1L, (1024 + wgs - 1) / max(wgs, 1L)));
+        if (d.act == ECHR_ACT_NONE && wgs < (use_split ? 200 : 512) && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
+            split = (int)min((long)kt_total, max(1L, ((use_split ? 400 : 1024) + wgs - 1) / max(wgs, 1L)));
             if (split > 1 && kt_total / split < 4) split = max(1, kt_total / 4);
         }
     }
@@ -321,8 +471,9 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     } else if (accumulate && split == 1) p.beta = 1.f;
     dim3 grid(p.tiles_m * p.tiles_n, 1, d.batch * split);
     // algorithmic work of this launch: 2MNK flops; one read of A and B, one write of C
-    ProfScope prof(PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch, st);
-    if (BMs == 128 && BNs == 128 && w8) launch_cfg<128, 128, 64, 32>(p, akc, bkc, grid, st);
+    ProfScope prof(use_split ? PROF_GEMM_SPLIT : PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch, st);
+    if (use_split) hipLaunchKernelGGL(gemm_split_kernel, grid, dim3(512), 0, st, p);
+    else if (BMs == 128 && BNs == 128 && w8) launch_cfg<128, 128, 64, 32>(p, akc, bkc, grid, st);
     else if (BMs == 128 && BNs == 128) launch_cfg<128, 128, 64, 64>(p, akc, bkc, grid, st);
     else if (BMs == 128) launch_cfg<128, 64, 64, 32>(p, akc, bkc, grid, st);
     else if (BNs == 128) launch_cfg<64, 128, 32, 64>(p, akc, bkc, grid, st);

@@ -293,7 +293,7 @@ def clamp_(g, clip):
     return g
 
 
-def gemm(A, B, trans_b=True, bias=None):
+def gemm(A, B, trans_b=True, bias=None, algo=0):
     """C = A @ B^T (trans_b) or A @ B on the fp32 MFMA path; exposed for kernel-level parity tests."""
     lib = L.load()
     M, K = A.shape
@@ -305,7 +305,7 @@ def gemm(A, B, trans_b=True, bias=None):
     d.sam, d.sak = K, 1
     d.sbk, d.sbn = (1, K) if trans_b else (Nn, 1)
     d.ldc = Nn
-    d.batch, d.alpha, d.beta, d.split_k = 1, 1.0, 0.0, -1
+    d.batch, d.alpha, d.beta, d.split_k, d.algo = 1, 1.0, 0.0, -1, algo
     d.bias = L.ptr(bias) if bias is not None else None
     L.check(lib.echr_gemm_f32(C.byref(d), L.stream_ptr()), 'gemm_f32')
     return Cc

@@ -39,6 +39,7 @@ const char* echr_last_error(void);
  * split_k > 1: partial sums are atomically added into C (which must already hold its base value);
  *              act must be ECHR_ACT_NONE and beta is ignored.
  * ---------------------------------------------------------------------------------------------- */
+enum { ECHR_GEMM_F32 = 0, ECHR_GEMM_BF16X3 = 1 };
 enum { ECHR_ACT_NONE = 0, ECHR_ACT_TANH = 1, ECHR_ACT_MUL_DTANH = 2 /* acc * (1 - aux^2) */ };
 
 typedef struct {
@@ -61,6 +62,9 @@ typedef struct {
     int64_t ld_aux;
     int32_t rowmap_mod, rowmap_mul; /* out row = (i % mod) * mul + i / mod ; mod = 0 -> identity */
     int32_t split_k;
+    int32_t algo; /* ECHR_GEMM_F32 (exact v_mfma_f32_32x32x2_f32) or ECHR_GEMM_BF16X3 (fp32 operands split exactly into three
+                     bf16 planes, six plane products on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-accurate, 2.7x the rate;
+                     needs both operands k-contiguous and 16-byte aligned, else the library silently uses ECHR_GEMM_F32) */
 } echr_gemm_desc;
 
 int echr_gemm_f32(const echr_gemm_desc* d, void* stream);
@@ -216,12 +220,18 @@ int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int
 /* ------------------------------------------------------------------------------------------------
  * Optional per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
  * class) for bench.py's roofline leg.  kind: 0 fp32 MFMA GEMM, 1 attention fwd, 2 attention bwd,
- * 3 attention post-pass, 4 LSTM gate math, 5 other.  echr_prof_read synchronises the recorded events and
+ * 3 attention post-pass, 4 recurrent grouped GEMM, 5 other, 6 bf16x3-split GEMM.  echr_prof_read synchronises the recorded events and
  * returns the totals since echr_prof_enable(1): elapsed ms, algorithmic flops / bytes, launches.
  * Not thread-safe; never enabled on the product path.
  * ---------------------------------------------------------------------------------------------- */
 int echr_prof_enable(int on);
 int echr_prof_read(int kind, double* ms, double* flops, double* bytes, int64_t* launches);
+
+/* Runtime switches (defaults from the environment variables ECHR_GEMM_BF16X3=1, ECHR_OVERLAP=0, ECHR_ATT_SLOTS=2):
+ *   "gemm_bf16x3" 0/1  use the three-plane bf16 split product for the large projections (fp32-accurate, faster) or not
+ *   "overlap"     0/1  run recurrence-independent GEMMs on a second HIP stream
+ *   "att_slots"   2/4/8 attention slots per wave */
+int echr_config_set(const char* key, int32_t value);
 
 /* stand-alone element-wise clamp (misc/utils.py:107-111) for optimisers other than the fused one */
 int echr_clamp(float* g, int64_t n, float clip, void* stream);

@@ -39,6 +39,21 @@ def test_gemm_f32(M, N, K, trans_b):
     assert np.max(np.abs(out - ref) / scale) < 1e-6, np.max(np.abs(out - ref) / scale)
 
 
+@pytest.mark.parametrize('M,N,K', [(128, 128, 32), (1280, 5001, 1536), (300, 700, 500), (4096, 512, 512), (130, 257, 36)])
+def test_gemm_bf16x3_split_is_fp32_accurate(M, N, K):
+    """The three-plane bf16 split product must be as accurate as the exact fp32 MFMA path (both against float64)."""
+    from echr_amd import functional as EF
+    rs = np.random.RandomState(M + N + K)
+    A = (rs.standard_normal((M, K)) * np.exp(rs.uniform(-6, 6, (M, 1)))).astype(np.float32)      # wide dynamic range
+    B = (rs.standard_normal((N, K)) * np.exp(rs.uniform(-6, 6, (N, 1)))).astype(np.float32)
+    ref = A.astype(np.float64) @ B.T.astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B.T).astype(np.float64) + 1e-30
+    At, Bt = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    e32 = np.max(np.abs(EF.gemm(At, Bt, True, None, 0).cpu().numpy() - ref) / scale)
+    esp = np.max(np.abs(EF.gemm(At, Bt, True, None, 1).cpu().numpy() - ref) / scale)
+    assert esp < 4e-7 and esp < 4 * e32 + 1e-7, (esp, e32)
+
+
 def test_position_embedding_matches_reference_numpy():
     from echr_amd import functional as EF
     g = U.gold('position.npz')

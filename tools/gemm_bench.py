@@ -16,7 +16,7 @@ SHAPES = [  # (name, layout, M, N, K)
 ]
 
 
-def run(name, layout, M, N, K, reps=20):
+def run(name, layout, M, N, K, reps=20, algo=0):
     lib = L.load()
     dev = torch.device('cuda')
     if layout == 'NT':
@@ -33,7 +33,7 @@ def run(name, layout, M, N, K, reps=20):
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cc.data_ptr()
     d.M, d.N, d.K = M, N, K
     d.sam, d.sak, d.sbk, d.sbn = st
-    d.ldc, d.batch, d.alpha, d.beta, d.split_k = N, 1, 1.0, 0.0, -1
+    d.ldc, d.batch, d.alpha, d.beta, d.split_k, d.algo = N, 1, 1.0, 0.0, -1, algo
     s = L.stream_ptr()
     for _ in range(3):
         L.check(lib.echr_gemm_f32(C.byref(d), s))
@@ -49,8 +49,7 @@ def run(name, layout, M, N, K, reps=20):
 
 if __name__ == '__main__':
     cfgs = [('auto', {}), ('t64s1', {'ECHR_GEMM_TILE': '64', 'ECHR_GEMM_SPLIT': '1'}), ('t64s2', {'ECHR_GEMM_TILE': '64', 'ECHR_GEMM_SPLIT': '2'}),
-            ('a128x64', {'ECHR_GEMM_TILE': 'a'}), ('a s1', {'ECHR_GEMM_TILE': 'a', 'ECHR_GEMM_SPLIT': '1'}), ('a s2', {'ECHR_GEMM_TILE': 'a', 'ECHR_GEMM_SPLIT': '2'}),
-            ('c128w8', {'ECHR_GEMM_TILE': 'c'}), ('c s1', {'ECHR_GEMM_TILE': 'c', 'ECHR_GEMM_SPLIT': '1'}), ('c s2', {'ECHR_GEMM_TILE': 'c', 'ECHR_GEMM_SPLIT': '2'})]
+            ]
     print('%-10s %-3s %5s %5s %5s | ' % ('name', 'lay', 'M', 'N', 'K') + ' '.join('%14s' % c[0] for c in cfgs))
     for sh in SHAPES:
         cells = []
@@ -60,4 +59,9 @@ if __name__ == '__main__':
             os.environ.update(env)
             us, tf = run(*sh)
             cells.append('%6.0fus %4.0fTF' % (us, tf))
+        for k in ('ECHR_GEMM_TILE', 'ECHR_GEMM_SPLIT'):
+            os.environ.pop(k, None)
+        if sh[1] == 'NT':
+            us, tf = run(*sh, algo=1)
+            cells.append('bf16x3 %6.0fus %4.0fTF' % (us, tf))
         print('%-10s %-3s %5d %5d %5d | ' % sh + ' '.join('%14s' % c for c in cells), flush=True)
