@@ -463,6 +463,8 @@ struct RecJob {
     const float* A; long lda; int K;
     const float* B; long ldb; int Nout;
     float* P; long slab_stride; long ldp;
+    int atomic;      // 1: all k-slices add atomically into ONE pre-zeroed slab (for outputs that many workgroups re-read,
+                     //    where summing slabs in every consumer would multiply the traffic); order-dependent last bits
 };
 struct RecArgs { RecJob job[MAXJOBS]; int njobs; int M; };
 
@@ -520,13 +522,16 @@ __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
     }
-    float* P = J.P + (long)blockIdx.y * J.slab_stride;
+    float* P = J.P + (J.atomic ? 0L : (long)blockIdx.y * J.slab_stride);
     const int col = n0 + wn + l31;
     if (col < J.Nout) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < args.M) P[(long)row * J.ldp + col] = acc[r];
+            if (row < args.M) {
+                if (J.atomic) atomicAdd(&P[(long)row * J.ldp + col], acc[r]);
+                else P[(long)row * J.ldp + col] = acc[r];
+            }
         }
     }
 }
@@ -563,13 +568,14 @@ struct LstmPtrs {
     long slab_stride;
     const float* c_prev[3];
     float* c_new[3];
+    int kmap[3];              // blockIdx.y -> stream index (lets a launch cover a subset of the streams)
 };
 
 __global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(LstmPtrs P, float* __restrict__ h_out, float* __restrict__ outd,
                                                                  int N, int H, int t, DropCfg dh, DropCfg dout) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= N * H) return;
-    const int k = blockIdx.y;
+    const int k = P.kmap[blockIdx.y];
     const int n = idx / H, j = idx % H;
     float* g = P.gates[k] + (long)n * 4 * H;
     float pi = g[j], pf = g[H + j], pg = g[2 * H + j], po = g[3 * H + j];
@@ -596,6 +602,7 @@ struct LstmBwdPtrs {
     const float* dh_slab[3];  // partial sums of d h(t) from step t+1: [N,H] slabs
     int nslab[3];
     long slab_stride;
+    int kmap[3];
 };
 
 // dh = dOUTD * m_out + sum of the recurrent slabs written while processing step t+1;  dC carries c-gradients.
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdPtrs P, 
                                                                  int N, int H, int t, DropCfg dh, DropCfg dout) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= N * H) return;
-    const int k = blockIdx.y;
+    const int k = P.kmap[blockIdx.y];
     const int n = idx / H, j = idx % H;
     const long o = (long)n * 3 * H + k * H + j;
     float dhv = doutd[o] * drop_mult(dout, (unsigned)o, (unsigned)t, SITE_OUT);
@@ -629,6 +636,7 @@ static inline long rup(long x, long a) { return (x + a - 1) / a * a; }
 struct DecWs {
     float *XT, *GATES[3], *CS[3], *HS, *OUTD, *PALL, *QS, *SC, *WT, *ATT, *EVB0, *VIDB;
     float *QSL, *GSL[3];         // split-K slabs of the current timestep (q and the three gate blocks)
+    float *QACC;                 // [S,N,Ha] atomic accumulation target of q (teacher-forced path)
     int nq, ng[3];
     long total;
 };
@@ -651,6 +659,7 @@ static DecWs carve_ws(const echr_dec_args* a, float* base) {
     w.VIDB = take(4 * H);
     w.nq = ksplit_of(a->H);
     w.QSL = take((long)w.nq * N * a->Ha);
+    w.QACC = take(S * N * a->Ha);
     w.ng[0] = w.ng[2] = ksplit_of(a->H);
     w.ng[1] = ksplit_of(a->H) + ksplit_of(a->D);
     for (int k = 0; k < 3; ++k) w.GSL[k] = take((long)w.ng[k] * N * 4 * H);
@@ -663,7 +672,7 @@ struct DecWsBwd {
     float *WT_HH[3], *WT_ATT, *WT_H2A;      // transposed weights: the backward recurrence runs as NT products too
     float *WLT, *DLGT, *OUTDT;               // W_logit^T [3H, ldg], DLG^T [V1, snp], OUTD^T [3H, snp]: NT operands for the split GEMM
     long snp;
-    float *DHSL[3], *DASL;                   // split-K slabs: d h(t-1) per stream, d ATT
+    float *DHSL[3], *DASL;                   // split-K slabs: d h(t-1) per stream; DASL: [S,N,D] atomic accumulation target of d ATT
     int ndh[3], nda;
     long ldg, total;
 };
@@ -695,7 +704,7 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     w.ndh[1] = ksplit_of(4 * a->H) + ksplit_of(a->Ha);
     w.nda = ksplit_of(4 * a->H);
     for (int k = 0; k < 3; ++k) w.DHSL[k] = take((long)w.ndh[k] * N * H);
-    w.DASL = take((long)w.nda * N * a->D);
+    w.DASL = take(S * N * a->D);
     w.total = off;
     return w;
 }
@@ -712,8 +721,10 @@ static int check_dims(const echr_dec_args* a, const char* who) {
 
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
-static RecJob mkjob(const float* A, long lda, int K, const float* B, long ldb, int Nout, float* P, long slab_stride, long ldp) {
+static RecJob mkjob(const float* A, long lda, int K, const float* B, long ldb, int Nout, float* P, long slab_stride, long ldp,
+                    int atomic = 0) {
     RecJob j; j.A = A; j.lda = lda; j.K = K; j.B = B; j.ldb = ldb; j.Nout = Nout; j.P = P; j.slab_stride = slab_stride; j.ldp = ldp;
+    j.atomic = atomic;
     return j;
 }
 
@@ -738,43 +749,56 @@ static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t
 //   launch 2,3: attention scores, softmax + context
 //   launch 4: attended-context columns of stream 1's W_ih                              -> slabs
 //   launch 5: gate math for the three streams (adds the slabs)
-static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg& dh, const DropCfg& dout, hipStream_t st) {
+// `chain`: 0 = all three streams in this call; 1 = only stream 1 (the attention chain); 2 = only streams 0 and 2 (pure LSTM
+// recurrences, independent of the attention chain -> they can run on a second HIP stream, see echr_decoder_fwd).
+static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg& dh, const DropCfg& dout, hipStream_t st, int chain = 0,
+                    bool q_atomic = false) {
     const int N = a->N, H = a->H, Ha = a->Ha, A = a->A, D = a->D, E = a->E;
     const float* hprev = w.HS + (long)t * N * 3 * H;          // [N,3H] dropped h of step t-1 (zeros at t=0)
     const long gs = (long)N * 4 * H, qs = (long)N * Ha;
     const int nh = ksplit_of(H);
+    const bool do1 = chain != 2, do02 = chain != 1;
     RecArgs ra;
-    ra.M = N; ra.njobs = 4;
-    ra.job[0] = mkjob(hprev + H, 3 * H, H, a->w_h2a, H, Ha, w.QSL, qs, Ha);
-    for (int k = 0; k < 3; ++k) ra.job[1 + k] = mkjob(hprev + k * H, 3 * H, H, a->w_hh[k], H, 4 * H, w.GSL[k], gs, 4 * H);
+    ra.M = N; ra.njobs = 0;
+    // q is re-read by every attention workgroup of an event: accumulate it atomically into one buffer (training) instead of
+    // letting each of them sum the k-slice slabs; the sampler keeps the slab form (bitwise reproducible decoding)
+    float* qacc = q_atomic ? w.QACC + (long)t * N * Ha : w.QSL;
+    if (do1) ra.job[ra.njobs++] = mkjob(hprev + H, 3 * H, H, a->w_h2a, H, Ha, qacc, qs, Ha, q_atomic ? 1 : 0);
+    for (int k = 0; k < 3; ++k)
+        if (k == 1 ? do1 : do02) ra.job[ra.njobs++] = mkjob(hprev + k * H, 3 * H, H, a->w_hh[k], H, 4 * H, w.GSL[k], gs, 4 * H);
     RC(rec_gemm(ra, st));
-    float* q = w.QS + (long)t * N * Ha;
-    float* sc = w.SC + (long)t * N * A;
-    float* wt = w.WT + (long)t * N * A;
-    float* att = w.ATT + (long)t * N * D;
-    {
-    // algorithmic bytes of one attention step: p_att rows + clip rows + scores/weights/context
-    const double rows = (double)N * A;
-    ProfScope prof(PROF_ATT_FWD, 2.0 * rows * (Ha + D) , 4.0 * (rows * (Ha + D + 2) + (double)N * (Ha + D)), st);
-    const AttDims ad{N, A, Ha, D};
-    RC(launch_att_score(ad, w.PALL, w.QSL, w.nq, qs, a->b_h2a, q, a->w_alpha, a->b_alpha, a->ev_start, a->ev_len, sc, st));
-    hipLaunchKernelGGL(att_context_kernel, dim3(N, (D + 127) / 128), dim3(256), (((A + 31) & ~31) + 8 * 128) * sizeof(float), st, a->c3d, sc,
-                       a->ev_start, a->ev_len, wt, att, A, D);
-    RC(check_launch("att_context"));
+    if (do1) {
+        float* q = w.QS + (long)t * N * Ha;
+        float* sc = w.SC + (long)t * N * A;
+        float* wt = w.WT + (long)t * N * A;
+        float* att = w.ATT + (long)t * N * D;
+        {
+        // algorithmic bytes of one attention step: p_att rows + clip rows + scores/weights/context
+        const double rows = (double)N * A;
+        ProfScope prof(PROF_ATT_FWD, 2.0 * rows * (Ha + D) , 4.0 * (rows * (Ha + D + 2) + (double)N * (Ha + D)), st);
+        const AttDims ad{N, A, Ha, D};
+        RC(launch_att_score(ad, w.PALL, qacc, q_atomic ? 1 : w.nq, qs, a->b_h2a, q, a->w_alpha, a->b_alpha, a->ev_start, a->ev_len, sc, st));
+        hipLaunchKernelGGL(att_context_kernel, dim3(N, (D + 127) / 128), dim3(256), (((A + 31) & ~31) + 8 * 128) * sizeof(float), st, a->c3d, sc,
+                           a->ev_start, a->ev_len, wt, att, A, D);
+        RC(check_launch("att_context"));
+        }
+        ra.njobs = 1;
+        ra.job[0] = mkjob(att, D, D, a->w_ih[1] + E, E + D, 4 * H, w.GSL[1] + nh * gs, gs, 4 * H);
+        RC(rec_gemm(ra, st));
     }
-    ra.njobs = 1;
-    ra.job[0] = mkjob(att, D, D, a->w_ih[1] + E, E + D, 4 * H, w.GSL[1] + nh * gs, gs, 4 * H);
-    RC(rec_gemm(ra, st));
     LstmPtrs P;
+    int nk = 0;
     for (int k = 0; k < 3; ++k) {
         P.gates[k] = w.GATES[k] + (long)t * N * 4 * H;
         P.slab[k] = w.GSL[k];
         P.nslab[k] = w.ng[k];
         P.c_prev[k] = w.CS[k] + (long)t * N * H;
         P.c_new[k] = w.CS[k] + (long)(t + 1) * N * H;
+        P.kmap[k] = 0;
+        if (k == 1 ? do1 : do02) P.kmap[nk++] = k;
     }
     P.slab_stride = gs;
-    hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3((N * H + 255) / 256, 3), dim3(256), 0, st, P,
+    hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3((N * H + 255) / 256, nk), dim3(256), 0, st, P,
                        w.HS + (long)(t + 1) * N * 3 * H, w.OUTD + (long)t * N * 3 * H, N, H, t, dh, dout);
     return check_launch("lstm_pointwise_fwd");
 }
@@ -812,6 +836,7 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
     const DropCfg dh = make_drop(drop, drop ? drop->p_h : 0.f), dout = make_drop(drop, drop ? drop->p_out : 0.f);
     RC(fill_zero(w.HS, (long)N * 3 * H, st));                       // h(-1) = 0   (init_hidden, :75-78)
     for (int k = 0; k < 3; ++k) RC(fill_zero(w.CS[k], (long)N * H, st));
+    RC(fill_zero(w.QACC, (long)S * N * a->Ha, st));
     RC(precompute_static(a, w, st));
     RC(embed_gather(a->embed, a->tokens, w.XT, S * N, E, a->V1, st));
     RC(input_gates(a, w, w.XT, 0, S, st));
@@ -824,13 +849,21 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
         RC(gemm(d, q));
         return logsoftmax_rows(a->logp, a->V1, N, S, t0, t1 - t0, a->V1, q);
     };
-    const bool ov = overlap_enabled() && S >= 4;
+    const bool two = config().chains2 == 1 && side().ok && S >= 2;     // streams 0/2 recur on the side stream
+    const bool ov = !two && overlap_enabled() && S >= 4;
     const int th = ov ? S / 2 : 0;
-    for (int t = 0; t < S; ++t) {
-        RC(step_fwd(a, w, t, dh, dout, st));
-        if (ov && t == th - 1) {
-            RC(hop(st, side().fork, side().s));
-            RC(logits_chunk(0, th, side().s));
+    if (two) {
+        RC(hop(st, side().fork, side().s));
+        for (int t = 0; t < S; ++t) RC(step_fwd(a, w, t, dh, dout, side().s, 2, true));
+        for (int t = 0; t < S; ++t) RC(step_fwd(a, w, t, dh, dout, st, 1, true));
+        RC(hop(side().s, side().join, st));
+    } else {
+        for (int t = 0; t < S; ++t) {
+            RC(step_fwd(a, w, t, dh, dout, st, 0, true));
+            if (ov && t == th - 1) {
+                RC(hop(st, side().fork, side().s));
+                RC(logits_chunk(0, th, side().s));
+            }
         }
     }
     RC(logits_chunk(th, S, st));
@@ -878,6 +911,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     RC(transpose(a->w_h2a, H, b.WT_H2A, Ha, Ha, H, Ha, st));
     RC(fill_zero(b.DC, (long)N * 3 * H, st));
     RC(fill_zero(b.DQ, (long)SN * Ha, st));
+    RC(fill_zero(b.DASL, (long)SN * D, st));
     const long hs = (long)N * H, as = (long)N * D;
     const int n4h = ksplit_of(4 * H);
     // weight gradients that are sums over timesteps [t0,t1): W_hh_k, W_ih_k[:, :E], W_ih1[:, E:], W_h2a.
@@ -903,8 +937,11 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         return gemm(e, q);
     };
     const int th_b = ov ? S / 2 : S;       // timesteps [th_b, S) get their weight gradients on the side stream
-    for (int t = S - 1; t >= 0; --t) {
+    // one reverse timestep; `chain` as in step_fwd (0 = everything, 1 = attention chain / stream 1, 2 = streams 0 and 2)
+    auto bwd_step = [&](int t, int chain, hipStream_t q) -> int {
+        const bool do1 = chain != 2, do02 = chain != 1;
         LstmBwdPtrs P;
+        int nk = 0;
         for (int k = 0; k < 3; ++k) {
             P.gates[k] = w.GATES[k] + (long)t * N * 4 * H;
             P.c_prev[k] = w.CS[k] + (long)t * N * H;
@@ -912,34 +949,51 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
             P.dgates[k] = b.DG[k] + (long)t * N * 4 * H;
             P.dh_slab[k] = b.DHSL[k];
             P.nslab[k] = (t == S - 1) ? 0 : b.ndh[k];           // slabs hold d h(t), written while processing step t+1
+            P.kmap[k] = 0;
+            if (k == 1 ? do1 : do02) P.kmap[nk++] = k;
         }
         P.slab_stride = hs;
-        hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((N * H + 255) / 256, 3), dim3(256), 0, st, P,
+        hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((N * H + 255) / 256, nk), dim3(256), 0, q, P,
                            b.DOUT + (long)t * N * 3 * H, b.DC, N, H, t, dh, dout);
         RC(check_launch("lstm_pointwise_bwd"));
         // d h(t-1) = dG_k(t) . W_hh_k  (skipped at t = 0: h(-1) is the constant zero state);  d ATT = dG_1(t) . W_ih1[:,E:]
         RecArgs ra;
         ra.M = N; ra.njobs = 0;
-        ra.job[ra.njobs++] = mkjob(P.dgates[1], 4 * H, 4 * H, b.WT_ATT, 4 * H, D, b.DASL, as, D);
+        float* datt = b.DASL + (long)t * N * D;     // re-read by every attention workgroup of an event: one atomically summed buffer
+        if (do1) ra.job[ra.njobs++] = mkjob(P.dgates[1], 4 * H, 4 * H, b.WT_ATT, 4 * H, D, datt, as, D, 1);
         if (t > 0)
-            for (int k = 0; k < 3; ++k) ra.job[ra.njobs++] = mkjob(P.dgates[k], 4 * H, 4 * H, b.WT_HH[k], 4 * H, H, b.DHSL[k], hs, H);
-        RC(rec_gemm(ra, st));
+            for (int k = 0; k < 3; ++k)
+                if (k == 1 ? do1 : do02) ra.job[ra.njobs++] = mkjob(P.dgates[k], 4 * H, 4 * H, b.WT_HH[k], 4 * H, H, b.DHSL[k], hs, H);
+        if (ra.njobs > 0) RC(rec_gemm(ra, q));
+        if (!do1) return 0;
         // attention backward (needed at every t: feeds d P_all, d alpha, d W_h)
         float* dq = b.DQ + (long)t * N * Ha;
         {
-        ProfScope prof(PROF_ATT_BWD, 4.0 * N * A * (Ha + D), 4.0 * ((double)N * A * (Ha + D + 2) + (double)N * (2 * Ha + 2 * D)), st);
+        ProfScope prof(PROF_ATT_BWD, 4.0 * N * A * (Ha + D), 4.0 * ((double)N * A * (Ha + D + 2) + (double)N * (2 * Ha + 2 * D)), q);
         const AttDims ad{N, A, Ha, D};
         RC(launch_att_bwd(ad, w.PALL, a->c3d, w.QS + (long)t * N * Ha, a->w_alpha, w.WT + (long)t * N * A, w.ATT + (long)t * N * D,
-                          b.DASL, b.nda, as, a->ev_start, a->ev_len, b.DSC + (long)t * N * A, dq, st));
+                          datt, 1, as, a->ev_start, a->ev_len, b.DSC + (long)t * N * A, dq, q));
         }
         if (t > 0) {   // d h1(t-1) += dq . W_h : extra slabs behind stream 1's W_hh slabs
             ra.njobs = 1;
             ra.job[0] = mkjob(dq, Ha, Ha, b.WT_H2A, Ha, H, b.DHSL[1] + n4h * hs, hs, H);
-            RC(rec_gemm(ra, st));
+            RC(rec_gemm(ra, q));
         }
-        if (ov && t == th_b) {     // DG / DQ of timesteps [th_b, S) are final: their weight gradients overlap the rest
-            RC(hop(st, side().half, sq));
-            RC(wgrad_chunk(th_b, S, zb, sq));
+        return 0;
+    };
+    const bool two = !ov && config().chains2 == 1 && side().ok && S >= 2;
+    if (two) {          // streams 0/2 are independent of the attention chain: their reverse recurrence runs on the side stream
+        RC(hop(st, side().fork, side().s));
+        for (int t = S - 1; t >= 0; --t) RC(bwd_step(t, 2, side().s));
+        for (int t = S - 1; t >= 0; --t) RC(bwd_step(t, 1, st));
+        RC(hop(side().s, side().join, st));
+    } else {
+        for (int t = S - 1; t >= 0; --t) {
+            RC(bwd_step(t, 0, st));
+            if (ov && t == th_b) {     // DG / DQ of timesteps [th_b, S) are final: their weight gradients overlap the rest
+                RC(hop(st, side().half, sq));
+                RC(wgrad_chunk(th_b, S, zb, sq));
+            }
         }
     }
     // 4. batched parameter gradients

@@ -17,7 +17,7 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; };
 Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);

@@ -1,2 +1,3 @@
-for sl in 2 4 8; do ECHR_ATT_SLOTS=$sl timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('slots', $sl, d['ms_per_step'], d['roofline']['classes_ms_per_step'])"; done
+for c in 1 0; do ECHR_CHAINS2=$c timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu --no-roofline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('chains2', $c, d['ms_per_step'], d['config']['final_loss'])"; done
+timeout -k 10 300 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -3
