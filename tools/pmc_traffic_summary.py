@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB), with the gfx950 correction
+(FETCH_SIZE reports exactly half of the bytes of wide coalesced reads -> doubled).  Writes JSON: kernel -> bytes/launch."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+d = sys.argv[1]
+
+
+def load(sub, counter):
+    f = glob.glob('%s/%s/**/*counter_collection.csv' % (d, sub), recursive=True)[0]
+    agg, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] != counter:
+            continue
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('echr::', '')
+        k = k.split('<')[0] if k.startswith('gemm_f32_kernel') else k
+        agg[k] += float(r['Counter_Value'])
+        cnt[k] += 1
+    return agg, cnt
+
+
+fe, nf = load('fetch', 'FETCH_SIZE')
+wr, nw = load('write', 'WRITE_SIZE')
+out = {}
+for k in sorted(fe, key=lambda k: -fe[k]):
+    if not (k.startswith(('gemm', 'rec_gemm', 'att_', 'lstm', 'clamp_adam'))):
+        continue
+    out[k] = dict(launches=nf[k], fetch_bytes_per_launch=round(2 * 1024 * fe[k] / nf[k]), write_bytes_per_launch=round(1024 * wr.get(k, 0) / max(nw.get(k, 1), 1)))
+    out[k]['hbm_bytes_per_launch'] = out[k]['fetch_bytes_per_launch'] + out[k]['write_bytes_per_launch']
+print(json.dumps(out, indent=1))
