@@ -286,3 +286,41 @@ def test_flat_arena_path_matches_per_tensor_path(case):
     for k, p in ma.named_parameters():
         if p.grad is not None:
             assert U.grad_close(k, p.grad.cpu().numpy(), 2 * g1[k].cpu().numpy(), 1e-4), k
+
+
+@pytest.mark.parametrize('N,A,T_v,L,V1', [(1, 5, 9, 4, 57), (100, 37, 160, 7, 301), (70, 200, 256, 6, 129), (3, 1, 4, 3, 11)])
+def test_odd_shapes_vs_oracle(N, A, T_v, L, V1):
+    """Shapes off the tuned path: N not a multiple of the 64-row MFMA block (N=1, 70, 100), A > 128 (config-5-like 256-segment
+    videos), single-slot events, tiny vocabularies -- forward, loss and every gradient against the oracle (train mode)."""
+    opt = synth.default_opt(vocab_size=V1 - 1, seq_length=L - 2)
+    params = synth.make_params(opt, 3)
+    vid = synth.make_video(N, A, L, V1, seed=N * 7 + A, T_v=T_v, min_len=1)
+    pred, loss, grads, _ = U.run_gpu(opt, params, vid, True)
+    rpred, rloss, rgrads = U.run_oracle(opt, params, vid, True)
+    assert pred.shape == rpred.shape
+    assert np.abs(pred - rpred).max() < TOL_LOGP, np.abs(pred - rpred).max()
+    assert abs(loss - rloss) < TOL_LOSS * abs(rloss)
+    for k, g in rgrads.items():
+        if g is None:
+            assert grads[k] is None, k
+        else:
+            assert U.grad_close(k, grads[k], g, TOL_GRAD), (k, U.relerr(grads[k], g))
+
+
+def test_split_gemm_switch_does_not_change_results_beyond_tolerance():
+    """echr_config_set('gemm_bf16x3', 0/1): the bf16-plane split products and the native fp32 MFMA products agree to ~1e-6."""
+    from echr_amd import _lib
+    lib = _lib.load()
+    opt, params, vid = synth.make_case('c1')
+    try:
+        assert lib.echr_config_set(b'gemm_bf16x3', 0) == 0
+        p0, l0, g0, _ = U.run_gpu(opt, params, vid, False)
+        assert lib.echr_config_set(b'gemm_bf16x3', 1) == 0
+        p1, l1, g1, _ = U.run_gpu(opt, params, vid, False)
+    finally:
+        lib.echr_config_set(b'gemm_bf16x3', 1)
+    assert np.abs(p0 - p1).max() < 2e-5 and abs(l0 - l1) < 1e-5 * abs(l0)
+    for k in g0:
+        if g0[k] is not None:
+            assert U.grad_close(k, g1[k], g0[k], 1e-4), k
+    assert lib.echr_config_set(b'no_such_key', 1) != 0
