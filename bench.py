@@ -46,6 +46,7 @@ def gpu_leg(args, rank, world, local_rank):
     from echr_amd.optim import ClampAdam
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+    use_dist = dist.is_available() and dist.is_initialized()
     opt, params, vid = make_workload(rank, args.overlap)
     model = echr_amd.CaptionGenerator(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
@@ -63,14 +64,14 @@ def gpu_leg(args, rank, world, local_rank):
         pred = model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
         loss = crit(pred, tgt, msk)
         loss.backward()
-        if world > 1:
-            parallel.allreduce_gradients(model)                    # SUM over ranks == reference m_batch accumulation
+        if use_dist:
+            parallel.allreduce_gradients(model, force=True)        # SUM over ranks == reference m_batch accumulation
         clip_gradient(optim, opt.grad_clip)
         optim.step()
         return loss
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -89,7 +90,7 @@ def gpu_leg(args, rank, world, local_rank):
         loss = iteration()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -214,8 +215,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or os.environ.get('ECHR_FORCE_DIST') == '1':       # ECHR_FORCE_DIST: exercise the RCCL path with one rank
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
     dt, loss, roof = gpu_leg(args, rank, world, local_rank)
@@ -236,7 +239,7 @@ def main():
         if world == 1 and not args.no_cpu:
             out['cpu_baseline'] = cpu_leg(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -16,9 +16,9 @@ def live_grads(module):
     return [p for p in module.parameters() if p.grad is not None]
 
 
-def allreduce_gradients(module, group=None, bucket_bytes=64 << 20):
+def allreduce_gradients(module, group=None, bucket_bytes=64 << 20, force=False):
     """Sum the gradients over ranks in a few large flat buckets (xGMI is point-to-point: few large messages)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return 0
     arena = getattr(module, '_echr_arena', None)
     if arena is not None and arena.grads_in_arena():
