@@ -1,34 +1,43 @@
-"""SST proposal encoder (reference: models/sst_model.py:5-40) -- the PRODUCER of `tap_feats`.
+"""SST proposal encoder -- the PRODUCER of `tap_feats` for the caption path (reference: models/sst_model.py:5-40).
 
-SURVEY section 8 marks this "next" (row f-1), outside rows (a)-(e): it is kept on stock PyTorch-ROCm
-modules (nn.LSTM -> MIOpen) so that reference-style drivers can construct `models.setup_tap(opt)` and feed
-the HIP caption path; it is NOT part of the parity/roofline claims of this round.
+SURVEY section 8 lists it as a "next" row (f-1), outside rows (a)-(e).  It is kept on stock PyTorch-ROCm modules
+(nn.LSTM runs on MIOpen) so that reference-style drivers can build `models.setup_tap(opt)` and feed the HIP caption path;
+it takes no part in this round's parity / roofline claims.  Parameter names (`rnn.*`, `scores.*`) match the reference, so
+its checkpoints load.
 """
 import torch
-import torch.nn as nn
+from torch import nn
 
 
 class SST(nn.Module):
+    """2-layer LSTM over the C3D segment sequence + a K-way sigmoid head (K anchor lengths ending at every segment)."""
+
     def __init__(self, opt):
-        super(SST, self).__init__()
-        self.scores = torch.nn.Linear(opt.hidden_dim, opt.K)
+        super().__init__()
+        self.K = opt.K
         self.video_dim = opt.video_dim
         self.rnn_type = opt.tap_rnn_type
         self.rnn_num_layers = opt.rnn_num_layers
         self.rnn_dropout = opt.rnn_dropout
-        self.K = opt.K
         self.data_for_test = []
-        self.rnn = nn.LSTM(opt.video_dim, opt.hidden_dim, opt.rnn_num_layers, batch_first=True, dropout=opt.rnn_dropout)
+        self.scores = nn.Linear(opt.hidden_dim, self.K)
+        self.rnn = nn.LSTM(input_size=opt.video_dim, hidden_size=opt.hidden_dim, num_layers=opt.rnn_num_layers,
+                           dropout=opt.rnn_dropout, batch_first=True)
 
-    def eval(self):                       # the reference only toggles the LSTM's inter-layer dropout (:25-29)
-        self.rnn.dropout = 0
+    # The reference overrides train()/eval() so that they ONLY switch the LSTM's inter-layer dropout (sst_model.py:25-29);
+    # module.training is left alone on purpose.
+    def _set_dropout(self, on):
+        self.rnn.dropout = self.rnn_dropout if on else 0
 
     def train(self, mode=True):
-        self.rnn.dropout = self.rnn_dropout if mode else 0
+        self._set_dropout(bool(mode))
+
+    def eval(self):
+        self._set_dropout(False)
 
     def forward(self, features):
-        x = features.unsqueeze(0)                                   # [1,T,D]
-        T = x.shape[1]
-        h, _ = self.rnn(x)
-        h = h.contiguous().view(T, -1)                              # tap_feats [T,hidden]
-        return h, torch.sigmoid(self.scores(h)).view(T, self.K)     # proposal scores [T,K]
+        """features [T, video_dim] -> (tap_feats [T, hidden_dim], proposal scores [T, K] in (0,1))."""
+        T = features.shape[0]
+        hidden, _ = self.rnn(features[None])          # one video per call: batch of 1
+        tap_feats = hidden.reshape(T, -1)
+        return tap_feats, self.scores(tap_feats).sigmoid().reshape(T, self.K)
