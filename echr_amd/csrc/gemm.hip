@@ -282,21 +282,23 @@ __device__ __forceinline__ void split_store(unsigned short* __restrict__ base, i
     *reinterpret_cast<uint2*>(base + 2 * plane_stride + off) = l;
 }
 
-// one [128 x 32] fp32 tile: 2 float4 per thread (512 threads); interior tiles load unconditionally, edge tiles use
-// clamped addresses + masks (both branch-free per lane; the tile class is workgroup-uniform)
-__device__ __forceinline__ void split_load(float4 (&r)[2], const float* __restrict__ P, long ld, int mn0, int k0, int MN, int K,
-                                           int kend, int tid) {
-    if (mn0 + 128 <= MN && k0 + BK <= kend) {
+// one [ROWS x 32] fp32 tile, ROWS*8/NT float4 per thread; interior tiles load unconditionally, edge tiles use clamped
+// addresses + masks (both branch-free per lane; the tile class is workgroup-uniform)
+template <int ROWS, int NT>
+__device__ __forceinline__ void split_load(float4 (&r)[ROWS * 8 / NT], const float* __restrict__ P, long ld, int mn0, int k0, int MN,
+                                           int K, int kend, int tid) {
+    constexpr int L = ROWS * 8 / NT;
+    if (mn0 + ROWS <= MN && k0 + BK <= kend) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + i * 512;
+        for (int i = 0; i < L; ++i) {
+            const int f = tid + i * NT;
             r[i] = *reinterpret_cast<const float4*>(P + (long)(mn0 + (f >> 3)) * ld + k0 + 4 * (f & 7));
         }
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int f = tid + i * 512;
+    for (int i = 0; i < L; ++i) {
+        const int f = tid + i * NT;
         const int row = mn0 + (f >> 3), k = k0 + 4 * (f & 7);
         const float4 v = *reinterpret_cast<const float4*>(P + (long)min(row, MN - 1) * ld + min(k, K - 4));
         const float msk = (row < MN && k < kend) ? 1.f : 0.f;
@@ -304,15 +306,18 @@ __device__ __forceinline__ void split_load(float4 (&r)[2], const float* __restri
     }
 }
 
-// 8 waves (2 x 4) of 64x32 wave tiles; <= 128 VGPRs so that two workgroups (4 waves per SIMD) share a CU and one wave's
-// operand splitting (VALU) overlaps the other waves' MFMAs.
-__global__ __launch_bounds__(512, 4) void gemm_split_kernel(GemmParams p) {
-    constexpr int BM = 128, BN = 128, PS = 128 * SLD;                 // plane stride (bf16 elements)
-    __shared__ __attribute__((aligned(16))) unsigned short sm[6 * PS];   // A planes 0..2, B planes 0..2: 61,440 B
+// 128 x BN tile, 2 x (BN/32) waves of 64x32 wave tiles (8 waves for BN = 128, 4 for BN = 64); <= 128 VGPRs so that several
+// workgroups (4 waves per SIMD) share a CU and one wave's operand splitting (VALU) overlaps the other waves' MFMAs.
+template <int BN>
+__global__ __launch_bounds__(BN * 4, 4) void gemm_split_kernel(GemmParams p) {
+    constexpr int BM = 128, NT = BN * 4, WN_CNT = BN / 32;
+    constexpr int PSA = BM * SLD, PSB = BN * SLD;                     // plane strides (bf16 elements)
+    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;
+    __shared__ __attribute__((aligned(16))) unsigned short sm[3 * PSA + 3 * PSB];   // 61,440 B (BN=128) / 46,080 B (BN=64)
     unsigned short* As = sm;
-    unsigned short* Bs = sm + 3 * PS;
+    unsigned short* Bs = sm + 3 * PSA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;
+    const int wm = (wave / WN_CNT) * 64, wn = (wave % WN_CNT) * 32;
     const int l31 = lane & 31, h = lane >> 5;
     const int nwg = p.tiles_m * p.tiles_n;
     int bid = blockIdx.x;
@@ -335,18 +340,19 @@ __global__ __launch_bounds__(512, 4) void gemm_split_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
 
-    float4 ra0[2], rb0[2], ra1[2], rb1[2];
-    if (kt0 < kt1) { split_load(ra0, A, p.sam, m0, kt0 * BK, p.M, p.K, kend, tid); split_load(rb0, B, p.sbn, n0, kt0 * BK, p.N, p.K, kend, tid); }
-    if (kt0 + 1 < kt1) { split_load(ra1, A, p.sam, m0, (kt0 + 1) * BK, p.M, p.K, kend, tid); split_load(rb1, B, p.sbn, n0, (kt0 + 1) * BK, p.N, p.K, kend, tid); }
+    float4 ra0[LA], rb0[LB], ra1[LA], rb1[LB];
+    auto fetch = [&](float4 (&ra)[LA], float4 (&rb)[LB], int kt) {
+        split_load<BM, NT>(ra, A, p.sam, m0, kt * BK, p.M, p.K, kend, tid);
+        split_load<BN, NT>(rb, B, p.sbn, n0, kt * BK, p.N, p.K, kend, tid);
+    };
+    if (kt0 < kt1) fetch(ra0, rb0, kt0);
+    if (kt0 + 1 < kt1) fetch(ra1, rb1, kt0 + 1);
 
-    auto stage = [&](const float4 (&ra)[2], const float4 (&rb)[2]) {
+    auto stage = [&](const float4 (&ra)[LA], const float4 (&rb)[LB]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + i * 512;
-            const int off = (f >> 3) * SLD + 4 * (f & 7);
-            split_store(As, PS, off, ra[i]);
-            split_store(Bs, PS, off, rb[i]);
-        }
+        for (int i = 0; i < LA; ++i) { const int f = tid + i * NT; split_store(As, PSA, (f >> 3) * SLD + 4 * (f & 7), ra[i]); }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) { const int f = tid + i * NT; split_store(Bs, PSB, (f >> 3) * SLD + 4 * (f & 7), rb[i]); }
     };
     auto compute = [&]() {
 #pragma unroll
@@ -354,9 +360,9 @@ __global__ __launch_bounds__(512, 4) void gemm_split_kernel(GemmParams p) {
             bf16x8 a[2][3], bb[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                a[0][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PS + (wm + l31) * SLD + 16 * s + 8 * h);
-                a[1][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PS + (wm + 32 + l31) * SLD + 16 * s + 8 * h);
-                bb[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PS + (wn + l31) * SLD + 16 * s + 8 * h);
+                a[0][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PSA + (wm + l31) * SLD + 16 * s + 8 * h);
+                a[1][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PSA + (wm + 32 + l31) * SLD + 16 * s + 8 * h);
+                bb[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PSB + (wn + l31) * SLD + 16 * s + 8 * h);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -374,13 +380,13 @@ __global__ __launch_bounds__(512, 4) void gemm_split_kernel(GemmParams p) {
     for (int kt = kt0; kt < kt1; kt += 2) {
         stage(ra0, rb0);
         __syncthreads();
-        if (kt + 2 < kt1) { split_load(ra0, A, p.sam, m0, (kt + 2) * BK, p.M, p.K, kend, tid); split_load(rb0, B, p.sbn, n0, (kt + 2) * BK, p.N, p.K, kend, tid); }
+        if (kt + 2 < kt1) fetch(ra0, rb0, kt + 2);
         compute();
         __syncthreads();
         if (kt + 1 < kt1) {
             stage(ra1, rb1);
             __syncthreads();
-            if (kt + 3 < kt1) { split_load(ra1, A, p.sam, m0, (kt + 3) * BK, p.M, p.K, kend, tid); split_load(rb1, B, p.sbn, n0, (kt + 3) * BK, p.N, p.K, kend, tid); }
+            if (kt + 3 < kt1) fetch(ra1, rb1, kt + 3);
             compute();
             __syncthreads();
         }
@@ -429,12 +435,12 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     // products (tile quantisation: 400 big tiles on 256 CUs), so it is the default; 128x128 stays selectable for tuning.
     int BMs = 64, BNs = 64;
     bool w8 = false;
-    if (use_split) { BMs = 128; BNs = 128; }
+    if (use_split) { BMs = 128; BNs = ((long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch >= 200) ? 128 : 64; }
     if (const char* e = getenv("ECHR_GEMM_TILE")) {          // tuning override (tools/gemm_bench.py); never set in production
         if (e[0] == '1') { BMs = 128; BNs = 128; } else if (e[0] == '6') { BMs = 64; BNs = 64; }
         else if (e[0] == 'a') { BMs = 128; BNs = 64; } else if (e[0] == 'b') { BMs = 64; BNs = 128; }
         else if (e[0] == 'c') { BMs = 128; BNs = 128; w8 = true; }
-        if (use_split) { BMs = 128; BNs = 128; }
+        if (use_split) { BMs = 128; BNs = (e[0] == 's') ? 64 : 128; }
     }
     p.tiles_m = (d.M + BMs - 1) / BMs;
     p.tiles_n = (d.N + BNs - 1) / BNs;
@@ -472,7 +478,8 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     dim3 grid(p.tiles_m * p.tiles_n, 1, d.batch * split);
     // algorithmic work of this launch: 2MNK flops; one read of A and B, one write of C
     ProfScope prof(use_split ? PROF_GEMM_SPLIT : PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch, st);
-    if (use_split) hipLaunchKernelGGL(gemm_split_kernel, grid, dim3(512), 0, st, p);
+    if (use_split && BNs == 128) hipLaunchKernelGGL(gemm_split_kernel<128>, grid, dim3(512), 0, st, p);
+    else if (use_split) hipLaunchKernelGGL(gemm_split_kernel<64>, grid, dim3(256), 0, st, p);
     else if (BMs == 128 && BNs == 128 && w8) launch_cfg<128, 128, 64, 32>(p, akc, bkc, grid, st);
     else if (BMs == 128 && BNs == 128) launch_cfg<128, 128, 64, 64>(p, akc, bkc, grid, st);
     else if (BMs == 128) launch_cfg<128, 64, 64, 32>(p, akc, bkc, grid, st);

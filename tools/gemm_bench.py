@@ -8,7 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from echr_amd import _lib as L
 
-SHAPES = [  # (name, layout, M, N, K)
+SHAPES = [  ('wgradNT', 'NT', 2048, 512, 1280), ('dXT_NT', 'NT', 1280, 512, 2048),
+  # (name, layout, M, N, K)
     ('logits', 'NT', 1280, 5001, 1536), ('dOUT', 'NN', 1280, 1536, 5001), ('g_w_logit', 'TN', 5001, 1536, 1280),
     ('gin', 'NT', 1280, 2048, 512), ('dXT', 'NN', 1280, 512, 2048), ('g_w_hh', 'TN', 2048, 512, 1280),
     ('g_w_att', 'TN', 2048, 500, 1280), ('g_w_h2a', 'TN', 512, 512, 1280), ('g_w_c2a', 'TN', 512, 500, 8192),
@@ -64,4 +65,9 @@ if __name__ == '__main__':
         if sh[1] == 'NT':
             us, tf = run(*sh, algo=1)
             cells.append('bf16x3 %6.0fus %4.0fTF' % (us, tf))
+            os.environ['ECHR_GEMM_TILE'] = 's'
+            for sp in ('1', '2', '4'):
+                os.environ['ECHR_GEMM_SPLIT'] = sp
+                us, tf = run(*sh, algo=1)
+                cells.append('x3/64 s%s %5.0fus %4.0fTF' % (sp, us, tf))
         print('%-10s %-3s %5d %5d %5d | ' % sh + ' '.join('%14s' % c for c in cells), flush=True)
