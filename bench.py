@@ -59,7 +59,14 @@ def gpu_leg(args, rank, world, local_rank):
     tgt = labels[:, 1:].to(dev)
     msk = torch.from_numpy(vid['masks'])[:, 1:].to(dev)
 
+    def fwd_only():
+        with torch.no_grad():
+            pred = model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+            return crit(pred, tgt, msk)
+
     def iteration():
+        if args.mode == 'fwd':
+            return fwd_only()
         optim.zero_grad()
         pred = model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
         loss = crit(pred, tgt, msk)
@@ -208,6 +215,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--overlap', action='store_true', help='SURVEY 8-d one-video layout (T_v=160, events share rows)')
+    ap.add_argument('--mode', choices=['train', 'fwd'], default='train',
+                    help="'train' = fwd+bwd+clamp+Adam (BASELINE config 3, the headline metric); 'fwd' = forward + loss only (config 2)")
     ap.add_argument('--no-arena', action='store_true', help='per-tensor gradients/optimiser instead of the flat arena')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -224,19 +233,20 @@ def main():
     dt, loss, roof = gpu_leg(args, rank, world, local_rank)
     if rank == 0:
         value = args.steps * S_STEPS * world / dt
+        workload = '%s: %d events x %d seg x 500-d C3D (%s), S=%d decoder timesteps, V1=%d, %s, one video per GPU' % (
+            'c3' if args.mode == 'train' else 'c2', N_EV, A_SEG, 'T_v=160 overlapping' if args.overlap else 'disjoint rows, T_v=8192',
+            S_STEPS, V1, 'fwd+bwd+clamp+Adam' if args.mode == 'train' else 'forward + loss only (train-mode dropout)')
         out = {
-            'metric': 'caption-decoder timesteps/sec (fwd+bwd)', 'value': round(value, 1), 'unit': 'timesteps/s',
+            'metric': 'caption-decoder timesteps/sec (fwd+bwd)' if args.mode == 'train' else 'caption-decoder timesteps/sec (fwd only)', 'value': round(value, 1), 'unit': 'timesteps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'c3: %d events x %d seg x 500-d C3D (%s), S=%d decoder timesteps, V1=%d, fwd+bwd+clamp+Adam, '
-                                   'one video per GPU' % (N_EV, A_SEG, 'T_v=160 overlapping' if args.overlap else 'disjoint rows, T_v=8192',
-                                                          S_STEPS, V1),
+            'config': {'workload': workload,
                        'global_events': N_EV * world, 'timesteps_per_step': S_STEPS, 'parallelism': 'dp%d' % world,
                        'final_loss': round(loss, 5)},
         }
         if roof is not None:
             out['roofline'] = roof
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and args.mode == 'train':
             out['cpu_baseline'] = cpu_leg(args)
         print(json.dumps(out), flush=True)
     if dist.is_available() and dist.is_initialized():

@@ -808,16 +808,17 @@ static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, 
     const int N = a->N, H = a->H, E = a->E;
     const int rows = nt * N;
     const int cin[3] = {E + a->De, E + a->D, E + a->Dv};
+    echr_gemm_desc d[3];
     for (int k = 0; k < 3; ++k) {
         float* g = w.GATES[k] + (long)t0 * N * 4 * H;
-        echr_gemm_desc d = desc_nt(xt, E, a->w_ih[k], cin[k], g, 4 * H, rows, 4 * H, E);
-        if (k == 0) { d.addend = w.EVB0; d.add_mod = N; d.ld_add = 4 * H; }
-        else if (k == 1) { d.bias = a->b_ih[1]; d.bias2 = a->b_hh[1]; }
-        else { d.bias = w.VIDB; }
-        d.split_k = -1;
-        RC(gemm(d, st));
+        d[k] = desc_nt(xt, E, a->w_ih[k], cin[k], g, 4 * H, rows, 4 * H, E);
+        d[k].add_mod = N; d[k].ld_add = 4 * H;
+        if (k == 0) d[k].addend = w.EVB0;
+        else if (k == 1) { d[k].bias = a->b_ih[1]; d[k].bias2 = a->b_hh[1]; }
+        else d[k].bias = w.VIDB;
+        d[k].split_k = -1;
     }
-    return 0;
+    return gemm_grouped(d, 3, st);       // the three streams' token-side products in one launch
 }
 
 }  // namespace echr
@@ -920,15 +921,15 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         if (t1 <= t0) return 0;
         const long r0 = (long)t0 * N;
         const int rows = (t1 - t0) * N;
-        echr_gemm_desc e;
+        echr_gemm_desc e, ghh[3], gih[3];
         for (int k = 0; k < 3; ++k) {
-            e = desc_tn(b.DG[k] + r0 * 4 * H, 4 * H, w.HS + r0 * 3 * H + k * H, 3 * H, g->g_w_hh[k], H, 4 * H, H, rows);
-            e.beta = beta; e.split_k = -1;
-            RC(gemm(e, q));
-            e = desc_tn(b.DG[k] + r0 * 4 * H, 4 * H, w.XT + r0 * E, E, g->g_w_ih[k], cin[k], 4 * H, E, rows);
-            e.beta = beta; e.split_k = -1;
-            RC(gemm(e, q));
+            ghh[k] = desc_tn(b.DG[k] + r0 * 4 * H, 4 * H, w.HS + r0 * 3 * H + k * H, 3 * H, g->g_w_hh[k], H, 4 * H, H, rows);
+            ghh[k].beta = beta; ghh[k].split_k = -1;
+            gih[k] = desc_tn(b.DG[k] + r0 * 4 * H, 4 * H, w.XT + r0 * E, E, g->g_w_ih[k], cin[k], 4 * H, E, rows);
+            gih[k].beta = beta; gih[k].split_k = -1;
         }
+        RC(gemm_grouped(ghh, 3, q));        // three W_hh gradients in one launch
+        RC(gemm_grouped(gih, 3, q));        // three W_ih[:, :E] gradients in one launch
         e = desc_tn(b.DG[1] + r0 * 4 * H, 4 * H, w.ATT + r0 * D, D, g->g_w_ih[1] + E, cin[1], 4 * H, D, rows);
         e.beta = beta; e.split_k = -1;
         RC(gemm(e, q));
@@ -1037,10 +1038,13 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         RC(gemm(d, st));
     }
     //    token embedding: dXT = sum_k DG_k . W_ih_k[:, :E], scatter-added into the (caller-zeroed) table gradient
-    for (int k = 0; k < 3; ++k) {
-        d = desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], b.DXT, E, SN, E, 4 * H);
-        d.beta = k == 0 ? 0.f : 1.f; d.split_k = -1;
-        RC(gemm(d, st));
+    {
+        echr_gemm_desc gx[3];
+        for (int k = 0; k < 3; ++k) {
+            gx[k] = desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], b.DXT, E, SN, E, 4 * H);
+            gx[k].split_k = -1;                                  // shared output: zero-filled once, k-slices of all three add atomically
+        }
+        RC(gemm_grouped(gx, 3, st));
     }
     RC(embed_scatter_add(b.DXT, a->tokens, g->g_embed, SN, E, V1, st));
     return 0;

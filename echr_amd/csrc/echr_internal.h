@@ -21,6 +21,7 @@ struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; };
 Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);
+int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st);
 
 // C[M,N] = A[M,K] . W[N,K]^T  (nn.Linear forward; row-major operands with leading dimensions)
 inline echr_gemm_desc desc_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K) {

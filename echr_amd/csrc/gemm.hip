@@ -11,6 +11,7 @@
 // LDS tiles are stored k-major ([BK][BM+pad]) so the 32 lanes of a half-wave read 32 consecutive
 // floats (conflict-free ds_read_b32); pad = 1 when the tile is filled by transposing float4 loads
 // along k (scatter of b32 writes, conflict-free at stride BM+1), pad = 4 when filled along m (b128 writes).
+#include <cstdio>
 #include <cstdlib>
 #include "echr_common.h"
 #include "echr_internal.h"
@@ -34,7 +35,25 @@ struct GemmParams {
     int split_k, k_tiles_per_split;
     int tiles_m, tiles_n;
     int vecA, vecB;
+    // grouped launch: up to 4 same-shaped problems in one grid (blockIdx.z = group * split_k + k-slice); per-group operands
+    int ngroup;
+    const float* gA[4]; const float* gB[4]; float* gC[4];
+    long gsbk[4], gsbn[4], gldc[4];
+    const float* gbias[4]; const float* gbias2[4]; const float* gaddend[4];
 };
+
+__device__ __forceinline__ GemmParams select_group(const GemmParams& pin, int& z) {
+    GemmParams p = pin;
+    if (pin.ngroup > 1) {
+        const int per = pin.split_k;           // batch == 1 in grouped launches
+        const int gi = z / per;
+        z = z % per;
+        p.A = pin.gA[gi]; p.B = pin.gB[gi]; p.C = pin.gC[gi];
+        p.sbk = pin.gsbk[gi]; p.sbn = pin.gsbn[gi]; p.ldc = pin.gldc[gi];
+        p.bias = pin.gbias[gi]; p.bias2 = pin.gbias2[gi]; p.addend = pin.gaddend[gi];
+    }
+    return p;
+}
 
 // Shared epilogue: C = act(alpha*acc + beta*C + biases + addend) with optional output row remap; split-K slices add atomically.
 template <int TM, int TN>
@@ -150,8 +169,10 @@ __device__ __forceinline__ void store_tile(const float4 (&r)[BMN * 8 / NT], floa
 }
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(GemmParams pin) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    int z = blockIdx.z;
+    const GemmParams p = select_group(pin, z);
     constexpr int LDA = BM + (AKC ? 1 : 4);
     constexpr int LDB = BN + (BKC ? 1 : 4);
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -177,7 +198,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_f32_kernel(Ge
     }
     const int m0 = (bid / p.tiles_n) * BM;
     const int n0 = (bid % p.tiles_n) * BN;
-    const int z = blockIdx.z;
     const int b = z / p.split_k;
     const int ks = z % p.split_k;
 
@@ -309,8 +329,10 @@ __device__ __forceinline__ void split_load(float4 (&r)[ROWS * 8 / NT], const flo
 // 128 x BN tile, 2 x (BN/32) waves of 64x32 wave tiles (8 waves for BN = 128, 4 for BN = 64); <= 128 VGPRs so that several
 // workgroups (4 waves per SIMD) share a CU and one wave's operand splitting (VALU) overlaps the other waves' MFMAs.
 template <int BN>
-__global__ __launch_bounds__(BN * 4, 4) void gemm_split_kernel(GemmParams p) {
+__global__ __launch_bounds__(BN * 4, 4) void gemm_split_kernel(GemmParams pin) {
     constexpr int BM = 128, NT = BN * 4, WN_CNT = BN / 32;
+    int z = blockIdx.z;
+    const GemmParams p = select_group(pin, z);
     constexpr int PSA = BM * SLD, PSB = BN * SLD;                     // plane strides (bf16 elements)
     constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;
     __shared__ __attribute__((aligned(16))) unsigned short sm[3 * PSA + 3 * PSB];   // 61,440 B (BN=128) / 46,080 B (BN=64)
@@ -326,7 +348,7 @@ __global__ __launch_bounds__(BN * 4, 4) void gemm_split_kernel(GemmParams p) {
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
     }
     const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
-    const int z = blockIdx.z, b = z / p.split_k, ks = z % p.split_k;
+    const int b = z / p.split_k, ks = z % p.split_k;
     const float* A = p.A + (long)b * p.bsa;
     const float* B = p.B + (long)b * p.bsb;
     float* C = p.C + (long)b * p.bsc;
@@ -405,7 +427,26 @@ static void launch_cfg(const GemmParams& p, bool akc, bool bkc, dim3 grid, hipSt
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int gemm(const echr_gemm_desc& d, hipStream_t st) {
+static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st);
+int gemm(const echr_gemm_desc& d, hipStream_t st) { return gemm_impl(&d, 1, st); }
+
+// Up to 4 problems of identical shape/layout/epilogue mode in ONE launch (the three streams' W_ih / W_hh products): fills the
+// chip better than three 640-workgroup grids and pays one launch ramp.  Problems may share C when they accumulate (beta = 1).
+int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st) {
+    ECHR_REQUIRE(ds && ng >= 1 && ng <= 4, "gemm_grouped: 1..4 problems");
+    for (int i = 1; i < ng; ++i) {
+        const echr_gemm_desc &a = ds[0], &b = ds[i];
+        ECHR_REQUIRE(a.M == b.M && a.N == b.N && a.K == b.K && a.sam == b.sam && a.sak == b.sak && (a.sbk == 1) == (b.sbk == 1) &&
+                     (a.sbn == 1) == (b.sbn == 1) && a.batch == 1 && b.batch == 1 && a.alpha == b.alpha && a.beta == b.beta &&
+                     a.act == b.act && a.split_k == b.split_k && a.algo == b.algo && a.rowmap_mod == b.rowmap_mod &&
+                     a.add_mod == b.add_mod && a.ld_add == b.ld_add && a.act == ECHR_ACT_NONE,
+                     "gemm_grouped: problems must share shape, layout and epilogue mode");
+    }
+    return gemm_impl(ds, ng, st);
+}
+
+static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
+    const echr_gemm_desc& d = ds[0];
     ECHR_REQUIRE(d.A && d.B && d.C, "gemm: null operand");
     ECHR_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch >= 1, "gemm: bad shape M=%d N=%d K=%d batch=%d", d.M, d.N, d.K, d.batch);
     ECHR_REQUIRE(d.sam == 1 || d.sak == 1, "gemm: A needs a unit stride (sam=%ld sak=%ld)", (long)d.sam, (long)d.sak);
@@ -422,20 +463,30 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     p.addend = d.addend; p.add_mod = d.add_mod; p.ld_add = d.ld_add;
     p.act = d.act; p.aux = d.aux; p.ld_aux = d.ld_aux;
     p.rowmap_mod = d.rowmap_mod; p.rowmap_mul = d.rowmap_mul;
+    p.ngroup = ng;
+    for (int i = 0; i < 4; ++i) {
+        const echr_gemm_desc& g = ds[i < ng ? i : 0];
+        p.gA[i] = g.A; p.gB[i] = g.B; p.gC[i] = g.C; p.gsbk[i] = g.sbk; p.gsbn[i] = g.sbn; p.gldc[i] = g.ldc;
+        p.gbias[i] = g.bias; p.gbias2[i] = g.bias2; p.gaddend[i] = g.addend;
+    }
     const bool akc = (d.sak == 1);
     const bool bkc = (d.sbk == 1);
     const bool use_split = d.algo == ECHR_GEMM_BF16X3 && config().gemm_bf16x3 && akc && bkc && d.K % 4 == 0 && d.K >= 4 && d.sam % 4 == 0 &&
                            d.sbn % 4 == 0 && aligned16(d.A) && aligned16(d.B) && d.bsa % 4 == 0 && d.bsb % 4 == 0 &&
-                           (long)d.M * d.N >= 128L * 128L;
+                           (long)d.M * d.N >= 128L * 128L && ng == 1;
     p.vecA = akc ? (d.sam % 4 == 0 && aligned16(d.A) && d.bsa % 4 == 0) : (d.sak % 4 == 0 && aligned16(d.A) && d.bsa % 4 == 0);
     p.vecB = bkc ? (d.sbn % 4 == 0 && aligned16(d.B) && d.bsb % 4 == 0) : (d.sbk % 4 == 0 && aligned16(d.B) && d.bsb % 4 == 0);
+    for (int i = 1; i < ng; ++i) {
+        p.vecA = p.vecA && aligned16(ds[i].A);
+        p.vecB = p.vecB && aligned16(ds[i].B) && (bkc ? ds[i].sbn % 4 == 0 : ds[i].sbk % 4 == 0);
+    }
 
     // tile choice.  Measured on the c3 shapes (tools/gemm_bench.py): the 64x64 tile (7 waves/SIMD resident, latency hidden by
     // occupancy) matches or beats 128x128 (2 waves/SIMD) everywhere at these sizes, including the 1280 x 5001 x 1536 logit
     // products (tile quantisation: 400 big tiles on 256 CUs), so it is the default; 128x128 stays selectable for tuning.
     int BMs = 64, BNs = 64;
     bool w8 = false;
-    if (use_split) { BMs = 128; BNs = ((long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch >= 200) ? 128 : 64; }
+    if (use_split) { BMs = 128; BNs = ((long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch >= 96) ? 128 : 64; }
     if (const char* e = getenv("ECHR_GEMM_TILE")) {          // tuning override (tools/gemm_bench.py); never set in production
         if (e[0] == '1') { BMs = 128; BNs = 128; } else if (e[0] == '6') { BMs = 64; BNs = 64; }
         else if (e[0] == 'a') { BMs = 128; BNs = 64; } else if (e[0] == 'b') { BMs = 64; BNs = 128; }
@@ -448,7 +499,7 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
     int split = d.split_k;
     const bool accumulate = (d.split_k > 1 || d.split_k < 0);   // caller promises C already holds its base value
     if (split < 0) {  // auto: fill ~2 waves of workgroups over the chip when the output grid is small
-        long wgs = (long)p.tiles_m * p.tiles_n * d.batch;
+        long wgs = (long)p.tiles_m * p.tiles_n * d.batch * ng;
         split = 1;
         // latency-bound regime: fewer than 2 workgroups per CU.  Split K so that ~1024 workgroups overlap each other's
         // load latency, keeping at least 4 k-tiles (128 deep) per split (measured optimum on the weight-gradient shapes).
@@ -458,6 +509,11 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
         }
     }
     if (const char* e = getenv("ECHR_GEMM_SPLIT")) { if (d.split_k < 0 && atoi(e) > 0) split = atoi(e); }
+    // grouped problems that share an output must add atomically even when K would not be split: force two k-slices
+    bool shared_c = false;
+    for (int gi = 1; gi < ng; ++gi) for (int gj = 0; gj < gi; ++gj) shared_c = shared_c || ds[gi].C == ds[gj].C;
+    ECHR_REQUIRE(!shared_c || (d.split_k < 0 && kt_total >= 2), "gemm_grouped: problems sharing C need auto split-K (accumulate mode) and K > 32");
+    if (shared_c && split < 2) split = 2;
     if (split < 1) split = 1;
     if (split > kt_total) split = kt_total;
     p.k_tiles_per_split = (kt_total + split - 1) / split;
@@ -468,16 +524,24 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) {
         ECHR_REQUIRE(d.beta == 0.f || d.beta == 1.f, "gemm: auto split needs beta in {0,1}");
         if (split > 1 && d.beta == 0.f) {
             ECHR_REQUIRE(d.rowmap_mod == 0, "gemm: auto split cannot zero a row-remapped output");
-            for (int bb = 0; bb < d.batch; ++bb) {
-                int rc = fill_zero_2d(d.C + (long)bb * d.bsc, d.M, d.N, d.ldc, st);
-                if (rc) return rc;
+            for (int gi = 0; gi < ng; ++gi) {
+                bool seen = false;
+                for (int gj = 0; gj < gi; ++gj) seen = seen || ds[gj].C == ds[gi].C;
+                if (seen) continue;
+                for (int bb = 0; bb < d.batch; ++bb) {
+                    int rc = fill_zero_2d(ds[gi].C + (long)bb * d.bsc, d.M, d.N, ds[gi].ldc, st);
+                    if (rc) return rc;
+                }
             }
         }
         if (split == 1) p.beta = d.beta;
     } else if (accumulate && split == 1) p.beta = 1.f;
-    dim3 grid(p.tiles_m * p.tiles_n, 1, d.batch * split);
+    dim3 grid(p.tiles_m * p.tiles_n, 1, d.batch * split * ng);
+    static const bool log_on = getenv("ECHR_GEMM_LOG") != nullptr;
+    if (log_on) fprintf(stderr, "[gemm] M=%d N=%d K=%d batch=%d %s%s tile=%dx%d split=%d algo=%s wgs=%d\n", d.M, d.N, d.K, d.batch, akc ? "N" : "T",
+                        bkc ? "T" : "N", BMs, BNs, split, use_split ? "bf16x3" : "f32", (int)(grid.x * grid.z));
     // algorithmic work of this launch: 2MNK flops; one read of A and B, one write of C
-    ProfScope prof(use_split ? PROF_GEMM_SPLIT : PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch, st);
+    ProfScope prof(use_split ? PROF_GEMM_SPLIT : PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch * ng, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch * ng, st);
     if (use_split && BNs == 128) hipLaunchKernelGGL(gemm_split_kernel<128>, grid, dim3(512), 0, st, p);
     else if (use_split) hipLaunchKernelGGL(gemm_split_kernel<64>, grid, dim3(256), 0, st, p);
     else if (BMs == 128 && BNs == 128 && w8) launch_cfg<128, 128, 64, 32>(p, akc, bkc, grid, st);
