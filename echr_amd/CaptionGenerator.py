@@ -82,6 +82,6 @@ class CaptionGenerator(nn.Module):
         (no `_ev`) get the reference's padded [N,A,D] tensor and [N,A] mask (CaptionGenerator.py:140-167)."""
         if _ev is not None:
             ev_start, ev_len, _, A = _ev
-            return ClipView(c3d_feats, ev_start, ev_len, A), None
+            return ClipView(c3d_feats, ev_start, ev_len, A, EF.rows_disjoint(soi_select_list)), None
         ev_start, ev_len, _, A = EF.event_index_tensors(soi_select_list, ind_select_list, c3d_feats.device)
         return ClipView(c3d_feats, ev_start, ev_len, A).materialize()

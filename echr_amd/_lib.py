@@ -42,7 +42,7 @@ class TsrmGrads(C.Structure):
 
 class DecArgs(C.Structure):
     _fields_ = [('N', i32), ('A', i32), ('Tv', i32), ('D', i32), ('H', i32), ('E', i32), ('Ha', i32), ('De', i32),
-                ('Dv', i32), ('V1', i32), ('S', i32),
+                ('Dv', i32), ('V1', i32), ('S', i32), ('rows_disjoint', i32),
                 ('embed', c_f), ('w_logit', c_f), ('b_logit', c_f),
                 ('w_ih', c_f * 3), ('w_hh', c_f * 3), ('b_ih', c_f * 3), ('b_hh', c_f * 3),
                 ('w_c2a', c_f), ('b_c2a', c_f), ('w_h2a', c_f), ('b_h2a', c_f), ('w_alpha', c_f), ('b_alpha', c_f),
@@ -80,6 +80,7 @@ SYMBOLS = [
     ('echr_decoder_fwd', i32, [C.POINTER(DecArgs), C.POINTER(Dropout), C.c_void_p]),
     ('echr_decoder_bwd', i32, [C.POINTER(DecArgs), C.POINTER(DecGrads), C.POINTER(Dropout), C.c_void_p]),
     ('echr_nll_loss_fwd', i32, [c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
+    ('echr_nll_loss_bwd', i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_sampler_ws_floats', i64, [C.POINTER(DecArgs)]),
     ('echr_decoder_sample', i32, [C.POINTER(SampleArgs), C.c_void_p]),
     ('echr_config_set', i32, [C.c_char_p, i32]),

@@ -142,7 +142,7 @@ int fill_zero(float* p, long n, hipStream_t st) {
 // several row chunks (grid.y) add their partial sums atomically into the zero-initialised output.
 constexpr int CS_ROWS = 256;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, int rows, int cols,
-                                                     float* __restrict__ out, int mode) {
+                                                     float* __restrict__ out, float* __restrict__ out2, int mode) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -154,16 +154,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     __syncthreads();
     if (wave == 0 && col < cols) {
         const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-        if (mode == 0) out[col] = t;            // single chunk, overwrite
-        else atomicAdd(&out[col], t);           // accumulate / multi-chunk
+        if (mode == 0) { out[col] = t; if (out2) out2[col] = t; }            // single chunk, overwrite
+        else { atomicAdd(&out[col], t); if (out2) atomicAdd(&out2[col], t); }   // accumulate / multi-chunk
     }
 }
-int colsum(const float* X, long ld, int rows, int cols, float* out, bool accumulate, hipStream_t st) {
+int colsum2(const float* X, long ld, int rows, int cols, float* out, float* out2, bool accumulate, hipStream_t st) {
     const int chunks = (rows + CS_ROWS - 1) / CS_ROWS;
     int mode = (accumulate || chunks > 1) ? 1 : 0;
-    if (!accumulate && chunks > 1) { int rc = fill_zero(out, cols, st); if (rc) return rc; }
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, st, X, ld, rows, cols, out, mode);
+    if (!accumulate && chunks > 1) {
+        int rc = fill_zero(out, cols, st); if (rc) return rc;
+        if (out2) { rc = fill_zero(out2, cols, st); if (rc) return rc; }
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, st, X, ld, rows, cols, out, out2, mode);
     return check_launch("colsum");
+}
+int colsum(const float* X, long ld, int rows, int cols, float* out, bool accumulate, hipStream_t st) {
+    return colsum2(X, ld, rows, cols, out, nullptr, accumulate, st);
 }
 
 __global__ void sum_over_time_kernel(const float* __restrict__ X, long ld, int S, int N, int cols,
@@ -268,6 +274,19 @@ __global__ __launch_bounds__(256) void nll_loss_kernel(const float* __restrict__
     s = block_sum(s, red);
     ms = block_sum(ms, red);
     if (threadIdx.x == 0) { out[0] = s / (ms + 1e-6f); out[1] = ms; }
+}
+
+// backward of the masked NLL as ONE pass: g_logp[n,s,:] = 0 except g_logp[n,s,target] = -mask / (sum(mask) + 1e-6) * g_loss
+__global__ __launch_bounds__(256) void nll_loss_bwd_kernel(const int* __restrict__ target, const float* __restrict__ mask,
+                                                           const float* __restrict__ fwd_out, const float* __restrict__ g_loss,
+                                                           float* __restrict__ g_logp, int V1) {
+    const long row = blockIdx.x;
+    float4* o = reinterpret_cast<float4*>(g_logp + row * V1);
+    const float gv = -mask[row] / (fwd_out[1] + 1e-6f) * g_loss[0];
+    const int tg = min(max(target[row], 0), V1 - 1);
+    float* of = g_logp + row * V1;
+    for (int j = threadIdx.x; j < V1; j += 256) of[j] = (j == tg) ? gv : 0.f;
+    (void)o;
 }
 
 // ---- event pooling + anchor gather (CaptionGenerator.py:111-114,121,128) -----------------------------
@@ -483,4 +502,11 @@ extern "C" int echr_config_set(const char* key, int32_t value) {
     else if (!strcmp(key, "att_slots")) { ECHR_REQUIRE(value == 2 || value == 4 || value == 8, "config_set: att_slots must be 2, 4 or 8"); c.att_slots = value; }
     else { set_error("config_set: unknown key %s", key); return -22; }
     return 0;
+}
+
+extern "C" int echr_nll_loss_bwd(const int32_t* target, const float* mask, const float* fwd_out, const float* g_loss, float* g_logp,
+                                 int32_t N, int32_t S, int32_t V1, void* stream) {
+    ECHR_REQUIRE(target && mask && fwd_out && g_loss && g_logp && N > 0 && S > 0 && V1 > 0, "nll_loss_bwd: bad arguments");
+    hipLaunchKernelGGL(nll_loss_bwd_kernel, dim3(N * S), dim3(256), 0, (hipStream_t)stream, target, mask, fwd_out, g_loss, g_logp, V1);
+    return check_launch("nll_loss_bwd");
 }

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
                                                        const float* __restrict__ alpha, const float* __restrict__ DSC,
                                                        const int* __restrict__ ev_start, const int* __restrict__ ev_len,
                                                        float* __restrict__ DPALL, float* __restrict__ g_alpha,
-                                                       float* __restrict__ g_balpha, int S, int N, int A, int Ha) {
+                                                       float* __restrict__ g_balpha, int S, int N, int A, int Ha, int disjoint) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sqt = sm;                   // [TT][Ha]
     float* sds = sqt + TT * Ha;        // [TT][8] dscore tile
@@ -369,10 +369,14 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
             for (int r = 0; r < R; ++r) {
                 const int j = lane * 4 + r * 256;
                 if (j < Ha) {
-                    atomicAdd(drow + j + 0, dp[i][r].x * a4[r].x);
-                    atomicAdd(drow + j + 1, dp[i][r].y * a4[r].y);
-                    atomicAdd(drow + j + 2, dp[i][r].z * a4[r].z);
-                    atomicAdd(drow + j + 3, dp[i][r].w * a4[r].w);
+                    if (disjoint) {      // the row belongs to this event alone: plain 16-byte store
+                        *reinterpret_cast<float4*>(drow + j) = make_float4(dp[i][r].x * a4[r].x, dp[i][r].y * a4[r].y, dp[i][r].z * a4[r].z, dp[i][r].w * a4[r].w);
+                    } else {
+                        atomicAdd(drow + j + 0, dp[i][r].x * a4[r].x);
+                        atomicAdd(drow + j + 1, dp[i][r].y * a4[r].y);
+                        atomicAdd(drow + j + 2, dp[i][r].z * a4[r].z);
+                        atomicAdd(drow + j + 3, dp[i][r].w * a4[r].w);
+                    }
                 }
             }
         }
@@ -431,11 +435,11 @@ static int launch_att_bwd(const AttDims& d, const float* PALL, const float* C3D,
 }
 
 static int launch_att_post(const AttDims& d, const float* PALL, const float* QS, const float* alpha, const float* DSC, const int* ev_start,
-                           const int* ev_len, float* DPALL, float* g_alpha, float* g_balpha, int S, hipStream_t st) {
+                           const int* ev_len, float* DPALL, float* g_alpha, float* g_balpha, int S, int disjoint, hipStream_t st) {
     const dim3 grid(d.N, (d.A + 7) / 8), blk(256);
     const size_t sm = ((size_t)TT * d.Ha + TT * 8 + 4 * d.Ha) * sizeof(float);
     switch ((d.Ha + 255) / 256) {
-#define ECHR_CASE(R) case R: hipLaunchKernelGGL((att_post_kernel<R>), grid, blk, sm, st, PALL, QS, alpha, DSC, ev_start, ev_len, DPALL, g_alpha, g_balpha, S, d.N, d.A, d.Ha); break;
+#define ECHR_CASE(R) case R: hipLaunchKernelGGL((att_post_kernel<R>), grid, blk, sm, st, PALL, QS, alpha, DSC, ev_start, ev_len, DPALL, g_alpha, g_balpha, S, d.N, d.A, d.Ha, disjoint); break;
         ECHR_CASE(1) ECHR_CASE(2) ECHR_CASE(3) ECHR_CASE(4)
 #undef ECHR_CASE
         default: set_error("att_post: Ha too large"); return -22;
@@ -674,7 +678,7 @@ struct DecWsBwd {
     long snp;
     float *DHSL[3], *DASL;                   // split-K slabs: d h(t-1) per stream; DASL: [S,N,D] atomic accumulation target of d ATT
     int ndh[3], nda;
-    long ldg, total;
+    long ldg, total, zero_floats;
 };
 static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     DecWsBwd w;
@@ -685,10 +689,13 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     w.DLG = take(S * N * w.ldg);
     w.DOUT = take(S * N * 3 * H);
     for (int k = 0; k < 3; ++k) w.DG[k] = take(S * N * 4 * H);
-    w.DC = take(N * 3 * H);
     w.DSC = take(S * N * a->A);
+    // one contiguous zero-initialised region: DC | DQ | DASL | DPALL (a single fill per backward)
+    w.DC = take(N * 3 * H);
     w.DQ = take(S * N * a->Ha);
+    w.DASL = take(S * N * a->D);
     w.DPALL = take((long)a->Tv * a->Ha);
+    w.zero_floats = (w.DPALL - w.DC) + rup((long)a->Tv * a->Ha, 64);
     for (int k = 0; k < 3; ++k) w.DGSUM[k] = take(N * 4 * H);
     for (int k = 0; k < 3; ++k) w.DGCOL[k] = take(4 * H);
     w.DXT = take(S * N * a->E);
@@ -704,7 +711,6 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     w.ndh[1] = ksplit_of(4 * a->H) + ksplit_of(a->Ha);
     w.nda = ksplit_of(4 * a->H);
     for (int k = 0; k < 3; ++k) w.DHSL[k] = take((long)w.ndh[k] * N * H);
-    w.DASL = take(S * N * a->D);
     w.total = off;
     return w;
 }
@@ -836,7 +842,7 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
     DecWs w = carve_ws(a, a->ws);
     const DropCfg dh = make_drop(drop, drop ? drop->p_h : 0.f), dout = make_drop(drop, drop ? drop->p_out : 0.f);
     RC(fill_zero(w.HS, (long)N * 3 * H, st));                       // h(-1) = 0   (init_hidden, :75-78)
-    for (int k = 0; k < 3; ++k) RC(fill_zero(w.CS[k], (long)N * H, st));
+    RC(fill_zero_2d(w.CS[0], 3, N * H, w.CS[1] - w.CS[0], st));     // c(-1) = 0 for the three streams (equally spaced carve-outs)
     RC(fill_zero(w.QACC, (long)S * N * a->Ha, st));
     RC(precompute_static(a, w, st));
     RC(embed_gather(a->embed, a->tokens, w.XT, S * N, E, a->V1, st));
@@ -910,9 +916,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     for (int k = 0; k < 3; ++k) RC(transpose(a->w_hh[k], H, b.WT_HH[k], 4 * H, 4 * H, H, 4 * H, st));
     RC(transpose(a->w_ih[1] + E, cin[1], b.WT_ATT, 4 * H, 4 * H, D, 4 * H, st));
     RC(transpose(a->w_h2a, H, b.WT_H2A, Ha, Ha, H, Ha, st));
-    RC(fill_zero(b.DC, (long)N * 3 * H, st));
-    RC(fill_zero(b.DQ, (long)SN * Ha, st));
-    RC(fill_zero(b.DASL, (long)SN * D, st));
+    RC(fill_zero(b.DC, b.zero_floats, st));                   // DC | DQ | DASL | DPALL
     const long hs = (long)N * H, as = (long)N * D;
     const int n4h = ksplit_of(4 * H);
     // weight gradients that are sums over timesteps [t0,t1): W_hh_k, W_ih_k[:, :E], W_ih1[:, E:], W_h2a.
@@ -999,7 +1003,6 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     }
     // 4. batched parameter gradients
     //    attention: d P_all / d alpha over all timesteps, then ctx2att and h2att weights
-    RC(fill_zero(b.DPALL, (long)a->Tv * Ha, st));
     if (!z) {
         RC(fill_zero(g->g_w_alpha, Ha, st));
         RC(fill_zero(g->g_b_alpha, 1, st));
@@ -1007,7 +1010,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     {
     ProfScope prof(PROF_ATT_POST, 6.0 * N * A * Ha * S, 4.0 * ((double)N * A * Ha * 2 + (double)S * N * (Ha + A)), st);
     const AttDims ad{N, A, Ha, D};
-    RC(launch_att_post(ad, w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, g->g_w_alpha, g->g_b_alpha, S, st));
+    RC(launch_att_post(ad, w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, g->g_w_alpha, g->g_b_alpha, S, a->rows_disjoint ? 1 : 0, st));
     }
     d = desc_tn(b.DPALL, Ha, a->c3d, D, g->g_w_c2a, D, Ha, D, a->Tv);
     d.beta = zb; d.split_k = -1;
@@ -1019,9 +1022,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     RC(colsum(b.DQ, Ha, SN, Ha, g->g_b_h2a, z, st));
     for (int k = 0; k < 3; ++k) {
         RC(sum_over_time(b.DG[k], 4 * H, S, N, 4 * H, b.DGSUM[k], 4 * H, st));
-        RC(colsum(b.DGSUM[k], 4 * H, N, 4 * H, b.DGCOL[k], false, st));
-        RC(hipMemcpyAsync(g->g_b_ih[k], b.DGCOL[k], sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : -5);
-        RC(hipMemcpyAsync(g->g_b_hh[k], b.DGCOL[k], sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : -5);
+        RC(colsum2(b.DGSUM[k], 4 * H, N, 4 * H, g->g_b_ih[k], g->g_b_hh[k], z, st));       // b_ih and b_hh share their gradient
+        if (k == 2) RC(colsum(b.DGSUM[k], 4 * H, N, 4 * H, b.DGCOL[k], false, st));          // also needed as a vector below
     }
     //    context halves of W_ih: event (stream 0), attended clip (stream 1), video (stream 2)
     d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);

@@ -46,6 +46,7 @@ inline echr_gemm_desc desc_tn(const float* A, long lda, const float* B, long ldb
 
 // column sums: out[j] (+)= sum_i X[i*ld + j], i < rows
 int colsum(const float* X, long ld, int rows, int cols, float* out, bool accumulate, hipStream_t st);
+int colsum2(const float* X, long ld, int rows, int cols, float* out, float* out2, bool accumulate, hipStream_t st);
 // out[n*ld_out + j] = sum_t X[(t*N + n)*ld + j]
 int sum_over_time(const float* X, long ld, int S, int N, int cols, float* out, long ld_out, hipStream_t st);
 int fill_zero(float* p, long n, hipStream_t st);

@@ -41,6 +41,13 @@ def event_index_tensors(soi_select_list, ind_select_list, device, n_rows=None):
     return t[0].contiguous(), t[1].contiguous(), t[2].contiguous(), int(lens.max())
 
 
+def rows_disjoint(soi_select_list):
+    """True when no two events share a segment row (then d P_all rows are stored instead of atomically added)."""
+    soi = np.asarray(soi_select_list, dtype=np.int64).reshape(-1, 2)
+    o = soi[np.argsort(soi[:, 0], kind='stable')]
+    return bool(np.all(o[1:, 0] >= o[:-1, 1]))
+
+
 def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
@@ -157,7 +164,7 @@ DEC_PARAMS = ('embed', 'w_logit', 'b_logit',
               'w_c2a', 'b_c2a', 'w_h2a', 'b_h2a', 'w_alpha', 'b_alpha')
 
 
-def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp):
+def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint=False):
     (embed, w_logit, b_logit, wi0, wi1, wi2, wh0, wh1, wh2, bi0, bi1, bi2, bh0, bh1, bh2, w_c2a, b_c2a, w_h2a, b_h2a,
      w_alpha, b_alpha) = ps
     N, De = event.shape
@@ -168,7 +175,7 @@ def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp):
     Dv = video.numel()
     V1 = embed.shape[0]
     assert wi0.shape[1] == E + De and wi1.shape[1] == E + D and wi2.shape[1] == E + Dv, 'LSTM input widths do not match the contexts'
-    return L.DecArgs(N, A, Tv, D, H, E, Ha, De, Dv, V1, S,
+    return L.DecArgs(N, A, Tv, D, H, E, Ha, De, Dv, V1, S, 1 if disjoint else 0,
                      L.ptr(embed), L.ptr(w_logit), L.ptr(b_logit),
                      L.ptr3((wi0, wi1, wi2), 'w_ih'), L.ptr3((wh0, wh1, wh2), 'w_hh'), L.ptr3((bi0, bi1, bi2), 'b_ih'),
                      L.ptr3((bh0, bh1, bh2), 'b_hh'),
@@ -181,7 +188,7 @@ class DecoderFunction(torch.autograd.Function):
     """OldModel.forward with the ThreeStream core (OldModel_NEW.py:98-137, :376-401, :801-823): log-probs [N,S,V1]."""
 
     @staticmethod
-    def forward(ctx, video, event, c3d, ev_start, ev_len, tokens, A, drop, sink, *params):
+    def forward(ctx, video, event, c3d, ev_start, ev_len, tokens, A, disjoint, drop, sink, *params):
         lib = L.load()
         ctx.sink = sink
         video, event, c3d = _f32c(video), _f32c(event), _f32c(c3d)
@@ -189,20 +196,20 @@ class DecoderFunction(torch.autograd.Function):
         S, N = tokens.shape
         V1 = ps[0].shape[0]
         logp = torch.empty(N, S, V1, device=event.device, dtype=torch.float32)
-        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, None, logp)
+        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, None, logp, disjoint)
         ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=event.device, dtype=torch.float32)
         a.ws = L.ptr(ws)
         d = drop.c()
         L.check(lib.echr_decoder_fwd(C.byref(a), C.byref(d), L.stream_ptr()), 'decoder_fwd')
         ctx.save_for_backward(video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps)
-        ctx.meta = (A, S, drop)
+        ctx.meta = (A, S, drop, disjoint)
         return logp
 
     @staticmethod
     def backward(ctx, g_logp):
         lib = L.load()
         video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps = ctx.saved_tensors
-        A, S, drop = ctx.meta
+        A, S, drop, disjoint = ctx.meta
         g_logp = _f32c(g_logp)
         zeroed = 1 if (ctx.sink is not None and ctx.sink.usable()) else 0
         if zeroed:
@@ -212,7 +219,7 @@ class DecoderFunction(torch.autograd.Function):
             grads[0].zero_()                                 # embedding table gradient is scatter-added
         g_event = torch.empty_like(event)
         g_video = torch.empty_like(video) if ctx.needs_input_grad[0] else None
-        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp)
+        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint)
         wsb = torch.empty(lib.echr_decoder_ws_bwd_floats(C.byref(a)), device=event.device, dtype=torch.float32)
         gp = [L.ptr(x) for x in grads]
         g = L.DecGrads(gp[0], gp[1], gp[2], (L.c_f * 3)(*gp[3:6]), (L.c_f * 3)(*gp[6:9]), (L.c_f * 3)(*gp[9:12]),
@@ -220,7 +227,7 @@ class DecoderFunction(torch.autograd.Function):
                        L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp), None, None, None, L.ptr(wsb), zeroed)
         d = drop.c()
         L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
-        return (g_video, g_event, None, None, None, None, None, None, None) + tuple(grads)
+        return (g_video, g_event, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
 def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params):
@@ -272,11 +279,12 @@ class MaskedNLL(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        lib = L.load()
         tgt, msk, out = ctx.saved_tensors
         N, S, V1 = ctx.shape
-        coef = (-g / (out[1] + 1e-6)) * msk                       # [N,S]
-        g_logp = torch.zeros(N, S, V1, device=msk.device, dtype=torch.float32)
-        g_logp.scatter_(2, tgt.long().clamp_(0, V1 - 1).unsqueeze(2), coef.unsqueeze(2))
+        g_logp = torch.empty(N, S, V1, device=msk.device, dtype=torch.float32)
+        L.check(lib.echr_nll_loss_bwd(L.ptr(tgt, torch.int32), L.ptr(msk), L.ptr(out), L.ptr(_f32c(g).reshape(1)), L.ptr(g_logp), N, S, V1,
+                                      L.stream_ptr()), 'nll_loss_bwd')
         return g_logp, None, None
 
 

@@ -17,8 +17,9 @@ class ClipView(object):
     """The frame-level ('CC') context without the zero-padded copy: event n's slot a is row
     ev_start[n] + a of `feats` [T,D] (CaptionGenerator.py:140-167 materialises [N,A,D] + mask instead)."""
 
-    def __init__(self, feats, ev_start, ev_len, max_len):
+    def __init__(self, feats, ev_start, ev_len, max_len, rows_disjoint=False):
         self.feats, self.ev_start, self.ev_len, self.max_len = feats, ev_start, ev_len, int(max_len)
+        self.rows_disjoint = bool(rows_disjoint)          # no two events share a row of `feats`
 
     @property
     def shape(self):
@@ -41,7 +42,7 @@ class ClipView(object):
         if int(lens.min()) <= 0:
             raise ValueError('clip_mask has an empty row')
         starts = (torch.arange(N, device=clip.device, dtype=torch.int32) * A)
-        return ClipView(clip.reshape(N * A, D).contiguous(), starts.contiguous(), lens.contiguous(), A)
+        return ClipView(clip.reshape(N * A, D).contiguous(), starts.contiguous(), lens.contiguous(), A, rows_disjoint=True)
 
 
 def n_decoder_steps(seq):
@@ -138,7 +139,7 @@ class OldModel(nn.Module):
             drop = self.next_drop_state()
         arena = getattr(self, '_echr_arena_ref', None)
         sink = EF.GradSink(arena, self.native_params()) if arena is not None else None
-        return EF.DecoderFunction.apply(video, event, cv.feats, cv.ev_start, cv.ev_len, tokens, cv.max_len, drop, sink,
+        return EF.DecoderFunction.apply(video, event, cv.feats, cv.ev_start, cv.ev_len, tokens, cv.max_len, cv.rows_disjoint, drop, sink,
                                         *self.native_params())
 
     def get_logprobs_state(self, it, video, event, clip, clip_mask, state):

@@ -143,6 +143,7 @@ int echr_tsrm_posemb(const int32_t* ev_start, const int32_t* ev_len, float* pos,
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t N, A, Tv, D, H, E, Ha, De, Dv, V1, S;
+    int32_t rows_disjoint;                     /* 1: no two events share a video row (lets d P_all be stored instead of atomically added) */
     /* parameters (reference state_dict names under lm_model.) */
     const float* embed;                        /* embed.weight [V1,E] */
     const float *w_logit, *b_logit;            /* logit [V1,3H],[V1] */
@@ -192,6 +193,11 @@ int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g, const echr
 /* masked NLL of LanguageModelCriterion on log-probs [N,S,V1]: loss (device scalar) */
 int echr_nll_loss_fwd(const float* logp, const int32_t* target, const float* mask, float* loss, int32_t N, int32_t S,
                       int32_t V1, void* stream);
+
+/* backward of echr_nll_loss_fwd in one pass: g_logp [N,S,V1] (fully written); fwd_out = the 2-float output of the forward
+ * (loss, sum(mask)), g_loss = upstream scalar gradient (device) */
+int echr_nll_loss_bwd(const int32_t* target, const float* mask, const float* fwd_out, const float* g_loss, float* g_logp,
+                      int32_t N, int32_t S, int32_t V1, void* stream);
 
 /* greedy sampler: runs seq_len+1 decoder steps on device without host syncs.
  * seq [N,seq_len] int64 (zero after a row finished), seq_logp [N,seq_len] fp32,
