@@ -118,3 +118,19 @@ def test_cpu_call_fails_loudly():
     with pytest.raises(EchrHipError):
         m(torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), torch.from_numpy(vid['labels']),
           vid['ind'], vid['soi'], mode='train')
+
+
+def test_reference_made_checkpoint_loads():
+    """tests/golden/ref_tiny_checkpoint.pth was written by the reference's own CaptionGenerator / SST (tools/make_golden.py,
+    train.py's dict layout): both state dicts load strictly into the build's modules."""
+    from echr_amd import models
+    opt = synth.default_opt(**synth.CASES['tiny']['opt'])
+    ck = torch.load(os.path.join(U.GOLD, 'ref_tiny_checkpoint.pth'), map_location='cpu')
+    assert set(ck) >= {'iteration', 'cg_model', 'tap_model'} and ck['iteration'] == 7
+    cg = echr_amd.CaptionGenerator(opt)
+    res = cg.load_state_dict(ck['cg_model'], strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    tap = models.setup_tap(opt)
+    res = tap.load_state_dict(ck['tap_model'], strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(cg.lm_model.core.layer1.weight_ih, ck['cg_model']['lm_model.core.layer1.weight_ih'])

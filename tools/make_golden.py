@@ -254,6 +254,22 @@ def do_proposals():
     print('wrote proposals.npz')
 
 
+def do_checkpoint():
+    """A checkpoint written by the REFERENCE's own modules (its own random init) in train.py's dict layout (:456-461), plus
+    the reference's eval-mode log-probs for those weights on the 'tiny' inputs: the build must load it as is."""
+    opt, _, vid = synth.make_case('tiny')
+    torch.manual_seed(123)
+    m = RefCG(copy.copy(opt))
+    tap = models.setup_tap(copy.copy(opt))
+    torch.save({'iteration': 7, 'cg_model': m.state_dict(), 'tap_model': tap.state_dict()}, os.path.join(GOLD, 'ref_tiny_checkpoint.pth'))
+    m.eval()
+    with torch.no_grad():
+        pred = m(torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), torch.from_numpy(vid['labels']),
+                 vid['ind'], vid['soi'].tolist(), mode='train')
+    np.savez_compressed(os.path.join(GOLD, 'ref_tiny_checkpoint_out.npz'), logp=pred.numpy())
+    print('wrote ref_tiny_checkpoint.pth / ref_tiny_checkpoint_out.npz')
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', nargs='*', default=['tiny', 'c1', 'c2', 'c2full'])
@@ -265,5 +281,6 @@ if __name__ == '__main__':
         do_position()
         do_adam()
         do_proposals()
+        do_checkpoint()
     for c in a.cases:
         do_case(c)
