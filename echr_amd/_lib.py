@@ -58,6 +58,17 @@ class DecGrads(C.Structure):
                 ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f), ('zeroed', i32)]
 
 
+class SstArgs(C.Structure):
+    _fields_ = [('T', i32), ('D', i32), ('H', i32), ('K', i32), ('p_drop', f32),
+                ('w_ih', c_f * 2), ('w_hh', c_f * 2), ('b_ih', c_f * 2), ('b_hh', c_f * 2), ('w_sc', c_f), ('b_sc', c_f),
+                ('x', c_f), ('ws', c_f), ('tap_feats', c_f), ('scores', c_f)]
+
+
+class SstGrads(C.Structure):
+    _fields_ = [('g_w_ih', c_f * 2), ('g_w_hh', c_f * 2), ('g_b_ih', c_f * 2), ('g_b_hh', c_f * 2), ('g_w_sc', c_f), ('g_b_sc', c_f),
+                ('g_tap', c_f), ('g_scores', c_f), ('ws_bwd', c_f)]
+
+
 class SampleArgs(C.Structure):
     _fields_ = [('dec', DecArgs), ('seq_len', i32), ('seq', c_f), ('seq_logp', c_f), ('n_unfinished', c_f),
                 ('ws_sample', c_f)]
@@ -86,6 +97,12 @@ SYMBOLS = [
     ('echr_config_set', i32, [C.c_char_p, i32]),
     ('echr_prof_enable', i32, [i32]),
     ('echr_prof_read', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
+    ('echr_sst_ws_floats', i64, [i32, i32, i32, i32]),
+    ('echr_sst_ws_bwd_floats', i64, [i32, i32, i32, i32]),
+    ('echr_sst_fwd', i32, [C.POINTER(SstArgs), C.POINTER(Dropout), C.c_void_p]),
+    ('echr_sst_bwd', i32, [C.POINTER(SstArgs), C.POINTER(SstGrads), C.POINTER(Dropout), C.c_void_p]),
+    ('echr_tap_bce_fwd', i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, C.c_void_p]),
+    ('echr_tap_bce_bwd', i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, C.c_void_p]),
     ('echr_clamp', i32, [c_f, i64, f32, C.c_void_p]),
     ('echr_clamp_adam', i32, [c_f, c_f, c_f, c_f, i64, i32, C.c_double, C.c_double, C.c_double, C.c_double, f32, C.c_void_p]),
 ]

@@ -317,3 +317,76 @@ def gemm(A, B, trans_b=True, bias=None, algo=0):
     d.bias = L.ptr(bias) if bias is not None else None
     L.check(lib.echr_gemm_f32(C.byref(d), L.stream_ptr()), 'gemm_f32')
     return Cc
+
+
+# --------------------------------------------------------------------------------------------------
+class SSTFunction(torch.autograd.Function):
+    """SST.forward (models/sst_model.py:31-40): 2-layer LSTM over one video + sigmoid proposal head, native."""
+
+    @staticmethod
+    def forward(ctx, x, p_drop, drop, *params):
+        lib = L.load()
+        x = _f32c(x)
+        ps = [_f32c(p) for p in params]           # w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_sc, b_sc
+        T, D = x.shape
+        H, K = ps[1].shape[1], ps[8].shape[0]
+        dev = x.device
+        ws = torch.empty(lib.echr_sst_ws_floats(T, D, H, K), device=dev, dtype=torch.float32)
+        tap = torch.empty(T, H, device=dev, dtype=torch.float32)
+        scores = torch.empty(T, K, device=dev, dtype=torch.float32)
+        a = SSTFunction._args(ps, x, p_drop, ws, tap, scores)
+        d = drop.c()
+        L.check(lib.echr_sst_fwd(C.byref(a), C.byref(d), L.stream_ptr()), 'sst_fwd')
+        ctx.save_for_backward(x, ws, tap, scores, *ps)
+        ctx.meta = (p_drop, drop)
+        return tap, scores
+
+    @staticmethod
+    def _args(ps, x, p_drop, ws, tap, scores):
+        T, D = x.shape
+        H, K = ps[1].shape[1], ps[8].shape[0]
+        two = lambda a, b: (L.c_f * 2)(L.ptr(a), L.ptr(b))
+        return L.SstArgs(T, D, H, K, float(p_drop), two(ps[0], ps[4]), two(ps[1], ps[5]), two(ps[2], ps[6]), two(ps[3], ps[7]),
+                         L.ptr(ps[8]), L.ptr(ps[9]), L.ptr(x), L.ptr(ws), L.ptr(tap), L.ptr(scores))
+
+    @staticmethod
+    def backward(ctx, g_tap, g_scores):
+        lib = L.load()
+        x, ws, tap, scores, *ps = ctx.saved_tensors
+        p_drop, drop = ctx.meta
+        T, D = x.shape
+        H, K = ps[1].shape[1], ps[8].shape[0]
+        grads = [torch.empty_like(p) for p in ps]
+        wsb = torch.empty(lib.echr_sst_ws_bwd_floats(T, D, H, K), device=x.device, dtype=torch.float32)
+        a = SSTFunction._args(ps, x, p_drop, ws, tap, scores)
+        two = lambda a_, b_: (L.c_f * 2)(L.ptr(a_), L.ptr(b_))
+        g = L.SstGrads(two(grads[0], grads[4]), two(grads[1], grads[5]), two(grads[2], grads[6]), two(grads[3], grads[7]),
+                       L.ptr(grads[8]), L.ptr(grads[9]), L.ptr(_f32c(g_tap)) if g_tap is not None else None,
+                       L.ptr(_f32c(g_scores)) if g_scores is not None else None, L.ptr(wsb))
+        d = drop.c()
+        L.check(lib.echr_sst_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'sst_bwd')
+        return (None, None, None) + tuple(grads)
+
+
+class TapBCE(torch.autograd.Function):
+    """TAPModelCriterion.forward (misc/utils.py:78-99) on device."""
+
+    @staticmethod
+    def forward(ctx, scores, masks, labels, w1):
+        lib = L.load()
+        scores, masks, labels, w1 = _f32c(scores), _f32c(masks), _f32c(labels), _f32c(w1).reshape(-1)
+        T, K = scores.shape
+        loss = torch.empty(1, device=scores.device, dtype=torch.float32)
+        L.check(lib.echr_tap_bce_fwd(L.ptr(scores), L.ptr(masks), L.ptr(labels), L.ptr(w1), L.ptr(loss), T, K, L.stream_ptr()), 'tap_bce_fwd')
+        ctx.save_for_backward(scores, masks, labels, w1)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        scores, masks, labels, w1 = ctx.saved_tensors
+        T, K = scores.shape
+        gs = torch.empty_like(scores)
+        L.check(lib.echr_tap_bce_bwd(L.ptr(scores), L.ptr(masks), L.ptr(labels), L.ptr(w1), L.ptr(_f32c(g).reshape(1)), L.ptr(gs), T, K,
+                                     L.stream_ptr()), 'tap_bce_bwd')
+        return gs, None, None, None

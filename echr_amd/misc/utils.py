@@ -31,14 +31,10 @@ class LanguageModelCriterion(nn.Module):
 
 
 class TAPModelCriterion(nn.Module):
-    """Weighted BCE of the proposal head (misc/utils.py:78-99).  Belongs to the SST producer: stock ops."""
+    """Weighted BCE of the proposal head (misc/utils.py:78-99), evaluated by echr_tap_bce_fwd/bwd."""
 
     def forward(self, scores, masks, labels, w1):
-        w0 = 1. - w1
-        labels = labels * masks
-        weights = (labels * w0.expand_as(labels) + (1. - labels) * w1.expand_as(labels)).view(-1)
-        loss = nn.functional.binary_cross_entropy((scores.view(-1) * masks.view(-1)), labels.view(-1), weight=weights)
-        return loss * w0.shape[0]
+        return EF.TapBCE.apply(scores, masks.to(scores.device), labels.to(scores.device), w1.to(scores.device))
 
 
 def set_lr(optimizer, lr):

@@ -1,12 +1,15 @@
-"""SST proposal encoder -- the PRODUCER of `tap_feats` for the caption path (reference: models/sst_model.py:5-40).
+"""SST proposal encoder -- the PRODUCER of `tap_feats` for the caption path (reference: models/sst_model.py:5-40;
+SURVEY section 8-f row 1).
 
-SURVEY section 8 lists it as a "next" row (f-1), outside rows (a)-(e).  It is kept on stock PyTorch-ROCm modules
-(nn.LSTM runs on MIOpen) so that reference-style drivers can build `models.setup_tap(opt)` and feed the HIP caption path;
-it takes no part in this round's parity / roofline claims.  Parameter names (`rnn.*`, `scores.*`) match the reference, so
-its checkpoints load.
+Parameter names (`rnn.weight_ih_l0` ..., `scores.*`) are nn.LSTM's / nn.Linear's, so the reference's checkpoints load.
+On the GPU the arithmetic runs in libechr_hip.so (echr_sst_fwd / echr_sst_bwd: batched input GEMMs + one fused
+GEMV+cell launch per timestep); the nn.LSTM module is only the parameter container.  On CPU tensors it falls back to
+nothing -- like the rest of echr_amd it raises.
 """
 import torch
 from torch import nn
+
+from .. import functional as EF
 
 
 class SST(nn.Module):
@@ -20,9 +23,13 @@ class SST(nn.Module):
         self.rnn_num_layers = opt.rnn_num_layers
         self.rnn_dropout = opt.rnn_dropout
         self.data_for_test = []
+        if opt.rnn_num_layers != 2 or str(opt.tap_rnn_type).upper() != 'LSTM':
+            raise NotImplementedError('the HIP path implements the shipped SST: a 2-layer LSTM (opts.py:72-78)')
         self.scores = nn.Linear(opt.hidden_dim, self.K)
         self.rnn = nn.LSTM(input_size=opt.video_dim, hidden_size=opt.hidden_dim, num_layers=opt.rnn_num_layers,
                            dropout=opt.rnn_dropout, batch_first=True)
+        self._drop_seed = None
+        self._drop_calls = 0
 
     # The reference overrides train()/eval() so that they ONLY switch the LSTM's inter-layer dropout (sst_model.py:25-29);
     # module.training is left alone on purpose.
@@ -35,9 +42,22 @@ class SST(nn.Module):
     def eval(self):
         self._set_dropout(False)
 
+    def set_dropout_state(self, seed, calls=0):
+        self._drop_seed, self._drop_calls = int(seed), int(calls)
+
+    def native_params(self):
+        r = self.rnn
+        return (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0, r.weight_ih_l1, r.weight_hh_l1, r.bias_ih_l1, r.bias_hh_l1,
+                self.scores.weight, self.scores.bias)
+
     def forward(self, features):
         """features [T, video_dim] -> (tap_feats [T, hidden_dim], proposal scores [T, K] in (0,1))."""
-        T = features.shape[0]
-        hidden, _ = self.rnn(features[None])          # one video per call: batch of 1
-        tap_feats = hidden.reshape(T, -1)
-        return tap_feats, self.scores(tap_feats).sigmoid().reshape(T, self.K)
+        if not features.is_cuda:
+            raise EF.L.EchrHipError('SST runs on the GPU only: move the module and its inputs with .cuda()')
+        p = float(self.rnn.dropout)
+        if self._drop_seed is None:
+            self._drop_seed = (int(torch.initial_seed()) ^ 0x55AA) & 0xFFFFFFFFFFFFFFFF
+        drop = EF.DropState(self._drop_seed, self._drop_calls, p > 0.0)
+        if p > 0.0:
+            self._drop_calls += 1
+        return EF.SSTFunction.apply(features, p, drop, *self.native_params())

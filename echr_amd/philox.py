@@ -18,6 +18,7 @@ SITE_H0 = 1        # [N, H]     p = 0.5 (stream 0 output)
 SITE_H1 = 2
 SITE_H2 = 3
 SITE_OUT = 4       # [N, 3H]    p = CG_drop_prob
+SITE_SST = 5       # [T, H]     p = rnn_dropout (SST inter-layer dropout; step counter 0, element t*H + j)
 
 _M0 = np.uint64(0xD2511F53)
 _M1 = np.uint64(0xCD9E8D57)

@@ -215,6 +215,46 @@ int64_t echr_sampler_ws_floats(const echr_dec_args* a);
 int echr_decoder_sample(const echr_sample_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * SST proposal encoder.  Replaces models/sst_model.py:31-40 (nn.LSTM over one video + Linear + sigmoid)
+ * and TAPModelCriterion (misc/utils.py:78-99).  Parameters use nn.LSTM's layout: w_ih[l] [4H, D or H], w_hh[l] [4H,H],
+ * gate order i,f,g,o.  p_drop = inter-layer dropout (applied to layer 0's output while training; site 5 of echr_dropout).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t T, D, H, K;
+    float p_drop;
+    const float* w_ih[2];
+    const float* w_hh[2];
+    const float* b_ih[2];
+    const float* b_hh[2];
+    const float *w_sc, *b_sc;       /* scores Linear [K,H],[K] */
+    const float* x;                 /* [T,D] C3D features of one video */
+    float* ws;                      /* saved activations, echr_sst_ws_floats */
+    float* tap_feats;               /* out [T,H]: top-layer hidden states */
+    float* scores;                  /* out [T,K]: sigmoid proposal scores */
+} echr_sst_args;
+
+typedef struct {
+    float* g_w_ih[2];
+    float* g_w_hh[2];
+    float* g_b_ih[2];
+    float* g_b_hh[2];
+    float *g_w_sc, *g_b_sc;
+    const float* g_tap;             /* [T,H] or NULL */
+    const float* g_scores;          /* [T,K] or NULL */
+    float* ws_bwd;                  /* scratch, echr_sst_ws_bwd_floats */
+} echr_sst_grads;
+
+int64_t echr_sst_ws_floats(int32_t T, int32_t D, int32_t H, int32_t K);
+int64_t echr_sst_ws_bwd_floats(int32_t T, int32_t D, int32_t H, int32_t K);
+int echr_sst_fwd(const echr_sst_args* a, const echr_dropout* drop, void* stream);
+int echr_sst_bwd(const echr_sst_args* a, const echr_sst_grads* g, const echr_dropout* drop, void* stream);
+/* weighted BCE of the proposal head: loss (device scalar) and its gradient w.r.t. the scores */
+int echr_tap_bce_fwd(const float* scores, const float* masks, const float* labels, const float* w1, float* loss, int32_t T,
+                     int32_t K, void* stream);
+int echr_tap_bce_bwd(const float* scores, const float* masks, const float* labels, const float* w1, const float* g_loss,
+                     float* g_scores, int32_t T, int32_t K, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused element-wise clamp(+-clip) + Adam (betas, eps, no weight decay, no amsgrad) over a flat
  * buffer.  Replaces misc/utils.py:107-111 + torch.optim.Adam.step as wired at train.py:209,315-317.
  * `step` is the 1-based step count; lr/betas/eps are doubles because torch derives 1-beta and the bias corrections

@@ -258,6 +258,41 @@ def caption_forward(P, tap, c3d, lda, labels, ind, soi, mode='train', drop=None,
 
 
 # ----------------------------------------------------------------------------------------------
+# SST proposal encoder + its criterion: models/sst_model.py:31-40, misc/utils.py:78-99
+# ----------------------------------------------------------------------------------------------
+
+def sst_forward(P, x, drop_mask=None, prefix=''):
+    """SST.forward: nn.LSTM(D -> H, 2 layers, batch_first) over one video [1,T,D] + Linear(H -> K) + sigmoid (sst_model.py:31-40).
+
+    P uses nn.LSTM's parameter names (rnn.weight_ih_l0 ...).  drop_mask: multiplicative [T,H] mask on layer 0's output
+    (nn.LSTM's inter-layer dropout), None in eval mode.  Returns (tap_feats [T,H], scores [T,K])."""
+    T = x.shape[0]
+    H = P[prefix + 'rnn.weight_hh_l0'].shape[1]
+    inp = x
+    for l in range(2):
+        w_ih, w_hh = P[prefix + 'rnn.weight_ih_l%d' % l], P[prefix + 'rnn.weight_hh_l%d' % l]
+        b_ih, b_hh = P[prefix + 'rnn.bias_ih_l%d' % l], P[prefix + 'rnn.bias_hh_l%d' % l]
+        h, c = x.new_zeros(1, H), x.new_zeros(1, H)
+        outs = []
+        for t in range(T):
+            h, c = lstm_cell(inp[t:t + 1], h, c, w_ih, w_hh, b_ih, b_hh)
+            outs.append(h)
+        out = torch.cat(outs, 0)
+        inp = out * drop_mask if (l == 0 and drop_mask is not None) else out
+    scores = torch.sigmoid(F.linear(out, P[prefix + 'scores.weight'], P[prefix + 'scores.bias']))
+    return out, scores
+
+
+def tap_criterion(scores, masks, labels, w1):
+    """TAPModelCriterion.forward (misc/utils.py:78-99): weighted BCE, mean over T*K, times K."""
+    w0 = 1.0 - w1
+    labels = labels * masks
+    weights = labels * w0.expand_as(labels) + (1.0 - labels) * w1.expand_as(labels)
+    loss = F.binary_cross_entropy((scores.reshape(-1) * masks.reshape(-1)), labels.reshape(-1), weight=weights.reshape(-1))
+    return loss * w0.shape[0]
+
+
+# ----------------------------------------------------------------------------------------------
 # optimiser step: misc/utils.py:107-111 + torch.optim.Adam as train.py:209,315-317 configures it
 # ----------------------------------------------------------------------------------------------
 

@@ -364,3 +364,58 @@ def test_reference_shaped_driver_trains_and_checkpoints(tmp_path, joint, m_batch
         assert torch.equal(a.cpu(), b), k
     if joint:
         assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in tap.parameters())
+
+
+def _sst_module(params, opt_over, train):
+    from echr_amd import models
+    opt = synth.default_opt(**opt_over)
+    m = models.setup_tap(opt)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    m = m.cuda()
+    m.train() if train else m.eval()
+    return m, opt
+
+
+def test_sst_native_matches_reference_fixture():
+    """models.setup_tap(opt) on the GPU (echr_sst_fwd/bwd, echr_tap_bce_*) against the reference's nn.LSTM-based SST +
+    TAPModelCriterion outputs and gradients (eval mode: no dropout)."""
+    from echr_amd.misc.utils import TAPModelCriterion
+    g = U.gold('sst.npz')
+    params = {k[len('param|'):]: v for k, v in g.items() if k.startswith('param|')}
+    m, _ = _sst_module(params, dict(synth.CASES['tiny']['opt'], K=8), False)
+    dev = torch.device('cuda')
+    tap, sc = m(torch.from_numpy(g['x']).to(dev))
+    assert np.abs(tap.detach().cpu().numpy() - g['tap']).max() < 1e-5 and np.abs(sc.detach().cpu().numpy() - g['scores']).max() < 1e-5
+    loss = TAPModelCriterion()(sc, torch.from_numpy(g['masks']), torch.from_numpy(g['labels']), torch.from_numpy(g['w1'])) + 0.1 * (tap * tap).sum()
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-4 * abs(float(g['loss']))
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert U.grad_close(k, p.grad.cpu().numpy(), g['grad|' + k], TOL_GRAD), (k, U.relerr(p.grad.cpu().numpy(), g['grad|' + k]))
+
+
+@pytest.mark.parametrize('T,D,H,K,train', [(37, 500, 512, 256, True), (5, 20, 24, 8, True), (64, 500, 512, 32, False)])
+def test_sst_native_vs_oracle(T, D, H, K, train):
+    """ECHR-sized SST (500 -> 512, K anchors) incl. the inter-layer dropout with injected Philox masks, forward and backward."""
+    from echr_amd import philox
+    from oracle import echr_ref_cpu as O
+    rs = np.random.RandomState(T + K)
+    shapes = {'rnn.weight_ih_l0': (4 * H, D), 'rnn.weight_hh_l0': (4 * H, H), 'rnn.bias_ih_l0': (4 * H,), 'rnn.bias_hh_l0': (4 * H,),
+              'rnn.weight_ih_l1': (4 * H, H), 'rnn.weight_hh_l1': (4 * H, H), 'rnn.bias_ih_l1': (4 * H,), 'rnn.bias_hh_l1': (4 * H,),
+              'scores.weight': (K, H), 'scores.bias': (K,)}
+    params = {k: (rs.uniform(-1, 1, size=s) / np.sqrt(H)).astype(np.float32) for k, s in shapes.items()}
+    m, opt = _sst_module(params, dict(video_dim=D, hidden_dim=H, K=K, rnn_dropout=0.5), train)
+    m.set_dropout_state(U.SEED, U.OFFSET)
+    x = rs.standard_normal((T, D)).astype(np.float32)
+    wt = rs.standard_normal((T, H)).astype(np.float32)
+    ws = rs.standard_normal((T, K)).astype(np.float32)
+    dev = torch.device('cuda')
+    tap, sc = m(torch.from_numpy(x).to(dev))
+    ((tap * torch.from_numpy(wt).to(dev)).sum() + (sc * torch.from_numpy(ws).to(dev)).sum()).backward()
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    mask = torch.from_numpy(philox.scale_mask((T, H), 0.5, U.SEED, U.OFFSET, philox.SITE_SST, 0)) if train else None
+    otap, osc = O.sst_forward(P, torch.from_numpy(x), mask)
+    ((otap * torch.from_numpy(wt)).sum() + (osc * torch.from_numpy(ws)).sum()).backward()
+    assert np.abs(tap.detach().cpu().numpy() - otap.detach().numpy()).max() < 2e-5
+    assert np.abs(sc.detach().cpu().numpy() - osc.detach().numpy()).max() < 2e-5
+    for k, p in m.named_parameters():
+        assert U.grad_close(k, p.grad.cpu().numpy(), P[k].grad.numpy(), TOL_GRAD), (k, U.relerr(p.grad.cpu().numpy(), P[k].grad.numpy()))

@@ -73,3 +73,17 @@ def test_proposal_selection_indices():
         ind, feat, _ = O.top_proposals(g['g%d|scores' % i], g['g%d|mask' % i], int(g['g%d|topN' % i]))
         assert np.array_equal(np.array(ind, np.int64), g['g%d|ind' % i])
         assert np.array_equal(np.array(feat, np.int64).reshape(-1, 2), g['g%d|feat' % i].reshape(-1, 2))
+
+
+def test_sst_restatement_matches_reference():
+    """The oracle's hand-written 2-layer LSTM + head + weighted BCE against the reference's SST / TAPModelCriterion outputs."""
+    g = U.gold('sst.npz')
+    P = {k[len('param|'):]: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in g.items() if k.startswith('param|')}
+    x = torch.from_numpy(g['x'])
+    tap, sc = O.sst_forward(P, x)
+    loss = O.tap_criterion(sc, torch.from_numpy(g['masks']), torch.from_numpy(g['labels']), torch.from_numpy(g['w1'])) + 0.1 * (tap * tap).sum()
+    loss.backward()
+    assert np.abs(tap.detach().numpy() - g['tap']).max() < 1e-6 and np.abs(sc.detach().numpy() - g['scores']).max() < 1e-6
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-5
+    for k, p in P.items():
+        assert U.relerr(p.grad.numpy(), g['grad|' + k]) < 1e-4, k

@@ -254,6 +254,42 @@ def do_proposals():
     print('wrote proposals.npz')
 
 
+def do_sst():
+    """The reference's SST (nn.LSTM + head, eval mode) and TAPModelCriterion on seeded inputs; also pins the oracle's hand-written
+    LSTM restatement against them."""
+    opt = synth.default_opt(**synth.CASES['tiny']['opt'], K=8)
+    rs = np.random.RandomState(77)
+    T, D, H, K = 9, opt.video_dim, opt.hidden_dim, opt.K
+    torch.manual_seed(5)
+    m = models.setup_tap(copy.copy(opt))
+    sd = {k: torch.from_numpy(rs.uniform(-0.3, 0.3, size=tuple(v.shape)).astype(np.float32)) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m.eval()
+    x = torch.from_numpy(rs.standard_normal((T, D)).astype(np.float32))
+    masks = torch.from_numpy((np.arange(T)[:, None] >= np.arange(K)[None, :]).astype(np.float32))
+    labels = torch.from_numpy((rs.uniform(size=(T, K)) > 0.7).astype(np.float32))
+    w1 = torch.from_numpy(rs.uniform(0.05, 0.4, size=(K,)).astype(np.float32))
+    tap, sc = m(x)
+    loss = ref_utils.TAPModelCriterion()(sc, masks, labels, w1) + 0.1 * (tap * tap).sum()
+    loss.backward()
+    out = {'x': x.numpy(), 'masks': masks.numpy(), 'labels': labels.numpy(), 'w1': w1.numpy(), 'tap': tap.detach().numpy(),
+           'scores': sc.detach().numpy(), 'loss': np.float64(loss.item())}
+    for k, v in sd.items():
+        out['param|' + k] = v.numpy()
+    for k, p in m.named_parameters():
+        out['grad|' + k] = p.grad.numpy().copy()
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    otap, osc = O.sst_forward(P, x)
+    oloss = O.tap_criterion(osc, masks, labels, w1) + 0.1 * (otap * otap).sum()
+    oloss.backward()
+    dev = max(rel(P[k].grad.numpy(), out['grad|' + k]) for k in sd)
+    print('[sst] oracle-vs-ref: max|dtap| %.2e max|dscore| %.2e dloss %.2e max rel grad %.2e'
+          % ((otap - tap).abs().max(), (osc - sc).abs().max(), abs(oloss.item() - loss.item()), dev))
+    assert (otap - tap).abs().max() < 1e-6 and dev < 1e-4
+    np.savez_compressed(os.path.join(GOLD, 'sst.npz'), **out)
+    print('wrote sst.npz')
+
+
 def do_checkpoint():
     """A checkpoint written by the REFERENCE's own modules (its own random init) in train.py's dict layout (:456-461), plus
     the reference's eval-mode log-probs for those weights on the 'tiny' inputs: the build must load it as is."""
@@ -282,5 +318,6 @@ if __name__ == '__main__':
         do_adam()
         do_proposals()
         do_checkpoint()
+        do_sst()
     for c in a.cases:
         do_case(c)
