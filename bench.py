@@ -30,10 +30,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA peak
 
 
-def make_workload(rank, overlap):
+def make_workload(rank, overlap, c5=False):
     from echr_amd import synth
     opt = synth.default_opt(vocab_size=V1 - 1, seq_length=S_STEPS - 1)
     params = synth.make_params(opt, 0)
+    if c5:      # BASELINE config 5: one 256-segment video, proposals of 4..256 segments, SST in the loop
+        vid = synth.make_video(N_EV, 256, S_STEPS + 1, V1, seed=1234 + rank, T_v=256)
+        rs = np.random.RandomState(99 + rank)
+        vid['tap_labels'] = (rs.uniform(size=(256, opt.K)) > 0.9).astype(np.float32)
+        vid['tap_masks'] = (np.arange(256)[:, None] >= np.arange(opt.K)[None, :]).astype(np.float32)
+        vid['w1'] = rs.uniform(0.05, 0.3, size=(opt.K,)).astype(np.float32)
+        return opt, params, vid
     vid = synth.make_video(N_EV, A_SEG, S_STEPS + 1, V1, seed=1234 + rank, full_len=True, disjoint=not overlap,
                            T_v=None if not overlap else 160)
     return opt, params, vid
@@ -47,7 +54,7 @@ def gpu_leg(args, rank, world, local_rank):
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     use_dist = dist.is_available() and dist.is_initialized()
-    opt, params, vid = make_workload(rank, args.overlap)
+    opt, params, vid = make_workload(rank, args.overlap, args.c5)
     model = echr_amd.CaptionGenerator(opt)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.to(dev).train()
@@ -59,12 +66,40 @@ def gpu_leg(args, rank, world, local_rank):
     tgt = labels[:, 1:].to(dev)
     msk = torch.from_numpy(vid['masks'])[:, 1:].to(dev)
 
+    if args.c5:
+        from echr_amd import models as EM
+        from echr_amd.misc.utils import TAPModelCriterion
+        torch.manual_seed(0)
+        tap_model = EM.setup_tap(opt).to(dev)
+        tap_model.train()
+        tap_optim = ClampAdam(tap_model.parameters(), lr=opt.lr)
+        tap_crit = TAPModelCriterion()
+        tl, tm, tw = (torch.from_numpy(vid[k]).to(dev) for k in ('tap_labels', 'tap_masks', 'w1'))
+
+    def c5_iteration():      # train.py's joint 'tap_cg' iteration: SST -> caption path -> lambda1*tap_loss + lambda2*cg_loss
+        optim.zero_grad()
+        tap_optim.zero_grad()
+        tap_feats, props = tap_model(c3d)
+        pred = model(tap_feats, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+        loss = 0.01 * tap_crit(props, tm, tl, tw) + crit(pred, tgt, msk)
+        loss.backward()
+        if use_dist:
+            parallel.allreduce_gradients(model, force=True)
+            parallel.allreduce_gradients(tap_model, force=True)
+        clip_gradient(optim, opt.grad_clip)
+        clip_gradient(tap_optim, opt.grad_clip)
+        optim.step()
+        tap_optim.step()
+        return loss
+
     def fwd_only():
         with torch.no_grad():
             pred = model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
             return crit(pred, tgt, msk)
 
     def iteration():
+        if args.c5:
+            return c5_iteration()
         if args.mode == 'fwd':
             return fwd_only()
         optim.zero_grad()
@@ -217,6 +252,8 @@ def main():
     ap.add_argument('--overlap', action='store_true', help='SURVEY 8-d one-video layout (T_v=160, events share rows)')
     ap.add_argument('--mode', choices=['train', 'fwd'], default='train',
                     help="'train' = fwd+bwd+clamp+Adam (BASELINE config 3, the headline metric); 'fwd' = forward + loss only (config 2)")
+    ap.add_argument('--c5', action='store_true', help='BASELINE config 5: SST proposal encoder over a 256-segment video + caption '
+                    'path with proposals of up to 256 segments, joint fwd+bwd+Adam (extra line; the headline metric is the default)')
     ap.add_argument('--no-arena', action='store_true', help='per-tensor gradients/optimiser instead of the flat arena')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -236,6 +273,9 @@ def main():
         workload = '%s: %d events x %d seg x 500-d C3D (%s), S=%d decoder timesteps, V1=%d, %s, one video per GPU' % (
             'c3' if args.mode == 'train' else 'c2', N_EV, A_SEG, 'T_v=160 overlapping' if args.overlap else 'disjoint rows, T_v=8192',
             S_STEPS, V1, 'fwd+bwd+clamp+Adam' if args.mode == 'train' else 'forward + loss only (train-mode dropout)')
+        if args.c5:
+            workload = ('c5: SST (2-layer LSTM 500->512, K=256) over one 256-segment video + caption path on %d proposals of 4..256 '
+                        'segments, S=%d, V1=%d, joint fwd+bwd+clamp+Adam, one video per GPU' % (N_EV, S_STEPS, V1))
         out = {
             'metric': 'caption-decoder timesteps/sec (fwd+bwd)' if args.mode == 'train' else 'caption-decoder timesteps/sec (fwd only)', 'value': round(value, 1), 'unit': 'timesteps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
@@ -246,7 +286,7 @@ def main():
         }
         if roof is not None:
             out['roofline'] = roof
-        if world == 1 and not args.no_cpu and args.mode == 'train':
+        if world == 1 and not args.no_cpu and args.mode == 'train' and not args.c5:
             out['cpu_baseline'] = cpu_leg(args)
         print(json.dumps(out), flush=True)
     if dist.is_available() and dist.is_initialized():

@@ -18,7 +18,7 @@ namespace echr {
 
 DropCfg make_drop(const echr_dropout* d, float p);
 enum { SITE_SST = 5 };
-constexpr int UPW = 8;          // hidden units per workgroup
+constexpr int UPW = 2;          // hidden units per workgroup (256 workgroups at H = 512: one per CU)
 
 // dot of one weight row with a vector held in LDS; lanes stride the k axis in float4
 __device__ __forceinline__ float row_dot(const float* __restrict__ wrow, const float* __restrict__ v, int K, int lane) {
@@ -44,11 +44,27 @@ __global__ __launch_bounds__(256) void sst_step_fwd_kernel(const float* __restri
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int k = threadIdx.x; k < H; k += 256) sh[k] = hprev ? hprev[k] : 0.f;
     __syncthreads();
-    for (int i = 0; i < UPW; ++i) {
-        const int u = u0 + i;
-        if (u >= H) break;
-        const float d = hprev ? row_dot(Whh + (long)(wave * H + u) * H, sh, H, lane) : 0.f;
-        if (lane == 0) pre[wave * UPW + i] = d + gin[wave * H + u];
+    {
+        // wave g owns gate g: its UPW rows are multiplied with independent accumulators (loads of all rows in flight together)
+        float acc[UPW];
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) acc[i] = 0.f;
+        if (hprev) {
+            for (int k = lane * 4; k < H; k += 256) {
+                const float4 x4 = *reinterpret_cast<const float4*>(sh + k);
+#pragma unroll
+                for (int i = 0; i < UPW; ++i) {
+                    const int u = min(u0 + i, H - 1);
+                    const float4 w4 = *reinterpret_cast<const float4*>(Whh + (long)(wave * H + u) * H + k);
+                    acc[i] += w4.x * x4.x + w4.y * x4.y + w4.z * x4.z + w4.w * x4.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const float d = wave_sum(acc[i]);
+            if (lane == 0 && u0 + i < H) pre[wave * UPW + i] = d + gin[wave * H + u0 + i];
+        }
     }
     __syncthreads();
     if (threadIdx.x < UPW && u0 + threadIdx.x < H) {
@@ -76,18 +92,19 @@ __global__ __launch_bounds__(256) void sst_step_bwd_kernel(const float* __restri
     if (dgnext) {
         for (int k = threadIdx.x; k < 4 * H; k += 256) sg[k] = dgnext[k];
         __syncthreads();
-        // 8 units x 4H-long rows: wave w takes units w, w+4 (2 rows each) -- whole rows, so no cross-wave sum is needed
-        for (int i = wave; i < UPW; i += 4) {
-            const int u = u0 + i;
-            if (u >= H) break;
-            const float d = row_dot(WhhT + (long)u * 4 * H, sg, 4 * H, lane);
-            if (lane == 0) part[i] = d;
-        }
+        // UPW rows of W_hh^T, each 4H long, split over the 4 waves: wave w takes unit (w % UPW), slice (w / UPW) of the row
+        constexpr int SL = 4 / UPW;                      // k-slices per row
+        const int i = wave % UPW, sl = wave / UPW;
+        const int u = min(u0 + i, H - 1);
+        const int klen = 4 * H / SL;
+        const float d = row_dot(WhhT + (long)u * 4 * H + sl * klen, sg + sl * klen, klen, lane);
+        if (lane == 0) part[sl * UPW + i] = d;
     }
     __syncthreads();
     if (threadIdx.x < UPW && u0 + threadIdx.x < H) {
         const int i = threadIdx.x, u = u0 + i;
-        const float dh = dh_out[u] + (dgnext ? part[i] : 0.f);
+        float dh = dh_out[u];
+        if (dgnext) for (int sl = 0; sl < 4 / UPW; ++sl) dh += part[sl * UPW + i];
         const float gi = act[u], gf = act[H + u], gg = act[2 * H + u], go = act[3 * H + u];
         const float tc = tanhf(c[u]);
         const float dcv = dh * go * (1.f - tc * tc) + dc[u];
