@@ -255,6 +255,13 @@ int echr_tap_bce_bwd(const float* scores, const float* masks, const float* label
                      float* g_scores, int32_t T, int32_t K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Proposal selection: the index outputs of eval_utils.gettop1000 (eval_utils.py:259-287), bit-exact.
+ * Output buffers must hold T*K entries (ties at the threshold are all kept); out_count[0] = number written.
+ * ---------------------------------------------------------------------------------------------- */
+int echr_top_proposals(const float* scores, const float* mask, int32_t T, int32_t K, int32_t topN, float val_thres,
+                       int32_t* out_ind, int32_t* out_feat, float* out_conf, int32_t* out_count, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused element-wise clamp(+-clip) + Adam (betas, eps, no weight decay, no amsgrad) over a flat
  * buffer.  Replaces misc/utils.py:107-111 + torch.optim.Adam.step as wired at train.py:209,315-317.
  * `step` is the 1-based step count; lr/betas/eps are doubles because torch derives 1-beta and the bias corrections

@@ -419,3 +419,23 @@ def test_sst_native_vs_oracle(T, D, H, K, train):
     assert np.abs(sc.detach().cpu().numpy() - osc.detach().numpy()).max() < 2e-5
     for k, p in m.named_parameters():
         assert U.grad_close(k, p.grad.cpu().numpy(), P[k].grad.numpy(), TOL_GRAD), (k, U.relerr(p.grad.cpu().numpy(), P[k].grad.numpy()))
+
+
+def test_top_proposals_bit_exact_vs_reference():
+    """echr_amd.eval_utils.gettop1000 (one HIP kernel) against the reference's gettop1000 index outputs (fixtures) incl. ties."""
+    from echr_amd import eval_utils as EU
+    g = U.gold('proposals.npz')
+    for i in range(3):
+        scores, mask, topN = g['g%d|scores' % i], g['g%d|mask' % i], int(g['g%d|topN' % i])
+        ind, feat, _, ts, conf = EU.gettop1000(torch.from_numpy(scores).cuda(), mask, [], 100.0, lambda s, e, n, d: [s, e], topN=topN)
+        assert ind == g['g%d|ind' % i].tolist() and feat == g['g%d|feat' % i].reshape(-1, 2).tolist() and ts == feat
+        assert np.allclose(conf, (scores * mask)[np.array(ind), np.array(ind) - np.array(feat)[:, 0]])
+    # heavy ties + a threshold above the topN-th value
+    rs = np.random.RandomState(0)
+    scores = np.round(rs.uniform(0, 1, size=(50, 20)), 1).astype(np.float32)
+    mask = (np.arange(50)[:, None] >= np.arange(20)[None, :]).astype(np.float32)
+    from oracle import echr_ref_cpu as O
+    for topN, thr in ((30, 0.0), (100, 0.75), (5000, 0.0)):
+        oi, of, oc = O.top_proposals(scores, mask, topN, thr)
+        ind, feat, _, _, conf = EU.gettop1000(torch.from_numpy(scores).cuda(), mask, [], 1.0, lambda s, e, n, d: 0, val_score_thres=thr, topN=topN)
+        assert ind == oi and feat == of and np.allclose(conf, oc)
