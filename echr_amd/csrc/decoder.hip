@@ -641,6 +641,7 @@ struct DecWs {
     float *XT, *GATES[3], *CS[3], *HS, *OUTD, *PALL, *QS, *SC, *WT, *ATT, *EVB0, *VIDB;
     float *QSL, *GSL[3];         // split-K slabs of the current timestep (q and the three gate blocks)
     float *QACC;                 // [S,N,Ha] atomic accumulation target of q (teacher-forced path)
+    float *PK_C3D, *PK_WC, *PK_WIH[3], *PK_WL, *PK_XT, *PK_OUTD;     // h2-packed GEMM operands of the forward pass
     int nq, ng[3];
     long total;
 };
@@ -667,6 +668,12 @@ static DecWs carve_ws(const echr_dec_args* a, float* base) {
     w.ng[0] = w.ng[2] = ksplit_of(a->H);
     w.ng[1] = ksplit_of(a->H) + ksplit_of(a->D);
     for (int k = 0; k < 3; ++k) w.GSL[k] = take((long)w.ng[k] * N * 4 * H);
+    w.PK_C3D = take(h2_floats(a->Tv, a->D));
+    w.PK_WC = take(h2_floats(a->Ha, a->D));
+    for (int k = 0; k < 3; ++k) w.PK_WIH[k] = take(h2_floats(4 * a->H, a->E));
+    w.PK_WL = take(h2_floats(a->V1, 3 * a->H));
+    w.PK_XT = take(h2_floats((int)(S * N), a->E));
+    w.PK_OUTD = take(h2_floats((int)(S * N), 3 * a->H));
     w.total = off;
     return w;
 }
@@ -675,6 +682,8 @@ struct DecWsBwd {
     float *DLG, *DOUT, *DG[3], *DC, *DSC, *DQ, *DPALL, *DGSUM[3], *DGCOL[3], *DXT, *MSUM;
     float *WT_HH[3], *WT_ATT, *WT_H2A;      // transposed weights: the backward recurrence runs as NT products too
     float *WLT, *DLGT, *OUTDT;               // W_logit^T [3H, ldg], DLG^T [V1, snp], OUTD^T [3H, snp]: NT operands for the split GEMM
+    // h2-packed operands of the backward GEMMs (suffix T: packed from the transposed view, i.e. contraction over rows of the source)
+    float *PK_DLGT, *PK_OUTDT, *PK_DLG, *PK_WLT, *PK_DGT[3], *PK_DG[3], *PK_HT[3], *PK_XTT, *PK_ATTT, *PK_DQT, *PK_WIHT[3], *PK_DPT, *PK_C3DT;
     long snp;
     float *DHSL[3], *DASL;                   // split-K slabs: d h(t-1) per stream; DASL: [S,N,D] atomic accumulation target of d ATT
     int ndh[3], nda;
@@ -711,6 +720,15 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     w.ndh[1] = ksplit_of(4 * a->H) + ksplit_of(a->Ha);
     w.nda = ksplit_of(4 * a->H);
     for (int k = 0; k < 3; ++k) w.DHSL[k] = take((long)w.ndh[k] * N * H);
+    const int SN = (int)(S * N), H4 = 4 * a->H;
+    w.PK_DLGT = take(h2_floats(a->V1, SN)); w.PK_OUTDT = take(h2_floats(3 * a->H, SN));
+    w.PK_DLG = take(h2_floats(SN, a->V1)); w.PK_WLT = take(h2_floats(3 * a->H, a->V1));
+    for (int k = 0; k < 3; ++k) {
+        w.PK_DGT[k] = take(h2_floats(H4, SN)); w.PK_DG[k] = take(h2_floats(SN, H4));
+        w.PK_HT[k] = take(h2_floats(a->H, SN)); w.PK_WIHT[k] = take(h2_floats(a->E, H4));
+    }
+    w.PK_XTT = take(h2_floats(a->E, SN)); w.PK_ATTT = take(h2_floats(a->D, SN)); w.PK_DQT = take(h2_floats(a->Ha, SN));
+    w.PK_DPT = take(h2_floats(a->Ha, a->Tv)); w.PK_C3DT = take(h2_floats(a->D, a->Tv));
     w.total = off;
     return w;
 }
@@ -736,10 +754,21 @@ static RecJob mkjob(const float* A, long lda, int K, const float* B, long ldb, i
 
 // P_all = c3d . W_c^T + b_c over the Tv video rows; EVB0 = event . W_ih0[:,E:]^T + b_ih0 + b_hh0;
 // VIDB = W_ih2[:,E:] . video + b_ih2 + b_hh2   (all time-invariant)
-static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t st) {
+static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t st, bool teacher_forced) {
     const int H = a->H, E = a->E;
-    echr_gemm_desc d = desc_nt(a->c3d, a->D, a->w_c2a, a->D, w.PALL, a->Ha, a->Tv, a->Ha, a->D);
-    d.bias = a->b_c2a; d.split_k = -1; d.algo = ECHR_GEMM_BF16X3;
+    echr_gemm_desc d;
+    if (config().gemm_h2) {
+        // every time-invariant GEMM operand of the forward pass is packed by one launch
+        H2PackJob pj[6] = {pack_rows(a->c3d, a->D, a->Tv, a->D, w.PK_C3D), pack_rows(a->w_c2a, a->D, a->Ha, a->D, w.PK_WC),
+                           pack_rows(a->w_logit, 3 * H, a->V1, 3 * H, w.PK_WL), pack_rows(a->w_ih[0], E + a->De, 4 * H, E, w.PK_WIH[0]),
+                           pack_rows(a->w_ih[1], E + a->D, 4 * H, E, w.PK_WIH[1]), pack_rows(a->w_ih[2], E + a->Dv, 4 * H, E, w.PK_WIH[2])};
+        RC(h2_pack_multi(pj, teacher_forced ? 6 : 2, st));      // the sampler's per-step products stay on the skinny-GEMM path
+        d = desc_h2(w.PK_C3D, w.PK_WC, w.PALL, a->Ha, a->Tv, a->Ha, a->D);
+    } else {
+        d = desc_nt(a->c3d, a->D, a->w_c2a, a->D, w.PALL, a->Ha, a->Tv, a->Ha, a->D);
+        d.split_k = -1; d.algo = ECHR_GEMM_BF16X3;
+    }
+    d.bias = a->b_c2a;
     RC(gemm(d, st));
     d = desc_nt(a->event, a->De, a->w_ih[0] + E, E + a->De, w.EVB0, 4 * H, a->N, 4 * H, a->De);
     d.bias = a->b_ih[0]; d.bias2 = a->b_hh[0]; d.split_k = -1;
@@ -815,9 +844,14 @@ static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, 
     const int rows = nt * N;
     const int cin[3] = {E + a->De, E + a->D, E + a->Dv};
     echr_gemm_desc d[3];
+    const bool h2 = config().gemm_h2 && xt == w.XT && t0 == 0 && nt == a->S;      // the teacher-forced call: all S*N token rows at once
+    if (h2) {
+        H2PackJob pj = pack_rows(xt, E, rows, E, w.PK_XT);
+        RC(h2_pack_multi(&pj, 1, st));
+    }
     for (int k = 0; k < 3; ++k) {
         float* g = w.GATES[k] + (long)t0 * N * 4 * H;
-        d[k] = desc_nt(xt, E, a->w_ih[k], cin[k], g, 4 * H, rows, 4 * H, E);
+        d[k] = h2 ? desc_h2(w.PK_XT, w.PK_WIH[k], g, 4 * H, rows, 4 * H, E) : desc_nt(xt, E, a->w_ih[k], cin[k], g, 4 * H, rows, 4 * H, E);
         d[k].add_mod = N; d[k].ld_add = 4 * H;
         if (k == 0) d[k].addend = w.EVB0;
         else if (k == 1) { d[k].bias = a->b_ih[1]; d[k].bias2 = a->b_hh[1]; }
@@ -844,7 +878,7 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
     RC(fill_zero(w.HS, (long)N * 3 * H, st));                       // h(-1) = 0   (init_hidden, :75-78)
     RC(fill_zero_2d(w.CS[0], 3, N * H, w.CS[1] - w.CS[0], st));     // c(-1) = 0 for the three streams (equally spaced carve-outs)
     RC(fill_zero(w.QACC, (long)S * N * a->Ha, st));
-    RC(precompute_static(a, w, st));
+    RC(precompute_static(a, w, st, true));
     RC(embed_gather(a->embed, a->tokens, w.XT, S * N, E, a->V1, st));
     RC(input_gates(a, w, w.XT, 0, S, st));
     // late fusion: logits = OUTD . W_logit^T + b, written [N,S,V1], then row log-softmax in place.  Timesteps [0,th) are
@@ -852,7 +886,14 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
     auto logits_chunk = [&](int t0, int t1, hipStream_t q) -> int {
         echr_gemm_desc d = desc_nt(w.OUTD + (long)t0 * N * 3 * H, 3 * H, a->w_logit, 3 * H, a->logp + (long)t0 * a->V1, a->V1,
                                    (t1 - t0) * N, a->V1, 3 * H);
-        d.bias = a->b_logit; d.rowmap_mod = N; d.rowmap_mul = S; d.algo = ECHR_GEMM_BF16X3;
+        d.algo = ECHR_GEMM_BF16X3;
+        if (config().gemm_h2 && t0 == 0 && t1 == S) {
+            H2PackJob pj = pack_rows(w.OUTD, 3 * H, S * N, 3 * H, w.PK_OUTD);
+            RC(h2_pack_multi(&pj, 1, q));
+            d = desc_h2(w.PK_OUTD, w.PK_WL, a->logp, a->V1, S * N, a->V1, 3 * H);
+            d.split_k = 1;
+        }
+        d.bias = a->b_logit; d.rowmap_mod = N; d.rowmap_mul = S;
         RC(gemm(d, q));
         return logsoftmax_rows(a->logp, a->V1, N, S, t0, t1 - t0, a->V1, q);
     };
@@ -902,6 +943,19 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     // Both late-fusion products run as NT problems on k-contiguous (transposed) operands so that they qualify for the
     // bf16-split matrix-core path: d W_logit = DLG^T . OUTD  and  d OUTD = DLG . W_logit.
     echr_gemm_desc d;
+    const bool h2 = config().gemm_h2 && !ov;
+    if (h2) {
+        // d W_logit = DLG^T . OUTD and d OUTD = DLG . W_logit on h2-packed operands; the four packs (two of them transposing) are one launch
+        H2PackJob pj[4] = {pack_cols(b.DLG, b.ldg, V1, SN, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SN, b.PK_OUTDT),
+                           pack_rows(b.DLG, b.ldg, SN, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
+        RC(h2_pack_multi(pj, 4, st));
+        d = desc_h2(b.PK_DLGT, b.PK_OUTDT, g->g_w_logit, 3 * H, V1, 3 * H, SN);
+        d.beta = zb;
+        RC(gemm(d, st));
+        RC(colsum(b.DLG, b.ldg, SN, V1, g->g_b_logit, z, st));
+        d = desc_h2(b.PK_DLG, b.PK_WLT, b.DOUT, 3 * H, SN, 3 * H, V1);
+        RC(gemm(d, st));
+    } else {
     RC(transpose(b.DLG, b.ldg, b.DLGT, b.snp, SN, V1, (int)b.snp, sq));
     RC(transpose(w.OUTD, 3 * H, b.OUTDT, b.snp, SN, 3 * H, (int)b.snp, sq));
     d = desc_nt(b.DLGT, b.snp, b.OUTDT, b.snp, g->g_w_logit, 3 * H, V1, 3 * H, (int)b.snp);
@@ -912,6 +966,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     d = desc_nt(b.DLG, b.ldg, b.WLT, b.ldg, b.DOUT, 3 * H, SN, 3 * H, (int)b.ldg);
     d.split_k = -1; d.algo = ECHR_GEMM_BF16X3;
     RC(gemm(d, st));
+    }
     // 3. reverse recurrence.  Transposed weights turn every d h / d ATT product into the same NT form as forward.
     for (int k = 0; k < 3; ++k) RC(transpose(a->w_hh[k], H, b.WT_HH[k], 4 * H, 4 * H, H, 4 * H, st));
     RC(transpose(a->w_ih[1] + E, cin[1], b.WT_ATT, 4 * H, 4 * H, D, 4 * H, st));
@@ -926,6 +981,33 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         const long r0 = (long)t0 * N;
         const int rows = (t1 - t0) * N;
         echr_gemm_desc e, ghh[3], gih[3];
+        if (h2 && t0 == 0 && t1 == S) {
+            // all S*N rows at once: DG_k^T, h(t-1)_k^T, XT^T, ATT^T, DQ^T packed (transposing) by one launch; DG_k^T is shared by the
+            // W_hh, W_ih[:, :E] and W_ih1[:, E:] gradients, h1^T by the W_hh1 and W_h2a gradients
+            H2PackJob pj[9];
+            for (int k = 0; k < 3; ++k) {
+                pj[k] = pack_cols(b.DG[k], 4 * H, 4 * H, SN, b.PK_DGT[k]);
+                pj[3 + k] = pack_cols(w.HS + k * H, 3 * H, H, SN, b.PK_HT[k]);
+            }
+            pj[6] = pack_cols(w.XT, E, E, SN, b.PK_XTT);
+            pj[7] = pack_cols(w.ATT, D, D, SN, b.PK_ATTT);
+            pj[8] = pack_cols(b.DQ, Ha, Ha, SN, b.PK_DQT);
+            RC(h2_pack_multi(pj, 9, q));
+            for (int k = 0; k < 3; ++k) {
+                ghh[k] = desc_h2(b.PK_DGT[k], b.PK_HT[k], g->g_w_hh[k], H, 4 * H, H, SN);
+                ghh[k].beta = beta;
+                gih[k] = desc_h2(b.PK_DGT[k], b.PK_XTT, g->g_w_ih[k], cin[k], 4 * H, E, SN);
+                gih[k].beta = beta;
+            }
+            RC(gemm_grouped(ghh, 3, q));
+            RC(gemm_grouped(gih, 3, q));
+            e = desc_h2(b.PK_DGT[1], b.PK_ATTT, g->g_w_ih[1] + E, cin[1], 4 * H, D, SN);
+            e.beta = beta;
+            RC(gemm(e, q));
+            e = desc_h2(b.PK_DQT, b.PK_HT[1], g->g_w_h2a, H, Ha, H, SN);
+            e.beta = beta;
+            return gemm(e, q);
+        }
         for (int k = 0; k < 3; ++k) {
             ghh[k] = desc_tn(b.DG[k] + r0 * 4 * H, 4 * H, w.HS + r0 * 3 * H + k * H, 3 * H, g->g_w_hh[k], H, 4 * H, H, rows);
             ghh[k].beta = beta; ghh[k].split_k = -1;
@@ -1012,8 +1094,15 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     const AttDims ad{N, A, Ha, D};
     RC(launch_att_post(ad, w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, g->g_w_alpha, g->g_b_alpha, S, a->rows_disjoint ? 1 : 0, st));
     }
-    d = desc_tn(b.DPALL, Ha, a->c3d, D, g->g_w_c2a, D, Ha, D, a->Tv);
-    d.beta = zb; d.split_k = -1;
+    if (h2) {
+        H2PackJob pj[2] = {pack_cols(b.DPALL, Ha, Ha, a->Tv, b.PK_DPT), pack_cols(a->c3d, D, D, a->Tv, b.PK_C3DT)};
+        RC(h2_pack_multi(pj, 2, st));
+        d = desc_h2(b.PK_DPT, b.PK_C3DT, g->g_w_c2a, D, Ha, D, a->Tv);
+    } else {
+        d = desc_tn(b.DPALL, Ha, a->c3d, D, g->g_w_c2a, D, Ha, D, a->Tv);
+        d.split_k = -1;
+    }
+    d.beta = zb;
     RC(gemm(d, st));
     RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
     //    LSTM / h2att weights: sums over timesteps, done in two chunks (see wgrad_chunk)
@@ -1042,8 +1131,16 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     //    token embedding: dXT = sum_k DG_k . W_ih_k[:, :E], scatter-added into the (caller-zeroed) table gradient
     {
         echr_gemm_desc gx[3];
+        if (h2) {
+            H2PackJob pj[6];
+            for (int k = 0; k < 3; ++k) {
+                pj[k] = pack_rows(b.DG[k], 4 * H, SN, 4 * H, b.PK_DG[k]);
+                pj[3 + k] = pack_cols(a->w_ih[k], cin[k], E, 4 * H, b.PK_WIHT[k]);
+            }
+            RC(h2_pack_multi(pj, 6, st));
+        }
         for (int k = 0; k < 3; ++k) {
-            gx[k] = desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], b.DXT, E, SN, E, 4 * H);
+            gx[k] = h2 ? desc_h2(b.PK_DG[k], b.PK_WIHT[k], b.DXT, E, SN, E, 4 * H) : desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], b.DXT, E, SN, E, 4 * H);
             gx[k].split_k = -1;                                  // shared output: zero-filled once, k-slices of all three add atomically
         }
         RC(gemm_grouped(gx, 3, st));
@@ -1087,7 +1184,7 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
     RC(fill_zero(reinterpret_cast<float*>(sa->n_unfinished), L + 1, st));
     RC(fill_zero(reinterpret_cast<float*>(sa->seq), 2L * N * L, st));
     RC(fill_zero(sa->seq_logp, (long)N * L, st));
-    RC(precompute_static(&a, w, st));
+    RC(precompute_static(&a, w, st, false));
     for (int t = 0; t < L; ++t) {
         RC(embed_gather(a.embed, s.IT, s.XT, N, E, a.V1, st));
         RC(input_gates(&a, w, s.XT, t, 1, st));

@@ -17,11 +17,27 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; };
 Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);
 int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st);
+// h2-packed operands (csrc/gemm.hip: two block-scaled fp16 planes): bytes of the packed image of a [rows x cols] operand (cols =
+// contraction axis), the packing pass, and a multi-operand packing launch
+struct H2PackJob { const float* src; unsigned char* dst; int R, K; long s_row, s_col; };
+long h2_bytes(int rows, int cols);
+int h2_pack(const float* src, int rows, int cols, long s_row, long s_col, void* dst, hipStream_t st);
+int h2_pack_multi(const H2PackJob* jobs, int n, hipStream_t st);
+inline long h2_floats(int rows, int cols) { return (h2_bytes(rows, cols) + 3) / 4; }
+// packed operand of the rows x K matrix stored k-contiguous with leading dimension ld ...
+inline H2PackJob pack_rows(const float* src, long ld, int rows, int K, float* dst) {
+    return H2PackJob{src, reinterpret_cast<unsigned char*>(dst), rows, K, ld, 1};
+}
+// ... or stored transposed: element (r, k) at src[k * ld + r]
+inline H2PackJob pack_cols(const float* src, long ld, int rows, int K, float* dst) {
+    return H2PackJob{src, reinterpret_cast<unsigned char*>(dst), rows, K, 1, ld};
+}
+
 
 // C[M,N] = A[M,K] . W[N,K]^T  (nn.Linear forward; row-major operands with leading dimensions)
 inline echr_gemm_desc desc_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K) {
@@ -41,6 +57,13 @@ inline echr_gemm_desc desc_nn(const float* A, long lda, const float* B, long ldb
 inline echr_gemm_desc desc_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K) {
     echr_gemm_desc d = desc_nn(A, 1, B, ldb, C, ldc, M, N, K);
     d.sam = 1; d.sak = lda;
+    return d;
+}
+
+// C[M,N] = A . B^T on two h2-packed operands
+inline echr_gemm_desc desc_h2(const float* Apk, const float* Bpk, float* C, long ldc, int M, int N, int K) {
+    echr_gemm_desc d = desc_nt(Apk, K, Bpk, K, C, ldc, M, N, K);
+    d.split_k = -1; d.algo = ECHR_GEMM_H2;
     return d;
 }
 

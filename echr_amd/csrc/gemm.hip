@@ -13,6 +13,7 @@
 // along k (scatter of b32 writes, conflict-free at stride BM+1), pad = 4 when filled along m (b128 writes).
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include "echr_common.h"
 #include "echr_internal.h"
 
@@ -34,6 +35,8 @@ struct GemmParams {
     int rowmap_mod, rowmap_mul;
     int split_k, k_tiles_per_split;
     int tiles_m, tiles_n;
+    int xcd_n, xr_m, xr_n;      // h2 kernel: XCD grid columns, tiles per XCD rectangle (rows, cols)
+    int dbg;
     int vecA, vecB;
     // grouped launch: up to 4 same-shaped problems in one grid (blockIdx.z = group * split_k + k-slice); per-group operands
     int ngroup;
@@ -416,6 +419,272 @@ __global__ __launch_bounds__(BN * 4, 4) void gemm_split_kernel(GemmParams pin) {
     epilogue<2, 1>(p, acc, C, b, ks, m0, n0, wm, wn, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// "h2" operands: fp32-grade products at twice the bf16x3 rate and at fp32's byte count.  h2_pack_kernel rewrites an operand
+// ONCE as two fp16 planes with a shared power-of-two scale per row and 32-wide k block (the block-exponent idea of the MX
+// formats, applied to fp16 pairs):
+//     xs = x * 2^(14 - floor(log2(max_k |x|)))      (exact; the block maximum lands in [2^14, 2^15))
+//     h1 = fp16_rne(xs),  h2 = fp16_rne(xs - h1)    (xs - h1 is exact in fp32; |xs - h1 - h2| <= 2^-24 |xs| while h2 is a
+//                                                    normal fp16, i.e. for every element within 2^-17 of its block maximum,
+//                                                    and <= 2^-25 absolute (2^-39 of the block maximum) below that)
+// and the GEMM accumulates, per 32-wide k block, the three fp16 MFMA products h1.h1' + h1.h2' + h2.h1' (each product exact in the
+// fp32 accumulator; the dropped h2.h2' is < 2^-22 of a term) into a scratch accumulator that is then folded into the result with
+// the two block scales: acc += tmp * 2^-(eA[row] + eB[col]).  Error against float64: a few 2^-24 . sum|a||b|, measured in
+// tests/test_gpu_parity.py at or below the native fp32 MFMA path -- with the exponent range of fp32, because no value is ever
+// held in fp16 unscaled.
+//
+// Packed image of a logical [R x K] operand (k = the contraction axis): chunks [ceil(R/128)][ceil(K/32)], each chunk = 2 planes x
+// 128 rows x 32 k fp16 = 16,384 contiguous bytes (zero-padded in both directions), followed by the inverse scales
+// [ceil(R/128)][ceil(K/32)][128] fp32.  Inside a plane a row is 64 B = four 16-byte slots; logical slot s (k = 8s..8s+7) of
+// row r sits at physical slot s ^ ((r>>2)&3): a wave's ds_read_b128 fragment read (16 rows, one logical slot) then touches 16
+// distinct 16-byte bank groups.  The swizzle is baked into the image, so the GEMM stages tiles with direct-to-LDS loads
+// (global_load_lds_dwordx4: linear source, linear destination, no VGPR round trip, no VALU).
+// ------------------------------------------------------------------------------------------------------
+constexpr int H2_ROWS = 128;
+constexpr int H2_PLANE = H2_ROWS * BK * 2;       // 8,192 B
+constexpr int H2_CHUNK = 2 * H2_PLANE;           // 16,384 B
+constexpr int H2_SCALES = H2_ROWS * 4;           // 512 B of inverse scales per chunk
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int H2_MAX_JOBS = 12;
+struct H2PackArgs { H2PackJob job[H2_MAX_JOBS]; int start[H2_MAX_JOBS + 1]; int njobs; };
+
+// one workgroup = one chunk (128 rows x 32 k).  src element (r, k) = src[r * s_row + k * s_col]; one of the strides is 1.
+__global__ __launch_bounds__(256) void h2_pack_kernel(H2PackArgs args) {
+    int ji = 0;
+    while (ji + 1 < args.njobs && (int)blockIdx.x >= args.start[ji + 1]) ++ji;      // chunks of all jobs share one linear grid
+    const H2PackJob jb = args.job[ji];
+    const int KT = (jb.K + BK - 1) / BK, RB = (jb.R + H2_ROWS - 1) / H2_ROWS;
+    const int ci = (int)blockIdx.x - args.start[ji];
+    const int kt = ci % KT, rb = ci / KT, tid = threadIdx.x;
+    __shared__ float tile[H2_ROWS][BK + 1];
+    const int r0 = rb * H2_ROWS, k0 = kt * BK;
+    const float* __restrict__ src = jb.src;
+    if (jb.s_col == 1) {           // k contiguous: 32 lanes cover one row's 32 k
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = tid + i * 256, row = f >> 5, k = f & 31;
+            tile[row][k] = (r0 + row < jb.R && k0 + k < jb.K) ? src[(long)(r0 + row) * jb.s_row + k0 + k] : 0.f;
+        }
+    } else {                       // rows contiguous: a wave reads 64 consecutive rows of one k
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = tid + i * 256, k = f >> 7, row = f & 127;
+            tile[row][k] = (r0 + row < jb.R && k0 + k < jb.K) ? src[(long)(k0 + k) * jb.s_col + r0 + row] : 0.f;
+        }
+    }
+    __syncthreads();
+    unsigned char* chunk = jb.dst + ((long)rb * KT + kt) * H2_CHUNK;
+    float* inv_scales = reinterpret_cast<float*>(jb.dst + (long)RB * KT * H2_CHUNK) + ((long)rb * KT + kt) * H2_ROWS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + i * 256, row = q >> 2, p = q & 3, sl = p ^ ((row >> 2) & 3);
+        float v[8];
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = tile[row][8 * sl + j]; mx = fmaxf(mx, fabsf(v[j])); }
+        mx = fmaxf(mx, __shfl_xor(mx, 1));          // the row's four slots sit in adjacent lanes
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        // block exponent e = floor(log2 mx) from the bit pattern; zero / subnormal / non-finite rows keep scale 1
+        const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
+        int e = (ex == 0 || ex == 255) ? 14 : ex - 127;
+        e = max(e, 14 - 126);                        // keeps 2^(14-e) a normal fp32 (rows below 2^-112 lose bits they do not need)
+        const float sc = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+        unsigned hw[8], lw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xs = v[j] * sc;
+            const _Float16 h1 = (_Float16)xs;
+            const _Float16 h2 = (_Float16)(xs - (float)h1);
+            hw[j] = (unsigned)__builtin_bit_cast(unsigned short, h1);
+            lw[j] = (unsigned)__builtin_bit_cast(unsigned short, h2);
+        }
+        *reinterpret_cast<uint4*>(chunk + q * 16) = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+        *reinterpret_cast<uint4*>(chunk + H2_PLANE + q * 16) = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
+        if (p == 0) inv_scales[row] = ldexpf(1.f, e - 14);
+    }
+}
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+
+// C[M,N] = A . B^T on h2-packed operands.  BM x 128 tile (BM = 128: 4 waves, 256: 8 waves), each wave a 64x64 block of 2x2 MFMA
+// tiles; BK = 32: per k block a wave reads 8 fragments (2 row blocks x 2 planes of A and of B), issues 24 MFMAs into the scratch
+// accumulators and folds them into the result with the block scales (128 VALU FMAs/MULs).
+// Two LDS stages: the global_load_lds pieces of k block t+1 are in flight while block t computes; one barrier per k block (its
+// vmcnt(0) retires the stage that is read next).  A CU pulls at most ~28 B/clk from its L2 (14 from the Infinity Cache), about what
+// a 128x128 stage needs at full MFMA rate, so the workgroup -> tile map gives every XCD a compact rectangle of tiles (xm x xn XCD
+// grid): co-running tiles then share their A and B panels through that XCD's L2.
+template <int BM, int WN>
+__global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, BM == 128 ? 2 : 1) void gemm_h2_kernel(GemmParams pin) {
+    constexpr int WAVES_N = 128 / WN, TN = WN / 32, NT = (BM / 64) * WAVES_N * 64, ACH = BM / 128;
+    constexpr int PLANES = (ACH + 1) * H2_CHUNK;          // plane bytes per stage
+    constexpr int STAGE = PLANES + (ACH + 1) * H2_SCALES;
+    constexpr int PIECES = PLANES / (NT * 16);            // 8 (BM = 128) / 6 (BM = 256) 16-byte pieces per thread and stage
+    constexpr int PPC = H2_CHUNK / (NT * 16);             // pieces per chunk: 4 / 2
+    int z = blockIdx.z;
+    const GemmParams p = select_group(pin, z);
+    __shared__ __attribute__((aligned(1024))) unsigned char sm[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * WN;
+    const int l31 = lane & 31, h = lane >> 5, sw = (l31 >> 2) & 3;
+    // XCD-rectangle tile map: workgroup b runs on XCD b % 8 (round-robin dispatch)
+    const int x = blockIdx.x & 7, sl = blockIdx.x >> 3;
+    const int mb = (x / p.xcd_n) * p.xr_m + sl / p.xr_n, nb = (x % p.xcd_n) * p.xr_n + sl % p.xr_n;
+    if (mb >= p.tiles_m || nb >= p.tiles_n) return;
+    const int ks = z;
+    const int KT = (p.K + BK - 1) / BK;
+    const int kt0 = ks * p.k_tiles_per_split, kt1 = min(KT, kt0 + p.k_tiles_per_split);
+    const int chunks_m = (p.M + H2_ROWS - 1) / H2_ROWS, chunks_n = (p.N + H2_ROWS - 1) / H2_ROWS;
+    const unsigned char* Ap = reinterpret_cast<const unsigned char*>(p.A);
+    const unsigned char* Bp = reinterpret_cast<const unsigned char*>(p.B);
+    const unsigned char* Ag[ACH];
+#pragma unroll
+    for (int c = 0; c < ACH; ++c) Ag[c] = Ap + ((long)min(mb * ACH + c, chunks_m - 1) * KT + kt0) * H2_CHUNK + tid * 16;
+    const unsigned char* Bg = Bp + ((long)nb * KT + kt0) * H2_CHUNK + tid * 16;
+    // inverse scales: waves 0..ACH-1 fetch an A chunk's, wave ACH the B chunk's (32 lanes x 16 B = 512 B each)
+    const unsigned char* Sg = nullptr;
+    if (wave < ACH) Sg = Ap + (long)chunks_m * KT * H2_CHUNK + ((long)min(mb * ACH + wave, chunks_m - 1) * KT + kt0) * H2_SCALES + l31 * 16;
+    else if (wave == ACH) Sg = Bp + (long)chunks_n * KT * H2_CHUNK + ((long)nb * KT + kt0) * H2_SCALES + l31 * 16;
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto stage = [&](int buf) {
+        unsigned char* dst = sm + buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int c = j / PPC, jj = j % PPC;
+            const unsigned char* src = (c < ACH ? Ag[c < ACH ? c : 0] : Bg) + jj * (NT * 16);
+            __builtin_amdgcn_global_load_lds((glb_vptr)src, (lds_vptr)(dst + j * (NT * 16)), 16, 0, 0);
+        }
+        if (wave <= ACH && lane < 32)
+            __builtin_amdgcn_global_load_lds((glb_vptr)Sg, (lds_vptr)(sm + buf * STAGE + PLANES + wave * H2_SCALES), 16, 0, 0);
+#pragma unroll
+        for (int c = 0; c < ACH; ++c) Ag[c] += H2_CHUNK;
+        Bg += H2_CHUNK;
+        Sg += H2_SCALES;
+    };
+    // fragment byte offsets (k half 0 / 1) inside the stage image [A chunk(s) | B chunk | A scales | B scales]
+    const int rowA = (wm & 127) + l31;
+    const int baseA = (wm >> 7) * H2_CHUNK + rowA * 64, baseB = ACH * H2_CHUNK + (wn + l31) * 64;
+    const int o0 = ((0 + h) ^ sw) * 16, o1 = ((2 + h) ^ sw) * 16;
+    const int scA = PLANES + (wm >> 7) * H2_SCALES + ((wm & 127) + 4 * h) * 4;     // + (i*32 + 8*g) * 4: rows (r&3) + 8g + 4h of block i
+    const int scB = PLANES + ACH * H2_SCALES + (wn + l31) * 4;                    // + j*32*4
+
+    if (kt0 < kt1) stage(0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        // every load this wave issued has landed (vmcnt(0)); after the barrier stage `cur` is visible everywhere and stage `cur^1`,
+        // read during the previous k block, is free again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < kt1 && p.dbg != 2) stage(cur ^ 1);
+        if (p.dbg == 1) continue;
+        const unsigned char* sb = sm + cur * STAGE;
+        f32x16 tmp[2][TN];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int o = s ? o1 : o0;
+            f16x8 a[2][2], bb[TN][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                a[0][pl] = *reinterpret_cast<const f16x8*>(sb + baseA + pl * H2_PLANE + o);
+                a[1][pl] = *reinterpret_cast<const f16x8*>(sb + baseA + pl * H2_PLANE + o + 32 * 64);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bb[j][pl] = *reinterpret_cast<const f16x8*>(sb + baseB + pl * H2_PLANE + o + j * 32 * 64);
+            }
+            // small terms first; the four accumulators interleave so that dependent MFMAs are 4 issues apart
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (s == 0) {
+                        f32x16 zero;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                        tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], bb[j][0], zero, 0, 0, 0);
+                    } else tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], bb[j][0], tmp[i][j], 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], bb[j][1], tmp[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], bb[j][0], tmp[i][j], 0, 0, 0);
+        }
+        // fold the block into the result: acc += tmp * invA[row] * invB[col].  The scales are read with inline-asm ds_reads: hipcc
+        // orders a plain LDS read of the glds-written scale area behind vmcnt(0), which would drain the next stage's loads in
+        // every k block (the barrier above already ordered this stage's DMA).
+        float cb[TN];
+        float4 ca[2][4];
+        {
+            const unsigned sbase = (unsigned)(size_t)(sm) + cur * STAGE;       // LDS byte address
+            const unsigned aB = sbase + scB, aA = sbase + scA;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(cb[0]) : "v"(aB));
+            if (TN == 2) asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(cb[TN - 1]) : "v"(aB));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(ca[i][g]) : "v"(aA + (i * 32 + 8 * g) * 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float cav[4] = {ca[i][g].x, ca[i][g].y, ca[i][g].z, ca[i][g].w};
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) acc[i][j][4 * g + r4] = fmaf(tmp[i][j][4 * g + r4], cav[r4] * cb[j], acc[i][j][4 * g + r4]);
+            }
+    }
+    epilogue<2, TN>(p, acc, p.C, 0, ks, mb * BM, nb * 128, wm, wn, lane);
+}
+
+long h2_bytes(int rows, int cols) {
+    return (long)((rows + H2_ROWS - 1) / H2_ROWS) * ((cols + BK - 1) / BK) * (H2_CHUNK + H2_SCALES);
+}
+
+// up to 12 operands packed by one launch (one workgroup per 128 x 32 chunk, all jobs in one linear grid)
+int h2_pack_multi(const H2PackJob* jobs, int n, hipStream_t st) {
+    ECHR_REQUIRE(jobs && n >= 1 && n <= H2_MAX_JOBS, "h2_pack: 1..%d jobs", H2_MAX_JOBS);
+    H2PackArgs a;
+    int total = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const H2PackJob& j = jobs[i];
+        ECHR_REQUIRE(j.src && j.dst && j.R > 0 && j.K > 0, "h2_pack: bad job %d", i);
+        ECHR_REQUIRE(j.s_row == 1 || j.s_col == 1, "h2_pack: one stride must be 1 (s_row=%ld s_col=%ld)", j.s_row, j.s_col);
+        ECHR_REQUIRE((reinterpret_cast<uintptr_t>(j.dst) & 15) == 0, "h2_pack: dst must be 16-byte aligned");
+        a.job[i] = j;
+        a.start[i] = total;
+        total += ((j.K + BK - 1) / BK) * ((j.R + H2_ROWS - 1) / H2_ROWS);
+        bytes += 4.0 * j.R * j.K + (double)h2_bytes(j.R, j.K);
+    }
+    a.start[n] = total;
+    for (int i = n; i < H2_MAX_JOBS; ++i) { a.job[i] = a.job[0]; a.start[i + 1] = total; }
+    a.njobs = n;
+    ProfScope prof(PROF_OTHER, 0.0, bytes, st);
+    hipLaunchKernelGGL(h2_pack_kernel, dim3(total), dim3(256), 0, st, a);
+    return check_launch("h2_pack");
+}
+
+int h2_pack(const float* src, int rows, int cols, long s_row, long s_col, void* dst, hipStream_t st) {
+    H2PackJob j{src, static_cast<unsigned char*>(dst), rows, cols, s_row, s_col};
+    return h2_pack_multi(&j, 1, st);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmParams& p, bool akc, bool bkc, dim3 grid, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -449,8 +718,8 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     const echr_gemm_desc& d = ds[0];
     ECHR_REQUIRE(d.A && d.B && d.C, "gemm: null operand");
     ECHR_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.batch >= 1, "gemm: bad shape M=%d N=%d K=%d batch=%d", d.M, d.N, d.K, d.batch);
-    ECHR_REQUIRE(d.sam == 1 || d.sak == 1, "gemm: A needs a unit stride (sam=%ld sak=%ld)", (long)d.sam, (long)d.sak);
-    ECHR_REQUIRE(d.sbk == 1 || d.sbn == 1, "gemm: B needs a unit stride (sbk=%ld sbn=%ld)", (long)d.sbk, (long)d.sbn);
+    ECHR_REQUIRE(d.algo == ECHR_GEMM_H2 || d.sam == 1 || d.sak == 1, "gemm: A needs a unit stride (sam=%ld sak=%ld)", (long)d.sam, (long)d.sak);
+    ECHR_REQUIRE(d.algo == ECHR_GEMM_H2 || d.sbk == 1 || d.sbn == 1, "gemm: B needs a unit stride (sbk=%ld sbn=%ld)", (long)d.sbk, (long)d.sbn);
     ECHR_REQUIRE(d.act == ECHR_ACT_NONE || d.split_k <= 1, "gemm: split-K cannot carry an activation");
     ECHR_REQUIRE(d.act != ECHR_ACT_MUL_DTANH || d.aux, "gemm: MUL_DTANH needs aux");
     ECHR_REQUIRE(!d.addend || d.add_mod > 0, "gemm: addend needs add_mod");
@@ -469,9 +738,11 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
         p.gA[i] = g.A; p.gB[i] = g.B; p.gC[i] = g.C; p.gsbk[i] = g.sbk; p.gsbn[i] = g.sbn; p.gldc[i] = g.ldc;
         p.gbias[i] = g.bias; p.gbias2[i] = g.bias2; p.gaddend[i] = g.addend;
     }
+    const bool h2 = d.algo == ECHR_GEMM_H2;
+    ECHR_REQUIRE(!h2 || d.batch == 1, "gemm: h2 operands take batch == 1");
     const bool akc = (d.sak == 1);
     const bool bkc = (d.sbk == 1);
-    const bool use_split = d.algo == ECHR_GEMM_BF16X3 && config().gemm_bf16x3 && akc && bkc && d.K % 4 == 0 && d.K >= 4 && d.sam % 4 == 0 &&
+    const bool use_split = !h2 && d.algo == ECHR_GEMM_BF16X3 && config().gemm_bf16x3 && akc && bkc && d.K % 4 == 0 && d.K >= 4 && d.sam % 4 == 0 &&
                            d.sbn % 4 == 0 && aligned16(d.A) && aligned16(d.B) && d.bsa % 4 == 0 && d.bsb % 4 == 0 &&
                            (long)d.M * d.N >= 128L * 128L && ng == 1;
     p.vecA = akc ? (d.sam % 4 == 0 && aligned16(d.A) && d.bsa % 4 == 0) : (d.sak % 4 == 0 && aligned16(d.A) && d.bsa % 4 == 0);
@@ -486,6 +757,7 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     // products (tile quantisation: 400 big tiles on 256 CUs), so it is the default; 128x128 stays selectable for tuning.
     int BMs = 64, BNs = 64;
     bool w8 = false;
+    if (h2) { BMs = (getenv("ECHR_H2_BM") ? atoi(getenv("ECHR_H2_BM")) : 128); BNs = 128; }
     if (use_split) { BMs = 128; BNs = ((long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch >= 96) ? 128 : 64; }
     if (const char* e = getenv("ECHR_GEMM_TILE")) {          // tuning override (tools/gemm_bench.py); never set in production
         if (e[0] == '1') { BMs = 128; BNs = 128; } else if (e[0] == '6') { BMs = 64; BNs = 64; }
@@ -503,7 +775,12 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
         split = 1;
         // latency-bound regime: fewer than 2 workgroups per CU.  Split K so that ~1024 workgroups overlap each other's
         // load latency, keeping at least 4 k-tiles (128 deep) per split (measured optimum on the weight-gradient shapes).
-        if (d.act == ECHR_ACT_NONE && wgs < (use_split ? 200 : 512) && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
+        if (h2) {
+            // two 8-wave workgroups per CU = 512 slots: split K only when the output grid leaves most of them empty, and keep at least
+            // 8 k blocks per slice (each slice pays a pipeline fill and an atomic epilogue)
+            if (d.act == ECHR_ACT_NONE && wgs < 200 && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0)
+                split = (int)max(1L, min((long)kt_total / 8, (400 + wgs - 1) / max(wgs, 1L)));
+        } else if (d.act == ECHR_ACT_NONE && wgs < (use_split ? 200 : 512) && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
             split = (int)min((long)kt_total, max(1L, ((use_split ? 400 : 1024) + wgs - 1) / max(wgs, 1L)));
             if (split > 1 && kt_total / split < 4) split = max(1, kt_total / 4);
         }
@@ -539,10 +816,26 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     dim3 grid(p.tiles_m * p.tiles_n, 1, d.batch * split * ng);
     static const bool log_on = getenv("ECHR_GEMM_LOG") != nullptr;
     if (log_on) fprintf(stderr, "[gemm] M=%d N=%d K=%d batch=%d %s%s tile=%dx%d split=%d algo=%s wgs=%d\n", d.M, d.N, d.K, d.batch, akc ? "N" : "T",
-                        bkc ? "T" : "N", BMs, BNs, split, use_split ? "bf16x3" : "f32", (int)(grid.x * grid.z));
+                        bkc ? "T" : "N", BMs, BNs, split, h2 ? "h2" : use_split ? "bf16x3" : "f32", (int)(grid.x * grid.z));
     // algorithmic work of this launch: 2MNK flops; one read of A and B, one write of C
-    ProfScope prof(use_split ? PROF_GEMM_SPLIT : PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch * ng, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch * ng, st);
-    if (use_split && BNs == 128) hipLaunchKernelGGL(gemm_split_kernel<128>, grid, dim3(512), 0, st, p);
+    ProfScope prof((use_split || h2) ? PROF_GEMM_SPLIT : PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch * ng, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch * ng, st);
+    if (h2) {
+        // XCD rectangles: xm x xn = 8, least padded tiles first, then fewest panels per XCD
+        int best = -1; long best_cost = 0;
+        for (int xm = 1; xm <= 8; xm *= 2) {
+            const int xn = 8 / xm, rm = (p.tiles_m + xm - 1) / xm, rn = (p.tiles_n + xn - 1) / xn;
+            const long cost = ((long)rm * rn * 8) * 100000L + (long)rm * BMs + (long)rn * BNs;
+            if (best < 0 || cost < best_cost) { best = xm; best_cost = cost; }
+        }
+        p.dbg = getenv("ECHR_H2_DBG") ? atoi(getenv("ECHR_H2_DBG")) : 0;
+        p.xcd_n = 8 / best; p.xr_m = (p.tiles_m + best - 1) / best; p.xr_n = (p.tiles_n + p.xcd_n - 1) / p.xcd_n;
+        grid.x = 8 * p.xr_m * p.xr_n;
+        static const int wn_sel = getenv("ECHR_H2_WN") ? atoi(getenv("ECHR_H2_WN")) : 32;
+        if (BMs == 256) hipLaunchKernelGGL((gemm_h2_kernel<256, 64>), grid, dim3(512), 0, st, p);
+        else if (wn_sel == 64) hipLaunchKernelGGL((gemm_h2_kernel<128, 64>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_h2_kernel<128, 32>), grid, dim3(512), 0, st, p);
+    }
+    else if (use_split && BNs == 128) hipLaunchKernelGGL(gemm_split_kernel<128>, grid, dim3(512), 0, st, p);
     else if (use_split) hipLaunchKernelGGL(gemm_split_kernel<64>, grid, dim3(256), 0, st, p);
     else if (BMs == 128 && BNs == 128 && w8) launch_cfg<128, 128, 64, 32>(p, akc, bkc, grid, st);
     else if (BMs == 128 && BNs == 128) launch_cfg<128, 128, 64, 64>(p, akc, bkc, grid, st);
@@ -553,6 +846,13 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
 }
 
 }  // namespace echr
+
+extern "C" int64_t echr_h2_bytes(int32_t rows, int32_t cols) { return echr::h2_bytes(rows, cols); }
+
+extern "C" int echr_h2_pack(const float* src, int32_t rows, int32_t cols, int64_t s_row, int64_t s_col, void* dst, void* stream) {
+    ECHR_REQUIRE(src && dst && rows > 0 && cols > 0, "h2_pack: bad arguments");
+    return echr::h2_pack(src, rows, cols, (long)s_row, (long)s_col, dst, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int echr_gemm_f32(const echr_gemm_desc* d, void* stream) {
     if (!d) { echr::set_error("echr_gemm_f32: null descriptor"); return -22; }

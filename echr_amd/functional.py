@@ -390,3 +390,37 @@ class TapBCE(torch.autograd.Function):
         L.check(lib.echr_tap_bce_bwd(L.ptr(scores), L.ptr(masks), L.ptr(labels), L.ptr(w1), L.ptr(_f32c(g).reshape(1)), L.ptr(gs), T, K,
                                      L.stream_ptr()), 'tap_bce_bwd')
         return gs, None, None, None
+
+
+def h2_pack(x, transposed=False):
+    """h2-packed image (two block-scaled fp16 planes, include/echr_hip.h) of the operand x [R,K] -- or, with transposed=True,
+    of x^T for x stored [K,R] (the pack transposes on the fly).  Returns (uint8 buffer, R, K)."""
+    lib = L.load()
+    x = _f32c(x)
+    if transposed:
+        K, R = x.shape
+        s_row, s_col = 1, x.stride(0)
+    else:
+        R, K = x.shape
+        s_row, s_col = x.stride(0), 1
+    buf = torch.empty(int(lib.echr_h2_bytes(R, K)), device=x.device, dtype=torch.uint8)
+    L.check(lib.echr_h2_pack(L.ptr(x), R, K, s_row, s_col, buf.data_ptr(), L.stream_ptr()), 'h2_pack')
+    return buf, R, K
+
+
+def gemm_h2(a_packed, b_packed, bias=None):
+    """C[M,N] = A . B^T (+ bias) from two h2-packed operands."""
+    lib = L.load()
+    (ab, M, K), (bb, N, K2) = a_packed, b_packed
+    if K != K2:
+        raise ValueError('contraction lengths differ (%d vs %d)' % (K, K2))
+    out = torch.empty(M, N, device=ab.device, dtype=torch.float32)
+    d = L.GemmDesc()
+    d.A, d.B, d.C = ab.data_ptr(), bb.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.sam, d.sak, d.sbk, d.sbn = K, 1, 1, K
+    d.ldc, d.batch, d.alpha, d.beta, d.split_k, d.algo = N, 1, 1.0, 0.0, -1, 2
+    if bias is not None:
+        d.bias = L.ptr(_f32c(bias))
+    L.check(lib.echr_gemm_f32(C.byref(d), L.stream_ptr()), 'gemm_h2')
+    return out

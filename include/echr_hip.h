@@ -39,7 +39,7 @@ const char* echr_last_error(void);
  * split_k > 1: partial sums are atomically added into C (which must already hold its base value);
  *              act must be ECHR_ACT_NONE and beta is ignored.
  * ---------------------------------------------------------------------------------------------- */
-enum { ECHR_GEMM_F32 = 0, ECHR_GEMM_BF16X3 = 1 };
+enum { ECHR_GEMM_F32 = 0, ECHR_GEMM_BF16X3 = 1, ECHR_GEMM_H2 = 2 };
 enum { ECHR_ACT_NONE = 0, ECHR_ACT_TANH = 1, ECHR_ACT_MUL_DTANH = 2 /* acc * (1 - aux^2) */ };
 
 typedef struct {
@@ -64,10 +64,22 @@ typedef struct {
     int32_t split_k;
     int32_t algo; /* ECHR_GEMM_F32 (exact v_mfma_f32_32x32x2_f32) or ECHR_GEMM_BF16X3 (fp32 operands split exactly into three
                      bf16 planes, six plane products on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-accurate, 2.7x the rate;
-                     needs both operands k-contiguous and 16-byte aligned, else the library silently uses ECHR_GEMM_F32) */
+                     needs both operands k-contiguous and 16-byte aligned, else the library silently uses ECHR_GEMM_F32),
+                     or ECHR_GEMM_H2: A and B point at operands that echr_h2_pack has already rewritten as two block-scaled fp16
+                     planes (below); three fp16 MFMA products per k block, fp32-grade accuracy at 5x the fp32 MFMA rate and
+                     fp32's byte count (strides are ignored; batch = 1, no activation) */
 } echr_gemm_desc;
 
 int echr_gemm_f32(const echr_gemm_desc* d, void* stream);
+
+/* h2 operands: a logical [rows x cols] fp32 operand (cols = the contraction axis) rewritten as two fp16 planes with one shared
+ * power-of-two scale per row and 32-wide k block: xs = x * 2^(14 - floor(log2 blockmax)), h1 = fp16(xs), h2 = fp16(xs - h1).
+ * No value is held in fp16 unscaled, so the fp32 exponent range survives; h1 + h2 carries 22..24 significand bits of every
+ * element within 2^-17 of its block maximum.  Laid out as zero-padded 128 x 32 chunks in the order the GEMM's direct-to-LDS
+ * loads consume.  Element (r, k) is read from src[r*s_row + k*s_col] (one stride must be 1, so a transposed source packs
+ * without a separate transpose).  dst: echr_h2_bytes(rows, cols) bytes, 16-byte aligned. */
+int64_t echr_h2_bytes(int32_t rows, int32_t cols);
+int echr_h2_pack(const float* src, int32_t rows, int32_t cols, int64_t s_row, int64_t s_col, void* dst, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dropout configuration shared by all training-mode entry points (counter-based Philox-4x32-10;
@@ -280,8 +292,9 @@ int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int
 int echr_prof_enable(int on);
 int echr_prof_read(int kind, double* ms, double* flops, double* bytes, int64_t* launches);
 
-/* Runtime switches (defaults from the environment variables ECHR_GEMM_BF16X3=1, ECHR_OVERLAP=0, ECHR_ATT_SLOTS=2):
- *   "gemm_bf16x3" 0/1  use the three-plane bf16 split product for the large projections (fp32-accurate, faster) or not
+/* Runtime switches (defaults from the environment variables ECHR_GEMM_H2=1, ECHR_GEMM_BF16X3=1, ECHR_OVERLAP=0, ECHR_ATT_SLOTS=2):
+ *   "gemm_h2"     0/1  run the decoder's large projections on h2-packed operands (two block-scaled fp16 planes, fp32-grade) or not
+ *   "gemm_bf16x3" 0/1  (gemm_h2 = 0) use the three-plane bf16 split product for the large projections or the native fp32 MFMA
  *   "overlap"     0/1  run recurrence-independent GEMMs on a second HIP stream
  *   "att_slots"   2/4/8 attention slots per wave */
 int echr_config_set(const char* key, int32_t value);

@@ -54,6 +54,32 @@ def test_gemm_bf16x3_split_is_fp32_accurate(M, N, K):
     assert esp < 4e-7 and esp < 4 * e32 + 1e-7, (esp, e32)
 
 
+@pytest.mark.parametrize('M,N,K', [(128, 128, 32), (1280, 5001, 1536), (300, 700, 500), (4096, 512, 512), (130, 257, 36), (77, 3, 8200)])
+def test_gemm_h2_packed_is_fp32_accurate(M, N, K):
+    """Two block-scaled fp16 planes + three fp16 MFMA products must be as accurate as the exact fp32 MFMA path (both against
+    float64, componentwise bound), over a wide dynamic range, and a transposing pack must give the identical image."""
+    from echr_amd import functional as EF
+    rs = np.random.RandomState(M + N + K)
+    A = (rs.standard_normal((M, K)) * np.exp(rs.uniform(-12, 12, (M, 1))) * np.exp2(rs.randint(-8, 8, (M, K)))).astype(np.float32)
+    B = (rs.standard_normal((N, K)) * np.exp(rs.uniform(-12, 12, (N, 1)))).astype(np.float32)
+    A[rs.uniform(size=A.shape) < 0.05] = 0.0
+    A[M // 2] = 0.0                                                      # an all-zero row: scale stays 1
+    bias = rs.standard_normal(N).astype(np.float32)
+    ref = A.astype(np.float64) @ B.T.astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B.T).astype(np.float64) + 1e-300
+    At, Bt = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    pa, pb = EF.h2_pack(At), EF.h2_pack(Bt)
+    pbt = EF.h2_pack(Bt.t().contiguous(), transposed=True)
+    assert torch.equal(pb[0], pbt[0])
+    out = EF.gemm_h2(pa, pb).cpu().numpy()
+    e32 = np.max(np.abs(EF.gemm(At, Bt, True, None, 0).cpu().numpy() - ref) / scale)
+    eh2 = np.max(np.abs(out - ref) / scale)
+    assert eh2 < 6e-7 and eh2 < 2 * e32 + 5e-8, (eh2, e32)
+    assert np.all(out[M // 2] == 0.0)
+    outb = EF.gemm_h2(pa, pb, torch.from_numpy(bias).cuda()).cpu().numpy()
+    assert np.max(np.abs(outb - (out.astype(np.float64) + bias)) / (scale + np.abs(bias))) < 1e-6     # split-K sums are order-dependent
+
+
 def test_position_embedding_matches_reference_numpy():
     from echr_amd import functional as EF
     g = U.gold('position.npz')
@@ -307,22 +333,27 @@ def test_odd_shapes_vs_oracle(N, A, T_v, L, V1):
             assert U.grad_close(k, grads[k], g, TOL_GRAD), (k, U.relerr(grads[k], g))
 
 
-def test_split_gemm_switch_does_not_change_results_beyond_tolerance():
-    """echr_config_set('gemm_bf16x3', 0/1): the bf16-plane split products and the native fp32 MFMA products agree to ~1e-6."""
+def test_gemm_path_switches_do_not_change_results_beyond_tolerance():
+    """echr_config_set('gemm_h2' / 'gemm_bf16x3'): the packed fp16-pair products, the bf16-plane split products and the native
+    fp32 MFMA products agree to ~1e-6 on the whole forward/backward path."""
     from echr_amd import _lib
     lib = _lib.load()
     opt, params, vid = synth.make_case('c1')
+    runs = {}
     try:
-        assert lib.echr_config_set(b'gemm_bf16x3', 0) == 0
-        p0, l0, g0, _ = U.run_gpu(opt, params, vid, False)
-        assert lib.echr_config_set(b'gemm_bf16x3', 1) == 0
-        p1, l1, g1, _ = U.run_gpu(opt, params, vid, False)
+        for name, h2, x3 in (('f32', 0, 0), ('bf16x3', 0, 1), ('h2', 1, 1)):
+            assert lib.echr_config_set(b'gemm_h2', h2) == 0 and lib.echr_config_set(b'gemm_bf16x3', x3) == 0
+            runs[name] = U.run_gpu(opt, params, vid, False)
     finally:
         lib.echr_config_set(b'gemm_bf16x3', 1)
-    assert np.abs(p0 - p1).max() < 2e-5 and abs(l0 - l1) < 1e-5 * abs(l0)
-    for k in g0:
-        if g0[k] is not None:
-            assert U.grad_close(k, g1[k], g0[k], 1e-4), k
+        lib.echr_config_set(b'gemm_h2', 1)
+    p0, l0, g0, _ = runs['f32']
+    for name in ('bf16x3', 'h2'):
+        p1, l1, g1, _ = runs[name]
+        assert np.abs(p0 - p1).max() < 2e-5 and abs(l0 - l1) < 1e-5 * abs(l0), name
+        for k in g0:
+            if g0[k] is not None:
+                assert U.grad_close(k, g1[k], g0[k], 1e-4), (name, k)
     assert lib.echr_config_set(b'no_such_key', 1) != 0
 
 

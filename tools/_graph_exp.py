@@ -1,0 +1,68 @@
+"""scratch: does a captured hipGraph of the whole iteration run faster than eager? (counters baked in -- timing only)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench, echr_amd
+from echr_amd import functional as EF
+from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+from echr_amd.optim import ClampAdam
+import echr_amd.models.MA_attention_8_NEW as MA
+
+dev = torch.device('cuda', 0)
+opt, params, vid = bench.make_workload(0, False)
+model = echr_amd.CaptionGenerator(opt)
+model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+model = model.to(dev).train()
+crit = LanguageModelCriterion()
+arena = model.build_arena()
+optim = ClampAdam(model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon, arena=arena)
+tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+labels = torch.from_numpy(vid['labels'])
+tgt = labels[:, 1:].to(dev); msk = torch.from_numpy(vid['masks'])[:, 1:].to(dev)
+
+# cache H2D uploads
+_orig = EF.event_index_tensors
+_cache = {}
+def cached(soi, ind, device, n_rows=None):
+    k = 'a'
+    if k not in _cache: _cache[k] = _orig(soi, ind, device, n_rows)
+    return _cache[k]
+EF.event_index_tensors = cached
+import echr_amd.models.OldModel_NEW as OM
+OM.n_decoder_steps = lambda seq: 20
+labels_dev = labels.to(dev)
+_oa = MA.torch.from_numpy
+
+_c2 = {}
+class _T:
+    pass
+def iteration():
+    optim.zero_grad()
+    pred = model(tap, c3d, lda, labels_dev, vid['ind'], vid['soi'], mode='train')
+    loss = crit(pred, tgt, msk)
+    loss.backward()
+    clip_gradient(optim, opt.grad_clip)
+    optim.step()
+    return loss
+
+def timeit(f, n=20):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+
+for _ in range(3): iteration()
+print('eager ms', timeit(iteration), flush=True)
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+try:
+    with torch.cuda.stream(s):
+        for _ in range(2): iteration()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss = iteration()
+    print('captured', flush=True)
+    for _ in range(3): g.replay()
+    print('graph ms', timeit(g.replay), 'loss', float(loss.item()), flush=True)
+except Exception as e:
+    import traceback; traceback.print_exc()
