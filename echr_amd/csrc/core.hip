@@ -173,6 +173,48 @@ int colsum(const float* X, long ld, int rows, int cols, float* out, bool accumul
     return colsum2(X, ld, rows, cols, out, nullptr, accumulate, st);
 }
 
+// several column-sum problems in ONE launch; every output accumulates atomically (the caller owns the base values: gradient
+// buffers that are already zeroed or being accumulated into).  Linear grid over (job, column tile, row chunk).
+struct ColsumArgs { ColsumJob job[COLSUM_MAX_JOBS]; int start[COLSUM_MAX_JOBS + 1]; int njobs; };
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumArgs a) {
+    __shared__ float red[4][64];
+    int ji = 0;
+    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.start[ji + 1]) ++ji;
+    const ColsumJob J = a.job[ji];
+    const int ci = (int)blockIdx.x - a.start[ji];
+    const int ctiles = (J.cols + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (ci % ctiles) * 64 + lane;
+    const int r0 = (ci / ctiles) * CS_ROWS, r1 = min(J.rows, r0 + CS_ROWS);
+    float s = 0.f;
+    if (col < J.cols)
+        for (int r = r0 + wave; r < r1; r += 4) s += J.X[(long)r * J.ld + col];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < J.cols) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        atomicAdd(&J.out[col], t);
+        if (J.out2) atomicAdd(&J.out2[col], t);
+        if (J.out3) atomicAdd(&J.out3[col], t);
+    }
+}
+int colsum_multi(const ColsumJob* jobs, int n, hipStream_t st) {
+    ECHR_REQUIRE(jobs && n >= 1 && n <= COLSUM_MAX_JOBS, "colsum_multi: 1..%d jobs", COLSUM_MAX_JOBS);
+    ColsumArgs a;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        ECHR_REQUIRE(jobs[i].X && jobs[i].out && jobs[i].rows > 0 && jobs[i].cols > 0, "colsum_multi: bad job %d", i);
+        a.job[i] = jobs[i];
+        a.start[i] = total;
+        total += ((jobs[i].cols + 63) / 64) * ((jobs[i].rows + CS_ROWS - 1) / CS_ROWS);
+    }
+    for (int i = n; i < COLSUM_MAX_JOBS; ++i) a.job[i] = jobs[0];
+    for (int i = n; i <= COLSUM_MAX_JOBS; ++i) a.start[i] = total;
+    a.njobs = n;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(total), dim3(256), 0, st, a);
+    return check_launch("colsum_multi");
+}
+
 __global__ void sum_over_time_kernel(const float* __restrict__ X, long ld, int S, int N, int cols,
                                      float* __restrict__ out, long ld_out) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -459,7 +459,11 @@ static int launch_att_post(const AttDims& d, const float* PALL, const float* QS,
 //   the same k pairing, so the products are exact fp32 sums over the slice.
 // ------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int RK = 128;              // k-slice staged per workgroup
+#ifndef ECHR_RK
+#define ECHR_RK 128
+#endif
+constexpr int RK = ECHR_RK;          // k-slice staged per workgroup
+constexpr int RQ = RK / 4, RLP = 64 * RQ / 256;      // float4 per row, staging float4 per thread and operand
 constexpr int RLD = RK + 4;          // LDS row stride (floats): 16-byte aligned rows, conflict-free b128 reads
 constexpr int MAXJOBS = 8;
 
@@ -483,20 +487,20 @@ __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
     const int tid = threadIdx.x;
     // branch-free staging: every lane loads from a clamped (always valid) address and zeroes what lies outside the
     // problem, so all 16 global loads of a thread are in flight together before the first LDS write
-    float4 va[8], vb[8];
+    float4 va[RLP], vb[RLP];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < RLP; ++p) {
         const int f = tid + p * 256;
-        const int row = f >> 5, kq = (f & 31) * 4;
+        const int row = f / RQ, kq = (f % RQ) * 4;
         const int kk = min(k0 + kq, J.K - 4);
         const int ra = min(m0 + row, args.M - 1), rbn = min(n0 + row, J.Nout - 1);
         va[p] = *reinterpret_cast<const float4*>(J.A + (long)ra * J.lda + kk);
         vb[p] = *reinterpret_cast<const float4*>(J.B + (long)rbn * J.ldb + kk);
     }
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < RLP; ++p) {
         const int f = tid + p * 256;
-        const int row = f >> 5, kq = (f & 31) * 4;
+        const int row = f / RQ, kq = (f % RQ) * 4;
         const bool kin = (k0 + kq) < k1;
         const float ma = (kin && (m0 + row) < args.M) ? 1.f : 0.f;
         const float mb = (kin && (n0 + row) < J.Nout) ? 1.f : 0.f;
@@ -699,14 +703,14 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     w.DOUT = take(S * N * 3 * H);
     for (int k = 0; k < 3; ++k) w.DG[k] = take(S * N * 4 * H);
     w.DSC = take(S * N * a->A);
-    // one contiguous zero-initialised region: DC | DQ | DASL | DPALL (a single fill per backward)
+    // one contiguous zero-initialised region: DC | DGCOL | DQ | DASL | DPALL (a single fill per backward)
     w.DC = take(N * 3 * H);
+    for (int k = 0; k < 3; ++k) w.DGCOL[k] = take(4 * H);
     w.DQ = take(S * N * a->Ha);
     w.DASL = take(S * N * a->D);
     w.DPALL = take((long)a->Tv * a->Ha);
     w.zero_floats = (w.DPALL - w.DC) + rup((long)a->Tv * a->Ha, 64);
     for (int k = 0; k < 3; ++k) w.DGSUM[k] = take(N * 4 * H);
-    for (int k = 0; k < 3; ++k) w.DGCOL[k] = take(4 * H);
     w.DXT = take(S * N * a->E);
     w.MSUM = take(64);
     for (int k = 0; k < 3; ++k) w.WT_HH[k] = take(H * 4 * H);
@@ -1104,15 +1108,26 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     }
     d.beta = zb;
     RC(gemm(d, st));
-    RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
     //    LSTM / h2att weights: sums over timesteps, done in two chunks (see wgrad_chunk)
     if (ov) RC(hop(sq, side().join, st));                     // chunk [th,S) and the logit gradients are complete
     RC(wgrad_chunk(0, th_b, (ov || z) ? 1.f : 0.f, st));
-    RC(colsum(b.DQ, Ha, SN, Ha, g->g_b_h2a, z, st));
-    for (int k = 0; k < 3; ++k) {
-        RC(sum_over_time(b.DG[k], 4 * H, S, N, 4 * H, b.DGSUM[k], 4 * H, st));
-        RC(colsum2(b.DGSUM[k], 4 * H, N, 4 * H, g->g_b_ih[k], g->g_b_hh[k], z, st));       // b_ih and b_hh share their gradient
-        if (k == 2) RC(colsum(b.DGSUM[k], 4 * H, N, 4 * H, b.DGCOL[k], false, st));          // also needed as a vector below
+    //    bias gradients: b_c2a, b_h2a, and per stream b_ih = b_hh = column sums of DG_k over all S*N rows (stream 2's also as the
+    //    plain vector DGCOL that the scene projection below consumes).  One launch when the gradient buffers accumulate.
+    if (z) {
+        const ColsumJob cj[5] = {{b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, nullptr, nullptr}, {b.DQ, Ha, SN, Ha, g->g_b_h2a, nullptr, nullptr},
+                                 {b.DG[0], 4 * H, SN, 4 * H, g->g_b_ih[0], g->g_b_hh[0], nullptr},
+                                 {b.DG[1], 4 * H, SN, 4 * H, g->g_b_ih[1], g->g_b_hh[1], nullptr},
+                                 {b.DG[2], 4 * H, SN, 4 * H, g->g_b_ih[2], g->g_b_hh[2], b.DGCOL[2]}};
+        RC(colsum_multi(cj, 5, st));
+        RC(sum_over_time(b.DG[0], 4 * H, S, N, 4 * H, b.DGSUM[0], 4 * H, st));     // per-event sums feed the event-context products
+    } else {
+        RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
+        RC(colsum(b.DQ, Ha, SN, Ha, g->g_b_h2a, z, st));
+        for (int k = 0; k < 3; ++k) {
+            RC(sum_over_time(b.DG[k], 4 * H, S, N, 4 * H, b.DGSUM[k], 4 * H, st));
+            RC(colsum2(b.DGSUM[k], 4 * H, N, 4 * H, g->g_b_ih[k], g->g_b_hh[k], z, st));       // b_ih and b_hh share their gradient
+            if (k == 2) RC(colsum(b.DGSUM[k], 4 * H, N, 4 * H, b.DGCOL[k], false, st));          // also needed as a vector below
+        }
     }
     //    context halves of W_ih: event (stream 0), attended clip (stream 1), video (stream 2)
     d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);

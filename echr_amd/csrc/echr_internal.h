@@ -70,6 +70,10 @@ inline echr_gemm_desc desc_h2(const float* Apk, const float* Bpk, float* C, long
 // column sums: out[j] (+)= sum_i X[i*ld + j], i < rows
 int colsum(const float* X, long ld, int rows, int cols, float* out, bool accumulate, hipStream_t st);
 int colsum2(const float* X, long ld, int rows, int cols, float* out, float* out2, bool accumulate, hipStream_t st);
+// several accumulating column sums in one launch (out / out2 / out3 += column sums of X; out2, out3 optional)
+constexpr int COLSUM_MAX_JOBS = 8;
+struct ColsumJob { const float* X; long ld; int rows, cols; float* out; float* out2; float* out3; };
+int colsum_multi(const ColsumJob* jobs, int n, hipStream_t st);
 // out[n*ld_out + j] = sum_t X[(t*N + n)*ld + j]
 int sum_over_time(const float* X, long ld, int S, int N, int cols, float* out, long ld_out, hipStream_t st);
 int fill_zero(float* p, long n, hipStream_t st);

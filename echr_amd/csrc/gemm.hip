@@ -451,6 +451,33 @@ constexpr int H2_MAX_JOBS = 12;
 struct H2PackArgs { H2PackJob job[H2_MAX_JOBS]; int start[H2_MAX_JOBS + 1]; int njobs; };
 
 // one workgroup = one chunk (128 rows x 32 k).  src element (r, k) = src[r * s_row + k * s_col]; one of the strides is 1.
+// k-contiguous sources need no staging: a thread owns (row, 16-byte slot) = 8 consecutive k and reads them as two float4.
+// Row-contiguous sources (a transposing pack) go through an LDS tile filled by float4 reads along the rows.
+__device__ __forceinline__ void h2_emit(const float (&v)[8], unsigned char* __restrict__ chunk, float* __restrict__ inv_scales, int q, int row, int p) {
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(v[j]));
+    mx = fmaxf(mx, __shfl_xor(mx, 1));          // the row's four slots sit in adjacent lanes
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    // block exponent e = floor(log2 mx) from the bit pattern; zero / subnormal / non-finite rows keep scale 1
+    const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
+    int e = (ex == 0 || ex == 255) ? 14 : ex - 127;
+    e = max(e, 14 - 126);                        // keeps 2^(14-e) a normal fp32 (rows below 2^-112 lose bits they do not need)
+    const float sc = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+    unsigned hw[8], lw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xs = v[j] * sc;
+        const _Float16 h1 = (_Float16)xs;
+        const _Float16 h2 = (_Float16)(xs - (float)h1);
+        hw[j] = (unsigned)__builtin_bit_cast(unsigned short, h1);
+        lw[j] = (unsigned)__builtin_bit_cast(unsigned short, h2);
+    }
+    *reinterpret_cast<uint4*>(chunk + q * 16) = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+    *reinterpret_cast<uint4*>(chunk + H2_PLANE + q * 16) = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
+    if (p == 0) inv_scales[row] = ldexpf(1.f, e - 14);
+}
+
 __global__ __launch_bounds__(256) void h2_pack_kernel(H2PackArgs args) {
     int ji = 0;
     while (ji + 1 < args.njobs && (int)blockIdx.x >= args.start[ji + 1]) ++ji;      // chunks of all jobs share one linear grid
@@ -458,16 +485,45 @@ __global__ __launch_bounds__(256) void h2_pack_kernel(H2PackArgs args) {
     const int KT = (jb.K + BK - 1) / BK, RB = (jb.R + H2_ROWS - 1) / H2_ROWS;
     const int ci = (int)blockIdx.x - args.start[ji];
     const int kt = ci % KT, rb = ci / KT, tid = threadIdx.x;
-    __shared__ float tile[H2_ROWS][BK + 1];
     const int r0 = rb * H2_ROWS, k0 = kt * BK;
     const float* __restrict__ src = jb.src;
-    if (jb.s_col == 1) {           // k contiguous: 32 lanes cover one row's 32 k
+    unsigned char* chunk = jb.dst + ((long)rb * KT + kt) * H2_CHUNK;
+    float* inv_scales = reinterpret_cast<float*>(jb.dst + (long)RB * KT * H2_CHUNK) + ((long)rb * KT + kt) * H2_ROWS;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    if (jb.s_col == 1) {
+        const bool vec = aligned && (jb.s_row & 3) == 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int f = tid + i * 256, row = f >> 5, k = f & 31;
-            tile[row][k] = (r0 + row < jb.R && k0 + k < jb.K) ? src[(long)(r0 + row) * jb.s_row + k0 + k] : 0.f;
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + i * 256, row = q >> 2, p = q & 3, sl = p ^ ((row >> 2) & 3);
+            const int r = r0 + row, k = k0 + 8 * sl;
+            float v[8];
+            const float* s8 = src + (long)min(r, jb.R - 1) * jb.s_row + k;
+            if (vec && k + 8 <= jb.K) {
+                const float4 x0 = *reinterpret_cast<const float4*>(s8), x1 = *reinterpret_cast<const float4*>(s8 + 4);
+                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (k + j < jb.K) ? s8[j] : 0.f;
+            }
+            if (r >= jb.R) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+            h2_emit(v, chunk, inv_scales, q, row, p);
         }
-    } else {                       // rows contiguous: a wave reads 64 consecutive rows of one k
+        return;
+    }
+    __shared__ float tile[H2_ROWS][BK + 1];
+    const bool vec = aligned && (jb.s_col & 3) == 0 && r0 + H2_ROWS <= jb.R;
+    if (vec) {                     // float4 = 4 consecutive rows of one k; a wave covers 256 rows x ... = two k of the 128-row strip
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * 256, k = f >> 5, row = (f & 31) * 4;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + k < jb.K) x = *reinterpret_cast<const float4*>(src + (long)(k0 + k) * jb.s_col + r0 + row);
+            tile[row][k] = x.x; tile[row + 1][k] = x.y; tile[row + 2][k] = x.z; tile[row + 3][k] = x.w;
+        }
+    } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int f = tid + i * 256, k = f >> 7, row = f & 127;
@@ -475,34 +531,13 @@ __global__ __launch_bounds__(256) void h2_pack_kernel(H2PackArgs args) {
         }
     }
     __syncthreads();
-    unsigned char* chunk = jb.dst + ((long)rb * KT + kt) * H2_CHUNK;
-    float* inv_scales = reinterpret_cast<float*>(jb.dst + (long)RB * KT * H2_CHUNK) + ((long)rb * KT + kt) * H2_ROWS;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q = tid + i * 256, row = q >> 2, p = q & 3, sl = p ^ ((row >> 2) & 3);
         float v[8];
-        float mx = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { v[j] = tile[row][8 * sl + j]; mx = fmaxf(mx, fabsf(v[j])); }
-        mx = fmaxf(mx, __shfl_xor(mx, 1));          // the row's four slots sit in adjacent lanes
-        mx = fmaxf(mx, __shfl_xor(mx, 2));
-        // block exponent e = floor(log2 mx) from the bit pattern; zero / subnormal / non-finite rows keep scale 1
-        const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
-        int e = (ex == 0 || ex == 255) ? 14 : ex - 127;
-        e = max(e, 14 - 126);                        // keeps 2^(14-e) a normal fp32 (rows below 2^-112 lose bits they do not need)
-        const float sc = __uint_as_float((unsigned)(127 + 14 - e) << 23);
-        unsigned hw[8], lw[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xs = v[j] * sc;
-            const _Float16 h1 = (_Float16)xs;
-            const _Float16 h2 = (_Float16)(xs - (float)h1);
-            hw[j] = (unsigned)__builtin_bit_cast(unsigned short, h1);
-            lw[j] = (unsigned)__builtin_bit_cast(unsigned short, h2);
-        }
-        *reinterpret_cast<uint4*>(chunk + q * 16) = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
-        *reinterpret_cast<uint4*>(chunk + H2_PLANE + q * 16) = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
-        if (p == 0) inv_scales[row] = ldexpf(1.f, e - 14);
+        for (int j = 0; j < 8; ++j) v[j] = tile[row][8 * sl + j];
+        h2_emit(v, chunk, inv_scales, q, row, p);
     }
 }
 

@@ -85,14 +85,16 @@ __global__ __launch_bounds__(64) void tsrm_softmax_bwd_kernel(const float* __res
 
 static inline long rup(long x, long a) { return (x + a - 1) / a * a; }
 
-struct TsrmWs { float *X, *POS, *P1, *GATE, *Q, *K, *XW, *AFF, *WSM, *WD; long total; };
+struct TsrmWs { float *X, *POS, *P1, *GATE, *Q, *K, *XW, *AFF, *WSM, *WD; long total, zero_floats; };
 static TsrmWs carve(int N, int Din, int Df, int Do, int G, float* base) {
     TsrmWs w;
     long off = 0;
     auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
     const long NN = (long)N * N;
-    w.X = take((long)N * Df); w.POS = take(NN * Df); w.P1 = take(NN * Df); w.GATE = take(NN * G);
-    w.Q = take((long)N * Df); w.K = take((long)N * Df); w.XW = take((long)N * Do);
+    // X | GATE | Q | K | XW are split-K (atomically accumulated) GEMM outputs: contiguous, zeroed by one fill
+    w.X = take((long)N * Df); w.GATE = take(NN * G); w.Q = take((long)N * Df); w.K = take((long)N * Df); w.XW = take((long)N * Do);
+    w.zero_floats = off;
+    w.POS = take(NN * Df); w.P1 = take(NN * Df);
     w.AFF = take(NN * G); w.WSM = take(NN * G); w.WD = take(NN * G);
     w.total = off;
     return w;
@@ -149,22 +151,26 @@ extern "C" int echr_tsrm_fwd(const echr_tsrm_args* a, const echr_dropout* drop, 
     const int NN = N * N, dgq = Df / G, dgo = Do / G;
     TsrmWs w = carve(N, Din, Df, Do, G, a->ws);
     echr_gemm_desc d;
+    RC(fill_zero(w.X, w.zero_floats, st));           // X | GATE | Q | K | XW: the split-K products below accumulate into zeros
     // event embedding (:44)
-    d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1;
+    d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1; d.beta = 1.f;
     RC(gemm(d, st));
     // pairwise position features -> per-head gates (:39-41, :108-116)
     RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, st));
     d = desc_nt(w.POS, Df, a->w_fc1, Df, w.P1, Df, NN, Df, Df); d.bias = a->b_fc1; d.act = ECHR_ACT_TANH;
     RC(gemm(d, st));
-    d = desc_nt(w.P1, Df, a->w_fc2, Df, w.GATE, G, NN, G, Df); d.bias = a->b_fc2; d.split_k = -1;
+    d = desc_nt(w.P1, Df, a->w_fc2, Df, w.GATE, G, NN, G, Df); d.bias = a->b_fc2; d.split_k = -1; d.beta = 1.f;
     RC(gemm(d, st));
-    // query / key / (pre-applied) output projection
-    d = desc_nt(w.X, Df, a->w_q, Df, w.Q, Df, N, Df, Df); d.bias = a->b_q; d.split_k = -1;
-    RC(gemm(d, st));
-    d = desc_nt(w.X, Df, a->w_k, Df, w.K, Df, N, Df, Df); d.bias = a->b_k; d.split_k = -1;
-    RC(gemm(d, st));
-    d = desc_nt(w.X, Df, a->w_out, Df, w.XW, Do, N, Do, Df); d.split_k = -1;
-    RC(gemm(d, st));
+    // query / key / (pre-applied) output projection of X: one grouped launch when the three problems have one shape
+    {
+        echr_gemm_desc q3[3];
+        q3[0] = desc_nt(w.X, Df, a->w_q, Df, w.Q, Df, N, Df, Df); q3[0].bias = a->b_q;
+        q3[1] = desc_nt(w.X, Df, a->w_k, Df, w.K, Df, N, Df, Df); q3[1].bias = a->b_k;
+        q3[2] = desc_nt(w.X, Df, a->w_out, Df, w.XW, Do, N, Do, Df);
+        for (int i = 0; i < 3; ++i) { q3[i].split_k = -1; q3[i].beta = 1.f; }
+        if (Do == Df) RC(gemm_grouped(q3, 3, st));
+        else for (int i = 0; i < 3; ++i) RC(gemm(q3[i], st));
+    }
     // per-head scaled affinities AFF[g] = Q_g . K_g^T / sqrt(dgq)   (:138-140)
     d = desc_nt(w.Q, Df, w.K, Df, w.AFF, N, N, N, dgq);
     d.batch = G; d.bsa = dgq; d.bsb = dgq; d.bsc = (long)NN; d.alpha = 1.0f / sqrtf((float)dgq);
@@ -191,7 +197,7 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     echr_gemm_desc d;
     const bool z = g->zeroed != 0;             // gradient buffers pre-zeroed by the caller: accumulate, no fills
     const float zb = z ? 1.f : 0.f;
-    RC(colsum(g->g_out, Do, N, Do, g->g_b_out, z, st));
+    if (!z) RC(colsum(g->g_out, Do, N, Do, g->g_b_out, false, st));
     // dWD_g = dOUT_g . XW_g^T ; dXW_g = WD_g^T . dOUT_g
     d = desc_nt(g->g_out, Do, w.XW, Do, b.DWD, N, N, N, dgo);
     d.batch = G; d.bsa = dgo; d.bsb = dgo; d.bsc = (long)NN;
@@ -209,35 +215,53 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     d = desc_tn(b.DAFF, N, w.Q, Df, b.DK, Df, N, dgq, N);
     d.batch = G; d.bsa = (long)NN; d.bsb = dgq; d.bsc = dgq; d.alpha = scale;
     RC(gemm(d, st));
-    // dX = dQ . Wq + dK . Wk + dXW . Wout
-    d = desc_nn(b.DQ, Df, a->w_q, Df, b.DX, Df, N, Df, Df); d.split_k = -1;
-    RC(gemm(d, st));
-    d = desc_nn(b.DK, Df, a->w_k, Df, b.DX, Df, N, Df, Df); d.beta = 1.f; d.split_k = -1;
-    RC(gemm(d, st));
-    d = desc_nn(b.DXW, Do, a->w_out, Df, b.DX, Df, N, Df, Do); d.beta = 1.f; d.split_k = -1;
-    RC(gemm(d, st));
-    // projection weights
-    d = desc_tn(b.DQ, Df, w.X, Df, g->g_w_q, Df, Df, Df, N); d.beta = zb; d.split_k = -1;
-    RC(gemm(d, st));
-    RC(colsum(b.DQ, Df, N, Df, g->g_b_q, z, st));
-    d = desc_tn(b.DK, Df, w.X, Df, g->g_w_k, Df, Df, Df, N); d.beta = zb; d.split_k = -1;
-    RC(gemm(d, st));
-    RC(colsum(b.DK, Df, N, Df, g->g_b_k, z, st));
-    d = desc_tn(b.DXW, Do, w.X, Df, g->g_w_out, Df, Do, Df, N); d.beta = zb; d.split_k = -1;
-    RC(gemm(d, st));
+    // dX = dQ . Wq + dK . Wk + dXW . Wout: three problems adding into one output -> one grouped launch
+    {
+        echr_gemm_desc x3[3];
+        x3[0] = desc_nn(b.DQ, Df, a->w_q, Df, b.DX, Df, N, Df, Df);
+        x3[1] = desc_nn(b.DK, Df, a->w_k, Df, b.DX, Df, N, Df, Df);
+        x3[2] = desc_nn(b.DXW, Do, a->w_out, Df, b.DX, Df, N, Df, Do);
+        for (int i = 0; i < 3; ++i) x3[i].split_k = -1;
+        if (Do == Df && Df > 32) RC(gemm_grouped(x3, 3, st));
+        else {
+            RC(gemm(x3[0], st));
+            x3[1].beta = 1.f; RC(gemm(x3[1], st));
+            x3[2].beta = 1.f; RC(gemm(x3[2], st));
+        }
+    }
+    // projection weights (three same-shaped products of X^T)
+    {
+        echr_gemm_desc w3[3];
+        w3[0] = desc_tn(b.DQ, Df, w.X, Df, g->g_w_q, Df, Df, Df, N);
+        w3[1] = desc_tn(b.DK, Df, w.X, Df, g->g_w_k, Df, Df, Df, N);
+        w3[2] = desc_tn(b.DXW, Do, w.X, Df, g->g_w_out, Df, Do, Df, N);
+        for (int i = 0; i < 3; ++i) { w3[i].beta = zb; w3[i].split_k = -1; }
+        if (Do == Df) RC(gemm_grouped(w3, 3, st));
+        else for (int i = 0; i < 3; ++i) RC(gemm(w3[i], st));
+    }
     // position MLP
     d = desc_tn(b.DGATE, G, w.P1, Df, g->g_w_fc2, Df, G, Df, NN); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
-    RC(colsum(b.DGATE, G, NN, G, g->g_b_fc2, z, st));
     d = desc_nn(b.DGATE, G, a->w_fc2, Df, b.DP1, Df, NN, Df, G); d.act = ECHR_ACT_MUL_DTANH; d.aux = w.P1; d.ld_aux = Df;
     RC(gemm(d, st));
     d = desc_tn(b.DP1, Df, w.POS, Df, g->g_w_fc1, Df, Df, Df, NN); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
-    RC(colsum(b.DP1, Df, NN, Df, g->g_b_fc1, z, st));
     // event embedding
     d = desc_tn(b.DX, Df, a->ech, Din, g->g_w_emb, Din, Df, Din, N); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
-    RC(colsum(b.DX, Df, N, Df, g->g_b_emb, z, st));
+    // bias gradients: all six column sums in one launch when the gradient buffers accumulate
+    if (z) {
+        const ColsumJob cj[6] = {{g->g_out, Do, N, Do, g->g_b_out, nullptr, nullptr}, {b.DQ, Df, N, Df, g->g_b_q, nullptr, nullptr},
+                                 {b.DK, Df, N, Df, g->g_b_k, nullptr, nullptr},        {b.DGATE, G, NN, G, g->g_b_fc2, nullptr, nullptr},
+                                 {b.DP1, Df, NN, Df, g->g_b_fc1, nullptr, nullptr},    {b.DX, Df, N, Df, g->g_b_emb, nullptr, nullptr}};
+        RC(colsum_multi(cj, 6, st));
+    } else {
+        RC(colsum(b.DQ, Df, N, Df, g->g_b_q, false, st));
+        RC(colsum(b.DK, Df, N, Df, g->g_b_k, false, st));
+        RC(colsum(b.DGATE, G, NN, G, g->g_b_fc2, false, st));
+        RC(colsum(b.DP1, Df, NN, Df, g->g_b_fc1, false, st));
+        RC(colsum(b.DX, Df, N, Df, g->g_b_emb, false, st));
+    }
     if (g->g_ech) {
         d = desc_nn(b.DX, Df, a->w_emb, Din, g->g_ech, Din, N, Din, Df); d.split_k = -1;
         RC(gemm(d, st));
