@@ -29,6 +29,7 @@ class ParamArena(object):
         self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
         self.index = {}
+        self._zeroed = []
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 v = self.flat_p[o:o + p.numel()].view(p.shape)
@@ -69,8 +70,26 @@ class ParamArena(object):
         base = self.flat_p.data_ptr()
         return all(p.data.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
 
-    def zero_unused_grads(self):
-        """Slots whose parameter received no gradient this step must not carry stale values into a flat update."""
-        for p, o in zip(self.params, self.offsets):
-            if p.grad is None:
-                self.flat_g[o:o + p.numel()].zero_()
+    def note_zeroed(self, lo, hi):
+        """A backward Function zero-filled flat_g[lo:hi] this step (GradSink.take)."""
+        self._zeroed.append((lo, hi))
+
+    def zero_unused_grads(self, keep=False):
+        """Slots whose parameter received no gradient this step must not carry stale values into a flat update.  Slots inside a
+        span that a backward Function zero-filled this step are already clean; adjacent remaining slots share one fill.
+        keep=True leaves the record in place for a later call in the same step (gradient all-reduce, then the optimiser)."""
+        todo = []
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if p.grad is not None:
+                continue
+            end = self.offsets[i + 1] if i + 1 < len(self.offsets) else self.total
+            if any(lo <= o and end <= hi for lo, hi in self._zeroed):
+                continue
+            if todo and todo[-1][1] == o:
+                todo[-1][1] = end
+            else:
+                todo.append([o, end])
+        for lo, hi in todo:
+            self.flat_g[lo:hi].zero_()
+        if not keep:
+            self._zeroed = []

@@ -50,6 +50,37 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     for (int i = ty; i < 32; i += 8)
         if (c0 + i < cols && r0 + tx < rows_pad) out[(long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
 }
+struct TransposeArgs { TransposeJob job[TRANSPOSE_MAX_JOBS]; int start[TRANSPOSE_MAX_JOBS + 1]; int njobs; };
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeArgs a) {
+    __shared__ float t[32][33];
+    int ji = 0;
+    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.start[ji + 1]) ++ji;
+    const TransposeJob J = a.job[ji];
+    const int ci = (int)blockIdx.x - a.start[ji], ct = (J.cols + 31) / 32;
+    const int r0 = (ci / ct) * 32, c0 = (ci % ct) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        t[i][tx] = (r0 + i < J.rows && c0 + tx < J.cols) ? J.in[(long)(r0 + i) * J.ld_in + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < J.cols && r0 + tx < J.rows) J.out[(long)(c0 + i) * J.ld_out + r0 + tx] = t[tx][i];
+}
+// several out[c, r] = in[r, c] problems in one launch
+int transpose_multi(const TransposeJob* jobs, int n, hipStream_t st) {
+    ECHR_REQUIRE(jobs && n >= 1 && n <= TRANSPOSE_MAX_JOBS, "transpose_multi: 1..%d jobs", TRANSPOSE_MAX_JOBS);
+    TransposeArgs a;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        a.job[i] = jobs[i];
+        a.start[i] = total;
+        total += ((jobs[i].cols + 31) / 32) * ((jobs[i].rows + 31) / 32);
+    }
+    for (int i = n; i < TRANSPOSE_MAX_JOBS; ++i) a.job[i] = jobs[0];
+    for (int i = n; i <= TRANSPOSE_MAX_JOBS; ++i) a.start[i] = total;
+    a.njobs = n;
+    hipLaunchKernelGGL(transpose_multi_kernel, dim3(total), dim3(256), 0, st, a);
+    return check_launch("transpose_multi");
+}
 int transpose(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, int rows_pad, hipStream_t st) {
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows_pad + 31) / 32), dim3(256), 0, st, in, ld_in, out, ld_out, rows, cols,
                        rows_pad);
@@ -137,6 +168,36 @@ int fill_zero(float* p, long n, hipStream_t st) {
     int grid = (int)min((n + 255) / 256, 2048L);
     hipLaunchKernelGGL(fill_zero_kernel, dim3(grid), dim3(256), 0, st, p, n);
     return check_launch("fill_zero");
+}
+
+// several ranges zeroed by one launch (each workgroup owns 4096 floats of one range)
+struct FillArgs { float* p[FILL_MAX_JOBS]; long n[FILL_MAX_JOBS]; int start[FILL_MAX_JOBS + 1]; int njobs; };
+__global__ __launch_bounds__(256) void fill_zero_multi_kernel(FillArgs a) {
+    int ji = 0;
+    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.start[ji + 1]) ++ji;
+    float* p = a.p[ji];
+    const long n = a.n[ji];
+    const long base = (long)((int)blockIdx.x - a.start[ji]) * 4096;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const long k = base + i * 256 + threadIdx.x;
+        if (k < n) p[k] = 0.f;
+    }
+}
+int fill_zero_multi(float* const* ptrs, const long* counts, int n, hipStream_t st) {
+    ECHR_REQUIRE(ptrs && counts && n >= 1 && n <= FILL_MAX_JOBS, "fill_zero_multi: 1..%d ranges", FILL_MAX_JOBS);
+    FillArgs a;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        a.p[i] = ptrs[i]; a.n[i] = counts[i]; a.start[i] = total;
+        total += (int)((counts[i] + 4095) / 4096);
+    }
+    for (int i = n; i < FILL_MAX_JOBS; ++i) { a.p[i] = ptrs[0]; a.n[i] = 0; }
+    for (int i = n; i <= FILL_MAX_JOBS; ++i) a.start[i] = total;
+    a.njobs = n;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(fill_zero_multi_kernel, dim3(total), dim3(256), 0, st, a);
+    return check_launch("fill_zero_multi");
 }
 
 // one lane per column (coalesced 256 B per wave-row), 4 waves stride the rows of one 256-row chunk, LDS combine;

@@ -758,7 +758,7 @@ static RecJob mkjob(const float* A, long lda, int K, const float* B, long ldb, i
 
 // P_all = c3d . W_c^T + b_c over the Tv video rows; EVB0 = event . W_ih0[:,E:]^T + b_ih0 + b_hh0;
 // VIDB = W_ih2[:,E:] . video + b_ih2 + b_hh2   (all time-invariant)
-static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t st, bool teacher_forced) {
+static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t st, bool teacher_forced, bool evb0_zeroed = false) {
     const int H = a->H, E = a->E;
     echr_gemm_desc d;
     if (config().gemm_h2) {
@@ -776,6 +776,7 @@ static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t
     RC(gemm(d, st));
     d = desc_nt(a->event, a->De, a->w_ih[0] + E, E + a->De, w.EVB0, 4 * H, a->N, 4 * H, a->De);
     d.bias = a->b_ih[0]; d.bias2 = a->b_hh[0]; d.split_k = -1;
+    if (evb0_zeroed) d.beta = 1.f;            // accumulate into the caller's zeros: no fill launch
     RC(gemm(d, st));
     d = desc_nt(a->video, a->Dv, a->w_ih[2] + E, E + a->Dv, w.VIDB, 4 * H, 1, 4 * H, a->Dv);
     d.bias = a->b_ih[2]; d.bias2 = a->b_hh[2];
@@ -879,10 +880,12 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
     const int N = a->N, S = a->S, H = a->H, E = a->E;
     DecWs w = carve_ws(a, a->ws);
     const DropCfg dh = make_drop(drop, drop ? drop->p_h : 0.f), dout = make_drop(drop, drop ? drop->p_out : 0.f);
-    RC(fill_zero(w.HS, (long)N * 3 * H, st));                       // h(-1) = 0   (init_hidden, :75-78)
-    RC(fill_zero_2d(w.CS[0], 3, N * H, w.CS[1] - w.CS[0], st));     // c(-1) = 0 for the three streams (equally spaced carve-outs)
-    RC(fill_zero(w.QACC, (long)S * N * a->Ha, st));
-    RC(precompute_static(a, w, st, true));
+    {   // h(-1) = c(-1) = 0 (init_hidden, :75-78), the atomic q accumulators and the split-K target EVB0: one launch
+        float* zp[6] = {w.HS, w.CS[0], w.CS[1], w.CS[2], w.QACC, w.EVB0};
+        const long zn[6] = {(long)N * 3 * H, (long)N * H, (long)N * H, (long)N * H, (long)S * N * a->Ha, (long)N * 4 * H};
+        RC(fill_zero_multi(zp, zn, 6, st));
+    }
+    RC(precompute_static(a, w, st, true, true));
     RC(embed_gather(a->embed, a->tokens, w.XT, S * N, E, a->V1, st));
     RC(input_gates(a, w, w.XT, 0, S, st));
     // late fusion: logits = OUTD . W_logit^T + b, written [N,S,V1], then row log-softmax in place.  Timesteps [0,th) are
@@ -940,6 +943,19 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     // 1. d logits (time-major, padded leading dimension)
     if (!g->g_logp) RC(colsum(g->nll_mask, 1, N * S, 1, b.MSUM, false, st));
     RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_mask, g->g_loss, b.MSUM, b.DLG, b.ldg, N, S, V1, st));
+    // scratch that is accumulated into, and the transposed recurrent weights (every d h / d ATT product of the reverse recurrence
+    // then has the same NT form as forward): two launches, independent of everything above
+    {
+        const TransposeJob tj[5] = {{a->w_hh[0], H, b.WT_HH[0], 4 * H, 4 * H, H}, {a->w_hh[1], H, b.WT_HH[1], 4 * H, 4 * H, H},
+                                    {a->w_hh[2], H, b.WT_HH[2], 4 * H, 4 * H, H}, {a->w_ih[1] + E, cin[1], b.WT_ATT, 4 * H, 4 * H, D},
+                                    {a->w_h2a, H, b.WT_H2A, Ha, Ha, H}};
+        RC(transpose_multi(tj, 5, st));
+    }
+    {   // DC | DGCOL | DQ | DASL | DPALL, and the split-K / accumulated outputs DXT, g_event and DOUT: one launch
+        float* zp[4] = {b.DC, b.DXT, g->g_event, b.DOUT};
+        const long zn[4] = {b.zero_floats, (long)SN * E, (long)N * a->De, (long)SN * 3 * H};
+        RC(fill_zero_multi(zp, zn, 4, st));
+    }
     // 2. late fusion gradients: the weight/bias gradients do not feed the recurrence -> side stream
     const bool ov = overlap_enabled() && S >= 4;
     hipStream_t sq = ov ? side().s : st;
@@ -958,6 +974,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         RC(gemm(d, st));
         RC(colsum(b.DLG, b.ldg, SN, V1, g->g_b_logit, z, st));
         d = desc_h2(b.PK_DLG, b.PK_WLT, b.DOUT, 3 * H, SN, 3 * H, V1);
+        d.beta = 1.f;                          // DOUT was zeroed above: the k slices add atomically, no fill launch
         RC(gemm(d, st));
     } else {
     RC(transpose(b.DLG, b.ldg, b.DLGT, b.snp, SN, V1, (int)b.snp, sq));
@@ -968,14 +985,10 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     RC(colsum(b.DLG, b.ldg, SN, V1, g->g_b_logit, z, sq));
     RC(transpose(a->w_logit, 3 * H, b.WLT, b.ldg, V1, 3 * H, (int)b.ldg, st));
     d = desc_nt(b.DLG, b.ldg, b.WLT, b.ldg, b.DOUT, 3 * H, SN, 3 * H, (int)b.ldg);
-    d.split_k = -1; d.algo = ECHR_GEMM_BF16X3;
+    d.split_k = -1; d.algo = ECHR_GEMM_BF16X3; d.beta = 1.f;
     RC(gemm(d, st));
     }
-    // 3. reverse recurrence.  Transposed weights turn every d h / d ATT product into the same NT form as forward.
-    for (int k = 0; k < 3; ++k) RC(transpose(a->w_hh[k], H, b.WT_HH[k], 4 * H, 4 * H, H, 4 * H, st));
-    RC(transpose(a->w_ih[1] + E, cin[1], b.WT_ATT, 4 * H, 4 * H, D, 4 * H, st));
-    RC(transpose(a->w_h2a, H, b.WT_H2A, Ha, Ha, H, Ha, st));
-    RC(fill_zero(b.DC, b.zero_floats, st));                   // DC | DQ | DASL | DPALL
+    // 3. reverse recurrence
     const long hs = (long)N * H, as = (long)N * D;
     const int n4h = ksplit_of(4 * H);
     // weight gradients that are sums over timesteps [t0,t1): W_hh_k, W_ih_k[:, :E], W_ih1[:, E:], W_h2a.
@@ -1134,7 +1147,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
     d = desc_nn(b.DGSUM[0], 4 * H, a->w_ih[0] + E, cin[0], g->g_event, a->De, N, a->De, 4 * H);
-    d.split_k = -1;
+    d.split_k = -1; d.beta = 1.f;                                // zeroed with the backward scratch above
     RC(gemm(d, st));
     d = desc_tn(b.DGCOL[2], 4 * H, a->video, a->Dv, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, 1);
     RC(gemm(d, st));
@@ -1156,7 +1169,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         }
         for (int k = 0; k < 3; ++k) {
             gx[k] = h2 ? desc_h2(b.PK_DG[k], b.PK_WIHT[k], b.DXT, E, SN, E, 4 * H) : desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], b.DXT, E, SN, E, 4 * H);
-            gx[k].split_k = -1;                                  // shared output: zero-filled once, k-slices of all three add atomically
+            gx[k].split_k = -1; gx[k].beta = 1.f;                // shared output (zeroed with the backward scratch): k-slices of all three add atomically
         }
         RC(gemm_grouped(gx, 3, st));
     }

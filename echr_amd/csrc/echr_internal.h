@@ -78,6 +78,11 @@ int colsum_multi(const ColsumJob* jobs, int n, hipStream_t st);
 int sum_over_time(const float* X, long ld, int S, int N, int cols, float* out, long ld_out, hipStream_t st);
 int fill_zero(float* p, long n, hipStream_t st);
 int fill_zero_2d(float* p, int rows, int cols, long ld, hipStream_t st);
+constexpr int FILL_MAX_JOBS = 8;
+int fill_zero_multi(float* const* ptrs, const long* counts, int n, hipStream_t st);     // several ranges, one launch
+constexpr int TRANSPOSE_MAX_JOBS = 8;
+struct TransposeJob { const float* in; long ld_in; float* out; long ld_out; int rows, cols; };
+int transpose_multi(const TransposeJob* jobs, int n, hipStream_t st);                    // several out[c,r] = in[r,c], one launch
 // out[c, r] = in[r, c] for r < rows, c < cols; rows..rows_pad-1 of the output's row are zero-filled (k padding)
 int transpose(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, int rows_pad, hipStream_t st);
 int embed_gather(const float* W, const int* tok, float* out, int rows, int E, int V1, hipStream_t st);

@@ -198,6 +198,11 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     const bool z = g->zeroed != 0;             // gradient buffers pre-zeroed by the caller: accumulate, no fills
     const float zb = z ? 1.f : 0.f;
     if (!z) RC(colsum(g->g_out, Do, N, Do, g->g_b_out, false, st));
+    {   // accumulated (split-K) outputs zeroed by one launch: dX and, when requested, d ech
+        float* zp[2] = {b.DX, g->g_ech};
+        const long zn[2] = {(long)N * Df, (long)N * Din};
+        RC(fill_zero_multi(zp, zn, g->g_ech ? 2 : 1, st));
+    }
     // dWD_g = dOUT_g . XW_g^T ; dXW_g = WD_g^T . dOUT_g
     d = desc_nt(g->g_out, Do, w.XW, Do, b.DWD, N, N, N, dgo);
     d.batch = G; d.bsa = dgo; d.bsb = dgo; d.bsc = (long)NN;
@@ -221,13 +226,9 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
         x3[0] = desc_nn(b.DQ, Df, a->w_q, Df, b.DX, Df, N, Df, Df);
         x3[1] = desc_nn(b.DK, Df, a->w_k, Df, b.DX, Df, N, Df, Df);
         x3[2] = desc_nn(b.DXW, Do, a->w_out, Df, b.DX, Df, N, Df, Do);
-        for (int i = 0; i < 3; ++i) x3[i].split_k = -1;
+        for (int i = 0; i < 3; ++i) { x3[i].split_k = -1; x3[i].beta = 1.f; }      // dX zeroed above
         if (Do == Df && Df > 32) RC(gemm_grouped(x3, 3, st));
-        else {
-            RC(gemm(x3[0], st));
-            x3[1].beta = 1.f; RC(gemm(x3[1], st));
-            x3[2].beta = 1.f; RC(gemm(x3[2], st));
-        }
+        else for (int i = 0; i < 3; ++i) RC(gemm(x3[i], st));
     }
     // projection weights (three same-shaped products of X^T)
     {
@@ -263,7 +264,7 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
         RC(colsum(b.DX, Df, N, Df, g->g_b_emb, false, st));
     }
     if (g->g_ech) {
-        d = desc_nn(b.DX, Df, a->w_emb, Din, g->g_ech, Din, N, Din, Df); d.split_k = -1;
+        d = desc_nn(b.DX, Df, a->w_emb, Din, g->g_ech, Din, N, Din, Df); d.split_k = -1; d.beta = 1.f;
         RC(gemm(d, st));
     }
     return 0;

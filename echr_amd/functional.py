@@ -70,6 +70,7 @@ class GradSink(object):
     def take(self):
         lo, hi = self.arena.span(self.slots)
         self.arena.flat_g[lo:hi].zero_()
+        self.arena.note_zeroed(lo, hi)
         return [self.arena.grad_view(s) for s in self.slots]
 
 

@@ -23,7 +23,7 @@ def allreduce_gradients(module, group=None, bucket_bytes=64 << 20, force=False):
     arena = getattr(module, '_echr_arena', None)
     if arena is not None and arena.grads_in_arena():
         # the flat gradient buffer IS the bucket: one collective, no pack/unpack copies
-        arena.zero_unused_grads()
+        arena.zero_unused_grads(keep=True)
         dist.all_reduce(arena.flat_g, op=dist.ReduceOp.SUM, group=group)
         return 1
     params = live_grads(module)
