@@ -202,16 +202,24 @@ int fill_zero_multi(float* const* ptrs, const long* counts, int n, hipStream_t s
 
 // one lane per column (coalesced 256 B per wave-row), 4 waves stride the rows of one 256-row chunk, LDS combine;
 // several row chunks (grid.y) add their partial sums atomically into the zero-initialised output.
-constexpr int CS_ROWS = 256;
+constexpr int CS_ROWS = 128;
+// column sum of rows [r0, r1) with stride 4 starting at r0 + wave: four independent loads in flight per lane
+__device__ __forceinline__ float colsum_rows(const float* __restrict__ X, long ld, int col, int r0, int r1, int wave) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {
+        s0 += X[(long)r * ld + col]; s1 += X[(long)(r + 4) * ld + col]; s2 += X[(long)(r + 8) * ld + col]; s3 += X[(long)(r + 12) * ld + col];
+    }
+    for (; r < r1; r += 4) s0 += X[(long)r * ld + col];
+    return (s0 + s1) + (s2 + s3);
+}
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, int rows, int cols,
                                                      float* __restrict__ out, float* __restrict__ out2, int mode) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
-    float s = 0.f;
-    if (col < cols)
-        for (int r = r0 + wave; r < r1; r += 4) s += X[(long)r * ld + col];
+    const float s = col < cols ? colsum_rows(X, ld, col, r0, r1, wave) : 0.f;
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && col < cols) {
@@ -247,9 +255,7 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = (ci % ctiles) * 64 + lane;
     const int r0 = (ci / ctiles) * CS_ROWS, r1 = min(J.rows, r0 + CS_ROWS);
-    float s = 0.f;
-    if (col < J.cols)
-        for (int r = r0 + wave; r < r1; r += 4) s += J.X[(long)r * J.ld + col];
+    const float s = col < J.cols ? colsum_rows(J.X, J.ld, col, r0, r1, wave) : 0.f;
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && col < J.cols) {
@@ -329,8 +335,36 @@ __global__ __launch_bounds__(256) void logsoftmax_rows_kernel(float* __restrict_
     const float lse = m + logf(s);
     for (int j = threadIdx.x; j < cols; j += 256) x[j] = x[j] - lse;
 }
+// same arithmetic with the row held in registers (one read, one write): rows of up to 256 * EPT columns
+template <int EPT>
+__global__ __launch_bounds__(256) void logsoftmax_rows_reg_kernel(float* __restrict__ X, long ld, int S, int t0, int nt, int cols) {
+    __shared__ float red[4];
+    float* x = X + ((long)(blockIdx.x / nt) * S + t0 + blockIdx.x % nt) * ld;
+    float v[EPT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int j = threadIdx.x + i * 256;
+        v[i] = j < cols ? x[j] : -INFINITY;
+        m = fmaxf(m, v[i]);
+    }
+    m = block_max(m, red);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) s += (threadIdx.x + i * 256 < cols) ? expf(v[i] - m) : 0.f;
+    s = block_sum(s, red);
+    const float lse = m + logf(s);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int j = threadIdx.x + i * 256;
+        if (j < cols) x[j] = v[i] - lse;
+    }
+}
 int logsoftmax_rows(float* X, long ld, int N, int S, int t0, int nt, int cols, hipStream_t st) {
-    hipLaunchKernelGGL(logsoftmax_rows_kernel, dim3(N * nt), dim3(256), 0, st, X, ld, S, t0, nt, cols);
+    if (cols <= 256 * 8) hipLaunchKernelGGL(logsoftmax_rows_reg_kernel<8>, dim3(N * nt), dim3(256), 0, st, X, ld, S, t0, nt, cols);
+    else if (cols <= 256 * 20) hipLaunchKernelGGL(logsoftmax_rows_reg_kernel<20>, dim3(N * nt), dim3(256), 0, st, X, ld, S, t0, nt, cols);
+    else if (cols <= 256 * 40) hipLaunchKernelGGL(logsoftmax_rows_reg_kernel<40>, dim3(N * nt), dim3(256), 0, st, X, ld, S, t0, nt, cols);
+    else hipLaunchKernelGGL(logsoftmax_rows_kernel, dim3(N * nt), dim3(256), 0, st, X, ld, S, t0, nt, cols);
     return check_launch("logsoftmax_rows");
 }
 
@@ -394,42 +428,47 @@ __global__ __launch_bounds__(256) void nll_loss_bwd_kernel(const int* __restrict
 }
 
 // ---- event pooling + anchor gather (CaptionGenerator.py:111-114,121,128) -----------------------------
+// grid (N, ceil(D/64)): a workgroup pools one event over one 64-column chunk -- 16 float4 lanes across the columns (256-byte row
+// segments), 16 row groups across the other threads (eight or so independent loads in flight per thread), LDS combine.
 __global__ __launch_bounds__(256) void event_pool_gather_kernel(const float* __restrict__ c3d, const float* __restrict__ tap,
                                                                 const int* __restrict__ ev_start, const int* __restrict__ ev_len,
                                                                 const int* __restrict__ ind, float* __restrict__ ech, int D, int Ht, int vec) {
-    extern __shared__ __attribute__((aligned(16))) float red[];            // [groups][D]
-    const int n = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) float red[16][64];
+    const int n = blockIdx.x, c0 = blockIdx.y * 64;
     const int s = ev_start[n], len = ev_len[n];
     float* o = ech + (long)n * (D + Ht);
-    const int C4 = D >> 2;
-    if (vec && C4 <= 256) {
-        // float4 lanes across the feature axis (coalesced rows), row groups across the remaining threads, LDS combine
-        const int groups = 256 / C4;
-        const int c = threadIdx.x % C4, rg = threadIdx.x / C4;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rg < groups) {
-            for (int a = rg; a < len; a += groups) {
-                const float4 v = *reinterpret_cast<const float4*>(c3d + (long)(s + a) * D + 4 * c);
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int col = c0 + 4 * c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec) {
+        if (col < D) {
+#pragma unroll 4
+            for (int a = rg; a < len; a += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(c3d + (long)(s + a) * D + col);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
-            *reinterpret_cast<float4*>(red + (long)rg * D + 4 * c) = acc;
-        }
-        __syncthreads();
-        const float inv = 1.0f / (float)len;
-        for (int j = threadIdx.x; j < D; j += 256) {
-            float t = 0.f;
-            for (int g = 0; g < groups; ++g) t += red[(long)g * D + j];
-            o[j] = t * inv;
         }
     } else {
-        for (int j = threadIdx.x; j < D; j += 256) {
-            float acc = 0.f;
-            for (int a = 0; a < len; ++a) acc += c3d[(long)(s + a) * D + j];
-            o[j] = acc / (float)len;
+        for (int a = rg; a < len; a += 16) {
+            const float* r = c3d + (long)(s + a) * D + col;
+            if (col < D) acc.x += r[0];
+            if (col + 1 < D) acc.y += r[1];
+            if (col + 2 < D) acc.z += r[2];
+            if (col + 3 < D) acc.w += r[3];
         }
     }
+    *reinterpret_cast<float4*>(&red[rg][4 * c]) = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 && c0 + (int)threadIdx.x < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+        o[c0 + threadIdx.x] = t / (float)len;
+    }
+    // the anchor's SST state: the chunks share the Ht columns
     const long trow = ind[n];
-    for (int j = threadIdx.x; j < Ht; j += 256) o[D + j] = tap[trow * Ht + j];
+    const int per = (Ht + gridDim.y - 1) / gridDim.y, j0 = blockIdx.y * per;
+    for (int j = j0 + threadIdx.x; j < min(Ht, j0 + per); j += 256) o[D + j] = tap[trow * Ht + j];
 }
 __global__ void event_gather_bwd_kernel(const float* __restrict__ d_ech, const int* __restrict__ ind, float* __restrict__ d_tap,
                                         int D, int Ht) {
@@ -544,9 +583,8 @@ extern "C" int echr_event_pool_gather_fwd(const float* c3d, const float* tap, co
                                           const int32_t* ind, float* ech, int32_t N, int32_t D, int32_t Ht, void* stream) {
     ECHR_REQUIRE(c3d && tap && ev_start && ev_len && ind && ech && N > 0 && D > 0 && Ht > 0, "event_pool_gather_fwd: bad arguments");
     const int vec = (D % 4 == 0) && ((uintptr_t)c3d % 16 == 0) && D >= 4;
-    const int groups = vec && D / 4 <= 256 ? 256 / (D / 4) : 1;
-    hipLaunchKernelGGL(event_pool_gather_kernel, dim3(N), dim3(256), (size_t)groups * D * sizeof(float), (hipStream_t)stream, c3d, tap,
-                       ev_start, ev_len, ind, ech, D, Ht, vec);
+    hipLaunchKernelGGL(event_pool_gather_kernel, dim3(N, (D + 63) / 64), dim3(256), 0, (hipStream_t)stream, c3d, tap, ev_start, ev_len, ind, ech, D,
+                       Ht, vec);
     return check_launch("event_pool_gather_fwd");
 }
 extern "C" int echr_event_pool_gather_bwd(const float* d_ech, const int32_t* ind, float* d_tap, int32_t N, int32_t D, int32_t Ht,

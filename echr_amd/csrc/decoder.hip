@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ 
 // Post-recurrence pass: d P_all[row,:] += sum_t dsc_t * alpha * (1 - tanh^2(P_row + q_t)),
 //                       d alpha      += sum_{t,n,a} dsc_t * tanh(P_row + q_t),  d b_alpha += sum dsc.
 // grid (N, ceil(A/8)): 4 waves x 2 slots; q_t[n,:] for a tile of TT timesteps is staged in LDS (4 workgroups per CU).
-constexpr int TT = 20;
+constexpr int TT = 10;
 constexpr int PSLOTS = 2;
 template <int R>
 __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__ PALL, const float* __restrict__ QS,
