@@ -608,6 +608,7 @@ struct LstmBwdPtrs {
     const float* c_new[3];
     float* dgates[3];         // [N,4H] slice of timestep t
     const float* dh_slab[3];  // partial sums of d h(t) from step t+1: [N,H] slabs
+    float* dh_acc[3];         // or (accumulate mode) ONE [N,H] buffer per stream that step t+1 added into atomically: read, then re-zeroed
     int nslab[3];
     long slab_stride;
     int kmap[3];
@@ -622,6 +623,7 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdPtrs P, 
     const int n = idx / H, j = idx % H;
     const long o = (long)n * 3 * H + k * H + j;
     float dhv = doutd[o] * drop_mult(dout, (unsigned)o, (unsigned)t, SITE_OUT);
+    if (P.dh_acc[k]) { dhv += P.dh_acc[k][idx]; P.dh_acc[k][idx] = 0.f; }
     for (int s = 0; s < P.nslab[k]; ++s) dhv += P.dh_slab[k][s * P.slab_stride + idx];
     dhv *= drop_mult(dh, (unsigned)idx, (unsigned)t, (unsigned)(SITE_H0 + k));
     const float* g = P.gates[k] + (long)n * 4 * H;
@@ -689,7 +691,7 @@ struct DecWsBwd {
     // h2-packed operands of the backward GEMMs (suffix T: packed from the transposed view, i.e. contraction over rows of the source)
     float *PK_DLGT, *PK_OUTDT, *PK_DLG, *PK_WLT, *PK_DGT[3], *PK_DG[3], *PK_HT[3], *PK_XTT, *PK_ATTT, *PK_DQT, *PK_WIHT[3], *PK_DPT, *PK_C3DT;
     long snp;
-    float *DHSL[3], *DASL;                   // split-K slabs: d h(t-1) per stream; DASL: [S,N,D] atomic accumulation target of d ATT
+    float *DHACC[3], *DASL;                  // atomic accumulation targets: d h(t-1) per stream [N,H]; DASL: d ATT [S,N,D]
     int ndh[3], nda;
     long ldg, total, zero_floats;
 };
@@ -703,9 +705,10 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     w.DOUT = take(S * N * 3 * H);
     for (int k = 0; k < 3; ++k) w.DG[k] = take(S * N * 4 * H);
     w.DSC = take(S * N * a->A);
-    // one contiguous zero-initialised region: DC | DGCOL | DQ | DASL | DPALL (a single fill per backward)
+    // one contiguous zero-initialised region: DC | DGCOL | DHACC | DQ | DASL | DPALL (a single fill per backward)
     w.DC = take(N * 3 * H);
     for (int k = 0; k < 3; ++k) w.DGCOL[k] = take(4 * H);
+    for (int k = 0; k < 3; ++k) w.DHACC[k] = take(N * H);
     w.DQ = take(S * N * a->Ha);
     w.DASL = take(S * N * a->D);
     w.DPALL = take((long)a->Tv * a->Ha);
@@ -723,7 +726,6 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     w.ndh[0] = w.ndh[2] = ksplit_of(4 * a->H);
     w.ndh[1] = ksplit_of(4 * a->H) + ksplit_of(a->Ha);
     w.nda = ksplit_of(4 * a->H);
-    for (int k = 0; k < 3; ++k) w.DHSL[k] = take((long)w.ndh[k] * N * H);
     const int SN = (int)(S * N), H4 = 4 * a->H;
     w.PK_DLGT = take(h2_floats(a->V1, SN)); w.PK_OUTDT = take(h2_floats(3 * a->H, SN));
     w.PK_DLG = take(h2_floats(SN, a->V1)); w.PK_WLT = take(h2_floats(3 * a->H, a->V1));
@@ -804,8 +806,13 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
     // letting each of them sum the k-slice slabs; the sampler keeps the slab form (bitwise reproducible decoding)
     float* qacc = q_atomic ? w.QACC + (long)t * N * Ha : w.QSL;
     if (do1) ra.job[ra.njobs++] = mkjob(hprev + H, 3 * H, H, a->w_h2a, H, Ha, qacc, qs, Ha, q_atomic ? 1 : 0);
+    // training path: the recurrent products add atomically into GATES[k][t], which already holds the input-side pre-activations,
+    // so the gate kernel reads one value per gate instead of summing 4..8 slabs (the sampler keeps the reproducible slab form)
+    const bool gacc = q_atomic;
     for (int k = 0; k < 3; ++k)
-        if (k == 1 ? do1 : do02) ra.job[ra.njobs++] = mkjob(hprev + k * H, 3 * H, H, a->w_hh[k], H, 4 * H, w.GSL[k], gs, 4 * H);
+        if (k == 1 ? do1 : do02)
+            ra.job[ra.njobs++] = gacc ? mkjob(hprev + k * H, 3 * H, H, a->w_hh[k], H, 4 * H, w.GATES[k] + (long)t * gs, gs, 4 * H, 1)
+                                      : mkjob(hprev + k * H, 3 * H, H, a->w_hh[k], H, 4 * H, w.GSL[k], gs, 4 * H);
     RC(rec_gemm(ra, st));
     if (do1) {
         float* q = w.QS + (long)t * N * Ha;
@@ -823,7 +830,8 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
         RC(check_launch("att_context"));
         }
         ra.njobs = 1;
-        ra.job[0] = mkjob(att, D, D, a->w_ih[1] + E, E + D, 4 * H, w.GSL[1] + nh * gs, gs, 4 * H);
+        ra.job[0] = gacc ? mkjob(att, D, D, a->w_ih[1] + E, E + D, 4 * H, w.GATES[1] + (long)t * gs, gs, 4 * H, 1)
+                         : mkjob(att, D, D, a->w_ih[1] + E, E + D, 4 * H, w.GSL[1] + nh * gs, gs, 4 * H);
         RC(rec_gemm(ra, st));
     }
     LstmPtrs P;
@@ -831,7 +839,7 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
     for (int k = 0; k < 3; ++k) {
         P.gates[k] = w.GATES[k] + (long)t * N * 4 * H;
         P.slab[k] = w.GSL[k];
-        P.nslab[k] = w.ng[k];
+        P.nslab[k] = gacc ? 0 : w.ng[k];
         P.c_prev[k] = w.CS[k] + (long)t * N * H;
         P.c_new[k] = w.CS[k] + (long)(t + 1) * N * H;
         P.kmap[k] = 0;
@@ -990,7 +998,6 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     }
     // 3. reverse recurrence
     const long hs = (long)N * H, as = (long)N * D;
-    const int n4h = ksplit_of(4 * H);
     // weight gradients that are sums over timesteps [t0,t1): W_hh_k, W_ih_k[:, :E], W_ih1[:, E:], W_h2a.
     // beta = 0 writes, beta = 1 accumulates.  HS[t] holds h(t-1), so rows t*N.. pair with DG[t].
     auto wgrad_chunk = [&](int t0, int t1, float beta, hipStream_t q) -> int {
@@ -1051,8 +1058,9 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
             P.c_prev[k] = w.CS[k] + (long)t * N * H;
             P.c_new[k] = w.CS[k] + (long)(t + 1) * N * H;
             P.dgates[k] = b.DG[k] + (long)t * N * 4 * H;
-            P.dh_slab[k] = b.DHSL[k];
-            P.nslab[k] = (t == S - 1) ? 0 : b.ndh[k];           // slabs hold d h(t), written while processing step t+1
+            P.dh_slab[k] = nullptr;
+            P.dh_acc[k] = b.DHACC[k];                           // d h(t), added atomically while processing step t+1 (zero at t = S-1)
+            P.nslab[k] = 0;
             P.kmap[k] = 0;
             if (k == 1 ? do1 : do02) P.kmap[nk++] = k;
         }
@@ -1067,7 +1075,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         if (do1) ra.job[ra.njobs++] = mkjob(P.dgates[1], 4 * H, 4 * H, b.WT_ATT, 4 * H, D, datt, as, D, 1);
         if (t > 0)
             for (int k = 0; k < 3; ++k)
-                if (k == 1 ? do1 : do02) ra.job[ra.njobs++] = mkjob(P.dgates[k], 4 * H, 4 * H, b.WT_HH[k], 4 * H, H, b.DHSL[k], hs, H);
+                if (k == 1 ? do1 : do02) ra.job[ra.njobs++] = mkjob(P.dgates[k], 4 * H, 4 * H, b.WT_HH[k], 4 * H, H, b.DHACC[k], hs, H, 1);
         if (ra.njobs > 0) RC(rec_gemm(ra, q));
         if (!do1) return 0;
         // attention backward (needed at every t: feeds d P_all, d alpha, d W_h)
@@ -1080,7 +1088,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         }
         if (t > 0) {   // d h1(t-1) += dq . W_h : extra slabs behind stream 1's W_hh slabs
             ra.njobs = 1;
-            ra.job[0] = mkjob(dq, Ha, Ha, b.WT_H2A, Ha, H, b.DHSL[1] + n4h * hs, hs, H);
+            ra.job[0] = mkjob(dq, Ha, Ha, b.WT_H2A, Ha, H, b.DHACC[1], hs, H, 1);
             RC(rec_gemm(ra, q));
         }
         return 0;
