@@ -7,7 +7,7 @@ namespace echr {
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 // Disabled by default: ProfScope is then a no-op.  Events are resolved in echr_prof_read after a stream sync.
-enum ProfKind { PROF_GEMM = 0, PROF_ATT_FWD = 1, PROF_ATT_BWD = 2, PROF_ATT_POST = 3, PROF_LSTM = 4, PROF_OTHER = 5, PROF_GEMM_SPLIT = 6, PROF_KINDS = 7 };
+enum ProfKind { PROF_GEMM = 0, PROF_ATT_FWD = 1, PROF_ATT_BWD = 2, PROF_ATT_POST = 3, PROF_LSTM = 4, PROF_OTHER = 5, PROF_GEMM_SPLIT = 6, PROF_GEMM_H2 = 7, PROF_PACK = 8, PROF_KINDS = 9 };
 struct ProfScope {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t st;

@@ -710,7 +710,7 @@ int h2_pack_multi(const H2PackJob* jobs, int n, hipStream_t st) {
     a.start[n] = total;
     for (int i = n; i < H2_MAX_JOBS; ++i) { a.job[i] = a.job[0]; a.start[i + 1] = total; }
     a.njobs = n;
-    ProfScope prof(PROF_OTHER, 0.0, bytes, st);
+    ProfScope prof(PROF_PACK, 0.0, bytes, st);
     hipLaunchKernelGGL(h2_pack_kernel, dim3(total), dim3(256), 0, st, a);
     return check_launch("h2_pack");
 }
@@ -853,7 +853,7 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     if (log_on) fprintf(stderr, "[gemm] M=%d N=%d K=%d batch=%d %s%s tile=%dx%d split=%d algo=%s wgs=%d\n", d.M, d.N, d.K, d.batch, akc ? "N" : "T",
                         bkc ? "T" : "N", BMs, BNs, split, h2 ? "h2" : use_split ? "bf16x3" : "f32", (int)(grid.x * grid.z));
     // algorithmic work of this launch: 2MNK flops; one read of A and B, one write of C
-    ProfScope prof((use_split || h2) ? PROF_GEMM_SPLIT : PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch * ng, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch * ng, st);
+    ProfScope prof(h2 ? PROF_GEMM_H2 : use_split ? PROF_GEMM_SPLIT : PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch * ng, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch * ng, st);
     if (h2) {
         // XCD rectangles: xm x xn = 8, least padded tiles first, then fewest panels per XCD
         int best = -1; long best_cost = 0;

@@ -285,7 +285,7 @@ int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int
 /* ------------------------------------------------------------------------------------------------
  * Optional per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
  * class) for bench.py's roofline leg.  kind: 0 fp32 MFMA GEMM, 1 attention fwd, 2 attention bwd,
- * 3 attention post-pass, 4 recurrent grouped GEMM, 5 other, 6 bf16x3-split GEMM.  echr_prof_read synchronises the recorded events and
+ * 3 attention post-pass, 4 recurrent grouped GEMM, 5 other, 6 bf16x3-split GEMM, 7 h2 (fp16-pair) GEMM, 8 h2 operand packing.  echr_prof_read synchronises the recorded events and
  * returns the totals since echr_prof_enable(1): elapsed ms, algorithmic flops / bytes, launches.
  * Not thread-safe; never enabled on the product path.
  * ---------------------------------------------------------------------------------------------- */

@@ -27,7 +27,7 @@ fe, nf = load('fetch', 'FETCH_SIZE')
 wr, nw = load('write', 'WRITE_SIZE')
 out = {}
 for k in sorted(fe, key=lambda k: -fe[k]):
-    if not (k.startswith(('gemm', 'rec_gemm', 'att_', 'lstm', 'clamp_adam'))):
+    if not (k.startswith(('gemm', 'rec_gemm', 'att_', 'lstm', 'clamp_adam', 'h2_pack'))):
         continue
     out[k] = dict(launches=nf[k], fetch_bytes_per_launch=round(2 * 1024 * fe[k] / nf[k]), write_bytes_per_launch=round(1024 * wr.get(k, 0) / max(nw.get(k, 1), 1)))
     out[k]['hbm_bytes_per_launch'] = out[k]['fetch_bytes_per_launch'] + out[k]['write_bytes_per_launch']
