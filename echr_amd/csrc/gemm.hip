@@ -36,7 +36,6 @@ struct GemmParams {
     int split_k, k_tiles_per_split;
     int tiles_m, tiles_n;
     int xcd_n, xr_m, xr_n;      // h2 kernel: XCD grid columns, tiles per XCD rectangle (rows, cols)
-    int dbg;
     int vecA, vecB;
     // grouped launch: up to 4 same-shaped problems in one grid (blockIdx.z = group * split_k + k-slice); per-group operands
     int ngroup;
@@ -619,8 +618,7 @@ __global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, BM == 128 ? 2 : 1) voi
         // read during the previous k block, is free again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < kt1 && p.dbg != 2) stage(cur ^ 1);
-        if (p.dbg == 1) continue;
+        if (kt + 1 < kt1) stage(cur ^ 1);
         const unsigned char* sb = sm + cur * STAGE;
         f32x16 tmp[2][TN];
 #pragma unroll
@@ -862,7 +860,6 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
             const long cost = ((long)rm * rn * 8) * 100000L + (long)rm * BMs + (long)rn * BNs;
             if (best < 0 || cost < best_cost) { best = xm; best_cost = cost; }
         }
-        p.dbg = getenv("ECHR_H2_DBG") ? atoi(getenv("ECHR_H2_DBG")) : 0;
         p.xcd_n = 8 / best; p.xr_m = (p.tiles_m + best - 1) / best; p.xr_n = (p.tiles_n + p.xcd_n - 1) / p.xcd_n;
         grid.x = 8 * p.xr_m * p.xr_n;
         static const int wn_sel = getenv("ECHR_H2_WN") ? atoi(getenv("ECHR_H2_WN")) : 32;
