@@ -205,6 +205,38 @@ def test_greedy_sample_bit_exact(case):
     assert np.abs(lp.cpu().numpy() - g['sample|logp']).max() < TOL_LOGP
 
 
+def test_sampler_at_eval_size_is_per_event_and_matches_small_batch():
+    """Eval-size property test (1000 proposals): the decoder is independent per event given its contexts, so a
+    batch of 1000 events made of 125 copies of 8 distinct events must decode every copy to the SAME token sequence as the 8-event batch, with log-probs
+    equal to rounding (5e-6)."""
+    from echr_amd.models.OldModel_NEW import ClipView
+    opt, params, vid = synth.make_case('c1')
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    rs = np.random.RandomState(5)
+    base, reps, T_v, D = 8, 125, 160, opt.video_dim
+    c3d = torch.from_numpy(rs.standard_normal((T_v, D)).astype(np.float32)).to(dev)
+    start = rs.randint(0, T_v - 128, size=base)
+    length = rs.randint(1, 129, size=base)
+    video = torch.from_numpy(rs.standard_normal(opt.video_context_dim).astype(np.float32)).to(dev)
+    event = torch.from_numpy(rs.standard_normal((base, opt.event_context_dim)).astype(np.float32)).to(dev)
+
+    def decode(n_rep):
+        st = torch.from_numpy(np.tile(start, n_rep).astype(np.int32)).to(dev)
+        ln = torch.from_numpy(np.tile(length, n_rep).astype(np.int32)).to(dev)
+        cv = ClipView(c3d, st, ln, int(length.max()), False)
+        with torch.no_grad():
+            seq, lp = m.lm_model.sample(video, event.repeat(n_rep, 1), cv, None)
+        return seq.cpu().numpy(), lp.cpu().numpy()
+
+    s1, l1 = decode(1)
+    sN, lN = decode(reps)
+    assert sN.shape[0] == base * reps
+    assert np.array_equal(sN, np.tile(s1, (reps, 1)))
+    assert np.abs(lN - np.tile(l1, (reps, 1))).max() < 5e-6          # the per-step logit GEMM picks a different split-K at M = 8 and M = 1000
+    assert (s1 != 0).any()
+
+
 def test_clamp_adam_matches_torch_adam():
     from echr_amd import functional as EF
     g = U.gold('adam.npz')
