@@ -973,7 +973,10 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     const bool z = g->zeroed != 0;             // gradient buffers pre-zeroed by the caller: accumulate, no fills
     const float zb = z ? 1.f : 0.f;
 
+    ECHR_REQUIRE(g->phase >= 0 && g->phase <= 2, "decoder_bwd: phase must be 0, 1 or 2");
+    const bool do_a = g->phase != 2, do_b = g->phase != 1;        // late-fusion stage / everything after it
     // 1. d logits (time-major, padded leading dimension)
+    if (do_a) {
     if (!g->g_logp) RC(colsum(g->nll_mask, 1, N * S, 1, b.MSUM, false, st));
     RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_mask, g->g_loss, b.MSUM, b.DLG, b.ldg, N, S, V1, st));
     // scratch that is accumulated into, and the transposed recurrent weights (every d h / d ATT product of the reverse recurrence
@@ -989,15 +992,17 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         const long zn[4] = {b.zero_floats, (long)SN * E, (long)N * a->De, (long)SN * 3 * H};
         RC(fill_zero_multi(zp, zn, 4, st));
     }
+    }
     // 2. late fusion gradients: the weight/bias gradients do not feed the recurrence -> side stream
-    const bool ov = overlap_enabled() && S >= 4;
+    const bool ov = overlap_enabled() && S >= 4 && g->phase == 0;
     hipStream_t sq = ov ? side().s : st;
     if (ov) RC(hop(st, side().fork, sq));
     // Both late-fusion products run as NT problems on k-contiguous (transposed) operands so that they qualify for the
     // bf16-split matrix-core path: d W_logit = DLG^T . OUTD  and  d OUTD = DLG . W_logit.
     echr_gemm_desc d;
     const bool h2 = config().gemm_h2 && !ov;
-    if (h2) {
+    if (!do_a) {
+    } else if (h2) {
         // d W_logit = DLG^T . OUTD and d OUTD = DLG . W_logit on h2-packed operands; the four packs (two of them transposing) are one launch
         H2PackJob pj[4] = {pack_cols(b.DLG, b.ldg, V1, SN, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SN, b.PK_OUTDT),
                            pack_rows(b.DLG, b.ldg, SN, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
@@ -1021,6 +1026,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     d.split_k = -1; d.algo = ECHR_GEMM_BF16X3; d.beta = 1.f;
     RC(gemm(d, st));
     }
+    if (!do_b) return 0;
     // 3. reverse recurrence
     const long hs = (long)N * H, as = (long)N * D;
     // weight gradients that are sums over timesteps [t0,t1): W_hh_k, W_ih_k[:, :E], W_ih1[:, E:], W_h2a.

@@ -225,8 +225,16 @@ class DecoderFunction(torch.autograd.Function):
         gp = [L.ptr(x) for x in grads]
         g = L.DecGrads(gp[0], gp[1], gp[2], (L.c_f * 3)(*gp[3:6]), (L.c_f * 3)(*gp[6:9]), (L.c_f * 3)(*gp[9:12]),
                        (L.c_f * 3)(*gp[12:15]), gp[15], gp[16], gp[17], gp[18], gp[19], gp[20],
-                       L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp), None, None, None, L.ptr(wsb), zeroed)
+                       L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp), None, None, None, L.ptr(wsb), zeroed, 0)
         d = drop.c()
+        hook = getattr(ctx.sink.arena, 'early_grad_hook', None) if zeroed else None
+        if hook is not None:
+            # data parallel: the late-fusion gradients are final after phase 1 -- hand them to the reducer, which starts their
+            # all-reduce on the collective stream while phase 2 (reverse recurrence, all other gradients) runs on this one
+            g.phase = 1
+            L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
+            hook([ctx.sink.params[1], ctx.sink.params[2]])          # logit.weight, logit.bias (native_params order)
+            g.phase = 2
         L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
         return (g_video, g_event, None, None, None, None, None, None, None, None) + tuple(grads)
 

@@ -195,6 +195,10 @@ typedef struct {
     const float* g_loss;                       /* device scalar */
     float* ws_bwd;                             /* scratch, echr_decoder_ws_bwd_floats */
     int32_t zeroed;                            /* 1: parameter-gradient buffers arrive zero-filled (see echr_tsrm_grads) */
+    int32_t phase;                             /* 0: the whole backward.  1: only the late-fusion stage (d logits, g_w_logit, g_b_logit,
+                                                  d OUTD); 2: everything after it, on the SAME ws_bwd.  Calling 1 then 2 equals 0 and
+                                                  lets a data-parallel caller start reducing the logit gradients (35 % of the bytes)
+                                                  while the reverse recurrence runs */
 } echr_dec_grads;
 
 int64_t echr_decoder_ws_floats(const echr_dec_args* a);

@@ -299,6 +299,36 @@ def test_cpu_tensors_fail_loudly():
           vid['ind'], vid['soi'], mode='train')
 
 
+def test_two_phase_decoder_backward_equals_single_call():
+    """echr_dec_grads.phase: late-fusion stage (1) then the rest (2) on the same scratch must equal the one-call backward (0);
+    the data-parallel early reducer hooks in between and gets logit.weight / logit.bias with their FINAL gradients."""
+    from echr_amd.misc.utils import LanguageModelCriterion
+    opt, params, vid = synth.make_case('c1')
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels = torch.from_numpy(vid['labels'])
+    tgt, msk = labels[:, 1:].to(dev), torch.from_numpy(vid['masks'])[:, 1:].to(dev)
+    grads, seen = [], []
+    for hooked in (False, True):
+        m = U.build_gpu_model(opt, params, True)
+        arena = m.build_arena()
+        if hooked:
+            def hook(ps, arena=arena):
+                torch.cuda.synchronize()
+                seen.append([p_.shape for p_ in ps] + [arena.grad_view(arena.slot(p_)).clone() for p_ in ps])
+            arena.early_grad_hook = hook
+        m.set_dropout_state(U.SEED, U.OFFSET)
+        LanguageModelCriterion()(m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), tgt, msk).backward()
+        grads.append({k: (p.grad.detach().cpu().numpy() if p.grad is not None else None) for k, p in m.named_parameters()})
+    assert len(seen) == 1 and tuple(seen[0][0]) == (opt.CG_vocab_size + 1, 3 * opt.CG_rnn_size)
+    for k in grads[0]:
+        if grads[0][k] is not None:
+            assert U.grad_close(k, grads[1][k], grads[0][k], 1e-5), k
+    # what the hook saw between the phases is what ends up in .grad (the reducer may start summing it right there)
+    assert U.grad_close('lm_model.logit.weight', seen[0][2].cpu().numpy(), grads[1]['lm_model.logit.weight'], 1e-7)
+    assert U.grad_close('lm_model.logit.bias', seen[0][3].cpu().numpy(), grads[1]['lm_model.logit.bias'], 1e-7)
+
+
 @pytest.mark.parametrize('case', ['tiny', 'c1'])
 def test_flat_arena_path_matches_per_tensor_path(case):
     """build_arena(): gradients land in the flat buffer (adopted as .grad without copies) and equal the per-tensor path's;

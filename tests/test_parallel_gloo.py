@@ -55,6 +55,53 @@ def test_allreduce_is_sum_over_ranks_and_skips_unused_params():
         assert np.allclose(a + b, s0, atol=1e-6) and np.allclose(s0, s1)     # SUM, no averaging; identical on every rank
 
 
+def _worker_early(rank, world, port, q):
+    """Arena path with the early (overlapped) collective: hook on the middle layer, then the remainder at the end."""
+    from echr_amd.arena import ParamArena
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 3))
+    arena = ParamArena(net)
+    rs = np.random.RandomState(20 + rank)
+    x = torch.from_numpy(rs.standard_normal((4, 7)).astype(np.float32))
+    net[1](net[0](x)).pow(2).sum().backward()
+    local = [p.grad.clone() for p in parallel.live_grads(net)]
+    # move the gradients into the arena the way the backward Functions leave them there (views of flat_g adopted as .grad)
+    for p in list(net[0].parameters()) + list(net[1].parameters()):
+        v = arena.grad_view(arena.slot(p))
+        v.copy_(p.grad)
+        p.grad = v
+    assert arena.grads_in_arena()
+    arena.flat_g[arena.offsets[arena.slot(net[2].weight)]] = 123.0      # stale junk in a never-used slot must not survive
+    red = parallel.enable_overlap(net)
+    red.hook([net[1].weight, net[1].bias])
+    assert red.pending is not None
+    n = parallel.allreduce_gradients(net)
+    q.put((rank, n, [g.numpy() for g in local], [p.grad.numpy().copy() for p in parallel.live_grads(net)], arena.flat_g.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_early_reducer_equals_single_allreduce():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_early, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, n0, l0, r0, f0), (_, n1, l1, r1, f1) = res
+    assert n0 == n1 == 3                                   # early range + the ranges before and after it
+    for a, b, s0, s1 in zip(l0, l1, r0, r1):
+        assert np.allclose(a + b, s0, atol=1e-6) and np.array_equal(s0, s1)
+    assert np.array_equal(f0, f1) and not (f0 == 246.0).any() and not (f0 == 123.0).any()
+
+
 def test_shard_videos_partition():
     got = sorted(sum((parallel.shard_videos(11, r, 4) for r in range(4)), []))
     assert got == list(range(11))
