@@ -3,13 +3,13 @@
 // (misc/utils.py:78-99).  SURVEY section 8-f row 1: the producer of `tap_feats` for the caption path.
 //
 // Batch size is 1, so the recurrence is a chain of GEMVs: there is no MFMA shape in it.  Layout of the work:
-//   * input-side products of a whole layer are batched over the T rows on the fp32 MFMA GEMM (gemm.hip);
-//   * one launch per (layer, timestep): workgroup u owns 8 hidden units, wave g (of 4) computes gate g's 8 rows of
-//     W_hh . h(t-1) with float4 lanes + cross-lane reduction, then 8 threads finish the cell (the 4 gates of a unit meet in
-//     LDS).  The 4 MB of W_hh are split over 64 workgroups that always land on the same XCDs -> they stay L2-resident
-//     across the T launches;
-//   * backward mirrors it with W_hh^T: workgroup u first forms d h(t)[its 8 units] = W_hh^T[u-rows] . dG(t+1) (all 4H of
-//     dG(t+1) are final from the previous launch) and then runs the cell backward for step t -- again one launch per step;
+//   * layer 0's input-side products are batched over the T rows on the fp32 MFMA GEMM (gemm.hip);
+//   * the two layers run as a WAVEFRONT: launch k = layer 0 at step k || layer 1 at step k-1 (T+1 dependent launches instead of
+//     2T).  A workgroup owns 2 hidden units; wave g (of 4) computes gate g's rows of W_hh . h(t-1) (layer 1: also W_ih1 . h0(t))
+//     with float4 lanes + cross-lane reduction, then 2 threads finish the cell (the 4 gates of a unit meet in LDS).  The weight
+//     rows of a workgroup always land on the same XCD -> they stay L2-resident across the launches;
+//   * backward mirrors it with the transposed matrices: launch k = layer 1 at step T-1-k || layer 0 at step T-k, where layer 0's
+//     upstream gradient W_ih1^T . dG1(t) (through the inter-layer dropout mask) is formed inside the step;
 //   * weight gradients are batched TN GEMMs over the T rows afterwards.
 #include "echr_common.h"
 #include "echr_internal.h"
@@ -20,10 +20,22 @@ DropCfg make_drop(const echr_dropout* d, float p);
 enum { SITE_SST = 5 };
 constexpr int UPW = 2;          // hidden units per workgroup (256 workgroups at H = 512: one per CU)
 
-// dot of one weight row with a vector held in LDS; lanes stride the k axis in float4
+// dot of one weight row with a vector held in LDS; lanes stride the k axis in float4.  Eight row loads are issued before the first
+// FMA (a 2048-long row is exactly one batch per lane): the step kernels are latency-bound, not bandwidth-bound.
 __device__ __forceinline__ float row_dot(const float* __restrict__ wrow, const float* __restrict__ v, int K, int lane) {
     float acc = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
+    int k = lane * 4;
+    for (; k + 7 * 256 < K; k += 8 * 256) {
+        float4 w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const float4*>(wrow + k + j * 256);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 x4 = *reinterpret_cast<const float4*>(v + k + j * 256);
+            acc += w[j].x * x4.x + w[j].y * x4.y + w[j].z * x4.z + w[j].w * x4.w;
+        }
+    }
+    for (; k < K; k += 256) {
         const float4 w4 = *reinterpret_cast<const float4*>(wrow + k);
         const float4 x4 = *reinterpret_cast<const float4*>(v + k);
         acc += w4.x * x4.x + w4.y * x4.y + w4.z * x4.z + w4.w * x4.w;
@@ -31,88 +43,116 @@ __device__ __forceinline__ float row_dot(const float* __restrict__ wrow, const f
     return wave_sum(acc);
 }
 
-// forward cell of one timestep.  gin: [4H] input-side pre-activations (biases included); hprev/cprev: [H] (dropout is
-// applied to the layer OUTPUT hdrop only, the recurrence uses the raw h as nn.LSTM does); act out: [4H] activations.
-__global__ __launch_bounds__(256) void sst_step_fwd_kernel(const float* __restrict__ Whh, const float* __restrict__ gin,
-                                                           const float* __restrict__ hprev, const float* __restrict__ cprev,
-                                                           float* __restrict__ act, float* __restrict__ hout, float* __restrict__ cout,
-                                                           float* __restrict__ hdrop, int H, int t, DropCfg dc) {
+// ---- wavefront over the two layers ----------------------------------------------------------------------------------
+// Layer 1 at step t needs only layer 0's output of step t, so launch k runs layer 0 at step k and layer 1 at step k-1 side by
+// side (blockIdx.y = role): T+1 dependent launches per direction instead of 2T.  Layer 1 then cannot take its input-side
+// pre-activations from a batched GEMM over all T rows; its step multiplies [W_ih1 | W_hh1] with [h0d(t) ; h1(t-1)] instead.
+struct SstFwdRole {
+    const float* W[2];        // up to two [4H, H] matrices ...
+    const float* v[2];        // ... each times one [H] vector (null: that product is skipped, e.g. h(-1) = 0)
+    const float* base;        // [4H] pre-activation base: a GIN row (layer 0) or b_ih (layer 1)
+    const float* base2;       // [4H] second bias (layer 1: b_hh) or null
+    const float* cprev;
+    float *act, *hout, *cout, *hdrop;
+    int t, active;
+};
+__global__ __launch_bounds__(256) void sst_wave_fwd_kernel(SstFwdRole r0, SstFwdRole r1, int H, DropCfg dc) {
+    const SstFwdRole r = blockIdx.y ? r1 : r0;
+    if (!r.active) return;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sh = sm;                 // [H]
-    float* pre = sm + H;            // [4][UPW]
+    float* sv = sm;                  // [2][H]
+    float* pre = sm + 2 * H;         // [4][UPW]
     const int u0 = blockIdx.x * UPW;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = threadIdx.x; k < H; k += 256) sh[k] = hprev ? hprev[k] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+        if (r.v[m]) for (int k = threadIdx.x; k < H; k += 256) sv[m * H + k] = r.v[m][k];
     __syncthreads();
-    {
-        // wave g owns gate g: its UPW rows are multiplied with independent accumulators (loads of all rows in flight together)
-        float acc[UPW];
+    float acc[UPW];
 #pragma unroll
-        for (int i = 0; i < UPW; ++i) acc[i] = 0.f;
-        if (hprev) {
-            for (int k = lane * 4; k < H; k += 256) {
-                const float4 x4 = *reinterpret_cast<const float4*>(sh + k);
+    for (int i = 0; i < UPW; ++i) acc[i] = 0.f;
 #pragma unroll
-                for (int i = 0; i < UPW; ++i) {
-                    const int u = min(u0 + i, H - 1);
-                    const float4 w4 = *reinterpret_cast<const float4*>(Whh + (long)(wave * H + u) * H + k);
-                    acc[i] += w4.x * x4.x + w4.y * x4.y + w4.z * x4.z + w4.w * x4.w;
-                }
+    for (int m = 0; m < 2; ++m) {
+        if (!r.v[m]) continue;
+        const float* W = r.W[m];
+        for (int k = lane * 4; k < H; k += 256) {
+            const float4 x4 = *reinterpret_cast<const float4*>(sv + m * H + k);
+#pragma unroll
+            for (int i = 0; i < UPW; ++i) {
+                const int u = min(u0 + i, H - 1);
+                const float4 w4 = *reinterpret_cast<const float4*>(W + (long)(wave * H + u) * H + k);
+                acc[i] += w4.x * x4.x + w4.y * x4.y + w4.z * x4.z + w4.w * x4.w;
             }
         }
+    }
 #pragma unroll
-        for (int i = 0; i < UPW; ++i) {
-            const float d = wave_sum(acc[i]);
-            if (lane == 0 && u0 + i < H) pre[wave * UPW + i] = d + gin[wave * H + u0 + i];
+    for (int i = 0; i < UPW; ++i) {
+        const float d = wave_sum(acc[i]);
+        if (lane == 0 && u0 + i < H) {
+            const int row = wave * H + u0 + i;
+            pre[wave * UPW + i] = d + r.base[row] + (r.base2 ? r.base2[row] : 0.f);
         }
     }
     __syncthreads();
     if (threadIdx.x < UPW && u0 + threadIdx.x < H) {
         const int i = threadIdx.x, u = u0 + i;
         const float gi = fast_sigmoid(pre[i]), gf = fast_sigmoid(pre[UPW + i]), gg = tanhf(pre[2 * UPW + i]), go = fast_sigmoid(pre[3 * UPW + i]);
-        const float c = gf * (cprev ? cprev[u] : 0.f) + gi * gg;
+        const float c = gf * (r.cprev ? r.cprev[u] : 0.f) + gi * gg;
         const float h = go * tanhf(c);
-        act[u] = gi; act[H + u] = gf; act[2 * H + u] = gg; act[3 * H + u] = go;
-        cout[u] = c; hout[u] = h;
-        if (hdrop) hdrop[u] = h * drop_mult(dc, (unsigned)(t * H + u), 0u, SITE_SST);
+        r.act[u] = gi; r.act[H + u] = gf; r.act[2 * H + u] = gg; r.act[3 * H + u] = go;
+        r.cout[u] = c; r.hout[u] = h;
+        if (r.hdrop) r.hdrop[u] = h * drop_mult(dc, (unsigned)(r.t * H + u), 0u, SITE_SST);
     }
 }
 
-// backward cell of one timestep: d h(t) = dh_out[t] (from above) + W_hh^T . dG(t+1); then the cell backward -> dG(t), dc.
-// WhhT: [H, 4H] (row u = column u of W_hh).  dgnext: [4H] of step t+1 or null at the last step.
-__global__ __launch_bounds__(256) void sst_step_bwd_kernel(const float* __restrict__ WhhT, const float* __restrict__ dgnext,
-                                                           const float* __restrict__ dh_out, const float* __restrict__ act,
-                                                           const float* __restrict__ c, const float* __restrict__ cprev,
-                                                           float* __restrict__ dc, float* __restrict__ dg, int H) {
+// backward wavefront: launch k runs layer 1 at step t = T-1-k and layer 0 at step t+1.
+//   d h(t) = dh_base[u] + drop?(WT[0][u,:] . vec[0]) + WT[1][u,:] . vec[1]
+//   layer 1: WT[0] = W_hh1^T, vec[0] = dG1(t+1); dh_base = upstream gradient row.
+//   layer 0: WT[0] = W_ih1^T (through the inter-layer dropout mask of (t,u)), vec[0] = dG1(t); WT[1] = W_hh0^T, vec[1] = dG0(t+1).
+struct SstBwdRole {
+    const float* WT[2];       // [H, 4H] transposed matrices
+    const float* vec[2];      // [4H] vectors or null
+    const float* dh_base;     // [H] or null
+    const float *act, *c, *cprev;
+    float *dc, *dg;
+    int drop_first, t, active;
+};
+__global__ __launch_bounds__(256) void sst_wave_bwd_kernel(SstBwdRole r0, SstBwdRole r1, int H, DropCfg dcfg) {
+    const SstBwdRole r = blockIdx.y ? r1 : r0;
+    if (!r.active) return;
+    static_assert(UPW == 2, "wave -> (unit, matrix) map below assumes two units per workgroup");
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sg = sm;                 // [4H]
-    float* part = sm + 4 * H;       // [4][UPW]
+    float* sg = sm;                  // [2][4H]
+    float* part = sm + 8 * H;        // [2][UPW]
     const int u0 = blockIdx.x * UPW;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (dgnext) {
-        for (int k = threadIdx.x; k < 4 * H; k += 256) sg[k] = dgnext[k];
-        __syncthreads();
-        // UPW rows of W_hh^T, each 4H long, split over the 4 waves: wave w takes unit (w % UPW), slice (w / UPW) of the row
-        constexpr int SL = 4 / UPW;                      // k-slices per row
-        const int i = wave % UPW, sl = wave / UPW;
+    // both vectors staged with float4 loads issued back to back (H % 4 == 0 and 256-byte aligned rows: checked on the host)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+        if (r.vec[m])
+            for (int k = threadIdx.x; k < H; k += 256) reinterpret_cast<float4*>(sg + m * 4 * H)[k] = reinterpret_cast<const float4*>(r.vec[m])[k];
+    __syncthreads();
+    {
+        const int i = wave % UPW, m = wave / UPW;       // 4 waves = 2 units x 2 matrices
         const int u = min(u0 + i, H - 1);
-        const int klen = 4 * H / SL;
-        const float d = row_dot(WhhT + (long)u * 4 * H + sl * klen, sg + sl * klen, klen, lane);
-        if (lane == 0) part[sl * UPW + i] = d;
+        float d = 0.f;
+        if (r.vec[m]) d = row_dot(r.WT[m] + (long)u * 4 * H, sg + m * 4 * H, 4 * H, lane);
+        if (lane == 0) part[m * UPW + i] = d;
     }
     __syncthreads();
     if (threadIdx.x < UPW && u0 + threadIdx.x < H) {
         const int i = threadIdx.x, u = u0 + i;
-        float dh = dh_out[u];
-        if (dgnext) for (int sl = 0; sl < 4 / UPW; ++sl) dh += part[sl * UPW + i];
-        const float gi = act[u], gf = act[H + u], gg = act[2 * H + u], go = act[3 * H + u];
-        const float tc = tanhf(c[u]);
-        const float dcv = dh * go * (1.f - tc * tc) + dc[u];
-        dg[u] = dcv * gg * gi * (1.f - gi);
-        dg[H + u] = dcv * (cprev ? cprev[u] : 0.f) * gf * (1.f - gf);
-        dg[2 * H + u] = dcv * gi * (1.f - gg * gg);
-        dg[3 * H + u] = dh * tc * go * (1.f - go);
-        dc[u] = dcv * gf;
+        float first = part[i];
+        if (r.drop_first) first *= drop_mult(dcfg, (unsigned)(r.t * H + u), 0u, SITE_SST);
+        const float dh = (r.dh_base ? r.dh_base[u] : 0.f) + first + part[UPW + i];
+        const float gi = r.act[u], gf = r.act[H + u], gg = r.act[2 * H + u], go = r.act[3 * H + u];
+        const float tc = tanhf(r.c[u]);
+        const float dcv = dh * go * (1.f - tc * tc) + r.dc[u];
+        r.dg[u] = dcv * gg * gi * (1.f - gi);
+        r.dg[H + u] = dcv * (r.cprev ? r.cprev[u] : 0.f) * gf * (1.f - gf);
+        r.dg[2 * H + u] = dcv * gi * (1.f - gg * gg);
+        r.dg[3 * H + u] = dh * tc * go * (1.f - go);
+        r.dc[u] = dcv * gf;
     }
 }
 
@@ -126,12 +166,6 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ s, const float* __r
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dz[i] = g[i] * s[i] * (1.f - s[i]);
 }
-// x[t, j] *= dropout(t, j)  (layer-0 gradient passes through the inter-layer dropout)
-__global__ void sst_drop_mul_kernel(float* __restrict__ x, int T, int H, DropCfg dc) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (long)T * H) x[i] *= drop_mult(dc, (unsigned)i, 0u, SITE_SST);
-}
-
 // weighted BCE of misc/utils.py:78-99:  labels *= masks; w = labels*w0 + (1-labels)*w1 (w0 = 1-w1, per anchor k);
 // loss = K * mean_{t,k} w * -(y log p + (1-y) log(1-p)),  p = scores*masks, logs clamped at -100 like torch's BCELoss.
 __global__ __launch_bounds__(256) void tap_bce_fwd_kernel(const float* __restrict__ scores, const float* __restrict__ masks,
@@ -176,13 +210,14 @@ static SstWs carve(int T, int D, int H, int K, float* base) {
     w.total = off;
     return w;
 }
-struct SstWsB { float *DG[2], *DHO, *DC, *DZ, *WT[2]; long total; };
+struct SstWsB { float *DG[2], *DHO, *DC[2], *DZ, *WT[2], *WT_IH1; long total; };
 static SstWsB carve_b(int T, int D, int H, int K, float* base) {
     SstWsB w;
     long off = 0;
     auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
     for (int l = 0; l < 2; ++l) { w.DG[l] = take((long)T * 4 * H); w.WT[l] = take((long)H * 4 * H); }
-    w.DHO = take((long)T * H); w.DC = take(H); w.DZ = take((long)T * K);
+    w.DHO = take((long)T * H); w.DC[0] = take(H); w.DC[1] = take(H); w.DZ = take((long)T * K);
+    w.WT_IH1 = take((long)H * 4 * H);
     w.total = off;
     return w;
 }
@@ -212,23 +247,33 @@ extern "C" int echr_sst_fwd(const echr_sst_args* a, const echr_dropout* drop, vo
     SstWs w = carve(T, D, H, K, a->ws);
     const DropCfg dc = make_drop(drop, a->p_drop);
     const int nwg = (H + UPW - 1) / UPW;
-    for (int l = 0; l < 2; ++l) {
-        // input-side pre-activations of the whole layer: X_l . W_ih^T + b_ih + b_hh   (layer 1 reads the dropped layer-0 output)
-        const float* xin = l == 0 ? a->x : w.H0D;
-        const int din = l == 0 ? D : H;
-        echr_gemm_desc d = desc_nt(xin, din, a->w_ih[l], din, w.GIN[l], 4 * H, T, 4 * H, din);
-        d.bias = a->b_ih[l]; d.bias2 = a->b_hh[l]; d.split_k = -1;
-        RC(gemm(d, st));
-        float* hs = l == 0 ? w.HS[0] : a->tap_feats;
-        for (int t = 0; t < T; ++t) {
-            const float* hp = t ? hs + (long)(t - 1) * H : nullptr;
-            const float* cp = t ? w.CS[l] + (long)(t - 1) * H : nullptr;
-            hipLaunchKernelGGL(sst_step_fwd_kernel, dim3(nwg), dim3(256), (H + 4 * UPW) * sizeof(float), st, a->w_hh[l],
-                               w.GIN[l] + (long)t * 4 * H, hp, cp, w.ACT[l] + (long)t * 4 * H, hs + (long)t * H, w.CS[l] + (long)t * H,
-                               l == 0 ? w.H0D + (long)t * H : nullptr, H, t, dc);
+    // layer 0's input-side pre-activations for all T rows: X . W_ih0^T + b_ih0 + b_hh0 (batched MFMA GEMM)
+    echr_gemm_desc d0 = desc_nt(a->x, D, a->w_ih[0], D, w.GIN[0], 4 * H, T, 4 * H, D);
+    d0.bias = a->b_ih[0]; d0.bias2 = a->b_hh[0]; d0.split_k = -1;
+    RC(gemm(d0, st));
+    // wavefront: launch k = layer 0 at step k  ||  layer 1 at step k-1 (reads the dropped layer-0 output of step k-1)
+    for (int k = 0; k <= T; ++k) {
+        SstFwdRole r0{}, r1{};
+        if (k < T) {
+            r0.active = 1; r0.t = k;
+            r0.W[0] = a->w_hh[0]; r0.v[0] = k ? w.HS[0] + (long)(k - 1) * H : nullptr;
+            r0.base = w.GIN[0] + (long)k * 4 * H;
+            r0.cprev = k ? w.CS[0] + (long)(k - 1) * H : nullptr;
+            r0.act = w.ACT[0] + (long)k * 4 * H; r0.hout = w.HS[0] + (long)k * H; r0.cout = w.CS[0] + (long)k * H;
+            r0.hdrop = w.H0D + (long)k * H;
         }
-        RC(check_launch("sst_step_fwd"));
+        if (k >= 1) {
+            const int t = k - 1;
+            r1.active = 1; r1.t = t;
+            r1.W[0] = a->w_ih[1]; r1.v[0] = w.H0D + (long)t * H;
+            r1.W[1] = a->w_hh[1]; r1.v[1] = t ? a->tap_feats + (long)(t - 1) * H : nullptr;
+            r1.base = a->b_ih[1]; r1.base2 = a->b_hh[1];
+            r1.cprev = t ? w.CS[1] + (long)(t - 1) * H : nullptr;
+            r1.act = w.ACT[1] + (long)t * 4 * H; r1.hout = a->tap_feats + (long)t * H; r1.cout = w.CS[1] + (long)t * H;
+        }
+        hipLaunchKernelGGL(sst_wave_fwd_kernel, dim3(nwg, 2), dim3(256), (2 * H + 4 * UPW) * sizeof(float), st, r0, r1, H, dc);
     }
+    RC(check_launch("sst_wave_fwd"));
     // proposal head
     echr_gemm_desc d = desc_nt(a->tap_feats, H, a->w_sc, H, a->scores, K, T, K, H);
     d.bias = a->b_sc; d.split_k = -1;
@@ -264,17 +309,40 @@ extern "C" int echr_sst_bwd(const echr_sst_args* a, const echr_sst_grads* g, con
         RC(fill_zero(g->g_w_sc, (long)K * H, st));
         RC(fill_zero(g->g_b_sc, K, st));
     }
-    for (int l = 1; l >= 0; --l) {
-        RC(transpose(a->w_hh[l], H, b.WT[l], 4 * H, 4 * H, H, 4 * H, st));
-        RC(fill_zero(b.DC, H, st));
-        const float* hs = l == 0 ? w.HS[0] : a->tap_feats;
-        for (int t = T - 1; t >= 0; --t) {
-            hipLaunchKernelGGL(sst_step_bwd_kernel, dim3(nwg), dim3(256), (4 * H + 4 * UPW) * sizeof(float), st, b.WT[l],
-                               t + 1 < T ? b.DG[l] + (long)(t + 1) * 4 * H : nullptr, b.DHO + (long)t * H, w.ACT[l] + (long)t * 4 * H,
-                               w.CS[l] + (long)t * H, t ? w.CS[l] + (long)(t - 1) * H : nullptr, b.DC, b.DG[l] + (long)t * 4 * H, H);
+    {
+        const TransposeJob tj[3] = {{a->w_hh[0], H, b.WT[0], 4 * H, 4 * H, H}, {a->w_hh[1], H, b.WT[1], 4 * H, 4 * H, H},
+                                    {a->w_ih[1], H, b.WT_IH1, 4 * H, 4 * H, H}};
+        RC(transpose_multi(tj, 3, st));
+        float* zp[2] = {b.DC[0], b.DC[1]};
+        const long zn[2] = {H, H};
+        RC(fill_zero_multi(zp, zn, 2, st));
+    }
+    // wavefront: launch k = layer 1 at step T-1-k  ||  layer 0 at step T-k (its upstream gradient is W_ih1^T . dG1 of the same step,
+    // through the inter-layer dropout mask)
+    for (int k = 0; k <= T; ++k) {
+        SstBwdRole r1{}, r0{};
+        if (k < T) {
+            const int t = T - 1 - k;
+            r1.active = 1; r1.t = t;
+            r1.WT[0] = b.WT[1]; r1.vec[0] = t + 1 < T ? b.DG[1] + (long)(t + 1) * 4 * H : nullptr;
+            r1.dh_base = b.DHO + (long)t * H;
+            r1.act = w.ACT[1] + (long)t * 4 * H; r1.c = w.CS[1] + (long)t * H; r1.cprev = t ? w.CS[1] + (long)(t - 1) * H : nullptr;
+            r1.dc = b.DC[1]; r1.dg = b.DG[1] + (long)t * 4 * H;
         }
-        RC(check_launch("sst_step_bwd"));
-        // parameter gradients of the layer (sums over the T rows); h(t-1) pairs with dG(t): rows 1..T-1
+        if (k >= 1) {
+            const int t = T - k;
+            r0.active = 1; r0.t = t; r0.drop_first = 1;
+            r0.WT[0] = b.WT_IH1; r0.vec[0] = b.DG[1] + (long)t * 4 * H;
+            r0.WT[1] = b.WT[0]; r0.vec[1] = t + 1 < T ? b.DG[0] + (long)(t + 1) * 4 * H : nullptr;
+            r0.act = w.ACT[0] + (long)t * 4 * H; r0.c = w.CS[0] + (long)t * H; r0.cprev = t ? w.CS[0] + (long)(t - 1) * H : nullptr;
+            r0.dc = b.DC[0]; r0.dg = b.DG[0] + (long)t * 4 * H;
+        }
+        hipLaunchKernelGGL(sst_wave_bwd_kernel, dim3(nwg, 2), dim3(256), (8 * H + 2 * UPW) * sizeof(float), st, r1, r0, H, dc);
+    }
+    RC(check_launch("sst_wave_bwd"));
+    // parameter gradients (sums over the T rows); h(t-1) pairs with dG(t): rows 1..T-1
+    for (int l = 1; l >= 0; --l) {
+        const float* hs = l == 0 ? w.HS[0] : a->tap_feats;
         const float* xin = l == 0 ? a->x : w.H0D;
         const int din = l == 0 ? D : H;
         d = desc_tn(b.DG[l], 4 * H, xin, din, g->g_w_ih[l], din, 4 * H, din, T); d.split_k = -1;
@@ -286,13 +354,6 @@ extern "C" int echr_sst_bwd(const echr_sst_args* a, const echr_sst_grads* g, con
             RC(fill_zero(g->g_w_hh[l], (long)4 * H * H, st));
         }
         RC(colsum2(b.DG[l], 4 * H, T, 4 * H, g->g_b_ih[l], g->g_b_hh[l], false, st));
-        if (l == 1) {   // gradient into layer 0's (dropped) output: dG1 . W_ih1, through the dropout mask
-            d = desc_nn(b.DG[1], 4 * H, a->w_ih[1], H, b.DHO, H, T, H, 4 * H); d.split_k = -1;
-            RC(gemm(d, st));
-            const long n = (long)T * H;
-            hipLaunchKernelGGL(sst_drop_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b.DHO, T, H, dc);
-            RC(check_launch("sst_drop_mul"));
-        }
     }
     return 0;
 }
