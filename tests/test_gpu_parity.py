@@ -151,7 +151,7 @@ def test_full_path_vs_oracle(case, train_mode):
         if g is None:
             assert grads[k] is None, k
         else:
-            assert U.relerr(grads[k], g, U.GRAD_FLOOR) < TOL_GRAD, (k, U.relerr(grads[k], g))
+            assert U.grad_close(k, grads[k], g, TOL_GRAD), (k, U.relerr(grads[k], g))
 
 
 @pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full'])
@@ -170,7 +170,7 @@ def test_full_path_vs_reference_golden(case, train_mode):
             if v is None:
                 assert key not in g
             else:
-                assert U.relerr(v, g[key], U.GRAD_FLOOR) < TOL_GRAD, (k, U.relerr(v, g[key]))
+                assert U.grad_close(k, v, g[key], TOL_GRAD), (k, U.relerr(v, g[key]))
         return
     s = SM.summarize_logp(pred)
     assert np.abs(s['slice'] - g[mode + '|logp|slice']).max() < TOL_LOGP
@@ -182,6 +182,9 @@ def test_full_path_vs_reference_golden(case, train_mode):
     for key, v in gs.items():
         ref = g[mode + '|grad|' + key]
         name = key.split('|')[0]
+        if name in U.NOISE_ONLY:          # true gradient is exactly zero: both sides are rounding noise (order-dependent atomics)
+            assert np.abs(np.asarray(v)).max() < 1e-6 and np.abs(np.asarray(ref)).max() < 1e-6, (key, v, ref)
+            continue
         scale = max(float(g[mode + '|grad|' + name + '|linf']), U.GRAD_FLOOR)
         if key.endswith('|l2') or key.endswith('|linf'):
             assert abs(float(v) - float(ref)) < TOL_GRAD * max(abs(float(ref)), U.GRAD_FLOOR), (key, float(v), float(ref))

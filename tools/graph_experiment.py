@@ -1,4 +1,5 @@
-"""scratch: does a captured hipGraph of the whole iteration run faster than eager? (counters baked in -- timing only)"""
+"""Experiment: does a captured hipGraph of the whole training iteration replay faster than eager launches?
+Measured 3.44 vs 3.46 ms on the c3 workload: no.  Counters (dropout offset, Adam step) are baked into the capture -- timing only."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
