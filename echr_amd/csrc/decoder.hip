@@ -717,7 +717,6 @@ struct DecWsBwd {
     float *PK_DLGT, *PK_OUTDT, *PK_DLG, *PK_WLT, *PK_DGT[3], *PK_DG[3], *PK_HT[3], *PK_XTT, *PK_ATTT, *PK_DQT, *PK_WIHT[3], *PK_DPT, *PK_C3DT;
     long snp;
     float *DHACC[3], *DASL;                  // atomic accumulation targets: d h(t-1) per stream [N,H]; DASL: d ATT [S,N,D]
-    int ndh[3], nda;
     long ldg, total, zero_floats;
 };
 static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
@@ -748,9 +747,6 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     w.WLT = take(3 * H * w.ldg);
     w.DLGT = take((long)a->V1 * w.snp);
     w.OUTDT = take(3 * H * w.snp);
-    w.ndh[0] = w.ndh[2] = ksplit_of(4 * a->H);
-    w.ndh[1] = ksplit_of(4 * a->H) + ksplit_of(a->Ha);
-    w.nda = ksplit_of(4 * a->H);
     const int SN = (int)(S * N), H4 = 4 * a->H;
     w.PK_DLGT = take(h2_floats(a->V1, SN)); w.PK_OUTDT = take(h2_floats(3 * a->H, SN));
     w.PK_DLG = take(h2_floats(SN, a->V1)); w.PK_WLT = take(h2_floats(3 * a->H, a->V1));
@@ -973,8 +969,11 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     const bool z = g->zeroed != 0;             // gradient buffers pre-zeroed by the caller: accumulate, no fills
     const float zb = z ? 1.f : 0.f;
 
-    ECHR_REQUIRE(g->phase >= 0 && g->phase <= 2, "decoder_bwd: phase must be 0, 1 or 2");
-    const bool do_a = g->phase != 2, do_b = g->phase != 1;        // late-fusion stage / everything after it
+    ECHR_REQUIRE(g->phase >= 0 && g->phase <= 4, "decoder_bwd: phase must be 0..4");
+    // stages: late fusion | reverse recurrence + LSTM-layer gradients (part A) | attention + embedding gradients (part B)
+    const bool do_a = g->phase == 0 || g->phase == 1;
+    const bool do_rec = g->phase == 0 || g->phase == 2 || g->phase == 3;
+    const bool do_pb = g->phase == 0 || g->phase == 2 || g->phase == 4;
     // 1. d logits (time-major, padded leading dimension)
     if (do_a) {
     if (!g->g_logp) RC(colsum(g->nll_mask, 1, N * S, 1, b.MSUM, false, st));
@@ -1026,7 +1025,6 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     d.split_k = -1; d.algo = ECHR_GEMM_BF16X3; d.beta = 1.f;
     RC(gemm(d, st));
     }
-    if (!do_b) return 0;
     // 3. reverse recurrence
     const long hs = (long)N * H, as = (long)N * D;
     // weight gradients that are sums over timesteps [t0,t1): W_hh_k, W_ih_k[:, :E], W_ih1[:, E:], W_h2a.
@@ -1125,7 +1123,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         return 0;
     };
     const bool two = !ov && config().chains2 == 1 && side().ok && S >= 2;
-    if (two) {          // streams 0/2 are independent of the attention chain: their reverse recurrence runs on the side stream
+    if (!do_rec) {
+    } else if (two) {          // streams 0/2 are independent of the attention chain: their reverse recurrence runs on the side stream
         RC(hop(st, side().fork, side().s));
         for (int t = S - 1; t >= 0; --t) RC(bwd_step(t, 2, side().s));
         for (int t = S - 1; t >= 0; --t) RC(bwd_step(t, 1, st));
@@ -1139,8 +1138,45 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
             }
         }
     }
-    // 4. batched parameter gradients
-    //    attention: d P_all / d alpha over all timesteps, then ctx2att and h2att weights
+    // 4. batched parameter gradients, part A: everything of the three LSTM layers (core.layer0..2) -- final after this block, so a
+    //    data-parallel caller can start reducing them (phase 3) while part B runs
+    if (do_rec) {
+    if (ov) RC(hop(sq, side().join, st));                     // chunk [th,S) and the logit gradients are complete
+    RC(wgrad_chunk(0, th_b, (ov || z) ? 1.f : 0.f, st));      // W_hh_k, W_ih_k[:, :E], W_ih1[:, E:], W_h2a: sums over timesteps
+    //    bias gradients b_h2a and per stream b_ih = b_hh = column sums of DG_k over all S*N rows (stream 2's also as the plain vector
+    //    DGCOL that the scene projection below consumes).  One launch when the gradient buffers accumulate.
+    if (z) {
+        const ColsumJob cj[4] = {{b.DQ, Ha, SN, Ha, g->g_b_h2a, nullptr, nullptr},
+                                 {b.DG[0], 4 * H, SN, 4 * H, g->g_b_ih[0], g->g_b_hh[0], nullptr},
+                                 {b.DG[1], 4 * H, SN, 4 * H, g->g_b_ih[1], g->g_b_hh[1], nullptr},
+                                 {b.DG[2], 4 * H, SN, 4 * H, g->g_b_ih[2], g->g_b_hh[2], b.DGCOL[2]}};
+        RC(colsum_multi(cj, 4, st));
+        RC(sum_over_time(b.DG[0], 4 * H, S, N, 4 * H, b.DGSUM[0], 4 * H, st));     // per-event sums feed the event-context products
+    } else {
+        RC(colsum(b.DQ, Ha, SN, Ha, g->g_b_h2a, z, st));
+        for (int k = 0; k < 3; ++k) {
+            RC(sum_over_time(b.DG[k], 4 * H, S, N, 4 * H, b.DGSUM[k], 4 * H, st));
+            RC(colsum2(b.DGSUM[k], 4 * H, N, 4 * H, g->g_b_ih[k], g->g_b_hh[k], z, st));       // b_ih and b_hh share their gradient
+            if (k == 2) RC(colsum(b.DGSUM[k], 4 * H, N, 4 * H, b.DGCOL[k], false, st));          // also needed as a vector below
+        }
+    }
+    //    context halves of W_ih: event (stream 0), video (stream 2)
+    d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);
+    d.beta = zb; d.split_k = -1;
+    RC(gemm(d, st));
+    d = desc_nn(b.DGSUM[0], 4 * H, a->w_ih[0] + E, cin[0], g->g_event, a->De, N, a->De, 4 * H);
+    d.split_k = -1; d.beta = 1.f;                                // zeroed with the backward scratch above
+    RC(gemm(d, st));
+    d = desc_tn(b.DGCOL[2], 4 * H, a->video, a->Dv, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, 1);
+    RC(gemm(d, st));
+    if (g->g_video) {
+        d = desc_nn(b.DGCOL[2], 4 * H, a->w_ih[2] + E, cin[2], g->g_video, a->Dv, 1, a->Dv, 4 * H);
+        d.split_k = -1;
+        RC(gemm(d, st));
+    }
+    }
+    if (!do_pb) return 0;
+    // 5. part B: attention parameters (d P_all / d alpha over all timesteps, then ctx2att) and the token embedding
     if (!z) {
         RC(fill_zero(g->g_w_alpha, Ha, st));
         RC(fill_zero(g->g_b_alpha, 1, st));
@@ -1160,41 +1196,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     }
     d.beta = zb;
     RC(gemm(d, st));
-    //    LSTM / h2att weights: sums over timesteps, done in two chunks (see wgrad_chunk)
-    if (ov) RC(hop(sq, side().join, st));                     // chunk [th,S) and the logit gradients are complete
-    RC(wgrad_chunk(0, th_b, (ov || z) ? 1.f : 0.f, st));
-    //    bias gradients: b_c2a, b_h2a, and per stream b_ih = b_hh = column sums of DG_k over all S*N rows (stream 2's also as the
-    //    plain vector DGCOL that the scene projection below consumes).  One launch when the gradient buffers accumulate.
-    if (z) {
-        const ColsumJob cj[5] = {{b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, nullptr, nullptr}, {b.DQ, Ha, SN, Ha, g->g_b_h2a, nullptr, nullptr},
-                                 {b.DG[0], 4 * H, SN, 4 * H, g->g_b_ih[0], g->g_b_hh[0], nullptr},
-                                 {b.DG[1], 4 * H, SN, 4 * H, g->g_b_ih[1], g->g_b_hh[1], nullptr},
-                                 {b.DG[2], 4 * H, SN, 4 * H, g->g_b_ih[2], g->g_b_hh[2], b.DGCOL[2]}};
-        RC(colsum_multi(cj, 5, st));
-        RC(sum_over_time(b.DG[0], 4 * H, S, N, 4 * H, b.DGSUM[0], 4 * H, st));     // per-event sums feed the event-context products
-    } else {
-        RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
-        RC(colsum(b.DQ, Ha, SN, Ha, g->g_b_h2a, z, st));
-        for (int k = 0; k < 3; ++k) {
-            RC(sum_over_time(b.DG[k], 4 * H, S, N, 4 * H, b.DGSUM[k], 4 * H, st));
-            RC(colsum2(b.DGSUM[k], 4 * H, N, 4 * H, g->g_b_ih[k], g->g_b_hh[k], z, st));       // b_ih and b_hh share their gradient
-            if (k == 2) RC(colsum(b.DGSUM[k], 4 * H, N, 4 * H, b.DGCOL[k], false, st));          // also needed as a vector below
-        }
-    }
-    //    context halves of W_ih: event (stream 0), attended clip (stream 1), video (stream 2)
-    d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);
-    d.beta = zb; d.split_k = -1;
-    RC(gemm(d, st));
-    d = desc_nn(b.DGSUM[0], 4 * H, a->w_ih[0] + E, cin[0], g->g_event, a->De, N, a->De, 4 * H);
-    d.split_k = -1; d.beta = 1.f;                                // zeroed with the backward scratch above
-    RC(gemm(d, st));
-    d = desc_tn(b.DGCOL[2], 4 * H, a->video, a->Dv, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, 1);
-    RC(gemm(d, st));
-    if (g->g_video) {
-        d = desc_nn(b.DGCOL[2], 4 * H, a->w_ih[2] + E, cin[2], g->g_video, a->Dv, 1, a->Dv, 4 * H);
-        d.split_k = -1;
-        RC(gemm(d, st));
-    }
+    RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
     //    token embedding: dXT = sum_k DG_k . W_ih_k[:, :E], scatter-added into the (caller-zeroed) table gradient
     {
         echr_gemm_desc gx[3];

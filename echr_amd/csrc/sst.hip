@@ -200,12 +200,13 @@ __global__ void tap_bce_bwd_kernel(const float* __restrict__ scores, const float
 
 static inline long rup(long x, long a) { return (x + a - 1) / a * a; }
 
-struct SstWs { float *GIN[2], *ACT[2], *HS[2], *CS[2], *H0D; long total; };
+struct SstWs { float *GIN0, *ACT[2], *HS[2], *CS[2], *H0D; long total; };
 static SstWs carve(int T, int D, int H, int K, float* base) {
     SstWs w;
     long off = 0;
     auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
-    for (int l = 0; l < 2; ++l) { w.GIN[l] = take((long)T * 4 * H); w.ACT[l] = take((long)T * 4 * H); w.HS[l] = take((long)T * H); w.CS[l] = take((long)T * H); }
+    w.GIN0 = take((long)T * 4 * H);        // layer 0's input-side pre-activations (layer 1 forms its own inside the wavefront step)
+    for (int l = 0; l < 2; ++l) { w.ACT[l] = take((long)T * 4 * H); w.HS[l] = take((long)T * H); w.CS[l] = take((long)T * H); }
     w.H0D = take((long)T * H);
     w.total = off;
     return w;
@@ -248,7 +249,7 @@ extern "C" int echr_sst_fwd(const echr_sst_args* a, const echr_dropout* drop, vo
     const DropCfg dc = make_drop(drop, a->p_drop);
     const int nwg = (H + UPW - 1) / UPW;
     // layer 0's input-side pre-activations for all T rows: X . W_ih0^T + b_ih0 + b_hh0 (batched MFMA GEMM)
-    echr_gemm_desc d0 = desc_nt(a->x, D, a->w_ih[0], D, w.GIN[0], 4 * H, T, 4 * H, D);
+    echr_gemm_desc d0 = desc_nt(a->x, D, a->w_ih[0], D, w.GIN0, 4 * H, T, 4 * H, D);
     d0.bias = a->b_ih[0]; d0.bias2 = a->b_hh[0]; d0.split_k = -1;
     RC(gemm(d0, st));
     // wavefront: launch k = layer 0 at step k  ||  layer 1 at step k-1 (reads the dropped layer-0 output of step k-1)
@@ -257,7 +258,7 @@ extern "C" int echr_sst_fwd(const echr_sst_args* a, const echr_dropout* drop, vo
         if (k < T) {
             r0.active = 1; r0.t = k;
             r0.W[0] = a->w_hh[0]; r0.v[0] = k ? w.HS[0] + (long)(k - 1) * H : nullptr;
-            r0.base = w.GIN[0] + (long)k * 4 * H;
+            r0.base = w.GIN0 + (long)k * 4 * H;
             r0.cprev = k ? w.CS[0] + (long)(k - 1) * H : nullptr;
             r0.act = w.ACT[0] + (long)k * 4 * H; r0.hout = w.HS[0] + (long)k * H; r0.cout = w.CS[0] + (long)k * H;
             r0.hdrop = w.H0D + (long)k * H;

@@ -229,13 +229,17 @@ class DecoderFunction(torch.autograd.Function):
         d = drop.c()
         hook = getattr(ctx.sink.arena, 'early_grad_hook', None) if zeroed else None
         if hook is not None:
-            # data parallel: the late-fusion gradients are final after phase 1 -- hand them to the reducer, which starts their
-            # all-reduce on the collective stream while phase 2 (reverse recurrence, all other gradients) runs on this one
-            g.phase = 1
+            # data parallel: hand gradients to the reducer as soon as they are final; it starts their all-reduce on the collective
+            # stream while the next stage runs on this one.  params order = OldModel.native_params():
+            #   [0] embed, [1] logit.weight, [2] logit.bias, [3:6] weight_ih, [6:9] weight_hh, [9:12] bias_ih, [12:15] bias_hh, ...
+            sp = ctx.sink.params
+            for phase, ready in ((1, [sp[1], sp[2]]), (3, list(sp[3:15])), (4, None)):
+                g.phase = phase
+                L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
+                if ready is not None:
+                    hook(ready)
+        else:
             L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
-            hook([ctx.sink.params[1], ctx.sink.params[2]])          # logit.weight, logit.bias (native_params order)
-            g.phase = 2
-        L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
         return (g_video, g_event, None, None, None, None, None, None, None, None) + tuple(grads)
 
 

@@ -19,46 +19,55 @@ def live_grads(module):
 class EarlyReducer(object):
     """Overlaps the all-reduce of gradients that are final early in the backward pass with the rest of the backward pass.
 
-    The late-fusion layer (logit.weight / logit.bias: 35 % of the gradient bytes) gets its gradient in the FIRST stage of the
-    decoder backward (echr_decoder_bwd phase 1); the reverse recurrence and every other gradient follow.  The decoder Function
-    calls `hook(params)` between the two stages; the hook starts an asynchronous SUM all-reduce on the arena range that holds
-    those gradients (torch.distributed runs it on the collective stream, ordered after the work already queued on the current
-    stream).  `allreduce_gradients` later reduces the remaining ranges and waits for the early one, so the result is the same
-    SUM over ranks as the single-collective path."""
+    The decoder backward runs in stages (echr_dec_grads.phase) and calls `hook(params)` after each stage with the parameters whose
+    gradients just became final: the late-fusion layer (logit.weight / logit.bias, 35 % of the gradient bytes) before the reverse
+    recurrence even starts, the three LSTM layers (39 %) right after it.  The hook starts an asynchronous SUM all-reduce on the arena
+    range that holds those gradients (torch.distributed runs it on the collective stream, ordered after the work already queued on
+    the current stream).  `allreduce_gradients` later reduces the ranges no early collective covered and waits for the early ones,
+    so the result is the same SUM over ranks as the single-collective path."""
 
     def __init__(self, arena, group=None):
         self.arena, self.group = arena, group
-        self.pending = None            # (lo, hi, work)
-        self.early_ids = set()         # parameters whose gradients the pending collective covers
+        self.pending = []              # [(lo, hi, work)], disjoint arena ranges in flight
+        self.early_ids = set()         # parameters whose gradients the pending collectives cover
         arena.early_grad_hook = self.hook
 
     def hook(self, params):
         ar = self.arena
-        if self.pending is not None or not (dist.is_available() and dist.is_initialized()):
+        if not (dist.is_available() and dist.is_initialized()):
             return
         slots = sorted(ar.slot(p) for p in params)
         if any(s is None for s in slots) or slots != list(range(slots[0], slots[-1] + 1)):
-            return                      # not one contiguous arena range: leave everything to the final collective
+            return                      # not one contiguous arena range: leave it to the final collective
         lo, hi = ar.span(slots)
+        if any(lo < phi and plo < hi for plo, phi, _ in self.pending):
+            return                      # overlaps a range already in flight (second backward in one step): final collective
         work = dist.all_reduce(ar.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.pending = (lo, hi, work)
-        self.early_ids = {id(p) for p in params}
+        self.pending.append((lo, hi, work))
+        self.early_ids.update(id(p) for p in params)
 
     def finish(self):
-        """Reduce what the early collective did not cover, then wait for it.  Returns the number of collectives."""
+        """Reduce what the early collectives did not cover, then wait for them.  Returns the number of collectives."""
         ar = self.arena
-        if self.pending is None:
-            dist.all_reduce(ar.flat_g, op=dist.ReduceOp.SUM, group=self.group)
-            return 1
-        lo, hi, work = self.pending
-        self.pending = None
-        n = 1
-        for a, b in ((0, lo), (hi, ar.total)):
-            if b > a:
-                dist.all_reduce(ar.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group)
+        pend = sorted(self.pending, key=lambda t: t[0])
+        self.pending, self.early_ids = [], set()
+        n, pos = len(pend), 0
+        for lo, hi, _ in pend + [(ar.total, ar.total, None)]:
+            if lo > pos:
+                dist.all_reduce(ar.flat_g[pos:lo], op=dist.ReduceOp.SUM, group=self.group)
                 n += 1
-        work.wait()
+            pos = max(pos, hi)
+        for _, _, work in pend:
+            work.wait()
         return n
+
+    def wait_pending(self):
+        """Finish the early collectives only (used when the gradients left the arena afterwards); returns the covered ids."""
+        ids = self.early_ids
+        for _, _, work in self.pending:
+            work.wait()
+        self.pending, self.early_ids = [], set()
+        return ids
 
     def disable(self):
         self.arena.early_grad_hook = None
@@ -89,10 +98,9 @@ def allreduce_gradients(module, group=None, bucket_bytes=64 << 20, force=False):
         return 1
     params = live_grads(module)
     red = getattr(module, '_echr_early_reducer', None)
-    if red is not None and red.pending is not None:      # gradients left the arena after an early collective started: finish it and
-        red.pending[2].wait()                             # keep its parameters out of the per-tensor buckets (already summed)
-        red.pending = None
-        params = [p for p in params if id(p) not in red.early_ids]
+    if red is not None and red.pending:                   # gradients left the arena after early collectives started: finish them and
+        done = red.wait_pending()                         # keep their parameters out of the per-tensor buckets (already summed)
+        params = [p for p in params if id(p) not in done]
     buckets, cur, cur_bytes = [], [], 0
     for p in params:
         nb = p.grad.numel() * p.grad.element_size()

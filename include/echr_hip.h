@@ -195,10 +195,13 @@ typedef struct {
     const float* g_loss;                       /* device scalar */
     float* ws_bwd;                             /* scratch, echr_decoder_ws_bwd_floats */
     int32_t zeroed;                            /* 1: parameter-gradient buffers arrive zero-filled (see echr_tsrm_grads) */
-    int32_t phase;                             /* 0: the whole backward.  1: only the late-fusion stage (d logits, g_w_logit, g_b_logit,
-                                                  d OUTD); 2: everything after it, on the SAME ws_bwd.  Calling 1 then 2 equals 0 and
-                                                  lets a data-parallel caller start reducing the logit gradients (35 % of the bytes)
-                                                  while the reverse recurrence runs */
+    int32_t phase;                             /* 0: the whole backward.  A data-parallel caller may run it in stages ON THE SAME ws_bwd and
+                                                  start reducing gradients as they become final:
+                                                    1 = late-fusion stage (d logits; g_w_logit, g_b_logit final: 35 % of the bytes),
+                                                    3 = reverse recurrence + every gradient of the three LSTM layers (g_w_ih, g_w_hh,
+                                                        g_b_ih, g_b_hh, plus g_w_h2a, g_b_h2a, g_event, g_video): 39 % of the bytes,
+                                                    4 = the rest (attention parameters, token embedding);
+                                                    2 = 3 followed by 4.   1, 3, 4 in this order equal 0. */
 } echr_dec_grads;
 
 int64_t echr_decoder_ws_floats(const echr_dec_args* a);

@@ -302,9 +302,10 @@ def test_cpu_tensors_fail_loudly():
           vid['ind'], vid['soi'], mode='train')
 
 
-def test_two_phase_decoder_backward_equals_single_call():
-    """echr_dec_grads.phase: late-fusion stage (1) then the rest (2) on the same scratch must equal the one-call backward (0);
-    the data-parallel early reducer hooks in between and gets logit.weight / logit.bias with their FINAL gradients."""
+def test_staged_decoder_backward_equals_single_call():
+    """echr_dec_grads.phase: late-fusion stage (1), reverse recurrence + LSTM-layer gradients (3), the rest (4) on the same scratch
+    must equal the one-call backward (0); the data-parallel early reducer hooks in after stages 1 and 3 and must see the FINAL
+    gradients of logit.* and of the twelve core.layer* tensors (it starts summing them over ranks right there)."""
     from echr_amd.misc.utils import LanguageModelCriterion
     opt, params, vid = synth.make_case('c1')
     dev = torch.device('cuda')
@@ -315,21 +316,24 @@ def test_two_phase_decoder_backward_equals_single_call():
     for hooked in (False, True):
         m = U.build_gpu_model(opt, params, True)
         arena = m.build_arena()
+        names = {id(p): k for k, p in m.named_parameters()}
         if hooked:
-            def hook(ps, arena=arena):
+            def hook(ps, arena=arena, names=names):
                 torch.cuda.synchronize()
-                seen.append([p_.shape for p_ in ps] + [arena.grad_view(arena.slot(p_)).clone() for p_ in ps])
+                seen.append({names[id(p_)]: arena.grad_view(arena.slot(p_)).clone().cpu().numpy() for p_ in ps})
             arena.early_grad_hook = hook
         m.set_dropout_state(U.SEED, U.OFFSET)
         LanguageModelCriterion()(m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), tgt, msk).backward()
         grads.append({k: (p.grad.detach().cpu().numpy() if p.grad is not None else None) for k, p in m.named_parameters()})
-    assert len(seen) == 1 and tuple(seen[0][0]) == (opt.CG_vocab_size + 1, 3 * opt.CG_rnn_size)
+    assert len(seen) == 2
+    assert sorted(seen[0]) == ['lm_model.logit.bias', 'lm_model.logit.weight']
+    assert len(seen[1]) == 12 and all(k.startswith('lm_model.core.layer') for k in seen[1])
     for k in grads[0]:
         if grads[0][k] is not None:
             assert U.grad_close(k, grads[1][k], grads[0][k], 1e-5), k
-    # what the hook saw between the phases is what ends up in .grad (the reducer may start summing it right there)
-    assert U.grad_close('lm_model.logit.weight', seen[0][2].cpu().numpy(), grads[1]['lm_model.logit.weight'], 1e-7)
-    assert U.grad_close('lm_model.logit.bias', seen[0][3].cpu().numpy(), grads[1]['lm_model.logit.bias'], 1e-7)
+    for call in seen:                          # what the hook saw between the stages is what ends up in .grad
+        for k, v in call.items():
+            assert np.array_equal(v, grads[1][k]), k
 
 
 @pytest.mark.parametrize('case', ['tiny', 'c1'])

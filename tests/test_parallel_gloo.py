@@ -77,7 +77,9 @@ def _worker_early(rank, world, port, q):
     arena.flat_g[arena.offsets[arena.slot(net[2].weight)]] = 123.0      # stale junk in a never-used slot must not survive
     red = parallel.enable_overlap(net)
     red.hook([net[1].weight, net[1].bias])
-    assert red.pending is not None
+    red.hook([net[0].weight])                      # a second early range, adjacent to nothing in flight
+    red.hook([net[1].bias])                        # overlaps a range in flight: must be ignored
+    assert len(red.pending) == 2
     n = parallel.allreduce_gradients(net)
     q.put((rank, n, [g.numpy() for g in local], [p.grad.numpy().copy() for p in parallel.live_grads(net)], arena.flat_g.numpy().copy()))
     dist.destroy_process_group()
@@ -96,7 +98,7 @@ def test_early_reducer_equals_single_allreduce():
         p.join(60)
         assert p.exitcode == 0
     (_, n0, l0, r0, f0), (_, n1, l1, r1, f1) = res
-    assert n0 == n1 == 3                                   # early range + the ranges before and after it
+    assert n0 == n1 == 4                                   # two early ranges + the gap between them + the tail
     for a, b, s0, s1 in zip(l0, l1, r0, r1):
         assert np.allclose(a + b, s0, atol=1e-6) and np.array_equal(s0, s1)
     assert np.array_equal(f0, f1) and not (f0 == 246.0).any() and not (f0 == 123.0).any()
