@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void tsrm_softmax_bwd_kernel(const float* __res
 
 static inline long rup(long x, long a) { return (x + a - 1) / a * a; }
 
-struct TsrmWs { float *X, *POS, *P1, *GATE, *Q, *K, *XW, *AFF, *WSM, *WD; long total, zero_floats; };
+struct TsrmWs { float *X, *POS, *P1, *GATE, *Q, *K, *XW, *AFF, *WSM, *WD, *PK_POS, *PK_WFC1; long total, zero_floats; };
 static TsrmWs carve(int N, int Din, int Df, int Do, int G, float* base) {
     TsrmWs w;
     long off = 0;
@@ -96,10 +96,11 @@ static TsrmWs carve(int N, int Din, int Df, int Do, int G, float* base) {
     w.zero_floats = off;
     w.POS = take(NN * Df); w.P1 = take(NN * Df);
     w.AFF = take(NN * G); w.WSM = take(NN * G); w.WD = take(NN * G);
+    w.PK_POS = take(h2_floats((int)NN, Df)); w.PK_WFC1 = take(h2_floats(Df, Df));      // h2-packed operands of the fc1 product
     w.total = off;
     return w;
 }
-struct TsrmWsB { float *DWD, *DGATE, *DAFF, *DQ, *DK, *DXW, *DX, *DP1; long total; };
+struct TsrmWsB { float *DWD, *DGATE, *DAFF, *DQ, *DK, *DXW, *DX, *DP1, *PK_DP1T, *PK_POST; long total; };
 static TsrmWsB carve_b(int N, int Din, int Df, int Do, int G, float* base) {
     TsrmWsB w;
     long off = 0;
@@ -108,6 +109,7 @@ static TsrmWsB carve_b(int N, int Din, int Df, int Do, int G, float* base) {
     w.DWD = take(NN * G); w.DGATE = take(NN * G); w.DAFF = take(NN * G);
     w.DQ = take((long)N * Df); w.DK = take((long)N * Df); w.DXW = take((long)N * Do); w.DX = take((long)N * Df);
     w.DP1 = take(NN * Df);
+    w.PK_DP1T = take(h2_floats(Df, (int)NN)); w.PK_POST = take(h2_floats(Df, (int)NN));  // transposed packs for the fc1 weight gradient
     w.total = off;
     return w;
 }
@@ -157,7 +159,16 @@ extern "C" int echr_tsrm_fwd(const echr_tsrm_args* a, const echr_dropout* drop, 
     RC(gemm(d, st));
     // pairwise position features -> per-head gates (:39-41, :108-116)
     RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, st));
-    d = desc_nt(w.POS, Df, a->w_fc1, Df, w.P1, Df, NN, Df, Df); d.bias = a->b_fc1; d.act = ECHR_ACT_TANH;
+    // fc1 over the N*N event pairs: the one TSRM product big enough for the h2 path (tanh fused in the epilogue)
+    if (config().gemm_h2 && NN >= 1024) {
+        H2PackJob pj[2] = {pack_rows(w.POS, Df, NN, Df, w.PK_POS), pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1)};
+        RC(h2_pack_multi(pj, 2, st));
+        d = desc_h2(w.PK_POS, w.PK_WFC1, w.P1, Df, NN, Df, Df);
+        d.split_k = 1;
+    } else {
+        d = desc_nt(w.POS, Df, a->w_fc1, Df, w.P1, Df, NN, Df, Df);
+    }
+    d.bias = a->b_fc1; d.act = ECHR_ACT_TANH;
     RC(gemm(d, st));
     d = desc_nt(w.P1, Df, a->w_fc2, Df, w.GATE, G, NN, G, Df); d.bias = a->b_fc2; d.split_k = -1; d.beta = 1.f;
     RC(gemm(d, st));
@@ -245,7 +256,14 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     RC(gemm(d, st));
     d = desc_nn(b.DGATE, G, a->w_fc2, Df, b.DP1, Df, NN, Df, G); d.act = ECHR_ACT_MUL_DTANH; d.aux = w.P1; d.ld_aux = Df;
     RC(gemm(d, st));
-    d = desc_tn(b.DP1, Df, w.POS, Df, g->g_w_fc1, Df, Df, Df, NN); d.beta = zb; d.split_k = -1;
+    if (config().gemm_h2 && NN >= 1024) {
+        H2PackJob pj[2] = {pack_cols(b.DP1, Df, Df, NN, b.PK_DP1T), pack_cols(w.POS, Df, Df, NN, b.PK_POST)};
+        RC(h2_pack_multi(pj, 2, st));
+        d = desc_h2(b.PK_DP1T, b.PK_POST, g->g_w_fc1, Df, Df, Df, NN);
+    } else {
+        d = desc_tn(b.DP1, Df, w.POS, Df, g->g_w_fc1, Df, Df, Df, NN); d.split_k = -1;
+    }
+    d.beta = zb;
     RC(gemm(d, st));
     // event embedding
     d = desc_tn(b.DX, Df, a->ech, Din, g->g_w_emb, Din, Df, Din, N); d.beta = zb; d.split_k = -1;
