@@ -1007,7 +1007,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
                            pack_rows(b.DLG, b.ldg, SN, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
         RC(h2_pack_multi(pj, 4, st));
         d = desc_h2(b.PK_DLGT, b.PK_OUTDT, g->g_w_logit, 3 * H, V1, 3 * H, SN);
-        d.beta = zb;
+        d.split_k = 1;                         // one k slice per tile: a plain overwrite, no read of the (zeroed or stale) 30 MB buffer
         RC(gemm(d, st));
         RC(colsum(b.DLG, b.ldg, SN, V1, g->g_b_logit, z, st));
         d = desc_h2(b.PK_DLG, b.PK_WLT, b.DOUT, 3 * H, SN, 3 * H, V1);
