@@ -106,6 +106,7 @@ SYMBOLS = [
     ('echr_h2_bytes', i64, [i32, i32]),
     ('echr_h2_pack', i32, [c_f, i32, i32, i64, i64, C.c_void_p, C.c_void_p]),
     ('echr_top_proposals', i32, [c_f, c_f, i32, i32, i32, f32, c_f, c_f, c_f, c_f, C.c_void_p]),
+    ('echr_top_proposals_nms', i32, [c_f, i32, i32, i32, C.c_double, c_f, c_f, c_f, c_f, C.c_void_p]),
     ('echr_clamp', i32, [c_f, i64, f32, C.c_void_p]),
     ('echr_clamp_adam', i32, [c_f, c_f, c_f, c_f, i64, i32, C.c_double, C.c_double, C.c_double, C.c_double, f32, C.c_void_p]),
 ]

@@ -280,6 +280,13 @@ int echr_tap_bce_bwd(const float* scores, const float* masks, const float* label
 int echr_top_proposals(const float* scores, const float* mask, int32_t T, int32_t K, int32_t topN, float val_thres,
                        int32_t* out_ind, int32_t* out_feat, float* out_conf, int32_t* out_count, void* stream);
 
+/* Greedy temporal NMS variant (eval_utils.gettop1000_nms, eval_utils.py:290-331): candidates (n, k < min(n,K)) = [n-k, n+1], picked by
+ * descending score until topN, suppressing inclusive-IoU > overlap (float64, the reference's operation order).  Equal scores: the
+ * later candidate wins (the reference's unstable argsort leaves ties undefined).  scratch: T*K floats.  out_feat [topN,2], out_conf
+ * [topN] in pick order; out_count[0] = number of picks. */
+int echr_top_proposals_nms(const float* scores, int32_t T, int32_t K, int32_t topN, double overlap, float* scratch,
+                           int32_t* out_feat, float* out_conf, int32_t* out_count, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused element-wise clamp(+-clip) + Adam (betas, eps, no weight decay, no amsgrad) over a flat
  * buffer.  Replaces misc/utils.py:107-111 + torch.optim.Adam.step as wired at train.py:209,315-317.

@@ -316,6 +316,38 @@ def clamp_adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip
 # proposal selection (index outputs): eval_utils.py:259-287
 # ----------------------------------------------------------------------------------------------
 
+def top_proposals_nms(scores, overlap=0.8, topN=1000):
+    """gettop1000_nms's index outputs: (pick order, props [M,2], scores [M]).  eval_utils.py:290-331: candidates (n, k < min(n, K))
+    -> [n-k, n+1]; greedy 1-D NMS by descending score with the inclusive (+1) temporal IoU, float64 like numpy.  Ties in the score
+    are broken towards the LATER candidate (a stable ascending sort's last element); the reference's unstable argsort leaves that
+    case undefined."""
+    scores = np.asarray(scores)
+    T, K = scores.shape
+    props, sc = [], []
+    for n in range(T):
+        for k in range(min(n, K)):
+            props.append([n - k, n + 1])
+            sc.append(float(scores[n, k]))
+    props = np.array(props).reshape(-1, 2)
+    sc = np.array(sc)
+    if len(sc) == 0:
+        return [], props, sc
+    t1, t2 = props[:, 0], props[:, 1]
+    ind = np.argsort(sc, kind='stable')
+    area = (t2 - t1 + 1).astype(float)
+    pick = []
+    while len(ind) > 0 and len(pick) < topN:
+        i = ind[-1]
+        pick.append(int(i))
+        ind = ind[:-1]
+        tt1 = np.maximum(t1[i], t1[ind])
+        tt2 = np.minimum(t2[i], t2[ind])
+        wh = np.maximum(0., tt2 - tt1 + 1.0)
+        o = wh / (area[i] + area[ind] - wh)
+        ind = ind[np.nonzero(o <= overlap)[0]]
+    return pick, props[pick, :], sc[pick]
+
+
 def top_proposals(scores, tap_masks, topN=1000, score_thres=0.0):
     """gettop1000's index outputs: (index_select_list, featstamp_list, confidence).  eval_utils.py:259-287."""
     scores = np.asarray(scores) * np.asarray(tap_masks)

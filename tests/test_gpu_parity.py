@@ -539,3 +539,22 @@ def test_top_proposals_bit_exact_vs_reference():
         oi, of, oc = O.top_proposals(scores, mask, topN, thr)
         ind, feat, _, _, conf = EU.gettop1000(torch.from_numpy(scores).cuda(), mask, [], 1.0, lambda s, e, n, d: 0, val_score_thres=thr, topN=topN)
         assert ind == oi and feat == of and np.allclose(conf, oc)
+
+
+def test_nms_proposals_bit_exact_vs_reference():
+    """echr_amd.eval_utils.gettop1000_nms (one HIP kernel) against the reference's gettop1000_nms outputs (fixtures) and, on a grid
+    with many tied scores, against the oracle's stable-sort reading of it."""
+    from echr_amd import eval_utils as EU
+    from oracle import echr_ref_cpu as O
+    g = U.gold('proposals.npz')
+    for i in range(3):
+        scores, topN, ov = g['n%d|scores' % i], int(g['n%d|topN' % i]), float(g['n%d|overlap' % i])
+        ind, props, gts, ts, conf = EU.gettop1000_nms(torch.from_numpy(scores).cuda(), None, [], 100.0, lambda s, e, n, d: [s, e], overlap=ov, topN=topN)
+        assert np.array_equal(props, g['n%d|props' % i]) and np.array_equal(conf, g['n%d|conf' % i])
+        assert np.array_equal(ind, props[:, 1] - 1) and ts == [[int(s), int(e)] for s, e in props]
+    rs = np.random.RandomState(3)
+    scores = np.round(rs.uniform(0, 1, size=(70, 24)), 1).astype(np.float32)
+    for ov, topN in ((0.5, 40), (0.95, 2000)):
+        _, oprops, oconf = O.top_proposals_nms(scores, ov, topN)
+        _, props, _, _, conf = EU.gettop1000_nms(torch.from_numpy(scores).cuda(), None, [], 1.0, lambda s, e, n, d: 0, overlap=ov, topN=topN)
+        assert np.array_equal(props, oprops) and np.array_equal(conf, oconf)

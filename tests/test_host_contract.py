@@ -26,7 +26,7 @@ def test_state_dict_contract_and_opt_side_effects():
     assert (opt.TSRM_input_dim, opt.d_pos_vec) == (1012, 512)                                         # MA_attention_8_NEW.py:14-22
     assert sum(v.numel() for v in sd.values()) == 11465343 + 2049 * 5001
     assert m.lm_model.seq_length == opt.CG_seq_length and m.lm_model.vocab_size == opt.CG_vocab_size and m.lm_model.ss_prob == 0.0
-    assert float(m.lm_model.logit.bias.detach().abs().max()) == 0.0 and float(m.lm_model.embed.weight.detach().abs().max()) <= 0.1
+    assert float(m.lm_model.logit.bias.detach().abs().max()) == 0.0 and float(m.lm_model.embed.weight.detach().abs().max()) <= 0.1 + 1e-6   # uniform_(-0.1, 0.1) may round onto fp32(0.1) > 0.1
 
 
 def test_loads_reference_shaped_state_dict():

@@ -87,3 +87,12 @@ def test_sst_restatement_matches_reference():
     assert abs(float(loss.detach()) - float(g['loss'])) < 1e-5
     for k, p in P.items():
         assert U.relerr(p.grad.numpy(), g['grad|' + k]) < 1e-4, k
+
+
+def test_oracle_nms_proposals_match_reference_fixture():
+    """oracle.top_proposals_nms against the reference's gettop1000_nms outputs (tools/make_golden.py do_proposals)."""
+    g = U.gold('proposals.npz')
+    for i in range(3):
+        pick, props, conf = O.top_proposals_nms(g['n%d|scores' % i], float(g['n%d|overlap' % i]), int(g['n%d|topN' % i]))
+        assert np.array_equal(props, g['n%d|props' % i]) and np.array_equal(conf, g['n%d|conf' % i])
+        assert len(pick) <= int(g['n%d|topN' % i])

@@ -250,6 +250,18 @@ def do_proposals():
         out['g%d|topN' % i] = np.int64(topN)
         out['g%d|ind' % i] = np.array(ind, np.int64)
         out['g%d|feat' % i] = np.array(feat, np.int64)
+    # gettop1000_nms (eval_utils.py:290-331): unique scores, so the reference's unstable argsort is deterministic
+    for i, (T, K, topN, ov) in enumerate(((40, 16, 50, 0.8), (96, 64, 100, 0.5), (64, 64, 1000, 0.9))):
+        rs = np.random.RandomState(200 + i)
+        scores = rs.permutation(T * K).reshape(T, K).astype(np.float32) / np.float32(T * K)
+        ind, props, _, ts, sc = ref_eval.gettop1000_nms(scores, None, [], 100.0, lambda s, e, n, d: [s, e], overlap=ov, topN=topN)
+        pick, oprops, osc = O.top_proposals_nms(scores, ov, topN)
+        assert np.array_equal(props, oprops) and np.array_equal(sc, osc) and np.array_equal(ind, oprops[:, 1] - 1)
+        out['n%d|scores' % i] = scores
+        out['n%d|topN' % i] = np.int64(topN)
+        out['n%d|overlap' % i] = np.float64(ov)
+        out['n%d|props' % i] = np.asarray(props, np.int64)
+        out['n%d|conf' % i] = np.asarray(sc, np.float64)
     np.savez_compressed(os.path.join(GOLD, 'proposals.npz'), **out)
     print('wrote proposals.npz')
 
@@ -310,9 +322,13 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', nargs='*', default=['tiny', 'c1', 'c2', 'c2full'])
     ap.add_argument('--skip-aux', action='store_true')
+    ap.add_argument('--only', choices=['position', 'adam', 'proposals', 'checkpoint', 'sst'], help='regenerate one auxiliary fixture only')
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
+    if a.only:
+        {'position': do_position, 'adam': do_adam, 'proposals': do_proposals, 'checkpoint': do_checkpoint, 'sst': do_sst}[a.only]()
+        sys.exit(0)
     if not a.skip_aux:
         do_position()
         do_adam()
