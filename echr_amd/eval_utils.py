@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from .misc import utils
 
 
 def top_proposals_device(pred_proposals, tap_masks, topN=1000, val_score_thres=0.0):
@@ -68,3 +69,46 @@ def gettop1000_nms(pred_proposals, tap_masks, cg_gts, duration, featstamp_to_tim
     prop_gts = np.array([cg_gts[e - 1, e - 1 - s] for s, e in props]) if len(cg_gts) else np.array([])
     timestamp_list = [featstamp_to_time(s, e, T, duration) for (s, e) in props]
     return props[:, 1] - 1, props, prop_gts, timestamp_list, nms_scores
+
+
+def caption_video(tap_model, cg_model, c3d_feats, lda_feats, duration, featstamp_to_time, vocab=None, tap_masks=None, cg_gts=(),
+                  topN=1000, nms_threshold=0.0, val_score_thres=0.0, flag_eval_what='tap_cg'):
+    """One video through the reference's evaluation flow (eval_utils.py:51-53,106-167 for flag_eval_what 'tap_cg' / 'tap'):
+    SST -> proposal selection (greedy NMS when nms_threshold != 0, else score threshold) -> greedy captions -> the per-proposal
+    records of result.json.  Everything between the two host reads (proposal count, caption lengths) stays on the GPU.
+
+    Returns (vid_info, extras): vid_info is the reference's list of dicts (sentence, timestamp, sentence_confidence, proposal_score,
+    re_score, num); extras carries the tensors (tap_feats, pred_proposals, seq, ind_select_list, soi_select_list)."""
+    if not c3d_feats.is_cuda:
+        raise L.EchrHipError('caption_video runs on the GPU: move the models and features with .cuda()')
+    nfeats = c3d_feats.shape[0]
+    with torch.no_grad():
+        tap_feats, pred_proposals = tap_model(c3d_feats)
+        if tap_masks is None:
+            K = pred_proposals.shape[1]
+            tap_masks = (np.arange(nfeats)[:, None] >= np.arange(K)[None, :]).astype(np.float32)
+        if nms_threshold != 0:
+            ind_select_list, soi_select_list, cg_select_list, good_time_stamps, tap_prob = gettop1000_nms(
+                pred_proposals, tap_masks, cg_gts, duration, featstamp_to_time, overlap=nms_threshold, topN=topN)
+        else:
+            ind_select_list, soi_select_list, cg_select_list, good_time_stamps, tap_prob = gettop1000(
+                pred_proposals, tap_masks, cg_gts, duration, featstamp_to_time, val_score_thres=val_score_thres, topN=topN)
+        extras = dict(tap_feats=tap_feats, pred_proposals=pred_proposals, ind_select_list=ind_select_list, soi_select_list=soi_select_list,
+                      seq=None, cg_prob=None)
+        n = len(ind_select_list)
+        if n == 0:
+            return [], extras
+        if flag_eval_what == 'tap':
+            sents, cg_score = [0] * n, [0] * n
+        else:
+            seq, cg_prob = cg_model(tap_feats, c3d_feats, lda_feats, [], ind_select_list, soi_select_list, mode='eval')
+            if len(seq) == 0:
+                return [], extras
+            extras['seq'], extras['cg_prob'] = seq, cg_prob
+            cg_score = cg_prob.sum(1).cpu().numpy().astype('float')
+            sents = utils.decode_sequence(vocab, seq) if vocab is not None else [row[row > 0].tolist() for row in seq.cpu().numpy()]
+    vid_info = []
+    for i, sent in enumerate(sents):
+        vid_info.append({'sentence': sent, 'timestamp': good_time_stamps[i], 'sentence_confidence': cg_score[i],
+                         'proposal_score': float(tap_prob[i]), 're_score': 10 * float(tap_prob[i]) + cg_score[i], 'num': [i, len(sents)]})
+    return vid_info, extras

@@ -558,3 +558,47 @@ def test_nms_proposals_bit_exact_vs_reference():
         _, oprops, oconf = O.top_proposals_nms(scores, ov, topN)
         _, props, _, _, conf = EU.gettop1000_nms(torch.from_numpy(scores).cuda(), None, [], 1.0, lambda s, e, n, d: 0, overlap=ov, topN=topN)
         assert np.array_equal(props, oprops) and np.array_equal(conf, oconf)
+
+
+@pytest.mark.parametrize('nms', [0.0, 0.6])
+def test_eval_flow_sst_to_captions_vs_oracle(nms):
+    """eval_utils.caption_video (SST -> proposal selection -> greedy captions, eval_utils.py:51-167) against the same chain built from
+    the oracle's pieces on the host: identical proposals (integers), identical token sequences, scores within 1e-4."""
+    from echr_amd import eval_utils as EU, models as EM
+    from oracle import echr_ref_cpu as O
+    opt, params, vid = synth.make_case('c1')
+    opt.K = 8
+    cg = U.build_gpu_model(opt, params, False)
+    torch.manual_seed(3)
+    tap = EM.setup_tap(opt).cuda()
+    tap.eval()                                   # the reference's SST.eval() returns None (sst_model.py:25-29)
+    dev = torch.device('cuda')
+    rs = np.random.RandomState(11)
+    T = 24
+    c3d = rs.standard_normal((T, opt.video_dim)).astype(np.float32)
+    lda = rs.standard_normal(opt.video_context_dim).astype(np.float32)
+    f2t = lambda s, e, n, d: [round(float(s) / n * d, 3), round(float(e) / n * d, 3)]
+    info, ex = EU.caption_video(tap, cg, torch.from_numpy(c3d).to(dev), torch.from_numpy(lda).to(dev), 60.0, f2t, topN=12,
+                                nms_threshold=nms)
+    # host chain from the oracle's pieces
+    P_tap = {k: v.detach().cpu() for k, v in tap.state_dict().items()}
+    tap_o, sc_o = O.sst_forward(P_tap, torch.from_numpy(c3d))
+    assert np.abs(ex['pred_proposals'].cpu().numpy() - sc_o.numpy()).max() < 1e-5
+    sc_dev = ex['pred_proposals'].cpu().numpy()                        # selection is discontinuous in the scores: feed both the same ones
+    masks = (np.arange(T)[:, None] >= np.arange(opt.K)[None, :]).astype(np.float32)
+    if nms:
+        _, props, conf = O.top_proposals_nms(sc_dev, nms, 12)
+        ind, soi = (props[:, 1] - 1).tolist(), props.tolist()
+    else:
+        ind, soi, conf = O.top_proposals(sc_dev, masks, 12, 0.0)
+    assert [list(map(int, x)) for x in ex['soi_select_list']] == [list(map(int, x)) for x in soi] and len(info) == len(ind)
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    assert np.abs(ex['tap_feats'].cpu().numpy() - tap_o.numpy()).max() < 1e-5
+    seq_o, lp_o = O.caption_forward(P, ex['tap_feats'].cpu(), torch.from_numpy(c3d), torch.from_numpy(lda), None, ind, soi, mode='eval',
+                                    seq_length=opt.CG_seq_length)
+    assert np.array_equal(ex['seq'].cpu().numpy(), seq_o.numpy())
+    for i, rec in enumerate(info):
+        assert rec['timestamp'] == f2t(soi[i][0], soi[i][1], T, 60.0) and rec['num'] == [i, len(info)]
+        assert abs(rec['proposal_score'] - float(conf[i])) < 1e-6
+        assert abs(rec['sentence_confidence'] - float(lp_o[i].sum())) < 1e-3
+        assert rec['sentence'] == [int(t) for t in seq_o[i].numpy() if t > 0]
