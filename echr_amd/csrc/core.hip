@@ -392,9 +392,37 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __rest
     }
     for (int j = V1 + threadIdx.x; j < ldo; j += 256) o[j] = 0.f;
 }
+// dense-G form with the row of G held in registers: one read of G and logp, one write (rows of up to 256 * EPT columns)
+template <int EPT>
+__global__ __launch_bounds__(256) void logsoftmax_bwd_reg_kernel(const float* __restrict__ logp, const float* __restrict__ G,
+                                                                 float* __restrict__ out, long ldo, int N, int S, int V1) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;             // time-major row = t*N + n
+    const int t = row / N, n = row % N;
+    const long src = ((long)n * S + t) * V1;
+    float* o = out + (long)row * ldo;
+    float g[EPT], lp[EPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int j = threadIdx.x + i * 256;
+        g[i] = j < V1 ? G[src + j] : 0.f;
+        lp[i] = j < V1 ? logp[src + j] : -INFINITY;
+        s += g[i];
+    }
+    s = block_sum(s, red);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int j = threadIdx.x + i * 256;
+        if (j < V1) o[j] = g[i] - expf(lp[i]) * s;
+        else if (j < ldo) o[j] = 0.f;
+    }
+}
 int logsoftmax_bwd(const float* logp, const float* G, const int* target, const float* mask, const float* g_loss,
                    const float* mask_sum, float* out, long ldo, int N, int S, int V1, hipStream_t st) {
-    hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(N * S), dim3(256), 0, st, logp, G, target, mask, g_loss, mask_sum, out, ldo, N, S, V1);
+    if (G && ldo <= 256 * 20 && ldo > 256 * 8) hipLaunchKernelGGL(logsoftmax_bwd_reg_kernel<20>, dim3(N * S), dim3(256), 0, st, logp, G, out, ldo, N, S, V1);
+    else if (G && ldo <= 256 * 8) hipLaunchKernelGGL(logsoftmax_bwd_reg_kernel<8>, dim3(N * S), dim3(256), 0, st, logp, G, out, ldo, N, S, V1);
+    else hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(N * S), dim3(256), 0, st, logp, G, target, mask, g_loss, mask_sum, out, ldo, N, S, V1);
     return check_launch("logsoftmax_bwd");
 }
 

@@ -134,7 +134,10 @@ class OldModel(nn.Module):
             raise ValueError('label tensor needs at least two columns')
         dev = event.device
         seq_t = torch.as_tensor(np.asarray(seq) if not isinstance(seq, torch.Tensor) else seq)
-        tokens = seq_t[:, :S].t().to(device=dev, dtype=torch.int32).contiguous()          # [S,N] time-major
+        if seq_t.is_cuda:
+            tokens = seq_t[:, :S].t().to(device=dev, dtype=torch.int32).contiguous()      # [S,N] time-major
+        else:       # host labels: slice / transpose / cast on the host, ONE small H2D copy instead of three device ops
+            tokens = seq_t[:, :S].t().to(torch.int32).contiguous().to(dev, non_blocking=True)
         if drop is None:
             drop = self.next_drop_state()
         arena = getattr(self, '_echr_arena_ref', None)
