@@ -143,13 +143,16 @@ def gpu_leg(args, rank, world, local_rank):
     say('timed region done: %.3f s for %d steps' % (dt, args.steps))
 
     roof = None
-    if rank == 0 and not args.no_roofline:
-        # second, instrumented pass over the same iterations: HIP events around every launch of each kernel class
+    if not args.no_roofline:
+        # second, instrumented pass over the same iterations: HIP events around every launch of each kernel class.  EVERY rank runs
+        # the iterations (they contain the gradient collectives); only rank 0 instruments and reports.
         lib = _lib.load()
-        lib.echr_prof_enable(1)
+        if rank == 0:
+            lib.echr_prof_enable(1)
         for _ in range(max(2, min(args.steps, 5))):
             iteration()
-        torch.cuda.synchronize()
+        fence()
+    if rank == 0 and not args.no_roofline:
         # kernel classes of libechr_hip.so (echr_prof_read kinds) -> (name, rocprof kernel symbol, bound)
         kinds = {0: ('gemm_f32_kernel', 'gemm_f32_kernel<*> (all tile/layout instantiations)', 'mfma'),
                  7: ('gemm_h2_kernel', 'gemm_h2_kernel<128, 32>', 'mfma'),
