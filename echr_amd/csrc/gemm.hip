@@ -331,7 +331,7 @@ __device__ __forceinline__ void split_load(float4 (&r)[ROWS * 8 / NT], const flo
 // 128 x BN tile, 2 x (BN/32) waves of 64x32 wave tiles (8 waves for BN = 128, 4 for BN = 64); <= 128 VGPRs so that several
 // workgroups (4 waves per SIMD) share a CU and one wave's operand splitting (VALU) overlaps the other waves' MFMAs.
 template <int BN>
-__global__ __launch_bounds__(BN * 4, 4) void gemm_split_kernel(GemmParams pin) {
+__global__ __launch_bounds__(BN * 4, BN == 128 ? 4 : 2) void gemm_split_kernel(GemmParams pin) {
     constexpr int BM = 128, NT = BN * 4, WN_CNT = BN / 32;
     int z = blockIdx.z;
     const GemmParams p = select_group(pin, z);
