@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void logsoftmax_rows_reg_kernel(float* __restr
     m = block_max(m, red);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) s += (threadIdx.x + i * 256 < cols) ? expf(v[i] - m) : 0.f;
+    for (int i = 0; i < EPT; ++i) s += ((int)threadIdx.x + i * 256 < cols) ? expf(v[i] - m) : 0.f;
     s = block_sum(s, red);
     const float lse = m + logf(s);
 #pragma unroll

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void sst_wave_fwd_kernel(SstFwdRole r0, SstFwd
         }
     }
     __syncthreads();
-    if (threadIdx.x < UPW && u0 + threadIdx.x < H) {
+    if (threadIdx.x < UPW && u0 + (int)threadIdx.x < H) {
         const int i = threadIdx.x, u = u0 + i;
         const float gi = fast_sigmoid(pre[i]), gf = fast_sigmoid(pre[UPW + i]), gg = tanhf(pre[2 * UPW + i]), go = fast_sigmoid(pre[3 * UPW + i]);
         const float c = gf * (r.cprev ? r.cprev[u] : 0.f) + gi * gg;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void sst_wave_bwd_kernel(SstBwdRole r0, SstBwd
         if (lane == 0) part[m * UPW + i] = d;
     }
     __syncthreads();
-    if (threadIdx.x < UPW && u0 + threadIdx.x < H) {
+    if (threadIdx.x < UPW && u0 + (int)threadIdx.x < H) {
         const int i = threadIdx.x, u = u0 + i;
         float first = part[i];
         if (r.drop_first) first *= drop_mult(dcfg, (unsigned)(r.t * H + u), 0u, SITE_SST);
