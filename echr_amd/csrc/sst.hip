@@ -64,6 +64,9 @@ __global__ __launch_bounds__(256) void sst_wave_fwd_kernel(SstFwdRole r0, SstFwd
     float* pre = sm + 2 * H;         // [4][UPW]
     const int u0 = blockIdx.x * UPW;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the finishing threads fetch their cell state now: the load overlaps the GEMV instead of trailing it
+    float cprev_v = 0.f;
+    if (threadIdx.x < UPW && u0 + (int)threadIdx.x < H && r.cprev) cprev_v = r.cprev[u0 + threadIdx.x];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
         if (r.v[m]) for (int k = threadIdx.x; k < H; k += 256) sv[m * H + k] = r.v[m][k];
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void sst_wave_fwd_kernel(SstFwdRole r0, SstFwd
     if (threadIdx.x < UPW && u0 + (int)threadIdx.x < H) {
         const int i = threadIdx.x, u = u0 + i;
         const float gi = fast_sigmoid(pre[i]), gf = fast_sigmoid(pre[UPW + i]), gg = tanhf(pre[2 * UPW + i]), go = fast_sigmoid(pre[3 * UPW + i]);
-        const float c = gf * (r.cprev ? r.cprev[u] : 0.f) + gi * gg;
+        const float c = gf * cprev_v + gi * gg;
         const float h = go * tanhf(c);
         r.act[u] = gi; r.act[H + u] = gf; r.act[2 * H + u] = gg; r.act[3 * H + u] = go;
         r.cout[u] = c; r.hout[u] = h;
@@ -126,6 +129,14 @@ __global__ __launch_bounds__(256) void sst_wave_bwd_kernel(SstBwdRole r0, SstBwd
     float* part = sm + 8 * H;        // [2][UPW]
     const int u0 = blockIdx.x * UPW;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the finishing threads fetch their cell operands now: the loads overlap the two dot products instead of trailing them
+    float p_base = 0.f, p_gi = 0.f, p_gf = 0.f, p_gg = 0.f, p_go = 0.f, p_c = 0.f, p_cprev = 0.f, p_dc = 0.f;
+    if (threadIdx.x < UPW && u0 + (int)threadIdx.x < H) {
+        const int u = u0 + threadIdx.x;
+        p_base = r.dh_base ? r.dh_base[u] : 0.f;
+        p_gi = r.act[u]; p_gf = r.act[H + u]; p_gg = r.act[2 * H + u]; p_go = r.act[3 * H + u];
+        p_c = r.c[u]; p_cprev = r.cprev ? r.cprev[u] : 0.f; p_dc = r.dc[u];
+    }
     // both vectors staged with float4 loads issued back to back (H % 4 == 0 and 256-byte aligned rows: checked on the host)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -144,12 +155,12 @@ __global__ __launch_bounds__(256) void sst_wave_bwd_kernel(SstBwdRole r0, SstBwd
         const int i = threadIdx.x, u = u0 + i;
         float first = part[i];
         if (r.drop_first) first *= drop_mult(dcfg, (unsigned)(r.t * H + u), 0u, SITE_SST);
-        const float dh = (r.dh_base ? r.dh_base[u] : 0.f) + first + part[UPW + i];
-        const float gi = r.act[u], gf = r.act[H + u], gg = r.act[2 * H + u], go = r.act[3 * H + u];
-        const float tc = tanhf(r.c[u]);
-        const float dcv = dh * go * (1.f - tc * tc) + r.dc[u];
+        const float dh = p_base + first + part[UPW + i];
+        const float gi = p_gi, gf = p_gf, gg = p_gg, go = p_go;
+        const float tc = tanhf(p_c);
+        const float dcv = dh * go * (1.f - tc * tc) + p_dc;
         r.dg[u] = dcv * gg * gi * (1.f - gi);
-        r.dg[H + u] = dcv * (r.cprev ? r.cprev[u] : 0.f) * gf * (1.f - gf);
+        r.dg[H + u] = dcv * p_cprev * gf * (1.f - gf);
         r.dg[2 * H + u] = dcv * gi * (1.f - gg * gg);
         r.dg[3 * H + u] = dh * tc * go * (1.f - go);
         r.dc[u] = dcv * gf;
