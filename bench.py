@@ -157,7 +157,7 @@ def gpu_leg(args, rank, world, local_rank):
         kinds = {0: ('gemm_f32_kernel', 'gemm_f32_kernel<*> (all tile/layout instantiations)', 'mfma'),
                  7: ('gemm_h2_kernel', 'gemm_h2_kernel<128, 32>', 'mfma'),
                  6: ('gemm_split_kernel', 'gemm_split_kernel', 'mfma'),
-                 4: ('rec_gemm_kernel', 'rec_gemm_kernel<1>', 'mfma'),
+                 4: ('rec_gemm_kernel', 'rec_gemm_kernel', 'mfma'),
                  8: ('h2_pack_kernel', 'h2_pack_kernel', 'hbm'),
                  1: ('att_fwd', 'att_score_kernel + att_context_kernel', 'hbm'),
                  2: ('att_bwd_kernel', 'att_bwd_kernel', 'hbm'),

@@ -476,15 +476,11 @@ struct RecJob {
 };
 struct RecArgs { RecJob job[MAXJOBS]; int njobs; int M; };
 
-// KW = wave groups along k inside a workgroup: the 128-wide slice is cut into KW sub-slices, each multiplied by its own 2x2 waves
-// (the dependent MFMA chain of a wave shrinks from 64 to 64/KW instructions); groups 1..KW-1 hand their tiles over through LDS.
-template <int KW>
-__global__ __launch_bounds__(256 * KW, 2) void rec_gemm_kernel(RecArgs args) {
-    constexpr int NT = 256 * KW;
-    __shared__ __attribute__((aligned(16))) float smem[2 * 64 * RLD];      // 67,584 B: A tile | B tile, later the k-group hand-over
+__global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
+    constexpr int NT = 256;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 64 * RLD];      // 67,584 B: A tile | B tile
     float* As = smem;
     float* Bs = smem + 64 * RLD;
-    static_assert((KW - 1) * 16 * 256 <= 2 * 64 * RLD, "hand-over buffer must fit the operand tiles");
     const int jz = blockIdx.z % args.njobs, rb = blockIdx.z / args.njobs;
     const RecJob J = args.job[jz];
     const int n0 = blockIdx.x * 64, k0 = blockIdx.y * RK, m0 = rb * 64;
@@ -493,7 +489,7 @@ __global__ __launch_bounds__(256 * KW, 2) void rec_gemm_kernel(RecArgs args) {
     const int tid = threadIdx.x;
     // branch-free staging: every lane loads from a clamped (always valid) address and zeroes what lies outside the
     // problem, so all global loads of a thread are in flight together before the first LDS write
-    constexpr int LP = RLP / KW;
+    constexpr int LP = RLP;
     float4 va[LP], vb[LP];
 #pragma unroll
     for (int p = 0; p < LP; ++p) {
@@ -518,38 +514,24 @@ __global__ __launch_bounds__(256 * KW, 2) void rec_gemm_kernel(RecArgs args) {
         *reinterpret_cast<float4*>(&Bs[row * RLD + kq]) = b;
     }
     __syncthreads();
-    const int lane = tid & 63, wave = (tid >> 6) & 3, kg = tid >> 8;
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int l31 = lane & 31, h = lane >> 5;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* ap = &As[(wm + l31) * RLD + 4 * h + kg * (RK / KW)];
-    const float* bp = &Bs[(wn + l31) * RLD + 4 * h + kg * (RK / KW)];
-    // the whole sub-slice is always multiplied (tails are zero-filled): a fixed trip count lets the compiler
+    const float* ap = &As[(wm + l31) * RLD + 4 * h];
+    const float* bp = &Bs[(wn + l31) * RLD + 4 * h];
+    // the whole slice is always multiplied (tails are zero-filled): a fixed trip count lets the compiler
     // hoist the LDS fragment reads ahead of the MFMA chain
 #pragma unroll
-    for (int c = 0; c < RK / KW / 8; ++c) {
+    for (int c = 0; c < RK / 8; ++c) {
         const float4 a4 = *reinterpret_cast<const float4*>(ap + 8 * c);
         const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * c);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
-    }
-    if (KW > 1) {       // k groups 1.. park their tiles in LDS (the operand tiles are dead by now), group 0 sums in a fixed order
-        __syncthreads();
-        float* red = smem;                   // [KW-1][16][256] floats
-        if (kg > 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((kg - 1) * 16 + r) * 256 + (tid & 255)] = acc[r];
-        }
-        __syncthreads();
-        if (kg > 0) return;
-#pragma unroll
-        for (int g = 1; g < KW; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += red[((g - 1) * 16 + r) * 256 + tid];
     }
     float* P = J.P + (J.atomic ? 0L : (long)blockIdx.y * J.slab_stride);
     const int col = n0 + wn + l31;
@@ -580,11 +562,7 @@ static int rec_gemm(const RecArgs& a, hipStream_t st) {
         by += 4.0 * ((double)a.M * J.K + (double)J.Nout * J.K + (double)a.M * J.Nout * ksplit_of(J.K));
     }
     ProfScope prof(PROF_LSTM, fl, by, st);
-    static const int kw = getenv("ECHR_REC_KW") ? atoi(getenv("ECHR_REC_KW")) : 1;
-    const dim3 grid(maxn, maxk, a.njobs * ((a.M + 63) / 64));
-    if (kw == 4) hipLaunchKernelGGL(rec_gemm_kernel<4>, grid, dim3(1024), 0, st, a);
-    else if (kw == 2) hipLaunchKernelGGL(rec_gemm_kernel<2>, grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(rec_gemm_kernel<1>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(rec_gemm_kernel, dim3(maxn, maxk, a.njobs * ((a.M + 63) / 64)), dim3(256), 0, st, a);
     return check_launch("rec_gemm");
 }
 
