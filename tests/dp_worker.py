@@ -1,0 +1,51 @@
+"""Worker of test_two_rank_data_parallel_on_one_gpu: one data-parallel rank (gloo transport, both ranks on cuda:0)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    rank, world, port, out, overlap = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5] == '1'
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', port
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import echr_amd
+    from echr_amd import parallel, synth
+    from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+    from echr_amd.optim import ClampAdam
+    from tests import util as U
+    dev = torch.device('cuda', 0)
+    opt, params, _ = synth.make_case('c1')
+    model = U.build_gpu_model(opt, params, True)
+    arena = model.build_arena()
+    if overlap:
+        parallel.enable_overlap(model)
+    optim = ClampAdam(model.parameters(), lr=1e-3, arena=arena)
+    crit = LanguageModelCriterion()
+    for step in range(2):
+        vid = synth.make_video(2, 16, 11, opt.CG_vocab_size + 1, seed=500 + 10 * step + rank, T_v=40, video_dim=opt.video_dim,
+                               hidden_dim=opt.hidden_dim, lda_dim=opt.video_context_dim)
+        tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+        labels = torch.from_numpy(vid['labels'])
+        model.set_dropout_state(U.SEED, U.OFFSET + 10 * step + rank)
+        optim.zero_grad()
+        loss = crit(model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), labels[:, 1:].to(dev),
+                    torch.from_numpy(vid['masks'])[:, 1:].to(dev))
+        loss.backward()
+        n = parallel.allreduce_gradients(model)
+        if step == 0:
+            torch.cuda.synchronize()
+            grads = {'grad|' + k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+        clip_gradient(optim, 0.05)
+        optim.step()
+    torch.cuda.synchronize()
+    np.savez(out, n_collectives=n, **grads, **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

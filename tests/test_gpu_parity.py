@@ -3,6 +3,8 @@ inputs and against the golden fixtures generated from the reference (tests/golde
 
 Tolerances (north_star): log-probs / losses within 1e-4 relative of the reference's PyTorch-CPU path; index
 outputs bit-exact.  Gradients: 1e-3 of each tensor's max-norm (fp32 atomics reorder sums; measured ~1e-6)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -602,3 +604,45 @@ def test_eval_flow_sst_to_captions_vs_oracle(nms):
         assert abs(rec['proposal_score'] - float(conf[i])) < 1e-6
         assert abs(rec['sentence_confidence'] - float(lp_o[i].sum())) < 1e-3
         assert rec['sentence'] == [int(t) for t in seq_o[i].numpy() if t > 0]
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_two_rank_data_parallel_on_one_gpu(tmp_path, overlap):
+    """Two data-parallel ranks (separate processes, gloo transport, both on cuda:0) run two optimiser steps on different videos:
+    both ranks must end with IDENTICAL parameters, equal to one process that accumulates the two videos' gradients before each
+    step (the reference's m_batch = 2, train.py:281-283,313-317) -- with the staged early all-reduce on and off."""
+    import socket
+    import subprocess
+    import sys as _sys
+    from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+    from echr_amd.optim import ClampAdam
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = str(s.getsockname()[1]); s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = [str(tmp_path / ('rank%d.npz' % r)) for r in range(2)]
+    procs = [subprocess.Popen([_sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), str(r), '2', port, outs[r], '1' if overlap else '0'],
+                              cwd=root) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    r0, r1 = np.load(outs[0]), np.load(outs[1])
+    assert int(r0['n_collectives']) == (4 if overlap else 1)
+    for k in synth.state_dict_shapes(synth.make_case('c1')[0]):
+        assert np.array_equal(r0[k], r1[k]), k                               # replicas stay bitwise identical after two steps
+    # one process accumulating the two videos' gradients of step 0 (same initial parameters)
+    dev = torch.device('cuda')
+    opt, params, _ = synth.make_case('c1')
+    model = U.build_gpu_model(opt, params, True)
+    crit = LanguageModelCriterion()
+    for rank in range(2):
+        vid = synth.make_video(2, 16, 11, opt.CG_vocab_size + 1, seed=500 + rank, T_v=40, video_dim=opt.video_dim,
+                               hidden_dim=opt.hidden_dim, lda_dim=opt.video_context_dim)
+        tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+        labels = torch.from_numpy(vid['labels'])
+        model.set_dropout_state(U.SEED, U.OFFSET + rank)
+        crit(model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), labels[:, 1:].to(dev),
+             torch.from_numpy(vid['masks'])[:, 1:].to(dev)).backward()
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            assert 'grad|' + k not in r0.files, k
+        else:
+            assert np.array_equal(r0['grad|' + k], r1['grad|' + k]), k
+            assert U.grad_close(k, r0['grad|' + k], p.grad.detach().cpu().numpy(), 1e-5), k     # SUM over ranks == accumulation, no 1/R
