@@ -651,6 +651,7 @@ struct DecWs {
     float *QSL, *GSL[3];         // split-K slabs of the current timestep (q and the three gate blocks)
     float *QACC;                 // [S,N,Ha] atomic accumulation target of q (teacher-forced path)
     float *PK_C3D, *PK_WC, *PK_WIH[3], *PK_WL, *PK_XT, *PK_OUTD;     // h2-packed GEMM operands of the forward pass
+    float *XWS;                  // exchange buffers + counters of the persistent recurrence kernel (csrc/persist.hip)
     int nq, ng[3];
     long total;
 };
@@ -683,6 +684,7 @@ static DecWs carve_ws(const echr_dec_args* a, float* base) {
     w.PK_WL = take(h2_floats(a->V1, 3 * a->H));
     w.PK_XT = take(h2_floats((int)(S * N), a->E));
     w.PK_OUTD = take(h2_floats((int)(S * N), 3 * a->H));
+    w.XWS = take(persist_fwd_ws_floats((int)S));
     w.total = off;
     return w;
 }
@@ -881,6 +883,7 @@ extern "C" int64_t echr_decoder_ws_floats(const echr_dec_args* a) { return a ? c
 extern "C" int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a) { return a ? carve_ws_bwd(a, nullptr).total : -1; }
 
 extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream) {
+    RC(persist_check_async());
     RC(check_dims(a, "decoder_fwd"));
     ECHR_REQUIRE(a->S > 0 && a->ws && a->logp && a->tokens, "decoder_fwd: missing buffers");
     hipStream_t st = (hipStream_t)stream;
@@ -914,7 +917,13 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
     const bool two = config().chains2 == 1 && side().ok && S >= 2;     // streams 0/2 recur on the side stream
     const bool ov = !two && overlap_enabled() && S >= 4;
     const int th = ov ? S / 2 : 0;
-    if (two) {
+    if (persist_fwd_eligible(a) && !ov && !two) {
+        // all S timesteps in ONE persistent launch: recurrent weights stay in LDS, attention operands in registers (csrc/persist.hip)
+        PersistFwdBufs pb;
+        for (int k = 0; k < 3; ++k) { pb.GATES[k] = w.GATES[k]; pb.CS[k] = w.CS[k]; }
+        pb.HS = w.HS; pb.OUTD = w.OUTD; pb.QS = w.QS; pb.WT = w.WT; pb.ATT = w.ATT; pb.PALL = w.PALL; pb.xws = w.XWS;
+        RC(persist_fwd(a, pb, dh, dout, st));
+    } else if (two) {
         RC(hop(st, side().fork, side().s));
         for (int t = 0; t < S; ++t) RC(step_fwd(a, w, t, dh, dout, side().s, 2, true));
         for (int t = 0; t < S; ++t) RC(step_fwd(a, w, t, dh, dout, st, 1, true));
@@ -934,6 +943,7 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
 }
 
 extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream) {
+    RC(persist_check_async());
     RC(check_dims(a, "decoder_bwd"));
     ECHR_REQUIRE(g && a->ws && g->ws_bwd && a->logp, "decoder_bwd: missing buffers");
     ECHR_REQUIRE(g->g_logp || (g->nll_target && g->nll_mask && g->g_loss), "decoder_bwd: need g_logp or the fused NLL inputs");

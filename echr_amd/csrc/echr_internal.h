@@ -7,7 +7,7 @@ namespace echr {
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 // Disabled by default: ProfScope is then a no-op.  Events are resolved in echr_prof_read after a stream sync.
-enum ProfKind { PROF_GEMM = 0, PROF_ATT_FWD = 1, PROF_ATT_BWD = 2, PROF_ATT_POST = 3, PROF_LSTM = 4, PROF_OTHER = 5, PROF_GEMM_SPLIT = 6, PROF_GEMM_H2 = 7, PROF_PACK = 8, PROF_KINDS = 9 };
+enum ProfKind { PROF_GEMM = 0, PROF_ATT_FWD = 1, PROF_ATT_BWD = 2, PROF_ATT_POST = 3, PROF_LSTM = 4, PROF_OTHER = 5, PROF_GEMM_SPLIT = 6, PROF_GEMM_H2 = 7, PROF_PACK = 8, PROF_PERSIST = 9, PROF_KINDS = 10 };
 struct ProfScope {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t st;
@@ -17,10 +17,18 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; };
 Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);
+
+// persistent (one launch for all timesteps) recurrence of the decoder, csrc/persist.hip
+struct DropCfg;
+struct PersistFwdBufs { float* GATES[3]; float* CS[3]; float *HS, *OUTD, *QS, *WT, *ATT, *PALL, *xws; };
+long persist_fwd_ws_floats(int S);
+bool persist_fwd_eligible(const echr_dec_args* a);
+int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
+int persist_check_async();
 int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st);
 // h2-packed operands (csrc/gemm.hip: two block-scaled fp16 planes): bytes of the packed image of a [rows x cols] operand (cols =
 // contraction axis), the packing pass, and a multi-operand packing launch

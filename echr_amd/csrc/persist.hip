@@ -1,0 +1,612 @@
+// Weights-stationary PERSISTENT recurrence of the three-stream decoder (forward): all S timesteps in ONE launch.
+//
+// Reference semantics: models/OldModel_NEW.py:801-823 (ThreeStream_Core.forward), :376-401 (Attention.forward), :105-130 (the
+// teacher-forced loop).  The launch-per-phase path (decoder.hip: step_fwd) runs five dependent launches per timestep, each of
+// which re-streams the 17.7 MB of time-invariant recurrent weights and 33 MB of attention operands; at 3-9 us of work per launch
+// the ~2 us launch boundaries and the re-streaming dominate.  Here:
+//   * 256 workgroups (one per CU, 256 threads = one wave per SIMD) stay resident for the whole sequence;
+//   * the recurrent weights live in LDS for all S steps, pre-arranged as MFMA B fragments (W_hh1 + W_ih1[:,E:] on 128 "gate"
+//     workgroups of 4 hidden units each, W_h2a on 32 "q" workgroups of 16 columns, W_hh0 / W_hh2 on 32 workgroups of 16 units each);
+//   * the attention operands live in REGISTERS for all S steps: event n's P_all and C3D rows are split over 3 workgroups
+//     (43 slots each, 11 per wave, 8 features per lane: 176 VGPRs);
+//   * per timestep the attention chain makes three all-to-all hand-offs (h1 -> q -> context -> h1), the two plain LSTM streams
+//     one each, on their own clock.  A hand-off is: write-through (sc1) stores -> every storing wave s_waitcnt vmcnt(0) ->
+//     workgroup barrier -> ONE lane's agent-scope atomic add on a per-(edge, timestep) counter sharded 8 ways; the consumer polls
+//     the shards with sc1 loads, joins a workgroup barrier and reads the payload with 16-byte sc1 loads (MI355X_MICROARCH.md,
+//     inter-workgroup visibility, table row 1; measured 2.65 us per hop + 2.5 us per 128 KB ingest, tools/micro/hop_bench.hip).
+//     Every exchanged address is written once per launch and read only after its counter is complete; counters are never reused
+//     inside a launch and are zeroed by a memset node ahead of it.  Every spin is bounded: a timeout raises an abort word that all
+//     pollers watch, the grid drains, and the host sees a sticky error at its next library call.
+//   * the softmax over an event's slots is split over 3 workgroups without an exchange: scores are alpha . tanh(.) (+ b_alpha, which
+//     cancels), so exp(score) needs no max-shift while sum|alpha| is moderate; the unnormalised context and the sum of exponentials
+//     are added atomically per event and normalised by the consumer.  When sum|alpha| > 40 the three workgroups of an event first
+//     exchange their local maxima through 8-byte {tag, value} granules (exact max-shifted softmax).
+// Products are exact fp32 (v_mfma_f32_16x16x4_f32).  Saved activations (GATES, CS, HS, OUTD, QS, WT, ATT) are written in the layouts
+// the backward pass and the batched projections expect, off the critical path (after the hand-off is published).
+#include "echr_common.h"
+#include "echr_internal.h"
+
+namespace echr {
+
+typedef unsigned u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define ECHR_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+namespace {
+
+constexpr int PH = 512;                 // H = Ha = K of every recurrent product (D is zero-padded to it)
+constexpr int PROWS = 64;               // events (MFMA rows)
+constexpr int PSL = 43, PSW = 11;       // attention slots per workgroup / per wave (3 workgroups per event: A <= 129)
+constexpr int NG1 = 128, NQ = 32, NATT = 192, NS = 32;
+constexpr int B_Q0 = NG1, NWG = 256;
+constexpr int SHARDS = 8, SHSTRIDE = 32;                 // one 128-byte line per counter shard
+constexpr int CNT_LINE = SHARDS * SHSTRIDE;              // u32 per counter
+enum { C_H1 = 0, C_Q = 1, C_C = 2, C_H0 = 3, C_H2 = 4, C_KINDS = 5 };
+constexpr u32 SPIN_LIMIT = 4000000;                      // ~ seconds
+constexpr int WU_LD = 132;
+constexpr int LDS_W = 128 * 1024, LDS_WA = 64 * 1024, LDS_RED = 16 * 1024;
+constexpr int LDS_BYTES_LSTM = LDS_W + LDS_RED + 256, LDS_BYTES_ATT = LDS_WA + LDS_RED + 256;
+constexpr float ALPHA_SAFE = 40.f;
+
+}  // namespace
+
+struct PersistLayout { long cnt, xc, xs, gran, zero_end, xh1, xh0, xh2, xq, wu, total; };
+static PersistLayout persist_layout(int S) {
+    PersistLayout L;
+    long off = 0;
+    auto take = [&](long n) { long o = off; off += (n + 63) / 64 * 64; return o; };
+    L.cnt = take((long)C_KINDS * (S + 1) * CNT_LINE);
+    L.xc = take((long)S * PROWS * PH);
+    L.xs = take((long)S * PROWS);
+    L.gran = take((long)S * PROWS * 3 * 2);
+    L.zero_end = off;
+    L.xh1 = take((long)S * PROWS * PH);
+    L.xh0 = take((long)S * PROWS * PH);
+    L.xh2 = take((long)S * PROWS * PH);
+    L.xq = take((long)S * PROWS * PH);
+    L.wu = take((long)S * PROWS * WU_LD);
+    L.total = off;
+    return L;
+}
+long persist_fwd_ws_floats(int S) { return persist_layout(S).total; }
+
+struct PersistK {
+    int N, A, D, S, ld_att;
+    const float* w_hh[3]; const float* w_h2a; const float* b_h2a; const float* w_att; const float* w_alpha;
+    const float* PALL; const float* c3d; const int* ev_start; const int* ev_len;
+    float* GATES[3]; float* CS[3]; float* HS; float* OUTD; float* QS; float* WT; float* ATT;
+    float *XH1, *XH0, *XH2, *XQ, *XC, *XS, *WU;
+    unsigned long long* GRAN;
+    u32* cnt; u32* abort_word; u32* host_flag;
+    DropCfg dh, dout;
+};
+
+// ---- hand-off primitives -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, u32 bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t r, u32 off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);      // aux 16 = sc1
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, u32 off, float4 v) {
+    u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 16);
+}
+__device__ __forceinline__ void st4_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, ECHR_AGENT); }
+__device__ __forceinline__ float ld4_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, ECHR_AGENT); }
+
+// every thread of the workgroup, after its write-through stores / atomics
+__device__ __forceinline__ void publish(u32* line) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(line + (blockIdx.x % SHARDS) * SHSTRIDE, 1u, __ATOMIC_RELAXED, ECHR_AGENT);
+}
+
+// every thread; false = the launch is being aborted (timeout somewhere): the caller returns
+__device__ __forceinline__ bool wait_total(const PersistK& P, u32* line, u32 target, int* flag, u32 code) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        u32 spins = 0;
+        bool ok = false;
+        for (;;) {
+            u32 v = lane < SHARDS ? __hip_atomic_load(line + lane * SHSTRIDE, __ATOMIC_RELAXED, ECHR_AGENT) : 0u;
+            v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            v = __shfl(v, 0);
+            if (v >= target) { ok = true; break; }
+            if ((++spins & 31) == 0) {
+                if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, ECHR_AGENT)) break;
+                if (spins > SPIN_LIMIT) {
+                    if (lane == 0) {
+                        __hip_atomic_store(P.abort_word, code, __ATOMIC_RELAXED, ECHR_AGENT);
+                        __hip_atomic_store(P.host_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) *flag = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool r = *flag != 0;
+    __syncthreads();
+    return r;
+}
+
+// ---- MFMA pieces: one wave multiplies its k range [128 w, 128 w + 128) of a [64 x 512] A operand by 16-column tiles ------------
+// A fragments straight from the exchange buffer: lane (r = l & 15, kq = l >> 4) holds, for row block rb and k chunk c, the
+// float4 A[16 rb + r][128 w + 16 c + 4 kq ..+3]; element j of it feeds MFMA j of the chunk (B uses the same k pairing).
+// LAYOUT 0: [k/4][64][4] (h1), 1: [k/16][64][16] (h0, h2), 2: row-major [64][512] (context)
+template <int LAYOUT>
+__device__ __forceinline__ void load_afrag(float4 (&a)[4][8], __amdgpu_buffer_rsrc_t rs, int w, int lane) {
+    const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int n = 16 * rb + r, k = 128 * w + 16 * c + 4 * kq;
+            u32 off;
+            if (LAYOUT == 0) off = (u32)(((k >> 2) * PROWS + n) * 16);
+            else if (LAYOUT == 1) off = (u32)((((k >> 4) * PROWS + n) * 16 + (k & 15)) * 4);
+            else off = (u32)((n * PH + k) * 4);
+            a[rb][c] = ld16_sc1(rs, off);
+        }
+}
+
+// acc[rb] += A . B for one 16-column tile whose B image starts at bimg (float4 [8 chunks][64 lanes] of this wave)
+__device__ __forceinline__ void mfma_tile(f32x4 (&acc)[4], const float4 (&a)[4][8], const float4* bimg, int lane) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 b = bimg[c * 64 + lane];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][c].x, b.x, acc[rb], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][c].y, b.y, acc[rb], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][c].z, b.z, acc[rb], 0, 0, 0);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][c].w, b.w, acc[rb], 0, 0, 0);
+    }
+}
+
+// the wave's partial [64 x 16] tile -> red[w][row][col] (C/D map: col = l & 15, row = 16 rb + 4 (l >> 4) + reg)
+__device__ __forceinline__ void acc_to_lds(const f32x4 (&acc)[4], float* red, int w, int lane) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(w * PROWS + 16 * rb + 4 * (lane >> 4) + g) * 16 + (lane & 15)] = acc[rb][g];
+}
+
+// B image of one 16-column tile: float4 index ((w * 8 + c) * 64 + lane) <- W[row(cc)][k .. k+3], zero beyond K
+template <typename RowFn>
+__device__ __forceinline__ void fill_bimg(float4* img, const float* W, long ld, int K, RowFn row_of, int tid) {
+    for (int idx = tid; idx < 4 * 8 * 64; idx += 256) {
+        const int lane = idx & 63, c = (idx >> 6) & 7, w = idx >> 9;
+        const int cc = lane & 15, kq = lane >> 4;
+        const int k = 128 * w + 16 * c + 4 * kq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) v = *reinterpret_cast<const float4*>(W + (long)row_of(cc) * ld + k);
+        img[idx] = v;
+    }
+}
+
+struct CellOut { float c, h, hd; float gi, gf, gg, go; };
+// nn.LSTMCell gate math (order i, f, g, o) + the two dropouts (OldModel_NEW.py:808-818, :136)
+__device__ __forceinline__ CellOut lstm_cell(float pi, float pf, float pg, float po, float c_prev, const DropCfg& dh, const DropCfg& dout,
+                                             int n, int j, int k, int t) {
+    CellOut o;
+    o.gi = fast_sigmoid(pi); o.gf = fast_sigmoid(pf); o.gg = tanhf(pg); o.go = fast_sigmoid(po);
+    o.c = o.gf * c_prev + o.gi * o.gg;
+    o.h = o.go * tanhf(o.c) * drop_mult(dh, (unsigned)(n * PH + j), (unsigned)t, (unsigned)(1 + k));        // SITE_H0 + k
+    o.hd = o.h * drop_mult(dout, (unsigned)(n * 3 * PH + k * PH + j), (unsigned)t, 4u);                     // SITE_OUT
+    return o;
+}
+
+// ---- kernel 1: the two plain LSTM streams (0: event context, 2: scene context), 32 workgroups of 16 hidden units each -------------
+__global__ __launch_bounds__(256, 1) void dec_persist_lstm_kernel(PersistK P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float4* wimg = reinterpret_cast<float4*>(lds);
+    float* red = reinterpret_cast<float*>(lds + LDS_W);
+    int* flag = reinterpret_cast<int*>(lds + LDS_W + LDS_RED);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_s0 = b < NS;
+    const int N = P.N, S = P.S;
+    const int k = is_s0 ? 0 : 2, bs = is_s0 ? b : b - NS, ck = is_s0 ? C_H0 : C_H2;
+    float* XH = is_s0 ? P.XH0 : P.XH2;
+    auto cnt = [&](int kind, int t) { return P.cnt + ((long)kind * (S + 1) + t) * CNT_LINE; };
+    {
+        const float* W = P.w_hh[k];
+        for (int ct = 0; ct < 4; ++ct) {
+            auto row = [&](int cc) { return (cc >> 2) * PH + 16 * bs + 4 * ct + (cc & 3); };       // tile column cc = gate * 4 + unit
+            fill_bimg(wimg + ct * 2048, W, PH, PH, row, tid);
+        }
+    }
+    __syncthreads();
+    const int gn = tid >> 2, gu = tid & 3;          // gate-math ownership: thread (event n, unit u)
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const u32 XB = PROWS * PH * 4;
+    for (int t = 0; t < S; ++t) {
+        float pre[4][4];
+        const float* grow = P.GATES[k] + ((long)t * N + min(gn, N - 1)) * 4 * PH + 16 * bs + gu;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[ct][g] = grow[g * PH + 4 * ct];
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) acc[ct][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            if (!wait_total(P, cnt(ck, t - 1), NS, flag, 1000u * (ck + 1) + t)) return;
+            float4 a[4][8];
+            load_afrag<1>(a, mk_rsrc(XH + (long)(t - 1) * PROWS * PH, XB), w, lane);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) mfma_tile(acc[ct], a, wimg + ct * 2048 + w * 512, lane);
+        }
+        CellOut co[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            if (t > 0) {
+                acc_to_lds(acc[ct], red, w, lane);
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int o = gn * 16 + 4 * g + gu;
+                    pre[ct][g] += red[o] + red[PROWS * 16 + o] + red[2 * PROWS * 16 + o] + red[3 * PROWS * 16 + o];
+                }
+                __syncthreads();
+            }
+            co[ct] = lstm_cell(pre[ct][0], pre[ct][1], pre[ct][2], pre[ct][3], cs[ct], P.dh, P.dout, gn, 16 * bs + 4 * ct + gu, k, t);
+            cs[ct] = co[ct].c;
+        }
+        // exchange layout [bs][n][16]: unit 4 ct + u
+        float* xo = XH + (long)t * PROWS * PH + (bs * PROWS + gn) * 16 + gu;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) st4_sc1(xo + 4 * ct, co[ct].h);
+        publish(cnt(ck, t));
+        if (gn < N) {          // saved activations, off the critical path
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int j = 16 * bs + 4 * ct + gu;
+                float* go = P.GATES[k] + ((long)t * N + gn) * 4 * PH + j;
+                go[0] = co[ct].gi; go[PH] = co[ct].gf; go[2 * PH] = co[ct].gg; go[3 * PH] = co[ct].go;
+                P.CS[k][((long)(t + 1) * N + gn) * PH + j] = co[ct].c;
+                const long o = ((long)gn * 3 + k) * PH + j;
+                P.HS[(long)(t + 1) * N * 3 * PH + o] = co[ct].h;
+                P.OUTD[(long)t * N * 3 * PH + o] = co[ct].hd;
+            }
+        }
+    }
+}
+
+// ---- kernel 2: the attention chain (stream 1): 128 gate + 32 q + 32 attention-only workgroups; all 192 hold attention operands ----
+__global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float4* wimg = reinterpret_cast<float4*>(lds);
+    float* red = reinterpret_cast<float*>(lds + LDS_WA);
+    int* flag = reinterpret_cast<int*>(lds + LDS_WA + LDS_RED);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_g1 = b < NG1, is_q = b >= B_Q0;
+    const int N = P.N, D = P.D, S = P.S;
+    auto cnt = [&](int kind, int t) { return P.cnt + ((long)kind * (S + 1) + t) * CNT_LINE; };
+
+    // ---- one-time: recurrent weights -> LDS (MFMA B-fragment order) ----
+    if (is_g1) {
+        auto row = [&](int cc) { return (cc >> 2) * PH + 4 * b + (cc & 3); };       // tile column cc = gate * 4 + unit
+        fill_bimg(wimg, P.w_hh[1], PH, PH, row, tid);
+        fill_bimg(wimg + 2048, P.w_att, P.ld_att, D, row, tid);
+    } else if (b < B_Q0 + NQ) {
+        auto row = [&](int cc) { return 16 * (b - B_Q0) + cc; };
+        fill_bimg(wimg, P.w_h2a, PH, PH, row, tid);
+    }
+    const bool is_qw = is_q && b < B_Q0 + NQ;
+
+    // ---- one-time: attention operands -> registers ----
+    const int an = b / 3, ap = b - 3 * an;                   // event, third
+    const bool att_live = an < N;
+    int alen = 0;
+    float4 Pr[PSW][2], Cr[PSW][2], al[2];
+    bool use_max = false;
+    {
+        float asum = 0.f;
+        for (int j = tid; j < PH; j += 256) asum += fabsf(P.w_alpha[j]);
+        asum = wave_sum(asum);
+        if (lane == 0) red[w] = asum;
+        __syncthreads();
+        use_max = (red[0] + red[1] + red[2] + red[3]) > ALPHA_SAFE;
+        __syncthreads();
+        al[0] = *reinterpret_cast<const float4*>(P.w_alpha + 8 * lane);
+        al[1] = *reinterpret_cast<const float4*>(P.w_alpha + 8 * lane + 4);
+    }
+    if (att_live) {
+        alen = P.ev_len[an];
+        const long row0 = P.ev_start[an];
+#pragma unroll
+        for (int i = 0; i < PSW; ++i) {
+            const int sl = w + 4 * i;
+            const int a = min(PSL * ap + min(sl, PSL - 1), alen - 1);
+            const float* pr = P.PALL + (row0 + a) * PH + 8 * lane;
+            Pr[i][0] = *reinterpret_cast<const float4*>(pr);
+            Pr[i][1] = *reinterpret_cast<const float4*>(pr + 4);
+            const float* cr = P.c3d + (row0 + a) * D;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int d = 8 * lane + 4 * h;
+                float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
+                if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                Cr[i][h] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PSW; ++i) { Pr[i][0] = Pr[i][1] = Cr[i][0] = Cr[i][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+    __syncthreads();
+
+    const int gn = tid >> 2, gu = tid & 3;          // gate-math ownership: thread (event n, unit u)
+    float c1 = 0.f;
+    const u32 XB = PROWS * PH * 4;       // bytes of one timestep of an exchange buffer
+
+    for (int t = 0; t < S; ++t) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float pre[4] = {0.f, 0.f, 0.f, 0.f};
+        if (is_g1) {
+            const float* grow = P.GATES[1] + ((long)t * N + min(gn, N - 1)) * 4 * PH + 4 * b + gu;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = grow[g * PH];
+        }
+        // ---- phase A: products with h1(t-1): W_hh1 . h1 (gate workgroups, kept in the accumulators), q = W_h2a . h1 + b ----
+        if ((is_g1 || is_qw) && t > 0) {
+            if (!wait_total(P, cnt(C_H1, t - 1), NG1, flag, 100000u + t)) return;
+            float4 a[4][8];
+            load_afrag<0>(a, mk_rsrc(P.XH1 + (long)(t - 1) * PROWS * PH, XB), w, lane);
+            mfma_tile(acc, a, wimg + w * 512, lane);
+        }
+        if (is_qw) {
+            const int cq = b - B_Q0;
+            float4 qv = *reinterpret_cast<const float4*>(P.b_h2a + 16 * cq + 4 * gu);
+            if (t > 0) {
+                acc_to_lds(acc, red, w, lane);
+                __syncthreads();
+                const float* rp = red + gn * 16 + 4 * gu;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const float4 v = *reinterpret_cast<const float4*>(rp + ww * PROWS * 16);
+                    qv.x += v.x; qv.y += v.y; qv.z += v.z; qv.w += v.w;
+                }
+            }
+            st16_sc1(mk_rsrc(P.XQ + (long)t * PROWS * PH, XB), (u32)(((cq * PROWS + gn) * 16 + 4 * gu) * 4), qv);
+            publish(cnt(C_Q, t));
+            if (gn < N) *reinterpret_cast<float4*>(P.QS + ((long)t * N + gn) * PH + 16 * cq + 4 * gu) = qv;
+        }
+        // ---- attention: scores, (split) softmax, context partial ----
+        {
+            if (!wait_total(P, cnt(C_Q, t), NQ, flag, 200000u + t)) return;
+            if (att_live) {
+                const __amdgpu_buffer_rsrc_t rq = mk_rsrc(P.XQ + (long)t * PROWS * PH, XB);
+                const u32 qoff = (u32)((((lane >> 1) * PROWS + an) * 16 + 8 * (lane & 1)) * 4);
+                const float4 q0 = ld16_sc1(rq, qoff), q1 = ld16_sc1(rq, qoff + 16);
+                float e[PSW];
+                float mloc = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < PSW; ++i) {
+                    float v = al[0].x * fast_tanh(Pr[i][0].x + q0.x) + al[0].y * fast_tanh(Pr[i][0].y + q0.y) +
+                              al[0].z * fast_tanh(Pr[i][0].z + q0.z) + al[0].w * fast_tanh(Pr[i][0].w + q0.w) +
+                              al[1].x * fast_tanh(Pr[i][1].x + q1.x) + al[1].y * fast_tanh(Pr[i][1].y + q1.y) +
+                              al[1].z * fast_tanh(Pr[i][1].z + q1.z) + al[1].w * fast_tanh(Pr[i][1].w + q1.w);
+                    v = wave_sum(v);
+                    const int sl = w + 4 * i;
+                    const bool valid = sl < PSL && PSL * ap + sl < alen;
+                    e[i] = valid ? v : -INFINITY;
+                    mloc = fmaxf(mloc, e[i]);
+                }
+                float shift = 0.f;
+                if (use_max) {       // exact max-shifted softmax: the event's three workgroups exchange their local maxima (8-byte granules)
+                    if (lane == 0) red[w] = mloc;
+                    __syncthreads();
+                    const float m4 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+                    unsigned long long* gr = P.GRAN + ((long)t * PROWS + an) * 3;
+                    if (tid == 0)
+                        __hip_atomic_store(gr + ap, ((unsigned long long)(t + 1) << 32) | __float_as_uint(m4), __ATOMIC_RELAXED, ECHR_AGENT);
+                    if (tid < 64) {
+                        float mm = -INFINITY;
+                        u32 spins = 0;
+                        for (;;) {
+                            unsigned long long x = lane < 3 ? __hip_atomic_load(gr + lane, __ATOMIC_RELAXED, ECHR_AGENT) : ((unsigned long long)(t + 1) << 32) | 0xff800000u;
+                            const bool ok = (u32)(x >> 32) == (u32)(t + 1);
+                            if (__all(ok)) { mm = __uint_as_float((u32)x); break; }
+                            if ((++spins & 31) == 0 && (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, ECHR_AGENT) || spins > SPIN_LIMIT)) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        mm = wave_max(mm);
+                        if (lane == 0) red[8] = mm;
+                    }
+                    __syncthreads();
+                    shift = red[8];
+                    __syncthreads();
+                    if (!(shift > -INFINITY)) shift = 0.f;
+                }
+                float ssum = 0.f;
+                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1v = c0;
+#pragma unroll
+                for (int i = 0; i < PSW; ++i) {
+                    const float x = __expf(e[i] - shift);          // exp(-inf) = 0 for slots past the event's end
+                    e[i] = x;
+                    ssum += x;
+                    c0.x += x * Cr[i][0].x; c0.y += x * Cr[i][0].y; c0.z += x * Cr[i][0].z; c0.w += x * Cr[i][0].w;
+                    c1v.x += x * Cr[i][1].x; c1v.y += x * Cr[i][1].y; c1v.z += x * Cr[i][1].z; c1v.w += x * Cr[i][1].w;
+                }
+                *reinterpret_cast<float4*>(red + w * PH + 8 * lane) = c0;
+                *reinterpret_cast<float4*>(red + w * PH + 8 * lane + 4) = c1v;
+                if (lane == 0) red[4 * PH + w] = ssum;
+                // unnormalised weights of this wave's slots (lane i holds slot w + 4 i)
+                float xw = e[0];
+#pragma unroll
+                for (int i = 1; i < PSW; ++i) xw = lane == i ? e[i] : xw;
+                if (lane < PSW && w + 4 * lane < PSL && PSL * ap + w + 4 * lane < alen)
+                    st4_sc1(P.WU + ((long)t * PROWS + an) * WU_LD + PSL * ap + w + 4 * lane, xw);
+                __syncthreads();
+                float* xc = P.XC + ((long)t * PROWS + an) * PH;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int d = tid + 256 * h;
+                    if (d < D) atomicAdd(xc + d, red[d] + red[PH + d] + red[2 * PH + d] + red[3 * PH + d]);
+                }
+                if (tid == 0) atomicAdd(P.XS + (long)t * PROWS + an, red[4 * PH] + red[4 * PH + 1] + red[4 * PH + 2] + red[4 * PH + 3]);
+            }
+            publish(cnt(C_C, t));
+        }
+        // ---- phase C: attended-context columns of stream 1 + gate math; the new h1 is handed to the next step ----
+        if (is_g1) {
+            if (!wait_total(P, cnt(C_C, t), NATT, flag, 300000u + t)) return;
+            f32x4 accc[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) accc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float4 inv4[4];
+            {
+                float4 a[4][8];
+                const __amdgpu_buffer_rsrc_t rc = mk_rsrc(P.XC + (long)t * PROWS * PH, XB);
+                load_afrag<2>(a, rc, w, lane);
+                // 1 / sum of exponentials of the rows this lane's accumulator registers belong to (C/D map: row = 16 rb + 4 (l >> 4) + reg)
+                const __amdgpu_buffer_rsrc_t rsum = mk_rsrc(P.XS + (long)t * PROWS, PROWS * 4);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) inv4[rb] = ld16_sc1(rsum, (u32)((16 * rb + 4 * (lane >> 4)) * 4));
+                mfma_tile(accc, a, wimg + 2048 + w * 512, lane);
+                // normalised context, saved for backward: this workgroup stores features [4b, 4b+4) of every event (wave b/32, chunk (b%32)/4, kq b%4)
+                if (4 * b < D && w == (b >> 5) && (lane >> 4) == (b & 3)) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c == ((b & 31) >> 2)) {
+#pragma unroll
+                            for (int rb = 0; rb < 4; ++rb) {
+                                const int n = 16 * rb + (lane & 15);
+                                if (n < N) {
+                                    const float is = 1.0f / ld4_sc1(P.XS + (long)t * PROWS + n);
+                                    *reinterpret_cast<float4*>(P.ATT + ((long)t * N + n) * D + 4 * b) =
+                                        make_float4(a[rb][c].x * is, a[rb][c].y * is, a[rb][c].z * is, a[rb][c].w * is);
+                                }
+                            }
+                        }
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                acc[rb][0] += accc[rb][0] / inv4[rb].x; acc[rb][1] += accc[rb][1] / inv4[rb].y;
+                acc[rb][2] += accc[rb][2] / inv4[rb].z; acc[rb][3] += accc[rb][3] / inv4[rb].w;
+            }
+            acc_to_lds(acc, red, w, lane);
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int o = gn * 16 + 4 * g + gu;
+                pre[g] += red[o] + red[PROWS * 16 + o] + red[2 * PROWS * 16 + o] + red[3 * PROWS * 16 + o];
+            }
+            const CellOut co = lstm_cell(pre[0], pre[1], pre[2], pre[3], c1, P.dh, P.dout, gn, 4 * b + gu, 1, t);
+            c1 = co.c;
+            st4_sc1(P.XH1 + (long)t * PROWS * PH + (b * PROWS + gn) * 4 + gu, co.h);
+            publish(cnt(C_H1, t));          // (its barrier also protects `red` for the next step)
+            // saved activations, off the critical path
+            if (gn < N) {
+                const int j = 4 * b + gu;
+                float* go = P.GATES[1] + ((long)t * N + gn) * 4 * PH + j;
+                go[0] = co.gi; go[PH] = co.gf; go[2 * PH] = co.gg; go[3 * PH] = co.go;
+                P.CS[1][((long)(t + 1) * N + gn) * PH + j] = co.c;
+                const long o = ((long)gn * 3 + 1) * PH + j;
+                P.HS[(long)(t + 1) * N * 3 * PH + o] = co.h;
+                P.OUTD[(long)t * N * 3 * PH + o] = co.hd;
+            }
+            // normalised attention weights: rows of event b/2, slots [65 (b&1), +65)
+            {
+                const int n = b >> 1, a0 = 65 * (b & 1) + tid;
+                if (tid < 65 && n < N && a0 < P.A) {
+                    const int len = P.ev_len[n];
+                    float wv = 0.f;
+                    if (a0 < len) wv = ld4_sc1(P.WU + ((long)t * PROWS + n) * WU_LD + a0) / ld4_sc1(P.XS + (long)t * PROWS + n);
+                    P.WT[((long)t * N + n) * P.A + a0] = wv;
+                }
+            }
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+struct PersistHost { u32* abort_dev = nullptr; u32* flag_host = nullptr; u32* flag_dev = nullptr; int cus = 0; bool ok = false; bool init = false;
+                     hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static PersistHost& phost() {
+    static PersistHost h;
+    if (!h.init) {
+        h.init = true;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        bool good = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
+        if (good) h.cus = prop.multiProcessorCount;
+        good = good && hipMalloc(&h.abort_dev, 256) == hipSuccess && hipMemset(h.abort_dev, 0, 256) == hipSuccess;
+        good = good && hipHostMalloc(&h.flag_host, 64, hipHostMallocMapped) == hipSuccess;
+        if (good) { h.flag_host[0] = 0; good = hipHostGetDevicePointer((void**)&h.flag_dev, h.flag_host, 0) == hipSuccess; }
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
+        int lo = 0, hi = 0;
+        good = good && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+        good = good && hipStreamCreateWithPriority(&h.side, hipStreamNonBlocking, hi) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&h.fork, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&h.join, hipEventDisableTiming) == hipSuccess;
+        (void)hipGetLastError();
+        h.ok = good;
+    }
+    return h;
+}
+
+// sticky asynchronous error of an earlier persistent launch (a bounded spin timed out): reported once, at the next library call
+int persist_check_async() {
+    PersistHost& h = phost();
+    if (h.ok && h.flag_host[0]) {
+        const u32 code = h.flag_host[0];
+        h.flag_host[0] = 0;
+        (void)hipMemset(h.abort_dev, 0, 256);
+        set_error("persistent decoder kernel aborted: a hand-off wait timed out (code %u); its outputs are invalid", code);
+        return -62;   // -ETIME
+    }
+    return 0;
+}
+
+bool persist_fwd_eligible(const echr_dec_args* a) {
+    if (!config().persist) return false;
+    PersistHost& h = phost();
+    return h.ok && h.cus >= NWG && a->N <= PROWS && a->A <= 3 * PSL && a->H == PH && a->Ha == PH && a->D <= PH && a->D % 4 == 0 && a->D >= 8 &&
+           a->S >= 1;
+}
+
+int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st) {
+    PersistHost& h = phost();
+    ECHR_REQUIRE(h.ok, "persist_fwd: device state unavailable");
+    const PersistLayout L = persist_layout(a->S);
+    PersistK K;
+    K.N = a->N; K.A = a->A; K.D = a->D; K.S = a->S; K.ld_att = a->E + a->D;
+    for (int k = 0; k < 3; ++k) { K.w_hh[k] = a->w_hh[k]; K.GATES[k] = B.GATES[k]; K.CS[k] = B.CS[k]; }
+    K.w_h2a = a->w_h2a; K.b_h2a = a->b_h2a; K.w_att = a->w_ih[1] + a->E; K.w_alpha = a->w_alpha;
+    K.PALL = B.PALL; K.c3d = a->c3d; K.ev_start = a->ev_start; K.ev_len = a->ev_len;
+    K.HS = B.HS; K.OUTD = B.OUTD; K.QS = B.QS; K.WT = B.WT; K.ATT = B.ATT;
+    float* x = B.xws;
+    K.cnt = reinterpret_cast<u32*>(x + L.cnt); K.XC = x + L.xc; K.XS = x + L.xs; K.GRAN = reinterpret_cast<unsigned long long*>(x + L.gran);
+    K.XH1 = x + L.xh1; K.XH0 = x + L.xh0; K.XH2 = x + L.xh2; K.XQ = x + L.xq; K.WU = x + L.wu;
+    K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
+    K.dh = dh; K.dout = dout;
+    if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_fwd: memset failed"); return -5; }
+    ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), 0.0, st);
+    // the two plain LSTM streams recur on a second HIP stream, concurrently with the attention chain (192 + 64 workgroups = 256 CUs;
+    // neither kernel waits on the other, so any residency order makes progress)
+    if (hipEventRecord(h.fork, st) != hipSuccess || hipStreamWaitEvent(h.side, h.fork, 0) != hipSuccess) { set_error("persist_fwd: fork failed"); return -5; }
+    hipLaunchKernelGGL(dec_persist_lstm_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM, h.side, K);
+    if (int rc = check_launch("dec_persist_lstm")) return rc;
+    hipLaunchKernelGGL(dec_persist_att_kernel, dim3(NATT), dim3(256), LDS_BYTES_ATT, st, K);
+    if (int rc = check_launch("dec_persist_att")) return rc;
+    if (hipEventRecord(h.join, h.side) != hipSuccess || hipStreamWaitEvent(st, h.join, 0) != hipSuccess) { set_error("persist_fwd: join failed"); return -5; }
+    return 0;
+}
+
+}  // namespace echr

@@ -428,6 +428,30 @@ def test_gemm_path_switches_do_not_change_results_beyond_tolerance():
     assert lib.echr_config_set(b'no_such_key', 1) != 0
 
 
+@pytest.mark.parametrize('case', ['c1', 'c2', 'c2full'])
+def test_persistent_recurrence_equals_launch_path(case):
+    """echr_config_set('persist'): the one-launch weights-stationary recurrence (csrc/persist.hip) against the launch-per-phase
+    recurrence on the same inputs, train mode (dropout), twice in a row (re-launch state: counters, exchange buffers)."""
+    from echr_amd import _lib
+    lib = _lib.load()
+    opt, params, vid = synth.make_case(case)
+    runs = {}
+    try:
+        for name, v in (('launch', 0), ('persist', 1), ('persist2', 1)):
+            assert lib.echr_config_set(b'persist', v) == 0
+            runs[name] = U.run_gpu(opt, params, vid, True)
+    finally:
+        lib.echr_config_set(b'persist', 1)
+    p0, l0, g0, _ = runs['launch']
+    for name in ('persist', 'persist2'):
+        p1, l1, g1, _ = runs[name]
+        assert np.isfinite(p1).all(), name
+        assert np.abs(p0 - p1).max() < 2e-5 and abs(l0 - l1) < 1e-5 * abs(l0), (name, np.abs(p0 - p1).max())
+        for k in g0:
+            if g0[k] is not None:
+                assert U.grad_close(k, g1[k], g0[k], 1e-4), (name, k, U.relerr(g1[k], g0[k]))
+
+
 def test_reference_checkpoint_reproduces_reference_output():
     """Weights initialised and saved by the reference itself -> loaded as is -> the reference's own eval-mode log-probs."""
     import echr_amd
