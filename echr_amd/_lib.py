@@ -95,6 +95,7 @@ SYMBOLS = [
     ('echr_sampler_ws_floats', i64, [C.POINTER(DecArgs)]),
     ('echr_decoder_sample', i32, [C.POINTER(SampleArgs), C.c_void_p]),
     ('echr_config_set', i32, [C.c_char_p, i32]),
+    ('echr_persist_read_stamps', i32, [C.c_void_p, i32]),
     ('echr_prof_enable', i32, [i32]),
     ('echr_prof_read', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     ('echr_sst_ws_floats', i64, [i32, i32, i32, i32]),

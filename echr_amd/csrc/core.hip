@@ -34,7 +34,7 @@ int check_launch(const char* what) {
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 Config& config() {
     static Config c = {env_int("ECHR_GEMM_BF16X3", 1), env_int("ECHR_OVERLAP", 0), env_int("ECHR_ATT_SLOTS", 2), env_int("ECHR_CHAINS2", 0),
-                       env_int("ECHR_GEMM_H2", 1), env_int("ECHR_PERSIST", 1)};
+                       env_int("ECHR_GEMM_H2", 1), env_int("ECHR_PERSIST", 1), env_int("ECHR_PERSIST_STAMPS", 0)};
     return c;
 }
 
@@ -663,6 +663,10 @@ extern "C" int echr_prof_read(int kind, double* ms, double* flops, double* bytes
     return 0;
 }
 
+extern "C" int echr_persist_read_stamps(uint64_t* dst, int32_t max_entries) {
+    return persist_read_stamps(reinterpret_cast<unsigned long long*>(dst), max_entries);
+}
+
 extern "C" int echr_config_set(const char* key, int32_t value) {
     ECHR_REQUIRE(key, "config_set: null key");
     Config& c = config();
@@ -671,6 +675,7 @@ extern "C" int echr_config_set(const char* key, int32_t value) {
     else if (!strcmp(key, "chains2")) c.chains2 = value;
     else if (!strcmp(key, "gemm_h2")) c.gemm_h2 = value;
     else if (!strcmp(key, "persist")) c.persist = value;
+    else if (!strcmp(key, "persist_stamps")) c.persist_stamps = value;
     else if (!strcmp(key, "att_slots")) { ECHR_REQUIRE(value == 2 || value == 4 || value == 8, "config_set: att_slots must be 2, 4 or 8"); c.att_slots = value; }
     else { set_error("config_set: unknown key %s", key); return -22; }
     return 0;

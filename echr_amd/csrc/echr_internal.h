@@ -17,7 +17,7 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; };
 Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);
@@ -29,6 +29,7 @@ long persist_fwd_ws_floats(int S);
 bool persist_fwd_eligible(const echr_dec_args* a);
 int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
 int persist_check_async();
+int persist_read_stamps(unsigned long long* dst, int max_entries);
 int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st);
 // h2-packed operands (csrc/gemm.hip: two block-scaled fp16 planes): bytes of the packed image of a [rows x cols] operand (cols =
 // contraction axis), the packing pass, and a multi-operand packing launch

@@ -37,7 +37,7 @@ namespace {
 
 constexpr int PH = 512;                 // H = Ha = K of every recurrent product (D is zero-padded to it)
 constexpr int PROWS = 64;               // events (MFMA rows)
-constexpr int PSL = 43, PSW = 11;       // attention slots per workgroup / per wave (3 workgroups per event: A <= 129)
+constexpr int PSL = 43, PSG = 3;        // attention slots per workgroup (3 workgroups per event: A <= 129) / per 16-lane row (16 rows)
 constexpr int NG1 = 128, NQ = 32, NATT = 192, NS = 32;
 constexpr int B_Q0 = NG1, NWG = 256;
 constexpr int SHARDS = 8, SHSTRIDE = 32;                 // one 128-byte line per counter shard
@@ -45,8 +45,8 @@ constexpr int CNT_LINE = SHARDS * SHSTRIDE;              // u32 per counter
 enum { C_H1 = 0, C_Q = 1, C_C = 2, C_H0 = 3, C_H2 = 4, C_KINDS = 5 };
 constexpr u32 SPIN_LIMIT = 4000000;                      // ~ seconds
 constexpr int WU_LD = 132;
-constexpr int LDS_W = 128 * 1024, LDS_WA = 64 * 1024, LDS_RED = 16 * 1024;
-constexpr int LDS_BYTES_LSTM = LDS_W + LDS_RED + 256, LDS_BYTES_ATT = LDS_WA + LDS_RED + 256;
+constexpr int LDS_W = 128 * 1024, LDS_WA = 64 * 1024, LDS_RED = 16 * 1024, LDS_RED_ATT = 32 * 1024 + 2048 + 256;
+constexpr int LDS_BYTES_LSTM = LDS_W + LDS_RED + 256, LDS_BYTES_ATT = LDS_WA + LDS_RED_ATT + 256;
 constexpr float ALPHA_SAFE = 40.f;
 
 }  // namespace
@@ -79,8 +79,10 @@ struct PersistK {
     float *XH1, *XH0, *XH2, *XQ, *XC, *XS, *WU;
     unsigned long long* GRAN;
     u32* cnt; u32* abort_word; u32* host_flag;
+    unsigned long long* stamps;      // diagnostic: [4 roles][S][16] s_memrealtime stamps (null = off)
     DropCfg dh, dout;
 };
+#define STAMP(role, i) do { if (P.stamps && tid == 0) P.stamps[((role) * S + t) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 // ---- hand-off primitives -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, u32 bytes) {
@@ -96,6 +98,15 @@ __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, u32 off, floa
 }
 __device__ __forceinline__ void st4_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, ECHR_AGENT); }
 __device__ __forceinline__ float ld4_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, ECHR_AGENT); }
+
+// sum over the 16 lanes of a DPP row, result in every lane: quad xor 1, quad xor 2, row_half_mirror, row_mirror
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+    return v;
+}
 
 // every thread of the workgroup, after its write-through stores / atomics
 __device__ __forceinline__ void publish(u32* line) {
@@ -138,14 +149,14 @@ __device__ __forceinline__ bool wait_total(const PersistK& P, u32* line, u32 tar
 // ---- MFMA pieces: one wave multiplies its k range [128 w, 128 w + 128) of a [64 x 512] A operand by 16-column tiles ------------
 // A fragments straight from the exchange buffer: lane (r = l & 15, kq = l >> 4) holds, for row block rb and k chunk c, the
 // float4 A[16 rb + r][128 w + 16 c + 4 kq ..+3]; element j of it feeds MFMA j of the chunk (B uses the same k pairing).
-// LAYOUT 0: [k/4][64][4] (h1), 1: [k/16][64][16] (h0, h2), 2: row-major [64][512] (context)
+// LAYOUT 0: [k/4][64][4] (h1), 1: [k/16][64][16] (h0, h2, context), 2: row-major [64][512]
 template <int LAYOUT>
 __device__ __forceinline__ void load_afrag(float4 (&a)[4][8], __amdgpu_buffer_rsrc_t rs, int w, int lane) {
     const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+    for (int c = 0; c < 8; ++c)             // chunk-major issue order: the MFMAs of chunk c only wait for the first 4 (c + 1) loads
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int rb = 0; rb < 4; ++rb) {
             const int n = 16 * rb + r, k = 128 * w + 16 * c + 4 * kq;
             u32 off;
             if (LAYOUT == 0) off = (u32)(((k >> 2) * PROWS + n) * 16);
@@ -197,9 +208,9 @@ struct CellOut { float c, h, hd; float gi, gf, gg, go; };
 __device__ __forceinline__ CellOut lstm_cell(float pi, float pf, float pg, float po, float c_prev, const DropCfg& dh, const DropCfg& dout,
                                              int n, int j, int k, int t) {
     CellOut o;
-    o.gi = fast_sigmoid(pi); o.gf = fast_sigmoid(pf); o.gg = tanhf(pg); o.go = fast_sigmoid(po);
+    o.gi = fast_sigmoid(pi); o.gf = fast_sigmoid(pf); o.gg = fast_tanh(pg); o.go = fast_sigmoid(po);
     o.c = o.gf * c_prev + o.gi * o.gg;
-    o.h = o.go * tanhf(o.c) * drop_mult(dh, (unsigned)(n * PH + j), (unsigned)t, (unsigned)(1 + k));        // SITE_H0 + k
+    o.h = o.go * fast_tanh(o.c) * drop_mult(dh, (unsigned)(n * PH + j), (unsigned)t, (unsigned)(1 + k));        // SITE_H0 + k
     o.hd = o.h * drop_mult(dout, (unsigned)(n * 3 * PH + k * PH + j), (unsigned)t, 4u);                     // SITE_OUT
     return o;
 }
@@ -227,7 +238,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_kernel(PersistK P) {
     const int gn = tid >> 2, gu = tid & 3;          // gate-math ownership: thread (event n, unit u)
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     const u32 XB = PROWS * PH * 4;
+    const bool st_on = b == 0;
     for (int t = 0; t < S; ++t) {
+        if (st_on) STAMP(3, 0);
         float pre[4][4];
         const float* grow = P.GATES[k] + ((long)t * N + min(gn, N - 1)) * 4 * PH + 16 * bs + gu;
 #pragma unroll
@@ -241,10 +254,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_kernel(PersistK P) {
             for (int rb = 0; rb < 4; ++rb) acc[ct][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (t > 0) {
             if (!wait_total(P, cnt(ck, t - 1), NS, flag, 1000u * (ck + 1) + t)) return;
+            if (st_on) STAMP(3, 1);
             float4 a[4][8];
             load_afrag<1>(a, mk_rsrc(XH + (long)(t - 1) * PROWS * PH, XB), w, lane);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) mfma_tile(acc[ct], a, wimg + ct * 2048 + w * 512, lane);
+            if (st_on) STAMP(3, 2);
         }
         CellOut co[4];
 #pragma unroll
@@ -266,7 +281,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_kernel(PersistK P) {
         float* xo = XH + (long)t * PROWS * PH + (bs * PROWS + gn) * 16 + gu;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) st4_sc1(xo + 4 * ct, co[ct].h);
+        if (st_on) STAMP(3, 3);
         publish(cnt(ck, t));
+        if (st_on) STAMP(3, 4);
         if (gn < N) {          // saved activations, off the critical path
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float4* wimg = reinterpret_cast<float4*>(lds);
     float* red = reinterpret_cast<float*>(lds + LDS_WA);
-    int* flag = reinterpret_cast<int*>(lds + LDS_WA + LDS_RED);
+    int* flag = reinterpret_cast<int*>(lds + LDS_WA + LDS_RED_ATT);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_g1 = b < NG1, is_q = b >= B_Q0;
     const int N = P.N, D = P.D, S = P.S;
@@ -304,37 +321,39 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
     }
     const bool is_qw = is_q && b < B_Q0 + NQ;
 
-    // ---- one-time: attention operands -> registers ----
-    const int an = b / 3, ap = b - 3 * an;                   // event, third
+    // ---- one-time: attention operands -> registers: DPP row g = 4 w + (lane >> 4) owns slots g, g + 16, g + 32 of this
+    //      workgroup's third of the event; lane r = lane & 15 of the row holds features [32 r, 32 r + 32) of P_all and C3D ----
+    float* red2 = red;                                  // [16 rows][512] cross-row context partials (32 KB)
+    float* sal = red + 16 * PH;                         // [512] alpha
+    float* sx = sal + PH;                               // small scratch: [0..15] row sums, [16..31] row maxima, [32] combined
+    const int an = b / 3, ap = b - 3 * an;              // event, third
     const bool att_live = an < N;
+    const int grow_ = 4 * w + (lane >> 4), lr = lane & 15;
     int alen = 0;
-    float4 Pr[PSW][2], Cr[PSW][2], al[2];
+    float4 Pr[PSG][8], Cr[PSG][8];
     bool use_max = false;
     {
         float asum = 0.f;
-        for (int j = tid; j < PH; j += 256) asum += fabsf(P.w_alpha[j]);
+        for (int j = tid; j < PH; j += 256) { const float av = P.w_alpha[j]; sal[j] = av; asum += fabsf(av); }
         asum = wave_sum(asum);
-        if (lane == 0) red[w] = asum;
+        if (lane == 0) sx[w] = asum;
         __syncthreads();
-        use_max = (red[0] + red[1] + red[2] + red[3]) > ALPHA_SAFE;
+        use_max = (sx[0] + sx[1] + sx[2] + sx[3]) > ALPHA_SAFE;
         __syncthreads();
-        al[0] = *reinterpret_cast<const float4*>(P.w_alpha + 8 * lane);
-        al[1] = *reinterpret_cast<const float4*>(P.w_alpha + 8 * lane + 4);
     }
     if (att_live) {
         alen = P.ev_len[an];
         const long row0 = P.ev_start[an];
 #pragma unroll
-        for (int i = 0; i < PSW; ++i) {
-            const int sl = w + 4 * i;
+        for (int i = 0; i < PSG; ++i) {
+            const int sl = grow_ + 16 * i;
             const int a = min(PSL * ap + min(sl, PSL - 1), alen - 1);
-            const float* pr = P.PALL + (row0 + a) * PH + 8 * lane;
-            Pr[i][0] = *reinterpret_cast<const float4*>(pr);
-            Pr[i][1] = *reinterpret_cast<const float4*>(pr + 4);
+            const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
             const float* cr = P.c3d + (row0 + a) * D;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int d = 8 * lane + 4 * h;
+            for (int h = 0; h < 8; ++h) {
+                Pr[i][h] = *reinterpret_cast<const float4*>(pr + 4 * h);
+                const int d = 32 * lr + 4 * h;
                 float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
                 if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 Cr[i][h] = v;
@@ -342,7 +361,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < PSW; ++i) { Pr[i][0] = Pr[i][1] = Cr[i][0] = Cr[i][1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int i = 0; i < PSG; ++i)
+#pragma unroll
+            for (int h = 0; h < 8; ++h) Pr[i][h] = Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
@@ -350,7 +371,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
     float c1 = 0.f;
     const u32 XB = PROWS * PH * 4;       // bytes of one timestep of an exchange buffer
 
+    const int srole = b == 0 ? 0 : (b == B_Q0 ? 1 : (b == B_Q0 + NQ ? 2 : -1));
     for (int t = 0; t < S; ++t) {
+        if (srole >= 0) STAMP(srole, 0);
         f32x4 acc[4];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -363,9 +386,11 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
         // ---- phase A: products with h1(t-1): W_hh1 . h1 (gate workgroups, kept in the accumulators), q = W_h2a . h1 + b ----
         if ((is_g1 || is_qw) && t > 0) {
             if (!wait_total(P, cnt(C_H1, t - 1), NG1, flag, 100000u + t)) return;
+            if (srole >= 0) STAMP(srole, 1);
             float4 a[4][8];
             load_afrag<0>(a, mk_rsrc(P.XH1 + (long)(t - 1) * PROWS * PH, XB), w, lane);
             mfma_tile(acc, a, wimg + w * 512, lane);
+            if (srole >= 0) STAMP(srole, 2);
         }
         if (is_qw) {
             const int cq = b - B_Q0;
@@ -381,39 +406,49 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
                 }
             }
             st16_sc1(mk_rsrc(P.XQ + (long)t * PROWS * PH, XB), (u32)(((cq * PROWS + gn) * 16 + 4 * gu) * 4), qv);
+            if (srole >= 0) STAMP(srole, 3);
             publish(cnt(C_Q, t));
+            if (srole >= 0) STAMP(srole, 4);
             if (gn < N) *reinterpret_cast<float4*>(P.QS + ((long)t * N + gn) * PH + 16 * cq + 4 * gu) = qv;
         }
         // ---- attention: scores, (split) softmax, context partial ----
         {
             if (!wait_total(P, cnt(C_Q, t), NQ, flag, 200000u + t)) return;
+            if (srole >= 0) STAMP(srole, 5);
             if (att_live) {
                 const __amdgpu_buffer_rsrc_t rq = mk_rsrc(P.XQ + (long)t * PROWS * PH, XB);
-                const u32 qoff = (u32)((((lane >> 1) * PROWS + an) * 16 + 8 * (lane & 1)) * 4);
-                const float4 q0 = ld16_sc1(rq, qoff), q1 = ld16_sc1(rq, qoff + 16);
-                float e[PSW];
+                // q[n, 32 lr .. +32): two 16-column pieces of the exchange layout [c][n][16]
+                float4 q[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h) q[h] = ld16_sc1(rq, (u32)((((2 * lr + (h >> 2)) * PROWS + an) * 16 + 4 * (h & 3)) * 4));
+                if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (srole >= 0) STAMP(srole, 12); }
+                float e[PSG];
                 float mloc = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < PSW; ++i) {
-                    float v = al[0].x * fast_tanh(Pr[i][0].x + q0.x) + al[0].y * fast_tanh(Pr[i][0].y + q0.y) +
-                              al[0].z * fast_tanh(Pr[i][0].z + q0.z) + al[0].w * fast_tanh(Pr[i][0].w + q0.w) +
-                              al[1].x * fast_tanh(Pr[i][1].x + q1.x) + al[1].y * fast_tanh(Pr[i][1].y + q1.y) +
-                              al[1].z * fast_tanh(Pr[i][1].z + q1.z) + al[1].w * fast_tanh(Pr[i][1].w + q1.w);
-                    v = wave_sum(v);
-                    const int sl = w + 4 * i;
+                for (int i = 0; i < PSG; ++i) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
+                        v += a4.x * fast_tanh(Pr[i][h].x + q[h].x) + a4.y * fast_tanh(Pr[i][h].y + q[h].y) +
+                             a4.z * fast_tanh(Pr[i][h].z + q[h].z) + a4.w * fast_tanh(Pr[i][h].w + q[h].w);
+                    }
+                    v = row16_sum(v);
+                    const int sl = grow_ + 16 * i;
                     const bool valid = sl < PSL && PSL * ap + sl < alen;
                     e[i] = valid ? v : -INFINITY;
                     mloc = fmaxf(mloc, e[i]);
                 }
                 float shift = 0.f;
                 if (use_max) {       // exact max-shifted softmax: the event's three workgroups exchange their local maxima (8-byte granules)
-                    if (lane == 0) red[w] = mloc;
+                    if (lr == 0) sx[16 + grow_] = mloc;
                     __syncthreads();
-                    const float m4 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
                     unsigned long long* gr = P.GRAN + ((long)t * PROWS + an) * 3;
-                    if (tid == 0)
-                        __hip_atomic_store(gr + ap, ((unsigned long long)(t + 1) << 32) | __float_as_uint(m4), __ATOMIC_RELAXED, ECHR_AGENT);
                     if (tid < 64) {
+                        float m16 = lane < 16 ? sx[16 + lane] : -INFINITY;
+                        m16 = wave_max(m16);
+                        if (lane == 0)
+                            __hip_atomic_store(gr + ap, ((unsigned long long)(t + 1) << 32) | __float_as_uint(m16), __ATOMIC_RELAXED, ECHR_AGENT);
                         float mm = -INFINITY;
                         u32 spins = 0;
                         for (;;) {
@@ -424,46 +459,65 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
                             __builtin_amdgcn_s_sleep(1);
                         }
                         mm = wave_max(mm);
-                        if (lane == 0) red[8] = mm;
+                        if (lane == 0) sx[32] = mm;
                     }
                     __syncthreads();
-                    shift = red[8];
-                    __syncthreads();
+                    shift = sx[32];
                     if (!(shift > -INFINITY)) shift = 0.f;
                 }
+                if (srole >= 0) STAMP(srole, 13);
                 float ssum = 0.f;
-                float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1v = c0;
+                float4 cx[8];
 #pragma unroll
-                for (int i = 0; i < PSW; ++i) {
+                for (int h = 0; h < 8; ++h) cx[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < PSG; ++i) {
                     const float x = __expf(e[i] - shift);          // exp(-inf) = 0 for slots past the event's end
                     e[i] = x;
                     ssum += x;
-                    c0.x += x * Cr[i][0].x; c0.y += x * Cr[i][0].y; c0.z += x * Cr[i][0].z; c0.w += x * Cr[i][0].w;
-                    c1v.x += x * Cr[i][1].x; c1v.y += x * Cr[i][1].y; c1v.z += x * Cr[i][1].z; c1v.w += x * Cr[i][1].w;
-                }
-                *reinterpret_cast<float4*>(red + w * PH + 8 * lane) = c0;
-                *reinterpret_cast<float4*>(red + w * PH + 8 * lane + 4) = c1v;
-                if (lane == 0) red[4 * PH + w] = ssum;
-                // unnormalised weights of this wave's slots (lane i holds slot w + 4 i)
-                float xw = e[0];
 #pragma unroll
-                for (int i = 1; i < PSW; ++i) xw = lane == i ? e[i] : xw;
-                if (lane < PSW && w + 4 * lane < PSL && PSL * ap + w + 4 * lane < alen)
-                    st4_sc1(P.WU + ((long)t * PROWS + an) * WU_LD + PSL * ap + w + 4 * lane, xw);
+                    for (int h = 0; h < 8; ++h) {
+                        cx[h].x += x * Cr[i][h].x; cx[h].y += x * Cr[i][h].y; cx[h].z += x * Cr[i][h].z; cx[h].w += x * Cr[i][h].w;
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 8; ++h) *reinterpret_cast<float4*>(red2 + grow_ * PH + 32 * lr + 4 * h) = cx[h];
+                if (lr == 0) sx[grow_] = ssum;
+                // unnormalised weights of this row's slots (lane i of the row stores slot grow_ + 16 i)
+                {
+                    const float xw = lr == 0 ? e[0] : (lr == 1 ? e[1] : e[2]);
+                    const int sl = grow_ + 16 * lr;
+                    if (lr < PSG && sl < PSL && PSL * ap + sl < alen) st4_sc1(P.WU + ((long)t * PROWS + an) * WU_LD + PSL * ap + sl, xw);
+                }
                 __syncthreads();
-                float* xc = P.XC + ((long)t * PROWS + an) * PH;
+                if (srole >= 0) STAMP(srole, 14);
+                // context partial of this workgroup: exchange layout [d / 16][n][16]
+                float* xc = P.XC + (long)t * PROWS * PH;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int d = tid + 256 * h;
-                    if (d < D) atomicAdd(xc + d, red[d] + red[PH + d] + red[2 * PH + d] + red[3 * PH + d]);
+                    if (d < D) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) sum += red2[g * PH + d];
+                        atomicAdd(xc + ((d >> 4) * PROWS + an) * 16 + (d & 15), sum);
+                    }
                 }
-                if (tid == 0) atomicAdd(P.XS + (long)t * PROWS + an, red[4 * PH] + red[4 * PH + 1] + red[4 * PH + 2] + red[4 * PH + 3]);
+                if (tid == 0) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) sum += sx[g];
+                    atomicAdd(P.XS + (long)t * PROWS + an, sum);
+                }
             }
+            if (srole >= 0) STAMP(srole, 6);
             publish(cnt(C_C, t));
+            if (srole >= 0) STAMP(srole, 7);
         }
         // ---- phase C: attended-context columns of stream 1 + gate math; the new h1 is handed to the next step ----
         if (is_g1) {
             if (!wait_total(P, cnt(C_C, t), NATT, flag, 300000u + t)) return;
+            if (srole >= 0) STAMP(srole, 8);
             f32x4 accc[4];
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) accc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -471,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
             {
                 float4 a[4][8];
                 const __amdgpu_buffer_rsrc_t rc = mk_rsrc(P.XC + (long)t * PROWS * PH, XB);
-                load_afrag<2>(a, rc, w, lane);
+                load_afrag<1>(a, rc, w, lane);
                 // 1 / sum of exponentials of the rows this lane's accumulator registers belong to (C/D map: row = 16 rb + 4 (l >> 4) + reg)
                 const __amdgpu_buffer_rsrc_t rsum = mk_rsrc(P.XS + (long)t * PROWS, PROWS * 4);
 #pragma unroll
@@ -499,6 +553,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
                 acc[rb][0] += accc[rb][0] / inv4[rb].x; acc[rb][1] += accc[rb][1] / inv4[rb].y;
                 acc[rb][2] += accc[rb][2] / inv4[rb].z; acc[rb][3] += accc[rb][3] / inv4[rb].w;
             }
+            if (srole >= 0) STAMP(srole, 9);
             acc_to_lds(acc, red, w, lane);
             __syncthreads();
 #pragma unroll
@@ -509,7 +564,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
             const CellOut co = lstm_cell(pre[0], pre[1], pre[2], pre[3], c1, P.dh, P.dout, gn, 4 * b + gu, 1, t);
             c1 = co.c;
             st4_sc1(P.XH1 + (long)t * PROWS * PH + (b * PROWS + gn) * 4 + gu, co.h);
+            if (srole >= 0) STAMP(srole, 10);
             publish(cnt(C_H1, t));          // (its barrier also protects `red` for the next step)
+            if (srole >= 0) STAMP(srole, 11);
             // saved activations, off the critical path
             if (gn < N) {
                 const int j = 4 * b + gu;
@@ -535,7 +592,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
-struct PersistHost { u32* abort_dev = nullptr; u32* flag_host = nullptr; u32* flag_dev = nullptr; int cus = 0; bool ok = false; bool init = false;
+struct PersistHost { u32* abort_dev = nullptr; u32* flag_host = nullptr; u32* flag_dev = nullptr; int cus = 0; bool ok = false; bool init = false; unsigned long long* stamps = nullptr; int stamps_S = 0;
                      hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 static PersistHost& phost() {
     static PersistHost h;
@@ -574,6 +631,15 @@ int persist_check_async() {
     return 0;
 }
 
+// diagnostic: copy the last stamped launch's s_memrealtime stamps ([4 roles][S][16] uint64, 100 MHz) to the host; returns S
+int persist_read_stamps(unsigned long long* dst, int max_entries) {
+    PersistHost& h = phost();
+    if (!h.stamps || h.stamps_S <= 0 || max_entries < 4 * h.stamps_S * 16) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    if (hipMemcpy(dst, h.stamps, (size_t)4 * h.stamps_S * 16 * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return h.stamps_S;
+}
+
 bool persist_fwd_eligible(const echr_dec_args* a) {
     if (!config().persist) return false;
     PersistHost& h = phost();
@@ -596,6 +662,11 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     K.XH1 = x + L.xh1; K.XH0 = x + L.xh0; K.XH2 = x + L.xh2; K.XQ = x + L.xq; K.WU = x + L.wu;
     K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
     K.dh = dh; K.dout = dout;
+    K.stamps = nullptr;
+    if (config().persist_stamps) {
+        if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
+        if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
+    }
     if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_fwd: memset failed"); return -5; }
     ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), 0.0, st);
     // the two plain LSTM streams recur on a second HIP stream, concurrently with the attention chain (192 + 64 workgroups = 256 CUs;

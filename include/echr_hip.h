@@ -310,8 +310,16 @@ int echr_prof_read(int kind, double* ms, double* flops, double* bytes, int64_t* 
  *   "gemm_h2"     0/1  run the decoder's large projections on h2-packed operands (two block-scaled fp16 planes, fp32-grade) or not
  *   "gemm_bf16x3" 0/1  (gemm_h2 = 0) use the three-plane bf16 split product for the large projections or the native fp32 MFMA
  *   "overlap"     0/1  run recurrence-independent GEMMs on a second HIP stream
- *   "att_slots"   2/4/8 attention slots per wave */
+ *   "att_slots"   2/4/8 attention slots per wave
+ *   "persist"     0/1  (default 1, ECHR_PERSIST) run the teacher-forced recurrence as ONE persistent launch (csrc/persist.hip) when the
+ *                      shape allows (N <= 64, A <= 129, H = Ha = 512, D <= 512, a full 256-CU device), else one launch per phase
+ *   "persist_stamps" 0/1 diagnostic phase stamps, see echr_persist_read_stamps */
 int echr_config_set(const char* key, int32_t value);
+
+/* Diagnostic (never on the product path): with echr_config_set("persist_stamps", 1) the persistent recurrence kernels record
+ * s_memrealtime stamps (100 MHz) at their phase boundaries for one workgroup per role; this copies the last launch's stamps
+ * ([4 roles][S][16] uint64) to host memory (synchronises the device) and returns S (0 = nothing recorded). */
+int echr_persist_read_stamps(uint64_t* dst, int32_t max_entries);
 
 /* stand-alone element-wise clamp (misc/utils.py:107-111) for optimisers other than the fused one */
 int echr_clamp(float* g, int64_t n, float clip, void* stream);

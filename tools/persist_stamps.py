@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic: phase timeline of the persistent recurrence kernels (csrc/persist.hip) on the c3 bench workload.
+Prints, per role (gate workgroup 0, q workgroup 128, attention-only workgroup 160, LSTM workgroup 0), the average
+time between consecutive stamps over the steady-state timesteps (s_memrealtime, 100 MHz)."""
+import ctypes as C
+import os
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import echr_amd
+from echr_amd import _lib
+from echr_amd.misc.utils import LanguageModelCriterion
+
+lib = _lib.load()
+opt, params, vid = bench.make_workload(0, False)
+dev = torch.device('cuda')
+model = echr_amd.CaptionGenerator(opt)
+model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+model = model.to(dev).train()
+tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+labels = torch.from_numpy(vid['labels'])
+for it in range(4):
+    if it == 3:
+        lib.echr_config_set(b'persist_stamps', 1)
+    with torch.no_grad():
+        model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+    torch.cuda.synchronize()
+S = 20
+buf = np.zeros(4 * 256 * 16, dtype=np.uint64)
+got = lib.echr_persist_read_stamps(buf.ctypes.data, buf.size)
+assert got == S, got
+st = buf[:4 * S * 16].reshape(4, S, 16).astype(np.float64) / 100.0     # us
+names = {0: ['step', 'waitH1', 'mfmaA', '-', '-', 'waitQ', 'att', 'pubC', 'waitC', 'mfmaC', 'gate', 'pubH1'],
+         1: ['step', 'waitH1', 'mfmaA', 'qepi', 'pubQ', 'waitQ', 'att', 'pubC'],
+         2: ['step', '-', '-', '-', '-', 'waitQ', 'att', 'pubC', '-', '-', '-', '-', 'qload', 'score', 'ctx+lds'],
+         3: ['step', 'waitH', 'mfma', 'gate', 'pub']}
+for role, rn in ((0, 'gate wg 0'), (1, 'q wg 128'), (2, 'att wg 160'), (3, 'lstm wg 0')):
+    a = st[role]
+    print('%s: step period %.2f us' % (rn, (a[S - 1, 0] - a[2, 0]) / (S - 3)))
+    prev_i = 0
+    out = []
+    for i in range(1, len(names[role])):
+        if names[role][i] == '-':
+            continue
+        if i == 12:
+            prev_i = 5
+        d = (a[3:S, i] - a[3:S, prev_i]).mean()
+        out.append('%s %.2f' % (names[role][i], d))
+        prev_i = i
+    print('   ' + ' | '.join(out))
