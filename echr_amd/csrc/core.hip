@@ -34,7 +34,8 @@ int check_launch(const char* what) {
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 Config& config() {
     static Config c = {env_int("ECHR_GEMM_BF16X3", 1), env_int("ECHR_OVERLAP", 0), env_int("ECHR_ATT_SLOTS", 2), env_int("ECHR_CHAINS2", 0),
-                       env_int("ECHR_GEMM_H2", 1), env_int("ECHR_PERSIST", 1), env_int("ECHR_PERSIST_STAMPS", 0)};
+                       env_int("ECHR_GEMM_H2", 1), env_int("ECHR_PERSIST", 1), env_int("ECHR_PERSIST_STAMPS", 0),
+                       getenv("ECHR_GEMM_TILE") ? (int)getenv("ECHR_GEMM_TILE")[0] : 0, env_int("ECHR_GEMM_SPLIT", 0)};
     return c;
 }
 
@@ -553,6 +554,9 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const float* __restric
     }
 }
 
+// torch.clamp semantics: a NaN gradient stays NaN (fminf/fmaxf alone would turn it into -clip and hide a diverged run)
+__device__ __forceinline__ float clamp_keep_nan(float g, float clip) { return (g != g) ? g : fminf(fmaxf(g, -clip), clip); }
+
 // ---- fused clamp + Adam (misc/utils.py:107-111 + torch.optim.Adam) ------------------------------------
 __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
         float* pp = &P.x; float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float gk = fminf(fmaxf(gg[k], -clip), clip);
+            float gk = clamp_keep_nan(gg[k], clip);
             mm[k] = mm[k] + (gk - mm[k]) * omb1;            // torch: exp_avg.lerp_(grad, 1 - beta1)
             vv[k] = b2 * vv[k] + omb2 * gk * gk;            // torch: exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
             const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
     const long base = n4 << 2;
     const long i = base + (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        float gk = fminf(fmaxf(g[i], -clip), clip);
+        float gk = clamp_keep_nan(g[i], clip);
         float mk = m[i] + (gk - m[i]) * omb1;
         float vk = b2 * v[i] + omb2 * gk * gk;
         m[i] = mk; v[i] = vk;
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
 
 __global__ void clamp_kernel(float* g, long n, float clip) {
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = fminf(fmaxf(g[i], -clip), clip);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = clamp_keep_nan(g[i], clip);
 }
 
 int greedy_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
@@ -676,6 +680,8 @@ extern "C" int echr_config_set(const char* key, int32_t value) {
     else if (!strcmp(key, "gemm_h2")) c.gemm_h2 = value;
     else if (!strcmp(key, "persist")) c.persist = value;
     else if (!strcmp(key, "persist_stamps")) c.persist_stamps = value;
+    else if (!strcmp(key, "gemm_tile")) c.gemm_tile = value;          // tuning only: ASCII code of the tile selector ('1','6','a','b','c','s'), 0 = heuristics
+    else if (!strcmp(key, "gemm_split")) c.gemm_split = value;        // tuning only: forced k-slice count of auto-split products, 0 = heuristics
     else if (!strcmp(key, "att_slots")) { ECHR_REQUIRE(value == 2 || value == 4 || value == 8, "config_set: att_slots must be 2, 4 or 8"); c.att_slots = value; }
     else { set_error("config_set: unknown key %s", key); return -22; }
     return 0;

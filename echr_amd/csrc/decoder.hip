@@ -1225,6 +1225,8 @@ extern "C" int64_t echr_sampler_ws_floats(const echr_dec_args* a) { return a ? c
 
 extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
     ECHR_REQUIRE(sa, "decoder_sample: null args");
+    RC(persist_check_async());
+    DeterministicScope det;                    // `seq` is an index output: bitwise reproducible logits (no atomic split-K anywhere below)
     echr_dec_args a = sa->dec;
     const int L = sa->seq_len;
     ECHR_REQUIRE(L > 0 && sa->seq && sa->seq_logp && sa->n_unfinished && sa->ws_sample && a.ws, "decoder_sample: missing buffers");
@@ -1247,10 +1249,54 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
         RC(input_gates(&a, w, s.XT, t, 1, st));
         RC(step_fwd(&a, w, t, off, off, st));
         echr_gemm_desc d = desc_nt(w.OUTD + (long)t * N * 3 * H, 3 * H, a.w_logit, 3 * H, s.LOGITS, a.V1, N, a.V1, 3 * H);
-        d.bias = a.b_logit; d.split_k = -1;
+        d.bias = a.b_logit; d.split_k = 1;
         RC(gemm(d, st));
         RC(greedy_step(s.LOGITS, a.V1, N, a.V1, t, L, s.IT, s.UNF, reinterpret_cast<long long*>(sa->seq), sa->seq_logp,
                        sa->n_unfinished, st));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// one decoder timestep with the state passed in and out (OldModel.get_logprobs_state, OldModel_NEW.py:133-137): the building block the
+// reference's forward()/sample() loop over.  Inference-style entry (no saved activations for a backward pass); bitwise reproducible.
+// ------------------------------------------------------------------------------------------------------
+static int copy2d(float* dst, long dpitch, const float* src, long spitch, long width, long height, hipStream_t st) {
+    if (hipMemcpy2DAsync(dst, dpitch * sizeof(float), src, spitch * sizeof(float), width * sizeof(float), height, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        set_error("decoder_step: state copy failed");
+        return -5;
+    }
+    return 0;
+}
+
+extern "C" int echr_decoder_step(const echr_dec_args* a0, const float* h_in, const float* c_in, float* h_out, float* c_out,
+                                 const echr_dropout* drop, void* stream) {
+    RC(persist_check_async());
+    ECHR_REQUIRE(a0 && h_in && c_in && h_out && c_out, "decoder_step: null arguments");
+    echr_dec_args a = *a0;
+    a.S = 1;
+    RC(check_dims(&a, "decoder_step"));
+    ECHR_REQUIRE(a.ws && a.logp && a.tokens, "decoder_step: missing buffers (ws from echr_decoder_ws_floats with S = 1, logp [N,V1], tokens [N])");
+    DeterministicScope det;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = a.N, H = a.H, E = a.E;
+    DecWs w = carve_ws(&a, a.ws);
+    const DropCfg dh = make_drop(drop, drop ? drop->p_h : 0.f), dout = make_drop(drop, drop ? drop->p_out : 0.f);
+    for (int k = 0; k < 3; ++k) {
+        RC(copy2d(w.HS + k * H, 3 * H, h_in + (long)k * N * H, H, H, N, st));          // [3,N,H] -> h(t-1) rows [N,3H]
+        RC(copy2d(w.CS[k], H, c_in + (long)k * N * H, H, H, N, st));
+    }
+    RC(precompute_static(&a, w, st, true));
+    RC(embed_gather(a.embed, a.tokens, w.XT, N, E, a.V1, st));
+    RC(input_gates(&a, w, w.XT, 0, 1, st));
+    RC(step_fwd(&a, w, 0, dh, dout, st));
+    echr_gemm_desc d = desc_nt(w.OUTD, 3 * H, a.w_logit, 3 * H, a.logp, a.V1, N, a.V1, 3 * H);
+    d.bias = a.b_logit; d.split_k = 1;
+    RC(gemm(d, st));
+    RC(logsoftmax_rows(a.logp, a.V1, N, 1, 0, 1, a.V1, st));
+    for (int k = 0; k < 3; ++k) {
+        RC(copy2d(h_out + (long)k * N * H, H, w.HS + (long)N * 3 * H + k * H, 3 * H, H, N, st));
+        RC(copy2d(c_out + (long)k * N * H, H, w.CS[k] + (long)N * H, H, H, N, st));
     }
     return 0;
 }

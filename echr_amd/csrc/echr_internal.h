@@ -17,10 +17,14 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; };
 Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);
+// while one is alive on the calling thread, auto split-K (fp32 atomics, order-dependent last bits) is disabled: every product is a
+// single fixed-order k loop per output tile
+struct DeterministicScope { DeterministicScope(); ~DeterministicScope(); };
+bool deterministic_gemm();
 
 // persistent (one launch for all timesteps) recurrence of the decoder, csrc/persist.hip
 struct DropCfg;

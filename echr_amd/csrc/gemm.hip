@@ -19,6 +19,11 @@
 
 namespace echr {
 
+static thread_local int g_det_depth = 0;
+bool deterministic_gemm() { return g_det_depth > 0; }
+DeterministicScope::DeterministicScope() { ++g_det_depth; }
+DeterministicScope::~DeterministicScope() { --g_det_depth; }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
@@ -790,13 +795,19 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     // products (tile quantisation: 400 big tiles on 256 CUs), so it is the default; 128x128 stays selectable for tuning.
     int BMs = 64, BNs = 64;
     bool w8 = false;
-    if (h2) { BMs = (getenv("ECHR_H2_BM") ? atoi(getenv("ECHR_H2_BM")) : 128); BNs = 128; }
+    // tuning knobs are read from the environment ONCE per process (tools/gemm_bench.py sets them before loading the library); a stray
+    // variable can therefore not change numerics or split order call by call
+    static const int env_h2_bm = getenv("ECHR_H2_BM") ? atoi(getenv("ECHR_H2_BM")) : 128;
+    const char tile_code = (char)config().gemm_tile;          // 0 = heuristics; set from ECHR_GEMM_TILE at load or by echr_config_set
+    const int env_split = config().gemm_split;
+    if (h2) { BMs = env_h2_bm; BNs = 128; }
     if (use_split) { BMs = 128; BNs = ((long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch >= 96) ? 128 : 64; }
-    if (const char* e = getenv("ECHR_GEMM_TILE")) {          // tuning override (tools/gemm_bench.py); never set in production
-        if (e[0] == '1') { BMs = 128; BNs = 128; } else if (e[0] == '6') { BMs = 64; BNs = 64; }
-        else if (e[0] == 'a') { BMs = 128; BNs = 64; } else if (e[0] == 'b') { BMs = 64; BNs = 128; }
-        else if (e[0] == 'c') { BMs = 128; BNs = 128; w8 = true; }
-        if (use_split) { BMs = 128; BNs = (e[0] == 's') ? 64 : 128; }
+    if (tile_code) {          // tuning override (tools/gemm_bench.py); never set in production
+        const char e0 = tile_code;
+        if (e0 == '1') { BMs = 128; BNs = 128; } else if (e0 == '6') { BMs = 64; BNs = 64; }
+        else if (e0 == 'a') { BMs = 128; BNs = 64; } else if (e0 == 'b') { BMs = 64; BNs = 128; }
+        else if (e0 == 'c') { BMs = 128; BNs = 128; w8 = true; }
+        if (use_split) { BMs = 128; BNs = (e0 == 's') ? 64 : 128; }
     }
     p.tiles_m = (d.M + BMs - 1) / BMs;
     p.tiles_n = (d.N + BNs - 1) / BNs;
@@ -818,7 +829,9 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
             if (split > 1 && kt_total / split < 4) split = max(1, kt_total / 4);
         }
     }
-    if (const char* e = getenv("ECHR_GEMM_SPLIT")) { if (d.split_k < 0 && atoi(e) > 0) split = atoi(e); }
+    if (env_split > 0 && d.split_k < 0) split = env_split;
+    // reproducible mode (greedy sampler: index outputs must be bit-exact run to run): no k-slices that add with fp32 atomics
+    if (deterministic_gemm() && d.split_k < 0) split = 1;
     // grouped problems that share an output must add atomically even when K would not be split: force two k-slices
     bool shared_c = false;
     for (int gi = 1; gi < ng; ++gi) for (int gj = 0; gj < gi; ++gj) shared_c = shared_c || ds[gi].C == ds[gj].C;

@@ -146,19 +146,42 @@ extern "C" int echr_tsrm_posemb(const int32_t* ev_start, const int32_t* ev_len, 
     return posemb(ev_start, ev_len, pos, N, Df, (hipStream_t)stream);
 }
 
+static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void* stream, const float* x_given, const float* pos_given);
+
 extern "C" int echr_tsrm_fwd(const echr_tsrm_args* a, const echr_dropout* drop, void* stream) {
     RC(check(a, "tsrm_fwd"));
+    return tsrm_fwd_impl(a, drop, stream, nullptr, nullptr);
+}
+
+// attention_module_multi_head.forward on its own (MA_attention_8_NEW.py:101-177): the caller hands in the already embedded events
+// roi_feat [N,Df] and the pairwise position embedding [N,N,Df]; inference-style entry (fST0, use_posit = 1)
+extern "C" int echr_tsrm_attn_fwd(const echr_tsrm_args* a, const float* roi_feat, const float* pos_emb, const echr_dropout* drop, void* stream) {
+    ECHR_REQUIRE(a && roi_feat && pos_emb, "tsrm_attn_fwd: null arguments");
+    ECHR_REQUIRE(a->N > 0 && a->Df > 0 && a->Do > 0 && a->G > 0 && a->Df % a->G == 0 && a->Do % a->G == 0 && a->Df % 4 == 0, "tsrm_attn_fwd: bad dims");
+    ECHR_REQUIRE(a->ws && a->out, "tsrm_attn_fwd: missing buffers");
+    return tsrm_fwd_impl(a, drop, stream, roi_feat, pos_emb);
+}
+
+static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void* stream, const float* x_given, const float* pos_given) {
     hipStream_t st = (hipStream_t)stream;
     const int N = a->N, Din = a->Din, Df = a->Df, Do = a->Do, G = a->G;
     const int NN = N * N, dgq = Df / G, dgo = Do / G;
     TsrmWs w = carve(N, Din, Df, Do, G, a->ws);
     echr_gemm_desc d;
     RC(fill_zero(w.X, w.zero_floats, st));           // X | GATE | Q | K | XW: the split-K products below accumulate into zeros
+    if (x_given) {
+        if (hipMemcpyAsync(w.X, x_given, (size_t)N * Df * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(w.POS, pos_given, (size_t)NN * Df * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("tsrm_attn_fwd: input copy failed");
+            return -5;
+        }
+    } else {
     // event embedding (:44)
     d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1; d.beta = 1.f;
     RC(gemm(d, st));
     // pairwise position features -> per-head gates (:39-41, :108-116)
     RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, st));
+    }
     // fc1 over the N*N event pairs: the one TSRM product big enough for the h2 path (tanh fused in the epilogue)
     if (config().gemm_h2 && NN >= 1024) {
         H2PackJob pj[2] = {pack_rows(w.POS, Df, NN, Df, w.PK_POS), pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1)};

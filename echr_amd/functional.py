@@ -243,7 +243,7 @@ class DecoderFunction(torch.autograd.Function):
         return (g_video, g_event, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
-def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params):
+def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, debug=None):
     """Greedy OldModel.sample (OldModel_NEW.py:139-187) with every step on device; one host sync at the end.
 
     Returns (seq int64 [N,T], logp fp32 [N,T]) with T <= seq_length, or ([], []) when nothing was generated."""
@@ -262,6 +262,11 @@ def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params):
     sa = L.SampleArgs(a, seq_length, L.ptr(seq, torch.int64), L.ptr(slp), L.ptr(nun, torch.int32), L.ptr(wss))
     L.check(lib.echr_decoder_sample(C.byref(sa), L.stream_ptr()), 'decoder_sample')
     counts = nun.cpu().numpy()                 # the only device->host sync of the whole decode
+    if debug is not None:                      # tests: the raw logits [N,V1] of the last decoder step (sampler workspace: XT | LOGITS | ...)
+        E, V1 = ps[0].shape[1], ps[0].shape[0]
+        o = (N * E + 63) // 64 * 64
+        debug['last_logits'] = wss[o:o + N * V1].view(N, V1).clone()
+        debug['seq_full'], debug['logp_full'] = seq.clone(), slp.clone()
     T = seq_length
     for t in range(1, seq_length + 1):        # OldModel_NEW.py:179-180: stop at the first step with nobody unfinished
         if counts[t] == 0:
@@ -270,6 +275,48 @@ def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params):
     if T == 0:
         return [], []
     return seq[:, :T].contiguous(), slp[:, :T].contiguous()
+
+
+def decoder_step(it, video, event, c3d, ev_start, ev_len, A, state, params, drop=None):
+    """OldModel.get_logprobs_state (OldModel_NEW.py:133-137): ONE timestep, state in / state out.
+
+    it int [N] tokens; state = (h [3,N,H] dropped outputs, c [3,N,H]).  Returns (log-probs [N,V1], (h', c')).  Forward only."""
+    lib = L.load()
+    video, event, c3d = _f32c(video), _f32c(event), _f32c(c3d)
+    ps = [_f32c(p) for p in params]
+    N = event.shape[0]
+    dev = event.device
+    V1 = ps[0].shape[0]
+    tok = it.to(device=dev, dtype=torch.int32).contiguous()
+    h_in, c_in = _f32c(state[0]), _f32c(state[1])
+    if tuple(h_in.shape) != tuple(c_in.shape) or h_in.shape[0] != 3 or h_in.shape[1] != N:
+        raise ValueError('state must be a pair of [3,N,H] tensors (got %s, %s)' % (tuple(h_in.shape), tuple(c_in.shape)))
+    logp = torch.empty(N, V1, device=dev, dtype=torch.float32)
+    a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tok, A, 1, None, logp)
+    ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=dev, dtype=torch.float32)
+    a.ws = L.ptr(ws)
+    h_out, c_out = torch.empty_like(h_in), torch.empty_like(c_in)
+    d = (drop if drop is not None else DropState(training=False)).c()
+    L.check(lib.echr_decoder_step(C.byref(a), L.ptr(h_in), L.ptr(c_in), L.ptr(h_out), L.ptr(c_out), C.byref(d), L.stream_ptr()), 'decoder_step')
+    return logp, (h_out, c_out)
+
+
+def tsrm_attention(roi_feat, position_embedding, n_head, params, d_o, drop=None):
+    """attention_module_multi_head.forward (MA_attention_8_NEW.py:101-177) on the embedded events roi_feat [N,Df] and the pairwise
+    position embedding [N,N,Df].  params = (fc1.w, fc1.b, fc2.w, fc2.b, q.w, q.b, k.w, k.b, out.w [Do,Df], out.b).  Forward only."""
+    lib = L.load()
+    x, pos = _f32c(roi_feat), _f32c(position_embedding)
+    ps = [_f32c(p) for p in params]
+    N, Df = x.shape
+    if tuple(pos.shape) != (N, N, Df):
+        raise ValueError('position_embedding must be [N,N,%d] (got %s)' % (Df, tuple(pos.shape)))
+    Din = Df
+    ws = torch.empty(lib.echr_tsrm_ws_floats(N, Din, Df, d_o, n_head), device=x.device, dtype=torch.float32)
+    out = torch.empty(N, d_o, device=x.device, dtype=torch.float32)
+    a = L.TsrmArgs(N, Din, Df, d_o, n_head, None, None, *[L.ptr(p) for p in ps], None, None, None, L.ptr(ws), L.ptr(out))
+    d = (drop if drop is not None else DropState(training=False)).c()
+    L.check(lib.echr_tsrm_attn_fwd(C.byref(a), L.ptr(x), L.ptr(pos), C.byref(d), L.stream_ptr()), 'tsrm_attn_fwd')
+    return out
 
 
 # --------------------------------------------------------------------------------------------------

@@ -107,6 +107,19 @@ class attention_module_multi_head(nn.Module):
         self.linear_out_1 = nn.Conv2d(in_channels=group * roi_emb_dim, out_channels=self.d_o, kernel_size=(1, 1), stride=1,
                                       groups=group)
         self.dropout = nn.Dropout(0.3)
+        self._drop_calls = 0
 
     def forward(self, roi_feat, position_embedding, use_posit=True):
-        raise NotImplementedError('call MA_Attention8.forward: the fused HIP encoder owns this sub-module\'s arithmetic')
+        """The gated multi-head relation attention on its own (MA_attention_8_NEW.py:101-177): roi_feat [N,d_feats] = embedded events,
+        position_embedding [N,N,pos_emb_dim].  Runs through echr_tsrm_attn_fwd; forward only (MA_Attention8.forward is the
+        differentiable, fused entry the caption path uses)."""
+        if not use_posit or self.fST_type != 'fST0':
+            raise NotImplementedError('the HIP path implements the shipped ECHR recipe: use_posit=1, fST_type=fST0')
+        w_out = self.linear_out_1.weight.reshape(self.linear_out_1.weight.shape[0], -1)
+        ps = (self.pair_pos_fc1.weight, self.pair_pos_fc1.bias, self.pair_pos_fc2.weight, self.pair_pos_fc2.bias,
+              self.query_1.weight, self.query_1.bias, self.key_1.weight, self.key_1.bias, w_out, self.linear_out_1.bias)
+        drop = EF.DropState(int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, self._drop_calls, self.training, self.dropout.p)
+        if self.training:
+            self._drop_calls += 1
+        with torch.no_grad():
+            return EF.tsrm_attention(roi_feat, position_embedding, self.group, ps, self.d_o, drop)

@@ -145,9 +145,21 @@ class OldModel(nn.Module):
         return EF.DecoderFunction.apply(video, event, cv.feats, cv.ev_start, cv.ev_len, tokens, cv.max_len, cv.rows_disjoint, drop, sink,
                                         *self.native_params())
 
+    def init_hidden(self, video, event, clip):
+        """Zero initial state (h, c), each [3,N,H] (OldModel_NEW.py:72-78 with CG_init_feats_type = '')."""
+        n = event.shape[0] if event is not None else clip.shape[0]
+        w = self.logit.weight
+        return (w.new_zeros(self.num_layers, n, self.rnn_size), w.new_zeros(self.num_layers, n, self.rnn_size))
+
     def get_logprobs_state(self, it, video, event, clip, clip_mask, state):
-        raise NotImplementedError('single-step API: use forward() (teacher forcing) or sample() (greedy), which run the whole '
-                                  'sequence inside libechr_hip.so')
+        """One decoder timestep, state in / state out (OldModel_NEW.py:133-137): (log-probs [N,V+1], (h', c')).
+
+        Runs through echr_decoder_step; forward only (the reference's training loop is forward(), which keeps the whole
+        sequence inside the library).  In training mode each call draws a fresh dropout stream."""
+        cv = self._clip_view(clip, clip_mask)
+        drop = self.next_drop_state()
+        with torch.no_grad():
+            return EF.decoder_step(it, video, event, cv.feats, cv.ev_start, cv.ev_len, cv.max_len, state, self.native_params(), drop)
 
     def sample(self, video, event, clip, clip_mask, opt={}):
         """Greedy decoding (OldModel_NEW.py:139-187 with sample_max=1, beam_size=1)."""

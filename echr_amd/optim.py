@@ -19,6 +19,10 @@ class ClampAdam(torch.optim.Optimizer):
         self.pending_clip = None
         self.arena = arena            # echr_amd.arena.ParamArena: one launch over the whole model when gradients live there
         self._flat = None
+        # True: `clip_gradient` only records the clip and the fused step kernel applies it (exact when every optimiser step follows
+        # ONE backward, i.e. the reference's m_batch = 1: clamp(g) either way; saves a 174 MB pass).  Set False for gradient
+        # accumulation (m_batch > 1), where the reference clamps the running sum after every backward.
+        self.defer_clamp = True
 
     def _flat_step(self, clip):
         """Whole-model update in ONE kernel launch; valid when all parameters and all live gradients alias the arena."""
@@ -38,6 +42,67 @@ class ClampAdam(torch.optim.Optimizer):
         b1, b2 = group['betas']
         EF.clamp_adam_(ar.flat_p, ar.flat_g, st['m'], st['v'], st['step'], group['lr'], b1, b2, group['eps'], clip)
         return True
+
+    @torch.no_grad()
+    def clamp_grads_(self, clip, fused_step_follows=False):
+        """In-place element-wise clamp of every live gradient (misc/utils.py:107-111).  With the flat arena: one launch."""
+        ar = self.arena
+        if ar is not None and ar.grads_in_arena():
+            if self.defer_clamp:
+                return                      # single-backward steps: the fused step kernel clamps (same values, one pass less)
+            ar.zero_unused_grads(keep=True)
+            EF.clamp_(ar.flat_g, clip)
+            return
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is not None:
+                    EF.clamp_(p.grad.data if p.grad.is_contiguous() else p.grad.data.contiguous(), clip)
+
+    # ---- checkpoint interop (train.py:214-216,456-461 save / restore cg_optimizer.state_dict()) --------------------------------
+    def _export_flat(self):
+        """Flat arena state -> torch.optim.Adam's per-parameter entries (step, exp_avg, exp_avg_sq); parameters that never received a
+        gradient have no entry, exactly like torch.optim.Adam (their flat moments are identically zero)."""
+        ar, st = self.arena, self._flat
+        for p, o in zip(ar.params, ar.offsets):
+            n = p.numel()
+            m, v = st['m'][o:o + n], st['v'][o:o + n]
+            if p.grad is None and not bool(m.any()) and not bool(v.any()):
+                continue
+            self.state[p] = dict(step=torch.tensor(float(st['step'])), exp_avg=m.view(p.shape).clone(), exp_avg_sq=v.view(p.shape).clone())
+
+    def state_dict(self):
+        """torch.optim.Adam's layout whichever path ran: a reference `cg_optimizer` blob and ours are interchangeable."""
+        if self._flat is not None:
+            saved = self.state
+            self.state = type(saved)()
+            try:
+                self._export_flat()
+                return super(ClampAdam, self).state_dict()
+            finally:
+                self.state = saved
+        return super(ClampAdam, self).state_dict()
+
+    def load_state_dict(self, state_dict):
+        """Accepts torch.optim.Adam's layout (ours or the reference's).  With an arena the per-parameter moments are folded back into
+        the flat buffers, so a resumed run stays on the single-launch path; all parameters must then share one step count (they do:
+        every live parameter is updated at every step)."""
+        super(ClampAdam, self).load_state_dict(state_dict)
+        self._flat = None
+        ar = self.arena
+        if ar is None or not self.state:
+            return
+        steps = {int(float(st['step'])) for st in self.state.values() if 'step' in st}
+        if len(steps) != 1 or {id(p) for p in self.param_groups[0]['params']} != {id(p) for p in ar.params} or len(self.param_groups) != 1:
+            return                                   # keep the per-tensor path (still correct, one launch per tensor)
+        flat = dict(step=steps.pop(), m=torch.zeros_like(ar.flat_p), v=torch.zeros_like(ar.flat_p))
+        for p, o in zip(ar.params, ar.offsets):
+            st = self.state.get(p)
+            if st:
+                n = p.numel()
+                flat['m'][o:o + n].copy_(st['exp_avg'].reshape(-1).to(flat['m']))
+                flat['v'][o:o + n].copy_(st['exp_avg_sq'].reshape(-1).to(flat['v']))
+        self.state.clear()
+        self._flat = flat
 
     @torch.no_grad()
     def step(self, closure=None):

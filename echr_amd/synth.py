@@ -143,7 +143,44 @@ CASES = {
     'c2': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=31)),
     # config 2/3 shape, every event 128 segments long (the dense batch 64 x 128 seg x 500-d bench workload)
     'c2full': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=41, full_len=True)),
+    # EXACTLY the layout bench.py times (BASELINE config 3): 64 disjoint 128-segment events on a T_v = 8192 video
+    'c3bench': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=1234, disjoint=True)),
 }
+
+
+def sst_param_shapes(opt):
+    """Name -> shape of SST.state_dict() (models/sst_model.py:12,22-23: nn.LSTM(video_dim, hidden_dim, 2 layers) + Linear(hidden_dim, K))."""
+    H, D, K = opt.hidden_dim, opt.video_dim, opt.K
+    s = {}
+    for l, cin in ((0, D), (1, H)):
+        s['rnn.weight_ih_l%d' % l] = (4 * H, cin)
+        s['rnn.weight_hh_l%d' % l] = (4 * H, H)
+        s['rnn.bias_ih_l%d' % l] = (4 * H,)
+        s['rnn.bias_hh_l%d' % l] = (4 * H,)
+    s['scores.weight'] = (K, H)
+    s['scores.bias'] = (K,)
+    return s
+
+
+def make_sst_params(opt, seed=7):
+    rs = np.random.RandomState(seed)
+    r = 1.0 / math.sqrt(opt.hidden_dim)
+    shapes = sst_param_shapes(opt)
+    return {k: rs.uniform(-r, r, size=shapes[k]).astype(np.float32) for k in sorted(shapes)}
+
+
+def make_c5(seed=51, N=64, T_v=256, L=21, V1=5001):
+    """BASELINE config 5: ONE 256-segment video; SST proposal encoder over all 256 segments -> tap_feats -> caption path on N
+    proposals of 4..256 segments (at least one spans the whole video), joint loss lambda1 * tap + lambda2 * cg (train.py:322-329).
+    Returns (opt, caption params, SST params, video dict incl. the proposal-loss inputs)."""
+    opt = default_opt(vocab_size=V1 - 1, seq_length=L - 2)
+    opt.lambda1, opt.lambda2 = 0.01, 1.0                   # opts.py:194-196
+    vid = make_video(N, T_v, L, V1, seed=seed, T_v=T_v)
+    rs = np.random.RandomState(seed + 1000)
+    vid['tap_labels'] = (rs.uniform(size=(T_v, opt.K)) > 0.9).astype(np.float32)
+    vid['tap_masks'] = (np.arange(T_v)[:, None] >= np.arange(opt.K)[None, :]).astype(np.float32)
+    vid['w1'] = rs.uniform(0.05, 0.3, size=(opt.K,)).astype(np.float32)
+    return opt, make_params(opt, 0), make_sst_params(opt), vid
 
 
 def make_case(name, param_seed=0):

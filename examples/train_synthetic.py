@@ -8,9 +8,10 @@ Follows the iteration protocol of the reference's train.py (:253-331) with the s
   total = lambda1 * tap_loss + lambda2 * cg_loss  ('tap_cg' joint mode, :322-329), backward,
   clip_gradient + optimizer.step every m_batch videos (:281-283,313-317), step LR decay (:232-240),
 and saves checkpoints in the reference's dict layout (:456-461) so that either code base can resume the other's run.
-The proposal encoder is the stock-PyTorch SST wrapper (not part of the HIP hot path); the caption path is echr_amd.
+Both models run natively (echr_amd's SST: echr_sst_fwd/bwd; the caption path: echr_tsrm_* / echr_decoder_*), both optimisers are
+the fused ClampAdam, and `--resume` restores models AND optimiser state (train.py:214-216).
 
-usage: python examples/train_synthetic.py [--iters 20] [--m_batch 2] [--joint] [--save /tmp/echr_ckpt.pth]
+usage: python examples/train_synthetic.py [--iters 20] [--m_batch 2] [--joint] [--save /tmp/echr_ckpt.pth] [--resume /tmp/echr_ckpt.pth]
 """
 import argparse
 import os
@@ -61,6 +62,7 @@ def main(argv=None):
     ap.add_argument('--vocab', type=int, default=500)
     ap.add_argument('--lr', type=float, default=5e-4)
     ap.add_argument('--save', type=str, default='')
+    ap.add_argument('--resume', type=str, default='', help='checkpoint written by --save (or by the reference): models + optimiser state')
     ap.add_argument('--quiet', action='store_true')
     a = ap.parse_args(argv)
     dev = torch.device('cuda')
@@ -70,13 +72,24 @@ def main(argv=None):
     cg_model = echr_amd.CaptionGenerator(opt).to(dev)
     tap_model.train()
     cg_model.train()
-    tap_opt = torch.optim.Adam(tap_model.parameters(), lr=opt.lr)
+    tap_opt = ClampAdam(tap_model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon)
     cg_opt = ClampAdam(cg_model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon,
                        arena=cg_model.build_arena())
+    # the reference clamps the running gradient after EVERY backward (train.py:315-317); with m_batch = 1 that equals the clamp fused
+    # into the step kernel, with accumulation it does not
+    cg_opt.defer_clamp = tap_opt.defer_clamp = a.m_batch == 1
+    start = 0
+    if a.resume:
+        ck = torch.load(a.resume, map_location=dev)
+        cg_model.load_state_dict(ck['cg_model'])
+        tap_model.load_state_dict(ck['tap_model'])
+        cg_opt.load_state_dict(ck['cg_optimizer'])
+        tap_opt.load_state_dict(ck['tap_optimizer'])
+        start = int(ck['iteration'])
     cg_crit, tap_crit = utils.LanguageModelCriterion(), utils.TAPModelCriterion()
     loader = make_loader(opt, 8, a.events, a.segments, opt.CG_seq_length + 2)
     history = []
-    for it in range(a.iters):
+    for it in range(start, start + a.iters):
         v = loader[it % len(loader)]
         set_lr_for_epoch(cg_opt, opt.lr, it // len(loader))
         if it % a.m_batch == 0:
@@ -94,16 +107,15 @@ def main(argv=None):
                                 torch.from_numpy(v['w1']).to(dev))
             loss = 0.01 * tap_loss + 1.0 * cg_loss                                # lambda1, lambda2 defaults (opts.py:194-196)
         loss.backward()
+        utils.clip_gradient(cg_opt, opt.grad_clip)                                # after every backward, as train.py:315,325-326
+        if a.joint:
+            utils.clip_gradient(tap_opt, opt.grad_clip)
         if (it + 1) % a.m_batch == 0:
-            utils.clip_gradient(cg_opt, opt.grad_clip)
             cg_opt.step()
             if a.joint:
-                for p in tap_model.parameters():
-                    if p.grad is not None:
-                        p.grad.clamp_(-opt.grad_clip, opt.grad_clip)
                 tap_opt.step()
         history.append(float(cg_loss))
-        if not a.quiet and (it % 5 == 0 or it == a.iters - 1):
+        if not a.quiet and (it % 5 == 0 or it == start + a.iters - 1):
             print('iter %3d  cg_loss %.4f' % (it, history[-1]), flush=True)
     cg_model.eval()
     with torch.no_grad():
@@ -115,7 +127,7 @@ def main(argv=None):
     if not a.quiet:
         print('greedy captions (token ids) of video 0:', seq[:3].tolist() if len(seq) else seq)
     if a.save:
-        save_checkpoint(a.save, a.iters, cg_model, tap_model, cg_opt, tap_opt)
+        save_checkpoint(a.save, start + a.iters, cg_model, tap_model, cg_opt, tap_opt)
     return history, cg_model, tap_model
 
 

@@ -143,6 +143,10 @@ int64_t echr_tsrm_ws_floats(int32_t N, int32_t Din, int32_t Df, int32_t Do, int3
 int64_t echr_tsrm_ws_bwd_floats(int32_t N, int32_t Din, int32_t Df, int32_t Do, int32_t G);
 int echr_tsrm_fwd(const echr_tsrm_args* a, const echr_dropout* drop, void* stream);
 int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr_dropout* drop, void* stream);
+/* attention_module_multi_head.forward on its own (MA_attention_8_NEW.py:101-177, fST0, use_posit = 1): roi_feat [N,Df] = the embedded
+ * events, pos_emb [N,N,Df] = the pairwise position embedding; a->ech / ev_start / ev_len / w_emb / b_emb are not read (Din only
+ * sizes the workspace).  Forward only. */
+int echr_tsrm_attn_fwd(const echr_tsrm_args* a, const float* roi_feat, const float* pos_emb, const echr_dropout* drop, void* stream);
 /* position embedding alone (float64 math on device, fp32 result [N,N,Df]); replaces the numpy
  * extract_position_matrix / extract_position_embedding (:51-79) + the host->device copy at :41 */
 int echr_tsrm_posemb(const int32_t* ev_start, const int32_t* ev_len, float* pos, int32_t N, int32_t Df, void* stream);
@@ -208,6 +212,14 @@ int64_t echr_decoder_ws_floats(const echr_dec_args* a);
 int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a);
 int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream);
 int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream);
+
+/* ONE decoder timestep with the recurrent state passed in and out: OldModel.get_logprobs_state (models/OldModel_NEW.py:133-137) =
+ * embed -> ThreeStream_Core.forward (:801-823, incl. Attention.forward :376-401) -> dropout -> logit -> log_softmax.
+ * a: S is ignored (treated as 1), tokens = it [N] int32, logp = out [N,V1], ws from echr_decoder_ws_floats with S = 1.
+ * h_in / c_in / h_out / c_out: [3,N,H] (the reference's `state` tuple; h holds the DROPPED outputs, :810,814,818,821).
+ * drop->offset selects the dropout stream of this call (training mode).  Forward only; bitwise reproducible. */
+int echr_decoder_step(const echr_dec_args* a, const float* h_in, const float* c_in, float* h_out, float* c_out,
+                      const echr_dropout* drop, void* stream);
 
 /* masked NLL of LanguageModelCriterion on log-probs [N,S,V1]: loss (device scalar) */
 int echr_nll_loss_fwd(const float* logp, const int32_t* target, const float* mask, float* loss, int32_t N, int32_t S,

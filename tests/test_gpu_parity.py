@@ -156,7 +156,7 @@ def test_full_path_vs_oracle(case, train_mode):
             assert U.grad_close(k, grads[k], g, TOL_GRAD), (k, U.relerr(grads[k], g))
 
 
-@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full'])
+@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full', 'c3bench'])
 @pytest.mark.parametrize('train_mode', [False, True])
 def test_full_path_vs_reference_golden(case, train_mode):
     """Same, against the fixtures the reference itself produced (full tensors for 'tiny', summaries otherwise)."""
@@ -194,7 +194,93 @@ def test_full_path_vs_reference_golden(case, train_mode):
             assert np.abs(v - ref).max() < TOL_GRAD * scale, (key, np.abs(v - ref).max() / scale)
 
 
-@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full'])
+def _check_summaries(g, mode, pred, loss, grads, loss_key='|loss', grad_tag='|grad|'):
+    assert abs(loss - float(g[mode + loss_key])) < TOL_LOSS * abs(float(g[mode + loss_key]))
+    s = SM.summarize_logp(pred)
+    assert np.abs(s['slice'] - g[mode + '|logp|slice']).max() < TOL_LOGP
+    assert np.abs(s['top1'] - g[mode + '|logp|top1']).max() < TOL_LOGP
+    safe = g[mode + '|logp|margin'] > 1e-4
+    assert np.array_equal(s['argmax'][safe], g[mode + '|logp|argmax'][safe])
+    for key, v in SM.summarize_grads(grads).items():
+        ref = g[mode + grad_tag + key]
+        name = key.split('|')[0]
+        if name in U.NOISE_ONLY:
+            assert np.abs(np.asarray(v)).max() < 1e-6 and np.abs(np.asarray(ref)).max() < 1e-6, (key, v, ref)
+            continue
+        scale = max(float(g[mode + grad_tag + name + '|linf']), U.GRAD_FLOOR)
+        if key.endswith('|l2') or key.endswith('|linf'):
+            assert abs(float(v) - float(ref)) < TOL_GRAD * max(abs(float(ref)), U.GRAD_FLOOR), (key, float(v), float(ref))
+        else:
+            assert np.abs(v - ref).max() < TOL_GRAD * scale, (key, np.abs(v - ref).max() / scale)
+
+
+@pytest.mark.parametrize('persist', [1, 0])
+def test_bench_layout_with_arena_vs_reference_golden(persist):
+    """The EXACT configuration bench.py times -- N64 x A128 disjoint events on T_v = 8192 (rows_disjoint = 1: plain-store branch of the
+    d P_all pass), train mode, flat parameter/gradient arena (zeroed = 1 accumulate paths), fused clamp+Adam afterwards -- against the
+    reference's own outputs on the same inputs (case_c3bench.npz); with the persistent recurrence and with the launch-per-phase one."""
+    from echr_amd import _lib
+    from echr_amd.misc.utils import LanguageModelCriterion
+    lib = _lib.load()
+    opt, params, vid = synth.make_case('c3bench')
+    assert vid['T_v'] == 8192
+    g = U.gold('case_c3bench.npz')
+    try:
+        assert lib.echr_config_set(b'persist', persist) == 0
+        m = U.build_gpu_model(opt, params, True)
+        arena = m.build_arena()
+        dev = torch.device('cuda')
+        tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+        labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+        pred = m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+        loss = LanguageModelCriterion()(pred, labels[:, 1:].to(dev), masks[:, 1:].to(dev))
+        loss.backward()
+        assert arena.grads_in_arena()
+        grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else None) for k, p in m.named_parameters()}
+        _check_summaries(g, 'train', pred.detach().cpu().numpy(), float(loss), grads)
+    finally:
+        lib.echr_config_set(b'persist', 1)
+
+
+@pytest.mark.parametrize('train_mode', [False, True])
+def test_c5_sst_plus_decoder_vs_reference_golden(train_mode):
+    """BASELINE config 5 as ONE unit: native SST over a 256-segment video -> tap_feats -> caption path on 64 proposals of 4..256
+    segments -> lambda1 * tap_loss + lambda2 * cg_loss -> gradients into both models (train.py:322-329), against the reference's
+    own summaries (case_c5.npz: reference SST in eval mode, caption model eval / train with the injected dropout masks)."""
+    from echr_amd import models as EM
+    from echr_amd.misc.utils import LanguageModelCriterion, TAPModelCriterion
+    opt, params, sst_params, vid = synth.make_c5()
+    g = U.gold('case_c5.npz')
+    mode = 'train' if train_mode else 'eval'
+    m = U.build_gpu_model(opt, params, train_mode)
+    dev = torch.device('cuda')
+    tapm = EM.setup_tap(opt)
+    tapm.load_state_dict({k: torch.from_numpy(v) for k, v in sst_params.items()})
+    tapm = tapm.to(dev)
+    tapm.eval()                                          # the fixture's SST runs without inter-layer dropout
+    c3d, lda = torch.from_numpy(vid['c3d']).to(dev), torch.from_numpy(vid['lda']).to(dev)
+    labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    tap_feats, props = tapm(c3d)
+    pred = m(tap_feats, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+    tap_loss = TAPModelCriterion()(props, torch.from_numpy(vid['tap_masks']), torch.from_numpy(vid['tap_labels']), torch.from_numpy(vid['w1']))
+    cg_loss = LanguageModelCriterion()(pred, labels[:, 1:].to(dev), masks[:, 1:].to(dev))
+    (opt.lambda1 * tap_loss + opt.lambda2 * cg_loss).backward()
+    assert abs(float(tap_loss) - float(g[mode + '|tap_loss'])) < TOL_LOSS * abs(float(g[mode + '|tap_loss']))
+    grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else None) for k, p in m.named_parameters()}
+    _check_summaries(g, mode, pred.detach().cpu().numpy(), float(cg_loss), grads, loss_key='|cg_loss')
+    assert np.abs(tap_feats.detach().cpu().numpy()[::8, ::16] - g['tap_feats|slice']).max() < 1e-5
+    assert np.abs(props.detach().cpu().numpy()[::8, ::16] - g['props|slice']).max() < 1e-5
+    sg = SM.summarize_grads({k: p.grad.detach().cpu().numpy() for k, p in tapm.named_parameters()})
+    for key, v in sg.items():
+        ref = g[mode + '|sstgrad|' + key]
+        scale = max(float(g[mode + '|sstgrad|' + key.split('|')[0] + '|linf']), U.GRAD_FLOOR)
+        if key.endswith('|l2') or key.endswith('|linf'):
+            assert abs(float(v) - float(ref)) < TOL_GRAD * max(abs(float(ref)), U.GRAD_FLOOR), (key, float(v), float(ref))
+        else:
+            assert np.abs(v - ref).max() < TOL_GRAD * scale, (key, np.abs(v - ref).max() / scale)
+
+
+@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full', 'c3bench'])
 def test_greedy_sample_bit_exact(case):
     """mode='eval': the index output must equal the reference's greedy sequence exactly; log-probs within 1e-4."""
     opt, params, vid = synth.make_case(case)
@@ -208,6 +294,32 @@ def test_greedy_sample_bit_exact(case):
     assert tuple(seq.shape) == tuple(g['sample|seq'].shape)
     assert np.array_equal(seq.cpu().numpy(), g['sample|seq'])
     assert np.abs(lp.cpu().numpy() - g['sample|logp']).max() < TOL_LOGP
+
+
+def test_greedy_sampler_is_bitwise_reproducible():
+    """`seq` is an index output: two decodes of the same inputs must agree bit for bit -- sequence, log-probs AND the raw logits of
+    the last step (no fp32-atomic split-K anywhere on the sampler path; OldModel_NEW.py:158 takes the lowest index on ties)."""
+    from echr_amd import functional as EF
+    opt, params, vid = synth.make_case('c2full')
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    runs = []
+    with torch.no_grad():
+        ev = EF.event_index_tensors(vid['soi'], vid['ind'], dev)
+        event = m.get_event_context(tap, c3d, lda, vid['ind'], vid['soi'], _ev=ev, _drop=m.lm_model.next_drop_state())
+        for rep in range(3):
+            if rep == 1:        # disturb the allocator / caches between the runs
+                junk = torch.randn(1 << 22, device=dev).sum().item()
+                assert junk == junk
+            dbg = {}
+            EF.greedy_sample(lda, event, c3d, ev[0], ev[1], ev[3], m.lm_model.seq_length, m.lm_model.native_params(), debug=dbg)
+            runs.append(dbg)
+    for r in runs[1:]:
+        assert torch.equal(r['seq_full'], runs[0]['seq_full'])
+        assert torch.equal(r['logp_full'], runs[0]['logp_full'])
+        assert torch.equal(r['last_logits'], runs[0]['last_logits'])
+    assert torch.isfinite(runs[0]['last_logits']).all()
 
 
 def test_sampler_at_eval_size_is_per_event_and_matches_small_batch():
@@ -452,6 +564,183 @@ def test_persistent_recurrence_equals_launch_path(case):
                 assert U.grad_close(k, g1[k], g0[k], 1e-4), (name, k, U.relerr(g1[k], g0[k]))
 
 
+def _train_steps(m, o, vid, n, first=0):
+    """n optimiser steps of the reference protocol on one video (clip_gradient + step); returns the parameters afterwards."""
+    from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    for i in range(first, first + n):
+        o.zero_grad()
+        pred = m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+        LanguageModelCriterion()(pred, labels[:, 1:].to(dev), masks[:, 1:].to(dev)).backward()
+        clip_gradient(o, 0.05)
+        o.step()
+    torch.cuda.synchronize()
+    return {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize('arena', [True, False])
+def test_optimizer_state_dict_resumes_and_matches_torch_adam_layout(arena):
+    """train.py:214-216,456-461 save / restore `cg_optimizer.state_dict()`: after 3 steps save model + optimiser, load both into a
+    FRESH model + optimiser, step 4 must equal the uninterrupted run (to the run-to-run noise of the fp32-atomic gradient sums, 1e-6
+    of a 1e-3 update; a resume WITHOUT the optimiser state is off by 1e-3); the saved blob has torch.optim.Adam's layout (it loads
+    into torch.optim.Adam and a torch.optim.Adam blob loads back)."""
+    from echr_amd.optim import ClampAdam
+    import io
+    opt, params, vid = synth.make_case('tiny')
+
+    def fresh(state=None):
+        m = U.build_gpu_model(opt, params, True)           # pins the dropout stream (seed, offset)
+        if state is not None:
+            m.load_state_dict(state)
+        ar = m.build_arena() if arena else None
+        return m, ClampAdam(m.parameters(), lr=1e-3, arena=ar)
+
+    m, o = fresh()
+    _train_steps(m, o, vid, 3)
+    buf = io.BytesIO()
+    torch.save({'cg_model': m.state_dict(), 'cg_optimizer': o.state_dict(), 'drop_calls': m.lm_model._drop_calls}, buf)
+    ref4 = _train_steps(m, o, vid, 1, first=3)
+    ck = torch.load(io.BytesIO(buf.getvalue()), map_location='cuda')
+    sd = ck['cg_optimizer']
+    live = [k for k, p in m.named_parameters() if p.grad is not None]
+    assert len(sd['state']) == len(live) and len(sd['state']) > 0
+    for st in sd['state'].values():
+        assert set(st) == {'step', 'exp_avg', 'exp_avg_sq'} and int(float(st['step'])) == 3
+    m2, o2 = fresh(ck['cg_model'])
+    o2.load_state_dict(sd)
+    m2.set_dropout_state(U.SEED, ck['drop_calls'])
+    got4 = _train_steps(m2, o2, vid, 1, first=3)
+    for k in list(ref4):
+        if k in U.NOISE_ONLY:          # true gradient exactly zero: Adam normalises pure rounding noise there (+-lr either way)
+            del ref4[k]
+    for k in ref4:
+        assert np.abs(ref4[k] - got4[k]).max() < 1e-5, (k, np.abs(ref4[k] - got4[k]).max())
+    m5, o5 = fresh(ck['cg_model'])                        # control: moments and step count lost -> visibly different step
+    m5.set_dropout_state(U.SEED, ck['drop_calls'])
+    lost4 = _train_steps(m5, o5, vid, 1, first=3)
+    assert max(np.abs(ref4[k] - lost4[k]).max() for k in ref4) > 1e-4
+    if arena:
+        assert o2._flat is not None and not o2.state      # the resumed run stays on the single-launch path
+    # layout interop with torch.optim.Adam (what the reference saves)
+    # (torch's load_state_dict adopts the blob's tensors without copying and the step kernel updates moments in place: read the
+    #  checkpoint again, as a real resume does)
+    ck = torch.load(io.BytesIO(buf.getvalue()), map_location='cuda')
+    m3, _ = fresh(ck['cg_model'])
+    ta = torch.optim.Adam(m3.parameters(), lr=1e-3)
+    ta.load_state_dict(ck['cg_optimizer'])
+    m4, o4 = fresh(ck['cg_model'])
+    o4.load_state_dict(ta.state_dict())
+    m4.set_dropout_state(U.SEED, ck['drop_calls'])
+    back4 = _train_steps(m4, o4, vid, 1, first=3)
+    for k in ref4:
+        assert np.abs(ref4[k] - back4[k]).max() < 1e-5, k
+
+
+def test_clip_gradient_with_accumulation_matches_reference_protocol():
+    """m_batch = 2 (train.py:281-283,313-317): the reference clamps the RUNNING gradient after every backward, i.e.
+    clamp(clamp(g1) + g2), then steps.  With defer_clamp = False ClampAdam follows that; .grad holds clamped values."""
+    from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+    from echr_amd.optim import ClampAdam
+    opt, params, vid = synth.make_case('tiny')
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    clip = 0.002
+    for arena in (True, False):
+        m = U.build_gpu_model(opt, params, True)
+        o = ClampAdam(m.parameters(), lr=1e-3, arena=m.build_arena() if arena else None)
+        o.defer_clamp = False
+        mr = U.build_gpu_model(opt, params, True)
+        ro = torch.optim.Adam(mr.parameters(), lr=1e-3)
+        for mm, oo, ref in ((m, o, False), (mr, ro, True)):
+            oo.zero_grad()
+            for _ in range(2):
+                pred = mm(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+                LanguageModelCriterion()(pred, labels[:, 1:].to(dev), masks[:, 1:].to(dev)).backward()
+                if ref:
+                    for p in mr.parameters():
+                        if p.grad is not None:
+                            p.grad.data.clamp_(-clip, clip)
+                else:
+                    clip_gradient(oo, clip)
+            oo.step()
+        for (k, p), (_, q) in zip(m.named_parameters(), mr.named_parameters()):
+            if k in U.NOISE_ONLY:
+                continue
+            if q.grad is not None:
+                assert float(p.grad.abs().max()) <= clip * (1 + 1e-6), k
+                assert float((p.grad - q.grad).abs().max()) <= 1e-6 * clip + 1e-4 * float(q.grad.abs().max()), k
+            assert float((p.detach() - q.detach()).abs().max()) < 2e-6, k
+
+
+def test_clamp_propagates_nan_like_torch():
+    from echr_amd import functional as EF
+    g = torch.tensor([1.0, float('nan'), -500.0, 7.0, float('inf'), 0.5, 3.0], device='cuda')
+    out = EF.clamp_(g.clone(), 100.0).cpu()
+    ref = g.cpu().clamp(-100.0, 100.0)
+    assert torch.isnan(out[1]) and torch.equal(torch.nan_to_num(out, nan=-1.0), torch.nan_to_num(ref, nan=-1.0))
+    p = torch.ones(7, device='cuda')
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    EF.clamp_adam_(p, g, m, v, 1, 1e-3, 0.9, 0.999, 1e-8, 100.0)
+    assert torch.isnan(p[1]) and torch.isfinite(p[[0, 2, 3, 4, 5, 6]]).all()
+
+
+@pytest.mark.parametrize('case', ['tiny', 'c1'])
+def test_get_logprobs_state_single_step_vs_oracle(case):
+    """OldModel.get_logprobs_state (OldModel_NEW.py:133-137): one timestep with state in / state out, three consecutive steps from the
+    zero state, against oracle.logprobs_state; also equals the teacher-forced forward()'s log-probs of those steps."""
+    from echr_amd import functional as EF
+    from oracle import echr_ref_cpu as O
+    opt, params, vid = synth.make_case(case)
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]) for k in ('tap', 'c3d', 'lda'))
+    labels = torch.from_numpy(vid['labels'])
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        event_ref = O.event_context(P, tap, c3d, vid['ind'], vid['soi'], opt.n_head)
+        clip_ref, mask_ref = O.clip_context(c3d, vid['soi'])
+        video = m.get_video_context(tap.to(dev), c3d.to(dev), lda.to(dev), vid['ind'], vid['soi'])
+        event = m.get_event_context(tap.to(dev), c3d.to(dev), lda.to(dev), vid['ind'], vid['soi'])
+        clip, cmask = m.get_clip_context(tap.to(dev), c3d.to(dev), lda.to(dev), vid['ind'], vid['soi'])     # padded [N,A,D] + mask (reference form)
+        full = m(tap.to(dev), c3d.to(dev), lda.to(dev), labels, vid['ind'], vid['soi'], mode='train').cpu()
+        state = m.lm_model.init_hidden(video, event, clip)
+        N, H = event.shape[0], opt.CG_rnn_size
+        rstate = (torch.zeros(3, N, H), torch.zeros(3, N, H))
+        for t in range(min(3, full.shape[1])):
+            it = labels[:, t]
+            logp, state = m.lm_model.get_logprobs_state(it.to(dev), video, event, clip, cmask, state)
+            rlogp, rstate = O.logprobs_state(P, it, lda, event_ref, clip_ref, mask_ref, rstate)
+            assert float((logp.cpu() - rlogp).abs().max()) < TOL_LOGP, t
+            assert float((state[0].cpu() - rstate[0]).abs().max()) < 1e-5 and float((state[1].cpu() - rstate[1]).abs().max()) < 1e-5, t
+            assert float((logp.cpu() - full[:, t]).abs().max()) < 2e-5, t
+
+
+def test_attention_module_multi_head_forward_vs_oracle():
+    """fusion_model.enc_attn(roi_feat, position_embedding) on its own (MA_attention_8_NEW.py:101-177) == the oracle's TSRM on the same
+    embedded events; and MA_Attention8.forward == enc_attn(event_emb(feats), pos)."""
+    from echr_amd import functional as EF
+    from oracle import echr_ref_cpu as O
+    opt, params, vid = synth.make_case('c1')
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d = torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d'])
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        ech = torch.cat((O.event_pool(c3d, vid['soi']), tap[torch.from_numpy(vid['ind'])]), 1)
+        ref = O.tsrm_forward(P, ech, vid['soi'], opt.n_head)
+        fm = m.fusion_model
+        pm = fm.extract_position_matrix(np.asarray(vid['soi']), len(vid['soi']))
+        pos = torch.from_numpy(fm.extract_position_embedding(pm, opt.d_feats).astype(np.float32)).to(dev)
+        x = torch.nn.functional.linear(ech, P['fusion_model.event_emb.weight'], P['fusion_model.event_emb.bias']).to(dev)
+        out = fm.enc_attn(x, pos, True)
+        whole = fm(ech.to(dev), vid['soi'])
+    assert float((out.cpu() - ref).abs().max()) < 1e-5
+    assert float((out - whole).abs().max()) < 1e-5
+
+
 def test_reference_checkpoint_reproduces_reference_output():
     """Weights initialised and saved by the reference itself -> loaded as is -> the reference's own eval-mode log-probs."""
     import echr_amd
@@ -484,6 +773,9 @@ def test_reference_shaped_driver_trains_and_checkpoints(tmp_path, joint, m_batch
     assert np.mean(hist[-4:]) < np.mean(hist[:4]) - 0.1, hist
     ck = torch.load(path, map_location='cpu')
     assert set(ck) == {'iteration', 'cg_model', 'tap_model', 'cg_optimizer', 'tap_optimizer'}
+    assert len(ck['cg_optimizer']['state']) > 0 and all('exp_avg' in st for st in ck['cg_optimizer']['state'].values())
+    hist2, _, _ = mod.main(['--iters', '4', '--m_batch', str(m_batch), '--resume', path, '--quiet', '--lr', '2e-3'] + (['--joint'] if joint else []))
+    assert np.mean(hist2) < np.mean(hist[:4]) - 0.1, (hist2, hist[:4])        # picks up where the first run stopped (not from scratch)
     fresh = echr_amd.CaptionGenerator(cg.opt)
     fresh.load_state_dict(ck['cg_model'])
     for (k, a), (_, b) in zip(cg.state_dict().items(), fresh.state_dict().items()):

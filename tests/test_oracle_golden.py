@@ -33,7 +33,7 @@ def test_tiny_full_tensors(train_mode):
             assert U.relerr(v, g[mode + '|grad|' + k]) < 1e-5, k
 
 
-@pytest.mark.parametrize('case', ['c1', 'c2'])
+@pytest.mark.parametrize('case', ['c1', 'c2', 'c3bench'])
 def test_config_summaries(case):
     opt, params, vid = synth.make_case(case)
     g = U.gold('case_%s.npz' % case)
@@ -96,3 +96,26 @@ def test_oracle_nms_proposals_match_reference_fixture():
         pick, props, conf = O.top_proposals_nms(g['n%d|scores' % i], float(g['n%d|overlap' % i]), int(g['n%d|topN' % i]))
         assert np.array_equal(props, g['n%d|props' % i]) and np.array_equal(conf, g['n%d|conf' % i])
         assert len(pick) <= int(g['n%d|topN' % i])
+
+
+def test_c5_joint_sst_and_caption_path():
+    """BASELINE config 5 as one unit (SST over 256 segments -> tap_feats -> caption path on proposals of 4..256 segments, joint loss,
+    gradients into both models): the oracle against the reference-generated summaries (tools/make_golden.py do_c5)."""
+    from tests.util import oracle_drop
+    opt, params, sst_params, vid = synth.make_c5()
+    g = U.gold('case_c5.npz')
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    SP = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sst_params.items()}
+    c3d, lda = torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda'])
+    labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    tap, props = O.sst_forward(SP, c3d)
+    pred = O.caption_forward(P, tap, c3d, lda, labels, vid['ind'], vid['soi'], 'train', oracle_drop(opt), opt.n_head)
+    tap_loss = O.tap_criterion(props, torch.from_numpy(vid['tap_masks']), torch.from_numpy(vid['tap_labels']), torch.from_numpy(vid['w1']))
+    cg_loss = O.lm_criterion(pred, labels[:, 1:], masks[:, 1:])
+    (opt.lambda1 * tap_loss + opt.lambda2 * cg_loss).backward()
+    assert abs(float(tap_loss) - float(g['train|tap_loss'])) < 1e-4 and abs(float(cg_loss) - float(g['train|cg_loss'])) < 1e-5
+    s = SM.summarize_logp(pred.detach().numpy())
+    assert np.abs(s['slice'] - g['train|logp|slice']).max() < 1e-5
+    for key, v in SM.summarize_grads({k: p.grad.numpy() for k, p in SP.items()}).items():
+        ref = g['train|sstgrad|' + key]
+        assert np.allclose(v, ref, rtol=1e-3, atol=1e-6 * (1 + np.abs(ref).max())), key

@@ -49,25 +49,28 @@ def run(name, layout, M, N, K, reps=20, algo=0):
 
 
 if __name__ == '__main__':
-    cfgs = [('auto', {}), ('t64s1', {'ECHR_GEMM_TILE': '64', 'ECHR_GEMM_SPLIT': '1'}), ('t64s2', {'ECHR_GEMM_TILE': '64', 'ECHR_GEMM_SPLIT': '2'}),
-            ]
+    from echr_amd import _lib
+    lib = _lib.load()
+
+    def knobs(tile='', split=0):          # tuning overrides go through echr_config_set (the environment is only read once, at load)
+        lib.echr_config_set(b'gemm_tile', ord(tile[0]) if tile else 0)
+        lib.echr_config_set(b'gemm_split', int(split))
+
+    cfgs = [('auto', {}), ('t64s1', dict(tile='6', split=1)), ('t64s2', dict(tile='6', split=2))]
     print('%-10s %-3s %5s %5s %5s | ' % ('name', 'lay', 'M', 'N', 'K') + ' '.join('%14s' % c[0] for c in cfgs))
     for sh in SHAPES:
         cells = []
         for cname, env in cfgs:
-            for k in ('ECHR_GEMM_TILE', 'ECHR_GEMM_SPLIT'):
-                os.environ.pop(k, None)
-            os.environ.update(env)
+            knobs(**env)
             us, tf = run(*sh)
             cells.append('%6.0fus %4.0fTF' % (us, tf))
-        for k in ('ECHR_GEMM_TILE', 'ECHR_GEMM_SPLIT'):
-            os.environ.pop(k, None)
+        knobs()
         if sh[1] == 'NT':
             us, tf = run(*sh, algo=1)
             cells.append('bf16x3 %6.0fus %4.0fTF' % (us, tf))
-            os.environ['ECHR_GEMM_TILE'] = 's'
-            for sp in ('1', '2', '4'):
-                os.environ['ECHR_GEMM_SPLIT'] = sp
+            for sp in (1, 2, 4):
+                knobs('s', sp)
                 us, tf = run(*sh, algo=1)
-                cells.append('x3/64 s%s %5.0fus %4.0fTF' % (sp, us, tf))
+                cells.append('x3/64 s%d %5.0fus %4.0fTF' % (sp, us, tf))
+            knobs()
         print('%-10s %-3s %5d %5d %5d | ' % sh + ' '.join('%14s' % c for c in cells), flush=True)

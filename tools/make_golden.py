@@ -189,6 +189,71 @@ def do_case(name):
     print('  wrote case_%s.npz (%d arrays)' % (name, len(out)))
 
 
+def do_c5():
+    """BASELINE config 5 as ONE unit: the reference's SST (eval: no inter-layer dropout, sst_model.py:25-26) over a 256-segment video
+    -> tap_feats -> reference CaptionGenerator on 64 proposals of 4..256 segments -> lambda1 * tap_loss + lambda2 * cg_loss
+    (train.py:322-329) -> backward into BOTH models.  Caption model in eval and in train mode (injected Philox masks)."""
+    opt, params, sst_params, vid = synth.make_c5()
+    m = build_ref(opt, params)
+    tapm = models.setup_tap(copy.copy(opt))
+    tapm.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sst_params.items()})
+    tapm.eval()
+    c3d, lda = torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda'])
+    labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    tl, tm, tw = (torch.from_numpy(vid[k]) for k in ('tap_labels', 'tap_masks', 'w1'))
+    out = {}
+    for mode in ('eval', 'train'):
+        m.zero_grad()
+        tapm.zero_grad()
+        orig = F.dropout
+        if mode == 'train':
+            m.train()
+            F.dropout = MaskFeeder(opt.CG_drop_prob)
+        else:
+            m.eval()
+        t0 = time.time()
+        try:
+            tap_feats, props = tapm(c3d)
+            pred = m(tap_feats, c3d, lda, labels, vid['ind'], vid['soi'].tolist(), mode='train')
+        finally:
+            F.dropout = orig
+        tap_loss = ref_utils.TAPModelCriterion()(props, tm, tl, tw)
+        cg_loss = ref_utils.LanguageModelCriterion()(pred, labels[:, 1:], masks[:, 1:])
+        total = opt.lambda1 * tap_loss + opt.lambda2 * cg_loss
+        total.backward()
+        t_ref = time.time() - t0
+        grads = {k: (p.grad.detach().numpy().copy() if p.grad is not None else None) for k, p in m.named_parameters()}
+        sgrads = {k: p.grad.detach().numpy().copy() for k, p in tapm.named_parameters()}
+        # the oracle on the same joint path
+        P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+        SP = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sst_params.items()}
+        otap, oprops = O.sst_forward(SP, c3d)
+        opred = O.caption_forward(P, otap, c3d, lda, labels, vid['ind'], vid['soi'], 'train', oracle_drop(opt) if mode == 'train' else None, opt.n_head)
+        ototal = opt.lambda1 * O.tap_criterion(oprops, tm, tl, tw) + opt.lambda2 * O.lm_criterion(opred, labels[:, 1:], masks[:, 1:])
+        ototal.backward()
+        # alpha_net.bias: the true gradient is exactly zero (softmax shift invariance); both sides hold rounding noise
+        dev = max(rel(P[k].grad.numpy(), grads[k]) for k in grads if grads[k] is not None and not k.endswith('alpha_net.bias'))
+        sdev = max(rel(SP[k].grad.numpy(), sgrads[k]) for k in sgrads)
+        print('[c5/%s] ref %.2fs tap_loss %.6f cg_loss %.6f | oracle-vs-ref: max|dlogp| %.2e dtotal %.2e max rel grad %.2e (cg) %.2e (sst)'
+              % (mode, t_ref, float(tap_loss), float(cg_loss), float((opred - pred).abs().max()), abs(float(ototal) - float(total)), dev, sdev))
+        assert float((opred - pred).abs().max()) < 2e-5 and dev < 1e-4 and sdev < 1e-4
+        out[mode + '|tap_loss'] = np.float64(float(tap_loss))
+        out[mode + '|cg_loss'] = np.float64(float(cg_loss))
+        out[mode + '|total'] = np.float64(float(total))
+        for k, v in SM.summarize_logp(pred.detach().numpy()).items():
+            out[mode + '|logp|' + k] = v
+        for k, v in SM.summarize_grads(grads).items():
+            out[mode + '|grad|' + k] = v
+        for k, v in SM.summarize_grads(sgrads).items():
+            out[mode + '|sstgrad|' + k] = v
+        if mode == 'eval':
+            tf = tap_feats.detach().numpy()
+            out['tap_feats|slice'] = tf[::8, ::16].copy()
+            out['props|slice'] = props.detach().numpy()[::8, ::16].copy()
+    np.savez_compressed(os.path.join(GOLD, 'case_c5.npz'), **out)
+    print('  wrote case_c5.npz (%d arrays)' % len(out))
+
+
 def do_position():
     RefMA = models.MA_Attention8
     out = {}
@@ -320,14 +385,14 @@ def do_checkpoint():
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cases', nargs='*', default=['tiny', 'c1', 'c2', 'c2full'])
+    ap.add_argument('--cases', nargs='*', default=['tiny', 'c1', 'c2', 'c2full', 'c3bench'])
     ap.add_argument('--skip-aux', action='store_true')
-    ap.add_argument('--only', choices=['position', 'adam', 'proposals', 'checkpoint', 'sst'], help='regenerate one auxiliary fixture only')
+    ap.add_argument('--only', choices=['position', 'adam', 'proposals', 'checkpoint', 'sst', 'c5'], help='regenerate one auxiliary fixture only')
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     if a.only:
-        {'position': do_position, 'adam': do_adam, 'proposals': do_proposals, 'checkpoint': do_checkpoint, 'sst': do_sst}[a.only]()
+        {'position': do_position, 'adam': do_adam, 'proposals': do_proposals, 'checkpoint': do_checkpoint, 'sst': do_sst, 'c5': do_c5}[a.only]()
         sys.exit(0)
     if not a.skip_aux:
         do_position()
@@ -335,5 +400,6 @@ if __name__ == '__main__':
         do_proposals()
         do_checkpoint()
         do_sst()
+        do_c5()
     for c in a.cases:
         do_case(c)
