@@ -99,6 +99,7 @@ SYMBOLS = [
     ('echr_tsrm_attn_fwd', i32, [C.POINTER(TsrmArgs), c_f, c_f, C.POINTER(Dropout), C.c_void_p]),
     ('echr_persist_read_stamps', i32, [C.c_void_p, i32]),
     ('echr_prof_enable', i32, [i32]),
+    ('echr_prof_event_overhead', i32, [C.POINTER(C.c_double), C.POINTER(i64)]),
     ('echr_prof_read', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),
     ('echr_sst_ws_floats', i64, [i32, i32, i32, i32]),
     ('echr_sst_ws_bwd_floats', i64, [i32, i32, i32, i32]),

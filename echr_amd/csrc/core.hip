@@ -667,6 +667,29 @@ extern "C" int echr_prof_read(int kind, double* ms, double* flops, double* bytes
     return 0;
 }
 
+// cost of one ProfScope event pair around NOTHING on an idle stream (the fixed per-launch overhead of event timing)
+extern "C" int echr_prof_event_overhead(double* ms, int64_t* n) {
+    if (!ms || !n) return -22;
+    const int reps = 200;
+    hipEvent_t e0[reps], e1[reps];
+    hipStream_t st = nullptr;
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < reps; ++i) {
+        (void)hipEventCreate(&e0[i]); (void)hipEventCreate(&e1[i]);
+        (void)hipEventRecord(e0[i], st); (void)hipEventRecord(e1[i], st);
+    }
+    (void)hipDeviceSynchronize();
+    double tot = 0;
+    for (int i = 0; i < reps; ++i) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0[i], e1[i]);
+        tot += t;
+        (void)hipEventDestroy(e0[i]); (void)hipEventDestroy(e1[i]);
+    }
+    *ms = tot; *n = reps;
+    return 0;
+}
+
 extern "C" int echr_persist_read_stamps(uint64_t* dst, int32_t max_entries) {
     return persist_read_stamps(reinterpret_cast<unsigned long long*>(dst), max_entries);
 }

@@ -216,6 +216,9 @@ class DecoderFunction(torch.autograd.Function):
         if zeroed:
             grads = ctx.sink.take()
         else:
+            red = getattr(ctx.sink.arena, 'early_reducer', None) if ctx.sink is not None else None
+            if red is not None:
+                red.check_no_backward_while_in_flight()      # accumulating into ranges whose all-reduce already started
             grads = [torch.empty_like(p) for p in ps]
             grads[0].zero_()                                 # embedding table gradient is scatter-added
         g_event = torch.empty_like(event)

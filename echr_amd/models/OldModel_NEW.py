@@ -103,7 +103,12 @@ class OldModel(nn.Module):
     def next_drop_state(self, p_tsrm=0.3):
         """Dropout configuration for the next forward: fresh Philox offset per training-mode call."""
         if self._drop_seed is None:
-            self._drop_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+            seed = int(torch.initial_seed())
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                # data parallel: every rank must draw its OWN masks (replicas see different videos, like m_batch different iterations
+                # of the reference), so the rank is mixed into the seed
+                seed ^= ((torch.distributed.get_rank() + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+            self._drop_seed = seed & 0xFFFFFFFFFFFFFFFF
         c = self.core
         st = EF.DropState(self._drop_seed, self._drop_calls, self.training, p_tsrm, c.dropout0.p, self.dropout.p)
         if self.training:

@@ -7,8 +7,31 @@ is therefore reference-equivalent to m_batch = R on the same R videos: all-reduc
 the reduce, identical fused Adam on every rank.  The collective runs on torch.distributed (backend "nccl" is
 RCCL over xGMI on ROCm; "gloo" for the CPU tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def reduce_sum_(flat, group=None, algo=None, async_op=False):
+    """SUM over ranks of a flat fp32 buffer, in place.
+
+    algo 'allreduce' (default): one dist.all_reduce -- RCCL picks ring / tree / direct itself.
+    algo 'rs_ag' (or ECHR_DP_ALGO=rs_ag): reduce-scatter + all-gather on the same buffer (on a fully connected
+    xGMI node each GPU then exchanges 1/R of the buffer with each of its R-1 peers over R-1 distinct links, instead of pushing the
+    whole buffer around a ring whose every hop is bound by ONE link).  Needs numel % R == 0 (the arena is 64-float aligned, so R = 2,
+    4, 8 always qualify); otherwise it falls back to all_reduce.  Returns a work handle when async_op (rs_ag is synchronous)."""
+    algo = algo or os.environ.get('ECHR_DP_ALGO', 'allreduce')
+    world = dist.get_world_size(group)
+    if algo == 'rs_ag' and world > 1 and flat.numel() % world == 0 and flat.is_contiguous():
+        rank = dist.get_rank(group)
+        n = flat.numel() // world
+        shard = torch.empty(n, device=flat.device, dtype=flat.dtype)
+        dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
+        dist.all_gather_into_tensor(flat, shard, group=group)
+        del rank
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
 def live_grads(module):
@@ -26,15 +49,32 @@ class EarlyReducer(object):
     the current stream).  `allreduce_gradients` later reduces the ranges no early collective covered and waits for the early ones,
     so the result is the same SUM over ranks as the single-collective path."""
 
-    def __init__(self, arena, group=None):
+    def __init__(self, arena, group=None, auto_arm=True):
         self.arena, self.group = arena, group
         self.pending = []              # [(lo, hi, work)], disjoint arena ranges in flight
         self.early_ids = set()         # parameters whose gradients the pending collectives cover
+        # Early collectives are only legal during the LAST backward of an optimiser step: a later backward would add its gradients
+        # into arena ranges that are already being reduced (allreduce(g1) + local g2, and a race with the in-flight collective).
+        # auto_arm=True (one backward per step, the reference's m_batch = 1): every backward is the last one.  With gradient
+        # accumulation pass auto_arm=False and call arm() right before the final backward of the step.
+        self.auto_arm = bool(auto_arm)
+        self.armed = self.auto_arm
         arena.early_grad_hook = self.hook
+        arena.early_reducer = self
+
+    def arm(self):
+        """The next backward is the last one of this optimiser step: its final gradients may start their all-reduce early."""
+        self.armed = True
+
+    def check_no_backward_while_in_flight(self):
+        """Called by the backward Functions when they are about to ACCUMULATE into existing gradients."""
+        if self.pending:
+            raise RuntimeError('a backward pass accumulates into gradients whose all-reduce is already in flight: with gradient '
+                               'accumulation create the reducer with auto_arm=False and call arm() only before the last backward')
 
     def hook(self, params):
         ar = self.arena
-        if not (dist.is_available() and dist.is_initialized()):
+        if not self.armed or not (dist.is_available() and dist.is_initialized()):
             return
         slots = sorted(ar.slot(p) for p in params)
         if any(s is None for s in slots) or slots != list(range(slots[0], slots[-1] + 1)):
@@ -51,10 +91,11 @@ class EarlyReducer(object):
         ar = self.arena
         pend = sorted(self.pending, key=lambda t: t[0])
         self.pending, self.early_ids = [], set()
+        self.armed = self.auto_arm
         n, pos = len(pend), 0
         for lo, hi, _ in pend + [(ar.total, ar.total, None)]:
             if lo > pos:
-                dist.all_reduce(ar.flat_g[pos:lo], op=dist.ReduceOp.SUM, group=self.group)
+                reduce_sum_(ar.flat_g[pos:lo], self.group)
                 n += 1
             pos = max(pos, hi)
         for _, _, work in pend:
@@ -73,18 +114,20 @@ class EarlyReducer(object):
         self.arena.early_grad_hook = None
 
 
-def enable_overlap(module, group=None):
-    """Install the early reducer on a module whose parameters live in a flat arena (CaptionGenerator.build_arena())."""
+def enable_overlap(module, group=None, auto_arm=True):
+    """Install the early reducer on a module whose parameters live in a flat arena (CaptionGenerator.build_arena()).
+    auto_arm=False: gradient accumulation -- call the returned reducer's arm() before the last backward of every optimiser step."""
     arena = getattr(module, '_echr_arena', None)
     if arena is None:
         raise ValueError('enable_overlap needs the flat arena: call module.build_arena() first')
-    red = EarlyReducer(arena, group)
+    red = EarlyReducer(arena, group, auto_arm)
     module._echr_early_reducer = red
     return red
 
 
-def allreduce_gradients(module, group=None, bucket_bytes=64 << 20, force=False):
-    """Sum the gradients over ranks in a few large flat buckets (xGMI is point-to-point: few large messages)."""
+def allreduce_gradients(module, group=None, bucket_bytes=64 << 20, force=False, algo=None):
+    """Sum the gradients over ranks in a few large flat buckets (xGMI is point-to-point: few large messages).
+    algo: None (ECHR_DP_ALGO, default 'allreduce') | 'allreduce' | 'rs_ag' -- see reduce_sum_."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return 0
     arena = getattr(module, '_echr_arena', None)
@@ -94,7 +137,7 @@ def allreduce_gradients(module, group=None, bucket_bytes=64 << 20, force=False):
         red = getattr(module, '_echr_early_reducer', None)
         if red is not None:
             return red.finish()
-        dist.all_reduce(arena.flat_g, op=dist.ReduceOp.SUM, group=group)
+        reduce_sum_(arena.flat_g, group, algo)
         return 1
     params = live_grads(module)
     red = getattr(module, '_echr_early_reducer', None)

@@ -311,12 +311,15 @@ int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int
 /* ------------------------------------------------------------------------------------------------
  * Optional per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
  * class) for bench.py's roofline leg.  kind: 0 fp32 MFMA GEMM, 1 attention fwd, 2 attention bwd,
- * 3 attention post-pass, 4 recurrent grouped GEMM, 5 other, 6 bf16x3-split GEMM, 7 h2 (fp16-pair) GEMM, 8 h2 operand packing.  echr_prof_read synchronises the recorded events and
+ * 3 attention post-pass, 4 recurrent grouped GEMM, 5 other, 6 bf16x3-split GEMM, 7 h2 (fp16-pair) GEMM, 8 h2 operand packing,
+ * 9 persistent recurrence kernels (csrc/persist.hip).  echr_prof_read synchronises the recorded events and
  * returns the totals since echr_prof_enable(1): elapsed ms, algorithmic flops / bytes, launches.
  * Not thread-safe; never enabled on the product path.
  * ---------------------------------------------------------------------------------------------- */
 int echr_prof_enable(int on);
 int echr_prof_read(int kind, double* ms, double* flops, double* bytes, int64_t* launches);
+/* total ms of `n` back-to-back event pairs around nothing: the fixed per-launch cost of event timing, which bench.py subtracts */
+int echr_prof_event_overhead(double* ms, int64_t* n);
 
 /* Runtime switches (defaults from the environment variables ECHR_GEMM_H2=1, ECHR_GEMM_BF16X3=1, ECHR_OVERLAP=0, ECHR_ATT_SLOTS=2):
  *   "gemm_h2"     0/1  run the decoder's large projections on h2-packed operands (two block-scaled fp16 planes, fp32-grade) or not

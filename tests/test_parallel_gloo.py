@@ -104,6 +104,80 @@ def test_early_reducer_equals_single_allreduce():
     assert np.array_equal(f0, f1) and not (f0 == 246.0).any() and not (f0 == 123.0).any()
 
 
+def _worker_algos(rank, world, port, q):
+    """reduce-scatter + all-gather == all-reduce on the arena buffer; accumulation (two backwards per step) with the early reducer
+    armed only before the last backward == the plain SUM, identical on every rank; a mis-armed reducer refuses."""
+    from echr_amd.arena import ParamArena
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 3))
+    arena = ParamArena(net)
+    live = list(net[0].parameters()) + list(net[1].parameters())
+    rs = np.random.RandomState(30 + rank)
+
+    def backward_into_arena(first):
+        x = torch.from_numpy(rs.standard_normal((4, 7)).astype(np.float32))
+        gs = torch.autograd.grad(net[1](net[0](x)).pow(2).sum(), live)
+        for p, g in zip(live, gs):
+            if first:
+                v = arena.grad_view(arena.slot(p))
+                v.copy_(g)
+                p.grad = v
+            else:
+                p.grad += g                       # what autograd does on the second backward: in place, into the arena view
+        return [g.clone() for g in gs]
+
+    # (1) rs_ag vs allreduce
+    g1 = backward_into_arena(True)
+    ref = arena.flat_g.clone()
+    dist.all_reduce(ref)
+    n = parallel.allreduce_gradients(net, algo='rs_ag')
+    same_algo = bool(torch.equal(ref, arena.flat_g)) and n == 1
+    # (2) accumulation with the early reducer: armed before the last backward only
+    for p in live:
+        p.grad = None
+    arena.flat_g.zero_()
+    red = parallel.enable_overlap(net, auto_arm=False)
+    ga = backward_into_arena(True)
+    red.hook([net[1].weight, net[1].bias])          # not armed: must do nothing
+    none_in_flight = len(red.pending) == 0
+    gb = backward_into_arena(False)
+    red.arm()
+    red.hook([net[1].weight, net[1].bias])          # final gradients of the last backward: early range
+    in_flight = len(red.pending) == 1
+    refused = False
+    try:
+        red.check_no_backward_while_in_flight()
+    except RuntimeError:
+        refused = True
+    parallel.allreduce_gradients(net)
+    local = [a + b for a, b in zip(ga, gb)]
+    q.put((rank, same_algo, none_in_flight, in_flight, refused, not red.armed, [t.numpy() for t in local],
+           [p.grad.numpy().copy() for p in live]))
+    dist.destroy_process_group()
+
+
+def test_rs_ag_and_accumulation_with_early_reducer():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_algos, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] and r[2] and r[3] and r[4] and r[5], r[:6]
+    (_, *_, l0, s0), (_, *_, l1, s1) = res
+    for a, b, x, y in zip(l0, l1, s0, s1):
+        assert np.allclose(a + b, x, atol=1e-6) and np.array_equal(x, y)          # plain SUM of both ranks' accumulated gradients
+
+
 def test_shard_videos_partition():
     got = sorted(sum((parallel.shard_videos(11, r, 4) for r in range(4)), []))
     assert got == list(range(11))

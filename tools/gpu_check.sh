@@ -10,4 +10,4 @@ if [ "$2" != "notest" ]; then
 fi
 timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu > $out/bench.json 2> $out/bench.err; echo "bench_exit=$?"; cat $out/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu --no-roofline > $out/prof.log 2>&1; echo "prof_exit=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu --no-roofline --no-native > $out/prof.log 2>&1; echo "prof_exit=$?"
