@@ -352,7 +352,11 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
             const float* cr = P.c3d + (row0 + a) * D;
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                Pr[i][h] = *reinterpret_cast<const float4*>(pr + 4 * h);
+                // tanh(p + q) = 1 - 2 / (e^{2p} e^{2q} + 1): e^{2p} is constant over the S timesteps and kept INSTEAD of p (arguments
+                // clamped to +-43 so that neither factor is 0 or inf: the product then saturates to 0 / inf -> tanh = -1 / +1, never NaN)
+                const float4 pv = *reinterpret_cast<const float4*>(pr + 4 * h);
+                Pr[i][h] = make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
+                                       __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
                 const int d = 32 * lr + 4 * h;
                 float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
                 if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -422,6 +426,16 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
 #pragma unroll
                 for (int h = 0; h < 8; ++h) q[h] = ld16_sc1(rq, (u32)((((2 * lr + (h >> 2)) * PROWS + an) * 16 + 4 * (h & 3)) * 4));
                 if (P.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (srole >= 0) STAMP(srole, 12); }
+                // score = sum_j alpha_j tanh(p_j + q_j) = sum_j alpha_j - 2 sum_j alpha_j / (e^{2 p_j} e^{2 q_j} + 1): one exp per q column
+                // and step (shared by the row's 3 slots), one fma + rcp + fma per (slot, feature)
+                float asum = 0.f;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    q[h] = make_float4(__expf(2.f * fminf(fmaxf(q[h].x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].y, -43.f), 43.f)),
+                                       __expf(2.f * fminf(fmaxf(q[h].z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].w, -43.f), 43.f)));
+                    const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
+                    asum += (a4.x + a4.y) + (a4.z + a4.w);
+                }
                 float e[PSG];
                 float mloc = -INFINITY;
 #pragma unroll
@@ -430,10 +444,10 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
 #pragma unroll
                     for (int h = 0; h < 8; ++h) {
                         const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
-                        v += a4.x * fast_tanh(Pr[i][h].x + q[h].x) + a4.y * fast_tanh(Pr[i][h].y + q[h].y) +
-                             a4.z * fast_tanh(Pr[i][h].z + q[h].z) + a4.w * fast_tanh(Pr[i][h].w + q[h].w);
+                        v += a4.x * __builtin_amdgcn_rcpf(fmaf(Pr[i][h].x, q[h].x, 1.f)) + a4.y * __builtin_amdgcn_rcpf(fmaf(Pr[i][h].y, q[h].y, 1.f)) +
+                             a4.z * __builtin_amdgcn_rcpf(fmaf(Pr[i][h].z, q[h].z, 1.f)) + a4.w * __builtin_amdgcn_rcpf(fmaf(Pr[i][h].w, q[h].w, 1.f));
                     }
-                    v = row16_sum(v);
+                    v = row16_sum(fmaf(-2.f, v, asum));
                     const int sl = grow_ + 16 * i;
                     const bool valid = sl < PSL && PSL * ap + sl < alen;
                     e[i] = valid ? v : -INFINITY;
