@@ -55,7 +55,7 @@ class DecGrads(C.Structure):
                 ('g_w_ih', c_f * 3), ('g_w_hh', c_f * 3), ('g_b_ih', c_f * 3), ('g_b_hh', c_f * 3),
                 ('g_w_c2a', c_f), ('g_b_c2a', c_f), ('g_w_h2a', c_f), ('g_b_h2a', c_f), ('g_w_alpha', c_f), ('g_b_alpha', c_f),
                 ('g_event', c_f), ('g_video', c_f), ('g_logp', c_f),
-                ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f), ('zeroed', i32), ('phase', i32)]
+                ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f), ('zeroed', i32), ('phase', i32), ('async_tail', i32)]
 
 
 class SstArgs(C.Structure):
@@ -95,6 +95,7 @@ SYMBOLS = [
     ('echr_sampler_ws_floats', i64, [C.POINTER(DecArgs)]),
     ('echr_decoder_sample', i32, [C.POINTER(SampleArgs), C.c_void_p]),
     ('echr_config_set', i32, [C.c_char_p, i32]),
+    ('echr_stream_join', i32, [C.c_void_p]),
     ('echr_decoder_step', i32, [C.POINTER(DecArgs), c_f, c_f, c_f, c_f, C.POINTER(Dropout), C.c_void_p]),
     ('echr_tsrm_attn_fwd', i32, [C.POINTER(TsrmArgs), c_f, c_f, C.POINTER(Dropout), C.c_void_p]),
     ('echr_persist_read_stamps', i32, [C.c_void_p, i32]),

@@ -636,6 +636,7 @@ extern "C" int echr_nll_loss_fwd(const float* logp, const int32_t* target, const
 extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
                                double beta2, double eps, float clip, void* stream) {
     ECHR_REQUIRE(p && g && m && v && n > 0 && step >= 1, "clamp_adam: bad arguments");
+    if (int rc = join_tail((hipStream_t)stream)) return rc;
     ECHR_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                  "clamp_adam: buffers must be 16-byte aligned");
     const double bc1 = 1.0 - pow(beta1, (double)step);
@@ -649,6 +650,7 @@ extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int
 
 extern "C" int echr_clamp(float* g, int64_t n, float clip, void* stream) {
     ECHR_REQUIRE(g && n > 0, "clamp: bad arguments");
+    if (int rc = join_tail((hipStream_t)stream)) return rc;
     int grid = (int)min(((long)n + 255) / 256, 4096L);
     hipLaunchKernelGGL(clamp_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, (long)n, clip);
     return check_launch("clamp");

@@ -62,6 +62,31 @@ static Side& side() {
     }
     return sd;
 }
+// Tail stream: part B of the decoder backward (attention-parameter and token-embedding gradients: ~10 launches that nothing else in the
+// backward pass depends on) can run on a second stream while autograd continues with the event encoder's / proposal encoder's
+// backward on the caller's stream.  The caller joins with echr_stream_join (the Python side does it in an end-of-backward callback);
+// every later library entry that takes a stream joins first as a safety net.
+struct Tail { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr; bool ok = false, init = false, pending = false; };
+static Tail& tail() {
+    static Tail t;
+    if (!t.init) {
+        t.init = true;
+        bool good = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
+        t.ok = good;
+    }
+    return t;
+}
+int join_tail(hipStream_t st) {
+    Tail& t = tail();
+    if (t.ok && t.pending) {
+        t.pending = false;
+        if (hipStreamWaitEvent(st, t.done, 0) != hipSuccess) { set_error("stream join failed"); return -5; }
+    }
+    return 0;
+}
+
 static bool overlap_enabled() {
     // measured neutral on the c3 workload (the recurrent GEMM's two 67 KB-LDS workgroups per CU leave no room for a
     // co-resident throughput GEMM, so the overlap only trades places): opt-in (ECHR_OVERLAP=1 / echr_config_set)
@@ -882,8 +907,11 @@ using namespace echr;
 extern "C" int64_t echr_decoder_ws_floats(const echr_dec_args* a) { return a ? carve_ws(a, nullptr).total : -1; }
 extern "C" int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a) { return a ? carve_ws_bwd(a, nullptr).total : -1; }
 
+extern "C" int echr_stream_join(void* stream) { return join_tail((hipStream_t)stream); }
+
 extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream) {
     RC(persist_check_async());
+    RC(join_tail((hipStream_t)stream));
     RC(check_dims(a, "decoder_fwd"));
     ECHR_REQUIRE(a->S > 0 && a->ws && a->logp && a->tokens, "decoder_fwd: missing buffers");
     hipStream_t st = (hipStream_t)stream;
@@ -944,6 +972,7 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
 
 extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream) {
     RC(persist_check_async());
+    RC(join_tail((hipStream_t)stream));
     RC(check_dims(a, "decoder_bwd"));
     ECHR_REQUIRE(g && a->ws && g->ws_bwd && a->logp, "decoder_bwd: missing buffers");
     ECHR_REQUIRE(g->g_logp || (g->nll_target && g->nll_mask && g->g_loss), "decoder_bwd: need g_logp or the fused NLL inputs");
@@ -1164,6 +1193,13 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     }
     }
     if (!do_pb) return 0;
+    // phase 0 + async_tail: nothing downstream in the backward pass needs part B's outputs -> second stream, joined by the caller
+    const bool async_tail = g->phase == 0 && g->async_tail != 0 && tail().ok && !ov;
+    hipStream_t sm = st;              // the caller's stream
+    if (async_tail) {
+        st = tail().s;
+        RC(hop(sm, tail().fork, st));
+    }
     // 5. part B: attention parameters (d P_all / d alpha over all timesteps, then ctx2att) and the token embedding
     if (!z) {
         RC(fill_zero(g->g_w_alpha, Ha, st));
@@ -1203,6 +1239,10 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         RC(gemm_grouped(gx, 3, st));
     }
     RC(embed_scatter_add(b.DXT, a->tokens, g->g_embed, SN, E, V1, st));
+    if (async_tail) {
+        if (hipEventRecord(tail().done, st) != hipSuccess) { set_error("decoder_bwd: event record failed"); return -5; }
+        tail().pending = true;
+    }
     return 0;
 }
 

@@ -33,6 +33,7 @@ long persist_fwd_ws_floats(int S);
 bool persist_fwd_eligible(const echr_dec_args* a);
 int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
 int persist_check_async();
+int join_tail(hipStream_t st);          // make st wait for an asynchronous decoder-backward tail (decoder.hip); no-op when none is pending
 int persist_read_stamps(unsigned long long* dst, int max_entries);
 int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st);
 // h2-packed operands (csrc/gemm.hip: two block-scaled fp16 planes): bytes of the packed image of a [rows x cols] operand (cols =

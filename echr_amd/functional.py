@@ -48,6 +48,9 @@ def rows_disjoint(soi_select_list):
     return bool(np.all(o[1:, 0] >= o[:-1, 1]))
 
 
+ASYNC_TAIL = [True]        # decoder backward: run the last stage on a second stream (arena path); tests may switch it off
+
+
 def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
@@ -228,7 +231,7 @@ class DecoderFunction(torch.autograd.Function):
         gp = [L.ptr(x) for x in grads]
         g = L.DecGrads(gp[0], gp[1], gp[2], (L.c_f * 3)(*gp[3:6]), (L.c_f * 3)(*gp[6:9]), (L.c_f * 3)(*gp[9:12]),
                        (L.c_f * 3)(*gp[12:15]), gp[15], gp[16], gp[17], gp[18], gp[19], gp[20],
-                       L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp), None, None, None, L.ptr(wsb), zeroed, 0)
+                       L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp), None, None, None, L.ptr(wsb), zeroed, 0, 0)
         d = drop.c()
         hook = getattr(ctx.sink.arena, 'early_grad_hook', None) if zeroed else None
         if hook is not None:
@@ -242,7 +245,20 @@ class DecoderFunction(torch.autograd.Function):
                 if ready is not None:
                     hook(ready)
         else:
+            # arena path: the returned parameter gradients are views that autograd adopts without touching them, so the last stage of
+            # the backward (attention-parameter / embedding gradients) may still be running on the library's second stream while
+            # autograd goes on with the event encoder's backward; an end-of-backward callback joins the streams and only then lets go
+            # of the workspaces that stage reads
+            g.async_tail = 1 if (zeroed and ASYNC_TAIL[0]) else 0
             L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
+            if g.async_tail:
+                keep = [ws, wsb, logp, c3d, tokens, ev_start, ev_len, g_logp]
+                sp = L.stream_ptr()
+
+                def _join(keep=keep, sp=sp):
+                    L.check(lib.echr_stream_join(sp), 'stream_join')
+                    del keep[:]
+                torch.autograd.Variable._execution_engine.queue_callback(_join)
         return (g_video, g_event, None, None, None, None, None, None, None, None) + tuple(grads)
 
 

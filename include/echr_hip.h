@@ -206,7 +206,16 @@ typedef struct {
                                                         g_b_ih, g_b_hh, plus g_w_h2a, g_b_h2a, g_event, g_video): 39 % of the bytes,
                                                     4 = the rest (attention parameters, token embedding);
                                                     2 = 3 followed by 4.   1, 3, 4 in this order equal 0. */
+    int32_t async_tail;                        /* phase 0 only: 1 = the last stage (attention-parameter and token-embedding gradients; nothing else
+                                                  in a backward pass depends on them) runs on a library-owned second stream and the call returns
+                                                  without joining it, so that the caller's next backward kernels (event encoder, proposal encoder)
+                                                  overlap it.  The caller MUST call echr_stream_join(stream) before anything reads g_w_c2a,
+                                                  g_b_c2a, g_w_alpha, g_b_alpha, g_embed or frees ws / ws_bwd (every library entry that takes a
+                                                  stream joins first as a safety net). */
 } echr_dec_grads;
+
+/* make `stream` wait for an asynchronous decoder-backward tail (echr_dec_grads.async_tail); no-op when none is pending */
+int echr_stream_join(void* stream);
 
 int64_t echr_decoder_ws_floats(const echr_dec_args* a);
 int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a);
