@@ -555,8 +555,8 @@ typedef const __attribute__((address_space(1))) void* glb_vptr;
 // vmcnt(0) retires the stage that is read next).  A CU pulls at most ~28 B/clk from its L2 (14 from the Infinity Cache), about what
 // a 128x128 stage needs at full MFMA rate, so the workgroup -> tile map gives every XCD a compact rectangle of tiles (xm x xn XCD
 // grid): co-running tiles then share their A and B panels through that XCD's L2.
-template <int BM, int WN>
-__global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, BM == 128 ? 2 : 1) void gemm_h2_kernel(GemmParams pin) {
+template <int BM, int WN, int NS>
+__global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, (NS == 2 && BM == 128) ? 2 : 1) void gemm_h2_kernel(GemmParams pin) {
     constexpr int WAVES_N = 128 / WN, TN = WN / 32, NT = (BM / 64) * WAVES_N * 64, ACH = BM / 128;
     constexpr int PLANES = (ACH + 1) * H2_CHUNK;          // plane bytes per stage
     constexpr int STAGE = PLANES + (ACH + 1) * H2_SCALES;
@@ -564,7 +564,8 @@ __global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, BM == 128 ? 2 : 1) voi
     constexpr int PPC = H2_CHUNK / (NT * 16);             // pieces per chunk: 4 / 2
     int z = blockIdx.z;
     const GemmParams p = select_group(pin, z);
-    __shared__ __attribute__((aligned(1024))) unsigned char sm[2 * STAGE];
+    // NS LDS stages (dynamic LDS: NS * STAGE bytes): the loads of k blocks t+1 .. t+NS-1 are in flight while block t computes.
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * WN;
     const int l31 = lane & 31, h = lane >> 5, sw = (l31 >> 2) & 3;
@@ -616,14 +617,22 @@ __global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, BM == 128 ? 2 : 1) voi
     const int scA = PLANES + (wm >> 7) * H2_SCALES + ((wm & 127) + 4 * h) * 4;     // + (i*32 + 8*g) * 4: rows (r&3) + 8g + 4h of block i
     const int scB = PLANES + ACH * H2_SCALES + (wn + l31) * 4;                    // + j*32*4
 
-    if (kt0 < kt1) stage(0);
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (kt0 + s0 < kt1) stage(s0);
+    int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        // every load this wave issued has landed (vmcnt(0)); after the barrier stage `cur` is visible everywhere and stage `cur^1`,
-        // read during the previous k block, is free again
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave's loads of stage `cur` have landed once at most the NS-2 younger stages' loads are outstanding (loads retire in
+        // issue order; a wave issues PIECES (+1 for the waves that fetch scales) load instructions per stage); after the barrier stage
+        // `cur` is visible everywhere and the stage read during the previous k block is free again
+        if (NS > 2 && kt + NS - 2 < kt1) {
+            if (wave <= ACH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (PIECES + 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PIECES) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < kt1) stage(cur ^ 1);
+        if (kt + NS - 1 < kt1) stage(cur == 0 ? NS - 1 : cur - 1);
         const unsigned char* sb = sm + cur * STAGE;
         f32x16 tmp[2][TN];
 #pragma unroll
@@ -686,6 +695,7 @@ __global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, BM == 128 ? 2 : 1) voi
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) acc[i][j][4 * g + r4] = fmaf(tmp[i][j][4 * g + r4], cav[r4] * cb[j], acc[i][j][4 * g + r4]);
             }
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
     epilogue<2, TN>(p, acc, p.C, 0, ks, mb * BM, nb * 128, wm, wn, lane);
 }
@@ -876,9 +886,28 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
         p.xcd_n = 8 / best; p.xr_m = (p.tiles_m + best - 1) / best; p.xr_n = (p.tiles_n + p.xcd_n - 1) / p.xcd_n;
         grid.x = 8 * p.xr_m * p.xr_n;
         static const int wn_sel = getenv("ECHR_H2_WN") ? atoi(getenv("ECHR_H2_WN")) : 32;
-        if (BMs == 256) hipLaunchKernelGGL((gemm_h2_kernel<256, 64>), grid, dim3(512), 0, st, p);
-        else if (wn_sel == 64) hipLaunchKernelGGL((gemm_h2_kernel<128, 64>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_h2_kernel<128, 32>), grid, dim3(512), 0, st, p);
+        // measured (tools/h2_bench.py): 2 stages x 2 workgroups per CU beats 3-4 stages x 1 workgroup per CU on every c3 shape (270 vs 245
+        // TF/s at 4096^3): the second resident workgroup hides more latency than a deeper ring does; the deeper rings stay selectable
+        static const int ns_sel = getenv("ECHR_H2_STAGES") ? atoi(getenv("ECHR_H2_STAGES")) : 2;
+        constexpr int ST128 = 2 * H2_CHUNK + 2 * H2_SCALES, ST256 = 3 * H2_CHUNK + 3 * H2_SCALES;
+        static bool attr_done = false;
+        if (!attr_done) {          // LDS beyond 64 KB needs the opt-in attribute, once per kernel
+            attr_done = true;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<128, 32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ST128);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<128, 32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST128);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<128, 64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * ST128);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<128, 32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST128);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<128, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST128);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<256, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST256);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel<256, 64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST256);
+        }
+        if (BMs == 256 && ns_sel >= 3) hipLaunchKernelGGL((gemm_h2_kernel<256, 64, 3>), grid, dim3(512), 3 * ST256, st, p);
+        else if (BMs == 256) hipLaunchKernelGGL((gemm_h2_kernel<256, 64, 2>), grid, dim3(512), 2 * ST256, st, p);
+        else if (wn_sel == 64 && ns_sel >= 4) hipLaunchKernelGGL((gemm_h2_kernel<128, 64, 4>), grid, dim3(256), 4 * ST128, st, p);
+        else if (wn_sel == 64) hipLaunchKernelGGL((gemm_h2_kernel<128, 64, 2>), grid, dim3(256), 2 * ST128, st, p);
+        else if (ns_sel >= 4) hipLaunchKernelGGL((gemm_h2_kernel<128, 32, 4>), grid, dim3(512), 4 * ST128, st, p);
+        else if (ns_sel == 3) hipLaunchKernelGGL((gemm_h2_kernel<128, 32, 3>), grid, dim3(512), 3 * ST128, st, p);
+        else hipLaunchKernelGGL((gemm_h2_kernel<128, 32, 2>), grid, dim3(512), 2 * ST128, st, p);
     }
     else if (use_split && BNs == 128) hipLaunchKernelGGL(gemm_split_kernel<128>, grid, dim3(512), 0, st, p);
     else if (use_split) hipLaunchKernelGGL(gemm_split_kernel<64>, grid, dim3(256), 0, st, p);
