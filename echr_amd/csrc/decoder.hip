@@ -722,6 +722,7 @@ struct DecWsBwd {
     float *PK_DLGT, *PK_OUTDT, *PK_DLG, *PK_WLT, *PK_DGT[3], *PK_DG[3], *PK_HT[3], *PK_XTT, *PK_ATTT, *PK_DQT, *PK_WIHT[3], *PK_DPT, *PK_C3DT;
     long snp;
     float *DHACC[3], *DASL;                  // atomic accumulation targets: d h(t-1) per stream [N,H]; DASL: d ATT [S,N,D]
+    float *XWSB;                             // exchange buffers + counters of the persistent reverse recurrence (csrc/persist.hip)
     long ldg, total, zero_floats;
 };
 static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
@@ -761,6 +762,7 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     }
     w.PK_XTT = take(h2_floats(a->E, SN)); w.PK_ATTT = take(h2_floats(a->D, SN)); w.PK_DQT = take(h2_floats(a->Ha, SN));
     w.PK_DPT = take(h2_floats(a->Ha, a->Tv)); w.PK_C3DT = take(h2_floats(a->D, a->Tv));
+    w.XWSB = take(persist_bwd_ws_floats((int)S));
     w.total = off;
     return w;
 }
@@ -1141,6 +1143,12 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     };
     const bool two = !ov && config().chains2 == 1 && side().ok && S >= 2;
     if (!do_rec) {
+    } else if (!ov && !two && persist_bwd_eligible(a)) {
+        // the whole reverse recurrence in two concurrent persistent launches (csrc/persist.hip)
+        PersistBwdBufs pb;
+        for (int k = 0; k < 3; ++k) { pb.GATES[k] = w.GATES[k]; pb.CS[k] = w.CS[k]; pb.DG[k] = b.DG[k]; }
+        pb.QS = w.QS; pb.WT = w.WT; pb.ATT = w.ATT; pb.PALL = w.PALL; pb.DOUT = b.DOUT; pb.DQ = b.DQ; pb.DSC = b.DSC; pb.xws = b.XWSB;
+        RC(persist_bwd(a, pb, dh, dout, st));
     } else if (two) {          // streams 0/2 are independent of the attention chain: their reverse recurrence runs on the side stream
         RC(hop(st, side().fork, side().s));
         for (int t = S - 1; t >= 0; --t) RC(bwd_step(t, 2, side().s));

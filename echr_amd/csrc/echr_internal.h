@@ -17,7 +17,7 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; };
 Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);
@@ -32,6 +32,10 @@ struct PersistFwdBufs { float* GATES[3]; float* CS[3]; float *HS, *OUTD, *QS, *W
 long persist_fwd_ws_floats(int S);
 bool persist_fwd_eligible(const echr_dec_args* a);
 int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
+struct PersistBwdBufs { const float* GATES[3]; const float* CS[3]; const float *QS, *WT, *ATT, *PALL, *DOUT; float* DG[3]; float *DQ, *DSC, *xws; };
+long persist_bwd_ws_floats(int S);
+bool persist_bwd_eligible(const echr_dec_args* a);
+int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
 int persist_check_async();
 int join_tail(hipStream_t st);          // make st wait for an asynchronous decoder-backward tail (decoder.hip); no-op when none is pending
 int persist_read_stamps(unsigned long long* dst, int max_entries);

@@ -116,7 +116,8 @@ __device__ __forceinline__ void publish(u32* line) {
 }
 
 // every thread; false = the launch is being aborted (timeout somewhere): the caller returns
-__device__ __forceinline__ bool wait_total(const PersistK& P, u32* line, u32 target, int* flag, u32 code) {
+template <typename PK>
+__device__ __forceinline__ bool wait_total(const PK& P, u32* line, u32 target, int* flag, u32 code) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         u32 spins = 0;
@@ -605,6 +606,402 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
     }
 }
 
+
+// ==========================================================================================================================
+// PERSISTENT REVERSE RECURRENCE (backward): all S timesteps of the three streams' BPTT in two concurrent launches.
+// Reference semantics: autograd of models/OldModel_NEW.py:801-823 (ThreeStream_Core.forward) and :376-401 (Attention.forward); the
+// launch-per-phase form is decoder.hip's bwd_step (four dependent launches per timestep).  Per reverse timestep the attention chain
+// makes three hand-offs:
+//   gate-gradient workgroups ("GD", 32 x 16 hidden units): d h1(t) = d OUTD part + [d G1(t+1) . W_hh1] (slabs) + d q(t+1) . W_h2a
+//       (MFMA on the ingested d q) -> LSTM-cell gradient -> d G1(t)                                  --- hand-off 1 (32 -> 128) --->
+//   product workgroups ("P", 32 column tiles x 4 k-slices of 512 gate columns): d ATT(t) partial = d G1(t)[:, slice] . W_att[slice, tile]
+//       --- hand-off 2 (128 -> 192) --->, then (off the critical path) the d h1 slab of the same slice for step t-1
+//   attention workgroups (all 192, operands register-resident as in the forward kernel): d score, d q(t) partial (fp32 atomics per event)
+//       --- hand-off 3 (192 -> 32) ---> back to the gate-gradient workgroups.
+// The plain LSTM streams 0 / 2 run in their own 64-workgroup launch (one hand-off per step: a workgroup owns 16 units, ingests all of
+// d G_k(t+1) and multiplies by its 16 columns of W_hh_k).  Hand-off protocol, abort handling and MFMA fragment scheme: as forward.
+// ==========================================================================================================================
+enum { CB_DG = 0, CB_DA = 1, CB_HH = 2, CB_DQ = 3, CB_G0 = 4, CB_G2 = 5, CB_KINDS = 6 };
+constexpr int NGD = 32, NP = 128;
+constexpr int XSTEP4 = 4 * PROWS * PH;          // floats per timestep of a [4][512-wide] exchange buffer
+
+struct PersistLayoutB { long cnt, xdq, zero_end, xdg, xda, xdh, xg0, xg2, total; };
+static PersistLayoutB persist_layout_b(int S) {
+    PersistLayoutB L;
+    long off = 0;
+    auto take = [&](long n) { long o = off; off += (n + 63) / 64 * 64; return o; };
+    L.cnt = take((long)CB_KINDS * (S + 1) * CNT_LINE);
+    L.xdq = take((long)S * PROWS * PH);
+    L.xda = take((long)S * PROWS * PH);          // d ATT and the d h1 product: the four k-slice partials are added atomically
+    L.xdh = take((long)S * PROWS * PH);
+    L.zero_end = off;
+    L.xdg = take((long)S * XSTEP4);
+    L.xg0 = take((long)S * XSTEP4);
+    L.xg2 = take((long)S * XSTEP4);
+    L.total = off;
+    return L;
+}
+long persist_bwd_ws_floats(int S) { return persist_layout_b(S).total; }
+
+struct PersistB {
+    int N, A, D, S, ld_att;
+    const float* w_hh[3]; const float* w_h2a; const float* w_att; const float* w_alpha;
+    const float* PALL; const float* c3d; const int* ev_start; const int* ev_len;
+    const float* GATES[3]; const float* CS[3]; const float* QS; const float* WT; const float* ATT;
+    const float* DOUT;
+    float* DG[3]; float* DQ; float* DSC;
+    float *XDG, *XDA, *XDH, *XDQ, *XG0, *XG2;
+    u32* cnt; u32* abort_word; u32* host_flag;
+    DropCfg dh, dout;
+};
+
+// B image of one 16-column tile whose source is k-strided: element (k, cc) = W[k * ld_k + cc] for k < K, cc < ncols; zero elsewhere
+__device__ __forceinline__ void fill_bimg_t(float4* img, const float* W, long ld_k, int K, int ncols, int tid) {
+    for (int idx = tid; idx < 4 * 8 * 64; idx += 256) {
+        const int lane = idx & 63, c = (idx >> 6) & 7, w = idx >> 9;
+        const int cc = lane & 15, kq = lane >> 4;
+        const int k = 128 * w + 16 * c + 4 * kq;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (k + j < K && cc < ncols) ? W[(long)(k + j) * ld_k + cc] : 0.f;
+        img[idx] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+struct CellGrad { float4 dg[4]; float4 dc; };
+// LSTM-cell backward for 4 consecutive units of one event (lstm_pointwise_bwd_kernel of decoder.hip): dhv = upstream d h (before the
+// recurrent dropout mask), dcin = carried d c
+__device__ __forceinline__ float cg1(float dhv, float gi, float gf, float gg, float go, float cn, float cp, float dcin, float& dgi, float& dgf,
+                                     float& dgg, float& dgo) {
+    const float tc = tanhf(cn);
+    const float dcv = dhv * go * (1.f - tc * tc) + dcin;
+    dgi = dcv * gg * gi * (1.f - gi);
+    dgf = dcv * cp * gf * (1.f - gf);
+    dgg = dcv * gi * (1.f - gg * gg);
+    dgo = dhv * tc * go * (1.f - go);
+    return dcv * gf;
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// shared by the LSTM kernel and the GD role: upstream d h of (event gn, units u0..u0+3 of stream k) from d OUTD, then gate gradients
+struct GradIn { float4 dout, g[4], cn, cp; };
+__device__ __forceinline__ GradIn load_grad_in(const PersistB& P, int k, int t, int gn, int u0) {
+    GradIn r;
+    const int n = min(gn, P.N - 1);
+    r.dout = *reinterpret_cast<const float4*>(P.DOUT + ((long)t * P.N + n) * 3 * PH + k * PH + u0);
+    const float* gp = P.GATES[k] + ((long)t * P.N + n) * 4 * PH + u0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) r.g[g] = *reinterpret_cast<const float4*>(gp + g * PH);
+    r.cn = *reinterpret_cast<const float4*>(P.CS[k] + ((long)(t + 1) * P.N + n) * PH + u0);
+    r.cp = *reinterpret_cast<const float4*>(P.CS[k] + ((long)t * P.N + n) * PH + u0);
+    return r;
+}
+__device__ __forceinline__ CellGrad cell_grad4(const PersistB& P, const GradIn& in, float4 dh_rec, float4 dc, int k, int t, int gn, int u0) {
+    CellGrad o;
+    float dhv[4] = {in.dout.x, in.dout.y, in.dout.z, in.dout.w};
+    const float rec[4] = {dh_rec.x, dh_rec.y, dh_rec.z, dh_rec.w};
+    const float dcin[4] = {dc.x, dc.y, dc.z, dc.w};
+    const float gi[4] = {in.g[0].x, in.g[0].y, in.g[0].z, in.g[0].w}, gf[4] = {in.g[1].x, in.g[1].y, in.g[1].z, in.g[1].w};
+    const float gg[4] = {in.g[2].x, in.g[2].y, in.g[2].z, in.g[2].w}, go[4] = {in.g[3].x, in.g[3].y, in.g[3].z, in.g[3].w};
+    const float cn[4] = {in.cn.x, in.cn.y, in.cn.z, in.cn.w}, cp[4] = {in.cp.x, in.cp.y, in.cp.z, in.cp.w};
+    float dg[4][4], dcn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned o3 = (unsigned)(gn * 3 * PH + k * PH + u0 + i), oh = (unsigned)(gn * PH + u0 + i);
+        float v = dhv[i] * drop_mult(P.dout, o3, (unsigned)t, 4u) + rec[i];
+        v *= drop_mult(P.dh, oh, (unsigned)t, (unsigned)(1 + k));
+        dcn[i] = cg1(v, gi[i], gf[i], gg[i], go[i], cn[i], cp[i], dcin[i], dg[0][i], dg[1][i], dg[2][i], dg[3][i]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) o.dg[g] = make_float4(dg[g][0], dg[g][1], dg[g][2], dg[g][3]);
+    o.dc = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
+    return o;
+}
+
+// ---- backward kernel 1: the two plain LSTM streams ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float4* wimg = reinterpret_cast<float4*>(lds);
+    float* red = reinterpret_cast<float*>(lds + LDS_W);
+    int* flag = reinterpret_cast<int*>(lds + LDS_W + LDS_RED);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_s0 = b < NS;
+    const int N = P.N, S = P.S;
+    const int k = is_s0 ? 0 : 2, bs = is_s0 ? b : b - NS, ck = is_s0 ? CB_G0 : CB_G2;
+    float* XG = is_s0 ? P.XG0 : P.XG2;
+    auto cnt = [&](int kind, int t) { return P.cnt + ((long)kind * (S + 1) + t) * CNT_LINE; };
+    // d h_k(t)[:, u] = sum_c d G_k(t+1)[:, c] W_hh_k[c, u]: B[k = c][col = u], four k-slices (= gates) of 512
+    for (int ks = 0; ks < 4; ++ks) fill_bimg_t(wimg + ks * 2048, P.w_hh[k] + (long)ks * PH * PH + 16 * bs, PH, PH, 16, tid);
+    __syncthreads();
+    const int gn = tid >> 2, gq = tid & 3, u0 = 16 * bs + 4 * gq;
+    float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const u32 XB = PROWS * PH * 4;
+    for (int t = S - 1; t >= 0; --t) {
+        const GradIn in = load_grad_in(P, k, t, gn, u0);
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < S - 1) {
+            if (!wait_total(P, cnt(ck, t + 1), NS, flag, 5000u * (ck + 1) + t)) return;
+            f32x4 acc[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < 4; ++ks) {
+                float4 a[4][8];
+                load_afrag<1>(a, mk_rsrc(XG + (long)(t + 1) * XSTEP4 + (long)ks * PROWS * PH, XB), w, lane);
+                mfma_tile(acc, a, wimg + ks * 2048 + w * 512, lane);
+            }
+            acc_to_lds(acc, red, w, lane);
+            __syncthreads();
+            const float* rp = red + gn * 16 + 4 * gq;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) rec = f4add(rec, *reinterpret_cast<const float4*>(rp + ww * PROWS * 16));
+        }
+        const CellGrad cgd = cell_grad4(P, in, rec, dc, k, t, gn, u0);
+        dc = cgd.dc;
+        // exchange layout [gate][unit / 16][n][16]
+        const __amdgpu_buffer_rsrc_t rx = mk_rsrc(XG + (long)t * XSTEP4, 4 * XB);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st16_sc1(rx, (u32)((((g * 32 + bs) * PROWS + gn) * 16 + 4 * gq) * 4), cgd.dg[g]);
+        publish(cnt(ck, t));            // (its barrier also protects `red`)
+        if (gn < N) {
+            float* dgp = P.DG[k] + ((long)t * N + gn) * 4 * PH + u0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dgp + g * PH) = cgd.dg[g];
+        }
+    }
+}
+
+// ---- backward kernel 2: the attention chain ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float4* wimg = reinterpret_cast<float4*>(lds);
+    float* red = reinterpret_cast<float*>(lds + LDS_WA);
+    int* flag = reinterpret_cast<int*>(lds + LDS_WA + LDS_RED_ATT);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_gd = b < NGD, is_p = b >= NGD && b < NGD + NP;
+    const int N = P.N, D = P.D, S = P.S;
+    auto cnt = [&](int kind, int t) { return P.cnt + ((long)kind * (S + 1) + t) * CNT_LINE; };
+    const int pct = (b - NGD) & 31, pks = (b - NGD) >> 5;         // product role: column tile, k-slice
+    if (is_gd) {
+        // d h1[:, u] += sum_j d q[:, j] W_h2a[j, u]
+        fill_bimg_t(wimg, P.w_h2a + 16 * b, PH, PH, 16, tid);
+    } else if (is_p) {
+        // d ATT[:, d] = sum_c d G1[:, c] W_ih1[c, E + d];  d h1[:, u] = sum_c d G1[:, c] W_hh1[c, u];  c in this workgroup's slice
+        fill_bimg_t(wimg, P.w_att + (long)pks * PH * P.ld_att + 16 * pct, P.ld_att, PH, max(0, min(16, D - 16 * pct)), tid);
+        fill_bimg_t(wimg + 2048, P.w_hh[1] + (long)pks * PH * PH + 16 * pct, PH, PH, 16, tid);
+    }
+    // ---- attention operands -> registers (as the forward kernel: e^{2p} and the C3D rows of this workgroup's slots) ----
+    float* red2 = red;
+    float* sal = red + 16 * PH;
+    const int an = b / 3, ap = b - 3 * an;
+    const bool att_live = an < N;
+    const int grow_ = 4 * w + (lane >> 4), lr = lane & 15;
+    int alen = 0;
+    float4 Pr[PSG][8], Cr[PSG][8];
+    for (int j = tid; j < PH; j += 256) sal[j] = P.w_alpha[j];
+    if (att_live) {
+        alen = P.ev_len[an];
+        const long row0 = P.ev_start[an];
+#pragma unroll
+        for (int i = 0; i < PSG; ++i) {
+            const int sl = grow_ + 16 * i;
+            const int a = min(PSL * ap + min(sl, PSL - 1), alen - 1);
+            const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
+            const float* cr = P.c3d + (row0 + a) * D;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const float4 pv = *reinterpret_cast<const float4*>(pr + 4 * h);
+                Pr[i][h] = make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
+                                       __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
+                const int d = 32 * lr + 4 * h;
+                float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
+                if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                Cr[i][h] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PSG; ++i)
+#pragma unroll
+            for (int h = 0; h < 8; ++h) Pr[i][h] = Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    const int gn = tid >> 2, gq = tid & 3, u0 = 16 * b + 4 * gq;        // gate-gradient ownership (GD role)
+    float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const u32 XB = PROWS * PH * 4;
+
+    for (int t = S - 1; t >= -1; --t) {
+        // ============ GD: d h1(t) -> d G1(t); at t = -1 only d q(0) is copied out ============
+        if (is_gd) {
+            GradIn in;
+            if (t >= 0) in = load_grad_in(P, 1, t, gn, u0);
+            float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < S - 1) {
+                if (!wait_total(P, cnt(CB_DQ, t + 1), NATT, flag, 400000u + t + 1)) return;
+                f32x4 acc[4];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                {
+                    float4 a[4][8];
+                    load_afrag<1>(a, mk_rsrc(P.XDQ + (long)(t + 1) * PROWS * PH, XB), w, lane);
+                    if (t >= 0) mfma_tile(acc, a, wimg + w * 512, lane);
+                    // d q(t+1) row-major for the weight-gradient products: this workgroup stores columns [16 b, 16 b + 16)
+                    if (w == (b >> 3)) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if (c == (b & 7)) {
+#pragma unroll
+                                for (int rb = 0; rb < 4; ++rb) {
+                                    const int n = 16 * rb + (lane & 15);
+                                    if (n < N) *reinterpret_cast<float4*>(P.DQ + ((long)(t + 1) * N + n) * PH + 16 * b + 4 * (lane >> 4)) = a[rb][c];
+                                }
+                            }
+                    }
+                }
+                if (t >= 0) {
+                    acc_to_lds(acc, red, w, lane);
+                    __syncthreads();
+                    const float* rp = red + gn * 16 + 4 * gq;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) rec = f4add(rec, *reinterpret_cast<const float4*>(rp + ww * PROWS * 16));
+                    // + d G1(t+1) . W_hh1: four k-slice slabs of the product workgroups
+                    if (!wait_total(P, cnt(CB_HH, t + 1), NP, flag, 500000u + t + 1)) return;
+                    const __amdgpu_buffer_rsrc_t rh = mk_rsrc(P.XDH + (long)(t + 1) * PROWS * PH, XB);
+                    rec = f4add(rec, ld16_sc1(rh, (u32)(((b * PROWS + gn) * 16 + 4 * gq) * 4)));
+                }
+            }
+            if (t >= 0) {
+                const CellGrad cgd = cell_grad4(P, in, rec, dc, 1, t, gn, u0);
+                dc = cgd.dc;
+                const __amdgpu_buffer_rsrc_t rx = mk_rsrc(P.XDG + (long)t * XSTEP4, 4 * XB);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) st16_sc1(rx, (u32)((((g * 32 + b) * PROWS + gn) * 16 + 4 * gq) * 4), cgd.dg[g]);
+                publish(cnt(CB_DG, t));
+                if (gn < N) {
+                    float* dgp = P.DG[1] + ((long)t * N + gn) * 4 * PH + u0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dgp + g * PH) = cgd.dg[g];
+                }
+            }
+        }
+        if (t < 0) break;
+        // ============ P: d ATT(t) slab (critical), then the d h1 slab for step t-1 ============
+        if (is_p) {
+            if (!wait_total(P, cnt(CB_DG, t), NGD, flag, 600000u + t)) return;
+            float4 a[4][8];
+            load_afrag<1>(a, mk_rsrc(P.XDG + (long)t * XSTEP4 + (long)pks * PROWS * PH, XB), w, lane);
+            {
+                f32x4 acc[4];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mfma_tile(acc, a, wimg + w * 512, lane);
+                acc_to_lds(acc, red, w, lane);
+                __syncthreads();
+                const float* rp = red + gn * 16 + 4 * gq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) v = f4add(v, *reinterpret_cast<const float4*>(rp + ww * PROWS * 16));
+                float* xa = P.XDA + (long)t * PROWS * PH + (pct * PROWS + gn) * 16 + 4 * gq;
+                atomicAdd(xa, v.x); atomicAdd(xa + 1, v.y); atomicAdd(xa + 2, v.z); atomicAdd(xa + 3, v.w);
+                publish(cnt(CB_DA, t));
+            }
+            if (t > 0) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mfma_tile(acc, a, wimg + 2048 + w * 512, lane);
+                acc_to_lds(acc, red, w, lane);
+                __syncthreads();
+                const float* rp = red + gn * 16 + 4 * gq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) v = f4add(v, *reinterpret_cast<const float4*>(rp + ww * PROWS * 16));
+                float* xh = P.XDH + (long)t * PROWS * PH + (pct * PROWS + gn) * 16 + 4 * gq;
+                atomicAdd(xh, v.x); atomicAdd(xh + 1, v.y); atomicAdd(xh + 2, v.z); atomicAdd(xh + 3, v.w);
+                publish(cnt(CB_HH, t));
+            }
+        }
+        // ============ attention backward of step t (all workgroups) ============
+        {
+            float4 q[8];
+            float wt[PSG];
+            if (att_live) {          // saved forward activations: plain loads, in flight while the hand-off is awaited
+                const float* qp = P.QS + ((long)t * N + an) * PH + 32 * lr;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) q[h] = *reinterpret_cast<const float4*>(qp + 4 * h);
+#pragma unroll
+                for (int i = 0; i < PSG; ++i) {
+                    const int sl = grow_ + 16 * i;
+                    const bool valid = sl < PSL && PSL * ap + sl < alen;
+                    wt[i] = valid ? P.WT[((long)t * N + an) * P.A + PSL * ap + sl] : 0.f;
+                }
+            }
+            if (!wait_total(P, cnt(CB_DA, t), NP, flag, 700000u + t)) return;
+            if (att_live) {
+                // d ATT[n, 32 lr .. +32), exchange layout [d / 16][n][16]; the saved context row rides along (plain loads)
+                const __amdgpu_buffer_rsrc_t ra = mk_rsrc(P.XDA + (long)t * PROWS * PH, XB);
+                const float* ap_ = P.ATT + ((long)t * N + an) * D;
+                float4 da[8];
+                float s0 = 0.f;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) da[h] = ld16_sc1(ra, (u32)((((2 * lr + (h >> 2)) * PROWS + an) * 16 + 4 * (h & 3)) * 4));
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const int d = 32 * lr + 4 * h;
+                    float4 at = *reinterpret_cast<const float4*>(ap_ + min(d, D - 4));
+                    if (d >= D) at = make_float4(0.f, 0.f, 0.f, 0.f);
+                    s0 += at.x * da[h].x + at.y * da[h].y + at.z * da[h].z + at.w * da[h].w;
+                }
+                s0 = row16_sum(s0);
+                float dsc[PSG];
+#pragma unroll
+                for (int i = 0; i < PSG; ++i) {
+                    float dw = 0.f;
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) dw += Cr[i][h].x * da[h].x + Cr[i][h].y * da[h].y + Cr[i][h].z * da[h].z + Cr[i][h].w * da[h].w;
+                    dw = row16_sum(dw);
+                    dsc[i] = wt[i] * (dw - s0);
+                }
+                // d q[j] = sum_a dsc_a alpha_j (1 - tanh^2(p_aj + q_j)),  1 - tanh^2 = 4 r (1 - r) with r = 1 / (e^{2p} e^{2q} + 1)
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const float4 eq = make_float4(__expf(2.f * fminf(fmaxf(q[h].x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].y, -43.f), 43.f)),
+                                                  __expf(2.f * fminf(fmaxf(q[h].z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].w, -43.f), 43.f)));
+                    float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < PSG; ++i) {
+                        float r;
+                        r = __builtin_amdgcn_rcpf(fmaf(Pr[i][h].x, eq.x, 1.f)); sacc.x += dsc[i] * (r - r * r);
+                        r = __builtin_amdgcn_rcpf(fmaf(Pr[i][h].y, eq.y, 1.f)); sacc.y += dsc[i] * (r - r * r);
+                        r = __builtin_amdgcn_rcpf(fmaf(Pr[i][h].z, eq.z, 1.f)); sacc.z += dsc[i] * (r - r * r);
+                        r = __builtin_amdgcn_rcpf(fmaf(Pr[i][h].w, eq.w, 1.f)); sacc.w += dsc[i] * (r - r * r);
+                    }
+                    const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
+                    // straight to the cross-row reduction buffer (keeps the register footprint under the 256 architectural VGPRs)
+                    *reinterpret_cast<float4*>(red2 + grow_ * PH + 32 * lr + 4 * h) =
+                        make_float4(4.f * a4.x * sacc.x, 4.f * a4.y * sacc.y, 4.f * a4.z * sacc.z, 4.f * a4.w * sacc.w);
+                }
+                {   // d score of this row's slots, kept for the post-recurrence pass (d P_all, d alpha)
+                    const float xw = lr == 0 ? dsc[0] : (lr == 1 ? dsc[1] : dsc[2]);
+                    const int sl = grow_ + 16 * lr;
+                    if (lr < PSG && sl < PSL && PSL * ap + sl < alen) P.DSC[((long)t * N + an) * P.A + PSL * ap + sl] = xw;
+                }
+                __syncthreads();
+                float* xq = P.XDQ + (long)t * PROWS * PH;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = tid + 256 * h;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) sum += red2[g * PH + j];
+                    atomicAdd(xq + ((j >> 4) * PROWS + an) * 16 + (j & 15), sum);
+                }
+            }
+            publish(cnt(CB_DQ, t));
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 struct PersistHost { u32* abort_dev = nullptr; u32* flag_host = nullptr; u32* flag_dev = nullptr; int cus = 0; bool ok = false; bool init = false; unsigned long long* stamps = nullptr; int stamps_S = 0;
                      hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
@@ -621,6 +1018,8 @@ static PersistHost& phost() {
         if (good) { h.flag_host[0] = 0; good = hipHostGetDevicePointer((void**)&h.flag_dev, h.flag_host, 0) == hipSuccess; }
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
         int lo = 0, hi = 0;
         good = good && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
         good = good && hipStreamCreateWithPriority(&h.side, hipStreamNonBlocking, hi) == hipSuccess;
@@ -654,12 +1053,13 @@ int persist_read_stamps(unsigned long long* dst, int max_entries) {
     return h.stamps_S;
 }
 
-bool persist_fwd_eligible(const echr_dec_args* a) {
-    if (!config().persist) return false;
+static bool persist_shape_ok(const echr_dec_args* a) {
     PersistHost& h = phost();
     return h.ok && h.cus >= NWG && a->N <= PROWS && a->A <= 3 * PSL && a->H == PH && a->Ha == PH && a->D <= PH && a->D % 4 == 0 && a->D >= 8 &&
            a->S >= 1;
 }
+
+bool persist_fwd_eligible(const echr_dec_args* a) { return config().persist && persist_shape_ok(a); }
 
 int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st) {
     PersistHost& h = phost();
@@ -691,6 +1091,35 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     hipLaunchKernelGGL(dec_persist_att_kernel, dim3(NATT), dim3(256), LDS_BYTES_ATT, st, K);
     if (int rc = check_launch("dec_persist_att")) return rc;
     if (hipEventRecord(h.join, h.side) != hipSuccess || hipStreamWaitEvent(st, h.join, 0) != hipSuccess) { set_error("persist_fwd: join failed"); return -5; }
+    return 0;
+}
+
+
+bool persist_bwd_eligible(const echr_dec_args* a) { return config().persist_bwd && persist_shape_ok(a); }
+
+int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st) {
+    PersistHost& h = phost();
+    ECHR_REQUIRE(h.ok, "persist_bwd: device state unavailable");
+    const PersistLayoutB L = persist_layout_b(a->S);
+    PersistB K;
+    K.N = a->N; K.A = a->A; K.D = a->D; K.S = a->S; K.ld_att = a->E + a->D;
+    for (int k = 0; k < 3; ++k) { K.w_hh[k] = a->w_hh[k]; K.GATES[k] = B.GATES[k]; K.CS[k] = B.CS[k]; K.DG[k] = B.DG[k]; }
+    K.w_h2a = a->w_h2a; K.w_att = a->w_ih[1] + a->E; K.w_alpha = a->w_alpha;
+    K.PALL = B.PALL; K.c3d = a->c3d; K.ev_start = a->ev_start; K.ev_len = a->ev_len;
+    K.QS = B.QS; K.WT = B.WT; K.ATT = B.ATT; K.DOUT = B.DOUT; K.DQ = B.DQ; K.DSC = B.DSC;
+    float* x = B.xws;
+    K.cnt = reinterpret_cast<u32*>(x + L.cnt); K.XDQ = x + L.xdq; K.XDG = x + L.xdg; K.XDA = x + L.xda; K.XDH = x + L.xdh;
+    K.XG0 = x + L.xg0; K.XG2 = x + L.xg2;
+    K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
+    K.dh = dh; K.dout = dout;
+    if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_bwd: memset failed"); return -5; }
+    ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), 0.0, st);
+    if (hipEventRecord(h.fork, st) != hipSuccess || hipStreamWaitEvent(h.side, h.fork, 0) != hipSuccess) { set_error("persist_bwd: fork failed"); return -5; }
+    hipLaunchKernelGGL(dec_persist_lstm_bwd_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM, h.side, K);
+    if (int rc = check_launch("dec_persist_lstm_bwd")) return rc;
+    hipLaunchKernelGGL(dec_persist_att_bwd_kernel, dim3(NATT), dim3(256), LDS_BYTES_ATT, st, K);
+    if (int rc = check_launch("dec_persist_att_bwd")) return rc;
+    if (hipEventRecord(h.join, h.side) != hipSuccess || hipStreamWaitEvent(st, h.join, 0) != hipSuccess) { set_error("persist_bwd: join failed"); return -5; }
     return 0;
 }
 

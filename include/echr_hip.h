@@ -337,6 +337,7 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *   "att_slots"   2/4/8 attention slots per wave
  *   "persist"     0/1  (default 1, ECHR_PERSIST) run the teacher-forced recurrence as ONE persistent launch (csrc/persist.hip) when the
  *                      shape allows (N <= 64, A <= 129, H = Ha = 512, D <= 512, a full 256-CU device), else one launch per phase
+ *   "persist_bwd" 0/1  (default 1, ECHR_PERSIST_BWD) the same for the reverse recurrence of echr_decoder_bwd (needs "persist" = 1)
  *   "persist_stamps" 0/1 diagnostic phase stamps, see echr_persist_read_stamps */
 int echr_config_set(const char* key, int32_t value);
 

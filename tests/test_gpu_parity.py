@@ -542,20 +542,22 @@ def test_gemm_path_switches_do_not_change_results_beyond_tolerance():
 
 @pytest.mark.parametrize('case', ['c1', 'c2', 'c2full'])
 def test_persistent_recurrence_equals_launch_path(case):
-    """echr_config_set('persist'): the one-launch weights-stationary recurrence (csrc/persist.hip) against the launch-per-phase
-    recurrence on the same inputs, train mode (dropout), twice in a row (re-launch state: counters, exchange buffers)."""
+    """echr_config_set('persist' / 'persist_bwd'): the persistent weights-stationary recurrences (csrc/persist.hip: forward and reverse)
+    against the launch-per-phase recurrences on the same inputs, train mode (dropout), twice in a row (re-launch state: counters,
+    exchange buffers), and each direction on its own."""
     from echr_amd import _lib
     lib = _lib.load()
     opt, params, vid = synth.make_case(case)
     runs = {}
     try:
-        for name, v in (('launch', 0), ('persist', 1), ('persist2', 1)):
-            assert lib.echr_config_set(b'persist', v) == 0
+        for name, v, vb in (('launch', 0, 0), ('persist', 1, 1), ('persist2', 1, 1), ('fwd_only', 1, 0), ('bwd_only', 0, 1)):
+            assert lib.echr_config_set(b'persist', v) == 0 and lib.echr_config_set(b'persist_bwd', vb) == 0
             runs[name] = U.run_gpu(opt, params, vid, True)
     finally:
         lib.echr_config_set(b'persist', 1)
+        lib.echr_config_set(b'persist_bwd', 1)
     p0, l0, g0, _ = runs['launch']
-    for name in ('persist', 'persist2'):
+    for name in ('persist', 'persist2', 'fwd_only', 'bwd_only'):
         p1, l1, g1, _ = runs[name]
         assert np.isfinite(p1).all(), name
         assert np.abs(p0 - p1).max() < 2e-5 and abs(l0 - l1) < 1e-5 * abs(l0), (name, np.abs(p0 - p1).max())
