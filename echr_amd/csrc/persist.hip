@@ -45,7 +45,7 @@ constexpr int CNT_LINE = SHARDS * SHSTRIDE;              // u32 per counter
 enum { C_H1 = 0, C_Q = 1, C_C = 2, C_H0 = 3, C_H2 = 4, C_KINDS = 5 };
 constexpr u32 SPIN_LIMIT = 4000000;                      // ~ seconds
 constexpr int WU_LD = 132;
-constexpr int LDS_W = 128 * 1024, LDS_WA = 64 * 1024, LDS_RED = 16 * 1024, LDS_RED_ATT = 32 * 1024 + 2048 + 256;
+constexpr int LDS_W = 128 * 1024, LDS_WA = 64 * 1024, LDS_RED = 16 * 1024, LDS_RED_ATT = 32 * 1024 + 2048 + 2048 + 256;
 constexpr int LDS_BYTES_LSTM = LDS_W + LDS_RED + 256, LDS_BYTES_ATT = LDS_WA + LDS_RED_ATT + 256;
 constexpr float ALPHA_SAFE = 40.f;
 
@@ -652,8 +652,10 @@ struct PersistB {
     float* DG[3]; float* DQ; float* DSC;
     float *XDG, *XDA, *XDH, *XDQ, *XG0, *XG2;
     u32* cnt; u32* abort_word; u32* host_flag;
+    unsigned long long* stamps;
     DropCfg dh, dout;
 };
+#define BSTAMP(role, i) do { if (P.stamps && tid == 0 && t >= 0) P.stamps[((role) * S + t) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 // B image of one 16-column tile whose source is k-strided: element (k, cc) = W[k * ld_k + cc] for k < K, cc < ncols; zero elsewhere
 __device__ __forceinline__ void fill_bimg_t(float4* img, const float* W, long ld_k, int K, int ncols, int tid) {
@@ -673,7 +675,7 @@ struct CellGrad { float4 dg[4]; float4 dc; };
 // recurrent dropout mask), dcin = carried d c
 __device__ __forceinline__ float cg1(float dhv, float gi, float gf, float gg, float go, float cn, float cp, float dcin, float& dgi, float& dgf,
                                      float& dgg, float& dgo) {
-    const float tc = tanhf(cn);
+    const float tc = fast_tanh(cn);
     const float dcv = dhv * go * (1.f - tc * tc) + dcin;
     dgi = dcv * gg * gi * (1.f - gi);
     dgf = dcv * cp * gf * (1.f - gf);
@@ -737,10 +739,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P
     float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
     const u32 XB = PROWS * PH * 4;
     for (int t = S - 1; t >= 0; --t) {
+        if (b == 0) BSTAMP(3, 0);
         const GradIn in = load_grad_in(P, k, t, gn, u0);
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < S - 1) {
             if (!wait_total(P, cnt(ck, t + 1), NS, flag, 5000u * (ck + 1) + t)) return;
+            if (b == 0) BSTAMP(3, 1);
             f32x4 acc[4];
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -749,6 +753,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P
                 load_afrag<1>(a, mk_rsrc(XG + (long)(t + 1) * XSTEP4 + (long)ks * PROWS * PH, XB), w, lane);
                 mfma_tile(acc, a, wimg + ks * 2048 + w * 512, lane);
             }
+            if (b == 0) BSTAMP(3, 2);
             acc_to_lds(acc, red, w, lane);
             __syncthreads();
             const float* rp = red + gn * 16 + 4 * gq;
@@ -761,7 +766,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P
         const __amdgpu_buffer_rsrc_t rx = mk_rsrc(XG + (long)t * XSTEP4, 4 * XB);
 #pragma unroll
         for (int g = 0; g < 4; ++g) st16_sc1(rx, (u32)((((g * 32 + bs) * PROWS + gn) * 16 + 4 * gq) * 4), cgd.dg[g]);
+        if (b == 0) BSTAMP(3, 3);
         publish(cnt(ck, t));            // (its barrier also protects `red`)
+        if (b == 0) BSTAMP(3, 4);
         if (gn < N) {
             float* dgp = P.DG[k] + ((long)t * N + gn) * 4 * PH + u0;
 #pragma unroll
@@ -792,6 +799,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
     // ---- attention operands -> registers (as the forward kernel: e^{2p} and the C3D rows of this workgroup's slots) ----
     float* red2 = red;
     float* sal = red + 16 * PH;
+    float* sat = sal + PH + 64;           // [512] saved context row ATT[t][n][:] of the current step (zero beyond D)
     const int an = b / 3, ap = b - 3 * an;
     const bool att_live = an < N;
     const int grow_ = 4 * w + (lane >> 4), lr = lane & 15;
@@ -830,7 +838,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
     float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
     const u32 XB = PROWS * PH * 4;
 
+    const int srole = b == 0 ? 0 : (b == NGD ? 1 : (b == NGD + NP ? 2 : -1));
     for (int t = S - 1; t >= -1; --t) {
+        if (srole >= 0) BSTAMP(srole, 0);
         // ============ GD: d h1(t) -> d G1(t); at t = -1 only d q(0) is copied out ============
         if (is_gd) {
             GradIn in;
@@ -838,6 +848,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
             float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < S - 1) {
                 if (!wait_total(P, cnt(CB_DQ, t + 1), NATT, flag, 400000u + t + 1)) return;
+                if (srole >= 0) BSTAMP(srole, 1);
                 f32x4 acc[4];
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -865,7 +876,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
 #pragma unroll
                     for (int ww = 0; ww < 4; ++ww) rec = f4add(rec, *reinterpret_cast<const float4*>(rp + ww * PROWS * 16));
                     // + d G1(t+1) . W_hh1: four k-slice slabs of the product workgroups
+                    if (srole >= 0) BSTAMP(srole, 2);
                     if (!wait_total(P, cnt(CB_HH, t + 1), NP, flag, 500000u + t + 1)) return;
+                    if (srole >= 0) BSTAMP(srole, 3);
                     const __amdgpu_buffer_rsrc_t rh = mk_rsrc(P.XDH + (long)(t + 1) * PROWS * PH, XB);
                     rec = f4add(rec, ld16_sc1(rh, (u32)(((b * PROWS + gn) * 16 + 4 * gq) * 4)));
                 }
@@ -876,7 +889,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
                 const __amdgpu_buffer_rsrc_t rx = mk_rsrc(P.XDG + (long)t * XSTEP4, 4 * XB);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) st16_sc1(rx, (u32)((((g * 32 + b) * PROWS + gn) * 16 + 4 * gq) * 4), cgd.dg[g]);
+                if (srole >= 0) BSTAMP(srole, 4);
                 publish(cnt(CB_DG, t));
+                if (srole >= 0) BSTAMP(srole, 5);
                 if (gn < N) {
                     float* dgp = P.DG[1] + ((long)t * N + gn) * 4 * PH + u0;
 #pragma unroll
@@ -888,6 +903,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
         // ============ P: d ATT(t) slab (critical), then the d h1 slab for step t-1 ============
         if (is_p) {
             if (!wait_total(P, cnt(CB_DG, t), NGD, flag, 600000u + t)) return;
+            if (srole >= 0) BSTAMP(srole, 6);
             float4 a[4][8];
             load_afrag<1>(a, mk_rsrc(P.XDG + (long)t * XSTEP4 + (long)pks * PROWS * PH, XB), w, lane);
             {
@@ -897,13 +913,17 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
                 mfma_tile(acc, a, wimg + w * 512, lane);
                 acc_to_lds(acc, red, w, lane);
                 __syncthreads();
-                const float* rp = red + gn * 16 + 4 * gq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                // the four k-slices of a tile add atomically; element e = row * 16 + col of the exchange tile is contiguous over the
+                // lanes, so every atomic wave-instruction covers 256 contiguous bytes (the full-rate shape)
+                float* xa = P.XDA + (long)t * PROWS * PH + pct * PROWS * 16;
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) v = f4add(v, *reinterpret_cast<const float4*>(rp + ww * PROWS * 16));
-                float* xa = P.XDA + (long)t * PROWS * PH + (pct * PROWS + gn) * 16 + 4 * gq;
-                atomicAdd(xa, v.x); atomicAdd(xa + 1, v.y); atomicAdd(xa + 2, v.z); atomicAdd(xa + 3, v.w);
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = tid + 256 * e4;
+                    atomicAdd(xa + e, red[e] + red[PROWS * 16 + e] + red[2 * PROWS * 16 + e] + red[3 * PROWS * 16 + e]);
+                }
+                if (srole >= 0) BSTAMP(srole, 7);
                 publish(cnt(CB_DA, t));
+                if (srole >= 0) BSTAMP(srole, 8);
             }
             if (t > 0) {
                 f32x4 acc[4];
@@ -912,13 +932,14 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
                 mfma_tile(acc, a, wimg + 2048 + w * 512, lane);
                 acc_to_lds(acc, red, w, lane);
                 __syncthreads();
-                const float* rp = red + gn * 16 + 4 * gq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                float* xh = P.XDH + (long)t * PROWS * PH + pct * PROWS * 16;
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) v = f4add(v, *reinterpret_cast<const float4*>(rp + ww * PROWS * 16));
-                float* xh = P.XDH + (long)t * PROWS * PH + (pct * PROWS + gn) * 16 + 4 * gq;
-                atomicAdd(xh, v.x); atomicAdd(xh + 1, v.y); atomicAdd(xh + 2, v.z); atomicAdd(xh + 3, v.w);
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = tid + 256 * e4;
+                    atomicAdd(xh + e, red[e] + red[PROWS * 16 + e] + red[2 * PROWS * 16 + e] + red[3 * PROWS * 16 + e]);
+                }
                 publish(cnt(CB_HH, t));
+                if (srole >= 0) BSTAMP(srole, 9);
             }
         }
         // ============ attention backward of step t (all workgroups) ============
@@ -935,21 +956,21 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
                     const bool valid = sl < PSL && PSL * ap + sl < alen;
                     wt[i] = valid ? P.WT[((long)t * N + an) * P.A + PSL * ap + sl] : 0.f;
                 }
+                // the saved context row goes to LDS before the wait (no register cost across it; the wait's barriers publish it)
+                for (int d = tid; d < PH; d += 256) sat[d] = d < D ? P.ATT[((long)t * N + an) * D + d] : 0.f;
             }
             if (!wait_total(P, cnt(CB_DA, t), NP, flag, 700000u + t)) return;
+            if (srole >= 0) BSTAMP(srole, 10);
             if (att_live) {
                 // d ATT[n, 32 lr .. +32), exchange layout [d / 16][n][16]; the saved context row rides along (plain loads)
                 const __amdgpu_buffer_rsrc_t ra = mk_rsrc(P.XDA + (long)t * PROWS * PH, XB);
-                const float* ap_ = P.ATT + ((long)t * N + an) * D;
                 float4 da[8];
                 float s0 = 0.f;
 #pragma unroll
                 for (int h = 0; h < 8; ++h) da[h] = ld16_sc1(ra, (u32)((((2 * lr + (h >> 2)) * PROWS + an) * 16 + 4 * (h & 3)) * 4));
 #pragma unroll
                 for (int h = 0; h < 8; ++h) {
-                    const int d = 32 * lr + 4 * h;
-                    float4 at = *reinterpret_cast<const float4*>(ap_ + min(d, D - 4));
-                    if (d >= D) at = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 at = *reinterpret_cast<const float4*>(sat + 32 * lr + 4 * h);
                     s0 += at.x * da[h].x + at.y * da[h].y + at.z * da[h].z + at.w * da[h].w;
                 }
                 s0 = row16_sum(s0);
@@ -997,7 +1018,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
                     atomicAdd(xq + ((j >> 4) * PROWS + an) * 16 + (j & 15), sum);
                 }
             }
+            if (srole >= 0) BSTAMP(srole, 11);
             publish(cnt(CB_DQ, t));
+            if (srole >= 0) BSTAMP(srole, 12);
         }
     }
 }
@@ -1077,7 +1100,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
     K.dh = dh; K.dout = dout;
     K.stamps = nullptr;
-    if (config().persist_stamps) {
+    if (config().persist_stamps == 1) {
         if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
@@ -1112,6 +1135,11 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
     K.XG0 = x + L.xg0; K.XG2 = x + L.xg2;
     K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
     K.dh = dh; K.dout = dout;
+    K.stamps = nullptr;
+    if (config().persist_stamps == 2) {
+        if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
+        if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
+    }
     if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_bwd: memset failed"); return -5; }
     ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), 0.0, st);
     if (hipEventRecord(h.fork, st) != hipSuccess || hipStreamWaitEvent(h.side, h.fork, 0) != hipSuccess) { set_error("persist_bwd: fork failed"); return -5; }

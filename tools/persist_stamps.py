@@ -21,11 +21,18 @@ model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
 model = model.to(dev).train()
 tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
 labels = torch.from_numpy(vid['labels'])
+BWD = len(sys.argv) > 1 and sys.argv[1] == 'bwd'
+crit = LanguageModelCriterion()
+tgt, msk = labels[:, 1:].to(dev), torch.from_numpy(vid['masks'])[:, 1:].to(dev)
 for it in range(4):
     if it == 3:
-        lib.echr_config_set(b'persist_stamps', 1)
-    with torch.no_grad():
-        model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+        lib.echr_config_set(b'persist_stamps', 2 if BWD else 1)
+    if BWD:
+        model.zero_grad()
+        crit(model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), tgt, msk).backward()
+    else:
+        with torch.no_grad():
+            model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
     torch.cuda.synchronize()
 S = 20
 buf = np.zeros(4 * 256 * 16, dtype=np.uint64)
@@ -36,17 +43,27 @@ names = {0: ['step', 'waitH1', 'mfmaA', '-', '-', 'waitQ', 'att', 'pubC', 'waitC
          1: ['step', 'waitH1', 'mfmaA', 'qepi', 'pubQ', 'waitQ', 'att', 'pubC'],
          2: ['step', '-', '-', '-', '-', 'waitQ', 'att', 'pubC', '-', '-', '-', '-', 'qload', 'score', 'ctx+lds'],
          3: ['step', 'waitH', 'mfma', 'gate', 'pub']}
-for role, rn in ((0, 'gate wg 0'), (1, 'q wg 128'), (2, 'att wg 160'), (3, 'lstm wg 0')):
+if BWD:
+    names = {0: ['step', 'waitDQ', 'mfmaQ', 'waitHH', 'gate', 'pubDG', '-', '-', '-', '-', 'waitDA', 'att', 'pubDQ'],
+             1: ['step', '-', '-', '-', '-', '-', 'waitDG', 'mfmaA', 'pubDA', 'tileB+pubHH', 'waitDA', 'att', 'pubDQ'],
+             2: ['step', '-', '-', '-', '-', '-', '-', '-', '-', '-', 'waitDA', 'att', 'pubDQ'],
+             3: ['step', 'waitG', 'mfma', 'gate', 'pub']}
+    rl = ((0, 'GD wg 0'), (1, 'P wg 32'), (2, 'att wg 160'), (3, 'lstm-bwd wg 0'))
+else:
+    rl = ((0, 'gate wg 0'), (1, 'q wg 128'), (2, 'att wg 160'), (3, 'lstm wg 0'))
+for role, rn in rl:
     a = st[role]
+    if BWD:
+        a = a[::-1]          # the reverse recurrence walks t downwards
     print('%s: step period %.2f us' % (rn, (a[S - 1, 0] - a[2, 0]) / (S - 3)))
     prev_i = 0
     out = []
     for i in range(1, len(names[role])):
         if names[role][i] == '-':
             continue
-        if i == 12:
+        if i == 12 and not BWD:
             prev_i = 5
-        d = (a[3:S, i] - a[3:S, prev_i]).mean()
+        d = (a[3:S - 1, i] - a[3:S - 1, prev_i]).mean()
         out.append('%s %.2f' % (names[role][i], d))
         prev_i = i
     print('   ' + ' | '.join(out))
