@@ -206,15 +206,17 @@ __device__ __forceinline__ void fill_bimg(float4* img, const float* W, long ld, 
 
 struct CellOut { float c, h, hd; float gi, gf, gg, go; };
 // nn.LSTMCell gate math (order i, f, g, o) + the two dropouts (OldModel_NEW.py:808-818, :136)
-__device__ __forceinline__ CellOut lstm_cell(float pi, float pf, float pg, float po, float c_prev, const DropCfg& dh, const DropCfg& dout,
-                                             int n, int j, int k, int t) {
+// mh / mo: the recurrent and the late-fusion dropout multipliers of the element (index-only work: computed ahead of the hand-off waits)
+__device__ __forceinline__ CellOut lstm_cell(float pi, float pf, float pg, float po, float c_prev, float mh, float mo) {
     CellOut o;
     o.gi = fast_sigmoid(pi); o.gf = fast_sigmoid(pf); o.gg = fast_tanh(pg); o.go = fast_sigmoid(po);
     o.c = o.gf * c_prev + o.gi * o.gg;
-    o.h = o.go * fast_tanh(o.c) * drop_mult(dh, (unsigned)(n * PH + j), (unsigned)t, (unsigned)(1 + k));        // SITE_H0 + k
-    o.hd = o.h * drop_mult(dout, (unsigned)(n * 3 * PH + k * PH + j), (unsigned)t, 4u);                     // SITE_OUT
+    o.h = o.go * fast_tanh(o.c) * mh;
+    o.hd = o.h * mo;
     return o;
 }
+__device__ __forceinline__ float mask_h(const DropCfg& dh, int n, int j, int k, int t) { return drop_mult(dh, (unsigned)(n * PH + j), (unsigned)t, (unsigned)(1 + k)); }      // SITE_H0 + k
+__device__ __forceinline__ float mask_o(const DropCfg& dout, int n, int j, int k, int t) { return drop_mult(dout, (unsigned)(n * 3 * PH + k * PH + j), (unsigned)t, 4u); }   // SITE_OUT
 
 // ---- kernel 1: the two plain LSTM streams (0: event context, 2: scene context), 32 workgroups of 16 hidden units each -------------
 __global__ __launch_bounds__(256, 1) void dec_persist_lstm_kernel(PersistK P) {
@@ -248,6 +250,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_kernel(PersistK P) {
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int g = 0; g < 4; ++g) pre[ct][g] = grow[g * PH + 4 * ct];
+        float mh[4], mo[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            mh[ct] = mask_h(P.dh, gn, 16 * bs + 4 * ct + gu, k, t);
+            mo[ct] = mask_o(P.dout, gn, 16 * bs + 4 * ct + gu, k, t);
+        }
         f32x4 acc[4][4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_kernel(PersistK P) {
                 }
                 __syncthreads();
             }
-            co[ct] = lstm_cell(pre[ct][0], pre[ct][1], pre[ct][2], pre[ct][3], cs[ct], P.dh, P.dout, gn, 16 * bs + 4 * ct + gu, k, t);
+            co[ct] = lstm_cell(pre[ct][0], pre[ct][1], pre[ct][2], pre[ct][3], cs[ct], mh[ct], mo[ct]);
             cs[ct] = co[ct].c;
         }
         // exchange layout [bs][n][16]: unit 4 ct + u
@@ -383,10 +391,13 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
         float pre[4] = {0.f, 0.f, 0.f, 0.f};
+        float mh1 = 1.f, mo1 = 1.f;
         if (is_g1) {
             const float* grow = P.GATES[1] + ((long)t * N + min(gn, N - 1)) * 4 * PH + 4 * b + gu;
 #pragma unroll
             for (int g = 0; g < 4; ++g) pre[g] = grow[g * PH];
+            mh1 = mask_h(P.dh, gn, 4 * b + gu, 1, t);
+            mo1 = mask_o(P.dout, gn, 4 * b + gu, 1, t);
         }
         // ---- phase A: products with h1(t-1): W_hh1 . h1 (gate workgroups, kept in the accumulators), q = W_h2a . h1 + b ----
         if ((is_g1 || is_qw) && t > 0) {
@@ -576,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
                 const int o = gn * 16 + 4 * g + gu;
                 pre[g] += red[o] + red[PROWS * 16 + o] + red[2 * PROWS * 16 + o] + red[3 * PROWS * 16 + o];
             }
-            const CellOut co = lstm_cell(pre[0], pre[1], pre[2], pre[3], c1, P.dh, P.dout, gn, 4 * b + gu, 1, t);
+            const CellOut co = lstm_cell(pre[0], pre[1], pre[2], pre[3], c1, mh1, mo1);
             c1 = co.c;
             st4_sc1(P.XH1 + (long)t * PROWS * PH + (b * PROWS + gn) * 4 + gu, co.h);
             if (srole >= 0) STAMP(srole, 10);
@@ -698,7 +709,18 @@ __device__ __forceinline__ GradIn load_grad_in(const PersistB& P, int k, int t, 
     r.cp = *reinterpret_cast<const float4*>(P.CS[k] + ((long)t * P.N + n) * PH + u0);
     return r;
 }
-__device__ __forceinline__ CellGrad cell_grad4(const PersistB& P, const GradIn& in, float4 dh_rec, float4 dc, int k, int t, int gn, int u0) {
+struct DropM { float mo[4], mh[4]; };
+// the two dropout multipliers of (event gn, units u0..u0+3, stream k, step t): index-only work, done ahead of the hand-off waits
+__device__ __forceinline__ DropM drop_masks4(const PersistB& P, int k, int t, int gn, int u0) {
+    DropM m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m.mo[i] = drop_mult(P.dout, (unsigned)(gn * 3 * PH + k * PH + u0 + i), (unsigned)t, 4u);
+        m.mh[i] = drop_mult(P.dh, (unsigned)(gn * PH + u0 + i), (unsigned)t, (unsigned)(1 + k));
+    }
+    return m;
+}
+__device__ __forceinline__ CellGrad cell_grad4(const PersistB& P, const GradIn& in, const DropM& m, float4 dh_rec, float4 dc) {
     CellGrad o;
     float dhv[4] = {in.dout.x, in.dout.y, in.dout.z, in.dout.w};
     const float rec[4] = {dh_rec.x, dh_rec.y, dh_rec.z, dh_rec.w};
@@ -709,9 +731,7 @@ __device__ __forceinline__ CellGrad cell_grad4(const PersistB& P, const GradIn& 
     float dg[4][4], dcn[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned o3 = (unsigned)(gn * 3 * PH + k * PH + u0 + i), oh = (unsigned)(gn * PH + u0 + i);
-        float v = dhv[i] * drop_mult(P.dout, o3, (unsigned)t, 4u) + rec[i];
-        v *= drop_mult(P.dh, oh, (unsigned)t, (unsigned)(1 + k));
+        const float v = (dhv[i] * m.mo[i] + rec[i]) * m.mh[i];
         dcn[i] = cg1(v, gi[i], gf[i], gg[i], go[i], cn[i], cp[i], dcin[i], dg[0][i], dg[1][i], dg[2][i], dg[3][i]);
     }
 #pragma unroll
@@ -741,6 +761,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P
     for (int t = S - 1; t >= 0; --t) {
         if (b == 0) BSTAMP(3, 0);
         const GradIn in = load_grad_in(P, k, t, gn, u0);
+        const DropM dm = drop_masks4(P, k, t, gn, u0);
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < S - 1) {
             if (!wait_total(P, cnt(ck, t + 1), NS, flag, 5000u * (ck + 1) + t)) return;
@@ -760,7 +781,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) rec = f4add(rec, *reinterpret_cast<const float4*>(rp + ww * PROWS * 16));
         }
-        const CellGrad cgd = cell_grad4(P, in, rec, dc, k, t, gn, u0);
+        const CellGrad cgd = cell_grad4(P, in, dm, rec, dc);
         dc = cgd.dc;
         // exchange layout [gate][unit / 16][n][16]
         const __amdgpu_buffer_rsrc_t rx = mk_rsrc(XG + (long)t * XSTEP4, 4 * XB);
@@ -844,8 +865,14 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
         // ============ GD: d h1(t) -> d G1(t); at t = -1 only d q(0) is copied out ============
         if (is_gd) {
             GradIn in;
-            if (t >= 0) in = load_grad_in(P, 1, t, gn, u0);
+            DropM dm;
+            if (t >= 0) { in = load_grad_in(P, 1, t, gn, u0); dm = drop_masks4(P, 1, t, gn, u0); }
             float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < S - 1 && t >= 0) {
+                // + d G1(t+1) . W_hh1 (the product workgroups' atomically summed tile): complete well before d q(t+1), fetched first
+                if (!wait_total(P, cnt(CB_HH, t + 1), NP, flag, 500000u + t + 1)) return;
+                rec = ld16_sc1(mk_rsrc(P.XDH + (long)(t + 1) * PROWS * PH, XB), (u32)(((b * PROWS + gn) * 16 + 4 * gq) * 4));
+            }
             if (t < S - 1) {
                 if (!wait_total(P, cnt(CB_DQ, t + 1), NATT, flag, 400000u + t + 1)) return;
                 if (srole >= 0) BSTAMP(srole, 1);
@@ -875,16 +902,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
                     const float* rp = red + gn * 16 + 4 * gq;
 #pragma unroll
                     for (int ww = 0; ww < 4; ++ww) rec = f4add(rec, *reinterpret_cast<const float4*>(rp + ww * PROWS * 16));
-                    // + d G1(t+1) . W_hh1: four k-slice slabs of the product workgroups
                     if (srole >= 0) BSTAMP(srole, 2);
-                    if (!wait_total(P, cnt(CB_HH, t + 1), NP, flag, 500000u + t + 1)) return;
                     if (srole >= 0) BSTAMP(srole, 3);
-                    const __amdgpu_buffer_rsrc_t rh = mk_rsrc(P.XDH + (long)(t + 1) * PROWS * PH, XB);
-                    rec = f4add(rec, ld16_sc1(rh, (u32)(((b * PROWS + gn) * 16 + 4 * gq) * 4)));
                 }
             }
             if (t >= 0) {
-                const CellGrad cgd = cell_grad4(P, in, rec, dc, 1, t, gn, u0);
+                const CellGrad cgd = cell_grad4(P, in, dm, rec, dc);
                 dc = cgd.dc;
                 const __amdgpu_buffer_rsrc_t rx = mk_rsrc(P.XDG + (long)t * XSTEP4, 4 * XB);
 #pragma unroll
