@@ -6,6 +6,8 @@ names (`fusion_model`, `lm_model`) and state_dict keys.  The three context level
 python loops over events: index lists are uploaded once as int32 (start, length, anchor) vectors and
 every kernel addresses the video features through them.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -22,6 +24,7 @@ class CaptionGenerator(nn.Module):
         if 'TSRM' in opt.fusion_model and 'ER' in opt.event_context_type:
             self.fusion_model = models.setup_fusion(opt)
         self.lm_model = models.setup_lm(opt)
+        self.overlap_encoder = os.environ.get('ECHR_OVERLAP_ENCODER', '1') != '0'        # 'train' mode: run the decoder's event-independent precompute concurrently with the event encoder
         if opt.video_context_type != 'VL' or opt.event_context_type != 'ER3' or opt.clip_context_type != 'CC':
             raise NotImplementedError('the HIP path implements the ECHR recipe: video_context_type=VL, event_context_type=ER3, '
                                       'clip_context_type=CC (experiments/train_ECHR.sh)')
@@ -50,10 +53,14 @@ class CaptionGenerator(nn.Module):
         drop = self.lm_model.next_drop_state(self.fusion_model.enc_attn.dropout.p if hasattr(self, 'fusion_model') else 0.0)
         drop.training = self.training
         video = self.get_video_context(tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list)
-        event = self.get_event_context(tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=ev, _drop=drop)
         clip, clip_mask = self.get_clip_context(tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=ev)
+        prepared = None
+        if mode == 'train' and self.overlap_encoder:
+            # the decoder's event-independent precompute starts on a second stream and overlaps the event encoder launched next
+            prepared = self.lm_model.prepare(video, clip, clip_mask, lm_labels)
+        event = self.get_event_context(tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=ev, _drop=drop)
         if mode == 'train':
-            return self.lm_model(video, event, clip, clip_mask, lm_labels, drop=drop)
+            return self.lm_model(video, event, clip, clip_mask, lm_labels, drop=drop, prepared=prepared)
         return self.lm_model.sample(video, event, clip, clip_mask)
 
     def change_context_dim(self):

@@ -47,7 +47,7 @@ class DecArgs(C.Structure):
                 ('w_ih', c_f * 3), ('w_hh', c_f * 3), ('b_ih', c_f * 3), ('b_hh', c_f * 3),
                 ('w_c2a', c_f), ('b_c2a', c_f), ('w_h2a', c_f), ('b_h2a', c_f), ('w_alpha', c_f), ('b_alpha', c_f),
                 ('c3d', c_f), ('ev_start', c_f), ('ev_len', c_f), ('event', c_f), ('video', c_f), ('tokens', c_f),
-                ('ws', c_f), ('logp', c_f)]
+                ('ws', c_f), ('logp', c_f), ('prepared', i32)]
 
 
 class DecGrads(C.Structure):
@@ -89,6 +89,7 @@ SYMBOLS = [
     ('echr_decoder_ws_floats', i64, [C.POINTER(DecArgs)]),
     ('echr_decoder_ws_bwd_floats', i64, [C.POINTER(DecArgs)]),
     ('echr_decoder_fwd', i32, [C.POINTER(DecArgs), C.POINTER(Dropout), C.c_void_p]),
+    ('echr_decoder_fwd_prepare', i32, [C.POINTER(DecArgs), C.c_void_p]),
     ('echr_decoder_bwd', i32, [C.POINTER(DecArgs), C.POINTER(DecGrads), C.POINTER(Dropout), C.c_void_p]),
     ('echr_nll_loss_fwd', i32, [c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_nll_loss_bwd', i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),

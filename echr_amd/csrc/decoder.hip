@@ -788,9 +788,11 @@ static RecJob mkjob(const float* A, long lda, int K, const float* B, long ldb, i
 
 // P_all = c3d . W_c^T + b_c over the Tv video rows; EVB0 = event . W_ih0[:,E:]^T + b_ih0 + b_hh0;
 // VIDB = W_ih2[:,E:] . video + b_ih2 + b_hh2   (all time-invariant)
-static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t st, bool teacher_forced, bool evb0_zeroed = false) {
+// parts: 1 = everything that does not read the event context (operand packs, P_all, VIDB), 2 = EVB0
+static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t st, bool teacher_forced, bool evb0_zeroed = false, int parts = 3) {
     const int H = a->H, E = a->E;
     echr_gemm_desc d;
+    if (!(parts & 1)) goto event_part;
     if (config().gemm_h2) {
         // every time-invariant GEMM operand of the forward pass is packed by one launch
         H2PackJob pj[6] = {pack_rows(a->c3d, a->D, a->Tv, a->D, w.PK_C3D), pack_rows(a->w_c2a, a->D, a->Ha, a->D, w.PK_WC),
@@ -804,14 +806,29 @@ static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t
     }
     d.bias = a->b_c2a;
     RC(gemm(d, st));
-    d = desc_nt(a->event, a->De, a->w_ih[0] + E, E + a->De, w.EVB0, 4 * H, a->N, 4 * H, a->De);
-    d.bias = a->b_ih[0]; d.bias2 = a->b_hh[0]; d.split_k = -1;
-    if (evb0_zeroed) d.beta = 1.f;            // accumulate into the caller's zeros: no fill launch
-    RC(gemm(d, st));
     d = desc_nt(a->video, a->Dv, a->w_ih[2] + E, E + a->Dv, w.VIDB, 4 * H, 1, 4 * H, a->Dv);
     d.bias = a->b_ih[2]; d.bias2 = a->b_hh[2];
     RC(gemm(d, st));
+event_part:
+    if (parts & 2) {
+        d = desc_nt(a->event, a->De, a->w_ih[0] + E, E + a->De, w.EVB0, 4 * H, a->N, 4 * H, a->De);
+        d.bias = a->b_ih[0]; d.bias2 = a->b_hh[0]; d.split_k = -1;
+        if (evb0_zeroed) d.beta = 1.f;            // accumulate into the caller's zeros: no fill launch
+        RC(gemm(d, st));
+    }
     return 0;
+}
+
+// G[t][n][:] += B[n][:] for every timestep (the event-context part of stream 0's gate pre-activations, added after the fact when the
+// token-side products were computed ahead of the event encoder)
+__global__ __launch_bounds__(256) void add_bcast_rows_kernel(float* __restrict__ G, const float* __restrict__ B, long rows, long per_step, int cols4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols4) return;
+    const long r = i / cols4, c = i % cols4;
+    float4 g = reinterpret_cast<float4*>(G)[i];
+    const float4 b = reinterpret_cast<const float4*>(B)[(r % per_step) * cols4 + c];
+    g.x += b.x; g.y += b.y; g.z += b.z; g.w += b.w;
+    reinterpret_cast<float4*>(G)[i] = g;
 }
 
 // one decoder timestep given the input-side gate pre-activations already in GATES[k][t]
@@ -880,7 +897,7 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
 }
 
 // input-side gate pre-activations for `rows` = nt*N token rows starting at timestep t0
-static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, int t0, int nt, hipStream_t st) {
+static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, int t0, int nt, hipStream_t st, bool no_evb0 = false) {
     const int N = a->N, H = a->H, E = a->E;
     const int rows = nt * N;
     const int cin[3] = {E + a->De, E + a->D, E + a->Dv};
@@ -894,7 +911,7 @@ static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, 
         float* g = w.GATES[k] + (long)t0 * N * 4 * H;
         d[k] = h2 ? desc_h2(w.PK_XT, w.PK_WIH[k], g, 4 * H, rows, 4 * H, E) : desc_nt(xt, E, a->w_ih[k], cin[k], g, 4 * H, rows, 4 * H, E);
         d[k].add_mod = N; d[k].ld_add = 4 * H;
-        if (k == 0) d[k].addend = w.EVB0;
+        if (k == 0) { if (!no_evb0) d[k].addend = w.EVB0; }
         else if (k == 1) { d[k].bias = a->b_ih[1]; d[k].bias2 = a->b_hh[1]; }
         else d[k].bias = w.VIDB;
         d[k].split_k = -1;
@@ -911,6 +928,46 @@ extern "C" int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a) { return a
 
 extern "C" int echr_stream_join(void* stream) { return join_tail((hipStream_t)stream); }
 
+// ---- event-independent part of the decoder forward, ahead of (and concurrent with) the event encoder ----
+struct Prep { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr; bool ok = false, init = false, pending = false; const void* ws = nullptr; };
+static Prep& prep() {
+    static Prep t;
+    if (!t.init) {
+        t.init = true;
+        bool good = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
+        t.ok = good;
+    }
+    return t;
+}
+static int decoder_fill(const echr_dec_args* a, const DecWs& w, hipStream_t st) {
+    const int N = a->N, S = a->S, H = a->H;
+    // h(-1) = c(-1) = 0 (init_hidden, :75-78), the atomic q accumulators and the split-K target EVB0: one launch
+    float* zp[6] = {w.HS, w.CS[0], w.CS[1], w.CS[2], w.QACC, w.EVB0};
+    const long zn[6] = {(long)N * 3 * H, (long)N * H, (long)N * H, (long)N * H, (long)S * N * a->Ha, (long)N * 4 * H};
+    return fill_zero_multi(zp, zn, 6, st);
+}
+
+extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
+    RC(persist_check_async());
+    RC(check_dims(a, "decoder_fwd_prepare"));
+    ECHR_REQUIRE(a->S > 0 && a->ws && a->tokens, "decoder_fwd_prepare: missing buffers");
+    Prep& pr = prep();
+    ECHR_REQUIRE(pr.ok, "decoder_fwd_prepare: stream state unavailable");
+    hipStream_t sm = (hipStream_t)stream, st = pr.s;
+    RC(join_tail(sm));
+    RC(hop(sm, pr.fork, st));
+    DecWs w = carve_ws(a, a->ws);
+    RC(decoder_fill(a, w, st));
+    RC(precompute_static(a, w, st, true, true, 1));
+    RC(embed_gather(a->embed, a->tokens, w.XT, a->S * a->N, a->E, a->V1, st));
+    RC(input_gates(a, w, w.XT, 0, a->S, st, true));
+    if (hipEventRecord(pr.done, st) != hipSuccess) { set_error("decoder_fwd_prepare: event record failed"); return -5; }
+    pr.pending = true; pr.ws = a->ws;
+    return 0;
+}
+
 extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream) {
     RC(persist_check_async());
     RC(join_tail((hipStream_t)stream));
@@ -920,14 +977,22 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
     const int N = a->N, S = a->S, H = a->H, E = a->E;
     DecWs w = carve_ws(a, a->ws);
     const DropCfg dh = make_drop(drop, drop ? drop->p_h : 0.f), dout = make_drop(drop, drop ? drop->p_out : 0.f);
-    {   // h(-1) = c(-1) = 0 (init_hidden, :75-78), the atomic q accumulators and the split-K target EVB0: one launch
-        float* zp[6] = {w.HS, w.CS[0], w.CS[1], w.CS[2], w.QACC, w.EVB0};
-        const long zn[6] = {(long)N * 3 * H, (long)N * H, (long)N * H, (long)N * H, (long)S * N * a->Ha, (long)N * 4 * H};
-        RC(fill_zero_multi(zp, zn, 6, st));
+    if (a->prepared) {
+        // echr_decoder_fwd_prepare already ran everything that does not need the event context on the library's second stream
+        Prep& pr = prep();
+        ECHR_REQUIRE(pr.ok && pr.pending && pr.ws == a->ws, "decoder_fwd: prepared = 1 without a matching echr_decoder_fwd_prepare on this workspace");
+        pr.pending = false;
+        if (hipStreamWaitEvent(st, pr.done, 0) != hipSuccess) { set_error("decoder_fwd: join failed"); return -5; }
+        RC(precompute_static(a, w, st, true, true, 2));
+        const long n4 = (long)S * N * H;            // 4H / 4 float4 per row
+        hipLaunchKernelGGL(add_bcast_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.GATES[0], w.EVB0, (long)S * N, (long)N, H);
+        RC(check_launch("add_bcast_rows"));
+    } else {
+        RC(decoder_fill(a, w, st));
+        RC(precompute_static(a, w, st, true, true));
+        RC(embed_gather(a->embed, a->tokens, w.XT, S * N, E, a->V1, st));
+        RC(input_gates(a, w, w.XT, 0, S, st));
     }
-    RC(precompute_static(a, w, st, true, true));
-    RC(embed_gather(a->embed, a->tokens, w.XT, S * N, E, a->V1, st));
-    RC(input_gates(a, w, w.XT, 0, S, st));
     // late fusion: logits = OUTD . W_logit^T + b, written [N,S,V1], then row log-softmax in place.  Timesteps [0,th) are
     // projected on the side stream while the recurrence of [th,S) is still running.
     auto logits_chunk = [&](int t0, int t1, hipStream_t q) -> int {

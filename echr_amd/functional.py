@@ -5,6 +5,7 @@ happens in libechr_hip.so (include/echr_hip.h).  Every call fails loudly when th
 is missing -- there is no eager/PyTorch fallback.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -48,7 +49,7 @@ def rows_disjoint(soi_select_list):
     return bool(np.all(o[1:, 0] >= o[:-1, 1]))
 
 
-ASYNC_TAIL = [True]        # decoder backward: run the last stage on a second stream (arena path); tests may switch it off
+ASYNC_TAIL = [os.environ.get('ECHR_ASYNC_TAIL', '1') != '0']        # decoder backward: run the last stage on a second stream (arena path); tests may switch it off
 
 
 def _f32c(t):
@@ -168,10 +169,10 @@ DEC_PARAMS = ('embed', 'w_logit', 'b_logit',
               'w_c2a', 'b_c2a', 'w_h2a', 'b_h2a', 'w_alpha', 'b_alpha')
 
 
-def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint=False):
+def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint=False, n_de=None, prepared=0):
     (embed, w_logit, b_logit, wi0, wi1, wi2, wh0, wh1, wh2, bi0, bi1, bi2, bh0, bh1, bh2, w_c2a, b_c2a, w_h2a, b_h2a,
      w_alpha, b_alpha) = ps
-    N, De = event.shape
+    N, De = event.shape if event is not None else n_de
     Tv, D = c3d.shape
     H = wh0.shape[1]
     E = embed.shape[1]
@@ -185,24 +186,47 @@ def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, d
                      L.ptr3((bh0, bh1, bh2), 'b_hh'),
                      L.ptr(w_c2a), L.ptr(b_c2a), L.ptr(w_h2a), L.ptr(b_h2a), L.ptr(w_alpha), L.ptr(b_alpha),
                      L.ptr(c3d), L.ptr(ev_start, torch.int32), L.ptr(ev_len, torch.int32), L.ptr(event), L.ptr(video),
-                     L.ptr(tokens, torch.int32) if tokens is not None else None, L.ptr(ws), L.ptr(logp) if logp is not None else None)
+                     L.ptr(tokens, torch.int32) if tokens is not None else None, L.ptr(ws), L.ptr(logp) if logp is not None else None,
+                     int(prepared))
+
+
+def decoder_prepare(video, c3d, ev_start, ev_len, tokens, A, disjoint, params):
+    """Start the event-independent part of the decoder forward (echr_decoder_fwd_prepare) on the library's second stream, BEFORE the
+    event encoder is launched on the current stream; returns the handle DecoderFunction.forward continues from."""
+    lib = L.load()
+    video, c3d = _f32c(video), _f32c(c3d)
+    ps = [_f32c(p) for p in params]
+    S, N = tokens.shape
+    V1, E = ps[0].shape
+    De = ps[3].shape[1] - E                       # layer0.weight_ih is [4H, E + event_context_dim]
+    logp = torch.empty(N, S, V1, device=c3d.device, dtype=torch.float32)
+    a = _dec_args(ps, c3d, ev_start, ev_len, None, video, tokens, A, S, None, logp, disjoint, n_de=(N, De))
+    ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=c3d.device, dtype=torch.float32)
+    a.ws = L.ptr(ws)
+    L.check(lib.echr_decoder_fwd_prepare(C.byref(a), L.stream_ptr()), 'decoder_fwd_prepare')
+    return dict(ws=ws, logp=logp, video=video, c3d=c3d, ps=ps, tokens=tokens, A=A, disjoint=disjoint)
 
 
 class DecoderFunction(torch.autograd.Function):
     """OldModel.forward with the ThreeStream core (OldModel_NEW.py:98-137, :376-401, :801-823): log-probs [N,S,V1]."""
 
     @staticmethod
-    def forward(ctx, video, event, c3d, ev_start, ev_len, tokens, A, disjoint, drop, sink, *params):
+    def forward(ctx, video, event, c3d, ev_start, ev_len, tokens, A, disjoint, drop, sink, prep, *params):
         lib = L.load()
         ctx.sink = sink
-        video, event, c3d = _f32c(video), _f32c(event), _f32c(c3d)
-        ps = [_f32c(p) for p in params]
+        event = _f32c(event)
         S, N = tokens.shape
-        V1 = ps[0].shape[0]
-        logp = torch.empty(N, S, V1, device=event.device, dtype=torch.float32)
-        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, None, logp, disjoint)
-        ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=event.device, dtype=torch.float32)
-        a.ws = L.ptr(ws)
+        if prep is not None:          # decoder_prepare() already ran the event-independent part on this workspace
+            video, c3d, ps, logp, ws = prep['video'], prep['c3d'], prep['ps'], prep['logp'], prep['ws']
+            a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint, prepared=1)
+        else:
+            video, c3d = _f32c(video), _f32c(c3d)
+            ps = [_f32c(p) for p in params]
+            V1 = ps[0].shape[0]
+            logp = torch.empty(N, S, V1, device=event.device, dtype=torch.float32)
+            a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, None, logp, disjoint)
+            ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=event.device, dtype=torch.float32)
+            a.ws = L.ptr(ws)
         d = drop.c()
         L.check(lib.echr_decoder_fwd(C.byref(a), C.byref(d), L.stream_ptr()), 'decoder_fwd')
         ctx.save_for_backward(video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps)
@@ -259,7 +283,7 @@ class DecoderFunction(torch.autograd.Function):
                     L.check(lib.echr_stream_join(sp), 'stream_join')
                     del keep[:]
                 torch.autograd.Variable._execution_engine.queue_callback(_join)
-        return (g_video, g_event, None, None, None, None, None, None, None, None) + tuple(grads)
+        return (g_video, g_event, None, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
 def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, debug=None):

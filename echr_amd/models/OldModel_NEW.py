@@ -129,26 +129,38 @@ class OldModel(nn.Module):
     def _clip_view(clip, clip_mask):
         return clip if isinstance(clip, ClipView) else ClipView.from_padded(clip, clip_mask)
 
-    def forward(self, video, event, clip, clip_mask, seq, drop=None):
+    def _tokens(self, seq, dev):
+        """[S,N] time-major int32 input tokens of the teacher-forced loop (S = its iteration count, OldModel_NEW.py:105,122)."""
+        S = n_decoder_steps(seq)
+        if S == 0:
+            raise ValueError('label tensor needs at least two columns')
+        seq_t = torch.as_tensor(np.asarray(seq) if not isinstance(seq, torch.Tensor) else seq)
+        if seq_t.is_cuda:
+            return seq_t[:, :S].t().to(device=dev, dtype=torch.int32).contiguous()
+        # host labels: slice / transpose / cast on the host, ONE small H2D copy instead of three device ops
+        return seq_t[:, :S].t().to(torch.int32).contiguous().to(dev, non_blocking=True)
+
+    def prepare(self, video, clip, clip_mask, seq):
+        """Start the part of forward() that does not need the event context (packs, ctx2att over the video, token-side gate products) on
+        the library's second stream; call BEFORE launching the event encoder and pass the result to forward(prepared=...)."""
+        if self.training and self.ss_prob > 0.0:
+            raise NotImplementedError('scheduled sampling (ss_prob > 0) is never enabled by the reference and is not on the HIP path')
+        cv = self._clip_view(clip, clip_mask)
+        tokens = self._tokens(seq, cv.feats.device)
+        return EF.decoder_prepare(video, cv.feats, cv.ev_start, cv.ev_len, tokens, cv.max_len, cv.rows_disjoint, self.native_params())
+
+    def forward(self, video, event, clip, clip_mask, seq, drop=None, prepared=None):
         """Teacher-forced log-probs [N,S,V+1] (OldModel_NEW.py:98-130)."""
         if self.training and self.ss_prob > 0.0:
             raise NotImplementedError('scheduled sampling (ss_prob > 0) is never enabled by the reference and is not on the HIP path')
         cv = self._clip_view(clip, clip_mask)
-        S = n_decoder_steps(seq)
-        if S == 0:
-            raise ValueError('label tensor needs at least two columns')
-        dev = event.device
-        seq_t = torch.as_tensor(np.asarray(seq) if not isinstance(seq, torch.Tensor) else seq)
-        if seq_t.is_cuda:
-            tokens = seq_t[:, :S].t().to(device=dev, dtype=torch.int32).contiguous()      # [S,N] time-major
-        else:       # host labels: slice / transpose / cast on the host, ONE small H2D copy instead of three device ops
-            tokens = seq_t[:, :S].t().to(torch.int32).contiguous().to(dev, non_blocking=True)
+        tokens = prepared['tokens'] if prepared is not None else self._tokens(seq, event.device)
         if drop is None:
             drop = self.next_drop_state()
         arena = getattr(self, '_echr_arena_ref', None)
         sink = EF.GradSink(arena, self.native_params()) if arena is not None else None
         return EF.DecoderFunction.apply(video, event, cv.feats, cv.ev_start, cv.ev_len, tokens, cv.max_len, cv.rows_disjoint, drop, sink,
-                                        *self.native_params())
+                                        prepared, *self.native_params())
 
     def init_hidden(self, video, event, clip):
         """Zero initial state (h, c), each [3,N,H] (OldModel_NEW.py:72-78 with CG_init_feats_type = '')."""

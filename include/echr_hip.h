@@ -180,6 +180,7 @@ typedef struct {
     float* ws;
     /* output: log-probs [N,S,V1] */
     float* logp;
+    int32_t prepared;                          /* echr_decoder_fwd only: 1 = echr_decoder_fwd_prepare already ran on this workspace */
 } echr_dec_args;
 
 typedef struct {
@@ -220,6 +221,11 @@ int echr_stream_join(void* stream);
 int64_t echr_decoder_ws_floats(const echr_dec_args* a);
 int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a);
 int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream);
+/* The part of echr_decoder_fwd that does not read the event context (operand packs, P_all = ctx2att over the video rows, token
+ * embedding, the token-side gate pre-activations of all S*N rows): started on a library-owned second stream, forked from `stream`, so
+ * that it overlaps the event encoder (echr_event_pool_gather_fwd + echr_tsrm_fwd) the caller runs next on `stream`.  a->event may be
+ * NULL here.  The following echr_decoder_fwd call must pass the same workspace with a->prepared = 1; it joins the streams. */
+int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream);
 int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream);
 
 /* ONE decoder timestep with the recurrent state passed in and out: OldModel.get_logprobs_state (models/OldModel_NEW.py:133-137) =
