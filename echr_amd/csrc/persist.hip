@@ -69,7 +69,7 @@ static PersistLayout persist_layout(int S) {
     L.total = off;
     return L;
 }
-long persist_fwd_ws_floats(int S) { return persist_layout(S).total; }
+long persist_fwd_ws_floats(int S);
 
 struct PersistK {
     int N, A, D, S, ld_att;
@@ -619,6 +619,384 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
 
 
 // ==========================================================================================================================
+// Forward attention chain, version 2: TWO HALF-CHIP MACHINES.  Events never interact in the decoder, so rows [0,32) and [32,64) are
+// two independent recurrences: workgroups [0,96) serve the first half, [96,192) the second, each with a full copy of stream 1's
+// recurrent weights in LDS (64 gate workgroups of 8 hidden units = 32 columns, 16 q workgroups of 32 columns, 16 attention-only; all 96
+// hold the attention operands of the half's 32 events).  Against version 1 this halves what a workgroup ingests per hand-off (64 KB),
+// the fan-in of every counter and the rows per MFMA tile (v_mfma_f32_32x32x2_f32, still exact fp32), at twice the LDS per workgroup.
+// Exchange layout of every [32 rows x 512] operand: [k / 8][32 rows][8 floats]: a wave's fragment load (lane = row, k half) covers 1 KB
+// of contiguous memory, and a gate workgroup's 8 units are one contiguous 1-KB group.
+// ==========================================================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int HR = 32;                        // rows per half machine
+constexpr int HWG = 96, HG1 = 64, HQ = 16;    // workgroups per half: gate, q (the remaining 16 are attention-only)
+constexpr int LDS_W2 = 128 * 1024, LDS_RED2 = 16 * 1024 + 2048 + 512;
+constexpr int LDS_BYTES_ATT2 = LDS_W2 + LDS_RED2 + 256;
+
+struct PersistLayout2 { long cnt, xc, xs, gran, zero_end, xh1, xq, wu, total; };
+static PersistLayout2 persist_layout2(int S) {
+    PersistLayout2 L;
+    long off = 0;
+    auto take = [&](long n) { long o = off; off += (n + 63) / 64 * 64; return o; };
+    L.cnt = take((long)3 * (S + 1) * 2 * CNT_LINE);
+    L.xc = take((long)S * PROWS * PH);
+    L.xs = take((long)S * PROWS);
+    L.gran = take((long)S * PROWS * 3 * 2);
+    L.zero_end = off;
+    L.xh1 = take((long)S * PROWS * PH);
+    L.xq = take((long)S * PROWS * PH);
+    L.wu = take((long)S * PROWS * WU_LD);
+    L.total = off;
+    return L;
+}
+
+// A fragments of the wave's k range [128 w, 128 w + 128): lane (r = l & 31, kh = l >> 5), chunk c: float4 A[r][128 w + 8 c + 4 kh ..+3]
+__device__ __forceinline__ void load_afrag32(float4 (&a)[16], __amdgpu_buffer_rsrc_t rs, int w, int lane) {
+    const int r = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = ld16_sc1(rs, (u32)((((16 * w + c) * HR + r) * 8 + 4 * kh) * 4));
+}
+__device__ __forceinline__ void mfma_tile32(f32x16& acc, const float4 (&a)[16], const float4* bimg, int lane) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float4 b = bimg[c * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, b.w, acc, 0, 0, 0);
+    }
+}
+// the wave's partial [32 x 32] tile -> red[w][row][col]  (C/D map: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5))
+__device__ __forceinline__ void acc_to_lds32(const f32x16& acc, float* red, int w, int lane) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) red[(w * HR + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[g];
+}
+// B image of one 32-column tile, k-contiguous source: float4 index ((w * 16 + c) * 64 + lane) <- W[row_of(cc)][k..k+3], zero beyond K
+template <typename RowFn>
+__device__ __forceinline__ void fill_bimg32(float4* img, const float* W, long ld, int K, RowFn row_of, int tid) {
+    for (int idx = tid; idx < 4 * 16 * 64; idx += 256) {
+        const int lane = idx & 63, c = (idx >> 6) & 15, w = idx >> 10;
+        const int cc = lane & 31, kh = lane >> 5;
+        const int k = 128 * w + 8 * c + 4 * kh;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) v = *reinterpret_cast<const float4*>(W + (long)row_of(cc) * ld + k);
+        img[idx] = v;
+    }
+}
+
+long persist_fwd_ws_floats(int S) { return persist_layout(S).total + persist_layout2(S).total; }
+
+struct PersistK2 {
+    int N, A, D, S, ld_att;
+    const float* w_hh1; const float* w_h2a; const float* b_h2a; const float* w_att; const float* w_alpha;
+    const float* PALL; const float* c3d; const int* ev_start; const int* ev_len;
+    float* GATES1; float* CS1; float* HS; float* OUTD; float* QS; float* WT; float* ATT;
+    float *XH1, *XQ, *XC, *XS, *WU;
+    unsigned long long* GRAN;
+    u32* cnt; u32* abort_word; u32* host_flag;
+    unsigned long long* stamps;
+    DropCfg dh, dout;
+};
+
+__global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float4* wimg = reinterpret_cast<float4*>(lds);
+    float* red = reinterpret_cast<float*>(lds + LDS_W2);          // 16 KB: cross-wave tile sums / cross-row attention partials (8 rows per pass)
+    float* sal = red + 4096;                                      // [512] alpha
+    float* sx = sal + PH;                                         // small scratch
+    int* flag = reinterpret_cast<int*>(lds + LDS_W2 + LDS_RED2);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = b / HWG, lb = b - m * HWG;
+    const int N = P.N, D = P.D, S = P.S;
+    if (HR * m >= N) return;                                     // this half machine has no events
+    const bool is_g1 = lb < HG1, is_qw = lb >= HG1 && lb < HG1 + HQ;
+    auto cnt = [&](int kind, int t) { return P.cnt + (((long)kind * (S + 1) + t) * 2 + m) * CNT_LINE; };
+
+    if (is_g1) {
+        auto row = [&](int cc) { return (cc >> 3) * PH + 8 * lb + (cc & 7); };       // tile column cc = gate * 8 + unit
+        fill_bimg32(wimg, P.w_hh1, PH, PH, row, tid);
+        fill_bimg32(wimg + 4096, P.w_att, P.ld_att, D, row, tid);
+    } else if (is_qw) {
+        auto row = [&](int cc) { return 32 * (lb - HG1) + cc; };
+        fill_bimg32(wimg, P.w_h2a, PH, PH, row, tid);
+    }
+    // ---- attention operands -> registers (as version 1) ----
+    const int ar = lb / 3, ap = lb - 3 * ar, an = HR * m + ar;    // row within the half, third, event
+    const bool att_live = an < N;
+    const int grow_ = 4 * w + (lane >> 4), lr = lane & 15;
+    int alen = 0;
+    float4 Pr[PSG][8], Cr[PSG][8];
+    bool use_max = false;
+    {
+        float asum = 0.f;
+        for (int j = tid; j < PH; j += 256) { const float av = P.w_alpha[j]; sal[j] = av; asum += fabsf(av); }
+        asum = wave_sum(asum);
+        if (lane == 0) sx[w] = asum;
+        __syncthreads();
+        use_max = (sx[0] + sx[1] + sx[2] + sx[3]) > ALPHA_SAFE;
+        __syncthreads();
+    }
+    if (att_live) {
+        alen = P.ev_len[an];
+        const long row0 = P.ev_start[an];
+#pragma unroll
+        for (int i = 0; i < PSG; ++i) {
+            const int sl = grow_ + 16 * i;
+            const int a = min(PSL * ap + min(sl, PSL - 1), alen - 1);
+            const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
+            const float* cr = P.c3d + (row0 + a) * D;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const float4 pv = *reinterpret_cast<const float4*>(pr + 4 * h);
+                Pr[i][h] = make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
+                                       __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
+                const int d = 32 * lr + 4 * h;
+                float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
+                if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                Cr[i][h] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PSG; ++i)
+#pragma unroll
+            for (int h = 0; h < 8; ++h) Pr[i][h] = Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    const int gr = tid >> 3, gu = tid & 7, gn = HR * m + gr;      // gate-math ownership: thread (row gr of the half, unit gu)
+    float c1 = 0.f;
+    const u32 XBH = HR * PH * 4;                                  // bytes of one half's [32 x 512] exchange operand
+    const long XHALF = (long)HR * PH;                             // floats
+    const int srole = b == 0 ? 0 : (b == HG1 ? 1 : (b == HG1 + HQ ? 2 : -1));
+
+    for (int t = 0; t < S; ++t) {
+        if (srole >= 0) STAMP(srole, 0);
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+        float pre[4] = {0.f, 0.f, 0.f, 0.f};
+        float mh1 = 1.f, mo1 = 1.f;
+        if (is_g1) {
+            const float* grow = P.GATES1 + ((long)t * N + min(gn, N - 1)) * 4 * PH + 8 * lb + gu;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = grow[g * PH];
+            mh1 = mask_h(P.dh, gn, 8 * lb + gu, 1, t);
+            mo1 = mask_o(P.dout, gn, 8 * lb + gu, 1, t);
+        }
+        // ---- phase A: W_hh1 . h1(t-1) (gate workgroups) / q = W_h2a . h1(t-1) + b (q workgroups) ----
+        if ((is_g1 || is_qw) && t > 0) {
+            if (!wait_total(P, cnt(C_H1, t - 1), HG1, flag, 100000u + t)) return;
+            if (srole >= 0) STAMP(srole, 1);
+            float4 a[16];
+            load_afrag32(a, mk_rsrc(P.XH1 + ((long)(t - 1) * 2 + m) * XHALF, XBH), w, lane);
+            mfma_tile32(acc, a, wimg + w * 1024, lane);
+            if (srole >= 0) STAMP(srole, 2);
+        }
+        if (is_qw) {
+            const int cq = lb - HG1, c4 = 4 * gu;                 // thread: row gr, columns 32 cq + c4 .. +3
+            float4 qv = *reinterpret_cast<const float4*>(P.b_h2a + 32 * cq + c4);
+            if (t > 0) {
+                acc_to_lds32(acc, red, w, lane);
+                __syncthreads();
+                const float* rp = red + gr * 32 + c4;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const float4 v = *reinterpret_cast<const float4*>(rp + ww * HR * 32);
+                    qv.x += v.x; qv.y += v.y; qv.z += v.z; qv.w += v.w;
+                }
+            }
+            st16_sc1(mk_rsrc(P.XQ + ((long)t * 2 + m) * XHALF, XBH), (u32)((((4 * cq + (c4 >> 3)) * HR + gr) * 8 + (c4 & 7)) * 4), qv);
+            if (srole >= 0) STAMP(srole, 3);
+            publish(cnt(C_Q, t));
+            if (srole >= 0) STAMP(srole, 4);
+            if (gn < N) *reinterpret_cast<float4*>(P.QS + ((long)t * N + gn) * PH + 32 * cq + c4) = qv;
+        }
+        // ---- attention: scores, (split) softmax, context partial ----
+        {
+            if (!wait_total(P, cnt(C_Q, t), HQ, flag, 200000u + t)) return;
+            if (srole >= 0) STAMP(srole, 5);
+            if (att_live) {
+                const __amdgpu_buffer_rsrc_t rq = mk_rsrc(P.XQ + ((long)t * 2 + m) * XHALF, XBH);
+                float4 q[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h) q[h] = ld16_sc1(rq, (u32)((((4 * lr + (h >> 1)) * HR + ar) * 8 + 4 * (h & 1)) * 4));
+                float asum = 0.f;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    q[h] = make_float4(__expf(2.f * fminf(fmaxf(q[h].x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].y, -43.f), 43.f)),
+                                       __expf(2.f * fminf(fmaxf(q[h].z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].w, -43.f), 43.f)));
+                    const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
+                    asum += (a4.x + a4.y) + (a4.z + a4.w);
+                }
+                float e[PSG];
+#pragma unroll
+                for (int i = 0; i < PSG; ++i) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
+                        v += a4.x * __builtin_amdgcn_rcpf(fmaf(Pr[i][h].x, q[h].x, 1.f)) + a4.y * __builtin_amdgcn_rcpf(fmaf(Pr[i][h].y, q[h].y, 1.f)) +
+                             a4.z * __builtin_amdgcn_rcpf(fmaf(Pr[i][h].z, q[h].z, 1.f)) + a4.w * __builtin_amdgcn_rcpf(fmaf(Pr[i][h].w, q[h].w, 1.f));
+                    }
+                    v = row16_sum(fmaf(-2.f, v, asum));
+                    const int sl = grow_ + 16 * i;
+                    const bool valid = sl < PSL && PSL * ap + sl < alen;
+                    e[i] = valid ? v : -INFINITY;
+                }
+                float shift = 0.f;
+                if (use_max) {       // exact max-shifted softmax: the event's three workgroups exchange their local maxima (8-byte granules)
+                    const float mloc = fmaxf(e[0], fmaxf(e[1], e[2]));
+                    if (lr == 0) sx[16 + grow_] = mloc;
+                    __syncthreads();
+                    unsigned long long* gr_ = P.GRAN + ((long)t * PROWS + an) * 3;
+                    if (tid < 64) {
+                        float m16 = lane < 16 ? sx[16 + lane] : -INFINITY;
+                        m16 = wave_max(m16);
+                        if (lane == 0)
+                            __hip_atomic_store(gr_ + ap, ((unsigned long long)(t + 1) << 32) | __float_as_uint(m16), __ATOMIC_RELAXED, ECHR_AGENT);
+                        float mm = -INFINITY;
+                        u32 spins = 0;
+                        for (;;) {
+                            unsigned long long x = lane < 3 ? __hip_atomic_load(gr_ + lane, __ATOMIC_RELAXED, ECHR_AGENT) : ((unsigned long long)(t + 1) << 32) | 0xff800000u;
+                            const bool ok = (u32)(x >> 32) == (u32)(t + 1);
+                            if (__all(ok)) { mm = __uint_as_float((u32)x); break; }
+                            if ((++spins & 31) == 0 && (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, ECHR_AGENT) || spins > SPIN_LIMIT)) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        mm = wave_max(mm);
+                        if (lane == 0) sx[32] = mm;
+                    }
+                    __syncthreads();
+                    shift = sx[32];
+                    if (!(shift > -INFINITY)) shift = 0.f;
+                }
+                float ssum = 0.f;
+                float4 cx[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h) cx[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < PSG; ++i) {
+                    const float x = __expf(e[i] - shift);          // exp(-inf) = 0 for slots past the event's end
+                    e[i] = x;
+                    ssum += x;
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) {
+                        cx[h].x += x * Cr[i][h].x; cx[h].y += x * Cr[i][h].y; cx[h].z += x * Cr[i][h].z; cx[h].w += x * Cr[i][h].w;
+                    }
+                }
+                if (lr == 0) sx[grow_] = ssum;
+                {
+                    const float xw = lr == 0 ? e[0] : (lr == 1 ? e[1] : e[2]);
+                    const int sl = grow_ + 16 * lr;
+                    if (lr < PSG && sl < PSL && PSL * ap + sl < alen) st4_sc1(P.WU + ((long)t * PROWS + an) * WU_LD + PSL * ap + sl, xw);
+                }
+                // cross-row sum of the context partials through 16 KB of LDS: DPP rows 0-7, then rows 8-15
+                float csum[2] = {0.f, 0.f};
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    if ((grow_ >> 3) == pass) {
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) *reinterpret_cast<float4*>(red + (grow_ & 7) * PH + 32 * lr + 4 * h) = cx[h];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int d = tid + 256 * h;
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) csum[h] += red[g * PH + d];
+                    }
+                    __syncthreads();
+                }
+                float* xc = P.XC + ((long)t * 2 + m) * XHALF;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int d = tid + 256 * h;
+                    if (d < D) atomicAdd(xc + ((d >> 3) * HR + ar) * 8 + (d & 7), csum[h]);
+                }
+                if (tid == 0) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) sum += sx[g];
+                    atomicAdd(P.XS + (long)t * PROWS + an, sum);
+                }
+            }
+            if (srole >= 0) STAMP(srole, 6);
+            publish(cnt(C_C, t));
+            if (srole >= 0) STAMP(srole, 7);
+        }
+        // ---- phase C: attended-context columns + gate math; the new h1 goes to the next step ----
+        if (is_g1) {
+            if (!wait_total(P, cnt(C_C, t), HWG, flag, 300000u + t)) return;
+            if (srole >= 0) STAMP(srole, 8);
+            f32x16 accc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) accc[g] = 0.f;
+            float4 s4[4];
+            {
+                float4 a[16];
+                load_afrag32(a, mk_rsrc(P.XC + ((long)t * 2 + m) * XHALF, XBH), w, lane);
+                // sums of exponentials of the rows this lane's accumulator registers belong to (row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5))
+                const __amdgpu_buffer_rsrc_t rsum = mk_rsrc(P.XS + (long)t * PROWS + HR * m, HR * 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) s4[g] = ld16_sc1(rsum, (u32)((8 * g + 4 * (lane >> 5)) * 4));
+                mfma_tile32(accc, a, wimg + 4096 + w * 1024, lane);
+                // normalised context, saved for backward: this workgroup stores features [8 lb, 8 lb + 8) (wave lb / 16, chunk lb % 16)
+                if (8 * lb < D && w == (lb >> 4)) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (c == (lb & 15)) {
+                            const int n = HR * m + (lane & 31), d0 = 8 * lb + 4 * (lane >> 5);
+                            if (n < N && d0 < D) {
+                                const float is = 1.0f / ld4_sc1(P.XS + (long)t * PROWS + n);
+                                *reinterpret_cast<float4*>(P.ATT + ((long)t * N + n) * D + d0) =
+                                    make_float4(a[c].x * is, a[c].y * is, a[c].z * is, a[c].w * is);
+                            }
+                        }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[4 * g + 0] += accc[4 * g + 0] / s4[g].x; acc[4 * g + 1] += accc[4 * g + 1] / s4[g].y;
+                acc[4 * g + 2] += accc[4 * g + 2] / s4[g].z; acc[4 * g + 3] += accc[4 * g + 3] / s4[g].w;
+            }
+            if (srole >= 0) STAMP(srole, 9);
+            acc_to_lds32(acc, red, w, lane);
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int o = gr * 32 + 8 * g + gu;
+                pre[g] += red[o] + red[HR * 32 + o] + red[2 * HR * 32 + o] + red[3 * HR * 32 + o];
+            }
+            const CellOut co = lstm_cell(pre[0], pre[1], pre[2], pre[3], c1, mh1, mo1);
+            c1 = co.c;
+            st4_sc1(P.XH1 + ((long)t * 2 + m) * XHALF + (lb * HR + gr) * 8 + gu, co.h);
+            if (srole >= 0) STAMP(srole, 10);
+            publish(cnt(C_H1, t));          // (its barrier also protects `red` for the next step)
+            if (srole >= 0) STAMP(srole, 11);
+            if (gn < N) {
+                const int j = 8 * lb + gu;
+                float* go = P.GATES1 + ((long)t * N + gn) * 4 * PH + j;
+                go[0] = co.gi; go[PH] = co.gf; go[2 * PH] = co.gg; go[3 * PH] = co.go;
+                P.CS1[((long)(t + 1) * N + gn) * PH + j] = co.c;
+                const long o = ((long)gn * 3 + 1) * PH + j;
+                P.HS[(long)(t + 1) * N * 3 * PH + o] = co.h;
+                P.OUTD[(long)t * N * 3 * PH + o] = co.hd;
+            }
+            {   // normalised attention weights: rows of event lb / 2 of this half, slots [65 (lb & 1), +65)
+                const int n = HR * m + (lb >> 1), a0 = 65 * (lb & 1) + tid;
+                if (tid < 65 && n < N && a0 < P.A) {
+                    const int len = P.ev_len[n];
+                    float wv = 0.f;
+                    if (a0 < len) wv = ld4_sc1(P.WU + ((long)t * PROWS + n) * WU_LD + a0) / ld4_sc1(P.XS + (long)t * PROWS + n);
+                    P.WT[((long)t * N + n) * P.A + a0] = wv;
+                }
+            }
+        }
+    }
+}
+
+// ==========================================================================================================================
 // PERSISTENT REVERSE RECURRENCE (backward): all S timesteps of the three streams' BPTT in two concurrent launches.
 // Reference semantics: autograd of models/OldModel_NEW.py:801-823 (ThreeStream_Core.forward) and :376-401 (Attention.forward); the
 // launch-per-phase form is decoder.hip's bwd_step (four dependent launches per timestep).  Per reverse timestep the attention chain
@@ -1064,6 +1442,7 @@ static PersistHost& phost() {
         if (good) { h.flag_host[0] = 0; good = hipHostGetDevicePointer((void**)&h.flag_dev, h.flag_host, 0) == hipSuccess; }
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT2) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
         int lo = 0, hi = 0;
@@ -1127,14 +1506,32 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
         if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
-    if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_fwd: memset failed"); return -5; }
+    const bool split = config().persist_split != 0;
+    const PersistLayout2 L2 = persist_layout2(a->S);
+    float* x2 = x + L.total;
+    PersistK2 K2;
+    if (split) {
+        K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
+        K2.w_hh1 = a->w_hh[1]; K2.w_h2a = a->w_h2a; K2.b_h2a = a->b_h2a; K2.w_att = K.w_att; K2.w_alpha = a->w_alpha;
+        K2.PALL = B.PALL; K2.c3d = a->c3d; K2.ev_start = a->ev_start; K2.ev_len = a->ev_len;
+        K2.GATES1 = B.GATES[1]; K2.CS1 = B.CS[1]; K2.HS = B.HS; K2.OUTD = B.OUTD; K2.QS = B.QS; K2.WT = B.WT; K2.ATT = B.ATT;
+        K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XC = x2 + L2.xc; K2.XS = x2 + L2.xs; K2.GRAN = reinterpret_cast<unsigned long long*>(x2 + L2.gran);
+        K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu;
+        K2.abort_word = h.abort_dev; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = dh; K2.dout = dout;
+        // version 2 keeps its own zero region; of version 1's only the counters of the LSTM kernel are needed
+        if (hipMemsetAsync(x, 0, (size_t)(L.xc) * sizeof(float), st) != hipSuccess || hipMemsetAsync(x2, 0, (size_t)L2.zero_end * sizeof(float), st) != hipSuccess) {
+            set_error("persist_fwd: memset failed");
+            return -5;
+        }
+    } else if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_fwd: memset failed"); return -5; }
     ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), 0.0, st);
     // the two plain LSTM streams recur on a second HIP stream, concurrently with the attention chain (192 + 64 workgroups = 256 CUs;
     // neither kernel waits on the other, so any residency order makes progress)
     if (hipEventRecord(h.fork, st) != hipSuccess || hipStreamWaitEvent(h.side, h.fork, 0) != hipSuccess) { set_error("persist_fwd: fork failed"); return -5; }
     hipLaunchKernelGGL(dec_persist_lstm_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM, h.side, K);
     if (int rc = check_launch("dec_persist_lstm")) return rc;
-    hipLaunchKernelGGL(dec_persist_att_kernel, dim3(NATT), dim3(256), LDS_BYTES_ATT, st, K);
+    if (split) hipLaunchKernelGGL(dec_persist_att2_kernel, dim3(2 * HWG), dim3(256), LDS_BYTES_ATT2, st, K2);
+    else hipLaunchKernelGGL(dec_persist_att_kernel, dim3(NATT), dim3(256), LDS_BYTES_ATT, st, K);
     if (int rc = check_launch("dec_persist_att")) return rc;
     if (hipEventRecord(h.join, h.side) != hipSuccess || hipStreamWaitEvent(st, h.join, 0) != hipSuccess) { set_error("persist_fwd: join failed"); return -5; }
     return 0;

@@ -50,7 +50,7 @@ if BWD:
              3: ['step', 'waitG', 'mfma', 'gate', 'pub']}
     rl = ((0, 'GD wg 0'), (1, 'P wg 32'), (2, 'att wg 160'), (3, 'lstm-bwd wg 0'))
 else:
-    rl = ((0, 'gate wg 0'), (1, 'q wg 128'), (2, 'att wg 160'), (3, 'lstm wg 0'))
+    rl = ((0, 'gate wg'), (1, 'q wg'), (2, 'att-only wg'), (3, 'lstm wg 0'))
 for role, rn in rl:
     a = st[role]
     if BWD:
