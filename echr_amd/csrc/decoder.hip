@@ -338,11 +338,17 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long row0 = ev_start[n];
     float4 p[PSLOTS][R], a4[R], dal[R];
+    // 1 - tanh^2(p + q) = 4 r (1 - r), tanh(p + q) = 1 - 2 r with r = 1 / (e^{2p} e^{2q} + 1): e^{2p} once per row, e^{2q} once per staged q
+    // element -- one fma + rcp per (slot, feature, timestep) instead of an exp + rcp (arguments clamped to +-43: never inf * 0)
 #pragma unroll
     for (int i = 0; i < PSLOTS; ++i) {
         const int a = min(a0 + wave * PSLOTS + i, len - 1);
 #pragma unroll
-        for (int r = 0; r < R; ++r) p[i][r] = *reinterpret_cast<const float4*>(PALL + (row0 + a) * Ha + min(lane * 4 + r * 256, Ha - 4));
+        for (int r = 0; r < R; ++r) {
+            const float4 pv = *reinterpret_cast<const float4*>(PALL + (row0 + a) * Ha + min(lane * 4 + r * 256, Ha - 4));
+            p[i][r] = make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
+                                  __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -361,7 +367,10 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
         __syncthreads();
         for (int idx = threadIdx.x; idx < nt * (Ha >> 2); idx += 256) {
             const int tt = idx / (Ha >> 2), j4 = idx % (Ha >> 2);
-            *reinterpret_cast<float4*>(sqt + tt * Ha + 4 * j4) = *reinterpret_cast<const float4*>(QS + ((long)(t0 + tt) * N + n) * Ha + 4 * j4);
+            const float4 qv = *reinterpret_cast<const float4*>(QS + ((long)(t0 + tt) * N + n) * Ha + 4 * j4);
+            *reinterpret_cast<float4*>(sqt + tt * Ha + 4 * j4) =
+                make_float4(__expf(2.f * fminf(fmaxf(qv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(qv.y, -43.f), 43.f)),
+                            __expf(2.f * fminf(fmaxf(qv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(qv.w, -43.f), 43.f)));
         }
         for (int idx = threadIdx.x; idx < nt * 8; idx += 256) {
             const int tt = idx >> 3, i = idx & 7;
@@ -372,15 +381,15 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < PSLOTS; ++i) {
                 const float dsc = sds[tt * 8 + wave * PSLOTS + i];
-                if (lane == 0) dsum += dsc;
+                dsum += dsc;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float4 q4 = *reinterpret_cast<const float4*>(sqt + tt * Ha + min(lane * 4 + r * 256, Ha - 4));
-                    float t;
-                    t = fast_tanh(p[i][r].x + q4.x); dp[i][r].x += dsc * (1.f - t * t); dal[r].x += dsc * t;
-                    t = fast_tanh(p[i][r].y + q4.y); dp[i][r].y += dsc * (1.f - t * t); dal[r].y += dsc * t;
-                    t = fast_tanh(p[i][r].z + q4.z); dp[i][r].z += dsc * (1.f - t * t); dal[r].z += dsc * t;
-                    t = fast_tanh(p[i][r].w + q4.w); dp[i][r].w += dsc * (1.f - t * t); dal[r].w += dsc * t;
+                    float rr;          // dp accumulates dsc * r (1 - r) (x 4 at the end); dal accumulates dsc * r (tanh = 1 - 2 r, fixed up at the end)
+                    rr = __builtin_amdgcn_rcpf(fmaf(p[i][r].x, q4.x, 1.f)); dp[i][r].x = fmaf(dsc, rr - rr * rr, dp[i][r].x); dal[r].x = fmaf(dsc, rr, dal[r].x);
+                    rr = __builtin_amdgcn_rcpf(fmaf(p[i][r].y, q4.y, 1.f)); dp[i][r].y = fmaf(dsc, rr - rr * rr, dp[i][r].y); dal[r].y = fmaf(dsc, rr, dal[r].y);
+                    rr = __builtin_amdgcn_rcpf(fmaf(p[i][r].z, q4.z, 1.f)); dp[i][r].z = fmaf(dsc, rr - rr * rr, dp[i][r].z); dal[r].z = fmaf(dsc, rr, dal[r].z);
+                    rr = __builtin_amdgcn_rcpf(fmaf(p[i][r].w, q4.w, 1.f)); dp[i][r].w = fmaf(dsc, rr - rr * rr, dp[i][r].w); dal[r].w = fmaf(dsc, rr, dal[r].w);
                 }
             }
         }
@@ -394,13 +403,14 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
             for (int r = 0; r < R; ++r) {
                 const int j = lane * 4 + r * 256;
                 if (j < Ha) {
+                    const float4 dv = make_float4(4.f * dp[i][r].x * a4[r].x, 4.f * dp[i][r].y * a4[r].y, 4.f * dp[i][r].z * a4[r].z, 4.f * dp[i][r].w * a4[r].w);
                     if (disjoint) {      // the row belongs to this event alone: plain 16-byte store
-                        *reinterpret_cast<float4*>(drow + j) = make_float4(dp[i][r].x * a4[r].x, dp[i][r].y * a4[r].y, dp[i][r].z * a4[r].z, dp[i][r].w * a4[r].w);
+                        *reinterpret_cast<float4*>(drow + j) = dv;
                     } else {
-                        atomicAdd(drow + j + 0, dp[i][r].x * a4[r].x);
-                        atomicAdd(drow + j + 1, dp[i][r].y * a4[r].y);
-                        atomicAdd(drow + j + 2, dp[i][r].z * a4[r].z);
-                        atomicAdd(drow + j + 3, dp[i][r].w * a4[r].w);
+                        atomicAdd(drow + j + 0, dv.x);
+                        atomicAdd(drow + j + 1, dv.y);
+                        atomicAdd(drow + j + 2, dv.z);
+                        atomicAdd(drow + j + 3, dv.w);
                     }
                 }
             }
@@ -410,7 +420,8 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int j = lane * 4 + r * 256;
-        if (j < Ha) *reinterpret_cast<float4*>(red + wave * Ha + j) = dal[r];
+        // sum dsc * tanh = sum dsc * (1 - 2 r) = dsum - 2 * (sum dsc * r)
+        if (j < Ha) *reinterpret_cast<float4*>(red + wave * Ha + j) = make_float4(dsum - 2.f * dal[r].x, dsum - 2.f * dal[r].y, dsum - 2.f * dal[r].z, dsum - 2.f * dal[r].w);
     }
     __syncthreads();
     for (int j = threadIdx.x; j < Ha; j += 256)
