@@ -891,7 +891,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
                     const int sl = grow_ + 16 * lr;
                     if (lr < PSG && sl < PSL && PSL * ap + sl < alen) st4_sc1(P.WU + ((long)t * PROWS + an) * WU_LD + PSL * ap + sl, xw);
                 }
-                // cross-row sum of the context partials through 16 KB of LDS: DPP rows 0-7, then rows 8-15
+                // cross-row sum of the context partials through 16 KB of LDS: DPP rows 0-7, then rows 8-15 (LDS float atomics into one
+                // vector were tried: 4-way same-address ds_add_f32 made this phase 3x slower)
                 float csum[2] = {0.f, 0.f};
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
@@ -1030,7 +1031,7 @@ static PersistLayoutB persist_layout_b(int S) {
     L.total = off;
     return L;
 }
-long persist_bwd_ws_floats(int S) { return persist_layout_b(S).total; }
+long persist_bwd_ws_floats(int S);
 
 struct PersistB {
     int N, A, D, S, ld_att;
@@ -1426,6 +1427,285 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
     }
 }
 
+
+// ==========================================================================================================================
+// Reverse attention chain, version 2: two half-chip machines of 32 rows (see the forward version 2).  Per half: 16 gate-gradient
+// workgroups of 32 hidden units, 64 product workgroups (16 column tiles of 32 x 4 k-slices of 512 gate columns, two 64-KB images each:
+// W_ih1[:, E:]^T and W_hh1^T), 16 attention-only; all 96 hold the attention operands of the half's 32 events.
+// ==========================================================================================================================
+constexpr int HGD = 16, HP = 64;
+constexpr int LDS_REDB2 = 16 * 1024 + 2048 + 2048 + 512;
+constexpr int LDS_BYTES_ATTB2 = LDS_W2 + LDS_REDB2 + 256;
+constexpr long XSTEPH = 4L * HR * PH;          // floats of one half's [4 gates][32 rows x 512] exchange operand
+
+struct PersistLayoutB2 { long cnt, xdq, xda, xdh, zero_end, xdg, total; };
+static PersistLayoutB2 persist_layout_b2(int S);
+long persist_bwd_ws_floats(int S) { return persist_layout_b(S).total + persist_layout_b2(S).total; }
+static PersistLayoutB2 persist_layout_b2(int S) {
+    PersistLayoutB2 L;
+    long off = 0;
+    auto take = [&](long n) { long o = off; off += (n + 63) / 64 * 64; return o; };
+    L.cnt = take((long)4 * (S + 1) * 2 * CNT_LINE);
+    L.xdq = take((long)S * PROWS * PH);
+    L.xda = take((long)S * PROWS * PH);
+    L.xdh = take((long)S * PROWS * PH);
+    L.zero_end = off;
+    L.xdg = take((long)S * 2 * XSTEPH);
+    L.total = off;
+    return L;
+}
+
+// B image of one 32-column tile whose source is k-strided: element (k, cc) = W[k * ld_k + cc] for k < K, cc < ncols; zero elsewhere
+__device__ __forceinline__ void fill_bimg32_t(float4* img, const float* W, long ld_k, int K, int ncols, int tid) {
+    for (int idx = tid; idx < 4 * 16 * 64; idx += 256) {
+        const int lane = idx & 63, c = (idx >> 6) & 15, w = idx >> 10;
+        const int cc = lane & 31, kh = lane >> 5;
+        const int k = 128 * w + 8 * c + 4 * kh;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (k + j < K && cc < ncols) ? W[(long)(k + j) * ld_k + cc] : 0.f;
+        img[idx] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void dec_persist_att_bwd2_kernel(PersistB P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float4* wimg = reinterpret_cast<float4*>(lds);
+    float* red = reinterpret_cast<float*>(lds + LDS_W2);          // 16 KB
+    float* sal = red + 4096;                                      // [512] alpha
+    float* sat = sal + PH;                                        // [512] saved context row of the current step
+    int* flag = reinterpret_cast<int*>(lds + LDS_W2 + LDS_REDB2);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = b / HWG, lb = b - m * HWG;
+    const int N = P.N, D = P.D, S = P.S;
+    if (HR * m >= N) return;
+    const bool is_gd = lb < HGD, is_p = lb >= HGD && lb < HGD + HP;
+    auto cnt = [&](int kind, int t) { return P.cnt + (((long)kind * (S + 1) + t) * 2 + m) * CNT_LINE; };
+    const int pct = (lb - HGD) & 15, pks = (lb - HGD) >> 4;       // product role: 32-column tile, k-slice (= gate)
+    if (is_gd) {
+        fill_bimg32_t(wimg, P.w_h2a + 32 * lb, PH, PH, 32, tid);                      // d h1[:, u] += sum_j d q[:, j] W_h2a[j, u]
+    } else if (is_p) {
+        fill_bimg32_t(wimg, P.w_att + (long)pks * PH * P.ld_att + 32 * pct, P.ld_att, PH, max(0, min(32, D - 32 * pct)), tid);
+        fill_bimg32_t(wimg + 4096, P.w_hh[1] + (long)pks * PH * PH + 32 * pct, PH, PH, 32, tid);
+    }
+    const int ar = lb / 3, ap = lb - 3 * ar, an = HR * m + ar;
+    const bool att_live = an < N;
+    const int grow_ = 4 * w + (lane >> 4), lr = lane & 15;
+    int alen = 0;
+    float4 Pr[PSG][8], Cr[PSG][8];
+    for (int j = tid; j < PH; j += 256) sal[j] = P.w_alpha[j];
+    if (att_live) {
+        alen = P.ev_len[an];
+        const long row0 = P.ev_start[an];
+#pragma unroll
+        for (int i = 0; i < PSG; ++i) {
+            const int sl = grow_ + 16 * i;
+            const int a = min(PSL * ap + min(sl, PSL - 1), alen - 1);
+            const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
+            const float* cr = P.c3d + (row0 + a) * D;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const float4 pv = *reinterpret_cast<const float4*>(pr + 4 * h);
+                Pr[i][h] = make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
+                                       __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
+                const int d = 32 * lr + 4 * h;
+                float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
+                if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                Cr[i][h] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PSG; ++i)
+#pragma unroll
+            for (int h = 0; h < 8; ++h) Pr[i][h] = Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    const int gr = tid >> 3, u4 = 4 * (tid & 7), gn = HR * m + gr, u0 = 32 * lb + u4;      // gate-gradient ownership (GD): row, 4 units
+    float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const u32 XBH = HR * PH * 4;
+    const long XHALF = (long)HR * PH;
+    const int srole = b == 0 ? 0 : (b == HGD ? 1 : (b == HGD + HP ? 2 : -1));
+
+    for (int t = S - 1; t >= -1; --t) {
+        if (srole >= 0) BSTAMP(srole, 0);
+        // ============ GD: d h1(t) -> d G1(t); at t = -1 only d q(0) is copied out ============
+        if (is_gd) {
+            GradIn in;
+            DropM dm;
+            if (t >= 0) { in = load_grad_in(P, 1, t, gn, u0); dm = drop_masks4(P, 1, t, gn, u0); }
+            float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < S - 1 && t >= 0) {
+                if (!wait_total(P, cnt(CB_HH, t + 1), HP, flag, 500000u + t + 1)) return;
+                rec = ld16_sc1(mk_rsrc(P.XDH + ((long)(t + 1) * 2 + m) * XHALF, XBH), (u32)((((4 * lb + (u4 >> 3)) * HR + gr) * 8 + (u4 & 7)) * 4));
+            }
+            if (t < S - 1) {
+                if (!wait_total(P, cnt(CB_DQ, t + 1), HWG, flag, 400000u + t + 1)) return;
+                if (srole >= 0) BSTAMP(srole, 1);
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+                {
+                    float4 a[16];
+                    load_afrag32(a, mk_rsrc(P.XDQ + ((long)(t + 1) * 2 + m) * XHALF, XBH), w, lane);
+                    if (t >= 0) mfma_tile32(acc, a, wimg + w * 1024, lane);
+                    // d q(t+1) row-major for the weight-gradient products: this workgroup stores columns [32 lb, 32 lb + 32)
+                    if (w == (lb >> 2)) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c)
+                            if ((c >> 2) == (lb & 3)) {
+                                const int n = HR * m + (lane & 31);
+                                if (n < N) *reinterpret_cast<float4*>(P.DQ + ((long)(t + 1) * N + n) * PH + 128 * w + 8 * c + 4 * (lane >> 5)) = a[c];
+                            }
+                    }
+                }
+                if (t >= 0) {
+                    acc_to_lds32(acc, red, w, lane);
+                    __syncthreads();
+                    const float* rp = red + gr * 32 + u4;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) rec = f4add(rec, *reinterpret_cast<const float4*>(rp + ww * HR * 32));
+                    if (srole >= 0) BSTAMP(srole, 2);
+                    if (srole >= 0) BSTAMP(srole, 3);
+                }
+            }
+            if (t >= 0) {
+                const CellGrad cgd = cell_grad4(P, in, dm, rec, dc);
+                dc = cgd.dc;
+                // exchange layout of this half: [gate][unit / 8][32 rows][8]
+                const __amdgpu_buffer_rsrc_t rx = mk_rsrc(P.XDG + ((long)t * 2 + m) * XSTEPH, (u32)(XSTEPH * 4));
+#pragma unroll
+                for (int g = 0; g < 4; ++g) st16_sc1(rx, (u32)((((g * 64 + 4 * lb + (u4 >> 3)) * HR + gr) * 8 + (u4 & 7)) * 4), cgd.dg[g]);
+                if (srole >= 0) BSTAMP(srole, 4);
+                publish(cnt(CB_DG, t));
+                if (srole >= 0) BSTAMP(srole, 5);
+                if (gn < N) {
+                    float* dgp = P.DG[1] + ((long)t * N + gn) * 4 * PH + u0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dgp + g * PH) = cgd.dg[g];
+                }
+            }
+        }
+        if (t < 0) break;
+        // ============ P: d ATT(t) tile (critical), then the d h1 tile for step t-1; the four k-slices add atomically ============
+        if (is_p) {
+            if (!wait_total(P, cnt(CB_DG, t), HGD, flag, 600000u + t)) return;
+            if (srole >= 0) BSTAMP(srole, 6);
+            float4 a[16];
+            load_afrag32(a, mk_rsrc(P.XDG + ((long)t * 2 + m) * XSTEPH + (long)pks * XHALF, XBH), w, lane);
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                if (which == 1 && t == 0) break;
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+                mfma_tile32(acc, a, wimg + which * 4096 + w * 1024, lane);
+                acc_to_lds32(acc, red, w, lane);
+                __syncthreads();
+                // element e of the tile in exchange order ([k8 of the tile][row][8]) is contiguous over the lanes: full-rate atomics
+                float* xo = (which == 0 ? P.XDA : P.XDH) + ((long)t * 2 + m) * XHALF + (long)4 * pct * HR * 8;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = tid + 256 * e4, k8l = e >> 8, r = (e >> 3) & 31, cc = 8 * k8l + (e & 7), o = r * 32 + cc;
+                    atomicAdd(xo + e, red[o] + red[HR * 32 + o] + red[2 * HR * 32 + o] + red[3 * HR * 32 + o]);
+                }
+                if (which == 0 && srole >= 0) BSTAMP(srole, 7);
+                publish(cnt(which == 0 ? CB_DA : CB_HH, t));
+                if (srole >= 0) BSTAMP(srole, which == 0 ? 8 : 9);
+            }
+        }
+        // ============ attention backward of step t (all workgroups) ============
+        {
+            float4 q[8];
+            float wt[PSG];
+            if (att_live) {
+                const float* qp = P.QS + ((long)t * N + an) * PH + 32 * lr;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) q[h] = *reinterpret_cast<const float4*>(qp + 4 * h);
+#pragma unroll
+                for (int i = 0; i < PSG; ++i) {
+                    const int sl = grow_ + 16 * i;
+                    const bool valid = sl < PSL && PSL * ap + sl < alen;
+                    wt[i] = valid ? P.WT[((long)t * N + an) * P.A + PSL * ap + sl] : 0.f;
+                }
+                for (int d = tid; d < PH; d += 256) sat[d] = d < D ? P.ATT[((long)t * N + an) * D + d] : 0.f;
+            }
+            if (!wait_total(P, cnt(CB_DA, t), HP, flag, 700000u + t)) return;
+            if (srole >= 0) BSTAMP(srole, 10);
+            if (att_live) {
+                const __amdgpu_buffer_rsrc_t ra = mk_rsrc(P.XDA + ((long)t * 2 + m) * XHALF, XBH);
+                float4 da[8];
+                float s0 = 0.f;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) da[h] = ld16_sc1(ra, (u32)((((4 * lr + (h >> 1)) * HR + ar) * 8 + 4 * (h & 1)) * 4));
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const float4 at = *reinterpret_cast<const float4*>(sat + 32 * lr + 4 * h);
+                    s0 += at.x * da[h].x + at.y * da[h].y + at.z * da[h].z + at.w * da[h].w;
+                }
+                s0 = row16_sum(s0);
+                float dsc[PSG];
+#pragma unroll
+                for (int i = 0; i < PSG; ++i) {
+                    float dw = 0.f;
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) dw += Cr[i][h].x * da[h].x + Cr[i][h].y * da[h].y + Cr[i][h].z * da[h].z + Cr[i][h].w * da[h].w;
+                    dw = row16_sum(dw);
+                    dsc[i] = wt[i] * (dw - s0);
+                }
+                {
+                    const float xw = lr == 0 ? dsc[0] : (lr == 1 ? dsc[1] : dsc[2]);
+                    const int sl = grow_ + 16 * lr;
+                    if (lr < PSG && sl < PSL && PSL * ap + sl < alen) P.DSC[((long)t * N + an) * P.A + PSL * ap + sl] = xw;
+                }
+                // d q partial of this DPP row (in place of q), then summed over the 16 rows through 16 KB of LDS: rows 0-7, then rows 8-15
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const float4 eq = make_float4(__expf(2.f * fminf(fmaxf(q[h].x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].y, -43.f), 43.f)),
+                                                  __expf(2.f * fminf(fmaxf(q[h].z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].w, -43.f), 43.f)));
+                    float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < PSG; ++i) {
+                        float r;
+                        r = __builtin_amdgcn_rcpf(fmaf(Pr[i][h].x, eq.x, 1.f)); sacc.x += dsc[i] * (r - r * r);
+                        r = __builtin_amdgcn_rcpf(fmaf(Pr[i][h].y, eq.y, 1.f)); sacc.y += dsc[i] * (r - r * r);
+                        r = __builtin_amdgcn_rcpf(fmaf(Pr[i][h].z, eq.z, 1.f)); sacc.z += dsc[i] * (r - r * r);
+                        r = __builtin_amdgcn_rcpf(fmaf(Pr[i][h].w, eq.w, 1.f)); sacc.w += dsc[i] * (r - r * r);
+                    }
+                    const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
+                    q[h] = make_float4(4.f * a4.x * sacc.x, 4.f * a4.y * sacc.y, 4.f * a4.z * sacc.z, 4.f * a4.w * sacc.w);
+                }
+                float qsum[2] = {0.f, 0.f};
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    if ((grow_ >> 3) == pass) {
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) *reinterpret_cast<float4*>(red + (grow_ & 7) * PH + 32 * lr + 4 * h) = q[h];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = tid + 256 * h;
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) qsum[h] += red[g * PH + j];
+                    }
+                    __syncthreads();
+                }
+                float* xq = P.XDQ + ((long)t * 2 + m) * XHALF;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = tid + 256 * h;
+                    atomicAdd(xq + ((j >> 3) * HR + ar) * 8 + (j & 7), qsum[h]);
+                }
+            }
+            if (srole >= 0) BSTAMP(srole, 11);
+            publish(cnt(CB_DQ, t));
+            if (srole >= 0) BSTAMP(srole, 12);
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------------
 struct PersistHost { u32* abort_dev = nullptr; u32* flag_host = nullptr; u32* flag_dev = nullptr; int cus = 0; bool ok = false; bool init = false; unsigned long long* stamps = nullptr; int stamps_S = 0;
                      hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
@@ -1443,6 +1723,7 @@ static PersistHost& phost() {
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT2) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATTB2) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
         int lo = 0, hi = 0;
@@ -1560,12 +1841,24 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
         if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
-    if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_bwd: memset failed"); return -5; }
+    const bool split = config().persist_split != 0;
+    PersistB K2 = K;
+    if (split) {
+        const PersistLayoutB2 L2 = persist_layout_b2(a->S);
+        float* x2 = x + L.total;
+        K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XDQ = x2 + L2.xdq; K2.XDA = x2 + L2.xda; K2.XDH = x2 + L2.xdh; K2.XDG = x2 + L2.xdg;
+        // version 2 keeps its own zero region; of version 1's only the counters (LSTM kernel) are needed
+        if (hipMemsetAsync(x, 0, (size_t)L.xdq * sizeof(float), st) != hipSuccess || hipMemsetAsync(x2, 0, (size_t)L2.zero_end * sizeof(float), st) != hipSuccess) {
+            set_error("persist_bwd: memset failed");
+            return -5;
+        }
+    } else if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_bwd: memset failed"); return -5; }
     ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), 0.0, st);
     if (hipEventRecord(h.fork, st) != hipSuccess || hipStreamWaitEvent(h.side, h.fork, 0) != hipSuccess) { set_error("persist_bwd: fork failed"); return -5; }
     hipLaunchKernelGGL(dec_persist_lstm_bwd_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM, h.side, K);
     if (int rc = check_launch("dec_persist_lstm_bwd")) return rc;
-    hipLaunchKernelGGL(dec_persist_att_bwd_kernel, dim3(NATT), dim3(256), LDS_BYTES_ATT, st, K);
+    if (split) hipLaunchKernelGGL(dec_persist_att_bwd2_kernel, dim3(2 * HWG), dim3(256), LDS_BYTES_ATTB2, st, K2);
+    else hipLaunchKernelGGL(dec_persist_att_bwd_kernel, dim3(NATT), dim3(256), LDS_BYTES_ATT, st, K);
     if (int rc = check_launch("dec_persist_att_bwd")) return rc;
     if (hipEventRecord(h.join, h.side) != hipSuccess || hipStreamWaitEvent(st, h.join, 0) != hipSuccess) { set_error("persist_bwd: join failed"); return -5; }
     return 0;
