@@ -998,6 +998,199 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
 }
 
 // ==========================================================================================================================
+// fp16-PAIR ("h2") products inside the persistent forward kernels.  The recurrent activations are bounded (|h| <= dropout scale), so
+// h is exchanged as two fp16 planes hi = fp16(h * 2^12), lo = fp16(h * 2^12 - hi) (22+ significant bits, no value ever held unscaled),
+// the weight columns live in LDS as two fp16 planes with one power-of-two scale per output column, and a product is three
+// v_mfma_f32_32x32x16_f16 (hi.hi' + hi.lo' + lo.hi', each exact in the fp32 accumulator; the dropped lo.lo' is < 2^-22 of a term) --
+// the same operand format as gemm.hip's h2 GEMM with the scale block stretched over the whole contraction.  16x the MFMA rate of the
+// f32 forms at 3 products: the plain LSTM streams' 8 us of MFMA time per step becomes 1.5 us.
+// ==========================================================================================================================
+typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
+constexpr float H2_SA = 4096.f, H2_INV_SA = 1.f / 4096.f;          // activation scale 2^12 (|h| < 16 keeps hi finite)
+
+__device__ __forceinline__ void split_h2(float x, unsigned short& hi, unsigned short& lo) {
+    const _Float16 h1 = (_Float16)x;
+    const _Float16 h2 = (_Float16)(x - (float)h1);
+    hi = __builtin_bit_cast(unsigned short, h1);
+    lo = __builtin_bit_cast(unsigned short, h2);
+}
+__device__ __forceinline__ f16x8p as_f16x8(float4 v) { return __builtin_bit_cast(f16x8p, v); }
+
+// B planes of `ncb` 32-column blocks over K = 512 for one workgroup: image float4 index ((((w * 8 + s) * ncb + cb) * 2 + plane) * 64 + lane),
+// lane = (col & 31) + 32 * kh holds W[row_of(32 cb + col)][128 w + 16 s + 8 kh + j], j < 8, times the column's scale 2^(14 - e).
+// inv_scale[col] receives 2^(e - 14).  scratch: ncb * 32 floats of LDS for the column scales.
+template <typename RowFn>
+__device__ __forceinline__ void fill_bimg_h2(float4* img, float* inv_scale, float* scratch, const float* W, long ld, int K, int ncb, RowFn row_of, int tid) {
+    const int ncol = 32 * ncb;
+    // column maxima: 4 threads per column, 128 k each
+    for (int c0 = 0; c0 < ncol; c0 += 64) {
+        const int col = c0 + (tid >> 2), qk = tid & 3;
+        float mx = 0.f;
+        if (col < ncol) {
+            const float* wp = W + (long)row_of(col) * ld;
+            for (int k = 128 * qk; k < min(128 * qk + 128, K); k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(wp + k);
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        if (col < ncol && qk == 0) {
+            const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
+            int e = (ex == 0 || ex == 255) ? 14 : ex - 127;
+            e = max(e, 14 - 126);
+            scratch[col] = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+            inv_scale[col] = ldexpf(1.f, e - 14);
+        }
+    }
+    __syncthreads();
+    const int total = 4 * 8 * ncb * 64;          // (w, s, cb, lane); both planes are produced together
+    for (int idx = tid; idx < total; idx += 256) {
+        const int lane = idx & 63, cb = (idx >> 6) % ncb, s_ = ((idx >> 6) / ncb) & 7, w = (idx >> 6) / ncb / 8;
+        const int col = 32 * cb + (lane & 31), k = 128 * w + 16 * s_ + 8 * (lane >> 5);
+        const float sc = scratch[col];
+        const float* wp = W + (long)row_of(col) * ld + k;
+        unsigned hw[8], lw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned short hi, lo;
+            split_h2((k + j < K ? wp[j] : 0.f) * sc, hi, lo);
+            hw[j] = hi; lw[j] = lo;
+        }
+        const long base = (((long)(w * 8 + s_) * ncb + cb) * 2) * 64 + lane;
+        reinterpret_cast<uint4*>(img)[base] = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+        reinterpret_cast<uint4*>(img)[base + 64] = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
+    }
+    __syncthreads();
+}
+
+// ---- the two plain LSTM streams, h2 products: 64 rows x 64 gate columns (16 units) per workgroup ----
+// h exchange layout (per timestep, 128 KB): [plane 2][k / 8 (64)][row 64][8 halves]
+__global__ __launch_bounds__(256, 1) void dec_persist_lstm_h2_kernel(PersistK P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float4* wimg = reinterpret_cast<float4*>(lds);                    // 128 KB
+    float* red = reinterpret_cast<float*>(lds + LDS_W);               // 16 KB: [4 waves][32][32] tile partials / staging of the exchanged h
+    float* invb = red + 4096;                                         // [64] inverse column scales
+    float* scr = invb + 64;                                           // [64] scratch
+    int* flag = reinterpret_cast<int*>(lds + LDS_W + LDS_RED + 1024);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_s0 = b < NS;
+    const int N = P.N, S = P.S;
+    const int k = is_s0 ? 0 : 2, bs = is_s0 ? b : b - NS, ck = is_s0 ? C_H0 : C_H2;
+    float* XH = is_s0 ? P.XH0 : P.XH2;
+    auto cnt = [&](int kind, int t) { return P.cnt + ((long)kind * (S + 1) + t) * CNT_LINE; };
+    {   // column 32 cb + g * 8 + u8  <->  gate g of unit 16 bs + 8 cb + u8
+        auto row = [&](int col) { return ((col >> 3) & 3) * PH + 16 * bs + 8 * (col >> 5) + (col & 7); };
+        fill_bimg_h2(wimg, invb, scr, P.w_hh[k], PH, PH, 2, row, tid);
+    }
+    // gate-math ownership in round (rb, cb): thread -> (row 32 rb + (tid >> 3), unit 16 bs + 8 cb + (tid & 7))
+    const int gr = tid >> 3, g8 = tid & 7;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const u32 XB = PROWS * PH * 4;
+    const bool st_on = b == 0;
+    for (int t = 0; t < S; ++t) {
+        if (st_on) STAMP(3, 0);
+        float pre[4][4], mh[4], mo[4];
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+            const int n = 32 * (rd >> 1) + gr, j = 16 * bs + 8 * (rd & 1) + g8;
+            const float* grow = P.GATES[k] + ((long)t * N + min(n, N - 1)) * 4 * PH + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[rd][g] = grow[g * PH];
+            mh[rd] = mask_h(P.dh, n, j, k, t);
+            mo[rd] = mask_o(P.dout, n, j, k, t);
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[rb][cb][g] = 0.f;
+        if (t > 0) {
+            if (!wait_total(P, cnt(ck, t - 1), NS, flag, 1000u * (ck + 1) + t)) return;
+            if (st_on) STAMP(3, 1);
+            // A fragments: lane (r = l & 31, kh = l >> 5): 8 halves of row 32 rb + r at k = 128 w + 16 s + 8 kh
+            const __amdgpu_buffer_rsrc_t ra = mk_rsrc(XH + (long)(t - 1) * PROWS * PH, XB);
+            float4 a[8][2][2];          // [k step][row block][plane]
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        a[s_][rb][pl] = ld16_sc1(ra, (u32)((((pl * 64 + 16 * w + 2 * s_ + (lane >> 5)) * PROWS) + 32 * rb + (lane & 31)) * 16));
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_) {
+                const float4* bp = wimg + ((long)(w * 8 + s_) * 2) * 2 * 64 + lane;
+                f16x8p bh[2], bl[2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) { bh[cb] = as_f16x8(bp[(cb * 2) * 64]); bl[cb] = as_f16x8(bp[(cb * 2 + 1) * 64]); }
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const f16x8p ah = as_f16x8(a[s_][rb][0]), al = as_f16x8(a[s_][rb][1]);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cb], acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[cb], acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cb], acc[rb][cb], 0, 0, 0);
+                    }
+                }
+            }
+            if (st_on) STAMP(3, 2);
+        }
+        CellOut co[4];
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+            const int rb = rd >> 1, cb = rd & 1;
+            if (t > 0) {
+                acc_to_lds32(acc[rb][cb], red, w, lane);
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int o = gr * 32 + 8 * g + g8;
+                    pre[rd][g] += (red[o] + red[HR * 32 + o] + red[2 * HR * 32 + o] + red[3 * HR * 32 + o]) * (H2_INV_SA * invb[32 * cb + 8 * g + g8]);
+                }
+                __syncthreads();
+            }
+            co[rd] = lstm_cell(pre[rd][0], pre[rd][1], pre[rd][2], pre[rd][3], cs[rd], mh[rd], mo[rd]);
+            cs[rd] = co[rd].c;
+        }
+        // new h as fp16 planes: staged in LDS as [plane][cb][row 64][8 halves], then one 16-byte write-through store per thread
+        {
+            unsigned short* sh = reinterpret_cast<unsigned short*>(red);
+#pragma unroll
+            for (int rd = 0; rd < 4; ++rd) {
+                unsigned short hi, lo;
+                split_h2(co[rd].h * H2_SA, hi, lo);
+                const int row = 32 * (rd >> 1) + gr, cb = rd & 1;
+                sh[((0 * 2 + cb) * 64 + row) * 8 + g8] = hi;
+                sh[((1 * 2 + cb) * 64 + row) * 8 + g8] = lo;
+            }
+            __syncthreads();
+            const int pl = tid >> 7, cb = (tid >> 6) & 1, row = tid & 63;
+            const float4 v = reinterpret_cast<const float4*>(red)[(pl * 2 + cb) * 64 + row];
+            st16_sc1(mk_rsrc(XH + (long)t * PROWS * PH, XB), (u32)((((pl * 64 + 2 * bs + cb) * PROWS) + row) * 16), v);
+        }
+        if (st_on) STAMP(3, 3);
+        publish(cnt(ck, t));
+        if (st_on) STAMP(3, 4);
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {          // saved activations, off the critical path
+            const int n = 32 * (rd >> 1) + gr, j = 16 * bs + 8 * (rd & 1) + g8;
+            if (n < N) {
+                float* go = P.GATES[k] + ((long)t * N + n) * 4 * PH + j;
+                go[0] = co[rd].gi; go[PH] = co[rd].gf; go[2 * PH] = co[rd].gg; go[3 * PH] = co[rd].go;
+                P.CS[k][((long)(t + 1) * N + n) * PH + j] = co[rd].c;
+                const long o = ((long)n * 3 + k) * PH + j;
+                P.HS[(long)(t + 1) * N * 3 * PH + o] = co[rd].h;
+                P.OUTD[(long)t * N * 3 * PH + o] = co[rd].hd;
+            }
+        }
+    }
+}
+
+// ==========================================================================================================================
 // PERSISTENT REVERSE RECURRENCE (backward): all S timesteps of the three streams' BPTT in two concurrent launches.
 // Reference semantics: autograd of models/OldModel_NEW.py:801-823 (ThreeStream_Core.forward) and :376-401 (Attention.forward); the
 // launch-per-phase form is decoder.hip's bwd_step (four dependent launches per timestep).  Per reverse timestep the attention chain
@@ -1722,6 +1915,7 @@ static PersistHost& phost() {
         if (good) { h.flag_host[0] = 0; good = hipHostGetDevicePointer((void**)&h.flag_dev, h.flag_host, 0) == hipSuccess; }
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM + 1024) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT2) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATTB2) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
@@ -1809,7 +2003,8 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     // the two plain LSTM streams recur on a second HIP stream, concurrently with the attention chain (192 + 64 workgroups = 256 CUs;
     // neither kernel waits on the other, so any residency order makes progress)
     if (hipEventRecord(h.fork, st) != hipSuccess || hipStreamWaitEvent(h.side, h.fork, 0) != hipSuccess) { set_error("persist_fwd: fork failed"); return -5; }
-    hipLaunchKernelGGL(dec_persist_lstm_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM, h.side, K);
+    if (config().persist_h2) hipLaunchKernelGGL(dec_persist_lstm_h2_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM + 1024, h.side, K);
+    else hipLaunchKernelGGL(dec_persist_lstm_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM, h.side, K);
     if (int rc = check_launch("dec_persist_lstm")) return rc;
     if (split) hipLaunchKernelGGL(dec_persist_att2_kernel, dim3(2 * HWG), dim3(256), LDS_BYTES_ATT2, st, K2);
     else hipLaunchKernelGGL(dec_persist_att_kernel, dim3(NATT), dim3(256), LDS_BYTES_ATT, st, K);

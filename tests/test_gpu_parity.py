@@ -550,17 +550,16 @@ def test_persistent_recurrence_equals_launch_path(case):
     opt, params, vid = synth.make_case(case)
     runs = {}
     try:
-        for name, v, vb, sp in (('launch', 0, 0, 1), ('persist', 1, 1, 1), ('persist2', 1, 1, 1), ('fwd_only', 1, 0, 1), ('bwd_only', 0, 1, 1),
-                                ('unsplit', 1, 1, 0)):
+        for name, v, vb, sp, h2 in (('launch', 0, 0, 1, 1), ('persist', 1, 1, 1, 1), ('persist2', 1, 1, 1, 1), ('fwd_only', 1, 0, 1, 1),
+                                    ('bwd_only', 0, 1, 1, 1), ('unsplit', 1, 1, 0, 1), ('f32_products', 1, 1, 1, 0)):
             assert lib.echr_config_set(b'persist', v) == 0 and lib.echr_config_set(b'persist_bwd', vb) == 0
-            assert lib.echr_config_set(b'persist_split', sp) == 0
+            assert lib.echr_config_set(b'persist_split', sp) == 0 and lib.echr_config_set(b'persist_h2', h2) == 0
             runs[name] = U.run_gpu(opt, params, vid, True)
     finally:
-        lib.echr_config_set(b'persist', 1)
-        lib.echr_config_set(b'persist_bwd', 1)
-        lib.echr_config_set(b'persist_split', 1)
+        for key in (b'persist', b'persist_bwd', b'persist_split', b'persist_h2'):
+            lib.echr_config_set(key, 1)
     p0, l0, g0, _ = runs['launch']
-    for name in ('persist', 'persist2', 'fwd_only', 'bwd_only', 'unsplit'):
+    for name in ('persist', 'persist2', 'fwd_only', 'bwd_only', 'unsplit', 'f32_products'):
         p1, l1, g1, _ = runs[name]
         assert np.isfinite(p1).all(), name
         assert np.abs(p0 - p1).max() < 2e-5 and abs(l0 - l1) < 1e-5 * abs(l0), (name, np.abs(p0 - p1).max())
