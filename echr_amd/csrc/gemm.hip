@@ -634,6 +634,32 @@ __global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, (NS == 2 && BM == 128)
         __builtin_amdgcn_s_barrier();
         if (kt + NS - 1 < kt1) stage(cur == 0 ? NS - 1 : cur - 1);
         const unsigned char* sb = sm + cur * STAGE;
+#ifdef ECHR_H2_NOFOLD
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int o = s ? o1 : o0;
+            f16x8 a[2][2], bb[TN][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                a[0][pl] = *reinterpret_cast<const f16x8*>(sb + baseA + pl * H2_PLANE + o);
+                a[1][pl] = *reinterpret_cast<const f16x8*>(sb + baseA + pl * H2_PLANE + o + 32 * 64);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bb[j][pl] = *reinterpret_cast<const f16x8*>(sb + baseB + pl * H2_PLANE + o + j * 32 * 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], bb[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], bb[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], bb[j][0], acc[i][j], 0, 0, 0);
+        }
+#else
         f32x16 tmp[2][TN];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -695,6 +721,7 @@ __global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, (NS == 2 && BM == 128)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) acc[i][j][4 * g + r4] = fmaf(tmp[i][j][4 * g + r4], cav[r4] * cb[j], acc[i][j][4 * g + r4]);
             }
+#endif
         cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
     epilogue<2, TN>(p, acc, p.C, 0, ks, mb * BM, nb * 128, wm, wn, lane);

@@ -92,6 +92,14 @@ __device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t r, u32 off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);      // aux 16 = sc1
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+#ifndef ECHR_BULK_AUX
+#define ECHR_BULK_AUX 16
+#endif
+// bulk operand fragments of a hand-off (tens of KB per workgroup)
+__device__ __forceinline__ float4 ld16_bulk(__amdgpu_buffer_rsrc_t r, u32 off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, ECHR_BULK_AUX);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, u32 off, float4 v) {
     u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 16);
@@ -163,7 +171,7 @@ __device__ __forceinline__ void load_afrag(float4 (&a)[4][8], __amdgpu_buffer_rs
             if (LAYOUT == 0) off = (u32)(((k >> 2) * PROWS + n) * 16);
             else if (LAYOUT == 1) off = (u32)((((k >> 4) * PROWS + n) * 16 + (k & 15)) * 4);
             else off = (u32)((n * PH + k) * 4);
-            a[rb][c] = ld16_sc1(rs, off);
+            a[rb][c] = ld16_bulk(rs, off);
         }
 }
 
@@ -630,10 +638,10 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HR = 32;                        // rows per half machine
 constexpr int HWG = 96, HG1 = 64, HQ = 16;    // workgroups per half: gate, q (the remaining 16 are attention-only)
-constexpr int LDS_W2 = 128 * 1024, LDS_RED2 = 16 * 1024 + 2048 + 512;
+constexpr int LDS_W2 = 128 * 1024, LDS_RED2 = 16 * 1024 + 2048 + 1536;
 constexpr int LDS_BYTES_ATT2 = LDS_W2 + LDS_RED2 + 256;
 
-struct PersistLayout2 { long cnt, xc, xs, gran, zero_end, xh1, xq, wu, total; };
+struct PersistLayout2 { long cnt, xc, xs, gran, xcmax, zero_end, xh1, xq, wu, total; };
 static PersistLayout2 persist_layout2(int S) {
     PersistLayout2 L;
     long off = 0;
@@ -642,6 +650,7 @@ static PersistLayout2 persist_layout2(int S) {
     L.xc = take((long)S * PROWS * PH);
     L.xs = take((long)S * PROWS);
     L.gran = take((long)S * PROWS * 3 * 2);
+    L.xcmax = take(PROWS);
     L.zero_end = off;
     L.xh1 = take((long)S * PROWS * PH);
     L.xq = take((long)S * PROWS * PH);
@@ -654,7 +663,7 @@ static PersistLayout2 persist_layout2(int S) {
 __device__ __forceinline__ void load_afrag32(float4 (&a)[16], __amdgpu_buffer_rsrc_t rs, int w, int lane) {
     const int r = lane & 31, kh = lane >> 5;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = ld16_sc1(rs, (u32)((((16 * w + c) * HR + r) * 8 + 4 * kh) * 4));
+    for (int c = 0; c < 16; ++c) a[c] = ld16_bulk(rs, (u32)((((16 * w + c) * HR + r) * 8 + 4 * kh) * 4));
 }
 __device__ __forceinline__ void mfma_tile32(f32x16& acc, const float4 (&a)[16], const float4* bimg, int lane) {
 #pragma unroll
@@ -686,24 +695,91 @@ __device__ __forceinline__ void fill_bimg32(float4* img, const float* W, long ld
 
 long persist_fwd_ws_floats(int S) { return persist_layout(S).total + persist_layout2(S).total; }
 
+typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
+constexpr float H2_SA = 4096.f, H2_INV_SA = 1.f / 4096.f;          // activation scale 2^12 (|h| < 16 keeps hi finite)
+
+__device__ __forceinline__ void split_h2(float x, unsigned short& hi, unsigned short& lo) {
+    const _Float16 h1 = (_Float16)x;
+    const _Float16 h2 = (_Float16)(x - (float)h1);
+    hi = __builtin_bit_cast(unsigned short, h1);
+    lo = __builtin_bit_cast(unsigned short, h2);
+}
+__device__ __forceinline__ f16x8p as_f16x8(float4 v) { return __builtin_bit_cast(f16x8p, v); }
+
+// B planes of `ncb` 32-column blocks over K = 512 for one workgroup: image float4 index ((((w * 8 + s) * ncb + cb) * 2 + plane) * 64 + lane),
+// lane = (col & 31) + 32 * kh holds W[row_of(32 cb + col)][128 w + 16 s + 8 kh + j], j < 8, times the column's scale 2^(14 - e).
+// inv_scale[col] receives 2^(e - 14).  scratch: ncb * 32 floats of LDS for the column scales.
+template <typename RowFn>
+__device__ __forceinline__ void fill_bimg_h2(float4* img, float* inv_scale, float* scratch, const float* W, long ld, int K, int ncb, RowFn row_of, int tid) {
+    const int ncol = 32 * ncb;
+    // column maxima: 4 threads per column, 128 k each
+    for (int c0 = 0; c0 < ncol; c0 += 64) {
+        const int col = c0 + (tid >> 2), qk = tid & 3;
+        float mx = 0.f;
+        if (col < ncol) {
+            const float* wp = W + (long)row_of(col) * ld;
+            for (int k = 128 * qk; k < min(128 * qk + 128, K); k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(wp + k);
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        if (col < ncol && qk == 0) {
+            const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
+            int e = (ex == 0 || ex == 255) ? 14 : ex - 127;
+            e = max(e, 14 - 126);
+            scratch[col] = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+            inv_scale[col] = ldexpf(1.f, e - 14);
+        }
+    }
+    __syncthreads();
+    const int total = 4 * 8 * ncb * 64;          // (w, s, cb, lane); both planes are produced together
+    for (int idx = tid; idx < total; idx += 256) {
+        const int lane = idx & 63, cb = (idx >> 6) % ncb, s_ = ((idx >> 6) / ncb) & 7, w = (idx >> 6) / ncb / 8;
+        const int col = 32 * cb + (lane & 31), k = 128 * w + 16 * s_ + 8 * (lane >> 5);
+        const float sc = scratch[col];
+        const float* wp = W + (long)row_of(col) * ld + k;
+        unsigned hw[8], lw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned short hi, lo;
+            split_h2((k + j < K ? wp[j] : 0.f) * sc, hi, lo);
+            hw[j] = hi; lw[j] = lo;
+        }
+        const long base = (((long)(w * 8 + s_) * ncb + cb) * 2) * 64 + lane;
+        reinterpret_cast<uint4*>(img)[base] = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+        reinterpret_cast<uint4*>(img)[base + 64] = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
+    }
+    __syncthreads();
+}
+
+
 struct PersistK2 {
     int N, A, D, S, ld_att;
     const float* w_hh1; const float* w_h2a; const float* b_h2a; const float* w_att; const float* w_alpha;
     const float* PALL; const float* c3d; const int* ev_start; const int* ev_len;
     float* GATES1; float* CS1; float* HS; float* OUTD; float* QS; float* WT; float* ATT;
-    float *XH1, *XQ, *XC, *XS, *WU;
+    float *XH1, *XQ, *XC, *XS, *WU, *XCMAX;
     unsigned long long* GRAN;
     u32* cnt; u32* abort_word; u32* host_flag;
     unsigned long long* stamps;
     DropCfg dh, dout;
 };
 
+template <bool H2>
 __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float4* wimg = reinterpret_cast<float4*>(lds);
     float* red = reinterpret_cast<float*>(lds + LDS_W2);          // 16 KB: cross-wave tile sums / cross-row attention partials (8 rows per pass)
     float* sal = red + 4096;                                      // [512] alpha
-    float* sx = sal + PH;                                         // small scratch
+    float* sx = sal + PH;                                         // small scratch [64]
+    float* invbA = sx + 64;                                       // h2: [32] inverse column scales of the phase-A image, [32] of the phase-C image,
+    float* invbC = invbA + 32;                                    //     [32] per-row conversion factor of the context, [32] its inverse scale,
+    float* sCt = invbC + 32;                                      //     [32] bound on |context| per row, [64] scratch
+    float* invAt = sCt + 32;
+    float* cmx = invAt + 32;
+    float* scr = cmx + 32;
     int* flag = reinterpret_cast<int*>(lds + LDS_W2 + LDS_RED2);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = b / HWG, lb = b - m * HWG;
@@ -714,11 +790,17 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
 
     if (is_g1) {
         auto row = [&](int cc) { return (cc >> 3) * PH + 8 * lb + (cc & 7); };       // tile column cc = gate * 8 + unit
-        fill_bimg32(wimg, P.w_hh1, PH, PH, row, tid);
-        fill_bimg32(wimg + 4096, P.w_att, P.ld_att, D, row, tid);
+        if (H2) {
+            fill_bimg_h2(wimg, invbA, scr, P.w_hh1, PH, PH, 1, row, tid);
+            fill_bimg_h2(wimg + 4096, invbC, scr, P.w_att, P.ld_att, D, 1, row, tid);
+        } else {
+            fill_bimg32(wimg, P.w_hh1, PH, PH, row, tid);
+            fill_bimg32(wimg + 4096, P.w_att, P.ld_att, D, row, tid);
+        }
     } else if (is_qw) {
         auto row = [&](int cc) { return 32 * (lb - HG1) + cc; };
-        fill_bimg32(wimg, P.w_h2a, PH, PH, row, tid);
+        if (H2) fill_bimg_h2(wimg, invbA, scr, P.w_h2a, PH, PH, 1, row, tid);
+        else fill_bimg32(wimg, P.w_h2a, PH, PH, row, tid);
     }
     // ---- attention operands -> registers (as version 1) ----
     const int ar = lb / 3, ap = lb - 3 * ar, an = HR * m + ar;    // row within the half, third, event
@@ -762,6 +844,17 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
 #pragma unroll
             for (int h = 0; h < 8; ++h) Pr[i][h] = Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (H2 && att_live) {
+        // bound on |context| of this event = max |C3D| over its slots: one atomic max per workgroup (non-negative floats order like uints);
+        // complete for every reader by the first context hand-off
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < PSG; ++i)
+#pragma unroll
+            for (int h = 0; h < 8; ++h) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(Cr[i][h].x), fabsf(Cr[i][h].y))), fmaxf(fabsf(Cr[i][h].z), fabsf(Cr[i][h].w)));
+        mx = wave_max(mx);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(P.XCMAX) + an, __float_as_uint(mx));
+    }
     __syncthreads();
 
     const int gr = tid >> 3, gu = tid & 7, gn = HR * m + gr;      // gate-math ownership: thread (row gr of the half, unit gu)
@@ -785,12 +878,43 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
             mo1 = mask_o(P.dout, gn, 8 * lb + gu, 1, t);
         }
         // ---- phase A: W_hh1 . h1(t-1) (gate workgroups) / q = W_h2a . h1(t-1) + b (q workgroups) ----
-        if ((is_g1 || is_qw) && t > 0) {
+        // h2: every load of a hand-off operand shares one chip-wide path (measured: 160 workgroups x 64 KB take 4.4 us, the 32 q workgroups alone
+        // 1.35 us, copies at other addresses or staggered readers change nothing), so the gate workgroups, whose product is not needed before the
+        // context arrives, fetch h1 behind their attention role instead of beside the q workgroups
+        const __amdgpu_buffer_rsrc_t rh = mk_rsrc(P.XH1 + ((long)max(t - 1, 0) * 2 + m) * XHALF, XBH);
+        float4 ha[H2 ? 8 : 1][2];
+        auto h1_fetch = [&]() {
+            // two fp16 planes [plane][k / 8][32 rows][8 halves]: lane (r, kh), k step s -> 16 bytes per plane
+#pragma unroll
+            for (int s_ = 0; s_ < (H2 ? 8 : 1); ++s_)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    ha[s_][pl] = ld16_bulk(rh, (u32)(((pl * 64 + 16 * w + 2 * s_ + (lane >> 5)) * HR + (lane & 31)) * 16));
+        };
+        auto h1_product = [&]() {
+#pragma unroll
+            for (int s_ = 0; s_ < (H2 ? 8 : 1); ++s_) {
+                const float4* bp = wimg + (w * 8 + s_) * 128 + lane;
+                const f16x8p bh = as_f16x8(bp[0]), bl = as_f16x8(bp[64]), ah = as_f16x8(ha[s_][0]), al = as_f16x8(ha[s_][1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            }
+            const float ca = H2_INV_SA * invbA[lane & 31];          // back to true scale (column = lane & 31)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] *= ca;
+        };
+        if (((is_g1 && !H2) || is_qw) && t > 0) {
             if (!wait_total(P, cnt(C_H1, t - 1), HG1, flag, 100000u + t)) return;
             if (srole >= 0) STAMP(srole, 1);
-            float4 a[16];
-            load_afrag32(a, mk_rsrc(P.XH1 + ((long)(t - 1) * 2 + m) * XHALF, XBH), w, lane);
-            mfma_tile32(acc, a, wimg + w * 1024, lane);
+            if (H2) {
+                h1_fetch();
+                h1_product();
+            } else {
+                float4 a[16];
+                load_afrag32(a, rh, w, lane);
+                mfma_tile32(acc, a, wimg + w * 1024, lane);
+            }
             if (srole >= 0) STAMP(srole, 2);
         }
         if (is_qw) {
@@ -821,6 +945,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
                 float4 q[8];
 #pragma unroll
                 for (int h = 0; h < 8; ++h) q[h] = ld16_sc1(rq, (u32)((((4 * lr + (h >> 1)) * HR + ar) * 8 + 4 * (h & 1)) * 4));
+                // q(t) complete => the q workgroups have consumed all of h1(t-1), so it is complete and visible here too
+                if (H2 && is_g1 && t > 0) h1_fetch();
                 float asum = 0.f;
 #pragma unroll
                 for (int h = 0; h < 8; ++h) {
@@ -926,6 +1052,10 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
             publish(cnt(C_C, t));
             if (srole >= 0) STAMP(srole, 7);
         }
+        if (H2 && is_g1 && t > 0) {
+            if (!att_live) h1_fetch();
+            h1_product();
+        }
         // ---- phase C: attended-context columns + gate math; the new h1 goes to the next step ----
         if (is_g1) {
             if (!wait_total(P, cnt(C_C, t), HWG, flag, 300000u + t)) return;
@@ -933,33 +1063,75 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
             f32x16 accc;
 #pragma unroll
             for (int g = 0; g < 16; ++g) accc[g] = 0.f;
-            float4 s4[4];
             {
-                float4 a[16];
-                load_afrag32(a, mk_rsrc(P.XC + ((long)t * 2 + m) * XHALF, XBH), w, lane);
-                // sums of exponentials of the rows this lane's accumulator registers belong to (row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5))
-                const __amdgpu_buffer_rsrc_t rsum = mk_rsrc(P.XS + (long)t * PROWS + HR * m, HR * 4);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) s4[g] = ld16_sc1(rsum, (u32)((8 * g + 4 * (lane >> 5)) * 4));
-                mfma_tile32(accc, a, wimg + 4096 + w * 1024, lane);
+                const __amdgpu_buffer_rsrc_t rc = mk_rsrc(P.XC + ((long)t * 2 + m) * XHALF, XBH);
+                float4 a[H2 ? 1 : 16];
+                if (H2) {
+                    // per-row tables: conversion factor 2^(12 - e_r) / s_r (e_r from the bound on |context|) and its inverse scale
+                    if (tid < HR) {
+                        if (t == 0) cmx[tid] = ld4_sc1(P.XCMAX + HR * m + tid);
+                        const int ex = (int)((__float_as_uint(fmaxf(cmx[tid], 1e-30f)) >> 23) & 0xFFu) - 127 + 1;      // |context| < 2^ex
+                        const float ssum = ld4_sc1(P.XS + (long)t * PROWS + HR * m + tid);
+                        sCt[tid] = ldexpf(1.f, 12 - ex) / ssum;
+                        invAt[tid] = ldexpf(1.f, ex - 12);
+                    }
+                    __syncthreads();
+                } else {
+                    load_afrag32(reinterpret_cast<float4(&)[16]>(a), rc, w, lane);
+                }
                 // normalised context, saved for backward: this workgroup stores features [8 lb, 8 lb + 8) (wave lb / 16, chunk lb % 16)
                 if (8 * lb < D && w == (lb >> 4)) {
+                    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (H2) av = ld16_sc1(rc, (u32)(((lb * HR + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4));
+                    else {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c)
-                        if (c == (lb & 15)) {
-                            const int n = HR * m + (lane & 31), d0 = 8 * lb + 4 * (lane >> 5);
-                            if (n < N && d0 < D) {
-                                const float is = 1.0f / ld4_sc1(P.XS + (long)t * PROWS + n);
-                                *reinterpret_cast<float4*>(P.ATT + ((long)t * N + n) * D + d0) =
-                                    make_float4(a[c].x * is, a[c].y * is, a[c].z * is, a[c].w * is);
-                            }
-                        }
+                        for (int c = 0; c < (H2 ? 1 : 16); ++c)
+                            if (c == (lb & 15)) av = a[c];
+                    }
+                    const int n = HR * m + (lane & 31), d0 = 8 * lb + 4 * (lane >> 5);
+                    if (n < N && d0 < D) {
+                        const float is = 1.0f / ld4_sc1(P.XS + (long)t * PROWS + n);
+                        *reinterpret_cast<float4*>(P.ATT + ((long)t * N + n) * D + d0) = make_float4(av.x * is, av.y * is, av.z * is, av.w * is);
+                    }
                 }
-            }
+                if (H2) {
+                    // fp32 context -> fp16 pair fragments on the fly: chunk c = 2 s + kh' holds k = 128 w + 8 c + 4 kh .. ; the 32x32x16 A
+                    // fragment of k step s wants lane (r, kh): k = 128 w + 16 s + 8 kh + j, j < 8 = the two float4 of chunk 2 s + kh held by
+                    // lanes (r, 0) and (r, 1) -> re-read them in that shape from the exchange buffer instead: 8 consecutive floats per lane
+                    const float f = sCt[lane & 31];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                acc[4 * g + 0] += accc[4 * g + 0] / s4[g].x; acc[4 * g + 1] += accc[4 * g + 1] / s4[g].y;
-                acc[4 * g + 2] += accc[4 * g + 2] / s4[g].z; acc[4 * g + 3] += accc[4 * g + 3] / s4[g].w;
+                    for (int s_ = 0; s_ < 8; ++s_) {
+                        const u32 off = (u32)((((16 * w + 2 * s_ + (lane >> 5)) * HR + (lane & 31)) * 8) * 4);
+                        const float4 v0 = ld16_bulk(rc, off), v1 = ld16_bulk(rc, off + 16);
+                        const float x[8] = {v0.x * f, v0.y * f, v0.z * f, v0.w * f, v1.x * f, v1.y * f, v1.z * f, v1.w * f};
+                        unsigned hw[8], lw[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { unsigned short hi, lo; split_h2(x[j], hi, lo); hw[j] = hi; lw[j] = lo; }
+                        const uint4 uh = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+                        const uint4 ul = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
+                        const f16x8p ah = __builtin_bit_cast(f16x8p, uh), al = __builtin_bit_cast(f16x8p, ul);
+                        const float4* bp = wimg + 4096 + (w * 8 + s_) * 128 + lane;
+                        const f16x8p bh = as_f16x8(bp[0]), bl = as_f16x8(bp[64]);
+                        accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc, 0, 0, 0);
+                        accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc, 0, 0, 0);
+                        accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accc, 0, 0, 0);
+                    }
+                    const float cb = invbC[lane & 31];
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc[g] += accc[g] * (cb * invAt[(g & 3) + 8 * (g >> 2) + 4 * (lane >> 5)]);
+                } else {
+                    // sums of exponentials of the rows this lane's accumulator registers belong to (row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5))
+                    float4 s4[4];
+                    const __amdgpu_buffer_rsrc_t rsum = mk_rsrc(P.XS + (long)t * PROWS + HR * m, HR * 4);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) s4[g] = ld16_sc1(rsum, (u32)((8 * g + 4 * (lane >> 5)) * 4));
+                    mfma_tile32(accc, reinterpret_cast<float4(&)[16]>(a), wimg + 4096 + w * 1024, lane);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[4 * g + 0] += accc[4 * g + 0] / s4[g].x; acc[4 * g + 1] += accc[4 * g + 1] / s4[g].y;
+                        acc[4 * g + 2] += accc[4 * g + 2] / s4[g].z; acc[4 * g + 3] += accc[4 * g + 3] / s4[g].w;
+                    }
+                }
             }
             if (srole >= 0) STAMP(srole, 9);
             acc_to_lds32(acc, red, w, lane);
@@ -971,7 +1143,23 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
             }
             const CellOut co = lstm_cell(pre[0], pre[1], pre[2], pre[3], c1, mh1, mo1);
             c1 = co.c;
-            st4_sc1(P.XH1 + ((long)t * 2 + m) * XHALF + (lb * HR + gr) * 8 + gu, co.h);
+            if (H2) {
+                // fp16 planes [plane][k / 8][32 rows][8 halves]: this workgroup's 8 units are group k / 8 = lb; staged through LDS so that
+                // 64 threads store one 16-byte piece each
+                __syncthreads();                        // every thread has read its tile sums
+                unsigned short hi, lo;
+                split_h2(co.h * H2_SA, hi, lo);
+                unsigned short* sh = reinterpret_cast<unsigned short*>(red);
+                sh[(0 * HR + gr) * 8 + gu] = hi;
+                sh[(1 * HR + gr) * 8 + gu] = lo;
+                __syncthreads();
+                {
+                    const int pl = lane >> 5, row = lane & 31;
+                    if (w == 0) st16_sc1(mk_rsrc(P.XH1 + ((long)t * 2 + m) * XHALF, XBH), (u32)(((pl * 64 + lb) * HR + row) * 16), reinterpret_cast<const float4*>(red)[pl * HR + row]);
+                }
+            } else {
+                st4_sc1(P.XH1 + ((long)t * 2 + m) * XHALF + (lb * HR + gr) * 8 + gu, co.h);
+            }
             if (srole >= 0) STAMP(srole, 10);
             publish(cnt(C_H1, t));          // (its barrier also protects `red` for the next step)
             if (srole >= 0) STAMP(srole, 11);
@@ -1005,65 +1193,6 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
 // the same operand format as gemm.hip's h2 GEMM with the scale block stretched over the whole contraction.  16x the MFMA rate of the
 // f32 forms at 3 products: the plain LSTM streams' 8 us of MFMA time per step becomes 1.5 us.
 // ==========================================================================================================================
-typedef _Float16 f16x8p __attribute__((ext_vector_type(8)));
-constexpr float H2_SA = 4096.f, H2_INV_SA = 1.f / 4096.f;          // activation scale 2^12 (|h| < 16 keeps hi finite)
-
-__device__ __forceinline__ void split_h2(float x, unsigned short& hi, unsigned short& lo) {
-    const _Float16 h1 = (_Float16)x;
-    const _Float16 h2 = (_Float16)(x - (float)h1);
-    hi = __builtin_bit_cast(unsigned short, h1);
-    lo = __builtin_bit_cast(unsigned short, h2);
-}
-__device__ __forceinline__ f16x8p as_f16x8(float4 v) { return __builtin_bit_cast(f16x8p, v); }
-
-// B planes of `ncb` 32-column blocks over K = 512 for one workgroup: image float4 index ((((w * 8 + s) * ncb + cb) * 2 + plane) * 64 + lane),
-// lane = (col & 31) + 32 * kh holds W[row_of(32 cb + col)][128 w + 16 s + 8 kh + j], j < 8, times the column's scale 2^(14 - e).
-// inv_scale[col] receives 2^(e - 14).  scratch: ncb * 32 floats of LDS for the column scales.
-template <typename RowFn>
-__device__ __forceinline__ void fill_bimg_h2(float4* img, float* inv_scale, float* scratch, const float* W, long ld, int K, int ncb, RowFn row_of, int tid) {
-    const int ncol = 32 * ncb;
-    // column maxima: 4 threads per column, 128 k each
-    for (int c0 = 0; c0 < ncol; c0 += 64) {
-        const int col = c0 + (tid >> 2), qk = tid & 3;
-        float mx = 0.f;
-        if (col < ncol) {
-            const float* wp = W + (long)row_of(col) * ld;
-            for (int k = 128 * qk; k < min(128 * qk + 128, K); k += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(wp + k);
-                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 1));
-        mx = fmaxf(mx, __shfl_xor(mx, 2));
-        if (col < ncol && qk == 0) {
-            const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
-            int e = (ex == 0 || ex == 255) ? 14 : ex - 127;
-            e = max(e, 14 - 126);
-            scratch[col] = __uint_as_float((unsigned)(127 + 14 - e) << 23);
-            inv_scale[col] = ldexpf(1.f, e - 14);
-        }
-    }
-    __syncthreads();
-    const int total = 4 * 8 * ncb * 64;          // (w, s, cb, lane); both planes are produced together
-    for (int idx = tid; idx < total; idx += 256) {
-        const int lane = idx & 63, cb = (idx >> 6) % ncb, s_ = ((idx >> 6) / ncb) & 7, w = (idx >> 6) / ncb / 8;
-        const int col = 32 * cb + (lane & 31), k = 128 * w + 16 * s_ + 8 * (lane >> 5);
-        const float sc = scratch[col];
-        const float* wp = W + (long)row_of(col) * ld + k;
-        unsigned hw[8], lw[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            unsigned short hi, lo;
-            split_h2((k + j < K ? wp[j] : 0.f) * sc, hi, lo);
-            hw[j] = hi; lw[j] = lo;
-        }
-        const long base = (((long)(w * 8 + s_) * ncb + cb) * 2) * 64 + lane;
-        reinterpret_cast<uint4*>(img)[base] = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
-        reinterpret_cast<uint4*>(img)[base + 64] = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
-    }
-    __syncthreads();
-}
-
 // ---- the two plain LSTM streams, h2 products: 64 rows x 64 gate columns (16 units) per workgroup ----
 // h exchange layout (per timestep, 128 KB): [plane 2][k / 8 (64)][row 64][8 halves]
 __global__ __launch_bounds__(256, 1) void dec_persist_lstm_h2_kernel(PersistK P) {
@@ -1119,7 +1248,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_h2_kernel(PersistK P)
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl)
-                        a[s_][rb][pl] = ld16_sc1(ra, (u32)((((pl * 64 + 16 * w + 2 * s_ + (lane >> 5)) * PROWS) + 32 * rb + (lane & 31)) * 16));
+                        a[s_][rb][pl] = ld16_bulk(ra, (u32)((((pl * 64 + 16 * w + 2 * s_ + (lane >> 5)) * PROWS) + 32 * rb + (lane & 31)) * 16));
 #pragma unroll
             for (int s_ = 0; s_ < 8; ++s_) {
                 const float4* bp = wimg + ((long)(w * 8 + s_) * 2) * 2 * 64 + lane;
@@ -1916,7 +2045,8 @@ static PersistHost& phost() {
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM + 1024) == hipSuccess;
-        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT2) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT2) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT2) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATTB2) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
@@ -1991,7 +2121,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
         K2.PALL = B.PALL; K2.c3d = a->c3d; K2.ev_start = a->ev_start; K2.ev_len = a->ev_len;
         K2.GATES1 = B.GATES[1]; K2.CS1 = B.CS[1]; K2.HS = B.HS; K2.OUTD = B.OUTD; K2.QS = B.QS; K2.WT = B.WT; K2.ATT = B.ATT;
         K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XC = x2 + L2.xc; K2.XS = x2 + L2.xs; K2.GRAN = reinterpret_cast<unsigned long long*>(x2 + L2.gran);
-        K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu;
+        K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
         K2.abort_word = h.abort_dev; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = dh; K2.dout = dout;
         // version 2 keeps its own zero region; of version 1's only the counters of the LSTM kernel are needed
         if (hipMemsetAsync(x, 0, (size_t)(L.xc) * sizeof(float), st) != hipSuccess || hipMemsetAsync(x2, 0, (size_t)L2.zero_end * sizeof(float), st) != hipSuccess) {
@@ -2006,7 +2136,8 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     if (config().persist_h2) hipLaunchKernelGGL(dec_persist_lstm_h2_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM + 1024, h.side, K);
     else hipLaunchKernelGGL(dec_persist_lstm_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM, h.side, K);
     if (int rc = check_launch("dec_persist_lstm")) return rc;
-    if (split) hipLaunchKernelGGL(dec_persist_att2_kernel, dim3(2 * HWG), dim3(256), LDS_BYTES_ATT2, st, K2);
+    if (split && config().persist_h2) hipLaunchKernelGGL(dec_persist_att2_kernel<true>, dim3(2 * HWG), dim3(256), LDS_BYTES_ATT2, st, K2);
+    else if (split) hipLaunchKernelGGL(dec_persist_att2_kernel<false>, dim3(2 * HWG), dim3(256), LDS_BYTES_ATT2, st, K2);
     else hipLaunchKernelGGL(dec_persist_att_kernel, dim3(NATT), dim3(256), LDS_BYTES_ATT, st, K);
     if (int rc = check_launch("dec_persist_att")) return rc;
     if (hipEventRecord(h.join, h.side) != hipSuccess || hipStreamWaitEvent(st, h.join, 0) != hipSuccess) { set_error("persist_fwd: join failed"); return -5; }
