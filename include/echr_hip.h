@@ -73,9 +73,9 @@ typedef struct {
 int echr_gemm_f32(const echr_gemm_desc* d, void* stream);
 
 /* h2 operands: a logical [rows x cols] fp32 operand (cols = the contraction axis) rewritten as two fp16 planes with one shared
- * power-of-two scale per row and 32-wide k block: xs = x * 2^(14 - floor(log2 blockmax)), h1 = fp16(xs), h2 = fp16(xs - h1).
+ * power-of-two scale per row and 256-wide k segment (8 blocks of 32): xs = x * 2^(14 - floor(log2 blockmax)), h1 = fp16(xs), h2 = fp16(xs - h1).
  * No value is held in fp16 unscaled, so the fp32 exponent range survives; h1 + h2 carries 22..24 significand bits of every
- * element within 2^-17 of its block maximum.  Laid out as zero-padded 128 x 32 chunks in the order the GEMM's direct-to-LDS
+ * element within 2^-17 of its segment maximum.  Laid out as zero-padded 128 x 32 chunks in the order the GEMM's direct-to-LDS
  * loads consume.  Element (r, k) is read from src[r*s_row + k*s_col] (one stride must be 1, so a transposed source packs
  * without a separate transpose).  dst: echr_h2_bytes(rows, cols) bytes, 16-byte aligned. */
 int64_t echr_h2_bytes(int32_t rows, int32_t cols);

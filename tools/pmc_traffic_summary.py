@@ -17,7 +17,7 @@ def load(sub, counter):
         if r['Counter_Name'] != counter:
             continue
         k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('echr::', '')
-        k = k.split('<')[0] if k.startswith('gemm_f32_kernel') else k
+        k = k.split('<')[0] if k.startswith(('gemm_f32_kernel', 'gemm_h2_kernel', 'dec_persist_att2_kernel', 'att_post_kernel')) else k
         agg[k] += float(r['Counter_Value'])
         cnt[k] += 1
     return agg, cnt
@@ -27,8 +27,16 @@ fe, nf = load('fetch', 'FETCH_SIZE')
 wr, nw = load('write', 'WRITE_SIZE')
 out = {}
 for k in sorted(fe, key=lambda k: -fe[k]):
-    if not (k.startswith(('gemm', 'rec_gemm', 'att_', 'lstm', 'clamp_adam', 'h2_pack'))):
+    if not (k.startswith(('gemm', 'rec_gemm', 'att_', 'lstm', 'clamp_adam', 'h2_pack', 'dec_persist'))):
         continue
     out[k] = dict(launches=nf[k], fetch_bytes_per_launch=round(2 * 1024 * fe[k] / nf[k]), write_bytes_per_launch=round(1024 * wr.get(k, 0) / max(nw.get(k, 1), 1)))
     out[k]['hbm_bytes_per_launch'] = out[k]['fetch_bytes_per_launch'] + out[k]['write_bytes_per_launch']
+# the four persistent recurrence kernels run as two concurrent pairs (forward, reverse); bench.py times each pair as one launch
+pk = [k for k in out if k.startswith('dec_persist')]
+if pk:
+    pairs = max(1, max(out[k]['launches'] for k in pk))
+    out['dec_persist_kernels'] = dict(launches=2 * pairs, members=pk,
+                                      fetch_bytes_per_launch=round(sum(out[k]['fetch_bytes_per_launch'] * out[k]['launches'] for k in pk) / (2 * pairs)),
+                                      write_bytes_per_launch=round(sum(out[k]['write_bytes_per_launch'] * out[k]['launches'] for k in pk) / (2 * pairs)))
+    out['dec_persist_kernels']['hbm_bytes_per_launch'] = out['dec_persist_kernels']['fetch_bytes_per_launch'] + out['dec_persist_kernels']['write_bytes_per_launch']
 print(json.dumps(out, indent=1))
