@@ -641,20 +641,22 @@ constexpr int HWG = 96, HG1 = 64, HQ = 16;    // workgroups per half: gate, q (t
 constexpr int LDS_W2 = 128 * 1024, LDS_RED2 = 16 * 1024 + 2048 + 1536;
 constexpr int LDS_BYTES_ATT2 = LDS_W2 + LDS_RED2 + 256;
 
-struct PersistLayout2 { long cnt, xc, xs, gran, xcmax, zero_end, xh1, xq, wu, total; };
+struct PersistLayout2 { long cnt, xc, xs, gran, xcmax, zero_begin, xh1, xq, wu, total; };
 static PersistLayout2 persist_layout2(int S) {
     PersistLayout2 L;
     long off = 0;
     auto take = [&](long n) { long o = off; off += (n + 63) / 64 * 64; return o; };
+    L.xh1 = take((long)S * PROWS * PH);
+    L.xq = take((long)S * PROWS * PH);
+    L.wu = take((long)S * PROWS * WU_LD);
+    // the zeroed region comes last: the version-1 layout (whose first region, the counters, is the only part of it the LSTM kernel needs
+    // zeroed) follows this one in the workspace, so one memset covers both
+    L.zero_begin = off;
     L.cnt = take((long)3 * (S + 1) * 2 * CNT_LINE);
     L.xc = take((long)S * PROWS * PH);
     L.xs = take((long)S * PROWS);
     L.gran = take((long)S * PROWS * 3 * 2);
     L.xcmax = take(PROWS);
-    L.zero_end = off;
-    L.xh1 = take((long)S * PROWS * PH);
-    L.xq = take((long)S * PROWS * PH);
-    L.wu = take((long)S * PROWS * WU_LD);
     L.total = off;
     return L;
 }
@@ -1760,19 +1762,19 @@ constexpr int LDS_REDB2 = 16 * 1024 + 2048 + 2048 + 512;
 constexpr int LDS_BYTES_ATTB2 = LDS_W2 + LDS_REDB2 + 256;
 constexpr long XSTEPH = 4L * HR * PH;          // floats of one half's [4 gates][32 rows x 512] exchange operand
 
-struct PersistLayoutB2 { long cnt, xdq, xda, xdh, zero_end, xdg, total; };
+struct PersistLayoutB2 { long cnt, xdq, xda, xdh, zero_begin, xdg, total; };
 static PersistLayoutB2 persist_layout_b2(int S);
 long persist_bwd_ws_floats(int S) { return persist_layout_b(S).total + persist_layout_b2(S).total; }
 static PersistLayoutB2 persist_layout_b2(int S) {
     PersistLayoutB2 L;
     long off = 0;
     auto take = [&](long n) { long o = off; off += (n + 63) / 64 * 64; return o; };
+    L.xdg = take((long)S * 2 * XSTEPH);
+    L.zero_begin = off;          // zeroed region last, the version-1 layout (counters first) follows: one memset
     L.cnt = take((long)4 * (S + 1) * 2 * CNT_LINE);
     L.xdq = take((long)S * PROWS * PH);
     L.xda = take((long)S * PROWS * PH);
     L.xdh = take((long)S * PROWS * PH);
-    L.zero_end = off;
-    L.xdg = take((long)S * 2 * XSTEPH);
     L.total = off;
     return L;
 }
@@ -2101,7 +2103,10 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     K.w_h2a = a->w_h2a; K.b_h2a = a->b_h2a; K.w_att = a->w_ih[1] + a->E; K.w_alpha = a->w_alpha;
     K.PALL = B.PALL; K.c3d = a->c3d; K.ev_start = a->ev_start; K.ev_len = a->ev_len;
     K.HS = B.HS; K.OUTD = B.OUTD; K.QS = B.QS; K.WT = B.WT; K.ATT = B.ATT;
-    float* x = B.xws;
+    const bool split = config().persist_split != 0;
+    const PersistLayout2 L2 = persist_layout2(a->S);
+    float* x2 = B.xws;                                  // version-2 layout first (its zeroed region last), version 1 behind it
+    float* x = split ? x2 + L2.total : B.xws;
     K.cnt = reinterpret_cast<u32*>(x + L.cnt); K.XC = x + L.xc; K.XS = x + L.xs; K.GRAN = reinterpret_cast<unsigned long long*>(x + L.gran);
     K.XH1 = x + L.xh1; K.XH0 = x + L.xh0; K.XH2 = x + L.xh2; K.XQ = x + L.xq; K.WU = x + L.wu;
     K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
@@ -2111,9 +2116,6 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
         if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
-    const bool split = config().persist_split != 0;
-    const PersistLayout2 L2 = persist_layout2(a->S);
-    float* x2 = x + L.total;
     PersistK2 K2;
     if (split) {
         K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
@@ -2123,8 +2125,8 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
         K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XC = x2 + L2.xc; K2.XS = x2 + L2.xs; K2.GRAN = reinterpret_cast<unsigned long long*>(x2 + L2.gran);
         K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
         K2.abort_word = h.abort_dev; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = dh; K2.dout = dout;
-        // version 2 keeps its own zero region; of version 1's only the counters of the LSTM kernel are needed
-        if (hipMemsetAsync(x, 0, (size_t)(L.xc) * sizeof(float), st) != hipSuccess || hipMemsetAsync(x2, 0, (size_t)L2.zero_end * sizeof(float), st) != hipSuccess) {
+        // one memset: version 2's zeroed region and, right behind it, version 1's counters (all the LSTM kernel needs of that layout)
+        if (hipMemsetAsync(x2 + L2.zero_begin, 0, (size_t)(L2.total - L2.zero_begin + L.xc) * sizeof(float), st) != hipSuccess) {
             set_error("persist_fwd: memset failed");
             return -5;
         }
@@ -2157,7 +2159,10 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
     K.w_h2a = a->w_h2a; K.w_att = a->w_ih[1] + a->E; K.w_alpha = a->w_alpha;
     K.PALL = B.PALL; K.c3d = a->c3d; K.ev_start = a->ev_start; K.ev_len = a->ev_len;
     K.QS = B.QS; K.WT = B.WT; K.ATT = B.ATT; K.DOUT = B.DOUT; K.DQ = B.DQ; K.DSC = B.DSC;
-    float* x = B.xws;
+    const bool split = config().persist_split != 0;
+    const PersistLayoutB2 L2 = persist_layout_b2(a->S);
+    float* x2 = B.xws;                                  // version-2 layout first (its zeroed region last), version 1 behind it
+    float* x = split ? x2 + L2.total : B.xws;
     K.cnt = reinterpret_cast<u32*>(x + L.cnt); K.XDQ = x + L.xdq; K.XDG = x + L.xdg; K.XDA = x + L.xda; K.XDH = x + L.xdh;
     K.XG0 = x + L.xg0; K.XG2 = x + L.xg2;
     K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
@@ -2167,14 +2172,11 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
         if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
-    const bool split = config().persist_split != 0;
     PersistB K2 = K;
     if (split) {
-        const PersistLayoutB2 L2 = persist_layout_b2(a->S);
-        float* x2 = x + L.total;
         K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XDQ = x2 + L2.xdq; K2.XDA = x2 + L2.xda; K2.XDH = x2 + L2.xdh; K2.XDG = x2 + L2.xdg;
-        // version 2 keeps its own zero region; of version 1's only the counters (LSTM kernel) are needed
-        if (hipMemsetAsync(x, 0, (size_t)L.xdq * sizeof(float), st) != hipSuccess || hipMemsetAsync(x2, 0, (size_t)L2.zero_end * sizeof(float), st) != hipSuccess) {
+        // one memset: version 2's zeroed region and, right behind it, version 1's counters (all the LSTM kernel needs of that layout)
+        if (hipMemsetAsync(x2 + L2.zero_begin, 0, (size_t)(L2.total - L2.zero_begin + L.xdq) * sizeof(float), st) != hipSuccess) {
             set_error("persist_bwd: memset failed");
             return -5;
         }
