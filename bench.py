@@ -181,14 +181,15 @@ def gpu_leg(args, rank, world, local_rank):
     if rank == 0 and not args.no_roofline:
         # kernel classes of libechr_hip.so (echr_prof_read kinds) -> (name, rocprof kernel symbol, bound)
         kinds = {0: ('gemm_f32_kernel', 'gemm_f32_kernel<*> (all tile/layout instantiations)', 'mfma'),
-                 7: ('gemm_h2_kernel', 'gemm_h2_kernel<128, 32>', 'mfma'),
+                 7: ('gemm_h2_kernel', 'gemm_h2m16_kernel<2> (v_mfma_f32_16x16x32_f16) + gemm_h2_kernel<128, 32, 2> (many-way split-K products)', 'mfma'),
                  6: ('gemm_split_kernel', 'gemm_split_kernel', 'mfma'),
                  4: ('rec_gemm_kernel', 'rec_gemm_kernel', 'mfma'),
                  8: ('h2_pack_kernel', 'h2_pack_kernel', 'hbm'),
                  1: ('att_fwd', 'att_score_kernel + att_context_kernel', 'hbm'),
                  2: ('att_bwd_kernel', 'att_bwd_kernel', 'hbm'),
                  3: ('att_post_kernel', 'att_post_kernel', 'valu'),
-                 9: ('dec_persist_kernels', 'dec_persist_att_kernel || dec_persist_lstm_kernel (two concurrent launches, all S steps)', 'mfma')}
+                 9: ('dec_persist_kernels', 'dec_persist_att2_kernel<true> || dec_persist_lstm_h2_kernel (forward) and dec_persist_att_bwd2_kernel || '
+                                            'dec_persist_lstm_bwd_kernel (reverse): each pair = two concurrent launches covering all S steps', 'mfma')}
         n_it = max(2, min(args.steps, 5))
         stats = {}
         for k, (name, sym, bound) in kinds.items():
@@ -206,6 +207,22 @@ def gpu_leg(args, rank, world, local_rank):
                 break
             except Exception:
                 pass
+        # MFMA activity (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles of the dispatch) likewise comes from the committed --pmc pass of the
+        # same command (tools/pmc_mfma.sh -> profiles/r02_pmc_mfma.json)
+        mfma_pmc = {}
+        try:
+            mfma_pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_mfma.json')))
+        except Exception:
+            pass
+
+        def mfma_busy(name):
+            if name == 'dec_persist_kernels':           # time-weighted over the four kernels of the two pairs
+                ks = [v for k, v in mfma_pmc.items() if k.startswith('dec_persist') and v.get('mfma_busy_frac') is not None]
+                tot = sum(v['avg_us'] * v['launches'] for v in ks)
+                return round(sum(v['mfma_busy_frac'] * v['avg_us'] * v['launches'] for v in ks) / tot, 4) if tot else None
+            v = mfma_pmc.get(name)
+            return v.get('mfma_busy_frac') if v else None
+
         # HIP-event pairs around a short launch add a fixed cost per launch (the second record waits for the first to retire):
         # measured here on an idle stream and subtracted, so that avg_launch_us agrees with rocprofv3's kernel durations
         ev_ms, ev_n = C.c_double(), C.c_int64()
@@ -234,6 +251,7 @@ def gpu_leg(args, rank, world, local_rank):
                         frac=round(ach / peak, 4), traffic=tb, traffic_source=traffic_src if tb else None,
                         algorithmic_bytes_per_launch=round(alg) if alg else None,
                         traffic_over_algorithmic=round(tb / alg, 2) if (tb and alg) else None,
+                        mfma_busy_frac_pmc=mfma_busy(name),
                         avg_launch_us=round(1e3 * ms / st['launches'], 2), event_overhead_us_subtracted=round(ev_us, 2),
                         launches_per_step=st['launches'] / n_it, ms_per_step=round(ms / n_it, 3))
 

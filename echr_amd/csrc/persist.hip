@@ -2131,7 +2131,12 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
             return -5;
         }
     } else if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_fwd: memset failed"); return -5; }
-    ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), 0.0, st);
+    // algorithmic bytes of the forward pair: every recurrent weight and every attention operand row once, plus the per-step activations in
+    // (input-side gate pre-activations) and out (c, h of three streams, dropped output, q, attention weights, context)
+    const double wbytes = 4.0 * (3.0 * 4 * PH * PH + (double)PH * PH + 4.0 * PH * a->D);
+    const double obytes = 4.0 * (double)a->N * a->A * (PH + a->D);
+    const double sbytes = 4.0 * (double)a->S * a->N * (3.0 * 4 * PH + 3.0 * 2 * PH + PH + PH + a->A + a->D);
+    ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), wbytes + obytes + sbytes, st);
     // the two plain LSTM streams recur on a second HIP stream, concurrently with the attention chain (192 + 64 workgroups = 256 CUs;
     // neither kernel waits on the other, so any residency order makes progress)
     if (hipEventRecord(h.fork, st) != hipSuccess || hipStreamWaitEvent(h.side, h.fork, 0) != hipSuccess) { set_error("persist_fwd: fork failed"); return -5; }
@@ -2181,7 +2186,12 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
             return -5;
         }
     } else if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_bwd: memset failed"); return -5; }
-    ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), 0.0, st);
+    // algorithmic bytes of the reverse pair: weights and attention operands once, per step the saved activations in (gates, cells, q,
+    // weights, context, upstream gradient) and the gradients out (gate gradients of three streams, d q, d score)
+    const double wbytes = 4.0 * (3.0 * 4 * PH * PH + (double)PH * PH + 4.0 * PH * a->D);
+    const double obytes = 4.0 * (double)a->N * a->A * (PH + a->D);
+    const double sbytes = 4.0 * (double)a->S * a->N * (3.0 * 4 * PH + 3.0 * 2 * PH + PH + a->A + a->D + PH + 3.0 * 4 * PH + PH + a->A);
+    ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), wbytes + obytes + sbytes, st);
     if (hipEventRecord(h.fork, st) != hipSuccess || hipStreamWaitEvent(h.side, h.fork, 0) != hipSuccess) { set_error("persist_bwd: fork failed"); return -5; }
     hipLaunchKernelGGL(dec_persist_lstm_bwd_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM, h.side, K);
     if (int rc = check_launch("dec_persist_lstm_bwd")) return rc;
