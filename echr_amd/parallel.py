@@ -49,9 +49,16 @@ class EarlyReducer(object):
     the current stream).  `allreduce_gradients` later reduces the ranges no early collective covered and waits for the early ones,
     so the result is the same SUM over ranks as the single-collective path."""
 
-    def __init__(self, arena, group=None, auto_arm=True):
+    def __init__(self, arena, group=None, auto_arm=True, defer_first=None):
         self.arena, self.group = arena, group
         self.pending = []              # [(lo, hi, work)], disjoint arena ranges in flight
+        # The first range of a backward pass (the late-fusion layer) becomes final BEFORE the reverse recurrence, which runs as a pair
+        # of persistent kernels that need every CU of the device: a collective kernel resident beside them would not overlap with
+        # them but serialise against them (and hold back the workgroups that found no CU).  defer_first (default on,
+        # ECHR_DP_DEFER_FIRST=0 to disable) keeps that range back until the next hook call (after the recurrence), where it starts
+        # together with the LSTM layers' range and overlaps with the launch-bound tail of the backward pass.
+        self.defer_first = bool(int(os.environ.get('ECHR_DP_DEFER_FIRST', '1'))) if defer_first is None else bool(defer_first)
+        self.deferred = []             # parameter lists kept back
         self.early_ids = set()         # parameters whose gradients the pending collectives cover
         # Early collectives are only legal during the LAST backward of an optimiser step: a later backward would add its gradients
         # into arena ranges that are already being reduced (allreduce(g1) + local g2, and a race with the in-flight collective).
@@ -73,9 +80,17 @@ class EarlyReducer(object):
                                'accumulation create the reducer with auto_arm=False and call arm() only before the last backward')
 
     def hook(self, params):
-        ar = self.arena
         if not self.armed or not (dist.is_available() and dist.is_initialized()):
             return
+        if self.defer_first and not self.pending and not self.deferred:
+            self.deferred.append(list(params))
+            return
+        held, self.deferred = self.deferred, []
+        for ps in held + [list(params)]:
+            self._start(ps)
+
+    def _start(self, params):
+        ar = self.arena
         slots = sorted(ar.slot(p) for p in params)
         if any(s is None for s in slots) or slots != list(range(slots[0], slots[-1] + 1)):
             return                      # not one contiguous arena range: leave it to the final collective
@@ -90,7 +105,7 @@ class EarlyReducer(object):
         """Reduce what the early collectives did not cover, then wait for them.  Returns the number of collectives."""
         ar = self.arena
         pend = sorted(self.pending, key=lambda t: t[0])
-        self.pending, self.early_ids = [], set()
+        self.pending, self.early_ids, self.deferred = [], set(), []        # a range still kept back is simply not covered early
         self.armed = self.auto_arm
         n, pos = len(pend), 0
         for lo, hi, _ in pend + [(ar.total, ar.total, None)]:
@@ -107,20 +122,21 @@ class EarlyReducer(object):
         ids = self.early_ids
         for _, _, work in self.pending:
             work.wait()
-        self.pending, self.early_ids = [], set()
+        self.pending, self.early_ids, self.deferred = [], set(), []
         return ids
 
     def disable(self):
         self.arena.early_grad_hook = None
 
 
-def enable_overlap(module, group=None, auto_arm=True):
+def enable_overlap(module, group=None, auto_arm=True, defer_first=None):
     """Install the early reducer on a module whose parameters live in a flat arena (CaptionGenerator.build_arena()).
-    auto_arm=False: gradient accumulation -- call the returned reducer's arm() before the last backward of every optimiser step."""
+    auto_arm=False: gradient accumulation -- call the returned reducer's arm() before the last backward of every optimiser step.
+    defer_first: see EarlyReducer (None = ECHR_DP_DEFER_FIRST, default on)."""
     arena = getattr(module, '_echr_arena', None)
     if arena is None:
         raise ValueError('enable_overlap needs the flat arena: call module.build_arena() first')
-    red = EarlyReducer(arena, group, auto_arm)
+    red = EarlyReducer(arena, group, auto_arm, defer_first)
     module._echr_early_reducer = red
     return red
 

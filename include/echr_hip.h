@@ -341,10 +341,14 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *   "gemm_bf16x3" 0/1  (gemm_h2 = 0) use the three-plane bf16 split product for the large projections or the native fp32 MFMA
  *   "overlap"     0/1  run recurrence-independent GEMMs on a second HIP stream
  *   "att_slots"   2/4/8 attention slots per wave
- *   "persist"     0/1  (default 1, ECHR_PERSIST) run the teacher-forced recurrence as ONE persistent launch (csrc/persist.hip) when the
- *                      shape allows (N <= 64, A <= 129, H = Ha = 512, D <= 512, a full 256-CU device), else one launch per phase
- *   "persist_bwd" 0/1  (default 1, ECHR_PERSIST_BWD) the same for the reverse recurrence of echr_decoder_bwd (needs "persist" = 1)
- *   "persist_stamps" 0/1 diagnostic phase stamps, see echr_persist_read_stamps */
+ *   "persist"     0/1  (default 1, ECHR_PERSIST) run the teacher-forced recurrence as a pair of persistent launches (csrc/persist.hip)
+ *                      when the shape allows (N <= 64, A <= 129, H = Ha = 512, D <= 512, a full 256-CU device), else one launch per phase
+ *   "persist_bwd" 0/1  (default 1, ECHR_PERSIST_BWD) the same for the reverse recurrence of echr_decoder_bwd (independent of "persist")
+ *   "persist_split" 0/1 (default 1, ECHR_PERSIST_SPLIT) attention chain as two half-chip machines of 32 event rows (0: one machine of 64)
+ *   "persist_h2"  0/1  (default 1, ECHR_PERSIST_H2) fp16-pair (fp32-grade) MFMA products in the forward persistent kernels (0: exact
+ *                      fp32 MFMAs); the reverse kernels always use fp32 MFMAs
+ *   "persist_stamps" 0/1/2 diagnostic phase stamps of the forward (1) / reverse (2) pair, see echr_persist_read_stamps
+ *   "gemm_tile", "gemm_split"  tuning overrides of the GEMM tile / split-K heuristics (0 = heuristics; tools/gemm_bench.py only) */
 int echr_config_set(const char* key, int32_t value);
 
 /* Diagnostic (never on the product path): with echr_config_set("persist_stamps", 1) the persistent recurrence kernels record

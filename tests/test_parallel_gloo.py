@@ -139,7 +139,7 @@ def _worker_algos(rank, world, port, q):
     for p in live:
         p.grad = None
     arena.flat_g.zero_()
-    red = parallel.enable_overlap(net, auto_arm=False)
+    red = parallel.enable_overlap(net, auto_arm=False, defer_first=False)
     ga = backward_into_arena(True)
     red.hook([net[1].weight, net[1].bias])          # not armed: must do nothing
     none_in_flight = len(red.pending) == 0
@@ -154,8 +154,20 @@ def _worker_algos(rank, world, port, q):
         refused = True
     parallel.allreduce_gradients(net)
     local = [a + b for a, b in zip(ga, gb)]
-    q.put((rank, same_algo, none_in_flight, in_flight, refused, not red.armed, [t.numpy() for t in local],
-           [p.grad.numpy().copy() for p in live]))
+    reduced = [p.grad.numpy().copy() for p in live]
+    # (3) defer_first (the default): the range that is final before the reverse recurrence is kept back until the next hook call
+    red.disable()
+    red2 = parallel.enable_overlap(net, auto_arm=True)
+    keep = arena.flat_g.clone()
+    red2.hook([net[1].weight, net[1].bias])
+    held = red2.defer_first and len(red2.pending) == 0 and len(red2.deferred) == 1
+    red2.hook([net[0].weight])
+    both = len(red2.pending) == 2 and not red2.deferred
+    parallel.allreduce_gradients(net)
+    ref2 = keep.clone()
+    dist.all_reduce(ref2)
+    deferred_ok = bool(held and both and torch.equal(ref2, arena.flat_g))
+    q.put((rank, same_algo, none_in_flight, in_flight, refused, not red.armed and deferred_ok, [t.numpy() for t in local], reduced))
     dist.destroy_process_group()
 
 
