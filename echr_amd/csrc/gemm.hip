@@ -1054,10 +1054,25 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
         // latency-bound regime: fewer than 2 workgroups per CU.  Split K so that ~1024 workgroups overlap each other's
         // load latency, keeping at least 4 k-tiles (128 deep) per split (measured optimum on the weight-gradient shapes).
         if (h2) {
-            // two 8-wave workgroups per CU = 512 slots: split K only when the output grid leaves most of them empty, and keep at least
-            // 8 k blocks per slice (each slice pays a pipeline fill and an atomic epilogue)
-            if (d.act == ECHR_ACT_NONE && wgs < 200 && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0)
-                split = (int)max(1L, min((long)kt_total / 8, (400 + wgs - 1) / max(wgs, 1L)));
+            // two 8-wave workgroups per CU = 512 slots.  Cost model fitted to tools/h2_bench.py / h2_ksweep.py on the c3 shapes (us): a k
+            // block costs 0.8 per workgroup while every CU holds at most one, 1.4 per pair once CUs hold two; a launch costs 9 for
+            // prologue + epilogue; a k-split adds its atomic epilogue (the output written `split` times at ~2.5 TB/s) and keeps at
+            // least 8 k blocks per slice.  (Round 1 split whenever the grid had fewer than 200 tiles: 192 tiles x 3 slices ran 1.35x
+            // slower than the unsplit product.)
+            if (d.act == ECHR_ACT_NONE && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
+                const double out_mb = 4e-6 * (double)d.M * d.N * ng;
+                double best = 1e30;
+                for (int sp = 1; sp <= 32 && (sp == 1 || kt_total / sp >= 8); ++sp) {
+                    const long W = wgs * sp;
+                    const int kb = (kt_total + sp - 1) / sp;
+                    double t;
+                    if (W <= 256) t = 0.8 * kb;
+                    else if (W <= 512) t = 1.4 * kb;
+                    else t = 1.4 * kb * (double)(W / 512) + ((W % 512) > 256 ? 1.4 : ((W % 512) ? 0.8 : 0.0)) * kb;
+                    t += 9.0 + (sp > 1 ? out_mb * sp / 2.5 + (d.beta == 0.f ? 3.0 : 0.0) : 0.0);
+                    if (t < best) { best = t; split = sp; }
+                }
+            }
         } else if (d.act == ECHR_ACT_NONE && wgs < (use_split ? 200 : 512) && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
             split = (int)min((long)kt_total, max(1L, ((use_split ? 400 : 1024) + wgs - 1) / max(wgs, 1L)));
             if (split > 1 && kt_total / split < 4) split = max(1, kt_total / 4);
