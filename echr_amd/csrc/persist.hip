@@ -714,20 +714,20 @@ __device__ __forceinline__ f16x8p as_f16x8(float4 v) { return __builtin_bit_cast
 template <typename RowFn>
 __device__ __forceinline__ void fill_bimg_h2(float4* img, float* inv_scale, float* scratch, const float* W, long ld, int K, int ncb, RowFn row_of, int tid) {
     const int ncol = 32 * ncb;
-    // column maxima: 4 threads per column, 128 k each
-    for (int c0 = 0; c0 < ncol; c0 += 64) {
-        const int col = c0 + (tid >> 2), qk = tid & 3;
+    // column maxima: 8 threads per column, 64 k each, all 16 loads of a thread in flight together (K % 4 == 0, rows 16-byte aligned)
+    for (int c0 = 0; c0 < ncol; c0 += 32) {
+        const int col = c0 + (tid >> 3), qk = tid & 7;
+        const float* wp = W + (long)row_of(col) * ld + 64 * qk;
+        float4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (64 * qk + 4 * i < K) ? *reinterpret_cast<const float4*>(wp + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
         float mx = 0.f;
-        if (col < ncol) {
-            const float* wp = W + (long)row_of(col) * ld;
-            for (int k = 128 * qk; k < min(128 * qk + 128, K); k += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(wp + k);
-                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-            }
-        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
         mx = fmaxf(mx, __shfl_xor(mx, 1));
         mx = fmaxf(mx, __shfl_xor(mx, 2));
-        if (col < ncol && qk == 0) {
+        mx = fmaxf(mx, __shfl_xor(mx, 4));
+        if (qk == 0) {
             const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
             int e = (ex == 0 || ex == 255) ? 14 : ex - 127;
             e = max(e, 14 - 126);
@@ -736,22 +736,37 @@ __device__ __forceinline__ void fill_bimg_h2(float4* img, float* inv_scale, floa
         }
     }
     __syncthreads();
-    const int total = 4 * 8 * ncb * 64;          // (w, s, cb, lane); both planes are produced together
-    for (int idx = tid; idx < total; idx += 256) {
-        const int lane = idx & 63, cb = (idx >> 6) % ncb, s_ = ((idx >> 6) / ncb) & 7, w = (idx >> 6) / ncb / 8;
-        const int col = 32 * cb + (lane & 31), k = 128 * w + 16 * s_ + 8 * (lane >> 5);
-        const float sc = scratch[col];
-        const float* wp = W + (long)row_of(col) * ld + k;
-        unsigned hw[8], lw[8];
+    // (w, s, cb, lane) -> both planes; 8 items per thread and pass, their 16 loads in flight together
+    const int total = 4 * 8 * ncb * 64;
+    for (int base0 = 0; base0 < total; base0 += 8 * 256) {
+        float4 x[8][2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            unsigned short hi, lo;
-            split_h2((k + j < K ? wp[j] : 0.f) * sc, hi, lo);
-            hw[j] = hi; lw[j] = lo;
+        for (int i = 0; i < 8; ++i) {
+            const int idx = base0 + tid + 256 * i;
+            const int lane = idx & 63, cb = (idx >> 6) % ncb, s_ = ((idx >> 6) / ncb) & 7, w = (idx >> 6) / ncb / 8;
+            const int col = 32 * cb + (lane & 31), k = 128 * w + 16 * s_ + 8 * (lane >> 5);
+            const float* wp = W + (long)row_of(col) * ld + k;
+            x[i][0] = (idx < total && k < K) ? *reinterpret_cast<const float4*>(wp) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[i][1] = (idx < total && k + 4 < K) ? *reinterpret_cast<const float4*>(wp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const long base = (((long)(w * 8 + s_) * ncb + cb) * 2) * 64 + lane;
-        reinterpret_cast<uint4*>(img)[base] = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
-        reinterpret_cast<uint4*>(img)[base + 64] = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = base0 + tid + 256 * i;
+            if (idx >= total) continue;
+            const int lane = idx & 63, cb = (idx >> 6) % ncb, s_ = ((idx >> 6) / ncb) & 7, w = (idx >> 6) / ncb / 8;
+            const float sc = scratch[32 * cb + (lane & 31)];
+            const float xv[8] = {x[i][0].x, x[i][0].y, x[i][0].z, x[i][0].w, x[i][1].x, x[i][1].y, x[i][1].z, x[i][1].w};
+            unsigned hw[8], lw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned short hi, lo;
+                split_h2(xv[j] * sc, hi, lo);
+                hw[j] = hi; lw[j] = lo;
+            }
+            const long base = (((long)(w * 8 + s_) * ncb + cb) * 2) * 64 + lane;
+            reinterpret_cast<uint4*>(img)[base] = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+            reinterpret_cast<uint4*>(img)[base + 64] = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
+        }
     }
     __syncthreads();
 }
@@ -771,6 +786,7 @@ struct PersistK2 {
 
 template <bool H2>
 __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
+    if (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[15] = __builtin_amdgcn_s_memrealtime();          // kernel entry (diagnostic)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float4* wimg = reinterpret_cast<float4*>(lds);
     float* red = reinterpret_cast<float*>(lds + LDS_W2);          // 16 KB: cross-wave tile sums / cross-row attention partials (8 rows per pass)
@@ -790,21 +806,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
     const bool is_g1 = lb < HG1, is_qw = lb >= HG1 && lb < HG1 + HQ;
     auto cnt = [&](int kind, int t) { return P.cnt + (((long)kind * (S + 1) + t) * 2 + m) * CNT_LINE; };
 
-    if (is_g1) {
-        auto row = [&](int cc) { return (cc >> 3) * PH + 8 * lb + (cc & 7); };       // tile column cc = gate * 8 + unit
-        if (H2) {
-            fill_bimg_h2(wimg, invbA, scr, P.w_hh1, PH, PH, 1, row, tid);
-            fill_bimg_h2(wimg + 4096, invbC, scr, P.w_att, P.ld_att, D, 1, row, tid);
-        } else {
-            fill_bimg32(wimg, P.w_hh1, PH, PH, row, tid);
-            fill_bimg32(wimg + 4096, P.w_att, P.ld_att, D, row, tid);
-        }
-    } else if (is_qw) {
-        auto row = [&](int cc) { return 32 * (lb - HG1) + cc; };
-        if (H2) fill_bimg_h2(wimg, invbA, scr, P.w_h2a, PH, PH, 1, row, tid);
-        else fill_bimg32(wimg, P.w_h2a, PH, PH, row, tid);
-    }
-    // ---- attention operands -> registers (as version 1) ----
+    // ---- attention operands -> registers (as version 1); the raw loads are issued ahead of the weight-image fills so that the two
+    //      set-up phases overlap (both are chains of dependent memory latencies) ----
     const int ar = lb / 3, ap = lb - 3 * ar, an = HR * m + ar;    // row within the half, third, event
     const bool att_live = an < N;
     const int grow_ = 4 * w + (lane >> 4), lr = lane & 15;
@@ -831,9 +834,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
             const float* cr = P.c3d + (row0 + a) * D;
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                const float4 pv = *reinterpret_cast<const float4*>(pr + 4 * h);
-                Pr[i][h] = make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
-                                       __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
+                Pr[i][h] = *reinterpret_cast<const float4*>(pr + 4 * h);
                 const int d = 32 * lr + 4 * h;
                 float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
                 if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -845,6 +846,30 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
         for (int i = 0; i < PSG; ++i)
 #pragma unroll
             for (int h = 0; h < 8; ++h) Pr[i][h] = Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (is_g1) {
+        auto row = [&](int cc) { return (cc >> 3) * PH + 8 * lb + (cc & 7); };       // tile column cc = gate * 8 + unit
+        if (H2) {
+            fill_bimg_h2(wimg, invbA, scr, P.w_hh1, PH, PH, 1, row, tid);
+            fill_bimg_h2(wimg + 4096, invbC, scr, P.w_att, P.ld_att, D, 1, row, tid);
+        } else {
+            fill_bimg32(wimg, P.w_hh1, PH, PH, row, tid);
+            fill_bimg32(wimg + 4096, P.w_att, P.ld_att, D, row, tid);
+        }
+    } else if (is_qw) {
+        auto row = [&](int cc) { return 32 * (lb - HG1) + cc; };
+        if (H2) fill_bimg_h2(wimg, invbA, scr, P.w_h2a, PH, PH, 1, row, tid);
+        else fill_bimg32(wimg, P.w_h2a, PH, PH, row, tid);
+    }
+    if (att_live) {
+#pragma unroll
+        for (int i = 0; i < PSG; ++i)
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const float4 pv = Pr[i][h];
+                Pr[i][h] = make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
+                                       __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
+            }
     }
     if (H2 && att_live) {
         // bound on |context| of this event = max |C3D| over its slots: one atomic max per workgroup (non-negative floats order like uints);
@@ -864,6 +889,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
     const u32 XBH = HR * PH * 4;                                  // bytes of one half's [32 x 512] exchange operand
     const long XHALF = (long)HR * PH;                             // floats
     const int srole = b == 0 ? 0 : (b == HG1 ? 1 : (b == HG1 + HQ ? 2 : -1));
+    if (P.stamps && b == 0 && tid == 0) P.stamps[14] = __builtin_amdgcn_s_memrealtime();          // set-up done
 
     for (int t = 0; t < S; ++t) {
         if (srole >= 0) STAMP(srole, 0);
@@ -1793,6 +1819,7 @@ __device__ __forceinline__ void fill_bimg32_t(float4* img, const float* W, long 
 }
 
 __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd2_kernel(PersistB P) {
+    if (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[15] = __builtin_amdgcn_s_memrealtime();          // kernel entry (diagnostic)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float4* wimg = reinterpret_cast<float4*>(lds);
     float* red = reinterpret_cast<float*>(lds + LDS_W2);          // 16 KB
@@ -1851,6 +1878,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd2_kernel(PersistB P
     const u32 XBH = HR * PH * 4;
     const long XHALF = (long)HR * PH;
     const int srole = b == 0 ? 0 : (b == HGD ? 1 : (b == HGD + HP ? 2 : -1));
+    if (P.stamps && b == 0 && tid == 0) P.stamps[14] = __builtin_amdgcn_s_memrealtime();          // set-up done
 
     for (int t = S - 1; t >= -1; --t) {
         if (srole >= 0) BSTAMP(srole, 0);

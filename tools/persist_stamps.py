@@ -51,6 +51,10 @@ if BWD:
     rl = ((0, 'GD wg 0'), (1, 'P wg 32'), (2, 'att wg 160'), (3, 'lstm-bwd wg 0'))
 else:
     rl = ((0, 'gate wg'), (1, 'q wg'), (2, 'att-only wg'), (3, 'lstm wg 0'))
+raw = st[0, 0]
+first = st[0, S - 1, 0] if BWD else st[0, 0, 0]
+last = st[0, 0, 0] if BWD else st[0, S - 1, 0]
+print('workgroup 0: set-up %.2f us (entry -> ready), ready -> first step stamp %.2f us, first -> last step stamp %.2f us' % (raw[14] - raw[15], first - raw[14], last - first))
 for role, rn in rl:
     a = st[role]
     if BWD:
