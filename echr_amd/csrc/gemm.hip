@@ -496,6 +496,7 @@ struct H2PackArgs { H2PackJob job[H2_MAX_JOBS]; int start[H2_MAX_JOBS + 1]; int 
 // (row, 16-byte slot) = 8 consecutive k of every chunk and reads them as two float4.  Row-contiguous sources (a transposing pack) go
 // through an LDS tile filled by float4 reads along the rows.  The whole segment is held in registers (2 x 8 x H2_SEG floats per thread)
 // so the source is read once.
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
 __device__ __forceinline__ float h2_rowmax(const float (&v)[8], float mx) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(v[j]));
@@ -548,6 +549,11 @@ __global__ __launch_bounds__(256) void h2_pack_kernel(H2PackArgs args) {
             if (c < nch && r < jb.R) {
                 if (vec && k + 8 <= jb.K) {
                     const float4 x0 = *reinterpret_cast<const float4*>(srow + k), x1 = *reinterpret_cast<const float4*>(srow + k + 4);
+                    v[c][0] = x0.x; v[c][1] = x0.y; v[c][2] = x0.z; v[c][3] = x0.w; v[c][4] = x1.x; v[c][5] = x1.y; v[c][6] = x1.z; v[c][7] = x1.w;
+                } else if (k + 8 <= jb.K) {
+                    // rows that are only 4-byte aligned (K = 5001): still two 16-byte loads where the target allows dword-aligned
+                    // dwordx4 access, four dword loads each otherwise -- the compiler decides from the declared alignment
+                    const F4U x0 = *reinterpret_cast<const F4U*>(srow + k), x1 = *reinterpret_cast<const F4U*>(srow + k + 4);
                     v[c][0] = x0.x; v[c][1] = x0.y; v[c][2] = x0.z; v[c][3] = x0.w; v[c][4] = x1.x; v[c][5] = x1.y; v[c][6] = x1.z; v[c][7] = x1.w;
                 } else {
 #pragma unroll
