@@ -190,8 +190,8 @@ def gpu_leg(args, rank, world, local_rank):
                  1: ('att_fwd', 'att_score_kernel + att_context_kernel', 'hbm'),
                  2: ('att_bwd_kernel', 'att_bwd_kernel', 'hbm'),
                  3: ('att_post_kernel', 'att_post_kernel', 'valu'),
-                 9: ('dec_persist_kernels', 'dec_persist_att2_kernel<true> || dec_persist_lstm_h2_kernel (forward) and dec_persist_att_bwd2_kernel || '
-                                            'dec_persist_lstm_bwd_kernel (reverse): each pair = two concurrent launches covering all S steps', 'mfma')}
+                 9: ('dec_persist_kernels', 'dec_persist_fwd_kernel<true> (forward) and dec_persist_bwd_kernel (reverse): each ONE launch of 256 workgroups '
+                                            '(attention chain on 192, the two plain LSTM streams on 64) covering all S steps', 'mfma')}
         n_it = max(2, min(args.steps, 5))
         stats = {}
         for k, (name, sym, bound) in kinds.items():

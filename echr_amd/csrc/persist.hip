@@ -227,12 +227,12 @@ __device__ __forceinline__ float mask_h(const DropCfg& dh, int n, int j, int k, 
 __device__ __forceinline__ float mask_o(const DropCfg& dout, int n, int j, int k, int t) { return drop_mult(dout, (unsigned)(n * 3 * PH + k * PH + j), (unsigned)t, 4u); }   // SITE_OUT
 
 // ---- kernel 1: the two plain LSTM streams (0: event context, 2: scene context), 32 workgroups of 16 hidden units each -------------
-__global__ __launch_bounds__(256, 1) void dec_persist_lstm_kernel(PersistK P) {
+__device__ __forceinline__ void dec_persist_lstm_body(const PersistK& P, const int bid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float4* wimg = reinterpret_cast<float4*>(lds);
     float* red = reinterpret_cast<float*>(lds + LDS_W);
     int* flag = reinterpret_cast<int*>(lds + LDS_W + LDS_RED);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = bid, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_s0 = b < NS;
     const int N = P.N, S = P.S;
     const int k = is_s0 ? 0 : 2, bs = is_s0 ? b : b - NS, ck = is_s0 ? C_H0 : C_H2;
@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_kernel(PersistK P) {
         }
     }
 }
+__global__ __launch_bounds__(256, 1) void dec_persist_lstm_kernel(PersistK P) { dec_persist_lstm_body(P, blockIdx.x); }
 
 // ---- kernel 2: the attention chain (stream 1): 128 gate + 32 q + 32 attention-only workgroups; all 192 hold attention operands ----
 __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
@@ -785,8 +786,8 @@ struct PersistK2 {
 };
 
 template <bool H2>
-__global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
-    if (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[15] = __builtin_amdgcn_s_memrealtime();          // kernel entry (diagnostic)
+__device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const int bid) {
+    if (P.stamps && bid == 0 && threadIdx.x == 0) P.stamps[15] = __builtin_amdgcn_s_memrealtime();          // kernel entry (diagnostic)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float4* wimg = reinterpret_cast<float4*>(lds);
     float* red = reinterpret_cast<float*>(lds + LDS_W2);          // 16 KB: cross-wave tile sums / cross-row attention partials (8 rows per pass)
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
     float* cmx = invAt + 32;
     float* scr = cmx + 32;
     int* flag = reinterpret_cast<int*>(lds + LDS_W2 + LDS_RED2);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = bid, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = b / HWG, lb = b - m * HWG;
     const int N = P.N, D = P.D, S = P.S;
     if (HR * m >= N) return;                                     // this half machine has no events
@@ -1212,6 +1213,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
         }
     }
 }
+template <bool H2>
+__global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) { dec_persist_att2_body<H2>(P, blockIdx.x); }
 
 // ==========================================================================================================================
 // fp16-PAIR ("h2") products inside the persistent forward kernels.  The recurrent activations are bounded (|h| <= dropout scale), so
@@ -1223,14 +1226,14 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) {
 // ==========================================================================================================================
 // ---- the two plain LSTM streams, h2 products: 64 rows x 64 gate columns (16 units) per workgroup ----
 // h exchange layout (per timestep, 128 KB): [plane 2][k / 8 (64)][row 64][8 halves]
-__global__ __launch_bounds__(256, 1) void dec_persist_lstm_h2_kernel(PersistK P) {
+__device__ __forceinline__ void dec_persist_lstm_h2_body(const PersistK& P, const int bid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float4* wimg = reinterpret_cast<float4*>(lds);                    // 128 KB
     float* red = reinterpret_cast<float*>(lds + LDS_W);               // 16 KB: [4 waves][32][32] tile partials / staging of the exchanged h
     float* invb = red + 4096;                                         // [64] inverse column scales
     float* scr = invb + 64;                                           // [64] scratch
     int* flag = reinterpret_cast<int*>(lds + LDS_W + LDS_RED + 1024);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = bid, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_s0 = b < NS;
     const int N = P.N, S = P.S;
     const int k = is_s0 ? 0 : 2, bs = is_s0 ? b : b - NS, ck = is_s0 ? C_H0 : C_H2;
@@ -1345,6 +1348,18 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_h2_kernel(PersistK P)
             }
         }
     }
+}
+__global__ __launch_bounds__(256, 1) void dec_persist_lstm_h2_kernel(PersistK P) { dec_persist_lstm_h2_body(P, blockIdx.x); }
+
+// ---- the forward pair as ONE launch: workgroups [0, 2 HWG) run the attention chain, [2 HWG, 2 HWG + 2 NS) the two plain LSTM streams.
+// Two concurrent launches on two HIP streams need two hardware queues; a process that owns more streams than the runtime has queues
+// (collective streams of a data-parallel run, user streams) can find both streams on one queue, and the pair then runs back to back.
+// One grid of 256 workgroups has no such dependence.
+template <bool H2>
+__global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(PersistK2 P2, PersistK P1) {
+    if (blockIdx.x < 2 * HWG) dec_persist_att2_body<H2>(P2, blockIdx.x);
+    else if (H2) dec_persist_lstm_h2_body(P1, blockIdx.x - 2 * HWG);
+    else dec_persist_lstm_body(P1, blockIdx.x - 2 * HWG);
 }
 
 // ==========================================================================================================================
@@ -1470,12 +1485,12 @@ __device__ __forceinline__ CellGrad cell_grad4(const PersistB& P, const GradIn& 
 }
 
 // ---- backward kernel 1: the two plain LSTM streams ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P) {
+__device__ __forceinline__ void dec_persist_lstm_bwd_body(const PersistB& P, const int bid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float4* wimg = reinterpret_cast<float4*>(lds);
     float* red = reinterpret_cast<float*>(lds + LDS_W);
     int* flag = reinterpret_cast<int*>(lds + LDS_W + LDS_RED);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = bid, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_s0 = b < NS;
     const int N = P.N, S = P.S;
     const int k = is_s0 ? 0 : 2, bs = is_s0 ? b : b - NS, ck = is_s0 ? CB_G0 : CB_G2;
@@ -1526,6 +1541,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P
         }
     }
 }
+__global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P) { dec_persist_lstm_bwd_body(P, blockIdx.x); }
 
 // ---- backward kernel 2: the attention chain ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P) {
@@ -1786,6 +1802,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P)
 constexpr int HGD = 16, HP = 64;
 constexpr int LDS_REDB2 = 16 * 1024 + 2048 + 2048 + 512;
 constexpr int LDS_BYTES_ATTB2 = LDS_W2 + LDS_REDB2 + 256;
+constexpr int LDS_BYTES_FWD = LDS_BYTES_ATT2 > LDS_BYTES_LSTM + 1024 ? LDS_BYTES_ATT2 : LDS_BYTES_LSTM + 1024;       // one-launch pairs: the larger of the two roles
+constexpr int LDS_BYTES_BWD = LDS_BYTES_ATTB2 > LDS_BYTES_LSTM ? LDS_BYTES_ATTB2 : LDS_BYTES_LSTM;
 constexpr long XSTEPH = 4L * HR * PH;          // floats of one half's [4 gates][32 rows x 512] exchange operand
 
 struct PersistLayoutB2 { long cnt, xdq, xda, xdh, zero_begin, xdg, total; };
@@ -1818,15 +1836,15 @@ __device__ __forceinline__ void fill_bimg32_t(float4* img, const float* W, long 
     }
 }
 
-__global__ __launch_bounds__(256, 1) void dec_persist_att_bwd2_kernel(PersistB P) {
-    if (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[15] = __builtin_amdgcn_s_memrealtime();          // kernel entry (diagnostic)
+__device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, const int bid) {
+    if (P.stamps && bid == 0 && threadIdx.x == 0) P.stamps[15] = __builtin_amdgcn_s_memrealtime();          // kernel entry (diagnostic)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float4* wimg = reinterpret_cast<float4*>(lds);
     float* red = reinterpret_cast<float*>(lds + LDS_W2);          // 16 KB
     float* sal = red + 4096;                                      // [512] alpha
     float* sat = sal + PH;                                        // [512] saved context row of the current step
     int* flag = reinterpret_cast<int*>(lds + LDS_W2 + LDS_REDB2);
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = bid, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = b / HWG, lb = b - m * HWG;
     const int N = P.N, D = P.D, S = P.S;
     if (HR * m >= N) return;
@@ -2057,6 +2075,13 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd2_kernel(PersistB P
         }
     }
 }
+__global__ __launch_bounds__(256, 1) void dec_persist_att_bwd2_kernel(PersistB P) { dec_persist_att_bwd2_body(P, blockIdx.x); }
+
+// ---- the reverse pair as one launch (see dec_persist_fwd_kernel) ----
+__global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(PersistB P2, PersistB P1) {
+    if (blockIdx.x < 2 * HWG) dec_persist_att_bwd2_body(P2, blockIdx.x);
+    else dec_persist_lstm_bwd_body(P1, blockIdx.x - 2 * HWG);
+}
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
 struct PersistHost { u32* abort_dev = nullptr; u32* flag_host = nullptr; u32* flag_dev = nullptr; int cus = 0; bool ok = false; bool init = false; unsigned long long* stamps = nullptr; int stamps_S = 0;
@@ -2080,15 +2105,26 @@ static PersistHost& phost() {
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATTB2) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
-        int lo = 0, hi = 0;
-        good = good && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
-        good = good && hipStreamCreateWithPriority(&h.side, hipStreamNonBlocking, hi) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&h.fork, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&h.join, hipEventDisableTiming) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_BWD) == hipSuccess;
         (void)hipGetLastError();
         h.ok = good;
     }
     return h;
+}
+// the second stream of the two-launch form, created on first use only: every HIP stream of a process competes for the runtime's few
+// hardware queues (a fifth active stream made the whole iteration 2x slower on this path), and the default one-launch form needs none
+static bool side_stream(PersistHost& h) {
+    if (!h.side) {
+        int lo = 0, hi = 0;
+        bool good = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+        good = good && hipStreamCreateWithPriority(&h.side, hipStreamNonBlocking, hi) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&h.fork, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&h.join, hipEventDisableTiming) == hipSuccess;
+        if (!good) { (void)hipGetLastError(); h.side = nullptr; }
+    }
+    return h.side != nullptr;
 }
 
 // sticky asynchronous error of an earlier persistent launch (a bounded spin timed out): reported once, at the next library call
@@ -2165,8 +2201,15 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     const double obytes = 4.0 * (double)a->N * a->A * (PH + a->D);
     const double sbytes = 4.0 * (double)a->S * a->N * (3.0 * 4 * PH + 3.0 * 2 * PH + PH + PH + a->A + a->D);
     ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), wbytes + obytes + sbytes, st);
-    // the two plain LSTM streams recur on a second HIP stream, concurrently with the attention chain (192 + 64 workgroups = 256 CUs;
+    if (split && config().persist_merge) {
+        // one launch of 192 + 64 workgroups (no dependence on two hardware queues being free)
+        if (config().persist_h2) hipLaunchKernelGGL(dec_persist_fwd_kernel<true>, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
+        else hipLaunchKernelGGL(dec_persist_fwd_kernel<false>, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
+        return check_launch("dec_persist_fwd");
+    }
+    // two launches: the two plain LSTM streams recur on a second HIP stream, concurrently with the attention chain (192 + 64 workgroups = 256 CUs;
     // neither kernel waits on the other, so any residency order makes progress)
+    ECHR_REQUIRE(side_stream(h), "persist_fwd: second stream unavailable");
     if (hipEventRecord(h.fork, st) != hipSuccess || hipStreamWaitEvent(h.side, h.fork, 0) != hipSuccess) { set_error("persist_fwd: fork failed"); return -5; }
     if (config().persist_h2) hipLaunchKernelGGL(dec_persist_lstm_h2_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM + 1024, h.side, K);
     else hipLaunchKernelGGL(dec_persist_lstm_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM, h.side, K);
@@ -2220,6 +2263,11 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
     const double obytes = 4.0 * (double)a->N * a->A * (PH + a->D);
     const double sbytes = 4.0 * (double)a->S * a->N * (3.0 * 4 * PH + 3.0 * 2 * PH + PH + a->A + a->D + PH + 3.0 * 4 * PH + PH + a->A);
     ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), wbytes + obytes + sbytes, st);
+    if (split && config().persist_merge) {
+        hipLaunchKernelGGL(dec_persist_bwd_kernel, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_BWD, st, K2, K);
+        return check_launch("dec_persist_bwd");
+    }
+    ECHR_REQUIRE(side_stream(h), "persist_bwd: second stream unavailable");
     if (hipEventRecord(h.fork, st) != hipSuccess || hipStreamWaitEvent(h.side, h.fork, 0) != hipSuccess) { set_error("persist_bwd: fork failed"); return -5; }
     hipLaunchKernelGGL(dec_persist_lstm_bwd_kernel, dim3(2 * NS), dim3(256), LDS_BYTES_LSTM, h.side, K);
     if (int rc = check_launch("dec_persist_lstm_bwd")) return rc;

@@ -347,6 +347,8 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *   "persist_split" 0/1 (default 1, ECHR_PERSIST_SPLIT) attention chain as two half-chip machines of 32 event rows (0: one machine of 64)
  *   "persist_h2"  0/1  (default 1, ECHR_PERSIST_H2) fp16-pair (fp32-grade) MFMA products in the forward persistent kernels (0: exact
  *                      fp32 MFMAs); the reverse kernels always use fp32 MFMAs
+ *   "persist_merge" 0/1 (default 1, ECHR_PERSIST_MERGE) each direction's pair (attention chain + the two plain LSTM streams) as ONE launch
+ *                      of 256 workgroups on the caller's stream (0: two concurrent launches on two streams; needs two free hardware queues)
  *   "persist_stamps" 0/1/2 diagnostic phase stamps of the forward (1) / reverse (2) pair, see echr_persist_read_stamps
  *   "gemm_tile", "gemm_split"  tuning overrides of the GEMM tile / split-K heuristics (0 = heuristics; tools/gemm_bench.py only) */
 int echr_config_set(const char* key, int32_t value);

@@ -17,7 +17,7 @@ def load(sub, counter):
         if r['Counter_Name'] != counter:
             continue
         k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('echr::', '')
-        k = k.split('<')[0] if k.startswith(('gemm_f32_kernel', 'gemm_h2_kernel', 'gemm_h2m16_kernel', 'dec_persist_att2_kernel', 'att_post_kernel')) else k
+        k = k.split('<')[0] if k.startswith(('gemm_f32_kernel', 'gemm_h2_kernel', 'gemm_h2m16_kernel', 'dec_persist', 'att_post_kernel')) else k
         k = 'gemm_h2_kernel' if k == 'gemm_h2m16_kernel' else k          # the two MFMA shapes of the h2 product: one class in bench.py
         agg[k] += float(r['Counter_Value'])
         cnt[k] += 1
