@@ -1906,10 +1906,6 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
             DropM dm;
             if (t >= 0) { in = load_grad_in(P, 1, t, gn, u0); dm = drop_masks4(P, 1, t, gn, u0); }
             float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < S - 1 && t >= 0) {
-                if (!wait_total(P, cnt(CB_HH, t + 1), HP, flag, 500000u + t + 1)) return;
-                rec = ld16_sc1(mk_rsrc(P.XDH + ((long)(t + 1) * 2 + m) * XHALF, XBH), (u32)((((4 * lb + (u4 >> 3)) * HR + gr) * 8 + (u4 & 7)) * 4));
-            }
             if (t < S - 1) {
                 if (!wait_total(P, cnt(CB_DQ, t + 1), HWG, flag, 400000u + t + 1)) return;
                 if (srole >= 0) BSTAMP(srole, 1);
@@ -1937,6 +1933,10 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
 #pragma unroll
                     for (int ww = 0; ww < 4; ++ww) rec = f4add(rec, *reinterpret_cast<const float4*>(rp + ww * HR * 32));
                     if (srole >= 0) BSTAMP(srole, 2);
+                    // + d G1(t+1) . W_hh1: the product workgroups form that tile behind their attention role of step t+1 (it is off their
+                    // critical path there), so it lands while the d q product above runs
+                    if (!wait_total(P, cnt(CB_HH, t + 1), HP, flag, 500000u + t + 1)) return;
+                    rec = f4add(rec, ld16_sc1(mk_rsrc(P.XDH + ((long)(t + 1) * 2 + m) * XHALF, XBH), (u32)((((4 * lb + (u4 >> 3)) * HR + gr) * 8 + (u4 & 7)) * 4)));
                     if (srole >= 0) BSTAMP(srole, 3);
                 }
             }
@@ -1958,32 +1958,31 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
             }
         }
         if (t < 0) break;
-        // ============ P: d ATT(t) tile (critical), then the d h1 tile for step t-1; the four k-slices add atomically ============
+        // ============ P: d ATT(t) tile (critical) now; the d h1 tile of the same fragments behind the attention role ============
+        float4 pa[16];
+        auto p_tile = [&](int which) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+            mfma_tile32(acc, pa, wimg + which * 4096 + w * 1024, lane);
+            acc_to_lds32(acc, red, w, lane);
+            __syncthreads();
+            // element e of the tile in exchange order ([k8 of the tile][row][8]) is contiguous over the lanes: full-rate atomics
+            float* xo = (which == 0 ? P.XDA : P.XDH) + ((long)t * 2 + m) * XHALF + (long)4 * pct * HR * 8;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int e = tid + 256 * e4, k8l = e >> 8, r = (e >> 3) & 31, cc = 8 * k8l + (e & 7), o = r * 32 + cc;
+                atomicAdd(xo + e, red[o] + red[HR * 32 + o] + red[2 * HR * 32 + o] + red[3 * HR * 32 + o]);
+            }
+            if (which == 0 && srole >= 0) BSTAMP(srole, 7);
+            publish(cnt(which == 0 ? CB_DA : CB_HH, t));
+            if (which == 0 && srole >= 0) BSTAMP(srole, 8);
+        };
         if (is_p) {
             if (!wait_total(P, cnt(CB_DG, t), HGD, flag, 600000u + t)) return;
             if (srole >= 0) BSTAMP(srole, 6);
-            float4 a[16];
-            load_afrag32(a, mk_rsrc(P.XDG + ((long)t * 2 + m) * XSTEPH + (long)pks * XHALF, XBH), w, lane);
-#pragma unroll
-            for (int which = 0; which < 2; ++which) {
-                if (which == 1 && t == 0) break;
-                f32x16 acc;
-#pragma unroll
-                for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-                mfma_tile32(acc, a, wimg + which * 4096 + w * 1024, lane);
-                acc_to_lds32(acc, red, w, lane);
-                __syncthreads();
-                // element e of the tile in exchange order ([k8 of the tile][row][8]) is contiguous over the lanes: full-rate atomics
-                float* xo = (which == 0 ? P.XDA : P.XDH) + ((long)t * 2 + m) * XHALF + (long)4 * pct * HR * 8;
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    const int e = tid + 256 * e4, k8l = e >> 8, r = (e >> 3) & 31, cc = 8 * k8l + (e & 7), o = r * 32 + cc;
-                    atomicAdd(xo + e, red[o] + red[HR * 32 + o] + red[2 * HR * 32 + o] + red[3 * HR * 32 + o]);
-                }
-                if (which == 0 && srole >= 0) BSTAMP(srole, 7);
-                publish(cnt(which == 0 ? CB_DA : CB_HH, t));
-                if (srole >= 0) BSTAMP(srole, which == 0 ? 8 : 9);
-            }
+            load_afrag32(pa, mk_rsrc(P.XDG + ((long)t * 2 + m) * XSTEPH + (long)pks * XHALF, XBH), w, lane);
+            p_tile(0);
         }
         // ============ attention backward of step t (all workgroups) ============
         {
@@ -2072,6 +2071,12 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
             if (srole >= 0) BSTAMP(srole, 11);
             publish(cnt(CB_DQ, t));
             if (srole >= 0) BSTAMP(srole, 12);
+        }
+        // the d h1 tile (W_hh1 columns) of the fragments fetched above: its consumers (the gate-gradient workgroups of step t-1) take
+        // it after their d q product, so it runs here instead of holding back this workgroup's attention role
+        if (is_p && t > 0) {
+            p_tile(1);
+            if (srole >= 0) BSTAMP(srole, 9);
         }
     }
 }

@@ -45,7 +45,7 @@ names = {0: ['step', 'waitH1', 'mfmaA', '-', '-', 'waitQ', 'att', 'pubC', 'waitC
          3: ['step', 'waitH', 'mfma', 'gate', 'pub']}
 if BWD:
     names = {0: ['step', 'waitDQ', 'mfmaQ', 'waitHH', 'gate', 'pubDG', '-', '-', '-', '-', 'waitDA', 'att', 'pubDQ'],
-             1: ['step', '-', '-', '-', '-', '-', 'waitDG', 'mfmaA', 'pubDA', 'tileB+pubHH', 'waitDA', 'att', 'pubDQ'],
+             1: ['step', '-', '-', '-', '-', '-', 'waitDG', 'mfmaA', 'pubDA', '-', 'waitDA', 'att', 'pubDQ'],
              2: ['step', '-', '-', '-', '-', '-', '-', '-', '-', '-', 'waitDA', 'att', 'pubDQ'],
              3: ['step', 'waitG', 'mfma', 'gate', 'pub']}
     rl = ((0, 'GD wg 0'), (1, 'P wg 32'), (2, 'att wg 160'), (3, 'lstm-bwd wg 0'))
@@ -70,4 +70,6 @@ for role, rn in rl:
         d = (a[3:S - 1, i] - a[3:S - 1, prev_i]).mean()
         out.append('%s %.2f' % (names[role][i], d))
         prev_i = i
+    if BWD and role == 1:          # the d h1 tile runs behind the attention role (stamp 9 follows stamp 12)
+        out.append('tileB+pubHH %.2f' % (a[3:S - 1, 9] - a[3:S - 1, 12]).mean())
     print('   ' + ' | '.join(out))
