@@ -1376,11 +1376,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(PersistK2 P2, P
 // The plain LSTM streams 0 / 2 run in their own 64-workgroup launch (one hand-off per step: a workgroup owns 16 units, ingests all of
 // d G_k(t+1) and multiplies by its 16 columns of W_hh_k).  Hand-off protocol, abort handling and MFMA fragment scheme: as forward.
 // ==========================================================================================================================
-enum { CB_DG = 0, CB_DA = 1, CB_HH = 2, CB_DQ = 3, CB_G0 = 4, CB_G2 = 5, CB_KINDS = 6 };
+enum { CB_DG = 0, CB_DA = 1, CB_HH = 2, CB_DQ = 3, CB_G0 = 4, CB_G2 = 5, CB_P0 = 6, CB_P2 = 7, CB_KINDS = 8 };
+constexpr int XPSTEP = 32 * 4 * PROWS * 16;     // floats per timestep of an LSTM stream's partial-product exchange [dst workgroup][source k group][row][16]
 constexpr int NGD = 32, NP = 128;
 constexpr int XSTEP4 = 4 * PROWS * PH;          // floats per timestep of a [4][512-wide] exchange buffer
 
-struct PersistLayoutB { long cnt, xdq, zero_end, xdg, xda, xdh, xg0, xg2, total; };
+struct PersistLayoutB { long cnt, xdq, zero_end, xdg, xda, xdh, xg0, xg2, xp0, xp2, total; };
 static PersistLayoutB persist_layout_b(int S) {
     PersistLayoutB L;
     long off = 0;
@@ -1393,6 +1394,8 @@ static PersistLayoutB persist_layout_b(int S) {
     L.xdg = take((long)S * XSTEP4);
     L.xg0 = take((long)S * XSTEP4);
     L.xg2 = take((long)S * XSTEP4);
+    L.xp0 = take((long)S * XPSTEP);
+    L.xp2 = take((long)S * XPSTEP);
     L.total = off;
     return L;
 }
@@ -1405,7 +1408,8 @@ struct PersistB {
     const float* GATES[3]; const float* CS[3]; const float* QS; const float* WT; const float* ATT;
     const float* DOUT;
     float* DG[3]; float* DQ; float* DSC;
-    float *XDG, *XDA, *XDH, *XDQ, *XG0, *XG2;
+    float *XDG, *XDA, *XDH, *XDQ, *XG0, *XG2, *XP0, *XP2;
+    int lstm_kgroups;
     u32* cnt; u32* abort_word; u32* host_flag;
     unsigned long long* stamps;
     DropCfg dh, dout;
@@ -1541,7 +1545,89 @@ __device__ __forceinline__ void dec_persist_lstm_bwd_body(const PersistB& P, con
         }
     }
 }
-__global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P) { dec_persist_lstm_bwd_body(P, blockIdx.x); }
+// The same role with the contraction split over workgroup groups: workgroup bs = 4 cg + kg multiplies the k group kg (= gate kg, 512 gate
+// columns) of d G(t+1) by W_hh[kg-th 512 rows][64 units of column group cg] and hands the three [64 x 16] partial tiles it does not own to
+// their owners (the workgroups of the same cg).  It ingests 128 KB per step instead of 512 KB (the per-CU ingest rate, not the fp32 MFMA, had
+// set the step: 15 us), at the price of a second, small hand-off per step.
+__device__ __forceinline__ void dec_persist_lstm_bwd_kg_body(const PersistB& P, const int bid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float4* wimg = reinterpret_cast<float4*>(lds);
+    float* red = reinterpret_cast<float*>(lds + LDS_W);
+    int* flag = reinterpret_cast<int*>(lds + LDS_W + LDS_RED);
+    const int b = bid, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_s0 = b < NS;
+    const int N = P.N, S = P.S;
+    const int k = is_s0 ? 0 : 2, bs = is_s0 ? b : b - NS, ck = is_s0 ? CB_G0 : CB_G2, cp = is_s0 ? CB_P0 : CB_P2;
+    const int kg = bs & 3, cg = bs >> 2;
+    float* XG = is_s0 ? P.XG0 : P.XG2;
+    float* XP = is_s0 ? P.XP0 : P.XP2;
+    auto cnt = [&](int kind, int t) { return P.cnt + ((long)kind * (S + 1) + t) * CNT_LINE; };
+    // B[k = c][col = u]: rows kg * 512 + [0, 512) of W_hh_k, columns 64 cg + 16 ct + [0, 16), ct = 0..3 (tile ct belongs to workgroup 4 cg + ct)
+    for (int ct = 0; ct < 4; ++ct) fill_bimg_t(wimg + ct * 2048, P.w_hh[k] + (long)kg * PH * PH + 64 * cg + 16 * ct, PH, PH, 16, tid);
+    __syncthreads();
+    const int gn = tid >> 2, gq = tid & 3, u0 = 16 * bs + 4 * gq;
+    float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const u32 XB = PROWS * PH * 4;
+    for (int t = S - 1; t >= 0; --t) {
+        if (b == 0) BSTAMP(3, 0);
+        const GradIn in = load_grad_in(P, k, t, gn, u0);
+        const DropM dm = drop_masks4(P, k, t, gn, u0);
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < S - 1) {
+            if (!wait_total(P, cnt(ck, t + 1), NS, flag, 5000u * (ck + 1) + t)) return;
+            if (b == 0) BSTAMP(3, 1);
+            f32x4 acc[4][4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) acc[ct][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                float4 a[4][8];
+                load_afrag<1>(a, mk_rsrc(XG + (long)(t + 1) * XSTEP4 + (long)kg * PROWS * PH, XB), w, lane);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) mfma_tile(acc[ct], a, wimg + ct * 2048 + w * 512, lane);
+            }
+            if (b == 0) BSTAMP(3, 2);
+            // cross-wave sums, one column tile at a time through the 16 KB buffer; foreign tiles leave for their owners
+            const __amdgpu_buffer_rsrc_t rp = mk_rsrc(XP + (long)(t + 1) * XPSTEP, (u32)(XPSTEP * 4));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                acc_to_lds(acc[ct], red, w, lane);
+                __syncthreads();
+                const float* rq = red + gn * 16 + 4 * gq;
+                float4 v = *reinterpret_cast<const float4*>(rq);
+#pragma unroll
+                for (int ww = 1; ww < 4; ++ww) v = f4add(v, *reinterpret_cast<const float4*>(rq + ww * PROWS * 16));
+                if (ct == kg) rec = v;
+                else st16_sc1(rp, (u32)(((((4 * cg + ct) * 4 + kg) * PROWS + gn) * 16 + 4 * gq) * 4), v);
+                __syncthreads();
+            }
+            publish(cnt(cp, t + 1));
+            if (!wait_total(P, cnt(cp, t + 1), NS, flag, 7000u * (cp + 1) + t)) return;
+#pragma unroll
+            for (int src = 0; src < 4; ++src)
+                if (src != kg) rec = f4add(rec, ld16_sc1(rp, (u32)((((bs * 4 + src) * PROWS + gn) * 16 + 4 * gq) * 4)));
+        }
+        const CellGrad cgd = cell_grad4(P, in, dm, rec, dc);
+        dc = cgd.dc;
+        // exchange layout [gate][unit / 16][n][16]
+        const __amdgpu_buffer_rsrc_t rx = mk_rsrc(XG + (long)t * XSTEP4, 4 * XB);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) st16_sc1(rx, (u32)((((g * 32 + bs) * PROWS + gn) * 16 + 4 * gq) * 4), cgd.dg[g]);
+        if (b == 0) BSTAMP(3, 3);
+        publish(cnt(ck, t));
+        if (b == 0) BSTAMP(3, 4);
+        if (gn < N) {
+            float* dgp = P.DG[k] + ((long)t * N + gn) * 4 * PH + u0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dgp + g * PH) = cgd.dg[g];
+        }
+    }
+}
+__global__ __launch_bounds__(256, 1) void dec_persist_lstm_bwd_kernel(PersistB P) {
+    if (P.lstm_kgroups) dec_persist_lstm_bwd_kg_body(P, blockIdx.x);
+    else dec_persist_lstm_bwd_body(P, blockIdx.x);
+}
 
 // ---- backward kernel 2: the attention chain ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd_kernel(PersistB P) {
@@ -2085,6 +2171,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd2_kernel(PersistB P
 // ---- the reverse pair as one launch (see dec_persist_fwd_kernel) ----
 __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(PersistB P2, PersistB P1) {
     if (blockIdx.x < 2 * HWG) dec_persist_att_bwd2_body(P2, blockIdx.x);
+    else if (P1.lstm_kgroups) dec_persist_lstm_bwd_kg_body(P1, blockIdx.x - 2 * HWG);
     else dec_persist_lstm_bwd_body(P1, blockIdx.x - 2 * HWG);
 }
 
@@ -2245,7 +2332,8 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
     float* x2 = B.xws;                                  // version-2 layout first (its zeroed region last), version 1 behind it
     float* x = split ? x2 + L2.total : B.xws;
     K.cnt = reinterpret_cast<u32*>(x + L.cnt); K.XDQ = x + L.xdq; K.XDG = x + L.xdg; K.XDA = x + L.xda; K.XDH = x + L.xdh;
-    K.XG0 = x + L.xg0; K.XG2 = x + L.xg2;
+    K.XG0 = x + L.xg0; K.XG2 = x + L.xg2; K.XP0 = x + L.xp0; K.XP2 = x + L.xp2;
+    K.lstm_kgroups = config().persist_kgroups;
     K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
     K.dh = dh; K.dout = dout;
     K.stamps = nullptr;

@@ -554,16 +554,18 @@ def test_persistent_recurrence_equals_launch_path(case):
         # of 256 workgroups; `two_launch` runs each pair as two concurrent launches on two streams, `unsplit` the 64-row machine
         for name, v, vb, sp, h2, mg in (('launch', 0, 0, 1, 1, 1), ('persist', 1, 1, 1, 1, 1), ('persist2', 1, 1, 1, 1, 1), ('fwd_only', 1, 0, 1, 1, 1),
                                         ('bwd_only', 0, 1, 1, 1, 1), ('unsplit', 1, 1, 0, 1, 1), ('f32_products', 1, 1, 1, 0, 1),
-                                        ('two_launch', 1, 1, 1, 1, 0), ('two_launch_f32', 1, 1, 1, 0, 0)):
+                                        ('two_launch', 1, 1, 1, 1, 0), ('two_launch_f32', 1, 1, 1, 0, 0), ('lstm_bwd_wide', 1, 1, 1, 1, 1)):
+            # lstm_bwd_wide: the reverse LSTM role without the k-group split (every workgroup ingests the whole gate gradient)
+            assert lib.echr_config_set(b'persist_kgroups', 0 if name == 'lstm_bwd_wide' else 1) == 0
             assert lib.echr_config_set(b'persist', v) == 0 and lib.echr_config_set(b'persist_bwd', vb) == 0
             assert lib.echr_config_set(b'persist_split', sp) == 0 and lib.echr_config_set(b'persist_h2', h2) == 0
             assert lib.echr_config_set(b'persist_merge', mg) == 0
             runs[name] = U.run_gpu(opt, params, vid, True)
     finally:
-        for key in (b'persist', b'persist_bwd', b'persist_split', b'persist_h2', b'persist_merge'):
+        for key in (b'persist', b'persist_bwd', b'persist_split', b'persist_h2', b'persist_merge', b'persist_kgroups'):
             lib.echr_config_set(key, 1)
     p0, l0, g0, _ = runs['launch']
-    for name in ('persist', 'persist2', 'fwd_only', 'bwd_only', 'unsplit', 'f32_products', 'two_launch', 'two_launch_f32'):
+    for name in ('persist', 'persist2', 'fwd_only', 'bwd_only', 'unsplit', 'f32_products', 'two_launch', 'two_launch_f32', 'lstm_bwd_wide'):
         p1, l1, g1, _ = runs[name]
         assert np.isfinite(p1).all(), name
         assert np.abs(p0 - p1).max() < 2e-5 and abs(l0 - l1) < 1e-5 * abs(l0), (name, np.abs(p0 - p1).max())
