@@ -38,8 +38,21 @@ def event_index_tensors(soi_select_list, ind_select_list, device, n_rows=None):
     if n_rows is not None and (soi.min() < 0 or soi[:, 1].max() > n_rows or ind.min() < 0 or ind.max() >= n_rows):
         raise ValueError('event intervals / anchors fall outside the %d feature rows' % n_rows)
     packed = np.stack([soi[:, 0], lens, ind]).astype(np.int32)
-    t = torch.from_numpy(packed).to(device, non_blocking=True)
+    t = upload(torch.from_numpy(packed), device)
     return t[0].contiguous(), t[1].contiguous(), t[2].contiguous(), int(lens.max())
+
+
+def upload(host_tensor, device):
+    """Small host -> device copy that does not stall the host: staged through a pinned buffer from PyTorch's caching host allocator (it
+    recycles a block only after the copy that reads it has completed).  A copy from pageable memory makes the host wait until the
+    stream has drained, i.e. for the whole previous iteration, and the GPU then idles while the host issues the next one."""
+    if host_tensor.is_cuda:
+        return host_tensor
+    if device.type != 'cuda':
+        return host_tensor.to(device)
+    stage = torch.empty(host_tensor.shape, dtype=host_tensor.dtype, pin_memory=True)
+    stage.copy_(host_tensor)
+    return stage.to(device, non_blocking=True)
 
 
 def rows_disjoint(soi_select_list):

@@ -138,7 +138,7 @@ class OldModel(nn.Module):
         if seq_t.is_cuda:
             return seq_t[:, :S].t().to(device=dev, dtype=torch.int32).contiguous()
         # host labels: slice / transpose / cast on the host, ONE small H2D copy instead of three device ops
-        return seq_t[:, :S].t().to(torch.int32).contiguous().to(dev, non_blocking=True)
+        return EF.upload(seq_t[:, :S].t().to(torch.int32).contiguous(), dev)
 
     def prepare(self, video, clip, clip_mask, seq):
         """Start the part of forward() that does not need the event context (packs, ctx2att over the video, token-side gate products) on
