@@ -115,6 +115,16 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
     return v;
 }
+// sum over the 4 DPP rows (16-lane groups) of the wave, lane by lane, result in every row: v_permlane16_swap / v_permlane32_swap with
+// both operands the same register return {x[l], x[l ^ 16]} resp. {x[l], x[l ^ 32]} (checked on gfx950: tools/micro/permlane_swap.hip)
+__device__ __forceinline__ float xrow_sum4(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned u2 = __float_as_uint(s);
+    const auto b = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 // every thread of the workgroup, after its write-through stores / atomics
 __device__ __forceinline__ void publish(u32* line) {
@@ -1048,22 +1058,21 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                 }
                 // cross-row sum of the context partials through 16 KB of LDS: DPP rows 0-7, then rows 8-15 (LDS float atomics into one
                 // vector were tried: 4-way same-address ds_add_f32 made this phase 3x slower)
+                // the wave's 4 rows are summed in registers (permlane swaps), the 4 waves through 8 KB of LDS
                 float csum[2] = {0.f, 0.f};
 #pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    if ((grow_ >> 3) == pass) {
+                for (int h = 0; h < 8; ++h) cx[h] = make_float4(xrow_sum4(cx[h].x), xrow_sum4(cx[h].y), xrow_sum4(cx[h].z), xrow_sum4(cx[h].w));
+                if ((lane >> 4) == 0) {
 #pragma unroll
-                        for (int h = 0; h < 8; ++h) *reinterpret_cast<float4*>(red + (grow_ & 7) * PH + 32 * lr + 4 * h) = cx[h];
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int d = tid + 256 * h;
-#pragma unroll
-                        for (int g = 0; g < 8; ++g) csum[h] += red[g * PH + d];
-                    }
-                    __syncthreads();
+                    for (int h = 0; h < 8; ++h) *reinterpret_cast<float4*>(red + w * PH + 32 * lr + 4 * h) = cx[h];
                 }
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int d = tid + 256 * h;
+                    csum[h] = (red[d] + red[PH + d]) + (red[2 * PH + d] + red[3 * PH + d]);
+                }
+                __syncthreads();
                 float* xc = P.XC + ((long)t * 2 + m) * XHALF;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
