@@ -62,6 +62,7 @@ def rows_disjoint(soi_select_list):
     return bool(np.all(o[1:, 0] >= o[:-1, 1]))
 
 
+FUSED_NLL = [os.environ.get('ECHR_FUSED_NLL', '1') != '0']        # see MaskedNLL.backward
 ASYNC_TAIL = [os.environ.get('ECHR_ASYNC_TAIL', '1') != '0']        # decoder backward: run the last stage on a second stream (arena path); tests may switch it off
 
 
@@ -251,7 +252,16 @@ class DecoderFunction(torch.autograd.Function):
         lib = L.load()
         video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps = ctx.saved_tensors
         A, S, drop, disjoint = ctx.meta
-        g_logp = _f32c(g_logp)
+        # criterion gradient left here in sparse form by MaskedNLL.backward (LanguageModelCriterion on this node's output)
+        pend = ctx.__dict__.pop('_echr_pending_nll', None)
+        fused = None
+        if pend is not None:
+            if getattr(g_logp, '_echr_nll_placeholder', False) and g_logp.stride() == (0, 0, 0):
+                fused, g_logp = pend, None
+            else:          # the log-probs had other consumers: their (accumulated) gradient plus the criterion's dense one
+                g_logp = g_logp + MaskedNLL.dense_grad(pend[0], pend[1], pend[2], pend[3], *logp.shape)
+        if g_logp is not None:
+            g_logp = _f32c(g_logp)
         zeroed = 1 if (ctx.sink is not None and ctx.sink.usable()) else 0
         if zeroed:
             grads = ctx.sink.take()
@@ -268,7 +278,9 @@ class DecoderFunction(torch.autograd.Function):
         gp = [L.ptr(x) for x in grads]
         g = L.DecGrads(gp[0], gp[1], gp[2], (L.c_f * 3)(*gp[3:6]), (L.c_f * 3)(*gp[6:9]), (L.c_f * 3)(*gp[9:12]),
                        (L.c_f * 3)(*gp[12:15]), gp[15], gp[16], gp[17], gp[18], gp[19], gp[20],
-                       L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp), None, None, None, L.ptr(wsb), zeroed, 0, 0)
+                       L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp) if g_logp is not None else None,
+                       L.ptr(fused[0], torch.int32) if fused else None, L.ptr(fused[1]) if fused else None, L.ptr(fused[3]) if fused else None,
+                       L.ptr(wsb), zeroed, 0, 0)
         d = drop.c()
         hook = getattr(ctx.sink.arena, 'early_grad_hook', None) if zeroed else None
         if hook is not None:
@@ -289,7 +301,7 @@ class DecoderFunction(torch.autograd.Function):
             g.async_tail = 1 if (zeroed and ASYNC_TAIL[0]) else 0
             L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
             if g.async_tail:
-                keep = [ws, wsb, logp, c3d, tokens, ev_start, ev_len, g_logp]
+                keep = [ws, wsb, logp, c3d, tokens, ev_start, ev_len, g_logp, fused]
                 sp = L.stream_ptr()
 
                 def _join(keep=keep, sp=sp):
@@ -380,8 +392,9 @@ class MaskedNLL(torch.autograd.Function):
     """LanguageModelCriterion.forward (misc/utils.py:66-75) on device."""
 
     @staticmethod
-    def forward(ctx, logp, target, mask):
+    def forward(ctx, logp, target, mask, node=None):
         lib = L.load()
+        ctx.node = node
         N, S, V1 = logp.shape
         logp = logp.contiguous()
         tgt = target[:, :S].to(torch.int32).contiguous()
@@ -398,10 +411,23 @@ class MaskedNLL(torch.autograd.Function):
         lib = L.load()
         tgt, msk, out = ctx.saved_tensors
         N, S, V1 = ctx.shape
+        if ctx.node is not None:
+            # the log-probs came from DecoderFunction: leave the criterion's gradient with that node in its sparse form (targets, mask,
+            # upstream scalar) and hand autograd a stride-0 all-zero placeholder.  DecoderFunction.backward takes the fused path when the
+            # placeholder arrives untouched, and adds the dense form when other consumers of the log-probs contributed gradients too.
+            ctx.node._echr_pending_nll = (tgt, msk, out, _f32c(g).reshape(1))
+            ph = torch.zeros((), device=msk.device, dtype=torch.float32).expand(N, S, V1)
+            ph._echr_nll_placeholder = True
+            return ph, None, None, None
+        return MaskedNLL.dense_grad(tgt, msk, out, g, N, S, V1), None, None, None
+
+    @staticmethod
+    def dense_grad(tgt, msk, out, g, N, S, V1):
+        lib = L.load()
         g_logp = torch.empty(N, S, V1, device=msk.device, dtype=torch.float32)
         L.check(lib.echr_nll_loss_bwd(L.ptr(tgt, torch.int32), L.ptr(msk), L.ptr(out), L.ptr(_f32c(g).reshape(1)), L.ptr(g_logp), N, S, V1,
                                       L.stream_ptr()), 'nll_loss_bwd')
-        return g_logp, None, None
+        return g_logp
 
 
 def clamp_adam_(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip=100.0):

@@ -27,7 +27,10 @@ class LanguageModelCriterion(nn.Module):
     """Masked NLL over log-probs [N,S,V+1] (misc/utils.py:62-75), evaluated by echr_nll_loss_fwd."""
 
     def forward(self, input, target, mask):
-        return EF.MaskedNLL.apply(input, target.to(input.device), mask.to(input.device))
+        # when `input` comes straight from the native decoder, its backward takes the criterion's gradient in fused form
+        # (echr_dec_grads.nll_*: softmax - one-hot in one pass) instead of a dense [N,S,V+1] tensor; see MaskedNLL.backward
+        node = input.grad_fn if (EF.FUSED_NLL[0] and type(input.grad_fn).__name__ == 'DecoderFunctionBackward') else None
+        return EF.MaskedNLL.apply(input, target.to(input.device), mask.to(input.device), node)
 
 
 class TAPModelCriterion(nn.Module):

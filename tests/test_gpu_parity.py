@@ -972,3 +972,36 @@ def test_two_rank_data_parallel_on_one_gpu(tmp_path, overlap):
         else:
             assert np.array_equal(r0['grad|' + k], r1['grad|' + k]), k
             assert U.grad_close(k, r0['grad|' + k], p.grad.detach().cpu().numpy(), 1e-5), k     # SUM over ranks == accumulation, no 1/R
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('extra_consumer', [False, True])
+def test_fused_criterion_gradient_equals_dense_path(extra_consumer):
+    """LanguageModelCriterion on the native decoder's output leaves its gradient with the decoder node in sparse form (targets, mask,
+    upstream scalar: echr_dec_grads.nll_*) instead of a dense [N,S,V+1] tensor.  Same gradients as the dense route (ECHR_FUSED_NLL=0),
+    also when the log-probs have a second consumer (then the placeholder is accumulated away and the dense form is added back) and
+    under an upstream factor (lambda2 * loss, train.py:322-329)."""
+    from echr_amd import functional as EF
+    from echr_amd.misc.utils import LanguageModelCriterion
+    opt, params, vid = synth.make_case('c1')
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    out = {}
+    try:
+        for fused in (True, False):
+            EF.FUSED_NLL[0] = fused
+            m = U.build_gpu_model(opt, params, True)
+            pred = m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+            loss = 0.7 * LanguageModelCriterion()(pred, labels[:, 1:].to(dev), masks[:, 1:].to(dev))
+            if extra_consumer:
+                wgt = torch.linspace(-1.0, 1.0, pred.numel(), device=dev).view_as(pred) * 1e-4
+                loss = loss + (pred * wgt).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            out[fused] = (float(loss.detach()), {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None})
+    finally:
+        EF.FUSED_NLL[0] = True
+    assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])
+    for k, g0 in out[False][1].items():
+        assert U.grad_close(k, out[True][1][k], g0, 2e-5), (k, U.relerr(out[True][1][k], g0))
