@@ -721,32 +721,6 @@ __global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, (NS == 2 && BM == 128)
         __builtin_amdgcn_s_barrier();
         if (kt + NS - 1 < kt1) stage(cur == 0 ? NS - 1 : cur - 1);
         const unsigned char* sb = sm + cur * STAGE;
-#ifdef ECHR_H2_NOFOLD
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int o = s ? o1 : o0;
-            f16x8 a[2][2], bb[TN][2];
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                a[0][pl] = *reinterpret_cast<const f16x8*>(sb + baseA + pl * H2_PLANE + o);
-                a[1][pl] = *reinterpret_cast<const f16x8*>(sb + baseA + pl * H2_PLANE + o + 32 * 64);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bb[j][pl] = *reinterpret_cast<const f16x8*>(sb + baseB + pl * H2_PLANE + o + j * 32 * 64);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], bb[j][0], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], bb[j][1], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], bb[j][0], acc[i][j], 0, 0, 0);
-        }
-#else
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int o = s ? o1 : o0;
@@ -806,7 +780,6 @@ __global__ __launch_bounds__((BM / 64) * (128 / WN) * 64, (NS == 2 && BM == 128)
                         }
                 }
         }
-#endif
         cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
     epilogue<2, TN>(p, acc, p.C, 0, ks, mb * BM, nb * 128, wm, wn, lane);

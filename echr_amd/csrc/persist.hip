@@ -92,12 +92,10 @@ __device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t r, u32 off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);      // aux 16 = sc1
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-#ifndef ECHR_BULK_AUX
-#define ECHR_BULK_AUX 16
-#endif
-// bulk operand fragments of a hand-off (tens of KB per workgroup)
+// bulk operand fragments of a hand-off (tens of KB per workgroup): sc1 like every other load of handed-off bytes (plain loads were timed
+// too: no faster, the consumers of one operand do not share its fetch through L2)
 __device__ __forceinline__ float4 ld16_bulk(__amdgpu_buffer_rsrc_t r, u32 off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, ECHR_BULK_AUX);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, u32 off, float4 v) {
