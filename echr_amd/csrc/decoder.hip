@@ -1333,7 +1333,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
 // ------------------------------------------------------------------------------------------------------
 // greedy sampler (OldModel_NEW.py:139-187, sample_max = 1, eval mode): every step on device
 // ------------------------------------------------------------------------------------------------------
-struct SampWs { float* XT; float* LOGITS; int *IT, *UNF; long total; };
+struct SampWs { float* XT; float* LOGITS; int *IT, *UNF; float* SLABS; long total; };
+constexpr int SAMP_SLABS = 4;       // k-slices of the per-step logits product when its output grid is small (summed in a fixed order)
 static SampWs carve_samp(const echr_dec_args* a, float* base) {
     SampWs s;
     long off = 0;
@@ -1342,8 +1343,18 @@ static SampWs carve_samp(const echr_dec_args* a, float* base) {
     s.LOGITS = take((long)a->N * a->V1);
     s.IT = reinterpret_cast<int*>(take(a->N));
     s.UNF = reinterpret_cast<int*>(take(a->N));
+    s.SLABS = take((long)SAMP_SLABS * a->N * a->V1);
     s.total = off;
     return s;
+}
+
+// LOGITS = ((S0 + S1) + (S2 + S3)) + bias: the k-slices of the logits product in one fixed order (bitwise reproducible, unlike atomics)
+__global__ __launch_bounds__(256) void slab_sum_bias_kernel(const float* __restrict__ slabs, long slab_stride, const float* __restrict__ bias,
+                                                            float* __restrict__ out, long n, int V1) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = (slabs[i] + slabs[slab_stride + i]) + (slabs[2 * slab_stride + i] + slabs[3 * slab_stride + i]);
+    out[i] = v + (bias ? bias[i % V1] : 0.f);
 }
 extern "C" int64_t echr_sampler_ws_floats(const echr_dec_args* a) { return a ? carve_samp(a, nullptr).total : -1; }
 
@@ -1372,9 +1383,22 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
         RC(embed_gather(a.embed, s.IT, s.XT, N, E, a.V1, st));
         RC(input_gates(&a, w, s.XT, t, 1, st));
         RC(step_fwd(&a, w, t, off, off, st));
-        echr_gemm_desc d = desc_nt(w.OUTD + (long)t * N * 3 * H, 3 * H, a.w_logit, 3 * H, s.LOGITS, a.V1, N, a.V1, 3 * H);
-        d.bias = a.b_logit; d.split_k = 1;
-        RC(gemm(d, st));
+        const long tiles = (long)((N + 63) / 64) * ((a.V1 + 63) / 64);
+        if (tiles < 400 && (3 * H) % (SAMP_SLABS * 32) == 0) {
+            // few rows: one k loop per tile would be 48 k blocks deep on 79 workgroups.  Four k-slices as a strided batch into four
+            // slabs (plain stores), then one fixed-order sum: still bitwise reproducible, a third of the time
+            const int ksl = 3 * H / SAMP_SLABS;
+            echr_gemm_desc d = desc_nt(w.OUTD + (long)t * N * 3 * H, 3 * H, a.w_logit, 3 * H, s.SLABS, a.V1, N, a.V1, ksl);
+            d.batch = SAMP_SLABS; d.bsa = ksl; d.bsb = ksl; d.bsc = (long)N * a.V1; d.split_k = 1;
+            RC(gemm(d, st));
+            const long n = (long)N * a.V1;
+            hipLaunchKernelGGL(slab_sum_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.SLABS, n, a.b_logit, s.LOGITS, n, a.V1);
+            RC(check_launch("slab_sum_bias"));
+        } else {
+            echr_gemm_desc d = desc_nt(w.OUTD + (long)t * N * 3 * H, 3 * H, a.w_logit, 3 * H, s.LOGITS, a.V1, N, a.V1, 3 * H);
+            d.bias = a.b_logit; d.split_k = 1;
+            RC(gemm(d, st));
+        }
         RC(greedy_step(s.LOGITS, a.V1, N, a.V1, t, L, s.IT, s.UNF, reinterpret_cast<long long*>(sa->seq), sa->seq_logp,
                        sa->n_unfinished, st));
     }
