@@ -179,21 +179,35 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ s, const float* __r
 }
 // weighted BCE of misc/utils.py:78-99:  labels *= masks; w = labels*w0 + (1-labels)*w1 (w0 = 1-w1, per anchor k);
 // loss = K * mean_{t,k} w * -(y log p + (1-y) log(1-p)),  p = scores*masks, logs clamped at -100 like torch's BCELoss.
-__global__ __launch_bounds__(256) void tap_bce_fwd_kernel(const float* __restrict__ scores, const float* __restrict__ masks,
-                                                          const float* __restrict__ labels, const float* __restrict__ w1,
-                                                          float* __restrict__ loss, int T, int K) {
-    __shared__ float red[4];
-    float s = 0.f;
-    for (long i = threadIdx.x; i < (long)T * K; i += 256) {
-        const int k = (int)(i % K);
-        const float y = labels[i] * masks[i], p = scores[i] * masks[i];
-        const float w = y * (1.f - w1[k]) + (1.f - y) * w1[k];
-        s -= w * (y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+__global__ __launch_bounds__(1024) void tap_bce_fwd_kernel(const float* __restrict__ scores, const float* __restrict__ masks,
+                                                           const float* __restrict__ labels, const float* __restrict__ w1,
+                                                           float* __restrict__ loss, int T, int K) {
+    // one workgroup of 16 waves (the sum stays in one fixed order: a scalar output that the tests compare bit for bit run to run);
+    // four independent elements per thread and pass keep the logf latency covered
+    __shared__ float red[16];
+    const long n = (long)T * K;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long i0 = threadIdx.x; i0 < n; i0 += 4096) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + 1024 * u;
+            if (i < n) {
+                const int k = (int)(i % K);
+                const float y = labels[i] * masks[i], p = scores[i] * masks[i];
+                const float w = y * (1.f - w1[k]) + (1.f - y) * w1[k];
+                s4[u] -= w * (y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+            }
+        }
     }
-    s = wave_sum(s);
+    float s = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)((long)T * K) * (float)K;
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        loss[0] = t / (float)n * (float)K;
+    }
 }
 __global__ void tap_bce_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ masks, const float* __restrict__ labels,
                                    const float* __restrict__ w1, const float* __restrict__ g_loss, float* __restrict__ g_scores, int T, int K) {
@@ -373,7 +387,7 @@ extern "C" int echr_sst_bwd(const echr_sst_args* a, const echr_sst_grads* g, con
 extern "C" int echr_tap_bce_fwd(const float* scores, const float* masks, const float* labels, const float* w1, float* loss, int32_t T,
                                 int32_t K, void* stream) {
     ECHR_REQUIRE(scores && masks && labels && w1 && loss && T > 0 && K > 0, "tap_bce_fwd: bad arguments");
-    hipLaunchKernelGGL(tap_bce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scores, masks, labels, w1, loss, T, K);
+    hipLaunchKernelGGL(tap_bce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scores, masks, labels, w1, loss, T, K);
     return check_launch("tap_bce_fwd");
 }
 extern "C" int echr_tap_bce_bwd(const float* scores, const float* masks, const float* labels, const float* w1, const float* g_loss,
