@@ -336,8 +336,8 @@ def cpu_leg(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)       # 0.2 s of timed work: one host hiccup no longer moves the average
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--overlap', action='store_true', help='SURVEY 8-d one-video layout (T_v=160, events share rows)')
     ap.add_argument('--mode', choices=['train', 'fwd'], default='train',
                     help="'train' = fwd+bwd+clamp+Adam (BASELINE config 3, the headline metric); 'fwd' = forward + loss only (config 2)")
