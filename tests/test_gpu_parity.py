@@ -1005,3 +1005,34 @@ def test_fused_criterion_gradient_equals_dense_path(extra_consumer):
     assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])
     for k, g0 in out[False][1].items():
         assert U.grad_close(k, out[True][1][k], g0, 2e-5), (k, U.relerr(out[True][1][k], g0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,A,L,min_len,video_dim', [(1, 1, 3, 1, 500), (31, 43, 4, 1, 500), (33, 44, 6, 2, 500), (64, 129, 5, 100, 500),
+                                                      (32, 5, 9, 1, 512), (17, 87, 3, 50, 8), (64, 2, 21, 1, 500)])
+def test_persistent_recurrence_edge_shapes(N, A, L, min_len, video_dim):
+    """The persistent recurrences at the edges of their eligibility (csrc/persist.hip: N <= 64 events split 32 + 32 over two half-chip
+    machines, A <= 129 slots split 43 + 43 + 43 over three workgroups, D <= 512, any S): one event, a half machine with a single row, slot
+    counts around the 43-slot thirds, the largest A, the smallest and the largest feature width, one and two decoder steps -- against the
+    launch-per-phase path on the same seeded inputs, train mode."""
+    from echr_amd import _lib
+    lib = _lib.load()
+    opt = synth.default_opt(vocab_size=300, seq_length=L - 2, video_dim=video_dim)
+    params = synth.make_params(opt, seed=5)
+    vid = synth.make_video(N, A, L, opt.CG_vocab_size + 1, seed=77 + N + A, min_len=min_len, video_dim=video_dim)
+    runs = {}
+    try:
+        for name, v in (('launch', 0), ('persist', 1)):
+            assert lib.echr_config_set(b'persist', v) == 0 and lib.echr_config_set(b'persist_bwd', v) == 0
+            runs[name] = U.run_gpu(opt, params, vid, True)
+    finally:
+        lib.echr_config_set(b'persist', 1)
+        lib.echr_config_set(b'persist_bwd', 1)
+    p0, l0, g0, _ = runs['launch']
+    p1, l1, g1, _ = runs['persist']
+    assert np.isfinite(p1).all()
+    assert np.abs(p0 - p1).max() < 2e-5 and abs(l0 - l1) < 1e-5 * abs(l0), np.abs(p0 - p1).max()
+    for k in g0:
+        if g0[k] is not None:
+            # absolute floor 1e-4: with single-slot events the attention parameters' true gradients are exactly zero (weights == 1)
+            assert U.relerr(g1[k], g0[k], 1e-4) < 1e-4, (k, U.relerr(g1[k], g0[k], 1e-4))
