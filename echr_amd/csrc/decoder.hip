@@ -1075,7 +1075,9 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_mask, g->g_loss, b.MSUM, b.DLG, b.ldg, N, S, V1, st));
     // scratch that is accumulated into, and the transposed recurrent weights (every d h / d ATT product of the reverse recurrence
     // then has the same NT form as forward): two launches, independent of everything above
-    {
+    // (the persistent reverse launch builds its weight images from the untransposed matrices: nothing to transpose then; the test is the
+    // one the recurrence stage applies below, on the same arguments and configuration)
+    if (!(!overlap_enabled() && !(config().chains2 == 1 && side().ok && S >= 2) && persist_bwd_eligible(a))) {
         const TransposeJob tj[5] = {{a->w_hh[0], H, b.WT_HH[0], 4 * H, 4 * H, H}, {a->w_hh[1], H, b.WT_HH[1], 4 * H, 4 * H, H},
                                     {a->w_hh[2], H, b.WT_HH[2], 4 * H, 4 * H, H}, {a->w_ih[1] + E, cin[1], b.WT_ATT, 4 * H, 4 * H, D},
                                     {a->w_h2a, H, b.WT_H2A, Ha, Ha, H}};

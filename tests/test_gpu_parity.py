@@ -1034,5 +1034,9 @@ def test_persistent_recurrence_edge_shapes(N, A, L, min_len, video_dim):
     assert np.abs(p0 - p1).max() < 2e-5 and abs(l0 - l1) < 1e-5 * abs(l0), np.abs(p0 - p1).max()
     for k in g0:
         if g0[k] is not None:
-            # absolute floor 1e-4: with single-slot events the attention parameters' true gradients are exactly zero (weights == 1)
-            assert U.relerr(g1[k], g0[k], 1e-4) < 1e-4, (k, U.relerr(g1[k], g0[k], 1e-4))
+            if A == 1 and '.attention.' in k:
+                # single-slot events: the attention weights are identically 1, the true gradients of ctx2att / h2att / alpha_net are
+                # exactly zero and both paths only hold rounding noise of their (different) summation orders
+                assert np.abs(g1[k]).max() < 1e-6 and np.abs(g0[k]).max() < 1e-6, k
+            else:
+                assert U.relerr(g1[k], g0[k], 1e-4) < 1e-4, (k, U.relerr(g1[k], g0[k], 1e-4))
