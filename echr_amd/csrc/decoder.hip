@@ -1143,17 +1143,16 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
             pj[7] = pack_cols(w.ATT, D, D, SN, b.PK_ATTT);
             pj[8] = pack_cols(b.DQ, Ha, Ha, SN, b.PK_DQT);
             RC(h2_pack_multi(pj, 9, q));
+            // the seven products that contract d G_k^T over the S*N rows (W_hh x3, W_ih[:, :E] x3, W_ih1[:, E:]) share M = 4H and K: ONE
+            // grouped launch of 7 x 64 tiles fills the chip in a single round (they were four launches of 192 + 192 + 64 tiles)
+            echr_gemm_desc g7[7];
             for (int k = 0; k < 3; ++k) {
-                ghh[k] = desc_h2(b.PK_DGT[k], b.PK_HT[k], g->g_w_hh[k], H, 4 * H, H, SN);
-                ghh[k].beta = beta;
-                gih[k] = desc_h2(b.PK_DGT[k], b.PK_XTT, g->g_w_ih[k], cin[k], 4 * H, E, SN);
-                gih[k].beta = beta;
+                g7[k] = desc_h2(b.PK_DGT[k], b.PK_HT[k], g->g_w_hh[k], H, 4 * H, H, SN);
+                g7[3 + k] = desc_h2(b.PK_DGT[k], b.PK_XTT, g->g_w_ih[k], cin[k], 4 * H, E, SN);
             }
-            RC(gemm_grouped(ghh, 3, q));
-            RC(gemm_grouped(gih, 3, q));
-            e = desc_h2(b.PK_DGT[1], b.PK_ATTT, g->g_w_ih[1] + E, cin[1], 4 * H, D, SN);
-            e.beta = beta;
-            RC(gemm(e, q));
+            g7[6] = desc_h2(b.PK_DGT[1], b.PK_ATTT, g->g_w_ih[1] + E, cin[1], 4 * H, D, SN);
+            for (int i = 0; i < 7; ++i) g7[i].beta = beta;
+            RC(gemm_grouped(g7, 7, q));
             e = desc_h2(b.PK_DQT, b.PK_HT[1], g->g_w_h2a, H, Ha, H, SN);
             e.beta = beta;
             return gemm(e, q);

@@ -28,6 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
 
+constexpr int GEMM_MAXG = 8;
 struct GemmParams {
     const float* A; const float* B; float* C;
     int M, N, K;
@@ -42,11 +43,13 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int xcd_n, xr_m, xr_n;      // h2 kernel: XCD grid columns, tiles per XCD rectangle (rows, cols)
     int vecA, vecB;
-    // grouped launch: up to 4 same-shaped problems in one grid (blockIdx.z = group * split_k + k-slice); per-group operands
+    // grouped launch: up to GEMM_MAXG problems in one grid (blockIdx.z = group * split_k + k-slice); per-group operands.  The problems share
+    // M, K and the epilogue mode; h2 problems may differ in N (the grid is sized for the widest, narrower ones retire their spare tiles)
     int ngroup;
-    const float* gA[4]; const float* gB[4]; float* gC[4];
-    long gsbk[4], gsbn[4], gldc[4];
-    const float* gbias[4]; const float* gbias2[4]; const float* gaddend[4];
+    const float* gA[GEMM_MAXG]; const float* gB[GEMM_MAXG]; float* gC[GEMM_MAXG];
+    long gsbk[GEMM_MAXG], gsbn[GEMM_MAXG], gldc[GEMM_MAXG];
+    int gN[GEMM_MAXG];
+    const float* gbias[GEMM_MAXG]; const float* gbias2[GEMM_MAXG]; const float* gaddend[GEMM_MAXG];
 };
 
 __device__ __forceinline__ GemmParams select_group(const GemmParams& pin, int& z) {
@@ -56,7 +59,7 @@ __device__ __forceinline__ GemmParams select_group(const GemmParams& pin, int& z
         const int gi = z / per;
         z = z % per;
         p.A = pin.gA[gi]; p.B = pin.gB[gi]; p.C = pin.gC[gi];
-        p.sbk = pin.gsbk[gi]; p.sbn = pin.gsbn[gi]; p.ldc = pin.gldc[gi];
+        p.sbk = pin.gsbk[gi]; p.sbn = pin.gsbn[gi]; p.ldc = pin.gldc[gi]; p.N = pin.gN[gi];
         p.bias = pin.gbias[gi]; p.bias2 = pin.gbias2[gi]; p.addend = pin.gaddend[gi];
     }
     return p;
@@ -953,10 +956,10 @@ int gemm(const echr_gemm_desc& d, hipStream_t st) { return gemm_impl(&d, 1, st);
 // Up to 4 problems of identical shape/layout/epilogue mode in ONE launch (the three streams' W_ih / W_hh products): fills the
 // chip better than three 640-workgroup grids and pays one launch ramp.  Problems may share C when they accumulate (beta = 1).
 int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st) {
-    ECHR_REQUIRE(ds && ng >= 1 && ng <= 4, "gemm_grouped: 1..4 problems");
+    ECHR_REQUIRE(ds && ng >= 1 && ng <= GEMM_MAXG, "gemm_grouped: 1..%d problems", GEMM_MAXG);
     for (int i = 1; i < ng; ++i) {
         const echr_gemm_desc &a = ds[0], &b = ds[i];
-        ECHR_REQUIRE(a.M == b.M && a.N == b.N && a.K == b.K && a.sam == b.sam && a.sak == b.sak && (a.sbk == 1) == (b.sbk == 1) &&
+        ECHR_REQUIRE(a.M == b.M && (a.N == b.N || (a.algo == ECHR_GEMM_H2 && b.algo == ECHR_GEMM_H2)) && a.K == b.K && a.sam == b.sam && a.sak == b.sak && (a.sbk == 1) == (b.sbk == 1) &&
                      (a.sbn == 1) == (b.sbn == 1) && a.batch == 1 && b.batch == 1 && a.alpha == b.alpha && a.beta == b.beta &&
                      a.act == b.act && a.split_k == b.split_k && a.algo == b.algo && a.rowmap_mod == b.rowmap_mod &&
                      a.add_mod == b.add_mod && a.ld_add == b.ld_add && a.act == ECHR_ACT_NONE,
@@ -984,9 +987,11 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     p.act = d.act; p.aux = d.aux; p.ld_aux = d.ld_aux;
     p.rowmap_mod = d.rowmap_mod; p.rowmap_mul = d.rowmap_mul;
     p.ngroup = ng;
-    for (int i = 0; i < 4; ++i) {
+    int maxN = d.N;
+    for (int i = 0; i < GEMM_MAXG; ++i) {
         const echr_gemm_desc& g = ds[i < ng ? i : 0];
-        p.gA[i] = g.A; p.gB[i] = g.B; p.gC[i] = g.C; p.gsbk[i] = g.sbk; p.gsbn[i] = g.sbn; p.gldc[i] = g.ldc;
+        maxN = g.N > maxN ? g.N : maxN;
+        p.gA[i] = g.A; p.gB[i] = g.B; p.gC[i] = g.C; p.gsbk[i] = g.sbk; p.gsbn[i] = g.sbn; p.gldc[i] = g.ldc; p.gN[i] = g.N;
         p.gbias[i] = g.bias; p.gbias2[i] = g.bias2; p.gaddend[i] = g.addend;
     }
     const bool h2 = d.algo == ECHR_GEMM_H2;
@@ -1023,7 +1028,7 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
         if (use_split) { BMs = 128; BNs = (e0 == 's') ? 64 : 128; }
     }
     p.tiles_m = (d.M + BMs - 1) / BMs;
-    p.tiles_n = (d.N + BNs - 1) / BNs;
+    p.tiles_n = (maxN + BNs - 1) / BNs;          // grouped h2 problems of different widths: sized for the widest
     const int kt_total = (d.K + BK - 1) / BK;
     int split = d.split_k;
     const bool accumulate = (d.split_k > 1 || d.split_k < 0);   // caller promises C already holds its base value
@@ -1080,7 +1085,7 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
                 for (int gj = 0; gj < gi; ++gj) seen = seen || ds[gj].C == ds[gi].C;
                 if (seen) continue;
                 for (int bb = 0; bb < d.batch; ++bb) {
-                    int rc = fill_zero_2d(ds[gi].C + (long)bb * d.bsc, d.M, d.N, ds[gi].ldc, st);
+                    int rc = fill_zero_2d(ds[gi].C + (long)bb * d.bsc, d.M, ds[gi].N, ds[gi].ldc, st);
                     if (rc) return rc;
                 }
             }
