@@ -1143,19 +1143,17 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
             pj[7] = pack_cols(w.ATT, D, D, SN, b.PK_ATTT);
             pj[8] = pack_cols(b.DQ, Ha, Ha, SN, b.PK_DQT);
             RC(h2_pack_multi(pj, 9, q));
-            // the seven products that contract d G_k^T over the S*N rows (W_hh x3, W_ih[:, :E] x3, W_ih1[:, E:]) share M = 4H and K: ONE
-            // grouped launch of 7 x 64 tiles fills the chip in a single round (they were four launches of 192 + 192 + 64 tiles)
-            echr_gemm_desc g7[7];
+            // the seven products that contract d G_k^T over the S*N rows (W_hh x3, W_ih[:, :E] x3, W_ih1[:, E:]) share M = 4H and K, the W_h2a
+            // gradient shares K: ONE grouped launch of 8 x 64 tile slots fills the chip in a single round (they were five launches)
+            echr_gemm_desc g7[8];
             for (int k = 0; k < 3; ++k) {
                 g7[k] = desc_h2(b.PK_DGT[k], b.PK_HT[k], g->g_w_hh[k], H, 4 * H, H, SN);
                 g7[3 + k] = desc_h2(b.PK_DGT[k], b.PK_XTT, g->g_w_ih[k], cin[k], 4 * H, E, SN);
             }
             g7[6] = desc_h2(b.PK_DGT[1], b.PK_ATTT, g->g_w_ih[1] + E, cin[1], 4 * H, D, SN);
-            for (int i = 0; i < 7; ++i) g7[i].beta = beta;
-            RC(gemm_grouped(g7, 7, q));
-            e = desc_h2(b.PK_DQT, b.PK_HT[1], g->g_w_h2a, H, Ha, H, SN);
-            e.beta = beta;
-            return gemm(e, q);
+            g7[7] = desc_h2(b.PK_DQT, b.PK_HT[1], g->g_w_h2a, H, Ha, H, SN);      // d q^T . h1 (M = Ha): same K, rides along
+            for (int i = 0; i < 8; ++i) g7[i].beta = beta;
+            return gemm_grouped(g7, 8, q);
         }
         for (int k = 0; k < 3; ++k) {
             ghh[k] = desc_tn(b.DG[k] + r0 * 4 * H, 4 * H, w.HS + r0 * 3 * H + k * H, 3 * H, g->g_w_hh[k], H, 4 * H, H, rows);

@@ -44,11 +44,11 @@ struct GemmParams {
     int xcd_n, xr_m, xr_n;      // h2 kernel: XCD grid columns, tiles per XCD rectangle (rows, cols)
     int vecA, vecB;
     // grouped launch: up to GEMM_MAXG problems in one grid (blockIdx.z = group * split_k + k-slice); per-group operands.  The problems share
-    // M, K and the epilogue mode; h2 problems may differ in N (the grid is sized for the widest, narrower ones retire their spare tiles)
+    // K and the epilogue mode; h2 problems may differ in M and N (the grid is sized for the largest, smaller ones retire their spare tiles)
     int ngroup;
     const float* gA[GEMM_MAXG]; const float* gB[GEMM_MAXG]; float* gC[GEMM_MAXG];
     long gsbk[GEMM_MAXG], gsbn[GEMM_MAXG], gldc[GEMM_MAXG];
-    int gN[GEMM_MAXG];
+    int gN[GEMM_MAXG], gM[GEMM_MAXG];
     const float* gbias[GEMM_MAXG]; const float* gbias2[GEMM_MAXG]; const float* gaddend[GEMM_MAXG];
 };
 
@@ -59,7 +59,7 @@ __device__ __forceinline__ GemmParams select_group(const GemmParams& pin, int& z
         const int gi = z / per;
         z = z % per;
         p.A = pin.gA[gi]; p.B = pin.gB[gi]; p.C = pin.gC[gi];
-        p.sbk = pin.gsbk[gi]; p.sbn = pin.gsbn[gi]; p.ldc = pin.gldc[gi]; p.N = pin.gN[gi];
+        p.sbk = pin.gsbk[gi]; p.sbn = pin.gsbn[gi]; p.ldc = pin.gldc[gi]; p.N = pin.gN[gi]; p.M = pin.gM[gi];
         p.bias = pin.gbias[gi]; p.bias2 = pin.gbias2[gi]; p.addend = pin.gaddend[gi];
     }
     return p;
@@ -959,7 +959,7 @@ int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     ECHR_REQUIRE(ds && ng >= 1 && ng <= GEMM_MAXG, "gemm_grouped: 1..%d problems", GEMM_MAXG);
     for (int i = 1; i < ng; ++i) {
         const echr_gemm_desc &a = ds[0], &b = ds[i];
-        ECHR_REQUIRE(a.M == b.M && (a.N == b.N || (a.algo == ECHR_GEMM_H2 && b.algo == ECHR_GEMM_H2)) && a.K == b.K && a.sam == b.sam && a.sak == b.sak && (a.sbk == 1) == (b.sbk == 1) &&
+        ECHR_REQUIRE(((a.M == b.M && a.N == b.N) || (a.algo == ECHR_GEMM_H2 && b.algo == ECHR_GEMM_H2)) && a.K == b.K && a.sam == b.sam && a.sak == b.sak && (a.sbk == 1) == (b.sbk == 1) &&
                      (a.sbn == 1) == (b.sbn == 1) && a.batch == 1 && b.batch == 1 && a.alpha == b.alpha && a.beta == b.beta &&
                      a.act == b.act && a.split_k == b.split_k && a.algo == b.algo && a.rowmap_mod == b.rowmap_mod &&
                      a.add_mod == b.add_mod && a.ld_add == b.ld_add && a.act == ECHR_ACT_NONE,
@@ -987,10 +987,12 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     p.act = d.act; p.aux = d.aux; p.ld_aux = d.ld_aux;
     p.rowmap_mod = d.rowmap_mod; p.rowmap_mul = d.rowmap_mul;
     p.ngroup = ng;
-    int maxN = d.N;
+    int maxN = d.N, maxM = d.M;
     for (int i = 0; i < GEMM_MAXG; ++i) {
         const echr_gemm_desc& g = ds[i < ng ? i : 0];
         maxN = g.N > maxN ? g.N : maxN;
+        maxM = g.M > maxM ? g.M : maxM;
+        p.gM[i] = g.M;
         p.gA[i] = g.A; p.gB[i] = g.B; p.gC[i] = g.C; p.gsbk[i] = g.sbk; p.gsbn[i] = g.sbn; p.gldc[i] = g.ldc; p.gN[i] = g.N;
         p.gbias[i] = g.bias; p.gbias2[i] = g.bias2; p.gaddend[i] = g.addend;
     }
@@ -1027,7 +1029,7 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
         else if (e0 == 'c') { BMs = 128; BNs = 128; w8 = true; }
         if (use_split) { BMs = 128; BNs = (e0 == 's') ? 64 : 128; }
     }
-    p.tiles_m = (d.M + BMs - 1) / BMs;
+    p.tiles_m = (maxM + BMs - 1) / BMs;
     p.tiles_n = (maxN + BNs - 1) / BNs;          // grouped h2 problems of different widths: sized for the widest
     const int kt_total = (d.K + BK - 1) / BK;
     int split = d.split_k;
@@ -1085,7 +1087,7 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
                 for (int gj = 0; gj < gi; ++gj) seen = seen || ds[gj].C == ds[gi].C;
                 if (seen) continue;
                 for (int bb = 0; bb < d.batch; ++bb) {
-                    int rc = fill_zero_2d(ds[gi].C + (long)bb * d.bsc, d.M, ds[gi].N, ds[gi].ldc, st);
+                    int rc = fill_zero_2d(ds[gi].C + (long)bb * d.bsc, ds[gi].M, ds[gi].N, ds[gi].ldc, st);
                     if (rc) return rc;
                 }
             }
