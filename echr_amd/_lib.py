@@ -55,7 +55,7 @@ class DecGrads(C.Structure):
                 ('g_w_ih', c_f * 3), ('g_w_hh', c_f * 3), ('g_b_ih', c_f * 3), ('g_b_hh', c_f * 3),
                 ('g_w_c2a', c_f), ('g_b_c2a', c_f), ('g_w_h2a', c_f), ('g_b_h2a', c_f), ('g_w_alpha', c_f), ('g_b_alpha', c_f),
                 ('g_event', c_f), ('g_video', c_f), ('g_logp', c_f),
-                ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f), ('zeroed', i32), ('phase', i32), ('async_tail', i32)]
+                ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f), ('zeroed', i32), ('phase', i32), ('async_tail', i32), ('nll_msum', c_f)]
 
 
 class SstArgs(C.Structure):

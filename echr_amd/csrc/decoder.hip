@@ -1071,8 +1071,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     const bool do_pb = g->phase == 0 || g->phase == 2 || g->phase == 4;
     // 1. d logits (time-major, padded leading dimension)
     if (do_a) {
-    if (!g->g_logp) RC(colsum(g->nll_mask, 1, N * S, 1, b.MSUM, false, st));
-    RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_mask, g->g_loss, b.MSUM, b.DLG, b.ldg, N, S, V1, st));
+    if (!g->g_logp && !g->nll_msum) RC(colsum(g->nll_mask, 1, N * S, 1, b.MSUM, false, st));
+    RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_mask, g->g_loss, g->nll_msum ? g->nll_msum : b.MSUM, b.DLG, b.ldg, N, S, V1, st));
     // scratch that is accumulated into, and the transposed recurrent weights (every d h / d ATT product of the reverse recurrence
     // then has the same NT form as forward): two launches, independent of everything above
     // (the persistent reverse launch builds its weight images from the untransposed matrices: nothing to transpose then; the test is the

@@ -280,7 +280,7 @@ class DecoderFunction(torch.autograd.Function):
                        (L.c_f * 3)(*gp[12:15]), gp[15], gp[16], gp[17], gp[18], gp[19], gp[20],
                        L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp) if g_logp is not None else None,
                        L.ptr(fused[0], torch.int32) if fused else None, L.ptr(fused[1]) if fused else None, L.ptr(fused[3]) if fused else None,
-                       L.ptr(wsb), zeroed, 0, 0)
+                       L.ptr(wsb), zeroed, 0, 0, L.ptr(fused[2][1:2]) if fused else None)
         d = drop.c()
         hook = getattr(ctx.sink.arena, 'early_grad_hook', None) if zeroed else None
         if hook is not None:

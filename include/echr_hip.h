@@ -213,6 +213,8 @@ typedef struct {
                                                   overlap it.  The caller MUST call echr_stream_join(stream) before anything reads g_w_c2a,
                                                   g_b_c2a, g_w_alpha, g_b_alpha, g_embed or frees ws / ws_bwd (every library entry that takes a
                                                   stream joins first as a safety net). */
+    const float* nll_msum;                     /* fused criterion path, optional: device pointer to sum(nll_mask) (the second output of
+                                                  echr_nll_loss_fwd); NULL = the library sums the mask itself */
 } echr_dec_grads;
 
 /* make `stream` wait for an asynchronous decoder-backward tail (echr_dec_grads.async_tail); no-op when none is pending */
