@@ -1048,6 +1048,16 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
     return 0;
 }
 
+// d W_logit = DLG^T . OUTD (plain overwrite) and d b_logit on packed operands that the caller has prepared
+static int logit_grads(const echr_dec_args* a, const echr_dec_grads* g, const DecWs& w, const DecWsBwd& b, bool z, hipStream_t st) {
+    (void)w;
+    const int SN = a->S * a->N;
+    echr_gemm_desc d = desc_h2(b.PK_DLGT, b.PK_OUTDT, g->g_w_logit, 3 * a->H, a->V1, 3 * a->H, SN);
+    d.split_k = 1;                         // one k slice per tile: a plain overwrite, no read of the (zeroed or stale) 30 MB buffer
+    RC(gemm(d, st));
+    return colsum(b.DLG, b.ldg, SN, a->V1, g->g_b_logit, z, st);
+}
+
 extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream) {
     RC(persist_check_async());
     RC(join_tail((hipStream_t)stream));
@@ -1100,13 +1110,18 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     if (!do_a) {
     } else if (h2) {
         // d W_logit = DLG^T . OUTD and d OUTD = DLG . W_logit on h2-packed operands; the four packs (two of them transposing) are one launch
-        H2PackJob pj[4] = {pack_cols(b.DLG, b.ldg, V1, SN, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SN, b.PK_OUTDT),
-                           pack_rows(b.DLG, b.ldg, SN, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
-        RC(h2_pack_multi(pj, 4, st));
-        d = desc_h2(b.PK_DLGT, b.PK_OUTDT, g->g_w_logit, 3 * H, V1, 3 * H, SN);
-        d.split_k = 1;                         // one k slice per tile: a plain overwrite, no read of the (zeroed or stale) 30 MB buffer
-        RC(gemm(d, st));
-        RC(colsum(b.DLG, b.ldg, SN, V1, g->g_b_logit, z, st));
+        // with an asynchronous tail (phase 0) the logit-layer gradients, which nothing in the backward pass reads, are formed on the tail
+        // stream beside the launch-bound rest of the backward instead of in front of the reverse recurrence
+        const bool defer_wl = g->phase == 0 && g->async_tail != 0 && tail().ok;
+        if (defer_wl) {
+            H2PackJob pj[2] = {pack_rows(b.DLG, b.ldg, SN, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
+            RC(h2_pack_multi(pj, 2, st));
+        } else {
+            H2PackJob pj[4] = {pack_cols(b.DLG, b.ldg, V1, SN, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SN, b.PK_OUTDT),
+                               pack_rows(b.DLG, b.ldg, SN, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
+            RC(h2_pack_multi(pj, 4, st));
+            RC(logit_grads(a, g, w, b, z, st));
+        }
         d = desc_h2(b.PK_DLG, b.PK_WLT, b.DOUT, 3 * H, SN, 3 * H, V1);
         d.beta = 1.f;                          // DOUT was zeroed above: the k slices add atomically, no fill launch
         RC(gemm(d, st));
@@ -1282,6 +1297,11 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     if (async_tail) {
         st = tail().s;
         RC(hop(sm, tail().fork, st));
+        if (h2) {          // the logit-layer gradients deferred above
+            H2PackJob pj[2] = {pack_cols(b.DLG, b.ldg, V1, SN, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SN, b.PK_OUTDT)};
+            RC(h2_pack_multi(pj, 2, st));
+            RC(logit_grads(a, g, w, b, z, st));
+        }
     }
     // 5. part B: attention parameters (d P_all / d alpha over all timesteps, then ctx2att) and the token embedding
     if (!z) {

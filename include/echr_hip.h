@@ -210,7 +210,8 @@ typedef struct {
     int32_t async_tail;                        /* phase 0 only: 1 = the last stage (attention-parameter and token-embedding gradients; nothing else
                                                   in a backward pass depends on them) runs on a library-owned second stream and the call returns
                                                   without joining it, so that the caller's next backward kernels (event encoder, proposal encoder)
-                                                  overlap it.  The caller MUST call echr_stream_join(stream) before anything reads g_w_c2a,
+                                                  overlap it; the logit-layer gradients are formed there too.  The caller MUST call
+                                                  echr_stream_join(stream) before anything reads g_w_logit, g_b_logit, g_w_c2a,
                                                   g_b_c2a, g_w_alpha, g_b_alpha, g_embed or frees ws / ws_bwd (every library entry that takes a
                                                   stream joins first as a safety net). */
     const float* nll_msum;                     /* fused criterion path, optional: device pointer to sum(nll_mask) (the second output of
