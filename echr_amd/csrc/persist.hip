@@ -130,6 +130,14 @@ __device__ __forceinline__ void publish(u32* line) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(line + (blockIdx.x % SHARDS) * SHSTRIDE, 1u, __ATOMIC_RELAXED, ECHR_AGENT);
 }
+// the same, leaving the wave's KEEP youngest vector-memory operations in flight: loads issued AFTER the stores / atomics being published
+// (the counter retires in issue order, so everything older than those loads has completed)
+template <int KEEP>
+__device__ __forceinline__ void publish_keep(u32* line) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(line + (blockIdx.x % SHARDS) * SHSTRIDE, 1u, __ATOMIC_RELAXED, ECHR_AGENT);
+}
 
 // every thread; false = the launch is being aborted (timeout somewhere): the caller returns
 template <typename PK>
@@ -982,8 +990,6 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                 float4 q[8];
 #pragma unroll
                 for (int h = 0; h < 8; ++h) q[h] = ld16_sc1(rq, (u32)((((4 * lr + (h >> 1)) * HR + ar) * 8 + 4 * (h & 1)) * 4));
-                // q(t) complete => the q workgroups have consumed all of h1(t-1), so it is complete and visible here too
-                if (H2 && is_g1 && t > 0) h1_fetch();
                 float asum = 0.f;
 #pragma unroll
                 for (int h = 0; h < 8; ++h) {
@@ -1085,13 +1091,17 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                 }
             }
             if (srole >= 0) STAMP(srole, 6);
-            publish(cnt(C_C, t));
+            if (H2 && is_g1 && t > 0) {
+                // the gate workgroups' h1(t-1) fetch (16 loads per lane) goes out behind the context atomics and stays in flight across
+                // the publish (q(t) complete => the q workgroups have consumed all of h1(t-1), so it is complete and visible here too)
+                h1_fetch();
+                publish_keep<16>(cnt(C_C, t));
+            } else {
+                publish(cnt(C_C, t));
+            }
             if (srole >= 0) STAMP(srole, 7);
         }
-        if (H2 && is_g1 && t > 0) {
-            if (!att_live) h1_fetch();
-            h1_product();
-        }
+        if (H2 && is_g1 && t > 0) h1_product();
         // ---- phase C: attended-context columns + gate math; the new h1 goes to the next step ----
         if (is_g1) {
             if (!wait_total(P, cnt(C_C, t), HWG, flag, 300000u + t)) return;
