@@ -112,3 +112,33 @@ def caption_video(tap_model, cg_model, c3d_feats, lda_feats, duration, featstamp
         vid_info.append({'sentence': sent, 'timestamp': good_time_stamps[i], 'sentence_confidence': cg_score[i],
                          'proposal_score': float(tap_prob[i]), 're_score': 10 * float(tap_prob[i]) + cg_score[i], 'num': [i, len(sents)]})
     return vid_info, extras
+
+
+def gettopN_nms(props, prop_scores, sent_score, nms_overlap=0.999, topN=1000):
+    """Host-side greedy temporal NMS over already materialised proposals (eval_utils.py:230-256; called from the per-video loop at
+    :89 with sent_score = prop_scores).  Proposals are visited by descending `prop_scores`; every proposal whose IoU (with the
+    reference's +1e-3 interval closure) with the current best reaches `nms_overlap` forms its cluster, the cluster is represented by
+    its member with the highest `sent_score`, and only proposals with IoU <= nms_overlap stay for the next round.  Returns
+    (props[pick], prop_scores[pick], pick) like the reference.  A handful of proposals per video: numpy on the host, as there."""
+    props = np.asarray(props)
+    prop_scores = np.asarray(prop_scores)
+    sent_score = np.asarray(sent_score)
+    start, end = props[:, 0], props[:, 1]
+    length = (end - start + 1e-3).astype(float)
+    alive = np.argsort(prop_scores)                 # ascending; the current best is the last entry (same sort call as the reference)
+    pick = []
+    while alive.size and len(pick) < topN:
+        best = alive[-1]
+        inter = np.maximum(0., np.minimum(end[best], end[alive]) - np.maximum(start[best], start[alive]) + 1e-3)
+        iou = inter / (length[best] + length[alive] - inter)
+        cluster = alive[np.nonzero(iou >= nms_overlap)[0]]
+        pick.append(cluster[np.argmax(sent_score[cluster])])
+        alive = alive[np.nonzero(iou <= nms_overlap)[0]]
+    return props[pick, :], prop_scores[pick], pick
+
+
+def reranking(vid_info):
+    """Keep the videos whose 're_score' reaches the 10th largest one (all of them when there are fewer than 10): eval_utils.py:334-345."""
+    scores = np.sort(np.array([v['re_score'] for v in vid_info]))
+    threshold = scores[-min(len(scores), 10)]
+    return [v for v in vid_info if v['re_score'] >= threshold]

@@ -362,3 +362,34 @@ def top_proposals(scores, tap_masks, topN=1000, score_thres=0.0):
                 feat.append([n - k, n + 1])
                 conf.append(float(scores[n, k]))
     return ind, feat, conf
+
+
+def topn_nms(props, prop_scores, sent_score, nms_overlap=0.999, topN=1000):
+    """eval_utils.py:230-256 `gettopN_nms`, element by element (test infrastructure: plain loops): pick order only."""
+    props = [(float(a), float(b)) for a, b in props]
+    order = list(np.argsort(np.asarray(prop_scores)))            # eval_utils.py:238
+    pick = []
+    while order and len(pick) < topN:                            # :241
+        i = order[-1]
+        keep, same = [], []
+        for j in order:
+            wh = max(0.0, min(props[i][1], props[j][1]) - max(props[i][0], props[j][0]) + 1e-3)          # :243-245
+            o = wh / ((props[i][1] - props[i][0] + 1e-3) + (props[j][1] - props[j][0] + 1e-3) - wh)     # :246
+            if o >= nms_overlap:
+                same.append(j)                                   # :247
+            if o <= nms_overlap:
+                keep.append(j)                                   # :251
+        best = same[0]
+        for j in same:                                           # :248 argmax -> first maximum
+            if sent_score[j] > sent_score[best]:
+                best = j
+        pick.append(int(best))                                   # :249-250
+        order = keep
+    return pick
+
+
+def rerank(vid_info):
+    """eval_utils.py:334-345 `reranking`."""
+    sc = sorted(v['re_score'] for v in vid_info)
+    thr = sc[-min(len(sc), 10)]
+    return [v for v in vid_info if v['re_score'] >= thr]

@@ -134,3 +134,19 @@ def test_reference_made_checkpoint_loads():
     res = tap.load_state_dict(ck['tap_model'], strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     assert torch.equal(cg.lm_model.core.layer1.weight_ih, ck['cg_model']['lm_model.core.layer1.weight_ih'])
+
+
+def test_host_side_proposal_utilities_match_reference_fixture():
+    """echr_amd.eval_utils.gettopN_nms / reranking (host numpy like the reference's eval_utils.py:230-256, :334-345) against the
+    reference-generated picks."""
+    from echr_amd import eval_utils as EU
+    from tests import util as U
+    g = U.gold('proposals.npz')
+    for i in range(3):
+        props, psc, ssc = g['m%d|props' % i], g['m%d|pscore' % i], g['m%d|sscore' % i]
+        rp, rs_, pick = EU.gettopN_nms(props, psc, ssc, nms_overlap=float(g['m%d|thr' % i]), topN=int(g['m%d|topN' % i]))
+        assert np.array_equal(np.asarray(pick, np.int64), g['m%d|pick' % i])
+        assert np.array_equal(rp, props[g['m%d|pick' % i]]) and np.array_equal(rs_, psc[g['m%d|pick' % i]])
+    for i in range(3):
+        info = [{'re_score': float(x), 'id': j} for j, x in enumerate(g['r%d|scores' % i])]
+        assert [v['id'] for v in EU.reranking(info)] == list(g['r%d|kept' % i])

@@ -119,3 +119,15 @@ def test_c5_joint_sst_and_caption_path():
     for key, v in SM.summarize_grads({k: p.grad.numpy() for k, p in SP.items()}).items():
         ref = g['train|sstgrad|' + key]
         assert np.allclose(v, ref, rtol=1e-3, atol=1e-6 * (1 + np.abs(ref).max())), key
+
+
+def test_topn_nms_and_reranking_match_reference_fixture():
+    """oracle.topn_nms / oracle.rerank against the reference's gettopN_nms / reranking outputs (tools/make_golden.py do_proposals)."""
+    g = U.gold('proposals.npz')
+    for i in range(3):
+        pick = O.topn_nms(g['m%d|props' % i], g['m%d|pscore' % i], g['m%d|sscore' % i], float(g['m%d|thr' % i]), int(g['m%d|topN' % i]))
+        assert np.array_equal(np.array(pick, np.int64), g['m%d|pick' % i])
+        assert len(pick) <= int(g['m%d|topN' % i])
+    for i in range(3):
+        info = [{'re_score': float(x), 'id': j} for j, x in enumerate(g['r%d|scores' % i])]
+        assert [v['id'] for v in O.rerank(info)] == list(g['r%d|kept' % i])

@@ -327,6 +327,29 @@ def do_proposals():
         out['n%d|overlap' % i] = np.float64(ov)
         out['n%d|props' % i] = np.asarray(props, np.int64)
         out['n%d|conf' % i] = np.asarray(sc, np.float64)
+    # gettopN_nms (eval_utils.py:230-256) on materialised proposals and reranking (:334-345); distinct scores keep the reference's
+    # (unstable) argsort deterministic
+    for i, (P, thr, topN) in enumerate(((40, 0.5, 1000), (200, 0.8, 25), (64, 0.999, 1000))):
+        rs = np.random.RandomState(300 + i)
+        t1 = rs.randint(0, 80, size=P)
+        props = np.stack([t1, t1 + rs.randint(1, 40, size=P)], axis=1).astype(np.float64)
+        psc = (rs.permutation(P).astype(np.float64) + 1.0) / P
+        ssc = (rs.permutation(P).astype(np.float64) + 1.0) / P
+        rp, rsco, pick = ref_eval.gettopN_nms(props, psc, ssc, nms_overlap=thr, topN=topN)
+        assert [int(x) for x in pick] == O.topn_nms(props, psc, ssc, thr, topN)
+        out['m%d|props' % i] = props
+        out['m%d|pscore' % i] = psc
+        out['m%d|sscore' % i] = ssc
+        out['m%d|thr' % i] = np.float64(thr)
+        out['m%d|topN' % i] = np.int64(topN)
+        out['m%d|pick' % i] = np.asarray(pick, np.int64)
+    for i, n in enumerate((4, 10, 37)):
+        rs = np.random.RandomState(400 + i)
+        info = [{'re_score': float(x), 'id': j} for j, x in enumerate(rs.permutation(n) / float(n))]
+        kept = ref_eval.reranking(info)
+        assert [v['id'] for v in kept] == [v['id'] for v in O.rerank(info)]
+        out['r%d|scores' % i] = np.array([v['re_score'] for v in info])
+        out['r%d|kept' % i] = np.array([v['id'] for v in kept], np.int64)
     np.savez_compressed(os.path.join(GOLD, 'proposals.npz'), **out)
     print('wrote proposals.npz')
 
