@@ -71,7 +71,7 @@ class SstGrads(C.Structure):
 
 class SampleArgs(C.Structure):
     _fields_ = [('dec', DecArgs), ('seq_len', i32), ('seq', c_f), ('seq_logp', c_f), ('n_unfinished', c_f),
-                ('ws_sample', c_f)]
+                ('ws_sample', c_f), ('multinomial', i32), ('temperature', C.c_float), ('seed', C.c_uint64)]
 
 
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)

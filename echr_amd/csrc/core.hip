@@ -598,6 +598,76 @@ __global__ void clamp_kernel(float* g, long n, float clip) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = clamp_keep_nan(g[i], clip);
 }
 
+// ---- multinomial step (OldModel_NEW.py:160-168, sample_max = 0): token j with probability exp(logp_j / T) / sum_j exp(logp_j / T) ---
+// by inverse CDF: thread th owns the contiguous indices [CH th, CH th + CH), a block scan of the per-thread masses finds the owner of
+// u * total, which then walks its chunk.  u comes from the library's counter-based Philox stream keyed by (seed, row, step), so a
+// decode is reproducible for a given seed (it is NOT torch.multinomial's stream: only the distribution matches the reference).
+// The emitted log-prob is the un-tempered log-softmax value of the sampled token (`logprobs.gather`, :167).
+constexpr unsigned SITE_SAMPLE = 6;
+__global__ __launch_bounds__(256) void sample_step_kernel(const float* __restrict__ logits, long ld, int V1, int t, int seq_len,
+                                                          int* __restrict__ it_next, int* __restrict__ unfinished,
+                                                          long long* __restrict__ seq, float* __restrict__ seq_logp,
+                                                          int* __restrict__ n_unfinished, float inv_temp, unsigned k0, unsigned k1) {
+    __shared__ float red[4];
+    __shared__ float pre[257];
+    const int n = blockIdx.x, th = threadIdx.x;
+    const float* x = logits + (long)n * ld;
+    const int CH = (V1 + 255) / 256, j0 = th * CH, j1 = min(V1, j0 + CH);
+    float m = -INFINITY;
+    for (int j = th; j < V1; j += 256) m = fmaxf(m, x[j]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int j = th; j < V1; j += 256) s += expf(x[j] - m);
+    s = block_sum(s, red);
+    const float lz = m + logf(s);                        // log-softmax: logp_j = x_j - lz
+    float mass = 0.f;
+    // (weights relative to the row maximum: softmax(logp / T) does not change, and the largest weight is 1 at any temperature)
+    for (int j = j0; j < j1; ++j) mass += expf((x[j] - m) * inv_temp);
+    pre[th + 1] = mass;
+    if (th == 0) pre[0] = 0.f;
+    __syncthreads();
+    if (th == 0) {                                       // 256 sequential adds: one fixed order, negligible beside the row reads
+        float acc = 0.f;
+        for (int i = 1; i <= 256; ++i) { acc += pre[i]; pre[i] = acc; }
+    }
+    __syncthreads();
+    const float total = pre[256];
+    const unsigned w = philox_word((unsigned)n, (unsigned)t, SITE_SAMPLE, 0u, k0, k1);
+    const float target = (float)(w >> 8) * (1.0f / 16777216.0f) * total;
+    // the owner: first thread whose inclusive prefix exceeds the target (the last thread with mass when rounding pushes it past the end)
+    const bool mine = (pre[th] <= target && target < pre[th + 1]) || (th == 255 && target >= total);
+    if (mine) {
+        float acc = pre[th];
+        int pick = -1;
+        for (int j = j0; j < j1; ++j) {
+            acc += expf((x[j] - m) * inv_temp);
+            if (acc > target) { pick = j; break; }
+        }
+        if (pick < 0) {                                  // rounding at the chunk end: the last index with non-zero mass up to here
+            pick = max(0, min(V1, j1) - 1);
+            while (pick > 0 && !(expf((x[pick] - m) * inv_temp) > 0.f)) --pick;
+        }
+        const float lp = x[pick] - lz;
+        int un = (t == 0) ? 1 : unfinished[n];
+        un = un && (pick > 0);
+        unfinished[n] = un;
+        it_next[n] = pick;
+        if (t < seq_len) {
+            seq[(long)n * seq_len + t] = un ? pick : 0;
+            seq_logp[(long)n * seq_len + t] = lp;
+        }
+        if (un) atomicAdd(&n_unfinished[t + 1], 1);
+    }
+}
+
+int sample_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished, long long* seq,
+                float* seq_logp, int* n_unfinished, float temperature, unsigned long long seed, hipStream_t st) {
+    const float inv_temp = 1.0f / (temperature > 0.f ? temperature : 1.0f);
+    hipLaunchKernelGGL(sample_step_kernel, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq, seq_logp, n_unfinished,
+                       inv_temp, (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32));
+    return check_launch("sample_step");
+}
+
 int greedy_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
                 long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st) {
     hipLaunchKernelGGL(greedy_step_kernel, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq, seq_logp, n_unfinished);

@@ -1418,8 +1418,12 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
             d.bias = a.b_logit; d.split_k = 1;
             RC(gemm(d, st));
         }
-        RC(greedy_step(s.LOGITS, a.V1, N, a.V1, t, L, s.IT, s.UNF, reinterpret_cast<long long*>(sa->seq), sa->seq_logp,
-                       sa->n_unfinished, st));
+        if (sa->multinomial)
+            RC(sample_step(s.LOGITS, a.V1, N, a.V1, t, L, s.IT, s.UNF, reinterpret_cast<long long*>(sa->seq), sa->seq_logp, sa->n_unfinished,
+                           sa->temperature, sa->seed, st));
+        else
+            RC(greedy_step(s.LOGITS, a.V1, N, a.V1, t, L, s.IT, s.UNF, reinterpret_cast<long long*>(sa->seq), sa->seq_logp,
+                           sa->n_unfinished, st));
     }
     return 0;
 }

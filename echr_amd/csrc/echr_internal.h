@@ -108,6 +108,8 @@ int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int 
 int logsoftmax_rows(float* X, long ld, int N, int S, int t0, int nt, int cols, hipStream_t st);
 int logsoftmax_bwd(const float* logp, const float* G, const int* target, const float* mask, const float* g_loss,
                    const float* mask_sum, float* out, long ldo, int N, int S, int V1, hipStream_t st);
+int sample_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished, long long* seq,
+                float* seq_logp, int* n_unfinished, float temperature, unsigned long long seed, hipStream_t st);
 int greedy_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
                 long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st);
 

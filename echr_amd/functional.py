@@ -311,8 +311,10 @@ class DecoderFunction(torch.autograd.Function):
         return (g_video, g_event, None, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
-def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, debug=None):
-    """Greedy OldModel.sample (OldModel_NEW.py:139-187) with every step on device; one host sync at the end.
+def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, debug=None, multinomial=False, temperature=1.0, seed=0):
+    """OldModel.sample (OldModel_NEW.py:139-187) with every step on device; one host sync at the end.  Greedy arg-max by default
+    (sample_max = 1); multinomial=True draws each token from softmax(logp / temperature) (:160-168) with the library's Philox stream
+    keyed by `seed`.
 
     Returns (seq int64 [N,T], logp fp32 [N,T]) with T <= seq_length, or ([], []) when nothing was generated."""
     lib = L.load()
@@ -327,7 +329,8 @@ def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, de
     seq = torch.empty(N, seq_length, device=dev, dtype=torch.int64)
     slp = torch.empty(N, seq_length, device=dev, dtype=torch.float32)
     nun = torch.empty(seq_length + 1, device=dev, dtype=torch.int32)
-    sa = L.SampleArgs(a, seq_length, L.ptr(seq, torch.int64), L.ptr(slp), L.ptr(nun, torch.int32), L.ptr(wss))
+    sa = L.SampleArgs(a, seq_length, L.ptr(seq, torch.int64), L.ptr(slp), L.ptr(nun, torch.int32), L.ptr(wss),
+                      1 if multinomial else 0, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF)
     L.check(lib.echr_decoder_sample(C.byref(sa), L.stream_ptr()), 'decoder_sample')
     counts = nun.cpu().numpy()                 # the only device->host sync of the whole decode
     if debug is not None:                      # tests: the raw logits [N,V1] of the last decoder step (sampler workspace: XT | LOGITS | ...)

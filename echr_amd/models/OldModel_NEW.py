@@ -179,13 +179,24 @@ class OldModel(nn.Module):
             return EF.decoder_step(it, video, event, cv.feats, cv.ev_start, cv.ev_len, cv.max_len, state, self.native_params(), drop)
 
     def sample(self, video, event, clip, clip_mask, opt={}):
-        """Greedy decoding (OldModel_NEW.py:139-187 with sample_max=1, beam_size=1)."""
-        if opt.get('sample_max', 1) != 1 or opt.get('beam_size', 1) != 1:
-            raise NotImplementedError('only greedy decoding (sample_max=1, beam_size=1) is on the HIP path')
+        """Decoding without beam search (OldModel_NEW.py:139-187, beam_size = 1): greedy arg-max (sample_max = 1, the recipe's setting) or,
+        with sample_max = 0, a draw from softmax(logp / temperature) per step (:160-168).  The draws come from the library's
+        counter-based Philox stream (seed: set_dropout_state / torch.initial_seed, advanced once per call), not from
+        torch.multinomial's generator: same distribution, different random numbers."""
+        if opt.get('beam_size', 1) != 1:
+            raise NotImplementedError('beam search (beam_size > 1) is not on the HIP path')
         cv = self._clip_view(clip, clip_mask)
+        multinomial = opt.get('sample_max', 1) != 1
+        seed = 0
+        if multinomial:
+            if self._drop_seed is None:
+                self.next_drop_state()                     # derives the (rank-mixed) seed once
+            self._sample_calls = getattr(self, '_sample_calls', 0) + 1
+            seed = (self._drop_seed * 0x9E3779B97F4A7C15 + self._sample_calls) & 0xFFFFFFFFFFFFFFFF
         with torch.no_grad():
             return EF.greedy_sample(video, event, cv.feats, cv.ev_start, cv.ev_len, cv.max_len, self.seq_length,
-                                    self.native_params())
+                                    self.native_params(), multinomial=multinomial, temperature=float(opt.get('temperature', 1.0)),
+                                    seed=seed)
 
 
 class Attention(nn.Module):

@@ -248,7 +248,7 @@ int echr_nll_loss_fwd(const float* logp, const int32_t* target, const float* mas
 int echr_nll_loss_bwd(const int32_t* target, const float* mask, const float* fwd_out, const float* g_loss, float* g_logp,
                       int32_t N, int32_t S, int32_t V1, void* stream);
 
-/* greedy sampler: runs seq_len+1 decoder steps on device without host syncs.
+/* sampler (greedy or multinomial): runs seq_len+1 decoder steps on device without host syncs.
  * seq [N,seq_len] int64 (zero after a row finished), seq_logp [N,seq_len] fp32,
  * n_unfinished [seq_len+1] int32: number of unfinished rows after step t (the host trims the output
  * at the first t >= 1 with n_unfinished[t] == 0, as OldModel.sample's break does). */
@@ -259,6 +259,11 @@ typedef struct {
     float* seq_logp;
     int32_t* n_unfinished;
     float* ws_sample;        /* echr_sampler_ws_floats */
+    int32_t multinomial;     /* 0 = greedy arg-max (sample_max = 1, lowest index on ties); 1 = draw from softmax(logp / temperature)
+                                (OldModel_NEW.py:160-168, sample_max = 0) with the library's Philox stream keyed by (seed, row, step):
+                                reproducible per seed, the reference's distribution but not torch.multinomial's random stream */
+    float temperature;       /* multinomial only; <= 0 means 1 */
+    uint64_t seed;
 } echr_sample_args;
 int64_t echr_sampler_ws_floats(const echr_dec_args* a);
 int echr_decoder_sample(const echr_sample_args* a, void* stream);

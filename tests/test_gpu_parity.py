@@ -1040,3 +1040,62 @@ def test_persistent_recurrence_edge_shapes(N, A, L, min_len, video_dim):
                 assert np.abs(g1[k]).max() < 1e-6 and np.abs(g0[k]).max() < 1e-6, k
             else:
                 assert U.relerr(g1[k], g0[k], 1e-4) < 1e-4, (k, U.relerr(g1[k], g0[k], 1e-4))
+
+
+@pytest.mark.gpu
+def test_multinomial_sampling_distribution_and_reproducibility():
+    """OldModel.sample with sample_max = 0 (OldModel_NEW.py:160-168): every step draws a token from softmax(logp / temperature).
+    The random stream is the library's Philox, not torch.multinomial's, so the check is distributional: over 3000 seeds the first
+    sampled token of each event follows the softmax of the <bos> step's log-probs (chi-square on the tokens with expected count >= 5,
+    the rest pooled; 5-sigma bound), also at temperature 0.7; a fixed seed reproduces the whole decode bit for bit; a very low
+    temperature reduces to the greedy decode; the emitted log-probs are the un-tempered log-softmax values of the sampled tokens."""
+    opt, params, vid = synth.make_case('tiny')
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    lm = m.lm_model
+    with torch.no_grad():
+        video = m.get_video_context(tap, c3d, lda, vid['ind'], vid['soi'])
+        event = m.get_event_context(tap, c3d, lda, vid['ind'], vid['soi'])
+        clip, cmask = m.get_clip_context(tap, c3d, lda, vid['ind'], vid['soi'])
+        N = event.shape[0]
+        logp0, _ = lm.get_logprobs_state(torch.zeros(N, dtype=torch.int64, device=dev), video, event, clip, cmask,
+                                         lm.init_hidden(video, event, clip))
+        logp0 = logp0.double().cpu().numpy()
+        V1 = logp0.shape[1]
+        greedy_seq, _ = lm.sample(video, event, clip, cmask, {'sample_max': 1})
+        for temp in (1.0, 0.7):
+            counts = np.zeros((N, V1))
+            draws = 3000
+            for s in range(draws):
+                m.set_dropout_state(1000 + s)
+                lm._sample_calls = 0
+                seq, slp = lm.sample(video, event, clip, cmask, {'sample_max': 0, 'temperature': temp})
+                first = seq[:, 0].cpu().numpy() if len(seq) else np.zeros(N, np.int64)
+                # a draw of token 0 ends the caption at once: the sampler then returns nothing for rows that all finished
+                counts[np.arange(N), first] += 1
+                if s == 0 and len(seq):
+                    tok = seq[:, 0].cpu().numpy()
+                    assert np.abs(slp[:, 0].cpu().numpy() - logp0[np.arange(N), tok]).max() < 1e-4
+            p = np.exp(logp0 / temp)
+            p /= p.sum(1, keepdims=True)
+            for n in range(N):
+                exp_c = p[n] * draws
+                big = exp_c >= 5
+                chi = ((counts[n, big] - exp_c[big]) ** 2 / exp_c[big]).sum()
+                dof = int(big.sum())
+                if (~big).any():
+                    e_rest, c_rest = exp_c[~big].sum(), counts[n, ~big].sum()
+                    if e_rest > 0:
+                        chi += (c_rest - e_rest) ** 2 / e_rest
+                        dof += 1
+                assert chi < dof + 5.0 * np.sqrt(2.0 * dof), (temp, n, chi, dof)
+        m.set_dropout_state(77)
+        lm._sample_calls = 0
+        a_seq, a_lp = lm.sample(video, event, clip, cmask, {'sample_max': 0})
+        m.set_dropout_state(77)
+        lm._sample_calls = 0
+        b_seq, b_lp = lm.sample(video, event, clip, cmask, {'sample_max': 0})
+        assert torch.equal(a_seq, b_seq) and torch.equal(a_lp, b_lp)
+        c_seq, _ = lm.sample(video, event, clip, cmask, {'sample_max': 0, 'temperature': 1e-3})
+        assert torch.equal(c_seq, greedy_seq)
