@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ 
 // grid (N, ceil(A/8)): 4 waves x 2 slots; q_t[n,:] for a tile of TT timesteps is staged in LDS (4 workgroups per CU).
 constexpr int TT = 10;
 constexpr int PSLOTS = 2;
+constexpr int ALPHA_REP = 32;       // replicas of d alpha / d b_alpha that att_post accumulates into
 template <int R>
 __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__ PALL, const float* __restrict__ QS,
                                                        const float* __restrict__ alpha, const float* __restrict__ DSC,
@@ -424,9 +425,12 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
         if (j < Ha) *reinterpret_cast<float4*>(red + wave * Ha + j) = make_float4(dsum - 2.f * dal[r].x, dsum - 2.f * dal[r].y, dsum - 2.f * dal[r].z, dsum - 2.f * dal[r].w);
     }
     __syncthreads();
+    // ALPHA_REP replicas of the two parameter gradients, summed by a column-sum launch afterwards: the N * ceil(A/8) workgroups used to
+    // add into ONE [Ha] vector (1024 adders per address on 16 cache lines: those atomics, not the arithmetic, were the kernel's 66 us)
+    const int rep = (int)((blockIdx.x + blockIdx.y * gridDim.x) % ALPHA_REP);
     for (int j = threadIdx.x; j < Ha; j += 256)
-        atomicAdd(&g_alpha[j], red[j] + red[Ha + j] + red[2 * Ha + j] + red[3 * Ha + j]);
-    if (lane == 0 && dsum != 0.f) atomicAdd(g_balpha, dsum);
+        atomicAdd(&g_alpha[(long)rep * Ha + j], red[j] + red[Ha + j] + red[2 * Ha + j] + red[3 * Ha + j]);
+    if (lane == 0 && dsum != 0.f) atomicAdd(g_balpha + rep, dsum);
 }
 
 // ---- launch helpers (dispatch on the per-lane row widths) ------------------------------------------------
@@ -733,6 +737,7 @@ struct DecWsBwd {
     float *PK_DLGT, *PK_OUTDT, *PK_DLG, *PK_WLT, *PK_DGT[3], *PK_DG[3], *PK_HT[3], *PK_XTT, *PK_ATTT, *PK_DQT, *PK_WIHT[3], *PK_DPT, *PK_C3DT;
     long snp;
     float *DHACC[3], *DASL;                  // atomic accumulation targets: d h(t-1) per stream [N,H]; DASL: d ATT [S,N,D]
+    float *GAREP, *GBREP;                    // replicated attention-vector gradients (att_post_kernel)
     float *XWSB;                             // exchange buffers + counters of the persistent reverse recurrence (csrc/persist.hip)
     long ldg, total, zero_floats;
 };
@@ -752,6 +757,8 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     for (int k = 0; k < 3; ++k) w.DHACC[k] = take(N * H);
     w.DQ = take(S * N * a->Ha);
     w.DASL = take(S * N * a->D);
+    w.GAREP = take((long)ALPHA_REP * a->Ha);      // att_post's replicated d alpha, then [ALPHA_REP] d b_alpha
+    w.GBREP = take(ALPHA_REP);
     w.DPALL = take((long)a->Tv * a->Ha);
     w.zero_floats = (w.DPALL - w.DC) + rup((long)a->Tv * a->Ha, 64);
     for (int k = 0; k < 3; ++k) w.DGSUM[k] = take(N * 4 * H);
@@ -1304,15 +1311,13 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         }
     }
     // 5. part B: attention parameters (d P_all / d alpha over all timesteps, then ctx2att) and the token embedding
-    if (!z) {
-        RC(fill_zero(g->g_w_alpha, Ha, st));
-        RC(fill_zero(g->g_b_alpha, 1, st));
-    }
     {
     ProfScope prof(PROF_ATT_POST, 6.0 * N * A * Ha * S, 4.0 * ((double)N * A * Ha * 2 + (double)S * N * (Ha + A)), st);
     const AttDims ad{N, A, Ha, D};
-    RC(launch_att_post(ad, w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, g->g_w_alpha, g->g_b_alpha, S, a->rows_disjoint ? 1 : 0, st));
+    RC(launch_att_post(ad, w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, b.GAREP, b.GBREP, S, a->rows_disjoint ? 1 : 0, st));
     }
+    RC(colsum(b.GAREP, Ha, ALPHA_REP, Ha, g->g_w_alpha, z, st));        // replicas -> d alpha, d b_alpha (overwrite or accumulate like every
+    RC(colsum(b.GBREP, 1, ALPHA_REP, 1, g->g_b_alpha, z, st));          // other parameter gradient)
     if (h2) {
         H2PackJob pj[2] = {pack_cols(b.DPALL, Ha, Ha, a->Tv, b.PK_DPT), pack_cols(a->c3d, D, D, a->Tv, b.PK_C3DT)};
         RC(h2_pack_multi(pj, 2, st));
