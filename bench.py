@@ -75,7 +75,8 @@ def gpu_leg(args, rank, world, local_rank):
         torch.manual_seed(0)
         tap_model = EM.setup_tap(opt).to(dev)
         tap_model.train()
-        tap_optim = ClampAdam(tap_model.parameters(), lr=opt.lr)
+        tap_arena = None if args.no_arena else tap_model.build_arena()
+        tap_optim = ClampAdam(tap_model.parameters(), lr=opt.lr, arena=tap_arena)
         tap_crit = TAPModelCriterion()
         tl, tm, tw = (torch.from_numpy(vid[k]).to(dev) for k in ('tap_labels', 'tap_masks', 'w1'))
 

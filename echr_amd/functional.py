@@ -469,8 +469,9 @@ class SSTFunction(torch.autograd.Function):
     """SST.forward (models/sst_model.py:31-40): 2-layer LSTM over one video + sigmoid proposal head, native."""
 
     @staticmethod
-    def forward(ctx, x, p_drop, drop, *params):
+    def forward(ctx, x, p_drop, drop, sink, *params):
         lib = L.load()
+        ctx.sink = sink
         x = _f32c(x)
         ps = [_f32c(p) for p in params]           # w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_sc, b_sc
         T, D = x.shape
@@ -501,7 +502,9 @@ class SSTFunction(torch.autograd.Function):
         p_drop, drop = ctx.meta
         T, D = x.shape
         H, K = ps[1].shape[1], ps[8].shape[0]
-        grads = [torch.empty_like(p) for p in ps]
+        # the library overwrites every gradient buffer: arena views (when the module has an arena and no gradient is live) need no fill
+        use_arena = ctx.sink is not None and ctx.sink.usable()
+        grads = [ctx.sink.arena.grad_view(s) for s in ctx.sink.slots] if use_arena else [torch.empty_like(p) for p in ps]
         wsb = torch.empty(lib.echr_sst_ws_bwd_floats(T, D, H, K), device=x.device, dtype=torch.float32)
         a = SSTFunction._args(ps, x, p_drop, ws, tap, scores)
         two = lambda a_, b_: (L.c_f * 2)(L.ptr(a_), L.ptr(b_))
@@ -510,7 +513,7 @@ class SSTFunction(torch.autograd.Function):
                        L.ptr(_f32c(g_scores)) if g_scores is not None else None, L.ptr(wsb))
         d = drop.c()
         L.check(lib.echr_sst_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'sst_bwd')
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
 class TapBCE(torch.autograd.Function):

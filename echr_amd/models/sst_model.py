@@ -60,4 +60,12 @@ class SST(nn.Module):
         drop = EF.DropState(self._drop_seed, self._drop_calls, p > 0.0)
         if p > 0.0:
             self._drop_calls += 1
-        return EF.SSTFunction.apply(features, p, drop, *self.native_params())
+        arena = getattr(self, '_echr_arena', None)
+        sink = EF.GradSink(arena, self.native_params()) if arena is not None else None
+        return EF.SSTFunction.apply(features, p, drop, sink, *self.native_params())
+
+    def build_arena(self):
+        """Pack parameters and gradients into flat device buffers (echr_amd/arena.py): ClampAdam(..., arena=...) then updates the whole
+        proposal encoder in ONE launch, as CaptionGenerator.build_arena() does for the caption path.  Call after .cuda()."""
+        from ..arena import ParamArena
+        return ParamArena(self)

@@ -1099,3 +1099,32 @@ def test_multinomial_sampling_distribution_and_reproducibility():
         assert torch.equal(a_seq, b_seq) and torch.equal(a_lp, b_lp)
         c_seq, _ = lm.sample(video, event, clip, cmask, {'sample_max': 0, 'temperature': 1e-3})
         assert torch.equal(c_seq, greedy_seq)
+
+
+@pytest.mark.gpu
+def test_sst_flat_arena_update_equals_per_tensor_update():
+    """SST.build_arena(): gradients land in the flat arena (views adopted by autograd) and ClampAdam updates the whole proposal encoder
+    in one launch; two optimiser steps equal the per-tensor path bit for bit (same kernels element-wise, no atomics in the SST)."""
+    from echr_amd.optim import ClampAdam
+    from echr_amd.misc.utils import clip_gradient
+    g = U.gold('sst.npz')
+    params = {k[len('param|'):]: v for k, v in g.items() if k.startswith('param|')}
+    dev = torch.device('cuda')
+    x = torch.from_numpy(g['x']).to(dev)
+    out = {}
+    for arena_on in (False, True):
+        m, _ = _sst_module(params, dict(synth.CASES['tiny']['opt'], K=8), False)
+        arena = m.build_arena() if arena_on else None
+        o = ClampAdam(m.parameters(), lr=1e-3, arena=arena)
+        for _ in range(2):
+            o.zero_grad()
+            tap, sc = m(x)
+            ((tap * tap).sum() + sc.sum()).backward()
+            if arena_on:
+                assert arena.grads_in_arena()
+            clip_gradient(o, 0.05)
+            o.step()
+        torch.cuda.synchronize()
+        out[arena_on] = {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+    for k in out[False]:
+        assert np.array_equal(out[False][k], out[True][k]), k
