@@ -114,7 +114,7 @@ def main(argv=None):
             cg_opt.step()
             if a.joint:
                 tap_opt.step()
-        history.append(float(cg_loss))
+        history.append(float(cg_loss.detach()))
         if not a.quiet and (it % 5 == 0 or it == start + a.iters - 1):
             print('iter %3d  cg_loss %.4f' % (it, history[-1]), flush=True)
     cg_model.eval()
