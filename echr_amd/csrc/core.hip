@@ -35,7 +35,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 Config& config() {
     static Config c = {env_int("ECHR_GEMM_BF16X3", 1), env_int("ECHR_OVERLAP", 0), env_int("ECHR_ATT_SLOTS", 2), env_int("ECHR_CHAINS2", 0),
                        env_int("ECHR_GEMM_H2", 1), env_int("ECHR_PERSIST", 1), env_int("ECHR_PERSIST_STAMPS", 0),
-                       getenv("ECHR_GEMM_TILE") ? (int)getenv("ECHR_GEMM_TILE")[0] : 0, env_int("ECHR_GEMM_SPLIT", 0), env_int("ECHR_PERSIST_BWD", 1), env_int("ECHR_PERSIST_SPLIT", 1), env_int("ECHR_PERSIST_H2", 1), env_int("ECHR_PERSIST_MERGE", 1), env_int("ECHR_PERSIST_KGROUPS", 1)};
+                       getenv("ECHR_GEMM_TILE") ? (int)getenv("ECHR_GEMM_TILE")[0] : 0, env_int("ECHR_GEMM_SPLIT", 0), env_int("ECHR_PERSIST_BWD", 1), env_int("ECHR_PERSIST_SPLIT", 1), env_int("ECHR_PERSIST_H2", 1), env_int("ECHR_PERSIST_MERGE", 1), env_int("ECHR_PERSIST_KGROUPS", 1), env_int("ECHR_TSRM_FORK", 1)};
     return c;
 }
 
@@ -780,6 +780,7 @@ extern "C" int echr_config_set(const char* key, int32_t value) {
     else if (!strcmp(key, "persist_h2")) c.persist_h2 = value;
     else if (!strcmp(key, "persist_merge")) c.persist_merge = value;
     else if (!strcmp(key, "persist_kgroups")) c.persist_kgroups = value;
+    else if (!strcmp(key, "tsrm_fork")) c.tsrm_fork = value;
     else if (!strcmp(key, "gemm_tile")) c.gemm_tile = value;          // tuning only: ASCII code of the tile selector ('1','6','a','b','c','s'), 0 = heuristics
     else if (!strcmp(key, "gemm_split")) c.gemm_split = value;        // tuning only: forced k-slice count of auto-split products, 0 = heuristics
     else if (!strcmp(key, "att_slots")) { ECHR_REQUIRE(value == 2 || value == 4 || value == 8, "config_set: att_slots must be 2, 4 or 8"); c.att_slots = value; }

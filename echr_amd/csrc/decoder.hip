@@ -66,7 +66,7 @@ static Side& side() {
 // backward pass depends on) can run on a second stream while autograd continues with the event encoder's / proposal encoder's
 // backward on the caller's stream.  The caller joins with echr_stream_join (the Python side does it in an end-of-backward callback);
 // every later library entry that takes a stream joins first as a safety net.
-struct Tail { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr; bool ok = false, init = false, pending = false; };
+struct Tail { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr, fork2 = nullptr, done2 = nullptr; bool ok = false, init = false, pending = false; };
 static Tail& tail() {
     static Tail t;
     if (!t.init) {
@@ -74,9 +74,22 @@ static Tail& tail() {
         bool good = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess;
         good = good && hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
         good = good && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.fork2, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.done2, hipEventDisableTiming) == hipSuccess;
         t.ok = good;
     }
     return t;
+}
+hipStream_t aux_fork(hipStream_t from) {
+    Tail& t = tail();
+    if (!t.ok) return nullptr;
+    if (hipEventRecord(t.fork2, from) != hipSuccess || hipStreamWaitEvent(t.s, t.fork2, 0) != hipSuccess) return nullptr;
+    return t.s;
+}
+int aux_join(hipStream_t to) {
+    Tail& t = tail();
+    if (hipEventRecord(t.done2, t.s) != hipSuccess || hipStreamWaitEvent(to, t.done2, 0) != hipSuccess) { set_error("stream join failed"); return -5; }
+    return 0;
 }
 int join_tail(hipStream_t st) {
     Tail& t = tail();

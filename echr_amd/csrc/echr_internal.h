@@ -17,7 +17,7 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; };
 Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);
@@ -37,6 +37,10 @@ long persist_bwd_ws_floats(int S);
 bool persist_bwd_eligible(const echr_dec_args* a);
 int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
 int persist_check_async();
+// the library's helper stream outside a backward pass (the one the asynchronous decoder-backward tail uses): `aux_fork` makes it continue
+// after everything queued on `from` and returns it, `aux_join` makes `to` wait for what was queued on it since
+hipStream_t aux_fork(hipStream_t from);          // nullptr when unavailable
+int aux_join(hipStream_t to);
 int join_tail(hipStream_t st);          // make st wait for an asynchronous decoder-backward tail (decoder.hip); no-op when none is pending
 int persist_read_stamps(unsigned long long* dst, int max_entries);
 int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st);

@@ -175,26 +175,31 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
             set_error("tsrm_attn_fwd: input copy failed");
             return -5;
         }
-    } else {
-    // event embedding (:44)
-    d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1; d.beta = 1.f;
-    RC(gemm(d, st));
-    // pairwise position features -> per-head gates (:39-41, :108-116)
-    RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, st));
+    }
+    // pairwise position features -> per-head gates (:39-41, :108-116): independent of the event features, so the branch runs on the
+    // library's helper stream beside the embedding / query / key products (it needs the zero fill above: GATE accumulates)
+    hipStream_t sp = config().tsrm_fork ? aux_fork(st) : nullptr;
+    const bool fork = sp != nullptr;
+    if (!fork) sp = st;
+    if (!x_given) {
+        // event embedding (:44)
+        d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1; d.beta = 1.f;
+        RC(gemm(d, st));
+        RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, sp));
     }
     // fc1 over the N*N event pairs: the one TSRM product big enough for the h2 path (tanh fused in the epilogue)
     if (config().gemm_h2 && NN >= 1024) {
         H2PackJob pj[2] = {pack_rows(w.POS, Df, NN, Df, w.PK_POS), pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1)};
-        RC(h2_pack_multi(pj, 2, st));
+        RC(h2_pack_multi(pj, 2, sp));
         d = desc_h2(w.PK_POS, w.PK_WFC1, w.P1, Df, NN, Df, Df);
         d.split_k = 1;
     } else {
         d = desc_nt(w.POS, Df, a->w_fc1, Df, w.P1, Df, NN, Df, Df);
     }
     d.bias = a->b_fc1; d.act = ECHR_ACT_TANH;
-    RC(gemm(d, st));
+    RC(gemm(d, sp));
     d = desc_nt(w.P1, Df, a->w_fc2, Df, w.GATE, G, NN, G, Df); d.bias = a->b_fc2; d.split_k = -1; d.beta = 1.f;
-    RC(gemm(d, st));
+    RC(gemm(d, sp));
     // query / key / (pre-applied) output projection of X: one grouped launch when the three problems have one shape
     {
         echr_gemm_desc q3[3];
@@ -210,6 +215,7 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
     d.batch = G; d.bsa = dgq; d.bsb = dgq; d.bsc = (long)NN; d.alpha = 1.0f / sqrtf((float)dgq);
     RC(gemm(d, st));
     const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
+    if (fork) RC(aux_join(st));
     hipLaunchKernelGGL(tsrm_softmax_fwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, w.WD, N, G, dc);
     RC(check_launch("tsrm_softmax_fwd"));
     // OUT[:, g] = WD_g . XW_g + b_out_g

@@ -359,6 +359,8 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *                      of 256 workgroups on the caller's stream (0: two concurrent launches on two streams; needs two free hardware queues)
  *   "persist_kgroups" 0/1 (default 1, ECHR_PERSIST_KGROUPS) reverse LSTM role with the contraction split over 4 workgroup groups (128 KB of
  *                      ingest per workgroup and step plus a small partial-tile exchange) instead of 512 KB per workgroup
+ *   "tsrm_fork"   0/1  (default 1, ECHR_TSRM_FORK) echr_tsrm_fwd runs its position branch (pair embedding -> fc1 -> fc2 gates) on the
+ *                      library's helper stream beside the event-embedding / query / key products
  *   "persist_stamps" 0/1/2 diagnostic phase stamps of the forward (1) / reverse (2) pair, see echr_persist_read_stamps
  *   "gemm_tile", "gemm_split"  tuning overrides of the GEMM tile / split-K heuristics (0 = heuristics; tools/gemm_bench.py only) */
 int echr_config_set(const char* key, int32_t value);
