@@ -334,6 +334,24 @@ def cpu_leg(args):
                        % (len(t_all), avail, os.cpu_count(), len(t_one), torch.__version__))
 
 
+def self_launch(args):
+    """Start `--gpus N` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and relay the
+    child's stdout (rank 0 prints the one JSON line) and exit code.  Runs before this process has made any GPU call."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    print('[bench] launching %d ranks: %s' % (args.gpus, ' '.join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -349,15 +367,47 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-native', action='store_true', help='skip the second timed figure on the native fp32 MFMA path')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without an outer launcher: start the N ranks ourselves (one process per GPU) BEFORE anything in this
+        # process touches the GPU -- the child is torch.distributed.run, this process only relays its output and exit code
+        sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('ECHR_BENCH_BACKEND', 'nccl')            # 'gloo': rehearsal of the N-rank path on a 1-GPU box
+    if os.environ.get('ECHR_BENCH_ONE_GPU') == '1':                   # rehearsal: every rank on cuda:0 (needs the gloo backend)
+        assert backend == 'gloo', 'ECHR_BENCH_ONE_GPU=1 needs ECHR_BENCH_BACKEND=gloo (RCCL wants one device per rank)'
+        local_rank = 0
     if world > 1 or os.environ.get('ECHR_FORCE_DIST') == '1':       # ECHR_FORCE_DIST: exercise the RCCL path with one rank
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    if os.environ.get('ECHR_BENCH_DRYRUN') == '1':
+        # launcher check without a GPU (tests/test_parallel_gloo.py): rendezvous, one MAX all-reduce like the timing reduction, one JSON line
+        assert backend == 'gloo' and world == args.gpus
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({'dryrun': True, 'n_gpus': world, 'max_rank_plus_1': float(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus %d`, which launches the ranks itself, or under '
+                 'torch.distributed.run --nproc-per-node %d)' % (args.gpus, world, args.gpus, args.gpus))
+    if world > 1:
+        # several ranks may share CUs with collective kernels (and, in the one-GPU rehearsal, with each other): the persistent recurrences
+        # are launched cooperatively, so a grid only starts once all of its workgroups can be resident
+        from echr_amd import _lib
+        _lib.load().echr_config_set(b'persist_coop', int(os.environ.get('ECHR_PERSIST_COOP', '1')))
+        if os.environ.get('ECHR_BENCH_ONE_GPU') == '1' and os.environ.get('ECHR_BENCH_PERSIST', '0') == '0':
+            # rehearsal with every rank on ONE device: two 256-workgroup persistent grids must not share it -> launch-per-phase recurrences
+            _lib.load().echr_config_set(b'persist', 0)
+            _lib.load().echr_config_set(b'persist_bwd', 0)
     dt, loss, roof, native = gpu_leg(args, rank, world, local_rank)
     if rank == 0:
         value = args.steps * S_STEPS * world / dt

@@ -78,6 +78,7 @@ class SampleArgs(C.Structure):
 SYMBOLS = [
     ('echr_version', i32, []),
     ('echr_last_error', C.c_char_p, []),
+    ('echr_check_async', i32, []),
     ('echr_gemm_f32', i32, [C.POINTER(GemmDesc), C.c_void_p]),
     ('echr_event_pool_gather_fwd', i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_event_pool_gather_bwd', i32, [c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),

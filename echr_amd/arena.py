@@ -30,6 +30,7 @@ class ParamArena(object):
         self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
         self.index = {}
         self._zeroed = []
+        self.deferred_clamp = None           # clip value of a clip_gradient call that was left to the fused step kernel (optim.ClampAdam)
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 v = self.flat_p[o:o + p.numel()].view(p.shape)
@@ -69,6 +70,15 @@ class ParamArena(object):
     def params_in_arena(self):
         base = self.flat_p.data_ptr()
         return all(p.data.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
+
+    def flush_deferred_clamp(self):
+        """Apply a clamp that `clip_gradient` deferred to the optimiser kernel: called when another backward is about to accumulate into
+        the running gradient (the reference clamps after EVERY backward, train.py:313-317)."""
+        clip, self.deferred_clamp = self.deferred_clamp, None
+        if clip is not None and self.grads_in_arena():
+            from . import functional as EF
+            self.zero_unused_grads(keep=True)
+            EF.clamp_(self.flat_g, clip)
 
     def note_zeroed(self, lo, hi):
         """A backward Function zero-filled flat_g[lo:hi] this step (GradSink.take)."""

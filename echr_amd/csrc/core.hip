@@ -35,7 +35,8 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 Config& config() {
     static Config c = {env_int("ECHR_GEMM_BF16X3", 1), env_int("ECHR_OVERLAP", 0), env_int("ECHR_ATT_SLOTS", 2), env_int("ECHR_CHAINS2", 0),
                        env_int("ECHR_GEMM_H2", 1), env_int("ECHR_PERSIST", 1), env_int("ECHR_PERSIST_STAMPS", 0),
-                       getenv("ECHR_GEMM_TILE") ? (int)getenv("ECHR_GEMM_TILE")[0] : 0, env_int("ECHR_GEMM_SPLIT", 0), env_int("ECHR_PERSIST_BWD", 1), env_int("ECHR_PERSIST_SPLIT", 1), env_int("ECHR_PERSIST_H2", 1), env_int("ECHR_PERSIST_MERGE", 1), env_int("ECHR_PERSIST_KGROUPS", 1), env_int("ECHR_TSRM_FORK", 1)};
+                       getenv("ECHR_GEMM_TILE") ? (int)getenv("ECHR_GEMM_TILE")[0] : 0, env_int("ECHR_GEMM_SPLIT", 0), env_int("ECHR_PERSIST_BWD", 1), env_int("ECHR_PERSIST_SPLIT", 1), env_int("ECHR_PERSIST_H2", 1), env_int("ECHR_PERSIST_MERGE", 1), env_int("ECHR_PERSIST_KGROUPS", 1), env_int("ECHR_TSRM_FORK", 1),
+                       env_int("ECHR_PERSIST_COOP", 0), 0, env_int("ECHR_PERSIST_SPIN_LIMIT", 0)};
     return c;
 }
 
@@ -560,7 +561,11 @@ __device__ __forceinline__ float clamp_keep_nan(float g, float clip) { return (g
 // ---- fused clamp + Adam (misc/utils.py:107-111 + torch.optim.Adam) ------------------------------------
 __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
-                                                         float omb1, float b2, float omb2, float eps, float clip) {
+                                                         float omb1, float b2, float omb2, float eps, float clip,
+                                                         const unsigned* __restrict__ abort_word) {
+    // a persistent recurrence launch of this iteration gave up (hand-off timeout): its gradients are garbage, so the update is skipped;
+    // the host reports -ETIME at its next library call (persist_check_async)
+    if (abort_word && *abort_word) return;
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -593,7 +598,8 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
     }
 }
 
-__global__ void clamp_kernel(float* g, long n, float clip) {
+__global__ void clamp_kernel(float* g, long n, float clip, const unsigned* __restrict__ abort_word) {
+    if (abort_word && *abort_word) return;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = clamp_keep_nan(g[i], clip);
 }
@@ -714,7 +720,7 @@ extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int
     const long n4 = n >> 2;
     int grid = (int)min(max((n4 + 255) / 256, 1L), 4096L);
     hipLaunchKernelGGL(clamp_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, (float)(lr / bc1),
-                       (float)(1.0 / sqrt(bc2)), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, clip);
+                       (float)(1.0 / sqrt(bc2)), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, clip, persist_abort_word());
     return check_launch("clamp_adam");
 }
 
@@ -722,7 +728,7 @@ extern "C" int echr_clamp(float* g, int64_t n, float clip, void* stream) {
     ECHR_REQUIRE(g && n > 0, "clamp: bad arguments");
     if (int rc = join_tail((hipStream_t)stream)) return rc;
     int grid = (int)min(((long)n + 255) / 256, 4096L);
-    hipLaunchKernelGGL(clamp_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, (long)n, clip);
+    hipLaunchKernelGGL(clamp_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, (long)n, clip, persist_abort_word());
     return check_launch("clamp");
 }
 
@@ -762,6 +768,8 @@ extern "C" int echr_prof_event_overhead(double* ms, int64_t* n) {
     return 0;
 }
 
+extern "C" int echr_check_async(void) { return persist_check_async(); }
+
 extern "C" int echr_persist_read_stamps(uint64_t* dst, int32_t max_entries) {
     return persist_read_stamps(reinterpret_cast<unsigned long long*>(dst), max_entries);
 }
@@ -781,6 +789,9 @@ extern "C" int echr_config_set(const char* key, int32_t value) {
     else if (!strcmp(key, "persist_merge")) c.persist_merge = value;
     else if (!strcmp(key, "persist_kgroups")) c.persist_kgroups = value;
     else if (!strcmp(key, "tsrm_fork")) c.tsrm_fork = value;
+    else if (!strcmp(key, "persist_coop")) c.persist_coop = value;
+    else if (!strcmp(key, "persist_inject_timeout")) c.persist_inject_timeout = value;
+    else if (!strcmp(key, "persist_spin_limit")) c.persist_spin_limit = value;
     else if (!strcmp(key, "gemm_tile")) c.gemm_tile = value;          // tuning only: ASCII code of the tile selector ('1','6','a','b','c','s'), 0 = heuristics
     else if (!strcmp(key, "gemm_split")) c.gemm_split = value;        // tuning only: forced k-slice count of auto-split products, 0 = heuristics
     else if (!strcmp(key, "att_slots")) { ECHR_REQUIRE(value == 2 || value == 4 || value == 8, "config_set: att_slots must be 2, 4 or 8"); c.att_slots = value; }

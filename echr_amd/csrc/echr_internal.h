@@ -17,7 +17,7 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; int persist_coop; int persist_inject_timeout; int persist_spin_limit; };
 Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);
@@ -37,6 +37,9 @@ long persist_bwd_ws_floats(int S);
 bool persist_bwd_eligible(const echr_dec_args* a);
 int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
 int persist_check_async();
+// device word that is non-zero from the moment a persistent launch aborts until the host has reported it (persist_check_async):
+// kernels that would apply results (clamp_adam, clamp) skip their update while it is set; nullptr when the state is unavailable
+const unsigned* persist_abort_word();
 // the library's helper stream outside a backward pass (the one the asynchronous decoder-backward tail uses): `aux_fork` makes it continue
 // after everything queued on `from` and returns it, `aux_join` makes `to` wait for what was queued on it since
 hipStream_t aux_fork(hipStream_t from);          // nullptr when unavailable

@@ -79,6 +79,7 @@ struct PersistK {
     float *XH1, *XH0, *XH2, *XQ, *XC, *XS, *WU;
     unsigned long long* GRAN;
     u32* cnt; u32* abort_word; u32* host_flag;
+    u32 spin_limit, inject;          // bound of every hand-off spin; diagnostic: the wait whose code equals `inject` never completes (0 = none)
     unsigned long long* stamps;      // diagnostic: [4 roles][S][16] s_memrealtime stamps (null = off)
     DropCfg dh, dout;
 };
@@ -150,10 +151,10 @@ __device__ __forceinline__ bool wait_total(const PK& P, u32* line, u32 target, i
             u32 v = lane < SHARDS ? __hip_atomic_load(line + lane * SHSTRIDE, __ATOMIC_RELAXED, ECHR_AGENT) : 0u;
             v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
             v = __shfl(v, 0);
-            if (v >= target) { ok = true; break; }
+            if (v >= target && code != P.inject) { ok = true; break; }
             if ((++spins & 31) == 0) {
                 if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, ECHR_AGENT)) break;
-                if (spins > SPIN_LIMIT) {
+                if (spins > P.spin_limit) {
                     if (lane == 0) {
                         __hip_atomic_store(P.abort_word, code, __ATOMIC_RELAXED, ECHR_AGENT);
                         __hip_atomic_store(P.host_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -506,7 +507,16 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
                             unsigned long long x = lane < 3 ? __hip_atomic_load(gr + lane, __ATOMIC_RELAXED, ECHR_AGENT) : ((unsigned long long)(t + 1) << 32) | 0xff800000u;
                             const bool ok = (u32)(x >> 32) == (u32)(t + 1);
                             if (__all(ok)) { mm = __uint_as_float((u32)x); break; }
-                            if ((++spins & 31) == 0 && (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, ECHR_AGENT) || spins > SPIN_LIMIT)) break;
+                            if ((++spins & 31) == 0) {
+                                if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, ECHR_AGENT)) break;
+                                if (spins > P.spin_limit) {      // timed out: abort the launch like every other bounded spin (shift = 0 below is never consumed)
+                                    if (lane == 0) {
+                                        __hip_atomic_store(P.abort_word, 9000u + (u32)t, __ATOMIC_RELAXED, ECHR_AGENT);
+                                        __hip_atomic_store(P.host_flag, 9000u + (u32)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    }
+                                    break;
+                                }
+                            }
                             __builtin_amdgcn_s_sleep(1);
                         }
                         mm = wave_max(mm);
@@ -797,6 +807,7 @@ struct PersistK2 {
     float *XH1, *XQ, *XC, *XS, *WU, *XCMAX;
     unsigned long long* GRAN;
     u32* cnt; u32* abort_word; u32* host_flag;
+    u32 spin_limit, inject;          // bound of every hand-off spin; diagnostic: the wait whose code equals `inject` never completes (0 = none)
     unsigned long long* stamps;
     DropCfg dh, dout;
 };
@@ -1030,7 +1041,16 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                             unsigned long long x = lane < 3 ? __hip_atomic_load(gr_ + lane, __ATOMIC_RELAXED, ECHR_AGENT) : ((unsigned long long)(t + 1) << 32) | 0xff800000u;
                             const bool ok = (u32)(x >> 32) == (u32)(t + 1);
                             if (__all(ok)) { mm = __uint_as_float((u32)x); break; }
-                            if ((++spins & 31) == 0 && (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, ECHR_AGENT) || spins > SPIN_LIMIT)) break;
+                            if ((++spins & 31) == 0) {
+                                if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, ECHR_AGENT)) break;
+                                if (spins > P.spin_limit) {      // timed out: abort the launch like every other bounded spin (shift = 0 below is never consumed)
+                                    if (lane == 0) {
+                                        __hip_atomic_store(P.abort_word, 9000u + (u32)t, __ATOMIC_RELAXED, ECHR_AGENT);
+                                        __hip_atomic_store(P.host_flag, 9000u + (u32)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    }
+                                    break;
+                                }
+                            }
                             __builtin_amdgcn_s_sleep(1);
                         }
                         mm = wave_max(mm);
@@ -1428,6 +1448,7 @@ struct PersistB {
     float *XDG, *XDA, *XDH, *XDQ, *XG0, *XG2, *XP0, *XP2;
     int lstm_kgroups;
     u32* cnt; u32* abort_word; u32* host_flag;
+    u32 spin_limit, inject;          // bound of every hand-off spin; diagnostic: the wait whose code equals `inject` never completes (0 = none)
     unsigned long long* stamps;
     DropCfg dh, dout;
 };
@@ -2237,13 +2258,32 @@ static bool side_stream(PersistHost& h) {
 }
 
 // sticky asynchronous error of an earlier persistent launch (a bounded spin timed out): reported once, at the next library call
+const unsigned* persist_abort_word() {
+    PersistHost& h = phost();
+    return h.ok ? h.abort_dev : nullptr;
+}
+
 int persist_check_async() {
+    // The library's helper streams, events and the abort word (phost / tail / prep / side) are process-wide and live on the device that was
+    // current at the first call: a call from another device would mix foreign-device streams and memory, so it is refused.
+    static int first_dev = -1;
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        if (first_dev < 0) first_dev = dev;
+        else if (dev != first_dev) {
+            set_error("libechr_hip.so keeps per-process helper state on device %d (one process per GPU); the current device is %d", first_dev, dev);
+            return -18;   // -EXDEV
+        }
+    }
     PersistHost& h = phost();
     if (h.ok && h.flag_host[0]) {
         const u32 code = h.flag_host[0];
         h.flag_host[0] = 0;
         (void)hipMemset(h.abort_dev, 0, 256);
-        set_error("persistent decoder kernel aborted: a hand-off wait timed out (code %u); its outputs are invalid", code);
+        // codes: attention chain 100000 * edge + timestep (edge 1 h1, 2 q, 3 context; reverse: 4 d q, 5 d h, 6 d G, 7 d ATT); plain LSTM streams
+        // 1000 / 5000 / 7000 * (counter kind + 1) + timestep; 9000 + timestep: the softmax max exchange
+        set_error("persistent decoder kernel aborted: a hand-off wait timed out (code %u, timestep %u); the outputs of that call and of every library "
+                  "call enqueued since are invalid, and the optimiser kernels enqueued since were skipped (parameters unchanged)", code, code % 1000);
         return -62;   // -ETIME
     }
     return 0;
@@ -2283,6 +2323,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     K.cnt = reinterpret_cast<u32*>(x + L.cnt); K.XC = x + L.xc; K.XS = x + L.xs; K.GRAN = reinterpret_cast<unsigned long long*>(x + L.gran);
     K.XH1 = x + L.xh1; K.XH0 = x + L.xh0; K.XH2 = x + L.xh2; K.XQ = x + L.xq; K.WU = x + L.wu;
     K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
+    K.spin_limit = config().persist_spin_limit > 0 ? (u32)config().persist_spin_limit : SPIN_LIMIT; K.inject = (u32)config().persist_inject_timeout;
     K.dh = dh; K.dout = dout;
     K.stamps = nullptr;
     if (config().persist_stamps == 1) {
@@ -2298,6 +2339,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
         K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XC = x2 + L2.xc; K2.XS = x2 + L2.xs; K2.GRAN = reinterpret_cast<unsigned long long*>(x2 + L2.gran);
         K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
         K2.abort_word = h.abort_dev; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = dh; K2.dout = dout;
+        K2.spin_limit = K.spin_limit; K2.inject = K.inject;
         // one memset: version 2's zeroed region and, right behind it, version 1's counters (all the LSTM kernel needs of that layout)
         if (hipMemsetAsync(x2 + L2.zero_begin, 0, (size_t)(L2.total - L2.zero_begin + L.xc) * sizeof(float), st) != hipSuccess) {
             set_error("persist_fwd: memset failed");
@@ -2312,6 +2354,17 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), wbytes + obytes + sbytes, st);
     if (split && config().persist_merge) {
         // one launch of 192 + 64 workgroups (no dependence on two hardware queues being free)
+        if (config().persist_coop) {
+            // cooperative launch: the dispatch starts only when all 256 workgroups can be resident together, whatever else holds CUs
+            // (collective kernels, another process' grid) -- the hand-off spins then never wait for a workgroup that has no CU
+            void* kargs[2] = {&K2, &K};
+            const void* fn = config().persist_h2 ? reinterpret_cast<const void*>(dec_persist_fwd_kernel<true>) : reinterpret_cast<const void*>(dec_persist_fwd_kernel<false>);
+            if (hipLaunchCooperativeKernel(fn, dim3(2 * HWG + 2 * NS), dim3(256), kargs, LDS_BYTES_FWD, st) != hipSuccess) {
+                set_error("persist_fwd: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
+                return -5;
+            }
+            return 0;
+        }
         if (config().persist_h2) hipLaunchKernelGGL(dec_persist_fwd_kernel<true>, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
         else hipLaunchKernelGGL(dec_persist_fwd_kernel<false>, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
         return check_launch("dec_persist_fwd");
@@ -2352,6 +2405,7 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
     K.XG0 = x + L.xg0; K.XG2 = x + L.xg2; K.XP0 = x + L.xp0; K.XP2 = x + L.xp2;
     K.lstm_kgroups = config().persist_kgroups;
     K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
+    K.spin_limit = config().persist_spin_limit > 0 ? (u32)config().persist_spin_limit : SPIN_LIMIT; K.inject = (u32)config().persist_inject_timeout;
     K.dh = dh; K.dout = dout;
     K.stamps = nullptr;
     if (config().persist_stamps == 2) {
@@ -2374,6 +2428,14 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
     const double sbytes = 4.0 * (double)a->S * a->N * (3.0 * 4 * PH + 3.0 * 2 * PH + PH + a->A + a->D + PH + 3.0 * 4 * PH + PH + a->A);
     ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), wbytes + obytes + sbytes, st);
     if (split && config().persist_merge) {
+        if (config().persist_coop) {
+            void* kargs[2] = {&K2, &K};
+            if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(dec_persist_bwd_kernel), dim3(2 * HWG + 2 * NS), dim3(256), kargs, LDS_BYTES_BWD, st) != hipSuccess) {
+                set_error("persist_bwd: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
+                return -5;
+            }
+            return 0;
+        }
         hipLaunchKernelGGL(dec_persist_bwd_kernel, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_BWD, st, K2, K);
         return check_launch("dec_persist_bwd");
     }

@@ -83,13 +83,24 @@ class GradSink(object):
         self.slots = [arena.slot(p) for p in self.params]
 
     def usable(self):
-        return all(s is not None for s in self.slots) and all(p.grad is None for p in self.params)
+        ok = all(s is not None for s in self.slots) and all(p.grad is None for p in self.params)
+        if not ok:
+            # gradient accumulation (a second backward before the optimiser step): a clamp that clip_gradient left to the fused step
+            # kernel has to be applied to the running gradient NOW, before autograd adds this backward's gradients to it -- the
+            # reference computes clamp(clamp(g1) + g2), not clamp(g1 + g2) (train.py:313-317)
+            self.arena.flush_deferred_clamp()
+        return ok
 
     def take(self):
         lo, hi = self.arena.span(self.slots)
         self.arena.flat_g[lo:hi].zero_()
         self.arena.note_zeroed(lo, hi)
         return [self.arena.grad_view(s) for s in self.slots]
+
+    def has_hooks(self):
+        """True when a parameter of the group carries tensor hooks (DDP / FSDP style post-accumulate hooks, register_hook): they read the
+        gradient inside the backward pass, so it must be final when the Function returns (no asynchronous tail)."""
+        return any(getattr(p, '_backward_hooks', None) or getattr(p, '_post_accumulate_grad_hooks', None) for p in self.params)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -253,13 +264,14 @@ class DecoderFunction(torch.autograd.Function):
         video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps = ctx.saved_tensors
         A, S, drop, disjoint = ctx.meta
         # criterion gradient left here in sparse form by MaskedNLL.backward (LanguageModelCriterion on this node's output)
-        pend = ctx.__dict__.pop('_echr_pending_nll', None)
+        pend = ctx.__dict__.pop('_echr_pending_nll', None)     # one entry per LanguageModelCriterion applied to this node's output
         fused = None
-        if pend is not None:
-            if getattr(g_logp, '_echr_nll_placeholder', False) and g_logp.stride() == (0, 0, 0):
-                fused, g_logp = pend, None
-            else:          # the log-probs had other consumers: their (accumulated) gradient plus the criterion's dense one
-                g_logp = g_logp + MaskedNLL.dense_grad(pend[0], pend[1], pend[2], pend[3], *logp.shape)
+        if pend:
+            if len(pend) == 1 and getattr(g_logp, '_echr_nll_placeholder', False) and g_logp.stride() == (0, 0, 0):
+                fused, g_logp = pend[0], None
+            else:          # other consumers of the log-probs (or several criteria): their accumulated gradient plus every criterion's dense one
+                for pe in pend:
+                    g_logp = g_logp + MaskedNLL.dense_grad(pe[0], pe[1], pe[2], pe[3], *logp.shape)
         if g_logp is not None:
             g_logp = _f32c(g_logp)
         zeroed = 1 if (ctx.sink is not None and ctx.sink.usable()) else 0
@@ -298,7 +310,9 @@ class DecoderFunction(torch.autograd.Function):
             # the backward (attention-parameter / embedding gradients) may still be running on the library's second stream while
             # autograd goes on with the event encoder's backward; an end-of-backward callback joins the streams and only then lets go
             # of the workspaces that stage reads
-            g.async_tail = 1 if (zeroed and ASYNC_TAIL[0]) else 0
+            # (not when a parameter hook would read those gradients inside the backward pass, nor under create_graph, where autograd may
+            # clone them: the gradients must then be final when this Function returns)
+            g.async_tail = 1 if (zeroed and ASYNC_TAIL[0] and not ctx.sink.has_hooks() and not torch.is_grad_enabled()) else 0
             L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
             if g.async_tail:
                 keep = [ws, wsb, logp, c3d, tokens, ev_start, ev_len, g_logp, fused]
@@ -333,6 +347,7 @@ def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, de
                       1 if multinomial else 0, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF)
     L.check(lib.echr_decoder_sample(C.byref(sa), L.stream_ptr()), 'decoder_sample')
     counts = nun.cpu().numpy()                 # the only device->host sync of the whole decode
+    L.check(lib.echr_check_async(), 'decoder_sample')
     if debug is not None:                      # tests: the raw logits [N,V1] of the last decoder step (sampler workspace: XT | LOGITS | ...)
         E, V1 = ps[0].shape[1], ps[0].shape[0]
         o = (N * E + 63) // 64 * 64
@@ -418,7 +433,7 @@ class MaskedNLL(torch.autograd.Function):
             # the log-probs came from DecoderFunction: leave the criterion's gradient with that node in its sparse form (targets, mask,
             # upstream scalar) and hand autograd a stride-0 all-zero placeholder.  DecoderFunction.backward takes the fused path when the
             # placeholder arrives untouched, and adds the dense form when other consumers of the log-probs contributed gradients too.
-            ctx.node._echr_pending_nll = (tgt, msk, out, _f32c(g).reshape(1))
+            ctx.node.__dict__.setdefault('_echr_pending_nll', []).append((tgt, msk, out, _f32c(g).reshape(1)))
             ph = torch.zeros((), device=msk.device, dtype=torch.float32).expand(N, S, V1)
             ph._echr_nll_placeholder = True
             return ph, None, None, None

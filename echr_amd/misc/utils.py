@@ -52,10 +52,11 @@ def clip_gradient(optimizer, grad_clip):
     applied inside `step()`); for any other optimiser the clamp runs as its own HIP kernel per tensor."""
     from ..optim import ClampAdam
     if isinstance(optimizer, ClampAdam):
-        # The reference clamps the RUNNING gradient after every backward (train.py:313-317), so with m_batch > 1 it computes
-        # clamp(clamp(g1) + g2).  The fused step kernel clamps once more on the fly (idempotent on an already clamped buffer), so
-        # clamping here in place keeps both the m_batch > 1 trajectory and what a caller reads from .grad identical to the reference;
-        # with the flat arena it is ONE launch over the gradient buffer.
+        # The reference clamps the RUNNING gradient after every backward (train.py:313-317): with m_batch > 1 it computes
+        # clamp(clamp(g1) + g2).  Per-tensor gradients are clamped in place here.  With the flat arena (ClampAdam.defer_clamp, default on)
+        # the clamp is left to the fused step kernel and, should another backward accumulate before the step, applied right before that
+        # accumulation -- the same trajectory for any m_batch; only `.grad` read between this call and step() shows unclamped values
+        # (set optimizer.defer_clamp = False to clamp in place here, one more 174 MB pass).
         optimizer.clamp_grads_(float(grad_clip))
         optimizer.pending_clip = float(grad_clip)
         return

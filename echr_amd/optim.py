@@ -19,9 +19,12 @@ class ClampAdam(torch.optim.Optimizer):
         self.pending_clip = None
         self.arena = arena            # echr_amd.arena.ParamArena: one launch over the whole model when gradients live there
         self._flat = None
-        # True: `clip_gradient` only records the clip and the fused step kernel applies it (exact when every optimiser step follows
-        # ONE backward, i.e. the reference's m_batch = 1: clamp(g) either way; saves a 174 MB pass).  Set False for gradient
-        # accumulation (m_batch > 1), where the reference clamps the running sum after every backward.
+        # True (default): with the flat arena `clip_gradient` does not run a clamp pass of its own -- the fused step kernel clamps on the
+        # fly (one 174 MB pass less per step).  The reference clamps the RUNNING gradient after every backward (train.py:313-317), which
+        # only differs from a single clamp when ANOTHER backward follows (m_batch > 1): the arena remembers the deferred clip value and
+        # the next backward that accumulates applies it first (GradSink.usable -> arena.flush_deferred_clamp), so the trajectory is the
+        # reference's clamp(clamp(g1) + g2) for any m_batch.  What deferral does change: `.grad` read between clip_gradient and step()
+        # holds the unclamped values.  False: clip_gradient clamps in place right away (reference-visible .grad, one more pass).
         self.defer_clamp = True
 
     def _flat_step(self, clip):
@@ -49,7 +52,8 @@ class ClampAdam(torch.optim.Optimizer):
         ar = self.arena
         if ar is not None and ar.grads_in_arena():
             if self.defer_clamp:
-                return                      # single-backward steps: the fused step kernel clamps (same values, one pass less)
+                ar.deferred_clamp = float(clip)     # the fused step kernel clamps; a further backward before it applies the clamp first
+                return
             ar.zero_unused_grads(keep=True)
             EF.clamp_(ar.flat_g, clip)
             return
@@ -104,8 +108,16 @@ class ClampAdam(torch.optim.Optimizer):
         self.state.clear()
         self._flat = flat
 
+    def zero_grad(self, set_to_none=True):
+        if self.arena is not None:
+            self.arena.deferred_clamp = None
+        return super(ClampAdam, self).zero_grad(set_to_none)
+
     @torch.no_grad()
     def step(self, closure=None):
+        EF.L.check(EF.L.load().echr_check_async(), 'ClampAdam.step')      # an aborted persistent launch of this iteration surfaces here at the latest
+        if self.arena is not None:
+            self.arena.deferred_clamp = None
         clip = self.pending_clip if self.pending_clip is not None else self.grad_clip
         self.pending_clip = None
         clip = float('inf') if clip is None else float(clip)

@@ -75,9 +75,8 @@ def main(argv=None):
     tap_opt = ClampAdam(tap_model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon)
     cg_opt = ClampAdam(cg_model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon,
                        arena=cg_model.build_arena())
-    # the reference clamps the running gradient after EVERY backward (train.py:315-317); with m_batch = 1 that equals the clamp fused
-    # into the step kernel, with accumulation it does not
-    cg_opt.defer_clamp = tap_opt.defer_clamp = a.m_batch == 1
+    # the reference clamps the running gradient after EVERY backward (train.py:315-317); ClampAdam keeps that trajectory for any m_batch
+    # (the clamp deferred to the fused step kernel is applied first whenever another backward accumulates)
     start = 0
     if a.resume:
         ck = torch.load(a.resume, map_location=dev)

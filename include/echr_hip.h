@@ -29,6 +29,11 @@ extern "C" {
 
 int echr_version(void);
 const char* echr_last_error(void);
+/* Asynchronous failures.  The persistent recurrence kernels (csrc/persist.hip) bound every inter-workgroup wait; when one gives up the
+ * launch drains, a device word stays set (echr_clamp_adam / echr_clamp then skip their update, so no parameter is touched by the
+ * invalid gradients) and the NEXT library call that takes a stream returns -ETIME (-62) once, naming the edge and timestep.
+ * echr_check_async() is that check on its own, for callers that want it right after a synchronisation point: 0 or -62. */
+int echr_check_async(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense fp32 projection on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
@@ -361,6 +366,12 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *                      ingest per workgroup and step plus a small partial-tile exchange) instead of 512 KB per workgroup
  *   "tsrm_fork"   0/1  (default 1, ECHR_TSRM_FORK) echr_tsrm_fwd runs its position branch (pair embedding -> fc1 -> fc2 gates) on the
  *                      library's helper stream beside the event-embedding / query / key products
+ *   "persist_coop" 0/1  (default 0, ECHR_PERSIST_COOP) launch the persistent pairs with hipLaunchCooperativeKernel: the dispatch starts only
+ *                      when all 256 workgroups can be co-resident, whatever else holds CUs (RCCL kernels of a data-parallel run, another
+ *                      process on the device).  echr_amd.parallel / bench.py switch it on when the world size is > 1
+ *   "persist_spin_limit" n  bound of every hand-off spin in polls (0 = default, about seconds; ECHR_PERSIST_SPIN_LIMIT)
+ *   "persist_inject_timeout" code  diagnostic: the hand-off wait with this code (attention chain: 100000 * edge + timestep, edge 1 h1 / 2 q / 3 context / 4 d q / 5 d h / 6 d G / 7 d ATT) never completes, so the
+ *                      launch aborts through its time-out path (tests/test_gpu_parity.py::test_persistent_abort_path); 0 = off
  *   "persist_stamps" 0/1/2 diagnostic phase stamps of the forward (1) / reverse (2) pair, see echr_persist_read_stamps
  *   "gemm_tile", "gemm_split"  tuning overrides of the GEMM tile / split-K heuristics (0 = heuristics; tools/gemm_bench.py only) */
 int echr_config_set(const char* key, int32_t value);

@@ -19,6 +19,16 @@ def main():
     from echr_amd.optim import ClampAdam
     from tests import util as U
     dev = torch.device('cuda', 0)
+    # both ranks share cuda:0 here: two 256-workgroup persistent grids must never be half-resident beside each other, so this rehearsal
+    # runs the launch-per-phase recurrences -- or, with ECHR_DP_WORKER_COOP=1, persistent grids launched cooperatively (a grid starts only
+    # when all of its workgroups can be resident)
+    from echr_amd import _lib
+    lib = _lib.load()
+    if os.environ.get('ECHR_DP_WORKER_COOP') == '1':
+        lib.echr_config_set(b'persist_coop', 1)
+    else:
+        lib.echr_config_set(b'persist', 0)
+        lib.echr_config_set(b'persist_bwd', 0)
     opt, params, _ = synth.make_case('c1')
     model = U.build_gpu_model(opt, params, True)
     arena = model.build_arena()

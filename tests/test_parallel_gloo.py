@@ -193,3 +193,26 @@ def test_rs_ag_and_accumulation_with_early_reducer():
 def test_shard_videos_partition():
     got = sorted(sum((parallel.shard_videos(11, r, 4) for r in range(4)), []))
     assert got == list(range(11))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without an outer torchrun must start the two ranks itself (before any GPU call), rank 0 prints ONE JSON
+    line, the exit code is the ranks'.  ECHR_BENCH_DRYRUN stops each rank after rendezvous + one MAX all-reduce (no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ECHR_BENCH_BACKEND='gloo', ECHR_BENCH_DRYRUN='1')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {'dryrun': True, 'n_gpus': 2, 'max_rank_plus_1': 2.0}
+    # a world size that does not match --gpus is refused with a message, not an assertion
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    env2.pop('ECHR_BENCH_DRYRUN')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env2, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'launches the ranks itself' in r.stderr
