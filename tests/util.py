@@ -87,4 +87,6 @@ def grad_close(name, a, b, tol):
     if name in NOISE_ONLY or float(np.abs(np.asarray(b)).max()) == 0.0:
         # exact zeros in the reference (e.g. single-slot events: attention weights are identically 1) vs rounding noise here
         return float(np.abs(np.asarray(a)).max()) < 1e-6 and float(np.abs(np.asarray(b)).max()) < 1e-6
-    return relerr(a, b, GRAD_FLOOR) < tol
+    # 1e-9 absolute: tensors whose true gradient vanishes (e.g. pair_pos_fc2.bias with a single event: ~1e-11 on both sides) are rounding noise
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max()) <= tol * max(float(np.abs(b).max()), GRAD_FLOOR) + 1e-9
