@@ -7,7 +7,7 @@ namespace echr {
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 // Disabled by default: ProfScope is then a no-op.  Events are resolved in echr_prof_read after a stream sync.
-enum ProfKind { PROF_GEMM = 0, PROF_ATT_FWD = 1, PROF_ATT_BWD = 2, PROF_ATT_POST = 3, PROF_LSTM = 4, PROF_OTHER = 5, PROF_GEMM_SPLIT = 6, PROF_GEMM_H2 = 7, PROF_PACK = 8, PROF_PERSIST = 9, PROF_KINDS = 10 };
+enum ProfKind { PROF_GEMM = 0, PROF_ATT_FWD = 1, PROF_ATT_BWD = 2, PROF_ATT_POST = 3, PROF_LSTM = 4, PROF_OTHER = 5, PROF_GEMM_SPLIT = 6, PROF_GEMM_H2 = 7, PROF_PACK = 8, PROF_PERSIST = 9, PROF_SST = 10, PROF_KINDS = 11 };
 struct ProfScope {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t st;
@@ -17,7 +17,7 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; int persist_coop; int persist_inject_timeout; int persist_spin_limit; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; int persist_coop; int persist_inject_timeout; int persist_spin_limit; int sst_persist; };
 Config& config();
 
 int gemm(const echr_gemm_desc& d, hipStream_t st);
@@ -40,12 +40,14 @@ int persist_check_async();
 // device word that is non-zero from the moment a persistent launch aborts until the host has reported it (persist_check_async):
 // kernels that would apply results (clamp_adam, clamp) skip their update while it is set; nullptr when the state is unavailable
 const unsigned* persist_abort_word();
+unsigned* persist_host_flag();          // device view of the host-mapped flag persist_check_async reads (nullptr when unavailable)
 // the library's helper stream outside a backward pass (the one the asynchronous decoder-backward tail uses): `aux_fork` makes it continue
 // after everything queued on `from` and returns it, `aux_join` makes `to` wait for what was queued on it since
 hipStream_t aux_fork(hipStream_t from);          // nullptr when unavailable
 int aux_join(hipStream_t to);
 int join_tail(hipStream_t st);          // make st wait for an asynchronous decoder-backward tail (decoder.hip); no-op when none is pending
 int persist_read_stamps(unsigned long long* dst, int max_entries);
+unsigned long long* persist_stamp_buffer(int S, hipStream_t st);      // diagnostic: [4][S <= 256][16] stamps, zeroed on st (nullptr: unavailable)
 int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st);
 // h2-packed operands (csrc/gemm.hip: two block-scaled fp16 planes): bytes of the packed image of a [rows x cols] operand (cols =
 // contraction axis), the packing pass, and a multi-operand packing launch

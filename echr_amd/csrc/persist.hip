@@ -2263,6 +2263,11 @@ const unsigned* persist_abort_word() {
     return h.ok ? h.abort_dev : nullptr;
 }
 
+unsigned* persist_host_flag() {
+    PersistHost& h = phost();
+    return h.ok ? h.flag_dev : nullptr;
+}
+
 int persist_check_async() {
     // The library's helper streams, events and the abort word (phost / tail / prep / side) are process-wide and live on the device that was
     // current at the first call: a call from another device would mix foreign-device streams and memory, so it is refused.
@@ -2296,6 +2301,16 @@ int persist_read_stamps(unsigned long long* dst, int max_entries) {
     if (hipDeviceSynchronize() != hipSuccess) return 0;
     if (hipMemcpy(dst, h.stamps, (size_t)4 * h.stamps_S * 16 * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return h.stamps_S;
+}
+
+// diagnostic stamp buffer for other persistent kernels (csrc/sst.hip): zeroed on `st`, read back with persist_read_stamps
+unsigned long long* persist_stamp_buffer(int S, hipStream_t st) {
+    PersistHost& h = phost();
+    if (!h.ok) return nullptr;
+    if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) { h.stamps = nullptr; return nullptr; }
+    h.stamps_S = S < 256 ? S : 256;
+    (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st);
+    return h.stamps;
 }
 
 static bool persist_shape_ok(const echr_dec_args* a) {

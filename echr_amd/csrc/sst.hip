@@ -223,6 +223,360 @@ __global__ void tap_bce_bwd_kernel(const float* __restrict__ scores, const float
     g_scores[i] = g_loss[0] * w * d * m / (float)T;       // K / (T*K)
 }
 
+// =====================================================================================================================
+// PERSISTENT form of the two wavefronts (H = 512): ONE launch per direction instead of T + 1 dependent launches.
+//   * 64 workgroups x 256 threads, a workgroup owns 8 hidden units of BOTH layers; its slices of W_hh0, W_ih1 and W_hh1
+//     (3 x 32 rows x 512: 192 KB) live in REGISTERS for all T steps (192 VGPRs per thread, one wave per SIMD);
+//   * the exchanged vectors ARE the saved activations: h0 / dropped h0 / h1 rows (forward) and the gate-gradient rows dG0 / dG1
+//     (reverse) are pre-filled with a sentinel bit pattern (0xFFFFFFFF, a NaN no fp32 operation produces), producers overwrite their
+//     elements with write-through stores, consumers POLL the rows they need until no sentinel word is left -- one memory round trip
+//     per step (no counters, no second "payload" fetch), each word validated on its own, so a torn read can only look "not ready";
+//   * every spin is bounded like the decoder's persistent kernels (abort word + host flag, csrc/persist.hip).
+// A step is: poll (h0(k-1), h0d(k-1), h1(k-2): 6 KB / dG1, dG0: 16 KB) -> LDS -> register GEMV slices + DPP reductions -> cell math -> publish.
+// =====================================================================================================================
+namespace {
+
+typedef unsigned u32s;
+typedef u32s u32x4s __attribute__((ext_vector_type(4)));
+constexpr int SP_WG = 64, SP_U = 8, SP_H = 512;
+constexpr u32s SP_SENT = 0xFFFFFFFFu;
+constexpr u32s SP_SPIN_DEFAULT = 4000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sp_rsrc(const void* p, u32s bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4s sp_ld16(__amdgpu_buffer_rsrc_t r, u32s off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); }   // sc1
+__device__ __forceinline__ void sp_store(float* p, float v) {
+    if (__float_as_uint(v) == SP_SENT) v = __uint_as_float(0x7FC00000u);          // never publish the sentinel pattern itself
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int CTRL> __device__ __forceinline__ float sp_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sp_sum16(float v) {       // 16-lane DPP row: quad xor 1, quad xor 2, row_half_mirror, row_mirror
+    v += sp_dpp<0xB1>(v); v += sp_dpp<0x4E>(v); v += sp_dpp<0x141>(v); v += sp_dpp<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float sp_sum32(float v) {       // + the neighbouring row (lane ^ 16): v_permlane16_swap of a register with itself
+    v = sp_sum16(v);
+    const u32s u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float sp_sum64(float v) {
+    v = sp_sum32(v);
+    const u32s u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+
+struct SpSync { u32s* abort_word; u32s* host_flag; u32s spin_limit; };
+
+// every thread: wait until each of its (needed) 16-byte pieces holds no sentinel word.  The loads of one sweep are issued together, so a
+// sweep costs ONE memory round trip however many pieces the thread owns (two sweeps in flight were measured: slower -- the straggling loads
+// of the second sweep delay the consumer).  false = give up (abort raised here or elsewhere)
+// `between` runs once, after the first sweep's loads have been issued and before they are waited for (index-only work and prefetches
+// of the step overlap the round trip).
+template <int NP, typename F>
+__device__ __forceinline__ bool sp_poll(const __amdgpu_buffer_rsrc_t (&r)[NP], const u32s (&off)[NP], const bool (&need)[NP], float4 (&out)[NP],
+                                        const SpSync& y, u32s code, F&& between) {
+    bool done[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) done[i] = !need[i];
+    u32s spins = 0;
+    bool first = true;
+    for (;;) {
+        u32x4s v[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) if (!done[i]) v[i] = sp_ld16(r[i], off[i]);
+        if (first) { between(); first = false; }
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (done[i]) continue;
+            if (v[i].x != SP_SENT && v[i].y != SP_SENT && v[i].z != SP_SENT && v[i].w != SP_SENT) {
+                out[i] = make_float4(__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z), __uint_as_float(v[i].w));
+                done[i] = true;
+            } else all = false;
+        }
+        if (all) return true;
+        if ((++spins & 31) == 0) {
+            if (__hip_atomic_load(y.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            if (spins > y.spin_limit) {
+                __hip_atomic_store(y.abort_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(y.host_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+#define SP_STAMP(i) do { if (P.stamps && blockIdx.x == 0 && tid == 0 && k < 256) P.stamps[k * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+struct SstPF {
+    int T;
+    const float *w_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1, *GIN0;
+    float *HS0, *H0D, *TAP;                  // [T,H] each: exchange rows = saved activations (sentinel-filled before the launch)
+    float *ACT0, *ACT1, *CS0, *CS1;
+    SpSync y;
+    DropCfg dc;
+    unsigned long long* stamps;      // diagnostic (null = off): [step][16] s_memrealtime stamps of workgroup 0
+};
+
+typedef float f2s __attribute__((ext_vector_type(2)));
+// acc += w . x as two packed FMAs (v_pk_fma_f32: both halves of a float4 pair per instruction)
+__device__ __forceinline__ void sp_dot4(f2s& acc, const float4& w, const float4& x) {
+    acc = __builtin_elementwise_fma(f2s{w.x, w.y}, f2s{x.x, x.y}, acc);
+    acc = __builtin_elementwise_fma(f2s{w.z, w.w}, f2s{x.z, x.w}, acc);
+}
+
+__global__ __launch_bounds__(256, 1) void sst_persist_fwd_kernel(SstPF P) {
+    __shared__ __attribute__((aligned(16))) float sv[3 * SP_H];      // h0(k-1) | h0d(k-1) | h1(k-2)
+    __shared__ int fail;
+    constexpr int H = SP_H;
+    const int tid = threadIdx.x, G = tid >> 5, kp = tid & 31;
+    const int u = blockIdx.x * SP_U + G;                              // this 32-lane group's hidden unit
+    const int T = P.T;
+    if (tid == 0) fail = 0;
+    // register-resident weight slices: gate g, k = 4 kp + 128 j (+0..3)
+    float4 W0[4][4], W1[4][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const long row = (long)(g * H + u) * H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) W0[g][j] = *reinterpret_cast<const float4*>(P.w_hh0 + row + 4 * kp + 128 * j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 4 * kp + 128 * j;
+            W1[g][j] = k < H ? *reinterpret_cast<const float4*>(P.w_ih1 + row + k) : *reinterpret_cast<const float4*>(P.w_hh1 + row + k - H);
+        }
+    }
+    // lane 0 of the group finishes layer 0's cell of the step, lane 1 layer 1's (the same instructions on different data)
+    const bool fin1 = kp == 1;
+    float bias1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias1[g] = P.b_ih1[g * H + u] + P.b_hh1[g * H + u];
+    float cst = 0.f;                                                  // lane 0: c0, lane 1: c1
+    if (tid < 128) reinterpret_cast<float4*>(sv)[256 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);       // h1(-1) = 0 (no row is polled for it)
+    __syncthreads();
+    const u32s ROWB = H * 4;
+    for (int k = 0; k <= T; ++k) {
+        const bool l0 = k < T, l1 = k >= 1;
+        float gin[4] = {0.f, 0.f, 0.f, 0.f};
+        float mk = 1.f;
+        auto prefetch = [&]() {
+            if (l0 && kp == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gin[g] = P.GIN0[(long)k * 4 * H + g * H + u];
+            }
+            if (l0) mk = drop_mult(P.dc, (unsigned)(k * H + u), 0u, SITE_SST);
+        };
+        // index-only work and prefetches FIRST: a row becomes visible ~0.3 us after its producers' stores were issued, so a sweep issued right
+        // after this workgroup's own publish would miss and cost a second round trip (measured: 0.28 + 0.56 us this way, 1.7 us the other)
+        prefetch();
+        SP_STAMP(0);
+        // ---- poll the rows published by the previous step: 384 float4 over 256 threads ----
+        if (k >= 1) {
+            // threads 0..127: h0(k-1) and, from step 2 on, h1(k-2); threads 128..255: h0d(k-1)
+            const __amdgpu_buffer_rsrc_t r[2] = {sp_rsrc((tid < 128 ? P.HS0 : P.H0D) + (long)(k - 1) * H, ROWB), sp_rsrc(P.TAP + (long)max(k - 2, 0) * H, ROWB)};
+            const u32s off[2] = {(u32s)((tid & 127) * 16), (u32s)((tid & 127) * 16)};
+            const bool need[2] = {true, k >= 2 && tid < 128};
+            float4 v[2];
+            if (sp_poll<2>(r, off, need, v, P.y, 8000u + (u32s)(k % 1000), [] {})) {
+                reinterpret_cast<float4*>(sv)[tid] = v[0];
+                if (need[1]) reinterpret_cast<float4*>(sv)[256 + tid] = v[1];
+            } else fail = 1;
+        }
+        SP_STAMP(1);
+        __syncthreads();
+        if (fail) return;
+        SP_STAMP(2);
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k >= 1) {
+            const float4* v4 = reinterpret_cast<const float4*>(sv);
+            f2s a0[4], a1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { a0[g] = f2s{0.f, 0.f}; a1[g] = f2s{0.f, 0.f}; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 x = v4[kp + 32 * j];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sp_dot4(a0[g], W0[g][j], x);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 x = v4[128 + kp + 32 * j];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sp_dot4(a1[g], W1[g][j], x);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { s0[g] = sp_sum32(a0[g].x + a0[g].y); s1[g] = sp_sum32(a1[g].x + a1[g].y); }
+        }
+        SP_STAMP(3);
+        // (no barrier here: the next step's rows are complete only after every wave of THIS workgroup has published, i.e. after its reads of sv)
+        // ---- cell math: lane 0 layer 0 at step k, lane 1 layer 1 at step k - 1 ----
+        {
+            const float pi = fin1 ? s1[0] + bias1[0] : s0[0] + gin[0], pf = fin1 ? s1[1] + bias1[1] : s0[1] + gin[1];
+            const float pg = fin1 ? s1[2] + bias1[2] : s0[2] + gin[2], po = fin1 ? s1[3] + bias1[3] : s0[3] + gin[3];
+            const float gi = fast_sigmoid(pi), gf = fast_sigmoid(pf), gg = fast_tanh(pg), go = fast_sigmoid(po);
+            const float c = gf * cst + gi * gg;
+            const float h = go * fast_tanh(c);
+            if (kp == 0 && l0) {
+                cst = c;
+                sp_store(P.HS0 + (long)k * H + u, h);
+                sp_store(P.H0D + (long)k * H + u, h * mk);
+                float* act = P.ACT0 + (long)k * 4 * H + u;
+                act[0] = gi; act[H] = gf; act[2 * H] = gg; act[3 * H] = go;
+                P.CS0[(long)k * H + u] = c;
+            } else if (fin1 && l1) {
+                const int t = k - 1;
+                cst = c;
+                sp_store(P.TAP + (long)t * H + u, h);
+                float* act = P.ACT1 + (long)t * 4 * H + u;
+                act[0] = gi; act[H] = gf; act[2 * H] = gg; act[3 * H] = go;
+                P.CS1[(long)t * H + u] = c;
+            }
+        }
+        SP_STAMP(4);
+    }
+}
+
+struct SstPB {
+    int T;
+    const float *w_hh0, *w_ih1, *w_hh1;
+    const float *ACT0, *ACT1, *CS0, *CS1, *DHO;
+    float *DG0, *DG1;                        // [T,4H] each: exchange rows = the gate gradients the weight-gradient GEMMs read afterwards
+    SpSync y;
+    DropCfg dc;
+    unsigned long long* stamps;
+};
+
+// reverse wavefront: step k = layer 1 at t = T-1-k  ||  layer 0 at t0 = T-k.  Wave w owns units 2w, 2w+1 of the workgroup's eight: the
+// columns u of W_hh1, W_ih1 and W_hh0 (2048 long each) are split over the 64 lanes, r = 4 lane + 256 j (+0..3).
+__global__ __launch_bounds__(256, 1) void sst_persist_bwd_kernel(SstPB P) {
+    extern __shared__ __attribute__((aligned(16))) float sdyn[];
+    float* sg = sdyn;                                                 // [2][4H]: dG1(T-k) | dG0(T-k+1)
+    float* sstage = sdyn + 2 * 4 * SP_H;                              // [8][4H]: set-up staging of one matrix' columns
+    __shared__ int fail;
+    constexpr int H = SP_H, H4 = 4 * SP_H;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int T = P.T;
+    if (tid == 0) fail = 0;
+    // register-resident columns, staged through LDS one matrix at a time: the workgroup's eight columns are 32 contiguous bytes of every
+    // row, so rows are read as float4 pairs (coalesced over rows would be 2 KB apart) and transposed into [unit][r] in LDS
+    float4 A1[2][8], A2[2][8], A3[2][8];
+    {
+        float* stage = sstage;                                        // [8 units][2048]
+        const float* Ws[3] = {P.w_hh1, P.w_ih1, P.w_hh0};
+#pragma unroll
+        for (int mtx = 0; mtx < 3; ++mtx) {
+            for (int idx = tid; idx < H4 * 2; idx += 256) {
+                const int row = idx >> 1, half = idx & 1;
+                const float4 v = *reinterpret_cast<const float4*>(Ws[mtx] + (long)row * H + blockIdx.x * SP_U + 4 * half);
+                stage[(4 * half + 0) * H4 + row] = v.x; stage[(4 * half + 1) * H4 + row] = v.y;
+                stage[(4 * half + 2) * H4 + row] = v.z; stage[(4 * half + 3) * H4 + row] = v.w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(stage + (2 * w + i) * H4 + 4 * lane + 256 * j);
+                    if (mtx == 0) A1[i][j] = v; else if (mtx == 1) A2[i][j] = v; else A3[i][j] = v;
+                }
+            __syncthreads();
+        }
+    }
+    // lanes 0..3 of the wave finish one cell each: unit 2w + (lane & 1), lanes 0 / 1 layer 1 at step t, lanes 2 / 3 layer 0 at step t0
+    const int ui = lane & 1;
+    const bool fl0 = (lane & 2) != 0;
+    const int u = blockIdx.x * SP_U + 2 * w + ui;
+    float dcst = 0.f;                                                 // d c carried to the previous timestep (this lane's cell)
+    __syncthreads();
+    const u32s ROWB = H4 * 4;
+    for (int k = 0; k <= T; ++k) {
+        const bool l1 = k < T, l0 = k >= 1;
+        const int t = T - 1 - k, t0 = T - k;
+        const bool act_on = lane < 4 && (fl0 ? l0 : l1);
+        const int tt = fl0 ? t0 : t;
+        // saved activations of the cell this lane finishes: issued behind the first sweep of the wait, consumed after it
+        float ac[4] = {0.f, 0.f, 0.f, 0.f}, cc = 0.f, cp = 0.f, dho = 0.f, mk = 1.f;
+        auto prefetch = [&]() {
+            if (act_on) {
+                const float* A = fl0 ? P.ACT0 : P.ACT1;
+                const float* Cs = fl0 ? P.CS0 : P.CS1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ac[g] = A[(long)tt * H4 + g * H + u];
+                cc = Cs[(long)tt * H + u]; cp = tt ? Cs[(long)(tt - 1) * H + u] : 0.f;
+                if (!fl0) dho = P.DHO[(long)tt * H + u];
+            }
+            if (l0) mk = drop_mult(P.dc, (unsigned)(t0 * H + u), 0u, SITE_SST);
+        };
+        prefetch();          // ahead of the wait, like the forward kernel
+        SP_STAMP(0);
+        if (k >= 1) {
+            const __amdgpu_buffer_rsrc_t r1 = sp_rsrc(P.DG1 + (long)t0 * H4, ROWB), r0 = sp_rsrc(P.DG0 + (long)min(t0 + 1, T - 1) * H4, ROWB);
+            const __amdgpu_buffer_rsrc_t r[4] = {r1, r1, r0, r0};
+            const u32s off[4] = {(u32s)(tid * 16), (u32s)((tid + 256) * 16), (u32s)(tid * 16), (u32s)((tid + 256) * 16)};
+            const bool need[4] = {true, true, k >= 2, k >= 2};
+            float4 v[4];
+            if (sp_poll<4>(r, off, need, v, P.y, 8500u + (u32s)(k % 500), [] {})) {
+                reinterpret_cast<float4*>(sg)[tid] = v[0];
+                reinterpret_cast<float4*>(sg)[tid + 256] = v[1];
+                if (k >= 2) { reinterpret_cast<float4*>(sg)[512 + tid] = v[2]; reinterpret_cast<float4*>(sg)[768 + tid] = v[3]; }
+            } else fail = 1;
+        }
+        SP_STAMP(1);
+        __syncthreads();
+        if (fail) return;
+        SP_STAMP(2);
+        float d1[2] = {0.f, 0.f}, d2[2] = {0.f, 0.f}, d3[2] = {0.f, 0.f};
+        if (k >= 1) {
+            const float4* g4 = reinterpret_cast<const float4*>(sg);
+            f2s b1[2], b2[2], b3[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b1[i] = b2[i] = b3[i] = f2s{0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 x = g4[lane + 64 * j];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { sp_dot4(b1[i], A1[i][j], x); sp_dot4(b2[i], A2[i][j], x); }
+            }
+            if (k >= 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 x = g4[512 + lane + 64 * j];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) sp_dot4(b3[i], A3[i][j], x);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { d1[i] = sp_sum64(b1[i].x + b1[i].y); d2[i] = sp_sum64(b2[i].x + b2[i].y); d3[i] = sp_sum64(b3[i].x + b3[i].y); }
+        }
+        SP_STAMP(3);
+        // (no barrier: a row of the next step completes only after every wave of this workgroup has published, i.e. after its reads of sg)
+        {
+            const float e1 = ui ? d1[1] : d1[0], e2 = ui ? d2[1] : d2[0], e3 = ui ? d3[1] : d3[0];
+            const float dh = fl0 ? e2 * mk + e3 : dho + e1;
+            const float gi = ac[0], gf = ac[1], gg = ac[2], go = ac[3];
+            const float tc = fast_tanh(cc);
+            const float dcv = dh * go * (1.f - tc * tc) + dcst;
+            if (act_on) {
+                float* dg = (fl0 ? P.DG0 : P.DG1) + (long)tt * H4 + u;
+                sp_store(dg, dcv * gg * gi * (1.f - gi));
+                sp_store(dg + H, dcv * cp * gf * (1.f - gf));
+                sp_store(dg + 2 * H, dcv * gi * (1.f - gg * gg));
+                sp_store(dg + 3 * H, dh * tc * go * (1.f - go));
+                dcst = dcv * gf;
+            }
+        }
+        SP_STAMP(4);
+    }
+}
+
+}  // namespace
+
 static inline long rup(long x, long a) { return (x + a - 1) / a * a; }
 
 struct SstWs { float *GIN0, *ACT[2], *HS[2], *CS[2], *H0D; long total; };
@@ -231,8 +585,9 @@ static SstWs carve(int T, int D, int H, int K, float* base) {
     long off = 0;
     auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
     w.GIN0 = take((long)T * 4 * H);        // layer 0's input-side pre-activations (layer 1 forms its own inside the wavefront step)
-    for (int l = 0; l < 2; ++l) { w.ACT[l] = take((long)T * 4 * H); w.HS[l] = take((long)T * H); w.CS[l] = take((long)T * H); }
-    w.H0D = take((long)T * H);
+    w.HS[0] = take((long)T * H); w.H0D = take((long)T * H);          // adjacent: the persistent kernel's exchange rows, one sentinel fill
+    w.HS[1] = take((long)T * H);
+    for (int l = 0; l < 2; ++l) { w.ACT[l] = take((long)T * 4 * H); w.CS[l] = take((long)T * H); }
     w.total = off;
     return w;
 }
@@ -241,7 +596,8 @@ static SstWsB carve_b(int T, int D, int H, int K, float* base) {
     SstWsB w;
     long off = 0;
     auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
-    for (int l = 0; l < 2; ++l) { w.DG[l] = take((long)T * 4 * H); w.WT[l] = take((long)H * 4 * H); }
+    for (int l = 0; l < 2; ++l) w.DG[l] = take((long)T * 4 * H);      // adjacent: the persistent kernel's exchange rows, one sentinel fill
+    for (int l = 0; l < 2; ++l) w.WT[l] = take((long)H * 4 * H);
     w.DHO = take((long)T * H); w.DC[0] = take(H); w.DC[1] = take(H); w.DZ = take((long)T * K);
     w.WT_IH1 = take((long)H * 4 * H);
     w.total = off;
@@ -249,6 +605,47 @@ static SstWsB carve_b(int T, int D, int H, int K, float* base) {
 }
 
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+// the persistent form needs H = 512 (64 workgroups x 8 units) and the abort plumbing of csrc/persist.hip
+static bool sst_persist_ok(int H) {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+    }
+    return config().sst_persist && H == SP_H && cus >= SP_WG && persist_abort_word() && persist_host_flag();
+}
+static SpSync sst_sync() {
+    SpSync y;
+    y.abort_word = const_cast<u32s*>(persist_abort_word());
+    y.host_flag = persist_host_flag();
+    y.spin_limit = config().persist_spin_limit > 0 ? (u32s)config().persist_spin_limit : SP_SPIN_DEFAULT;
+    return y;
+}
+template <typename K, typename P>
+static int sst_persist_launch(K kernel, P& args, const char* what, hipStream_t st, size_t lds = 0) {
+    if (lds > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                set_error("%s: cannot reserve %zu bytes of LDS", what, lds);
+                return -5;
+            }
+            attr_set = true;
+        }
+    }
+    if (config().persist_coop) {          // shared device: start only when all 64 workgroups can be resident (see persist.hip)
+        void* kargs[1] = {&args};
+        if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3(SP_WG), dim3(256), kargs, lds, st) != hipSuccess) {
+            set_error("%s: cooperative launch failed: %s", what, hipGetErrorString(hipGetLastError()));
+            return -5;
+        }
+        return 0;
+    }
+    hipLaunchKernelGGL(kernel, dim3(SP_WG), dim3(256), lds, st, args);
+    return check_launch(what);
+}
 
 }  // namespace echr
 
@@ -277,29 +674,44 @@ extern "C" int echr_sst_fwd(const echr_sst_args* a, const echr_dropout* drop, vo
     echr_gemm_desc d0 = desc_nt(a->x, D, a->w_ih[0], D, w.GIN0, 4 * H, T, 4 * H, D);
     d0.bias = a->b_ih[0]; d0.bias2 = a->b_hh[0]; d0.split_k = -1;
     RC(gemm(d0, st));
+    if (sst_persist_ok(H)) {
+        RC(persist_check_async());
+        // exchange rows = saved activations: sentinel-fill h0 | h0d (adjacent) and the output rows h1 = tap_feats, then ONE launch
+        if (hipMemsetAsync(w.HS[0], 0xFF, sizeof(float) * (size_t)((w.H0D - w.HS[0]) + (long)T * H), st) != hipSuccess ||
+            hipMemsetAsync(a->tap_feats, 0xFF, sizeof(float) * (size_t)T * H, st) != hipSuccess) { set_error("sst_fwd: memset failed"); return -5; }
+        SstPF P;
+        P.T = T; P.w_hh0 = a->w_hh[0]; P.w_ih1 = a->w_ih[1]; P.w_hh1 = a->w_hh[1]; P.b_ih1 = a->b_ih[1]; P.b_hh1 = a->b_hh[1]; P.GIN0 = w.GIN0;
+        P.HS0 = w.HS[0]; P.H0D = w.H0D; P.TAP = a->tap_feats; P.ACT0 = w.ACT[0]; P.ACT1 = w.ACT[1]; P.CS0 = w.CS[0]; P.CS1 = w.CS[1];
+        P.y = sst_sync(); P.dc = dc;
+        P.stamps = config().persist_stamps == 3 ? persist_stamp_buffer(T + 1, st) : nullptr;
+        // algorithmic bytes: the three recurrent matrices once + per step the pre-activation row in and gates / cells / outputs of both layers out
+        ProfScope prof(PROF_SST, 2.0 * T * 3.0 * 4 * H * H, 4.0 * (3.0 * 4 * H * H + (double)T * (4.0 * H + 2 * (4.0 * H + 2.0 * H) + H)), st);
+        RC(sst_persist_launch(sst_persist_fwd_kernel, P, "sst_persist_fwd", st));
+    } else {
     // wavefront: launch k = layer 0 at step k  ||  layer 1 at step k-1 (reads the dropped layer-0 output of step k-1)
-    for (int k = 0; k <= T; ++k) {
-        SstFwdRole r0{}, r1{};
-        if (k < T) {
-            r0.active = 1; r0.t = k;
-            r0.W[0] = a->w_hh[0]; r0.v[0] = k ? w.HS[0] + (long)(k - 1) * H : nullptr;
-            r0.base = w.GIN0 + (long)k * 4 * H;
-            r0.cprev = k ? w.CS[0] + (long)(k - 1) * H : nullptr;
-            r0.act = w.ACT[0] + (long)k * 4 * H; r0.hout = w.HS[0] + (long)k * H; r0.cout = w.CS[0] + (long)k * H;
-            r0.hdrop = w.H0D + (long)k * H;
+        for (int k = 0; k <= T; ++k) {
+            SstFwdRole r0{}, r1{};
+            if (k < T) {
+                r0.active = 1; r0.t = k;
+                r0.W[0] = a->w_hh[0]; r0.v[0] = k ? w.HS[0] + (long)(k - 1) * H : nullptr;
+                r0.base = w.GIN0 + (long)k * 4 * H;
+                r0.cprev = k ? w.CS[0] + (long)(k - 1) * H : nullptr;
+                r0.act = w.ACT[0] + (long)k * 4 * H; r0.hout = w.HS[0] + (long)k * H; r0.cout = w.CS[0] + (long)k * H;
+                r0.hdrop = w.H0D + (long)k * H;
+            }
+            if (k >= 1) {
+                const int t = k - 1;
+                r1.active = 1; r1.t = t;
+                r1.W[0] = a->w_ih[1]; r1.v[0] = w.H0D + (long)t * H;
+                r1.W[1] = a->w_hh[1]; r1.v[1] = t ? a->tap_feats + (long)(t - 1) * H : nullptr;
+                r1.base = a->b_ih[1]; r1.base2 = a->b_hh[1];
+                r1.cprev = t ? w.CS[1] + (long)(t - 1) * H : nullptr;
+                r1.act = w.ACT[1] + (long)t * 4 * H; r1.hout = a->tap_feats + (long)t * H; r1.cout = w.CS[1] + (long)t * H;
+            }
+            hipLaunchKernelGGL(sst_wave_fwd_kernel, dim3(nwg, 2), dim3(256), (2 * H + 4 * UPW) * sizeof(float), st, r0, r1, H, dc);
         }
-        if (k >= 1) {
-            const int t = k - 1;
-            r1.active = 1; r1.t = t;
-            r1.W[0] = a->w_ih[1]; r1.v[0] = w.H0D + (long)t * H;
-            r1.W[1] = a->w_hh[1]; r1.v[1] = t ? a->tap_feats + (long)(t - 1) * H : nullptr;
-            r1.base = a->b_ih[1]; r1.base2 = a->b_hh[1];
-            r1.cprev = t ? w.CS[1] + (long)(t - 1) * H : nullptr;
-            r1.act = w.ACT[1] + (long)t * 4 * H; r1.hout = a->tap_feats + (long)t * H; r1.cout = w.CS[1] + (long)t * H;
-        }
-        hipLaunchKernelGGL(sst_wave_fwd_kernel, dim3(nwg, 2), dim3(256), (2 * H + 4 * UPW) * sizeof(float), st, r0, r1, H, dc);
+        RC(check_launch("sst_wave_fwd"));
     }
-    RC(check_launch("sst_wave_fwd"));
     // proposal head
     echr_gemm_desc d = desc_nt(a->tap_feats, H, a->w_sc, H, a->scores, K, T, K, H);
     d.bias = a->b_sc; d.split_k = -1;
@@ -335,37 +747,49 @@ extern "C" int echr_sst_bwd(const echr_sst_args* a, const echr_sst_grads* g, con
         RC(fill_zero(g->g_w_sc, (long)K * H, st));
         RC(fill_zero(g->g_b_sc, K, st));
     }
+    if (sst_persist_ok(H)) {
+        RC(persist_check_async());
+        if (hipMemsetAsync(b.DG[0], 0xFF, sizeof(float) * (size_t)((b.DG[1] - b.DG[0]) + (long)T * 4 * H), st) != hipSuccess) { set_error("sst_bwd: memset failed"); return -5; }
+        SstPB P;
+        P.T = T; P.w_hh0 = a->w_hh[0]; P.w_ih1 = a->w_ih[1]; P.w_hh1 = a->w_hh[1];
+        P.ACT0 = w.ACT[0]; P.ACT1 = w.ACT[1]; P.CS0 = w.CS[0]; P.CS1 = w.CS[1]; P.DHO = b.DHO; P.DG0 = b.DG[0]; P.DG1 = b.DG[1];
+        P.y = sst_sync(); P.dc = dc;
+        P.stamps = config().persist_stamps == 4 ? persist_stamp_buffer(T + 1, st) : nullptr;
+        ProfScope prof(PROF_SST, 2.0 * T * 3.0 * 4 * H * H, 4.0 * (3.0 * 4 * H * H + (double)T * (2 * (4.0 * H + 2.0 * H) + H + 2 * 4.0 * H)), st);
+        RC(sst_persist_launch(sst_persist_bwd_kernel, P, "sst_persist_bwd", st, sizeof(float) * (2 + 8) * 4 * SP_H));
+    } else {
     {
-        const TransposeJob tj[3] = {{a->w_hh[0], H, b.WT[0], 4 * H, 4 * H, H}, {a->w_hh[1], H, b.WT[1], 4 * H, 4 * H, H},
-                                    {a->w_ih[1], H, b.WT_IH1, 4 * H, 4 * H, H}};
-        RC(transpose_multi(tj, 3, st));
-        float* zp[2] = {b.DC[0], b.DC[1]};
-        const long zn[2] = {H, H};
-        RC(fill_zero_multi(zp, zn, 2, st));
-    }
-    // wavefront: launch k = layer 1 at step T-1-k  ||  layer 0 at step T-k (its upstream gradient is W_ih1^T . dG1 of the same step,
-    // through the inter-layer dropout mask)
-    for (int k = 0; k <= T; ++k) {
-        SstBwdRole r1{}, r0{};
-        if (k < T) {
-            const int t = T - 1 - k;
-            r1.active = 1; r1.t = t;
-            r1.WT[0] = b.WT[1]; r1.vec[0] = t + 1 < T ? b.DG[1] + (long)(t + 1) * 4 * H : nullptr;
-            r1.dh_base = b.DHO + (long)t * H;
-            r1.act = w.ACT[1] + (long)t * 4 * H; r1.c = w.CS[1] + (long)t * H; r1.cprev = t ? w.CS[1] + (long)(t - 1) * H : nullptr;
-            r1.dc = b.DC[1]; r1.dg = b.DG[1] + (long)t * 4 * H;
+            const TransposeJob tj[3] = {{a->w_hh[0], H, b.WT[0], 4 * H, 4 * H, H}, {a->w_hh[1], H, b.WT[1], 4 * H, 4 * H, H},
+                                        {a->w_ih[1], H, b.WT_IH1, 4 * H, 4 * H, H}};
+            RC(transpose_multi(tj, 3, st));
+            float* zp[2] = {b.DC[0], b.DC[1]};
+            const long zn[2] = {H, H};
+            RC(fill_zero_multi(zp, zn, 2, st));
         }
-        if (k >= 1) {
-            const int t = T - k;
-            r0.active = 1; r0.t = t; r0.drop_first = 1;
-            r0.WT[0] = b.WT_IH1; r0.vec[0] = b.DG[1] + (long)t * 4 * H;
-            r0.WT[1] = b.WT[0]; r0.vec[1] = t + 1 < T ? b.DG[0] + (long)(t + 1) * 4 * H : nullptr;
-            r0.act = w.ACT[0] + (long)t * 4 * H; r0.c = w.CS[0] + (long)t * H; r0.cprev = t ? w.CS[0] + (long)(t - 1) * H : nullptr;
-            r0.dc = b.DC[0]; r0.dg = b.DG[0] + (long)t * 4 * H;
+        // wavefront: launch k = layer 1 at step T-1-k  ||  layer 0 at step T-k (its upstream gradient is W_ih1^T . dG1 of the same step,
+        // through the inter-layer dropout mask)
+        for (int k = 0; k <= T; ++k) {
+            SstBwdRole r1{}, r0{};
+            if (k < T) {
+                const int t = T - 1 - k;
+                r1.active = 1; r1.t = t;
+                r1.WT[0] = b.WT[1]; r1.vec[0] = t + 1 < T ? b.DG[1] + (long)(t + 1) * 4 * H : nullptr;
+                r1.dh_base = b.DHO + (long)t * H;
+                r1.act = w.ACT[1] + (long)t * 4 * H; r1.c = w.CS[1] + (long)t * H; r1.cprev = t ? w.CS[1] + (long)(t - 1) * H : nullptr;
+                r1.dc = b.DC[1]; r1.dg = b.DG[1] + (long)t * 4 * H;
+            }
+            if (k >= 1) {
+                const int t = T - k;
+                r0.active = 1; r0.t = t; r0.drop_first = 1;
+                r0.WT[0] = b.WT_IH1; r0.vec[0] = b.DG[1] + (long)t * 4 * H;
+                r0.WT[1] = b.WT[0]; r0.vec[1] = t + 1 < T ? b.DG[0] + (long)(t + 1) * 4 * H : nullptr;
+                r0.act = w.ACT[0] + (long)t * 4 * H; r0.c = w.CS[0] + (long)t * H; r0.cprev = t ? w.CS[0] + (long)(t - 1) * H : nullptr;
+                r0.dc = b.DC[0]; r0.dg = b.DG[0] + (long)t * 4 * H;
+            }
+            hipLaunchKernelGGL(sst_wave_bwd_kernel, dim3(nwg, 2), dim3(256), (8 * H + 2 * UPW) * sizeof(float), st, r1, r0, H, dc);
         }
-        hipLaunchKernelGGL(sst_wave_bwd_kernel, dim3(nwg, 2), dim3(256), (8 * H + 2 * UPW) * sizeof(float), st, r1, r0, H, dc);
+        RC(check_launch("sst_wave_bwd"));
     }
-    RC(check_launch("sst_wave_bwd"));
     // parameter gradients (sums over the T rows); h(t-1) pairs with dG(t): rows 1..T-1
     for (int l = 1; l >= 0; --l) {
         const float* hs = l == 0 ? w.HS[0] : a->tap_feats;

@@ -950,7 +950,8 @@ def test_sst_native_matches_reference_fixture():
         assert U.grad_close(k, p.grad.cpu().numpy(), g['grad|' + k], TOL_GRAD), (k, U.relerr(p.grad.cpu().numpy(), g['grad|' + k]))
 
 
-@pytest.mark.parametrize('T,D,H,K,train', [(37, 500, 512, 256, True), (5, 20, 24, 8, True), (64, 500, 512, 32, False)])
+@pytest.mark.parametrize('T,D,H,K,train', [(37, 500, 512, 256, True), (5, 20, 24, 8, True), (64, 500, 512, 32, False), (1, 500, 512, 16, True),
+                                           (2, 500, 512, 16, True), (256, 500, 512, 256, True)])
 def test_sst_native_vs_oracle(T, D, H, K, train):
     """ECHR-sized SST (500 -> 512, K anchors) incl. the inter-layer dropout with injected Philox masks, forward and backward."""
     from echr_amd import philox
@@ -976,6 +977,37 @@ def test_sst_native_vs_oracle(T, D, H, K, train):
     assert np.abs(sc.detach().cpu().numpy() - osc.detach().numpy()).max() < 2e-5
     for k, p in m.named_parameters():
         assert U.grad_close(k, p.grad.cpu().numpy(), P[k].grad.numpy(), TOL_GRAD), (k, U.relerr(p.grad.cpu().numpy(), P[k].grad.numpy()))
+
+
+def test_sst_persistent_equals_wavefront_launches():
+    """The one-launch persistent form of the proposal encoder's recurrence (registers hold the recurrent matrices, sentinel-polled rows)
+    against the T+1-launch wavefront form it replaces: outputs and gradients agree to fp32 summation-order noise."""
+    from echr_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(5)
+    T, D, H, K = 96, 500, 512, 64
+    shapes = {'rnn.weight_ih_l0': (4 * H, D), 'rnn.weight_hh_l0': (4 * H, H), 'rnn.bias_ih_l0': (4 * H,), 'rnn.bias_hh_l0': (4 * H,),
+              'rnn.weight_ih_l1': (4 * H, H), 'rnn.weight_hh_l1': (4 * H, H), 'rnn.bias_ih_l1': (4 * H,), 'rnn.bias_hh_l1': (4 * H,),
+              'scores.weight': (K, H), 'scores.bias': (K,)}
+    params = {k: (rs.uniform(-1, 1, size=s) / np.sqrt(H)).astype(np.float32) for k, s in shapes.items()}
+    x = torch.from_numpy(rs.standard_normal((T, D)).astype(np.float32)).cuda()
+    wt = torch.from_numpy(rs.standard_normal((T, H)).astype(np.float32)).cuda()
+    out = {}
+    try:
+        for persist in (1, 0):
+            assert lib.echr_config_set(b'sst_persist', persist) == 0
+            m, _ = _sst_module(params, dict(video_dim=D, hidden_dim=H, K=K, rnn_dropout=0.5), True)
+            m.set_dropout_state(U.SEED, U.OFFSET)
+            tap, sc = m(x)
+            ((tap * wt).sum() + sc.sum()).backward()
+            torch.cuda.synchronize()
+            out[persist] = (tap.detach().cpu().numpy(), sc.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()})
+    finally:
+        lib.echr_config_set(b'sst_persist', 1)
+    assert lib.echr_check_async() == 0
+    assert np.isfinite(out[1][0]).all() and np.abs(out[1][0] - out[0][0]).max() < 1e-5 and np.abs(out[1][1] - out[0][1]).max() < 1e-5
+    for k, g in out[0][2].items():
+        assert U.grad_close(k, out[1][2][k], g, TOL_GRAD), (k, U.relerr(out[1][2][k], g))
 
 
 def test_top_proposals_bit_exact_vs_reference():
