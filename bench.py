@@ -192,7 +192,9 @@ def gpu_leg(args, rank, world, local_rank):
                  2: ('att_bwd_kernel', 'att_bwd_kernel', 'hbm'),
                  3: ('att_post_kernel', 'att_post_kernel', 'valu'),
                  9: ('dec_persist_kernels', 'dec_persist_fwd_kernel<true> (forward) and dec_persist_bwd_kernel (reverse): each ONE launch of 256 workgroups '
-                                            '(attention chain on 192, the two plain LSTM streams on 64) covering all S steps', 'mfma')}
+                                            '(attention chain on 192, the two plain LSTM streams on 64) covering all S steps', 'mfma'),
+                 10: ('sst_persist_kernels', 'sst_persist_fwd_kernel / sst_persist_bwd_kernel: the proposal encoder\'s two-layer LSTM over the video, ONE '
+                                             'launch of 64 workgroups per direction (recurrent matrices in registers, batch-1 GEMV chain: latency-bound)', 'hbm')}
         n_it = max(2, min(args.steps, 5))
         stats = {}
         for k, (name, sym, bound) in kinds.items():
@@ -203,7 +205,7 @@ def gpu_leg(args, rank, world, local_rank):
         # HBM traffic per launch cannot be collected inside a timed run (PMC needs rocprofv3 --pmc in separate passes): it is read from
         # the committed summary of the SAME command (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.json); null when absent
         traffic, traffic_src = {}, None
-        for name in ('r02_pmc_traffic.json',):
+        for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
             try:
                 traffic = json.load(open(os.path.join(ROOT, 'profiles', name)))
                 traffic_src = 'profiles/' + name
@@ -213,10 +215,13 @@ def gpu_leg(args, rank, world, local_rank):
         # MFMA activity (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles of the dispatch) likewise comes from the committed --pmc pass of the
         # same command (tools/pmc_mfma.sh -> profiles/r02_pmc_mfma.json)
         mfma_pmc = {}
-        try:
-            mfma_pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_mfma.json')))
-        except Exception:
-            pass
+        for name in ('r03_pmc_mfma.json', 'r02_pmc_mfma.json'):
+            try:
+                mfma_pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
+                break
+            except Exception:
+                pass
+        traffic_commit = traffic.get('_commit') if isinstance(traffic, dict) else None
 
         def mfma_busy(name):
             if name == 'dec_persist_kernels':           # time-weighted over the four kernels of the two pairs
@@ -251,7 +256,7 @@ def gpu_leg(args, rank, world, local_rank):
             tb = (tr or {}).get('hbm_bytes_per_launch')
             alg = st['bytes'] / st['launches'] if st['bytes'] > 0 else None
             return dict(bound='mfma' if st['bound'] == 'valu' else st['bound'], kernel=st['sym'], achieved=round(ach, 2), peak=peak, unit=unit,
-                        frac=round(ach / peak, 4), traffic=tb, traffic_source=traffic_src if tb else None,
+                        frac=round(ach / peak, 4), traffic=tb, traffic_source=traffic_src if tb else None, traffic_commit=traffic_commit if tb else None,
                         algorithmic_bytes_per_launch=round(alg) if alg else None,
                         traffic_over_algorithmic=round(tb / alg, 2) if (tb and alg) else None,
                         mfma_busy_frac_pmc=mfma_busy(name),
@@ -267,12 +272,23 @@ def gpu_leg(args, rank, world, local_rank):
     return dt, final_loss, roof, native
 
 
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
 def cpu_leg(args):
     """The oracle (a CPU port of the reference algorithm, kind='port') timed on this box's host cores on the SAME workload
     (fwd + criterion + backward + clamp + Adam), per BASELINE.md section 3: all cores available to this process AND one thread,
-    2 warm-ups, min of up to 5 repeats, bounded to ~25 s per setting."""
+    2 warm-ups, min of up to 5 repeats, bounded to ~25 s per setting; the forward-only figure (BASELINE config 2) beside it.
+    --c5: the joint SST + caption iteration (oracle sst_forward + tap_criterion + caption path)."""
     from oracle import echr_ref_cpu as O
-    opt, params, vid = make_workload(0, args.overlap)
+    opt, params, vid = make_workload(0, args.overlap, args.c5)
     # host cores actually available to this process: the scheduler affinity, capped by the cgroup CPU quota when one is set
     avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     try:
@@ -284,54 +300,79 @@ def cpu_leg(args):
     if os.environ.get('ECHR_CPU_THREADS'):
         avail = max(1, min(avail, int(os.environ['ECHR_CPU_THREADS'])))
     P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    if args.c5:      # the proposal encoder's parameters (nn.LSTM layout), same init ranges as the GPU leg's module
+        H, D, K = opt.hidden_dim, opt.video_dim, opt.K
+        rs0 = np.random.RandomState(7)
+        shapes = {'rnn.weight_ih_l0': (4 * H, D), 'rnn.weight_hh_l0': (4 * H, H), 'rnn.bias_ih_l0': (4 * H,), 'rnn.bias_hh_l0': (4 * H,),
+                  'rnn.weight_ih_l1': (4 * H, H), 'rnn.weight_hh_l1': (4 * H, H), 'rnn.bias_ih_l1': (4 * H,), 'rnn.bias_hh_l1': (4 * H,),
+                  'scores.weight': (K, H), 'scores.bias': (K,)}
+        for k, shp in shapes.items():
+            P['tap.' + k] = torch.from_numpy((rs0.uniform(-1, 1, size=shp) / np.sqrt(H)).astype(np.float32)).requires_grad_(True)
     ms = {k: torch.zeros_like(v) for k, v in P.items()}
     vs = {k: torch.zeros_like(v) for k, v in P.items()}
     tap, c3d, lda = (torch.from_numpy(vid[k]) for k in ('tap', 'c3d', 'lda'))
     labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    if args.c5:
+        tl, tm, tw = (torch.from_numpy(vid[k]) for k in ('tap_labels', 'tap_masks', 'w1'))
     rs = np.random.RandomState(0)
 
     def drop(site, step, shape):
         p = 0.3 if site == 'tsrm' else 0.5
         return torch.from_numpy(((rs.random_sample(shape) >= p) / (1 - p)).astype(np.float32))
 
-    def iteration(step):
+    def forward():
+        tap_in, loss = tap, 0.0
+        if args.c5:
+            Pt = {k[4:]: v for k, v in P.items() if k.startswith('tap.')}
+            tap_in, props = O.sst_forward(Pt, c3d, drop('sst', 0, (c3d.shape[0], opt.hidden_dim)))
+            loss = 0.01 * O.tap_criterion(props, tm, tl, tw)
+        pred = O.caption_forward(P, tap_in, c3d, lda, labels, vid['ind'], vid['soi'], 'train', drop, opt.n_head)
+        return loss + O.lm_criterion(pred, labels[:, 1:], masks[:, 1:])
+
+    def iteration(step, fwd_only=False):
+        if fwd_only:
+            with torch.no_grad():
+                forward()
+            return
         for v in P.values():
             v.grad = None
-        pred = O.caption_forward(P, tap, c3d, lda, labels, vid['ind'], vid['soi'], 'train', drop, opt.n_head)
-        loss = O.lm_criterion(pred, labels[:, 1:], masks[:, 1:])
-        loss.backward()
+        forward().backward()
         with torch.no_grad():
             for k, v in P.items():
                 if v.grad is not None:
                     O.clamp_adam_step(v, v.grad, ms[k], vs[k], step, opt.lr, clip=opt.grad_clip)
 
-    def timed(threads, budget_s, warm):
+    def timed(threads, budget_s, warm, fwd_only=False):
         torch.set_num_threads(threads)
-        print('[bench] cpu baseline: %d thread(s): %d warm-up(s)' % (threads, warm), file=sys.stderr, flush=True)
+        print('[bench] cpu baseline: %d thread(s)%s: %d warm-up(s)' % (threads, ' forward only' if fwd_only else '', warm), file=sys.stderr, flush=True)
         step = 1
         t_all = time.perf_counter()
         for _ in range(warm):
-            iteration(step)
+            iteration(step, fwd_only)
             step += 1
             if time.perf_counter() - t_all > budget_s:
                 break
         times = []
         while len(times) < 5 and (not times or time.perf_counter() - t_all < budget_s):
             t0 = time.perf_counter()
-            iteration(step)
+            iteration(step, fwd_only)
             times.append(time.perf_counter() - t0)
             step += 1
         return times
 
     t_all = timed(avail, 25.0, 2)
+    t_fwd = timed(avail, 10.0, 1, fwd_only=True)
     t_one = timed(1, 25.0, 1 if avail > 1 else 0) if avail > 1 else t_all
     best = min(t_all)
+    what = ('joint SST + caption iterations of the same c5 workload (T_v=256, 64 proposals of 4..256 segments, S=20)' if args.c5 else
+            'fwd+bwd+clamp+Adam iterations of the same N=64 x A=128 x S=20 workload')
     return dict(value=round(S_STEPS / best, 2), unit='timesteps/s', cores=avail, kind='port',
                 median=round(S_STEPS / float(np.median(t_all)), 2),
+                fwd_only=dict(value=round(S_STEPS / min(t_fwd), 2), unit='timesteps/s', repeats=len(t_fwd)),
                 one_thread=dict(value=round(S_STEPS / min(t_one), 2), repeats=len(t_one)),
-                sample='fwd+bwd+clamp+Adam iterations of the same N=64 x A=128 x S=20 workload: min of %d after 2 warm-ups on all %d available '
-                       'cores (os.cpu_count()=%s), and min of %d on 1 thread; torch %s CPU fp32'
-                       % (len(t_all), avail, os.cpu_count(), len(t_one), torch.__version__))
+                cpu_model=cpu_model_name(), torch=torch.__version__, os_cpu_count=os.cpu_count(),
+                sample='%s: min of %d after 2 warm-ups on all %d available cores (os.cpu_count()=%s), forward-only min of %d, and min of %d on '
+                       '1 thread; torch %s CPU fp32' % (what, len(t_all), avail, os.cpu_count(), len(t_fwd), len(t_one), torch.__version__))
 
 
 def self_launch(args):
@@ -433,7 +474,7 @@ def main():
             out['native_f32'] = native
         if roof is not None:
             out['roofline'] = roof
-        if world == 1 and not args.no_cpu and args.mode == 'train' and not args.c5:
+        if world == 1 and not args.no_cpu and args.mode == 'train':
             out['cpu_baseline'] = cpu_leg(args)
         print(json.dumps(out), flush=True)
     if dist.is_available() and dist.is_initialized():

@@ -372,8 +372,12 @@ int logsoftmax_rows(float* X, long ld, int N, int S, int t0, int nt, int cols, h
 
 // d logits (time-major rows t*N+n, leading dim ldo, zero padded) from log-probs [N,S,V1] and either a
 // dense upstream gradient G [N,S,V1] or the fused masked-NLL gradient (target/mask/g_loss/inv_den).
+// target indices arrive as int32 or, straight from the reference's LongTensor labels, as int64 (no conversion pass)
+__device__ __forceinline__ int load_index(const void* p, long i, int is64) {
+    return is64 ? (int)reinterpret_cast<const long long*>(p)[i] : reinterpret_cast<const int*>(p)[i];
+}
 __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __restrict__ logp, const float* __restrict__ G,
-                                                             const int* __restrict__ target, const float* __restrict__ mask,
+                                                             const void* __restrict__ target, int tgt64, const float* __restrict__ mask,
                                                              const float* __restrict__ g_loss, const float* __restrict__ mask_sum,
                                                              float* __restrict__ out, long ldo, int N, int S, int V1) {
     __shared__ float red[4];
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __rest
     } else {
         // loss = -sum(logp[target]*mask)/(sum(mask)+1e-6)  =>  g[target] = -mask/(den) * g_loss, other entries 0
         const float gv = -mask[n * S + t] / (mask_sum[0] + 1e-6f) * g_loss[0];
-        const int tg = target[n * S + t];
+        const int tg = load_index(target, n * S + t, tgt64);
         for (int j = threadIdx.x; j < V1; j += 256) o[j] = (j == tg ? gv : 0.f) - expf(logp[src + j]) * gv;
     }
     for (int j = V1 + threadIdx.x; j < ldo; j += 256) o[j] = 0.f;
@@ -420,22 +424,22 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_reg_kernel(const float* __
         else if (j < ldo) o[j] = 0.f;
     }
 }
-int logsoftmax_bwd(const float* logp, const float* G, const int* target, const float* mask, const float* g_loss,
+int logsoftmax_bwd(const float* logp, const float* G, const void* target, int tgt64, const float* mask, const float* g_loss,
                    const float* mask_sum, float* out, long ldo, int N, int S, int V1, hipStream_t st) {
     if (G && ldo <= 256 * 20 && ldo > 256 * 8) hipLaunchKernelGGL(logsoftmax_bwd_reg_kernel<20>, dim3(N * S), dim3(256), 0, st, logp, G, out, ldo, N, S, V1);
     else if (G && ldo <= 256 * 8) hipLaunchKernelGGL(logsoftmax_bwd_reg_kernel<8>, dim3(N * S), dim3(256), 0, st, logp, G, out, ldo, N, S, V1);
-    else hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(N * S), dim3(256), 0, st, logp, G, target, mask, g_loss, mask_sum, out, ldo, N, S, V1);
+    else hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(N * S), dim3(256), 0, st, logp, G, target, tgt64, mask, g_loss, mask_sum, out, ldo, N, S, V1);
     return check_launch("logsoftmax_bwd");
 }
 
 // masked NLL (misc/utils.py:66-75): out[0] = loss, out[1] = sum(mask)
-__global__ __launch_bounds__(256) void nll_loss_kernel(const float* __restrict__ logp, const int* __restrict__ target,
+__global__ __launch_bounds__(256) void nll_loss_kernel(const float* __restrict__ logp, const void* __restrict__ target, int tgt64,
                                                        const float* __restrict__ mask, float* __restrict__ out, int NS, int V1) {
     __shared__ float red[4];
     float s = 0.f, ms = 0.f;
     for (int i = threadIdx.x; i < NS; i += 256) {
         const float mk = mask[i];
-        int tg = min(max(target[i], 0), V1 - 1);
+        int tg = min(max(load_index(target, i, tgt64), 0), V1 - 1);
         s -= logp[(long)i * V1 + tg] * mk;
         ms += mk;
     }
@@ -445,13 +449,13 @@ __global__ __launch_bounds__(256) void nll_loss_kernel(const float* __restrict__
 }
 
 // backward of the masked NLL as ONE pass: g_logp[n,s,:] = 0 except g_logp[n,s,target] = -mask / (sum(mask) + 1e-6) * g_loss
-__global__ __launch_bounds__(256) void nll_loss_bwd_kernel(const int* __restrict__ target, const float* __restrict__ mask,
+__global__ __launch_bounds__(256) void nll_loss_bwd_kernel(const void* __restrict__ target, int tgt64, const float* __restrict__ mask,
                                                            const float* __restrict__ fwd_out, const float* __restrict__ g_loss,
                                                            float* __restrict__ g_logp, int V1) {
     const long row = blockIdx.x;
     float4* o = reinterpret_cast<float4*>(g_logp + row * V1);
     const float gv = -mask[row] / (fwd_out[1] + 1e-6f) * g_loss[0];
-    const int tg = min(max(target[row], 0), V1 - 1);
+    const int tg = min(max(load_index(target, row, tgt64), 0), V1 - 1);
     float* of = g_logp + row * V1;
     for (int j = threadIdx.x; j < V1; j += 256) of[j] = (j == tg) ? gv : 0.f;
     (void)o;
@@ -702,12 +706,15 @@ extern "C" int echr_event_pool_gather_bwd(const float* d_ech, const int32_t* ind
     return check_launch("event_pool_gather_bwd");
 }
 
-extern "C" int echr_nll_loss_fwd(const float* logp, const int32_t* target, const float* mask, float* loss, int32_t N, int32_t S,
-                                 int32_t V1, void* stream) {
+static int nll_fwd(const float* logp, const void* target, int tgt64, const float* mask, float* loss, int32_t N, int32_t S, int32_t V1, void* stream) {
     ECHR_REQUIRE(logp && target && mask && loss && N > 0 && S > 0 && V1 > 0, "nll_loss_fwd: bad arguments");
-    hipLaunchKernelGGL(nll_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, target, mask, loss, N * S, V1);
+    hipLaunchKernelGGL(nll_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, target, tgt64, mask, loss, N * S, V1);
     return check_launch("nll_loss_fwd");
 }
+extern "C" int echr_nll_loss_fwd(const float* logp, const int32_t* target, const float* mask, float* loss, int32_t N, int32_t S,
+                                 int32_t V1, void* stream) { return nll_fwd(logp, target, 0, mask, loss, N, S, V1, stream); }
+extern "C" int echr_nll_loss_fwd_i64(const float* logp, const int64_t* target, const float* mask, float* loss, int32_t N, int32_t S,
+                                     int32_t V1, void* stream) { return nll_fwd(logp, target, 1, mask, loss, N, S, V1, stream); }
 
 extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
                                double beta2, double eps, float clip, void* stream) {
@@ -800,9 +807,13 @@ extern "C" int echr_config_set(const char* key, int32_t value) {
     return 0;
 }
 
-extern "C" int echr_nll_loss_bwd(const int32_t* target, const float* mask, const float* fwd_out, const float* g_loss, float* g_logp,
-                                 int32_t N, int32_t S, int32_t V1, void* stream) {
+static int nll_bwd(const void* target, int tgt64, const float* mask, const float* fwd_out, const float* g_loss, float* g_logp,
+                   int32_t N, int32_t S, int32_t V1, void* stream) {
     ECHR_REQUIRE(target && mask && fwd_out && g_loss && g_logp && N > 0 && S > 0 && V1 > 0, "nll_loss_bwd: bad arguments");
-    hipLaunchKernelGGL(nll_loss_bwd_kernel, dim3(N * S), dim3(256), 0, (hipStream_t)stream, target, mask, fwd_out, g_loss, g_logp, V1);
+    hipLaunchKernelGGL(nll_loss_bwd_kernel, dim3(N * S), dim3(256), 0, (hipStream_t)stream, target, tgt64, mask, fwd_out, g_loss, g_logp, V1);
     return check_launch("nll_loss_bwd");
 }
+extern "C" int echr_nll_loss_bwd(const int32_t* target, const float* mask, const float* fwd_out, const float* g_loss, float* g_logp,
+                                 int32_t N, int32_t S, int32_t V1, void* stream) { return nll_bwd(target, 0, mask, fwd_out, g_loss, g_logp, N, S, V1, stream); }
+extern "C" int echr_nll_loss_bwd_i64(const int64_t* target, const float* mask, const float* fwd_out, const float* g_loss, float* g_logp,
+                                     int32_t N, int32_t S, int32_t V1, void* stream) { return nll_bwd(target, 1, mask, fwd_out, g_loss, g_logp, N, S, V1, stream); }

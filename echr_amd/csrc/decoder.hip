@@ -972,12 +972,21 @@ static Prep& prep() {
     }
     return t;
 }
+// will echr_decoder_fwd run the persistent forward launch on these arguments (same test as there)?
+static bool fwd_uses_persist(const echr_dec_args* a) {
+    const bool two = config().chains2 == 1 && side().ok && a->S >= 2;
+    const bool ov = !two && overlap_enabled() && a->S >= 4;
+    return persist_fwd_eligible(a) && !ov && !two;
+}
 static int decoder_fill(const echr_dec_args* a, const DecWs& w, hipStream_t st) {
     const int N = a->N, S = a->S, H = a->H;
-    // h(-1) = c(-1) = 0 (init_hidden, :75-78), the atomic q accumulators and the split-K target EVB0: one launch
-    float* zp[6] = {w.HS, w.CS[0], w.CS[1], w.CS[2], w.QACC, w.EVB0};
-    const long zn[6] = {(long)N * 3 * H, (long)N * H, (long)N * H, (long)N * H, (long)S * N * a->Ha, (long)N * 4 * H};
-    return fill_zero_multi(zp, zn, 6, st);
+    // h(-1) = c(-1) = 0 (init_hidden, :75-78), the atomic q accumulators and the split-K target EVB0 -- and the zeroed part of the persistent
+    // launch's exchange workspace (counters, accumulated buffers): one launch
+    float* zp[7] = {w.HS, w.CS[0], w.CS[1], w.CS[2], w.QACC, w.EVB0, nullptr};
+    long zn[7] = {(long)N * 3 * H, (long)N * H, (long)N * H, (long)N * H, (long)S * N * a->Ha, (long)N * 4 * H, 0};
+    int n = 6;
+    if (fwd_uses_persist(a)) { persist_fwd_zero_range(a, w.XWS, &zp[6], &zn[6]); n = 7; }
+    return fill_zero_multi(zp, zn, n, st);
 }
 
 extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
@@ -1048,6 +1057,7 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
         PersistFwdBufs pb;
         for (int k = 0; k < 3; ++k) { pb.GATES[k] = w.GATES[k]; pb.CS[k] = w.CS[k]; }
         pb.HS = w.HS; pb.OUTD = w.OUTD; pb.QS = w.QS; pb.WT = w.WT; pb.ATT = w.ATT; pb.PALL = w.PALL; pb.xws = w.XWS;
+        pb.prezeroed = true;                    // decoder_fill covered the exchange workspace's zeroed part
         RC(persist_fwd(a, pb, dh, dout, st));
     } else if (two) {
         RC(hop(st, side().fork, side().s));
@@ -1099,10 +1109,12 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     const bool do_a = g->phase == 0 || g->phase == 1;
     const bool do_rec = g->phase == 0 || g->phase == 2 || g->phase == 3;
     const bool do_pb = g->phase == 0 || g->phase == 2 || g->phase == 4;
+    // the reverse recurrence of this call runs as the persistent launch (same test as stage 3 applies)
+    const bool bwd_persist = !overlap_enabled() && !(config().chains2 == 1 && side().ok && S >= 2) && persist_bwd_eligible(a);
     // 1. d logits (time-major, padded leading dimension)
     if (do_a) {
     if (!g->g_logp && !g->nll_msum) RC(colsum(g->nll_mask, 1, N * S, 1, b.MSUM, false, st));
-    RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_mask, g->g_loss, g->nll_msum ? g->nll_msum : b.MSUM, b.DLG, b.ldg, N, S, V1, st));
+    RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_target_i64, g->nll_mask, g->g_loss, g->nll_msum ? g->nll_msum : b.MSUM, b.DLG, b.ldg, N, S, V1, st));
     // scratch that is accumulated into, and the transposed recurrent weights (every d h / d ATT product of the reverse recurrence
     // then has the same NT form as forward): two launches, independent of everything above
     // (the persistent reverse launch builds its weight images from the untransposed matrices: nothing to transpose then; the test is the
@@ -1113,10 +1125,14 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
                                     {a->w_h2a, H, b.WT_H2A, Ha, Ha, H}};
         RC(transpose_multi(tj, 5, st));
     }
-    {   // DC | DGCOL | DQ | DASL | DPALL, and the split-K / accumulated outputs DXT, g_event and DOUT: one launch
-        float* zp[4] = {b.DC, b.DXT, g->g_event, b.DOUT};
-        const long zn[4] = {b.zero_floats, (long)SN * E, (long)N * a->De, (long)SN * 3 * H};
-        RC(fill_zero_multi(zp, zn, 4, st));
+    {   // DC | DGCOL | DQ | DASL | DPALL, the split-K / accumulated outputs DXT, g_event and DOUT, the zeroed part of the persistent reverse
+        // launch's exchange workspace and, when the caller asks for it (zero_extra), its gradient arena span: one launch
+        float* zp[6] = {b.DC, b.DXT, g->g_event, b.DOUT, nullptr, nullptr};
+        long zn[6] = {b.zero_floats, (long)SN * E, (long)N * a->De, (long)SN * 3 * H, 0, 0};
+        int nz = 4;
+        if (bwd_persist) { persist_bwd_zero_range(a, b.XWSB, &zp[nz], &zn[nz]); ++nz; }
+        if (g->zero_extra && g->zero_extra_count > 0) { zp[nz] = g->zero_extra; zn[nz] = (long)g->zero_extra_count; ++nz; }
+        RC(fill_zero_multi(zp, zn, nz, st));
     }
     }
     // 2. late fusion gradients: the weight/bias gradients do not feed the recurrence -> side stream
@@ -1258,6 +1274,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         PersistBwdBufs pb;
         for (int k = 0; k < 3; ++k) { pb.GATES[k] = w.GATES[k]; pb.CS[k] = w.CS[k]; pb.DG[k] = b.DG[k]; }
         pb.QS = w.QS; pb.WT = w.WT; pb.ATT = w.ATT; pb.PALL = w.PALL; pb.DOUT = b.DOUT; pb.DQ = b.DQ; pb.DSC = b.DSC; pb.xws = b.XWSB;
+        pb.prezeroed = do_a;                    // stage 1 of this call zeroed the exchange workspace with the backward scratch
         RC(persist_bwd(a, pb, dh, dout, st));
     } else if (two) {          // streams 0/2 are independent of the attention chain: their reverse recurrence runs on the side stream
         RC(hop(st, side().fork, side().s));
@@ -1275,7 +1292,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     }
     // 4. batched parameter gradients, part A: everything of the three LSTM layers (core.layer0..2) -- final after this block, so a
     //    data-parallel caller can start reducing them (phase 3) while part B runs
-    if (do_rec) {
+    auto part_a = [&]() -> int {
+    if (!do_rec) return 0;
     if (ov) RC(hop(sq, side().join, st));                     // chunk [th,S) and the logit gradients are complete
     RC(wgrad_chunk(0, th_b, (ov || z) ? 1.f : 0.f, st));      // W_hh_k, W_ih_k[:, :E], W_ih1[:, E:], W_h2a: sums over timesteps
     //    bias gradients b_h2a and per stream b_ih = b_hh = column sums of DG_k over all S*N rows (stream 2's also as the plain vector
@@ -1309,11 +1327,16 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         d.split_k = -1;
         RC(gemm(d, st));
     }
-    }
-    if (!do_pb) return 0;
-    // phase 0 + async_tail: nothing downstream in the backward pass needs part B's outputs -> second stream, joined by the caller
-    const bool async_tail = g->phase == 0 && g->async_tail != 0 && tail().ok && !ov;
+    return 0;
+    };
+    // phase 0 + async_tail: nothing downstream in the backward pass needs part B's outputs -> second stream, joined by the caller.  The tail
+    // forks right behind the reverse recurrence, AHEAD of part A: its three chains (logit-layer gradients, attention parameters, token
+    // embedding) read only what the recurrence left (DLG, OUTD, DG, DQ, DSC), so they keep the chip busy while part A's and the event
+    // encoder's small launch-bound products trickle through the caller's stream
+    const bool async_tail = g->phase == 0 && g->async_tail != 0 && tail().ok && !ov && do_pb;
     hipStream_t sm = st;              // the caller's stream
+    auto part_b = [&]() -> int {
+    if (!do_pb) return 0;
     if (async_tail) {
         st = tail().s;
         RC(hop(sm, tail().fork, st));
@@ -1363,7 +1386,12 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     if (async_tail) {
         if (hipEventRecord(tail().done, st) != hipSuccess) { set_error("decoder_bwd: event record failed"); return -5; }
         tail().pending = true;
+        st = sm;
     }
+    return 0;
+    };
+    if (async_tail) { RC(part_b()); RC(part_a()); }
+    else { RC(part_a()); RC(part_b()); }
     return 0;
 }
 

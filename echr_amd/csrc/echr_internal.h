@@ -28,11 +28,13 @@ bool deterministic_gemm();
 
 // persistent (one launch for all timesteps) recurrence of the decoder, csrc/persist.hip
 struct DropCfg;
-struct PersistFwdBufs { float* GATES[3]; float* CS[3]; float *HS, *OUTD, *QS, *WT, *ATT, *PALL, *xws; };
+struct PersistFwdBufs { float* GATES[3]; float* CS[3]; float *HS, *OUTD, *QS, *WT, *ATT, *PALL, *xws; bool prezeroed = false; };
+void persist_fwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, long* count);
 long persist_fwd_ws_floats(int S);
 bool persist_fwd_eligible(const echr_dec_args* a);
 int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
-struct PersistBwdBufs { const float* GATES[3]; const float* CS[3]; const float *QS, *WT, *ATT, *PALL, *DOUT; float* DG[3]; float *DQ, *DSC, *xws; };
+struct PersistBwdBufs { const float* GATES[3]; const float* CS[3]; const float *QS, *WT, *ATT, *PALL, *DOUT; float* DG[3]; float *DQ, *DSC, *xws; bool prezeroed = false; };
+void persist_bwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, long* count);
 long persist_bwd_ws_floats(int S);
 bool persist_bwd_eligible(const echr_dec_args* a);
 int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
@@ -115,7 +117,7 @@ int transpose(const float* in, long ld_in, float* out, long ld_out, int rows, in
 int embed_gather(const float* W, const int* tok, float* out, int rows, int E, int V1, hipStream_t st);
 int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st);
 int logsoftmax_rows(float* X, long ld, int N, int S, int t0, int nt, int cols, hipStream_t st);
-int logsoftmax_bwd(const float* logp, const float* G, const int* target, const float* mask, const float* g_loss,
+int logsoftmax_bwd(const float* logp, const float* G, const void* target, int tgt64, const float* mask, const float* g_loss,
                    const float* mask_sum, float* out, long ldo, int N, int S, int V1, hipStream_t st);
 int sample_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished, long long* seq,
                 float* seq_logp, int* n_unfinished, float temperature, unsigned long long seed, hipStream_t st);

@@ -2321,6 +2321,15 @@ static bool persist_shape_ok(const echr_dec_args* a) {
 
 bool persist_fwd_eligible(const echr_dec_args* a) { return config().persist && persist_shape_ok(a); }
 
+// the part of the exchange workspace the persistent launch needs zeroed (counters, atomically accumulated buffers): callers that run a
+// multi-range fill anyway fold it in (PersistFwdBufs::prezeroed / PersistBwdBufs::prezeroed) instead of paying a memset launch
+void persist_fwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, long* count) {
+    const PersistLayout L = persist_layout(a->S);
+    const PersistLayout2 L2 = persist_layout2(a->S);
+    if (config().persist_split) { *ptr = xws + L2.zero_begin; *count = L2.total - L2.zero_begin + L.xc; }
+    else { *ptr = xws; *count = L.zero_end; }
+}
+
 int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st) {
     PersistHost& h = phost();
     ECHR_REQUIRE(h.ok, "persist_fwd: device state unavailable");
@@ -2356,11 +2365,11 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
         K2.abort_word = h.abort_dev; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = dh; K2.dout = dout;
         K2.spin_limit = K.spin_limit; K2.inject = K.inject;
         // one memset: version 2's zeroed region and, right behind it, version 1's counters (all the LSTM kernel needs of that layout)
-        if (hipMemsetAsync(x2 + L2.zero_begin, 0, (size_t)(L2.total - L2.zero_begin + L.xc) * sizeof(float), st) != hipSuccess) {
+        if (!B.prezeroed && hipMemsetAsync(x2 + L2.zero_begin, 0, (size_t)(L2.total - L2.zero_begin + L.xc) * sizeof(float), st) != hipSuccess) {
             set_error("persist_fwd: memset failed");
             return -5;
         }
-    } else if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_fwd: memset failed"); return -5; }
+    } else if (!B.prezeroed && hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_fwd: memset failed"); return -5; }
     // algorithmic bytes of the forward pair: every recurrent weight and every attention operand row once, plus the per-step activations in
     // (input-side gate pre-activations) and out (c, h of three streams, dropped output, q, attention weights, context)
     const double wbytes = 4.0 * (3.0 * 4 * PH * PH + (double)PH * PH + 4.0 * PH * a->D);
@@ -2402,6 +2411,13 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
 
 bool persist_bwd_eligible(const echr_dec_args* a) { return config().persist_bwd && persist_shape_ok(a); }
 
+void persist_bwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, long* count) {
+    const PersistLayoutB L = persist_layout_b(a->S);
+    const PersistLayoutB2 L2 = persist_layout_b2(a->S);
+    if (config().persist_split) { *ptr = xws + L2.zero_begin; *count = L2.total - L2.zero_begin + L.xdq; }
+    else { *ptr = xws; *count = L.zero_end; }
+}
+
 int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st) {
     PersistHost& h = phost();
     ECHR_REQUIRE(h.ok, "persist_bwd: device state unavailable");
@@ -2431,11 +2447,11 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
     if (split) {
         K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XDQ = x2 + L2.xdq; K2.XDA = x2 + L2.xda; K2.XDH = x2 + L2.xdh; K2.XDG = x2 + L2.xdg;
         // one memset: version 2's zeroed region and, right behind it, version 1's counters (all the LSTM kernel needs of that layout)
-        if (hipMemsetAsync(x2 + L2.zero_begin, 0, (size_t)(L2.total - L2.zero_begin + L.xdq) * sizeof(float), st) != hipSuccess) {
+        if (!B.prezeroed && hipMemsetAsync(x2 + L2.zero_begin, 0, (size_t)(L2.total - L2.zero_begin + L.xdq) * sizeof(float), st) != hipSuccess) {
             set_error("persist_bwd: memset failed");
             return -5;
         }
-    } else if (hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_bwd: memset failed"); return -5; }
+    } else if (!B.prezeroed && hipMemsetAsync(x, 0, (size_t)L.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_bwd: memset failed"); return -5; }
     // algorithmic bytes of the reverse pair: weights and attention operands once, per step the saved activations in (gates, cells, q,
     // weights, context, upstream gradient) and the gradients out (gate gradients of three streams, d q, d score)
     const double wbytes = 4.0 * (3.0 * 4 * PH * PH + (double)PH * PH + 4.0 * PH * a->D);

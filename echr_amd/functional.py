@@ -91,11 +91,16 @@ class GradSink(object):
             self.arena.flush_deferred_clamp()
         return ok
 
-    def take(self):
+    def take(self, defer_zero=False):
+        """Fresh arena views of the group's gradients over a zero-filled span.  defer_zero: the caller zero-fills the span itself (the
+        decoder backward folds it into its own multi-range fill launch) -- returns (views, span tensor)."""
         lo, hi = self.arena.span(self.slots)
-        self.arena.flat_g[lo:hi].zero_()
+        span = self.arena.flat_g[lo:hi]
+        if not defer_zero:
+            span.zero_()
         self.arena.note_zeroed(lo, hi)
-        return [self.arena.grad_view(s) for s in self.slots]
+        views = [self.arena.grad_view(s) for s in self.slots]
+        return (views, span) if defer_zero else views
 
     def has_hooks(self):
         """True when a parameter of the group carries tensor hooks (DDP / FSDP style post-accumulate hooks, register_hook): they read the
@@ -275,8 +280,9 @@ class DecoderFunction(torch.autograd.Function):
         if g_logp is not None:
             g_logp = _f32c(g_logp)
         zeroed = 1 if (ctx.sink is not None and ctx.sink.usable()) else 0
+        zero_span = None
         if zeroed:
-            grads = ctx.sink.take()
+            grads, zero_span = ctx.sink.take(defer_zero=True)      # zero-filled inside echr_decoder_bwd's first stage (one fill launch less)
         else:
             red = getattr(ctx.sink.arena, 'early_reducer', None) if ctx.sink is not None else None
             if red is not None:
@@ -291,8 +297,10 @@ class DecoderFunction(torch.autograd.Function):
         g = L.DecGrads(gp[0], gp[1], gp[2], (L.c_f * 3)(*gp[3:6]), (L.c_f * 3)(*gp[6:9]), (L.c_f * 3)(*gp[9:12]),
                        (L.c_f * 3)(*gp[12:15]), gp[15], gp[16], gp[17], gp[18], gp[19], gp[20],
                        L.ptr(g_event), L.ptr(g_video), L.ptr(g_logp) if g_logp is not None else None,
-                       L.ptr(fused[0], torch.int32) if fused else None, L.ptr(fused[1]) if fused else None, L.ptr(fused[3]) if fused else None,
-                       L.ptr(wsb), zeroed, 0, 0, L.ptr(fused[2][1:2]) if fused else None)
+                       L.ptr(fused[0], fused[0].dtype) if fused else None, L.ptr(fused[1]) if fused else None, L.ptr(fused[3]) if fused else None,
+                       L.ptr(wsb), zeroed, 0, 0, L.ptr(fused[2][1:2]) if fused else None,
+                       L.ptr(zero_span) if zero_span is not None else None, zero_span.numel() if zero_span is not None else 0,
+                       1 if (fused and fused[0].dtype == torch.int64) else 0)
         d = drop.c()
         hook = getattr(ctx.sink.arena, 'early_grad_hook', None) if zeroed else None
         if hook is not None:
@@ -406,6 +414,17 @@ def tsrm_attention(roi_feat, position_embedding, n_head, params, d_o, drop=None)
 
 
 # --------------------------------------------------------------------------------------------------
+_ZERO_PLACEHOLDER = {}
+
+
+def _nll_target(target, S):
+    """Targets for the criterion kernels: int64 (the reference's LongTensor labels) and int32 are both read in place."""
+    t = target[:, :S]
+    if t.dtype not in (torch.int64, torch.int32):
+        t = t.to(torch.int64)
+    return t.contiguous()
+
+
 class MaskedNLL(torch.autograd.Function):
     """LanguageModelCriterion.forward (misc/utils.py:66-75) on device."""
 
@@ -415,18 +434,17 @@ class MaskedNLL(torch.autograd.Function):
         ctx.node = node
         N, S, V1 = logp.shape
         logp = logp.contiguous()
-        tgt = target[:, :S].to(torch.int32).contiguous()
+        tgt = _nll_target(target, S)
         msk = mask[:, :S].to(torch.float32).contiguous()
         out = torch.empty(2, device=logp.device, dtype=torch.float32)
-        L.check(lib.echr_nll_loss_fwd(L.ptr(logp), L.ptr(tgt, torch.int32), L.ptr(msk), L.ptr(out), N, S, V1, L.stream_ptr()),
-                'nll_loss_fwd')
+        fn = lib.echr_nll_loss_fwd_i64 if tgt.dtype == torch.int64 else lib.echr_nll_loss_fwd
+        L.check(fn(L.ptr(logp), L.ptr(tgt, tgt.dtype), L.ptr(msk), L.ptr(out), N, S, V1, L.stream_ptr()), 'nll_loss_fwd')
         ctx.save_for_backward(tgt, msk, out)
         ctx.shape = (N, S, V1)
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
-        lib = L.load()
         tgt, msk, out = ctx.saved_tensors
         N, S, V1 = ctx.shape
         if ctx.node is not None:
@@ -434,7 +452,10 @@ class MaskedNLL(torch.autograd.Function):
             # upstream scalar) and hand autograd a stride-0 all-zero placeholder.  DecoderFunction.backward takes the fused path when the
             # placeholder arrives untouched, and adds the dense form when other consumers of the log-probs contributed gradients too.
             ctx.node.__dict__.setdefault('_echr_pending_nll', []).append((tgt, msk, out, _f32c(g).reshape(1)))
-            ph = torch.zeros((), device=msk.device, dtype=torch.float32).expand(N, S, V1)
+            z = _ZERO_PLACEHOLDER.get(msk.device)
+            if z is None:                         # one zero scalar per device, filled once (never written: only ever expanded)
+                z = _ZERO_PLACEHOLDER[msk.device] = torch.zeros((), device=msk.device, dtype=torch.float32)
+            ph = z.expand(N, S, V1)
             ph._echr_nll_placeholder = True
             return ph, None, None, None
         return MaskedNLL.dense_grad(tgt, msk, out, g, N, S, V1), None, None, None
@@ -443,8 +464,9 @@ class MaskedNLL(torch.autograd.Function):
     def dense_grad(tgt, msk, out, g, N, S, V1):
         lib = L.load()
         g_logp = torch.empty(N, S, V1, device=msk.device, dtype=torch.float32)
-        L.check(lib.echr_nll_loss_bwd(L.ptr(tgt, torch.int32), L.ptr(msk), L.ptr(out), L.ptr(_f32c(g).reshape(1)), L.ptr(g_logp), N, S, V1,
-                                      L.stream_ptr()), 'nll_loss_bwd')
+        fn = lib.echr_nll_loss_bwd_i64 if tgt.dtype == torch.int64 else lib.echr_nll_loss_bwd
+        L.check(fn(L.ptr(tgt, tgt.dtype), L.ptr(msk), L.ptr(out), L.ptr(_f32c(g).reshape(1)), L.ptr(g_logp), N, S, V1,
+                   L.stream_ptr()), 'nll_loss_bwd')
         return g_logp
 
 

@@ -221,6 +221,12 @@ typedef struct {
                                                   stream joins first as a safety net). */
     const float* nll_msum;                     /* fused criterion path, optional: device pointer to sum(nll_mask) (the second output of
                                                   echr_nll_loss_fwd); NULL = the library sums the mask itself */
+    float* zero_extra;                         /* optional: a range the caller wants zero-filled before any gradient is written (its gradient
+                                                  arena span when `zeroed` = 1): folded into the backward's own multi-range fill launch
+                                                  (stage 1) instead of a separate fill; NULL = none */
+    int64_t zero_extra_count;                  /* floats */
+    int32_t nll_target_i64;                    /* 1: nll_target points at int64 indices (the reference's LongTensor labels as they are: no
+                                                  conversion pass), 0: int32 */
 } echr_dec_grads;
 
 /* make `stream` wait for an asynchronous decoder-backward tail (echr_dec_grads.async_tail); no-op when none is pending */
@@ -247,11 +253,16 @@ int echr_decoder_step(const echr_dec_args* a, const float* h_in, const float* c_
 /* masked NLL of LanguageModelCriterion on log-probs [N,S,V1]: loss (device scalar) */
 int echr_nll_loss_fwd(const float* logp, const int32_t* target, const float* mask, float* loss, int32_t N, int32_t S,
                       int32_t V1, void* stream);
+/* the same on int64 targets (torch.LongTensor labels as train.py:298-303 passes them) */
+int echr_nll_loss_fwd_i64(const float* logp, const int64_t* target, const float* mask, float* loss, int32_t N, int32_t S,
+                          int32_t V1, void* stream);
 
 /* backward of echr_nll_loss_fwd in one pass: g_logp [N,S,V1] (fully written); fwd_out = the 2-float output of the forward
  * (loss, sum(mask)), g_loss = upstream scalar gradient (device) */
 int echr_nll_loss_bwd(const int32_t* target, const float* mask, const float* fwd_out, const float* g_loss, float* g_logp,
                       int32_t N, int32_t S, int32_t V1, void* stream);
+int echr_nll_loss_bwd_i64(const int64_t* target, const float* mask, const float* fwd_out, const float* g_loss, float* g_logp,
+                          int32_t N, int32_t S, int32_t V1, void* stream);
 
 /* sampler (greedy or multinomial): runs seq_len+1 decoder steps on device without host syncs.
  * seq [N,seq_len] int64 (zero after a row finished), seq_logp [N,seq_len] fp32,
