@@ -44,7 +44,8 @@ constexpr int SHARDS = 8, SHSTRIDE = 32;                 // one 128-byte line pe
 constexpr int CNT_LINE = SHARDS * SHSTRIDE;              // u32 per counter
 enum { C_H1 = 0, C_Q = 1, C_C = 2, C_H0 = 3, C_H2 = 4, C_KINDS = 5 };
 constexpr u32 SPIN_LIMIT = 4000000;                      // ~ seconds
-constexpr int WU_LD = 132;
+constexpr int WU_LD = 264;                               // unnormalised attention weights per event: up to 2 x 129 slots (second slot set, below)
+constexpr int PSET2 = 3 * PSL;                           // first slot of an event's SECOND slot set (events longer than 129 segments)
 constexpr int LDS_W = 128 * 1024, LDS_WA = 64 * 1024, LDS_RED = 16 * 1024, LDS_RED_ATT = 32 * 1024 + 2048 + 2048 + 256;
 constexpr int LDS_BYTES_LSTM = LDS_W + LDS_RED + 256, LDS_BYTES_ATT = LDS_WA + LDS_RED_ATT + 256;
 constexpr float ALPHA_SAFE = 40.f;
@@ -812,7 +813,11 @@ struct PersistK2 {
     DropCfg dh, dout;
 };
 
-template <bool H2>
+// BIG: events of up to 258 segments (BASELINE config 5's 256-segment proposals).  An event's first 129 slots live in registers as before;
+// slots [129, 258) form a SECOND set of 43 per workgroup whose P_all / C3D rows are re-read from L2 every step (a 256-row video's operands are
+// 1 MB: L2-resident), scored with the same q and folded into the same split softmax.  Events of <= 129 segments skip it, and the BIG = false
+// instantiation (what shapes with A <= 129 launch) is the previous code unchanged.
+template <bool H2, bool BIG>
 __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const int bid) {
     if (P.stamps && bid == 0 && threadIdx.x == 0) P.stamps[15] = __builtin_amdgcn_s_memrealtime();          // kernel entry (diagnostic)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -840,6 +845,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
     const bool att_live = an < N;
     const int grow_ = 4 * w + (lane >> 4), lr = lane & 15;
     int alen = 0;
+    long row0 = 0;
     float4 Pr[PSG][8], Cr[PSG][8];
     bool use_max = false;
     {
@@ -853,7 +859,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
     }
     if (att_live) {
         alen = P.ev_len[an];
-        const long row0 = P.ev_start[an];
+        row0 = P.ev_start[an];
 #pragma unroll
         for (int i = 0; i < PSG; ++i) {
             const int sl = grow_ + 16 * i;
@@ -907,10 +913,25 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
         for (int i = 0; i < PSG; ++i)
 #pragma unroll
             for (int h = 0; h < 8; ++h) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(Cr[i][h].x), fabsf(Cr[i][h].y))), fmaxf(fabsf(Cr[i][h].z), fabsf(Cr[i][h].w)));
+        if (BIG && alen > PSET2) {          // the second slot set's rows bound the context too
+#pragma unroll
+            for (int i = 0; i < PSG; ++i) {
+                const int sl = grow_ + 16 * i;
+                const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
+                const float* cr = P.c3d + (row0 + a) * D;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const int d = 32 * lr + 4 * h;
+                    const float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
+                    if (d < D) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+            }
+        }
         mx = wave_max(mx);
         if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(P.XCMAX) + an, __float_as_uint(mx));
     }
     __syncthreads();
+    const bool has2 = BIG && att_live && alen > PSET2;           // uniform over the workgroup
 
     const int gr = tid >> 3, gu = tid & 7, gn = HR * m + gr;      // gate-math ownership: thread (row gr of the half, unit gu)
     float c1 = 0.f;
@@ -1024,9 +1045,34 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                     const bool valid = sl < PSL && PSL * ap + sl < alen;
                     e[i] = valid ? v : -INFINITY;
                 }
+                // second slot set (BIG, events longer than 129 segments): same scores from P_all rows fetched now (L2-resident)
+                float e2[PSG] = {-INFINITY, -INFINITY, -INFINITY};
+                if (has2) {
+#pragma unroll
+                    for (int i = 0; i < PSG; ++i) {
+                        const int sl = grow_ + 16 * i;
+                        const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
+                        const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
+                        float4 pv[8];
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) pv[h] = *reinterpret_cast<const float4*>(pr + 4 * h);
+                        float v = 0.f;
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) {
+                            const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
+                            const float4 ep = make_float4(__expf(2.f * fminf(fmaxf(pv[h].x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv[h].y, -43.f), 43.f)),
+                                                          __expf(2.f * fminf(fmaxf(pv[h].z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv[h].w, -43.f), 43.f)));
+                            v += a4.x * __builtin_amdgcn_rcpf(fmaf(ep.x, q[h].x, 1.f)) + a4.y * __builtin_amdgcn_rcpf(fmaf(ep.y, q[h].y, 1.f)) +
+                                 a4.z * __builtin_amdgcn_rcpf(fmaf(ep.z, q[h].z, 1.f)) + a4.w * __builtin_amdgcn_rcpf(fmaf(ep.w, q[h].w, 1.f));
+                        }
+                        v = row16_sum(fmaf(-2.f, v, asum));
+                        const bool valid = sl < PSL && PSET2 + PSL * ap + sl < alen;
+                        e2[i] = valid ? v : -INFINITY;
+                    }
+                }
                 float shift = 0.f;
                 if (use_max) {       // exact max-shifted softmax: the event's three workgroups exchange their local maxima (8-byte granules)
-                    const float mloc = fmaxf(e[0], fmaxf(e[1], e[2]));
+                    const float mloc = fmaxf(fmaxf(e[0], fmaxf(e[1], e[2])), fmaxf(e2[0], fmaxf(e2[1], e2[2])));
                     if (lr == 0) sx[16 + grow_] = mloc;
                     __syncthreads();
                     unsigned long long* gr_ = P.GRAN + ((long)t * PROWS + an) * 3;
@@ -1074,11 +1120,37 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                         cx[h].x += x * Cr[i][h].x; cx[h].y += x * Cr[i][h].y; cx[h].z += x * Cr[i][h].z; cx[h].w += x * Cr[i][h].w;
                     }
                 }
+                if (has2) {
+#pragma unroll
+                    for (int i = 0; i < PSG; ++i) {
+                        const float x = __expf(e2[i] - shift);
+                        e2[i] = x;
+                        ssum += x;
+                        const int sl = grow_ + 16 * i;
+                        const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
+                        const float* cr = P.c3d + (row0 + a) * D;
+                        float4 cv[8];
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) {
+                            const int d = 32 * lr + 4 * h;
+                            cv[h] = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
+                            if (d >= D) cv[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) { cx[h].x += x * cv[h].x; cx[h].y += x * cv[h].y; cx[h].z += x * cv[h].z; cx[h].w += x * cv[h].w; }
+                    }
+                }
                 if (lr == 0) sx[grow_] = ssum;
                 {
                     const float xw = lr == 0 ? e[0] : (lr == 1 ? e[1] : e[2]);
                     const int sl = grow_ + 16 * lr;
                     if (lr < PSG && sl < PSL && PSL * ap + sl < alen) st4_sc1(P.WU + ((long)t * PROWS + an) * WU_LD + PSL * ap + sl, xw);
+                    if (has2) {          // lanes 3..5 of the DPP row store the second set's unnormalised weights
+                        const float xw2 = lr == 3 ? e2[0] : (lr == 4 ? e2[1] : e2[2]);
+                        const int sl2 = grow_ + 16 * (lr - 3);
+                        if (lr >= 3 && lr < 3 + PSG && sl2 < PSL && PSET2 + PSL * ap + sl2 < alen)
+                            st4_sc1(P.WU + ((long)t * PROWS + an) * WU_LD + PSET2 + PSL * ap + sl2, xw2);
+                    }
                 }
                 // cross-row sum of the context partials through 16 KB of LDS: DPP rows 0-7, then rows 8-15 (LDS float atomics into one
                 // vector were tried: 4-way same-address ds_add_f32 made this phase 3x slower)
@@ -1238,9 +1310,10 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                 P.HS[(long)(t + 1) * N * 3 * PH + o] = co.h;
                 P.OUTD[(long)t * N * 3 * PH + o] = co.hd;
             }
-            {   // normalised attention weights: rows of event lb / 2 of this half, slots [65 (lb & 1), +65)
-                const int n = HR * m + (lb >> 1), a0 = 65 * (lb & 1) + tid;
-                if (tid < 65 && n < N && a0 < P.A) {
+            {   // normalised attention weights: rows of event lb / 2 of this half, slots [65 (lb & 1), +65) -- BIG: [130 (lb & 1), +130)
+                constexpr int WSPAN = BIG ? 130 : 65;
+                const int n = HR * m + (lb >> 1), a0 = WSPAN * (lb & 1) + tid;
+                if (tid < WSPAN && n < N && a0 < P.A) {
                     const int len = P.ev_len[n];
                     float wv = 0.f;
                     if (a0 < len) wv = ld4_sc1(P.WU + ((long)t * PROWS + n) * WU_LD + a0) / ld4_sc1(P.XS + (long)t * PROWS + n);
@@ -1251,7 +1324,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
     }
 }
 template <bool H2>
-__global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) { dec_persist_att2_body<H2>(P, blockIdx.x); }
+__global__ __launch_bounds__(256, 1) void dec_persist_att2_kernel(PersistK2 P) { dec_persist_att2_body<H2, false>(P, blockIdx.x); }
 
 // ==========================================================================================================================
 // fp16-PAIR ("h2") products inside the persistent forward kernels.  The recurrent activations are bounded (|h| <= dropout scale), so
@@ -1392,9 +1465,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_lstm_h2_kernel(PersistK P)
 // Two concurrent launches on two HIP streams need two hardware queues; a process that owns more streams than the runtime has queues
 // (collective streams of a data-parallel run, user streams) can find both streams on one queue, and the pair then runs back to back.
 // One grid of 256 workgroups has no such dependence.
-template <bool H2>
+template <bool H2, bool BIG>
 __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(PersistK2 P2, PersistK P1) {
-    if (blockIdx.x < 2 * HWG) dec_persist_att2_body<H2>(P2, blockIdx.x);
+    if (blockIdx.x < 2 * HWG) dec_persist_att2_body<H2, BIG>(P2, blockIdx.x);
     else if (H2) dec_persist_lstm_h2_body(P1, blockIdx.x - 2 * HWG);
     else dec_persist_lstm_body(P1, blockIdx.x - 2 * HWG);
 }
@@ -1960,6 +2033,7 @@ __device__ __forceinline__ void fill_bimg32_t(float4* img, const float* W, long 
     }
 }
 
+template <bool BIG>          // BIG: events of up to 258 segments, second slot set re-read from L2 every step (see dec_persist_att2_body)
 __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, const int bid) {
     if (P.stamps && bid == 0 && threadIdx.x == 0) P.stamps[15] = __builtin_amdgcn_s_memrealtime();          // kernel entry (diagnostic)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1985,11 +2059,12 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
     const bool att_live = an < N;
     const int grow_ = 4 * w + (lane >> 4), lr = lane & 15;
     int alen = 0;
+    long row0 = 0;
     float4 Pr[PSG][8], Cr[PSG][8];
     for (int j = tid; j < PH; j += 256) sal[j] = P.w_alpha[j];
     if (att_live) {
         alen = P.ev_len[an];
-        const long row0 = P.ev_start[an];
+        row0 = P.ev_start[an];
 #pragma unroll
         for (int i = 0; i < PSG; ++i) {
             const int sl = grow_ + 16 * i;
@@ -2014,6 +2089,7 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
             for (int h = 0; h < 8; ++h) Pr[i][h] = Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    const bool has2 = BIG && att_live && alen > PSET2;           // uniform over the workgroup
 
     const int gr = tid >> 3, u4 = 4 * (tid & 7), gn = HR * m + gr, u0 = 32 * lb + u4;      // gate-gradient ownership (GD): row, 4 units
     float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2111,7 +2187,7 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
         // ============ attention backward of step t (all workgroups) ============
         {
             float4 q[8];
-            float wt[PSG];
+            float wt[PSG], wt2[PSG] = {0.f, 0.f, 0.f};
             if (att_live) {
                 const float* qp = P.QS + ((long)t * N + an) * PH + 32 * lr;
 #pragma unroll
@@ -2121,6 +2197,10 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
                     const int sl = grow_ + 16 * i;
                     const bool valid = sl < PSL && PSL * ap + sl < alen;
                     wt[i] = valid ? P.WT[((long)t * N + an) * P.A + PSL * ap + sl] : 0.f;
+                    if (has2) {
+                        const bool valid2 = sl < PSL && PSET2 + PSL * ap + sl < alen;
+                        wt2[i] = valid2 ? P.WT[((long)t * N + an) * P.A + PSET2 + PSL * ap + sl] : 0.f;
+                    }
                 }
                 for (int d = tid; d < PH; d += 256) sat[d] = d < D ? P.ATT[((long)t * N + an) * D + d] : 0.f;
             }
@@ -2152,12 +2232,61 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
                     const int sl = grow_ + 16 * lr;
                     if (lr < PSG && sl < PSL && PSL * ap + sl < alen) P.DSC[((long)t * N + an) * P.A + PSL * ap + sl] = xw;
                 }
+                // second slot set: d score from C3D rows fetched now, then its share of d q from the P_all rows (one slot's rows in flight at a time)
+                float4 s2[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h) s2[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (has2) {
+                    float dsc2[PSG];
+#pragma unroll
+                    for (int i = 0; i < PSG; ++i) {
+                        const int sl = grow_ + 16 * i;
+                        const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
+                        const float* cr = P.c3d + (row0 + a) * D;
+                        float4 cv[8];
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) {
+                            const int d = 32 * lr + 4 * h;
+                            cv[h] = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
+                            if (d >= D) cv[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                        float dw = 0.f;
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) dw += cv[h].x * da[h].x + cv[h].y * da[h].y + cv[h].z * da[h].z + cv[h].w * da[h].w;
+                        dw = row16_sum(dw);
+                        dsc2[i] = wt2[i] * (dw - s0);
+                    }
+                    {
+                        const float xw2 = lr == 3 ? dsc2[0] : (lr == 4 ? dsc2[1] : dsc2[2]);
+                        const int sl2 = grow_ + 16 * (lr - 3);
+                        if (lr >= 3 && lr < 3 + PSG && sl2 < PSL && PSET2 + PSL * ap + sl2 < alen) P.DSC[((long)t * N + an) * P.A + PSET2 + PSL * ap + sl2] = xw2;
+                    }
+#pragma unroll
+                    for (int i = 0; i < PSG; ++i) {
+                        const int sl = grow_ + 16 * i;
+                        const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
+                        const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
+                        float4 pv[8];
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) pv[h] = *reinterpret_cast<const float4*>(pr + 4 * h);
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) {
+                            const float4 eq = make_float4(__expf(2.f * fminf(fmaxf(q[h].x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].y, -43.f), 43.f)),
+                                                          __expf(2.f * fminf(fmaxf(q[h].z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].w, -43.f), 43.f)));
+                            float r;
+                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv[h].x, -43.f), 43.f)), eq.x, 1.f)); s2[h].x += dsc2[i] * (r - r * r);
+                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv[h].y, -43.f), 43.f)), eq.y, 1.f)); s2[h].y += dsc2[i] * (r - r * r);
+                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv[h].z, -43.f), 43.f)), eq.z, 1.f)); s2[h].z += dsc2[i] * (r - r * r);
+                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv[h].w, -43.f), 43.f)), eq.w, 1.f)); s2[h].w += dsc2[i] * (r - r * r);
+                        }
+                    }
+                }
                 // d q partial of this DPP row (in place of q), then summed over the 16 rows through 16 KB of LDS: rows 0-7, then rows 8-15
 #pragma unroll
                 for (int h = 0; h < 8; ++h) {
                     const float4 eq = make_float4(__expf(2.f * fminf(fmaxf(q[h].x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].y, -43.f), 43.f)),
                                                   __expf(2.f * fminf(fmaxf(q[h].z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].w, -43.f), 43.f)));
-                    float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 sacc = BIG ? s2[h] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int i = 0; i < PSG; ++i) {
                         float r;
@@ -2204,11 +2333,12 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
         }
     }
 }
-__global__ __launch_bounds__(256, 1) void dec_persist_att_bwd2_kernel(PersistB P) { dec_persist_att_bwd2_body(P, blockIdx.x); }
+__global__ __launch_bounds__(256, 1) void dec_persist_att_bwd2_kernel(PersistB P) { dec_persist_att_bwd2_body<false>(P, blockIdx.x); }
 
 // ---- the reverse pair as one launch (see dec_persist_fwd_kernel) ----
+template <bool BIG>
 __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(PersistB P2, PersistB P1) {
-    if (blockIdx.x < 2 * HWG) dec_persist_att_bwd2_body(P2, blockIdx.x);
+    if (blockIdx.x < 2 * HWG) dec_persist_att_bwd2_body<BIG>(P2, blockIdx.x);
     else if (P1.lstm_kgroups) dec_persist_lstm_bwd_kg_body(P1, blockIdx.x - 2 * HWG);
     else dec_persist_lstm_bwd_body(P1, blockIdx.x - 2 * HWG);
 }
@@ -2235,9 +2365,12 @@ static PersistHost& phost() {
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATTB2) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_att_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_ATT) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_lstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_LSTM) == hipSuccess;
-        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
-        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
-        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_BWD) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_BWD) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_BWD) == hipSuccess;
         (void)hipGetLastError();
         h.ok = good;
     }
@@ -2315,7 +2448,9 @@ unsigned long long* persist_stamp_buffer(int S, hipStream_t st) {
 
 static bool persist_shape_ok(const echr_dec_args* a) {
     PersistHost& h = phost();
-    return h.ok && h.cus >= NWG && a->N <= PROWS && a->A <= 3 * PSL && a->H == PH && a->Ha == PH && a->D <= PH && a->D % 4 == 0 && a->D >= 8 &&
+    // A <= 129: every form; 129 < A <= 258: the one-launch pairs of two half-chip machines only (their BIG instantiations: second slot set)
+    const bool a_ok = a->A <= PSET2 || (a->A <= 2 * PSET2 && config().persist_split && config().persist_merge);
+    return h.ok && h.cus >= NWG && a->N <= PROWS && a_ok && a->H == PH && a->Ha == PH && a->D <= PH && a->D % 4 == 0 && a->D >= 8 &&
            a->S >= 1;
 }
 
@@ -2376,21 +2511,26 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     const double obytes = 4.0 * (double)a->N * a->A * (PH + a->D);
     const double sbytes = 4.0 * (double)a->S * a->N * (3.0 * 4 * PH + 3.0 * 2 * PH + PH + PH + a->A + a->D);
     ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH), wbytes + obytes + sbytes, st);
+    const bool big = a->A > PSET2;          // events longer than 129 segments: BIG instantiation (persist_shape_ok admitted it for this form only)
     if (split && config().persist_merge) {
         // one launch of 192 + 64 workgroups (no dependence on two hardware queues being free)
         if (config().persist_coop) {
             // cooperative launch: the dispatch starts only when all 256 workgroups can be resident together, whatever else holds CUs
             // (collective kernels, another process' grid) -- the hand-off spins then never wait for a workgroup that has no CU
             void* kargs[2] = {&K2, &K};
-            const void* fn = config().persist_h2 ? reinterpret_cast<const void*>(dec_persist_fwd_kernel<true>) : reinterpret_cast<const void*>(dec_persist_fwd_kernel<false>);
+            const void* fn = big ? (config().persist_h2 ? reinterpret_cast<const void*>(dec_persist_fwd_kernel<true, true>) : reinterpret_cast<const void*>(dec_persist_fwd_kernel<false, true>))
+                                 : (config().persist_h2 ? reinterpret_cast<const void*>(dec_persist_fwd_kernel<true, false>) : reinterpret_cast<const void*>(dec_persist_fwd_kernel<false, false>));
             if (hipLaunchCooperativeKernel(fn, dim3(2 * HWG + 2 * NS), dim3(256), kargs, LDS_BYTES_FWD, st) != hipSuccess) {
                 set_error("persist_fwd: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
                 return -5;
             }
             return 0;
         }
-        if (config().persist_h2) hipLaunchKernelGGL(dec_persist_fwd_kernel<true>, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
-        else hipLaunchKernelGGL(dec_persist_fwd_kernel<false>, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
+        if (big) {
+            if (config().persist_h2) hipLaunchKernelGGL((dec_persist_fwd_kernel<true, true>), dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
+            else hipLaunchKernelGGL((dec_persist_fwd_kernel<false, true>), dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
+        } else if (config().persist_h2) hipLaunchKernelGGL((dec_persist_fwd_kernel<true, false>), dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
+        else hipLaunchKernelGGL((dec_persist_fwd_kernel<false, false>), dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
         return check_launch("dec_persist_fwd");
     }
     // two launches: the two plain LSTM streams recur on a second HIP stream, concurrently with the attention chain (192 + 64 workgroups = 256 CUs;
@@ -2461,13 +2601,15 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
     if (split && config().persist_merge) {
         if (config().persist_coop) {
             void* kargs[2] = {&K2, &K};
-            if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(dec_persist_bwd_kernel), dim3(2 * HWG + 2 * NS), dim3(256), kargs, LDS_BYTES_BWD, st) != hipSuccess) {
+            const void* fn = a->A > PSET2 ? reinterpret_cast<const void*>(dec_persist_bwd_kernel<true>) : reinterpret_cast<const void*>(dec_persist_bwd_kernel<false>);
+            if (hipLaunchCooperativeKernel(fn, dim3(2 * HWG + 2 * NS), dim3(256), kargs, LDS_BYTES_BWD, st) != hipSuccess) {
                 set_error("persist_bwd: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
                 return -5;
             }
             return 0;
         }
-        hipLaunchKernelGGL(dec_persist_bwd_kernel, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_BWD, st, K2, K);
+        if (a->A > PSET2) hipLaunchKernelGGL(dec_persist_bwd_kernel<true>, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_BWD, st, K2, K);
+        else hipLaunchKernelGGL(dec_persist_bwd_kernel<false>, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_BWD, st, K2, K);
         return check_launch("dec_persist_bwd");
     }
     ECHR_REQUIRE(side_stream(h), "persist_bwd: second stream unavailable");

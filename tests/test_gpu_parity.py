@@ -1194,7 +1194,10 @@ def test_fused_criterion_gradient_equals_dense_path(extra_consumer):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('N,A,L,min_len,video_dim', [(1, 1, 3, 1, 500), (31, 43, 4, 1, 500), (33, 44, 6, 2, 500), (64, 129, 5, 100, 500),
-                                                      (32, 5, 9, 1, 512), (17, 87, 3, 50, 8), (64, 2, 21, 1, 500)])
+                                                      (32, 5, 9, 1, 512), (17, 87, 3, 50, 8), (64, 2, 21, 1, 500),
+                                                      # events longer than 129 segments: the second slot set of the BIG instantiations
+                                                      (64, 258, 5, 1, 500), (33, 130, 4, 120, 500), (20, 200, 6, 4, 500), (64, 256, 21, 4, 500),
+                                                      (7, 173, 3, 172, 8)])
 def test_persistent_recurrence_edge_shapes(N, A, L, min_len, video_dim):
     """The persistent recurrences at the edges of their eligibility (csrc/persist.hip: N <= 64 events split 32 + 32 over two half-chip
     machines, A <= 129 slots split 43 + 43 + 43 over three workgroups, D <= 512, any S): one event, a half machine with a single row, slot
