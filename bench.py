@@ -225,11 +225,11 @@ def gpu_leg(args, rank, world, local_rank):
 
         def mfma_busy(name):
             if name == 'dec_persist_kernels':           # time-weighted over the four kernels of the two pairs
-                ks = [v for k, v in mfma_pmc.items() if k.startswith('dec_persist') and v.get('mfma_busy_frac') is not None]
+                ks = [v for k, v in mfma_pmc.items() if k.startswith('dec_persist') and isinstance(v, dict) and v.get('mfma_busy_frac') is not None]
                 tot = sum(v['avg_us'] * v['launches'] for v in ks)
                 return round(sum(v['mfma_busy_frac'] * v['avg_us'] * v['launches'] for v in ks) / tot, 4) if tot else None
             v = mfma_pmc.get(name)
-            return v.get('mfma_busy_frac') if v else None
+            return v.get('mfma_busy_frac') if isinstance(v, dict) else None
 
         # HIP-event pairs around a short launch add a fixed cost per launch (the second record waits for the first to retire):
         # measured here on an idle stream and subtracted, so that avg_launch_us agrees with rocprofv3's kernel durations
@@ -253,6 +253,7 @@ def gpu_leg(args, rank, world, local_rank):
             else:
                 ach, peak, unit = st['bytes'] / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
             tr = traffic.get(name) or next((v for k, v in traffic.items() if k.startswith(name + '<')), None)
+            tr = tr if isinstance(tr, dict) else None
             tb = (tr or {}).get('hbm_bytes_per_launch')
             alg = st['bytes'] / st['launches'] if st['bytes'] > 0 else None
             return dict(bound='mfma' if st['bound'] == 'valu' else st['bound'], kernel=st['sym'], achieved=round(ach, 2), peak=peak, unit=unit,

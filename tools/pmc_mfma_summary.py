@@ -12,7 +12,7 @@ d = sys.argv[1]
 
 
 def name(k):
-    k = k.split('(')[0].replace('void ', '').replace('echr::', '')
+    k = k.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('echr::', '')
     k = k.split('<')[0] if k.startswith(('gemm_f32_kernel', 'gemm_h2_kernel', 'gemm_h2m16_kernel', 'dec_persist')) else k
     return 'gemm_h2_kernel' if k == 'gemm_h2m16_kernel' else k          # the two MFMA shapes of the h2 product: one class in bench.py
 
@@ -53,4 +53,5 @@ for k in sorted(busy, key=lambda k: -busy[k].get('SQ_VALU_MFMA_BUSY_CYCLES', 0))
                  mfma_insts_per_launch=round(m.get('SQ_INSTS_MFMA', 0) / max(nm[k], 1)),
                  valu_insts_per_launch=round(m.get('SQ_INSTS_VALU', 0) / max(nm[k], 1)))
     out[k] = e
+out['_commit'] = sys.argv[2] if len(sys.argv) > 2 else None
 print(json.dumps(out, indent=1))

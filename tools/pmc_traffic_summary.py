@@ -16,7 +16,7 @@ def load(sub, counter):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != counter:
             continue
-        k = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('echr::', '')
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('echr::', '')
         k = k.split('<')[0] if k.startswith(('gemm_f32_kernel', 'gemm_h2_kernel', 'gemm_h2m16_kernel', 'dec_persist', 'att_post_kernel')) else k
         k = 'gemm_h2_kernel' if k == 'gemm_h2m16_kernel' else k          # the two MFMA shapes of the h2 product: one class in bench.py
         agg[k] += float(r['Counter_Value'])
@@ -28,7 +28,7 @@ fe, nf = load('fetch', 'FETCH_SIZE')
 wr, nw = load('write', 'WRITE_SIZE')
 out = {}
 for k in sorted(fe, key=lambda k: -fe[k]):
-    if not (k.startswith(('gemm', 'rec_gemm', 'att_', 'lstm', 'clamp_adam', 'h2_pack', 'dec_persist'))):
+    if not (k.startswith(('gemm', 'rec_gemm', 'att_', 'lstm', 'clamp_adam', 'h2_pack', 'dec_persist', 'sst_persist'))):
         continue
     out[k] = dict(launches=nf[k], fetch_bytes_per_launch=round(2 * 1024 * fe[k] / nf[k]), write_bytes_per_launch=round(1024 * wr.get(k, 0) / max(nw.get(k, 1), 1)))
     out[k]['hbm_bytes_per_launch'] = out[k]['fetch_bytes_per_launch'] + out[k]['write_bytes_per_launch']
@@ -40,4 +40,5 @@ if pk:
                                       fetch_bytes_per_launch=round(sum(out[k]['fetch_bytes_per_launch'] * out[k]['launches'] for k in pk) / (2 * pairs)),
                                       write_bytes_per_launch=round(sum(out[k]['write_bytes_per_launch'] * out[k]['launches'] for k in pk) / (2 * pairs)))
     out['dec_persist_kernels']['hbm_bytes_per_launch'] = out['dec_persist_kernels']['fetch_bytes_per_launch'] + out['dec_persist_kernels']['write_bytes_per_launch']
+out['_commit'] = sys.argv[2] if len(sys.argv) > 2 else None          # the tree these counters were collected from
 print(json.dumps(out, indent=1))

@@ -1,0 +1,26 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): bash tools/round_profiles.sh <round tag, e.g. r03> <commit hash>
+# Regenerates everything under profiles/ that bench.py's roofline leg and DESIGN.md cite, FROM THE TREE THAT IS RUNNING:
+#   <tag>_pmc_traffic.json / <tag>_pmc_mfma.json (separate --pmc passes, commit hash stored inside), <tag>_rocprof_kernel_stats_final.txt
+#   (rocprofv3 --kernel-trace --stats of the bench command), <tag>_bench_final.json (the bench line, written AFTER the PMC files so that
+#   it carries their traffic numbers), and the same pair for --c5.  Results land in gpurun_out/<tag>_profiles/ (copy them into profiles/).
+tag=${1:-r03}; commit=${2:-unknown}
+root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out/${tag}_profiles
+rm -rf $out; mkdir -p $out
+cd $root
+bash tools/pmc_traffic.sh ${tag}_pmc_traffic_raw > $out/pmc_traffic.log 2>&1
+python3 tools/pmc_traffic_summary.py gpurun_out/${tag}_pmc_traffic_raw $commit > $out/${tag}_pmc_traffic.json && cp $out/${tag}_pmc_traffic.json profiles/
+bash tools/pmc_mfma.sh ${tag}_pmc_mfma_raw > $out/pmc_mfma.log 2>&1
+python3 tools/pmc_mfma_summary.py gpurun_out/${tag}_pmc_mfma_raw $commit > $out/${tag}_pmc_mfma.json && cp $out/${tag}_pmc_mfma.json profiles/
+rm -rf gpurun_out/${tag}_pmc_traffic_raw gpurun_out/${tag}_pmc_mfma_raw
+cd /tmp; export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $root/bench.py --steps 12 --warmup 3 --no-cpu --no-roofline --no-native > $out/prof.log 2>&1
+python3 $root/tools/prof_summary.py $out/prof 15 40 > $out/${tag}_rocprof_kernel_stats_final.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -- python3 $root/bench.py --c5 --steps 12 --warmup 3 --no-cpu --no-roofline --no-native > $out/prof5.log 2>&1
+python3 $root/tools/prof_summary.py $out/prof5 15 40 > $out/${tag}_rocprof_kernel_stats_c5.txt
+rm -rf $out/prof $out/prof5
+cd $root
+timeout -k 10 400 python3 bench.py > $out/${tag}_bench_final.json 2> $out/bench.err; echo bench_exit=$?
+timeout -k 10 400 python3 bench.py --c5 > $out/${tag}_bench_c5.json 2> $out/bench5.err; echo bench5_exit=$?
+ls -la $out
