@@ -67,7 +67,7 @@ class SstArgs(C.Structure):
 
 class SstGrads(C.Structure):
     _fields_ = [('g_w_ih', c_f * 2), ('g_w_hh', c_f * 2), ('g_b_ih', c_f * 2), ('g_b_hh', c_f * 2), ('g_w_sc', c_f), ('g_b_sc', c_f),
-                ('g_tap', c_f), ('g_scores', c_f), ('ws_bwd', c_f)]
+                ('g_tap', c_f), ('g_scores', c_f), ('ws_bwd', c_f), ('zeroed', i32)]
 
 
 class SampleArgs(C.Structure):
@@ -112,6 +112,7 @@ SYMBOLS = [
     ('echr_sst_fwd', i32, [C.POINTER(SstArgs), C.POINTER(Dropout), C.c_void_p]),
     ('echr_sst_bwd', i32, [C.POINTER(SstArgs), C.POINTER(SstGrads), C.POINTER(Dropout), C.c_void_p]),
     ('echr_tap_bce_fwd', i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, C.c_void_p]),
+    ('echr_tap_bce_fwd_ws', i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, C.c_void_p]),
     ('echr_tap_bce_bwd', i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, C.c_void_p]),
     ('echr_h2_bytes', i64, [i32, i32]),
     ('echr_h2_pack', i32, [c_f, i32, i32, i64, i64, C.c_void_p, C.c_void_p]),

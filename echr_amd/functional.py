@@ -539,15 +539,16 @@ class SSTFunction(torch.autograd.Function):
         p_drop, drop = ctx.meta
         T, D = x.shape
         H, K = ps[1].shape[1], ps[8].shape[0]
-        # the library overwrites every gradient buffer: arena views (when the module has an arena and no gradient is live) need no fill
+        # flat arena (no gradient live yet): ONE zero fill of the span, then every product accumulates (`zeroed`): the split-K weight-gradient
+        # products would otherwise zero-fill their own outputs, one launch each
         use_arena = ctx.sink is not None and ctx.sink.usable()
-        grads = [ctx.sink.arena.grad_view(s) for s in ctx.sink.slots] if use_arena else [torch.empty_like(p) for p in ps]
+        grads = ctx.sink.take() if use_arena else [torch.empty_like(p) for p in ps]
         wsb = torch.empty(lib.echr_sst_ws_bwd_floats(T, D, H, K), device=x.device, dtype=torch.float32)
         a = SSTFunction._args(ps, x, p_drop, ws, tap, scores)
         two = lambda a_, b_: (L.c_f * 2)(L.ptr(a_), L.ptr(b_))
         g = L.SstGrads(two(grads[0], grads[4]), two(grads[1], grads[5]), two(grads[2], grads[6]), two(grads[3], grads[7]),
                        L.ptr(grads[8]), L.ptr(grads[9]), L.ptr(_f32c(g_tap)) if g_tap is not None else None,
-                       L.ptr(_f32c(g_scores)) if g_scores is not None else None, L.ptr(wsb))
+                       L.ptr(_f32c(g_scores)) if g_scores is not None else None, L.ptr(wsb), 1 if use_arena else 0)
         d = drop.c()
         L.check(lib.echr_sst_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'sst_bwd')
         return (None, None, None, None) + tuple(grads)
@@ -561,8 +562,10 @@ class TapBCE(torch.autograd.Function):
         lib = L.load()
         scores, masks, labels, w1 = _f32c(scores), _f32c(masks), _f32c(labels), _f32c(w1).reshape(-1)
         T, K = scores.shape
-        loss = torch.empty(1, device=scores.device, dtype=torch.float32)
-        L.check(lib.echr_tap_bce_fwd(L.ptr(scores), L.ptr(masks), L.ptr(labels), L.ptr(w1), L.ptr(loss), T, K, L.stream_ptr()), 'tap_bce_fwd')
+        buf = torch.empty(65, device=scores.device, dtype=torch.float32)          # loss | 64 partial sums
+        loss = buf[:1]
+        L.check(lib.echr_tap_bce_fwd_ws(L.ptr(scores), L.ptr(masks), L.ptr(labels), L.ptr(w1), L.ptr(loss), L.ptr(buf[1:]), T, K, L.stream_ptr()),
+                'tap_bce_fwd')
         ctx.save_for_backward(scores, masks, labels, w1)
         return loss[0]
 

@@ -312,6 +312,8 @@ typedef struct {
     const float* g_tap;             /* [T,H] or NULL */
     const float* g_scores;          /* [T,K] or NULL */
     float* ws_bwd;                  /* scratch, echr_sst_ws_bwd_floats */
+    int32_t zeroed;                 /* 1: every parameter-gradient buffer arrives zero-filled (flat arena, one fill by the caller): the library
+                                       accumulates into them instead of zero-filling each split-K product's output itself */
 } echr_sst_grads;
 
 int64_t echr_sst_ws_floats(int32_t T, int32_t D, int32_t H, int32_t K);
@@ -321,6 +323,10 @@ int echr_sst_bwd(const echr_sst_args* a, const echr_sst_grads* g, const echr_dro
 /* weighted BCE of the proposal head: loss (device scalar) and its gradient w.r.t. the scores */
 int echr_tap_bce_fwd(const float* scores, const float* masks, const float* labels, const float* w1, float* loss, int32_t T,
                      int32_t K, void* stream);
+/* the same loss with a caller-provided scratch of 64 floats (`partials`): 64 workgroups + a final fixed-order add instead of one workgroup
+ * (bit-reproducible either way; what echr_amd uses) */
+int echr_tap_bce_fwd_ws(const float* scores, const float* masks, const float* labels, const float* w1, float* loss, float* partials,
+                        int32_t T, int32_t K, void* stream);
 int echr_tap_bce_bwd(const float* scores, const float* masks, const float* labels, const float* w1, const float* g_loss,
                      float* g_scores, int32_t T, int32_t K, void* stream);
 
