@@ -30,6 +30,7 @@ class ParamArena(object):
         self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
         self.index = {}
         self._zeroed = []
+        self.whole_zero_pass = False         # True from the moment a backward Function zero-filled the WHOLE arena until that backward pass ends
         self.deferred_clamp = None           # clip value of a clip_gradient call that was left to the fused step kernel (optim.ClampAdam)
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
@@ -79,6 +80,9 @@ class ParamArena(object):
             from . import functional as EF
             self.zero_unused_grads(keep=True)
             EF.clamp_(self.flat_g, clip)
+
+    def end_backward_pass(self):
+        self.whole_zero_pass = False
 
     def note_zeroed(self, lo, hi):
         """A backward Function zero-filled flat_g[lo:hi] this step (GradSink.take)."""

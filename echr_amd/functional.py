@@ -95,6 +95,14 @@ class GradSink(object):
         """Fresh arena views of the group's gradients over a zero-filled span.  defer_zero: the caller zero-fills the span itself (the
         decoder backward folds it into its own multi-range fill launch) -- returns (views, span tensor)."""
         lo, hi = self.arena.span(self.slots)
+        if self.arena.whole_zero_pass:
+            # an earlier Function of THIS backward pass (the decoder, which runs first) zero-filled the whole arena: nothing to fill
+            views = [self.arena.grad_view(s) for s in self.slots]
+            return (views, None) if defer_zero else views
+        if defer_zero and all(p.grad is None for p in self.arena.params):
+            lo, hi = 0, self.arena.total      # fresh step: ONE fill covers every group's span and the never-used parameters' slots
+            self.arena.whole_zero_pass = True  # valid until this backward pass ends (autograd end-of-pass callback)
+            torch.autograd.Variable._execution_engine.queue_callback(self.arena.end_backward_pass)
         span = self.arena.flat_g[lo:hi]
         if not defer_zero:
             span.zero_()

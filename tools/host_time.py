@@ -35,3 +35,15 @@ ts = []
 for _ in range(10):
     torch.cuda.synchronize(); a = time.perf_counter(); iteration(); ts.append(time.perf_counter() - a)
 print('host time of one iteration issued into an empty queue: min %.3f ms' % (min(ts) * 1e3))
+if 'profile' in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    pr.enable()
+    for _ in range(20):
+        iteration()
+        torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats('cumulative').print_stats(45)
+    st.sort_stats('tottime').print_stats(30)
