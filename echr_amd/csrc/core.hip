@@ -513,18 +513,26 @@ __global__ void event_gather_bwd_kernel(const float* __restrict__ d_ech, const i
 
 // ---- greedy arg-max over logits rows: lowest index on ties (torch.max semantics, OldModel_NEW.py:158) ---
 // Updates the sampler state: it_next[n] (int32), unfinished[n], seq/seq_logp column, n_unfinished counter.
-__global__ __launch_bounds__(256) void greedy_step_kernel(const float* __restrict__ logits, long ld, int V1, int t, int seq_len,
+// slabs != nullptr: the row is first formed from the four k-slice slabs of the logits product, ((S0 + S1) + (S2 + S3)) + bias in that fixed
+// order (bitwise reproducible), and written to `logits` by the thread that scans it -- the separate slab-sum launch of every decoder step folded in
+__global__ __launch_bounds__(256) void greedy_step_kernel(float* __restrict__ logits, long ld, int V1, int t, int seq_len,
                                                           int* __restrict__ it_next, int* __restrict__ unfinished,
                                                           long long* __restrict__ seq, float* __restrict__ seq_logp,
-                                                          int* __restrict__ n_unfinished) {
+                                                          int* __restrict__ n_unfinished, const float* __restrict__ slabs, long slab_stride,
+                                                          const float* __restrict__ bias) {
     __shared__ float red[4];
     __shared__ int redi[4];
     const int n = blockIdx.x;
-    const float* x = logits + (long)n * ld;
+    float* x = logits + (long)n * ld;
     float m = -INFINITY;
     int mi = 0x7fffffff;
     for (int j = threadIdx.x; j < V1; j += 256) {
-        const float v = x[j];
+        float v;
+        if (slabs) {
+            const float* sp = slabs + (long)n * V1 + j;
+            v = ((sp[0] + sp[slab_stride]) + (sp[2 * slab_stride] + sp[3 * slab_stride])) + (bias ? bias[j] : 0.f);
+            x[j] = v;
+        } else v = x[j];
         if (v > m) { m = v; mi = j; }   // ascending j per thread: first maximum kept
     }
     // wave arg-max with (value, lowest index) ordering
@@ -678,9 +686,10 @@ int sample_step(const float* logits, long ld, int N, int V1, int t, int seq_len,
     return check_launch("sample_step");
 }
 
-int greedy_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
-                long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st) {
-    hipLaunchKernelGGL(greedy_step_kernel, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq, seq_logp, n_unfinished);
+int greedy_step(float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
+                long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st, const float* slabs, long slab_stride, const float* bias) {
+    hipLaunchKernelGGL(greedy_step_kernel, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq, seq_logp, n_unfinished,
+                       slabs, slab_stride, bias);
     return check_launch("greedy_step");
 }
 

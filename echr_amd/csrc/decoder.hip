@@ -928,12 +928,13 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
 }
 
 // input-side gate pre-activations for `rows` = nt*N token rows starting at timestep t0
-static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, int t0, int nt, hipStream_t st, bool no_evb0 = false) {
+static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, int t0, int nt, hipStream_t st, bool no_evb0 = false, bool force_h2 = false) {
     const int N = a->N, H = a->H, E = a->E;
     const int rows = nt * N;
     const int cin[3] = {E + a->De, E + a->D, E + a->Dv};
     echr_gemm_desc d[3];
-    const bool h2 = config().gemm_h2 && xt == w.XT && t0 == 0 && nt == a->S;      // the teacher-forced call: all S*N token rows at once
+    // the teacher-forced call (all S*N token rows at once), or a sampler step over many events (force_h2: PK_WIH packed by the caller)
+    const bool h2 = config().gemm_h2 && ((xt == w.XT && t0 == 0 && nt == a->S) || force_h2);
     if (h2) {
         H2PackJob pj = pack_rows(xt, E, rows, E, w.PK_XT);
         RC(h2_pack_multi(&pj, 1, st));
@@ -945,7 +946,7 @@ static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, 
         if (k == 0) { if (!no_evb0) d[k].addend = w.EVB0; }
         else if (k == 1) { d[k].bias = a->b_ih[1]; d[k].bias2 = a->b_hh[1]; }
         else d[k].bias = w.VIDB;
-        d[k].split_k = -1;
+        d[k].split_k = force_h2 ? 1 : -1;          // sampler: one fixed-order k loop per tile (bitwise reproducible)
     }
     return gemm_grouped(d, 3, st);       // the three streams' token-side products in one launch
 }
@@ -1443,22 +1444,36 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
     RC(fill_zero(reinterpret_cast<float*>(sa->n_unfinished), L + 1, st));
     RC(fill_zero(reinterpret_cast<float*>(sa->seq), 2L * N * L, st));
     RC(fill_zero(sa->seq_logp, (long)N * L, st));
-    RC(precompute_static(&a, w, st, false));
+    // many events (evaluation: up to 1000 proposals): the per-step token-side gate products and the logits product are 6 + 15 GF -- they run
+    // on h2 operands (weights packed once per decode, the step's N rows packed per step; one fixed-order k loop per tile, so the decode stays
+    // bitwise reproducible).  Few events: exact fp32 MFMA as before (the products are launch-bound there).
+    const bool big = config().gemm_h2 && N >= 192;
+    RC(precompute_static(&a, w, st, big));
     for (int t = 0; t < L; ++t) {
         RC(embed_gather(a.embed, s.IT, s.XT, N, E, a.V1, st));
-        RC(input_gates(&a, w, s.XT, t, 1, st));
+        RC(input_gates(&a, w, s.XT, t, 1, st, false, big));
         RC(step_fwd(&a, w, t, off, off, st));
         const long tiles = (long)((N + 63) / 64) * ((a.V1 + 63) / 64);
-        if (tiles < 400 && (3 * H) % (SAMP_SLABS * 32) == 0) {
+        bool slab_form = false;
+        if (big) {
+            H2PackJob pj = pack_rows(w.OUTD + (long)t * N * 3 * H, 3 * H, N, 3 * H, w.PK_OUTD);
+            RC(h2_pack_multi(&pj, 1, st));
+            echr_gemm_desc d = desc_h2(w.PK_OUTD, w.PK_WL, s.LOGITS, a.V1, N, a.V1, 3 * H);
+            d.bias = a.b_logit; d.split_k = 1;
+            RC(gemm(d, st));
+        } else if (tiles < 400 && (3 * H) % (SAMP_SLABS * 32) == 0) {
             // few rows: one k loop per tile would be 48 k blocks deep on 79 workgroups.  Four k-slices as a strided batch into four
             // slabs (plain stores), then one fixed-order sum: still bitwise reproducible, a third of the time
             const int ksl = 3 * H / SAMP_SLABS;
             echr_gemm_desc d = desc_nt(w.OUTD + (long)t * N * 3 * H, 3 * H, a.w_logit, 3 * H, s.SLABS, a.V1, N, a.V1, ksl);
             d.batch = SAMP_SLABS; d.bsa = ksl; d.bsb = ksl; d.bsc = (long)N * a.V1; d.split_k = 1;
             RC(gemm(d, st));
-            const long n = (long)N * a.V1;
-            hipLaunchKernelGGL(slab_sum_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.SLABS, n, a.b_logit, s.LOGITS, n, a.V1);
-            RC(check_launch("slab_sum_bias"));
+            slab_form = true;
+            if (sa->multinomial) {         // the multinomial step reads finished logits: sum the slabs first (the greedy step folds the sum in)
+                const long n = (long)N * a.V1;
+                hipLaunchKernelGGL(slab_sum_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.SLABS, n, a.b_logit, s.LOGITS, n, a.V1);
+                RC(check_launch("slab_sum_bias"));
+            }
         } else {
             echr_gemm_desc d = desc_nt(w.OUTD + (long)t * N * 3 * H, 3 * H, a.w_logit, 3 * H, s.LOGITS, a.V1, N, a.V1, 3 * H);
             d.bias = a.b_logit; d.split_k = 1;
@@ -1469,7 +1484,7 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
                            sa->temperature, sa->seed, st));
         else
             RC(greedy_step(s.LOGITS, a.V1, N, a.V1, t, L, s.IT, s.UNF, reinterpret_cast<long long*>(sa->seq), sa->seq_logp,
-                           sa->n_unfinished, st));
+                           sa->n_unfinished, st, slab_form ? s.SLABS : nullptr, (long)N * a.V1, a.b_logit));
     }
     return 0;
 }

@@ -121,7 +121,9 @@ int logsoftmax_bwd(const float* logp, const float* G, const void* target, int tg
                    const float* mask_sum, float* out, long ldo, int N, int S, int V1, hipStream_t st);
 int sample_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished, long long* seq,
                 float* seq_logp, int* n_unfinished, float temperature, unsigned long long seed, hipStream_t st);
-int greedy_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
-                long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st);
+// slabs != nullptr: logits rows are formed here from four k-slice slabs (+ bias) in a fixed order and written to `logits`
+int greedy_step(float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
+                long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st, const float* slabs = nullptr, long slab_stride = 0,
+                const float* bias = nullptr);
 
 }  // namespace echr

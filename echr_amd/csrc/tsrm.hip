@@ -20,13 +20,29 @@ enum { SITE_TSRM = 0 };
 // pos[i,j,:] for the event pair (i,j): [sin(dc*f_k), cos(dc*f_k), sin(dl*f_k), cos(dl*f_k)], k < Df/4, where
 // dc = max(|c_i - c_j| / l_i, 1e-3) (float64), dl = log(l_j / l_i) evaluated in float32 as the reference does
 // (lengths are cast to float32, MA_attention_8_NEW.py:70), arguments scaled by 100 / 10000^(4k/Df).
-__global__ void posemb_kernel(const int* __restrict__ ev_start, const int* __restrict__ ev_len, float* __restrict__ pos,
-                              int N, int Df) {
-    const int F4 = Df / 4;
+// sin and cos of a float64 argument to float32 accuracy: quadrant reduction in float64 (two-term pi/2; the arguments reach 10^4 rad, so
+// it must not happen in float32), then the classic degree-9 / degree-10 polynomials on |r| <= pi/4 in float32 (truncation < 3e-9)
+__device__ __forceinline__ void sincos_f64arg(double x, float& s, float& c) {
+    const double q = rint(x * 0.6366197723675814);                        // 2 / pi
+    const float r = (float)fma(-q, 6.123233995736766e-17, fma(-q, 1.5707963267948966, x));
+    const float r2 = r * r;
+    const float sp = r + r * r2 * (-1.6666667e-1f + r2 * (8.3333333e-3f + r2 * (-1.9841270e-4f + r2 * 2.7557319e-6f)));
+    const float cp = 1.f + r2 * (-0.5f + r2 * (4.1666667e-2f + r2 * (-1.3888889e-3f + r2 * (2.4801587e-5f + r2 * -2.7557319e-7f))));
+    const int n = (int)(long long)q & 3;
+    const float ss = (n & 1) ? cp : sp, cs = (n & 1) ? sp : cp;
+    s = (n & 2) ? -ss : ss;
+    c = ((n + 1) & 2) ? -cs : cs;
+}
+
+// One thread forms 16 consecutive frequencies of one pair: the frequency scale 100 / 10000^(4k/Df) by one pow and a float64 recurrence, the
+// arguments in float64, sin / cos by sincos_f64arg -- the values the reference's float64 numpy sin / cos round to, to ~1e-7.
+__global__ __launch_bounds__(256) void posemb_kernel(const int* __restrict__ ev_start, const int* __restrict__ ev_len, float* __restrict__ pos,
+                                                     int N, int Df) {
+    const int F4 = Df / 4, KC = (F4 + 15) / 16;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)N * N * F4) return;
-    const int k = (int)(idx % F4);
-    const long ij = idx / F4;
+    if (idx >= (long)N * N * KC) return;
+    const int kc = (int)(idx % KC);
+    const long ij = idx / KC;
     const int j = (int)(ij % N), i = (int)(ij / N);
     const double ci = 0.5 * ((double)ev_start[i] + (double)(ev_start[i] + ev_len[i]));
     const double cj = 0.5 * ((double)ev_start[j] + (double)(ev_start[j] + ev_len[j]));
@@ -35,13 +51,21 @@ __global__ void posemb_kernel(const int* __restrict__ ev_start, const int* __res
     dc = dc > 1e-3 ? dc : 1e-3;
     const float ratio = __fdiv_rn(lj, li);
     const double dl = (double)(float)log((double)ratio);
-    const double dim = pow(10000.0, (4.0 / (double)Df) * (double)k);
-    const double ac = 100.0 * dc / dim, al = 100.0 * dl / dim;
+    const double step = pow(10000.0, -4.0 / (double)Df);                 // 1 / (ratio of consecutive frequency divisors)
+    double inv_dim = 100.0 * pow(10000.0, -(4.0 / (double)Df) * (double)(16 * kc));
     float* o = pos + ij * Df;
-    o[k] = (float)sin(ac);
-    o[F4 + k] = (float)cos(ac);
-    o[2 * F4 + k] = (float)sin(al);
-    o[3 * F4 + k] = (float)cos(al);
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = 16 * kc + kk;
+        if (k >= F4) break;
+        float sc, cc, sl, cl;
+        sincos_f64arg(dc * inv_dim, sc, cc);
+        sincos_f64arg(dl * inv_dim, sl, cl);
+        o[k] = sc;
+        o[F4 + k] = cc;
+        o[2 * F4 + k] = sl;
+        o[3 * F4 + k] = cl;
+        inv_dim *= step;
+    }
 }
 
 // one wave per (event n, head g): w[m] = softmax_m(gate[n,m,g] * aff[g,n,m]); wd = w * dropout
@@ -125,7 +149,7 @@ static int check(const echr_tsrm_args* a, const char* who) {
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
 int posemb(const int* ev_start, const int* ev_len, float* pos, int N, int Df, hipStream_t st) {
-    const long tot = (long)N * N * (Df / 4);
+    const long tot = (long)N * N * ((Df / 4 + 15) / 16);
     hipLaunchKernelGGL(posemb_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ev_start, ev_len, pos, N, Df);
     return check_launch("posemb");
 }

@@ -16,7 +16,8 @@ params = synth.make_params(opt, 0)
 m = echr_amd.CaptionGenerator(opt)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
 m = m.to(dev).eval()
-for N, T_v in ((64, 8192), (1000, 256)):
+SIZES = [(n, 8192 if n <= 64 else 256) for n in (int(a) for a in sys.argv[1:] if a.isdigit())] or [(64, 8192), (1000, 256)]
+for N, T_v in SIZES:
     vid = synth.make_video(N, 128, 21, 5001, seed=7, T_v=T_v if N > 64 else None, full_len=(N == 64), disjoint=(N == 64))
     tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
     with torch.no_grad():
