@@ -389,6 +389,8 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *   "persist_spin_limit" n  bound of every hand-off spin in polls (0 = default, about seconds; ECHR_PERSIST_SPIN_LIMIT)
  *   "persist_inject_timeout" code  diagnostic: the hand-off wait with this code (attention chain: 100000 * edge + timestep, edge 1 h1 / 2 q / 3 context / 4 d q / 5 d h / 6 d G / 7 d ATT) never completes, so the
  *                      launch aborts through its time-out path (tests/test_gpu_parity.py::test_persistent_abort_path); 0 = off
+ *   "sst_persist" 0/1   (default 1, ECHR_SST_PERSIST) proposal encoder's recurrences as one persistent launch per direction (H = 512)
+ *   "tail_early"  0/1   (default 0, ECHR_TAIL_EARLY) fork the asynchronous decoder-backward tail ahead of the LSTM-layer gradient stage
  *   "persist_stamps" 0/1/2 diagnostic phase stamps of the forward (1) / reverse (2) pair, see echr_persist_read_stamps
  *   "gemm_tile", "gemm_split"  tuning overrides of the GEMM tile / split-K heuristics (0 = heuristics; tools/gemm_bench.py only) */
 int echr_config_set(const char* key, int32_t value);
