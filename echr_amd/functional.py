@@ -311,7 +311,8 @@ class DecoderFunction(torch.autograd.Function):
                        1 if (fused and fused[0].dtype == torch.int64) else 0)
         d = drop.c()
         hook = getattr(ctx.sink.arena, 'early_grad_hook', None) if zeroed else None
-        if hook is not None:
+        staged = hook is not None and getattr(ctx.sink.arena, 'early_staged', True)
+        if staged:
             # data parallel: hand gradients to the reducer as soon as they are final; it starts their all-reduce on the collective
             # stream while the next stage runs on this one.  params order = OldModel.native_params():
             #   [0] embed, [1] logit.weight, [2] logit.bias, [3:6] weight_ih, [6:9] weight_hh, [9:12] bias_ih, [12:15] bias_hh, ...
@@ -330,6 +331,10 @@ class DecoderFunction(torch.autograd.Function):
             # clone them: the gradients must then be final when this Function returns)
             g.async_tail = 1 if (zeroed and ASYNC_TAIL[0] and not ctx.sink.has_hooks() and not torch.is_grad_enabled()) else 0
             L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
+            if hook is not None:
+                # data parallel, one-call form: the LSTM-layer gradients (and everything else part A of the backward produced) are final in
+                # stream order now; the reducer starts their all-reduce, which overlaps the asynchronous tail and the event encoder's backward
+                hook(list(ctx.sink.params[3:15]), after_recurrence=True)
             if g.async_tail:
                 keep = [ws, wsb, logp, c3d, tokens, ev_start, ev_len, g_logp, fused]
                 sp = L.stream_ptr()

@@ -49,8 +49,16 @@ class EarlyReducer(object):
     the current stream).  `allreduce_gradients` later reduces the ranges no early collective covered and waits for the early ones,
     so the result is the same SUM over ranks as the single-collective path."""
 
-    def __init__(self, arena, group=None, auto_arm=True, defer_first=None):
+    def __init__(self, arena, group=None, auto_arm=True, defer_first=None, staged=None):
         self.arena, self.group = arena, group
+        # staged = False (default since round 3, ECHR_DP_STAGED=1 for the old form): the decoder backward stays ONE library call with its
+        # asynchronous tail (logit-layer / attention / embedding gradients on the helper stream) and hands over the twelve LSTM-layer gradients
+        # (39 % of the bytes), which are final in stream order when the call returns; their all-reduce then overlaps the tail and the event
+        # encoder's backward.  The three-stage form (True) makes 74 % of the bytes early-reducible but gives up the asynchronous tail and puts
+        # the logit-layer gradient products back in front of the reverse recurrence: +0.2 ms of compute per iteration for ranges that
+        # `defer_first` holds back until the recurrence is over anyway.
+        self.staged = bool(int(os.environ.get('ECHR_DP_STAGED', '0'))) if staged is None else bool(staged)
+        arena.early_staged = self.staged
         self.pending = []              # [(lo, hi, work)], disjoint arena ranges in flight
         # The first range of a backward pass (the late-fusion layer) becomes final BEFORE the reverse recurrence, which runs as a pair
         # of persistent kernels that need every CU of the device: a collective kernel resident beside them would not overlap with
@@ -79,10 +87,11 @@ class EarlyReducer(object):
             raise RuntimeError('a backward pass accumulates into gradients whose all-reduce is already in flight: with gradient '
                                'accumulation create the reducer with auto_arm=False and call arm() only before the last backward')
 
-    def hook(self, params):
+    def hook(self, params, after_recurrence=False):
+        """after_recurrence: the persistent reverse recurrence of this backward pass is over (nothing to keep back for)."""
         if not self.armed or not (dist.is_available() and dist.is_initialized()):
             return
-        if self.defer_first and not self.pending and not self.deferred:
+        if self.defer_first and not after_recurrence and not self.pending and not self.deferred:
             self.deferred.append(list(params))
             return
         held, self.deferred = self.deferred, []
@@ -129,14 +138,15 @@ class EarlyReducer(object):
         self.arena.early_grad_hook = None
 
 
-def enable_overlap(module, group=None, auto_arm=True, defer_first=None):
+def enable_overlap(module, group=None, auto_arm=True, defer_first=None, staged=None):
     """Install the early reducer on a module whose parameters live in a flat arena (CaptionGenerator.build_arena()).
     auto_arm=False: gradient accumulation -- call the returned reducer's arm() before the last backward of every optimiser step.
-    defer_first: see EarlyReducer (None = ECHR_DP_DEFER_FIRST, default on)."""
+    defer_first: see EarlyReducer (None = ECHR_DP_DEFER_FIRST, default on).  staged: three-stage decoder backward (None = ECHR_DP_STAGED,
+    default off: one call + LSTM-layer gradients reduced early)."""
     arena = getattr(module, '_echr_arena', None)
     if arena is None:
         raise ValueError('enable_overlap needs the flat arena: call module.build_arena() first')
-    red = EarlyReducer(arena, group, auto_arm, defer_first)
+    red = EarlyReducer(arena, group, auto_arm, defer_first, staged)
     module._echr_early_reducer = red
     return red
 

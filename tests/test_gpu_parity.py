@@ -1093,7 +1093,7 @@ def test_eval_flow_sst_to_captions_vs_oracle(nms):
         assert rec['sentence'] == [int(t) for t in seq_o[i].numpy() if t > 0]
 
 
-@pytest.mark.parametrize('overlap', [False, True])
+@pytest.mark.parametrize('overlap', [False, True, 'staged'])
 def test_two_rank_data_parallel_on_one_gpu(tmp_path, overlap):
     """Two data-parallel ranks (separate processes, gloo transport, both on cuda:0) run two optimiser steps on different videos:
     both ranks must end with IDENTICAL parameters, equal to one process that accumulates the two videos' gradients before each
@@ -1108,13 +1108,15 @@ def test_two_rank_data_parallel_on_one_gpu(tmp_path, overlap):
     outs = [str(tmp_path / ('rank%d.npz' % r)) for r in range(2)]
     # overlap=False: launch-per-phase recurrences; overlap=True: persistent recurrences launched cooperatively by both processes (the form
     # real data-parallel runs use) -- two plain 256-workgroup persistent grids must never share a device
-    env = dict(os.environ, ECHR_DP_WORKER_COOP='1' if overlap else '0')
+    # 'staged': the three-stage decoder backward (ECHR_DP_STAGED=1: logit- and LSTM-layer ranges early); True: the one-call backward with the
+    # LSTM-layer range reduced early (the default form)
+    env = dict(os.environ, ECHR_DP_WORKER_COOP='1' if overlap is True else '0', ECHR_DP_STAGED='1' if overlap == 'staged' else '0')
     procs = [subprocess.Popen([_sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), str(r), '2', port, outs[r], '1' if overlap else '0'],
                               cwd=root, env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     r0, r1 = np.load(outs[0]), np.load(outs[1])
-    assert int(r0['n_collectives']) == (4 if overlap else 1)
+    assert int(r0['n_collectives']) == {False: 1, True: 3, 'staged': 4}[overlap]
     for k in synth.state_dict_shapes(synth.make_case('c1')[0]):
         assert np.array_equal(r0[k], r1[k]), k                               # replicas stay bitwise identical after two steps
     # one process accumulating the two videos' gradients of step 0 (same initial parameters)
