@@ -154,7 +154,13 @@ def check(rc, what=''):
         raise EchrHipError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_ptr():
+    """The current HIP stream as a void* (torch.cuda.current_stream() builds a Python Stream object per call: ~8 us; the raw getter 0.3)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -67,6 +67,9 @@ ASYNC_TAIL = [os.environ.get('ECHR_ASYNC_TAIL', '1') != '0']        # decoder ba
 
 
 def _f32c(t):
+    # (inside autograd.Function.forward / backward grad mode is off: inputs can be used and saved as they are)
+    if t.dtype is torch.float32 and t.is_contiguous() and (not t.requires_grad or not torch.is_grad_enabled()):
+        return t
     return t.detach().to(torch.float32).contiguous()
 
 

@@ -116,6 +116,13 @@ class OldModel(nn.Module):
         return st
 
     def native_params(self):
+        cached = self.__dict__.get('_native_params')
+        if cached is not None:
+            return cached
+        self.__dict__['_native_params'] = self._native_params_now()          # Parameter OBJECTS are stable (.data may move into an arena)
+        return self.__dict__['_native_params']
+
+    def _native_params_now(self):
         c = self.core
         a = c.attention
         return (self.embed.weight, self.logit.weight, self.logit.bias,

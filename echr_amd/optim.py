@@ -19,6 +19,7 @@ class ClampAdam(torch.optim.Optimizer):
         self.pending_clip = None
         self.arena = arena            # echr_amd.arena.ParamArena: one launch over the whole model when gradients live there
         self._flat = None
+        self._same_params = None
         # True (default): with the flat arena `clip_gradient` does not run a clamp pass of its own -- the fused step kernel clamps on the
         # fly (one 174 MB pass less per step).  The reference clamps the RUNNING gradient after every backward (train.py:313-317), which
         # only differs from a single clamp when ANOTHER backward follows (m_batch > 1): the arena remembers the deferred clip value and
@@ -32,7 +33,9 @@ class ClampAdam(torch.optim.Optimizer):
         ar = self.arena
         if ar is None or len(self.param_groups) != 1 or not ar.params_in_arena() or not ar.grads_in_arena():
             return False
-        if {id(p) for p in self.param_groups[0]['params']} != {id(p) for p in ar.params}:
+        if self._same_params is None:          # the optimiser's parameter set == the arena's (checked once: both lists are fixed after construction)
+            self._same_params = {id(p) for p in self.param_groups[0]['params']} == {id(p) for p in ar.params}
+        if not self._same_params:
             return False
         group = self.param_groups[0]
         if self._flat is None:

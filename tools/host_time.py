@@ -47,3 +47,29 @@ if 'profile' in sys.argv:
     st = pstats.Stats(pr)
     st.sort_stats('cumulative').print_stats(45)
     st.sort_stats('tottime').print_stats(30)
+if 'calls' in sys.argv:
+    # time spent inside each library entry point (host side of the ctypes call: argument marshalling + the HIP launches it issues)
+    from echr_amd import _lib
+    lib = _lib.load()
+    acc = {}
+    import threading
+    lock = threading.Lock()
+    def wrap(name, fn):
+        def f(*a):
+            t = time.perf_counter()
+            r = fn(*a)
+            dt = time.perf_counter() - t
+            with lock:
+                e = acc.setdefault(name, [0, 0.0]); e[0] += 1; e[1] += dt
+            return r
+        return f
+    for name, _, _ in _lib.SYMBOLS:
+        if name not in ('echr_last_error', 'echr_version'):
+            setattr(lib, name, wrap(name, getattr(lib, name)))
+    R = 20
+    for _ in range(R):
+        iteration(); torch.cuda.synchronize()
+    tot = 0.0
+    for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        print('%-32s %5.1f calls/iter %8.1f us/iter' % (k, n / R, t / R * 1e6)); tot += t / R * 1e6
+    print('library calls total %.1f us/iter' % tot)
