@@ -39,6 +39,7 @@ long persist_bwd_ws_floats(int S);
 bool persist_bwd_eligible(const echr_dec_args* a);
 int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
 int persist_check_async();
+void coop_refused(const char* who, const char* why);          // one stderr line the first time a cooperative launch is refused
 // device word that is non-zero from the moment a persistent launch aborts until the host has reported it (persist_check_async):
 // kernels that would apply results (clamp_adam, clamp) skip their update while it is set; nullptr when the state is unavailable
 const unsigned* persist_abort_word();

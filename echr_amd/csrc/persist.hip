@@ -1048,20 +1048,27 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                 // second slot set (BIG, events longer than 129 segments): same scores from P_all rows fetched now (L2-resident)
                 float e2[PSG] = {-INFINITY, -INFINITY, -INFINITY};
                 if (has2) {
-#pragma unroll
-                    for (int i = 0; i < PSG; ++i) {
+                    // two slots' rows in flight: slot i + 1 is fetched while slot i is scored
+                    float4 pv[2][8];
+                    auto fetch_p = [&](int i, float4 (&dst)[8]) {
                         const int sl = grow_ + 16 * i;
                         const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
                         const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
-                        float4 pv[8];
 #pragma unroll
-                        for (int h = 0; h < 8; ++h) pv[h] = *reinterpret_cast<const float4*>(pr + 4 * h);
+                        for (int h = 0; h < 8; ++h) dst[h] = *reinterpret_cast<const float4*>(pr + 4 * h);
+                    };
+                    fetch_p(0, pv[0]);
+#pragma unroll
+                    for (int i = 0; i < PSG; ++i) {
+                        if (i + 1 < PSG) fetch_p(i + 1, pv[(i + 1) & 1]);
+                        const int sl = grow_ + 16 * i;
                         float v = 0.f;
 #pragma unroll
                         for (int h = 0; h < 8; ++h) {
                             const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
-                            const float4 ep = make_float4(__expf(2.f * fminf(fmaxf(pv[h].x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv[h].y, -43.f), 43.f)),
-                                                          __expf(2.f * fminf(fmaxf(pv[h].z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv[h].w, -43.f), 43.f)));
+                            const float4 pp = pv[i & 1][h];
+                            const float4 ep = make_float4(__expf(2.f * fminf(fmaxf(pp.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pp.y, -43.f), 43.f)),
+                                                          __expf(2.f * fminf(fmaxf(pp.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pp.w, -43.f), 43.f)));
                             v += a4.x * __builtin_amdgcn_rcpf(fmaf(ep.x, q[h].x, 1.f)) + a4.y * __builtin_amdgcn_rcpf(fmaf(ep.y, q[h].y, 1.f)) +
                                  a4.z * __builtin_amdgcn_rcpf(fmaf(ep.z, q[h].z, 1.f)) + a4.w * __builtin_amdgcn_rcpf(fmaf(ep.w, q[h].w, 1.f));
                         }
@@ -1121,23 +1128,27 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                     }
                 }
                 if (has2) {
-#pragma unroll
-                    for (int i = 0; i < PSG; ++i) {
-                        const float x = __expf(e2[i] - shift);
-                        e2[i] = x;
-                        ssum += x;
+                    float4 cv[2][8];
+                    auto fetch_c = [&](int i, float4 (&dst)[8]) {
                         const int sl = grow_ + 16 * i;
                         const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
                         const float* cr = P.c3d + (row0 + a) * D;
-                        float4 cv[8];
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) dst[h] = *reinterpret_cast<const float4*>(cr + min(32 * lr + 4 * h, D - 4));
+                    };
+                    fetch_c(0, cv[0]);
+#pragma unroll
+                    for (int i = 0; i < PSG; ++i) {
+                        if (i + 1 < PSG) fetch_c(i + 1, cv[(i + 1) & 1]);
+                        const float x = __expf(e2[i] - shift);
+                        e2[i] = x;
+                        ssum += x;
 #pragma unroll
                         for (int h = 0; h < 8; ++h) {
-                            const int d = 32 * lr + 4 * h;
-                            cv[h] = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
-                            if (d >= D) cv[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            float4 c4 = cv[i & 1][h];
+                            if (32 * lr + 4 * h >= D) c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            cx[h].x += x * c4.x; cx[h].y += x * c4.y; cx[h].z += x * c4.z; cx[h].w += x * c4.w;
                         }
-#pragma unroll
-                        for (int h = 0; h < 8; ++h) { cx[h].x += x * cv[h].x; cx[h].y += x * cv[h].y; cx[h].z += x * cv[h].z; cx[h].w += x * cv[h].w; }
                     }
                 }
                 if (lr == 0) sx[grow_] = ssum;
@@ -2238,21 +2249,33 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
                 for (int h = 0; h < 8; ++h) s2[h] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (has2) {
                     float dsc2[PSG];
-#pragma unroll
-                    for (int i = 0; i < PSG; ++i) {
+                    float4 xv[2][8];
+                    auto fetch_c = [&](int i, float4 (&dst)[8]) {
                         const int sl = grow_ + 16 * i;
                         const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
                         const float* cr = P.c3d + (row0 + a) * D;
-                        float4 cv[8];
 #pragma unroll
-                        for (int h = 0; h < 8; ++h) {
-                            const int d = 32 * lr + 4 * h;
-                            cv[h] = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
-                            if (d >= D) cv[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
+                        for (int h = 0; h < 8; ++h) dst[h] = *reinterpret_cast<const float4*>(cr + min(32 * lr + 4 * h, D - 4));
+                    };
+                    auto fetch_p = [&](int i, float4 (&dst)[8]) {
+                        const int sl = grow_ + 16 * i;
+                        const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
+                        const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) dst[h] = *reinterpret_cast<const float4*>(pr + 4 * h);
+                    };
+                    fetch_c(0, xv[0]);
+#pragma unroll
+                    for (int i = 0; i < PSG; ++i) {
+                        if (i + 1 < PSG) fetch_c(i + 1, xv[(i + 1) & 1]);
+                        else fetch_p(0, xv[(i + 1) & 1]);                  // the first P_all row rides behind the last C3D row
                         float dw = 0.f;
 #pragma unroll
-                        for (int h = 0; h < 8; ++h) dw += cv[h].x * da[h].x + cv[h].y * da[h].y + cv[h].z * da[h].z + cv[h].w * da[h].w;
+                        for (int h = 0; h < 8; ++h) {
+                            float4 c4 = xv[i & 1][h];
+                            if (32 * lr + 4 * h >= D) c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            dw += c4.x * da[h].x + c4.y * da[h].y + c4.z * da[h].z + c4.w * da[h].w;
+                        }
                         dw = row16_sum(dw);
                         dsc2[i] = wt2[i] * (dw - s0);
                     }
@@ -2263,21 +2286,18 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
                     }
 #pragma unroll
                     for (int i = 0; i < PSG; ++i) {
-                        const int sl = grow_ + 16 * i;
-                        const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
-                        const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
-                        float4 pv[8];
-#pragma unroll
-                        for (int h = 0; h < 8; ++h) pv[h] = *reinterpret_cast<const float4*>(pr + 4 * h);
+                        // slot i's P_all row sits in buffer (PSG + i) & 1 (slot 0 was fetched into buffer PSG & 1 above)
+                        if (i + 1 < PSG) fetch_p(i + 1, xv[(PSG + i + 1) & 1]);
 #pragma unroll
                         for (int h = 0; h < 8; ++h) {
+                            const float4 pv = xv[(PSG + i) & 1][h];
                             const float4 eq = make_float4(__expf(2.f * fminf(fmaxf(q[h].x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].y, -43.f), 43.f)),
                                                           __expf(2.f * fminf(fmaxf(q[h].z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].w, -43.f), 43.f)));
                             float r;
-                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv[h].x, -43.f), 43.f)), eq.x, 1.f)); s2[h].x += dsc2[i] * (r - r * r);
-                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv[h].y, -43.f), 43.f)), eq.y, 1.f)); s2[h].y += dsc2[i] * (r - r * r);
-                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv[h].z, -43.f), 43.f)), eq.z, 1.f)); s2[h].z += dsc2[i] * (r - r * r);
-                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv[h].w, -43.f), 43.f)), eq.w, 1.f)); s2[h].w += dsc2[i] * (r - r * r);
+                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), eq.x, 1.f)); s2[h].x += dsc2[i] * (r - r * r);
+                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)), eq.y, 1.f)); s2[h].y += dsc2[i] * (r - r * r);
+                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), eq.z, 1.f)); s2[h].z += dsc2[i] * (r - r * r);
+                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)), eq.w, 1.f)); s2[h].w += dsc2[i] * (r - r * r);
                         }
                     }
                 }
@@ -2388,6 +2408,11 @@ static bool side_stream(PersistHost& h) {
         if (!good) { (void)hipGetLastError(); h.side = nullptr; }
     }
     return h.side != nullptr;
+}
+
+void coop_refused(const char* who, const char* why) {
+    static bool said = false;
+    if (!said) { said = true; fprintf(stderr, "[libechr_hip] %s: cooperative launch refused (%s); falling back to the plain launch\n", who, why); }
 }
 
 // sticky asynchronous error of an earlier persistent launch (a bounded spin timed out): reported once, at the next library call
@@ -2520,11 +2545,10 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
             void* kargs[2] = {&K2, &K};
             const void* fn = big ? (config().persist_h2 ? reinterpret_cast<const void*>(dec_persist_fwd_kernel<true, true>) : reinterpret_cast<const void*>(dec_persist_fwd_kernel<false, true>))
                                  : (config().persist_h2 ? reinterpret_cast<const void*>(dec_persist_fwd_kernel<true, false>) : reinterpret_cast<const void*>(dec_persist_fwd_kernel<false, false>));
-            if (hipLaunchCooperativeKernel(fn, dim3(2 * HWG + 2 * NS), dim3(256), kargs, LDS_BYTES_FWD, st) != hipSuccess) {
-                set_error("persist_fwd: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
-                return -5;
-            }
-            return 0;
+            if (hipLaunchCooperativeKernel(fn, dim3(2 * HWG + 2 * NS), dim3(256), kargs, LDS_BYTES_FWD, st) == hipSuccess) return 0;
+            // the runtime refused the cooperative form (configuration / driver): say so once and use the plain launch, whose bounded waits
+            // still turn a co-residency problem into -ETIME rather than a hang
+            coop_refused("persist_fwd", hipGetErrorString(hipGetLastError()));
         }
         if (big) {
             if (config().persist_h2) hipLaunchKernelGGL((dec_persist_fwd_kernel<true, true>), dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K);
@@ -2602,11 +2626,8 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
         if (config().persist_coop) {
             void* kargs[2] = {&K2, &K};
             const void* fn = a->A > PSET2 ? reinterpret_cast<const void*>(dec_persist_bwd_kernel<true>) : reinterpret_cast<const void*>(dec_persist_bwd_kernel<false>);
-            if (hipLaunchCooperativeKernel(fn, dim3(2 * HWG + 2 * NS), dim3(256), kargs, LDS_BYTES_BWD, st) != hipSuccess) {
-                set_error("persist_bwd: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
-                return -5;
-            }
-            return 0;
+            if (hipLaunchCooperativeKernel(fn, dim3(2 * HWG + 2 * NS), dim3(256), kargs, LDS_BYTES_BWD, st) == hipSuccess) return 0;
+            coop_refused("persist_bwd", hipGetErrorString(hipGetLastError()));
         }
         if (a->A > PSET2) hipLaunchKernelGGL(dec_persist_bwd_kernel<true>, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_BWD, st, K2, K);
         else hipLaunchKernelGGL(dec_persist_bwd_kernel<false>, dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_BWD, st, K2, K);

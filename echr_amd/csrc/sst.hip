@@ -671,11 +671,8 @@ static int sst_persist_launch(K kernel, P& args, const char* what, hipStream_t s
     }
     if (config().persist_coop) {          // shared device: start only when all 64 workgroups can be resident (see persist.hip)
         void* kargs[1] = {&args};
-        if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3(SP_WG), dim3(256), kargs, lds, st) != hipSuccess) {
-            set_error("%s: cooperative launch failed: %s", what, hipGetErrorString(hipGetLastError()));
-            return -5;
-        }
-        return 0;
+        if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3(SP_WG), dim3(256), kargs, lds, st) == hipSuccess) return 0;
+        coop_refused(what, hipGetErrorString(hipGetLastError()));
     }
     hipLaunchKernelGGL(kernel, dim3(SP_WG), dim3(256), lds, st, args);
     return check_launch(what);
