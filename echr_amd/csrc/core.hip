@@ -513,27 +513,68 @@ __global__ void event_gather_bwd_kernel(const float* __restrict__ d_ech, const i
 
 // ---- greedy arg-max over logits rows: lowest index on ties (torch.max semantics, OldModel_NEW.py:158) ---
 // Updates the sampler state: it_next[n] (int32), unfinished[n], seq/seq_logp column, n_unfinished counter.
-// slabs != nullptr: the row is first formed from the four k-slice slabs of the logits product, ((S0 + S1) + (S2 + S3)) + bias in that fixed
+// slabs != nullptr: the row is first formed from the nslab k-slice slabs of the logits product, four at a time in slab order, + bias -- one fixed
 // order (bitwise reproducible), and written to `logits` by the thread that scans it -- the separate slab-sum launch of every decoder step folded in
+template <int EPT>          // EPT > 0: the row is held in registers (V1 <= 256 EPT; every load of the thread in flight at once); 0: any V1, streamed
 __global__ __launch_bounds__(256) void greedy_step_kernel(float* __restrict__ logits, long ld, int V1, int t, int seq_len,
                                                           int* __restrict__ it_next, int* __restrict__ unfinished,
                                                           long long* __restrict__ seq, float* __restrict__ seq_logp,
                                                           int* __restrict__ n_unfinished, const float* __restrict__ slabs, long slab_stride,
-                                                          const float* __restrict__ bias) {
+                                                          const float* __restrict__ bias, int nslab) {
     __shared__ float red[4];
     __shared__ int redi[4];
     const int n = blockIdx.x;
     float* x = logits + (long)n * ld;
     float m = -INFINITY;
     int mi = 0x7fffffff;
-    for (int j = threadIdx.x; j < V1; j += 256) {
-        float v;
+    float rv[EPT > 0 ? EPT : 1];
+    if (EPT > 0) {
+        // a strided scan with one load per iteration is a chain of ~20 dependent memory latencies (measured 19.5 us per step at V1 = 5001);
+        // with the row in registers the loads overlap
         if (slabs) {
-            const float* sp = slabs + (long)n * V1 + j;
-            v = ((sp[0] + sp[slab_stride]) + (sp[2 * slab_stride] + sp[3 * slab_stride])) + (bias ? bias[j] : 0.f);
-            x[j] = v;
-        } else v = x[j];
-        if (v > m) { m = v; mi = j; }   // ascending j per thread: first maximum kept
+            // nslab (a multiple of four) k-slice slabs added four at a time in slab order, then the bias: rounds of four slabs' loads in flight
+            float s0[EPT > 0 ? EPT : 1], s1[EPT > 0 ? EPT : 1], s2[EPT > 0 ? EPT : 1], s3[EPT > 0 ? EPT : 1];
+            for (int sb = 0; sb < nslab; sb += 4) {
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int j = threadIdx.x + 256 * i;
+                    const float* sp = slabs + (long)sb * slab_stride + (long)n * V1 + (j < V1 ? j : 0);
+                    s0[i] = sp[0]; s1[i] = sp[slab_stride]; s2[i] = sp[2 * slab_stride]; s3[i] = sp[3 * slab_stride];
+                }
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const float part = (s0[i] + s1[i]) + (s2[i] + s3[i]);
+                    rv[i] = sb == 0 ? part : rv[i] + part;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) { const int j = threadIdx.x + 256 * i; rv[i] += bias ? bias[j < V1 ? j : 0] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) { const int j = threadIdx.x + 256 * i; if (j < V1) x[j] = rv[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) { const int j = threadIdx.x + 256 * i; rv[i] = x[j < V1 ? j : 0]; }
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int j = threadIdx.x + 256 * i;
+            if (j < V1 && rv[i] > m) { m = rv[i]; mi = j; }   // ascending j per thread: first maximum kept
+        }
+    } else {
+        for (int j = threadIdx.x; j < V1; j += 256) {
+            float v;
+            if (slabs) {
+                v = 0.f;
+                for (int sb = 0; sb < nslab; sb += 4) {
+                    const float* sp = slabs + (long)sb * slab_stride + (long)n * V1 + j;
+                    const float part = (sp[0] + sp[slab_stride]) + (sp[2 * slab_stride] + sp[3 * slab_stride]);
+                    v = sb == 0 ? part : v + part;
+                }
+                v += bias ? bias[j] : 0.f;
+                x[j] = v;
+            } else v = x[j];
+            if (v > m) { m = v; mi = j; }   // ascending j per thread: first maximum kept
+        }
     }
     // wave arg-max with (value, lowest index) ordering
     for (int off = 32; off > 0; off >>= 1) {
@@ -549,7 +590,12 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(float* __restrict__ lo
     for (int w = 1; w < 4; ++w)
         if (red[w] > bm || (red[w] == bm && redi[w] < bi)) { bm = red[w]; bi = redi[w]; }
     float s = 0.f;
-    for (int j = threadIdx.x; j < V1; j += 256) s += expf(x[j] - bm);
+    if (EPT > 0) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) if (threadIdx.x + 256 * i < V1) s += expf(rv[i] - bm);      // same order of additions as the streamed form
+    } else {
+        for (int j = threadIdx.x; j < V1; j += 256) s += expf(x[j] - bm);
+    }
     s = block_sum(s, red);
     if (threadIdx.x == 0) {
         // step t produced logits(t); the token fed at step t+1 is argmax -> sample position t (0-based)
@@ -687,9 +733,13 @@ int sample_step(const float* logits, long ld, int N, int V1, int t, int seq_len,
 }
 
 int greedy_step(float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
-                long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st, const float* slabs, long slab_stride, const float* bias) {
-    hipLaunchKernelGGL(greedy_step_kernel, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq, seq_logp, n_unfinished,
-                       slabs, slab_stride, bias);
+                long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st, const float* slabs, long slab_stride, const float* bias, int nslab) {
+    if (V1 <= 256 * 8) hipLaunchKernelGGL(greedy_step_kernel<8>, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq, seq_logp,
+                                          n_unfinished, slabs, slab_stride, bias, nslab);
+    else if (V1 <= 256 * 20) hipLaunchKernelGGL(greedy_step_kernel<20>, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq,
+                                                seq_logp, n_unfinished, slabs, slab_stride, bias, nslab);
+    else hipLaunchKernelGGL(greedy_step_kernel<0>, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq, seq_logp,
+                            n_unfinished, slabs, slab_stride, bias, nslab);
     return check_launch("greedy_step");
 }
 

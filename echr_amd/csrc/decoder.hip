@@ -526,6 +526,7 @@ struct RecJob {
     float* P; long slab_stride; long ldp;
     int atomic;      // 1: all k-slices add atomically into ONE pre-zeroed slab (for outputs that many workgroups re-read,
                      //    where summing slabs in every consumer would multiply the traffic); order-dependent last bits
+    const int* rowidx;   // optional row gather: row m of the A operand is A[rowidx[m]] (the sampler's embedding rows by token id)
 };
 struct RecArgs { RecJob job[MAXJOBS]; int njobs; int M; };
 
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
         const int row = f / RQ, kq = (f % RQ) * 4;
         const int kk = min(k0 + kq, J.K - 4);
         const int ra = min(m0 + row, args.M - 1), rbn = min(n0 + row, J.Nout - 1);
-        va[p] = *reinterpret_cast<const float4*>(J.A + (long)ra * J.lda + kk);
+        va[p] = *reinterpret_cast<const float4*>(J.A + (long)(J.rowidx ? J.rowidx[ra] : ra) * J.lda + kk);
         vb[p] = *reinterpret_cast<const float4*>(J.B + (long)rbn * J.ldb + kk);
     }
 #pragma unroll
@@ -633,6 +634,9 @@ struct LstmPtrs {
     const float* c_prev[3];
     float* c_new[3];
     int kmap[3];              // blockIdx.y -> stream index (lets a launch cover a subset of the streams)
+    // optional (sampler): time-invariant part of the pre-activation read from base[k] + (n % bmod[k]) * 4H (+ base2[k], a [4H] vector) instead
+    // of from `gates` -- the token-side products then arrive as slabs like the recurrent ones, and no per-step input-gate GEMM runs
+    const float* base[3]; const float* base2[3]; int bmod[3];
 };
 
 __global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(LstmPtrs P, float* __restrict__ h_out, float* __restrict__ outd,
@@ -642,7 +646,12 @@ __global__ __launch_bounds__(256) void lstm_pointwise_fwd_kernel(LstmPtrs P, flo
     const int k = P.kmap[blockIdx.y];
     const int n = idx / H, j = idx % H;
     float* g = P.gates[k] + (long)n * 4 * H;
-    float pi = g[j], pf = g[H + j], pg = g[2 * H + j], po = g[3 * H + j];
+    float pi, pf, pg, po;
+    if (P.base[k]) {
+        const float* bq = P.base[k] + (long)(n % P.bmod[k]) * 4 * H;
+        pi = bq[j]; pf = bq[H + j]; pg = bq[2 * H + j]; po = bq[3 * H + j];
+        if (P.base2[k]) { const float* b2 = P.base2[k]; pi += b2[j]; pf += b2[H + j]; pg += b2[2 * H + j]; po += b2[3 * H + j]; }
+    } else { pi = g[j]; pf = g[H + j]; pg = g[2 * H + j]; po = g[3 * H + j]; }
     const float* sl = P.slab[k] + (long)n * 4 * H;
     for (int s = 0; s < P.nslab[k]; ++s) {
         const float* q = sl + s * P.slab_stride;
@@ -728,8 +737,9 @@ static DecWs carve_ws(const echr_dec_args* a, float* base) {
     w.nq = ksplit_of(a->H);
     w.QSL = take((long)w.nq * N * a->Ha);
     w.QACC = take(S * N * a->Ha);
-    w.ng[0] = w.ng[2] = ksplit_of(a->H);
-    w.ng[1] = ksplit_of(a->H) + ksplit_of(a->D);
+    // slabs per stream: W_hh . h, (stream 1: W_ih1[:, E:] . ctx), and -- sampler only -- the token-side product W_ih[:, :E] . embed(token)
+    w.ng[0] = w.ng[2] = ksplit_of(a->H) + ksplit_of(a->E);
+    w.ng[1] = ksplit_of(a->H) + ksplit_of(a->D) + ksplit_of(a->E);
     for (int k = 0; k < 3; ++k) w.GSL[k] = take((long)w.ng[k] * N * 4 * H);
     w.PK_C3D = take(h2_floats(a->Tv, a->D));
     w.PK_WC = take(h2_floats(a->Ha, a->D));
@@ -813,7 +823,7 @@ static int check_dims(const echr_dec_args* a, const char* who) {
 static RecJob mkjob(const float* A, long lda, int K, const float* B, long ldb, int Nout, float* P, long slab_stride, long ldp,
                     int atomic = 0) {
     RecJob j; j.A = A; j.lda = lda; j.K = K; j.B = B; j.ldb = ldb; j.Nout = Nout; j.P = P; j.slab_stride = slab_stride; j.ldp = ldp;
-    j.atomic = atomic;
+    j.atomic = atomic; j.rowidx = nullptr;
     return j;
 }
 
@@ -870,7 +880,7 @@ __global__ __launch_bounds__(256) void add_bcast_rows_kernel(float* __restrict__
 // `chain`: 0 = all three streams in this call; 1 = only stream 1 (the attention chain); 2 = only streams 0 and 2 (pure LSTM
 // recurrences, independent of the attention chain -> they can run on a second HIP stream, see echr_decoder_fwd).
 static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg& dh, const DropCfg& dout, hipStream_t st, int chain = 0,
-                    bool q_atomic = false) {
+                    bool q_atomic = false, const int* tok = nullptr) {
     const int N = a->N, H = a->H, Ha = a->Ha, A = a->A, D = a->D, E = a->E;
     const float* hprev = w.HS + (long)t * N * 3 * H;          // [N,3H] dropped h of step t-1 (zeros at t=0)
     const long gs = (long)N * 4 * H, qs = (long)N * Ha;
@@ -889,6 +899,17 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
         if (k == 1 ? do1 : do02)
             ra.job[ra.njobs++] = gacc ? mkjob(hprev + k * H, 3 * H, H, a->w_hh[k], H, 4 * H, w.GATES[k] + (long)t * gs, gs, 4 * H, 1)
                                       : mkjob(hprev + k * H, 3 * H, H, a->w_hh[k], H, 4 * H, w.GSL[k], gs, 4 * H);
+    const int ne = ksplit_of(E), nd = ksplit_of(D);
+    if (tok) {
+        // sampler, few events: the token-side products W_ih_k[:, :E] . embed(token) ride in the same launch (A rows gathered from the embedding
+        // table by token id); their k-slices are slabs behind the stream's other slabs, summed by the gate kernel in a fixed order
+        for (int k = 0; k < 3; ++k) {
+            const int cin_k = E + (k == 0 ? a->De : (k == 1 ? D : a->Dv));
+            RecJob j = mkjob(a->embed, E, E, a->w_ih[k], cin_k, 4 * H, w.GSL[k] + (long)(nh + (k == 1 ? nd : 0)) * gs, gs, 4 * H);
+            j.rowidx = tok;
+            ra.job[ra.njobs++] = j;
+        }
+    }
     RC(rec_gemm(ra, st));
     if (do1) {
         float* q = w.QS + (long)t * N * Ha;
@@ -915,7 +936,13 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
     for (int k = 0; k < 3; ++k) {
         P.gates[k] = w.GATES[k] + (long)t * N * 4 * H;
         P.slab[k] = w.GSL[k];
-        P.nslab[k] = gacc ? 0 : w.ng[k];
+        P.nslab[k] = gacc ? 0 : (nh + (k == 1 ? nd : 0) + (tok ? ne : 0));
+        P.base[k] = nullptr; P.base2[k] = nullptr; P.bmod[k] = 1;
+        if (tok) {
+            if (k == 0) { P.base[k] = w.EVB0; P.bmod[k] = N; }
+            else if (k == 1) { P.base[k] = a->b_ih[1]; P.base2[k] = a->b_hh[1]; }
+            else P.base[k] = w.VIDB;
+        }
         P.c_prev[k] = w.CS[k] + (long)t * N * H;
         P.c_new[k] = w.CS[k] + (long)(t + 1) * N * H;
         P.kmap[k] = 0;
@@ -1401,7 +1428,14 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
 // greedy sampler (OldModel_NEW.py:139-187, sample_max = 1, eval mode): every step on device
 // ------------------------------------------------------------------------------------------------------
 struct SampWs { float* XT; float* LOGITS; int *IT, *UNF; float* SLABS; long total; };
-constexpr int SAMP_SLABS = 4;       // k-slices of the per-step logits product when its output grid is small (summed in a fixed order)
+// few events (N < SAMP_SLAB_ROWS): one k loop per tile of the per-step logits product would be 48 k blocks deep on 79 workgroups; its K is cut into
+// SAMP_SLABS slices that run as a strided batch into slabs (plain stores), and the arg-max kernel adds the slabs in a fixed order (bitwise
+// reproducible).  Measured alternatives at N = 64 (1 GF, 30.7 MB of weights per step): 8 slices 20 us, 12 slices on the recurrence's grouped
+// skinny-GEMM kernel 21 us, 4 slices 23 us -- the product sits at the fp32-MFMA + weight-streaming floor of ~15 us either way; 4 slices write
+// the fewest slab bytes
+constexpr int SAMP_SLAB_ROWS = 192;
+constexpr int SAMP_SLABS = 4;
+static inline int samp_slabs(const echr_dec_args* a) { (void)a; return SAMP_SLABS; }
 static SampWs carve_samp(const echr_dec_args* a, float* base) {
     SampWs s;
     long off = 0;
@@ -1410,17 +1444,23 @@ static SampWs carve_samp(const echr_dec_args* a, float* base) {
     s.LOGITS = take((long)a->N * a->V1);
     s.IT = reinterpret_cast<int*>(take(a->N));
     s.UNF = reinterpret_cast<int*>(take(a->N));
-    s.SLABS = take((long)SAMP_SLABS * a->N * a->V1);
+    s.SLABS = take(a->N < SAMP_SLAB_ROWS ? (long)((samp_slabs(a) + 3) / 4 * 4) * a->N * a->V1 : 64);
     s.total = off;
     return s;
 }
 
-// LOGITS = ((S0 + S1) + (S2 + S3)) + bias: the k-slices of the logits product in one fixed order (bitwise reproducible, unlike atomics)
-__global__ __launch_bounds__(256) void slab_sum_bias_kernel(const float* __restrict__ slabs, long slab_stride, const float* __restrict__ bias,
+// LOGITS = (...((S0 + S1) + (S2 + S3)) + ((S4 + S5) + (S6 + S7)) ...) + bias: the k-slices of the logits product in groups of four, one fixed
+// order (bitwise reproducible, unlike atomics); nslab is a multiple of 4 (spare slabs are zero)
+__global__ __launch_bounds__(256) void slab_sum_bias_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, const float* __restrict__ bias,
                                                             float* __restrict__ out, long n, int V1) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float v = (slabs[i] + slabs[slab_stride + i]) + (slabs[2 * slab_stride + i] + slabs[3 * slab_stride + i]);
+    float v = 0.f;
+    for (int s0 = 0; s0 < nslab; s0 += 4) {
+        const float* sp = slabs + (long)s0 * slab_stride + i;
+        const float part = (sp[0] + sp[slab_stride]) + (sp[2 * slab_stride] + sp[3 * slab_stride]);
+        v = s0 == 0 ? part : v + part;
+    }
     out[i] = v + (bias ? bias[i % V1] : 0.f);
 }
 extern "C" int64_t echr_sampler_ws_floats(const echr_dec_args* a) { return a ? carve_samp(a, nullptr).total : -1; }
@@ -1448,13 +1488,20 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
     // many events (evaluation: up to 1000 proposals): the per-step token-side gate products and the logits product are 6 + 15 GF -- they run
     // on h2 operands (weights packed once per decode, the step's N rows packed per step; one fixed-order k loop per tile, so the decode stays
     // bitwise reproducible).  Few events: exact fp32 MFMA as before (the products are launch-bound there).
-    const bool big = config().gemm_h2 && N >= 192;
+    const bool big = config().gemm_h2 && N >= SAMP_SLAB_ROWS;
     RC(precompute_static(&a, w, st, big));
+    const int nsl = samp_slabs(&a), nsl4 = (nsl + 3) / 4 * 4;          // slabs are added four at a time: the spare ones stay zero
+    if (N < SAMP_SLAB_ROWS && nsl4 > nsl) RC(fill_zero(s.SLABS + (long)nsl * N * a.V1, (long)(nsl4 - nsl) * N * a.V1, st));
     for (int t = 0; t < L; ++t) {
-        RC(embed_gather(a.embed, s.IT, s.XT, N, E, a.V1, st));
-        RC(input_gates(&a, w, s.XT, t, 1, st, false, big));
-        RC(step_fwd(&a, w, t, off, off, st));
-        const long tiles = (long)((N + 63) / 64) * ((a.V1 + 63) / 64);
+        if (big) {
+            RC(embed_gather(a.embed, s.IT, s.XT, N, E, a.V1, st));
+            RC(input_gates(&a, w, s.XT, t, 1, st, false, true));
+            RC(step_fwd(&a, w, t, off, off, st));
+        } else {
+            // few events: no embedding gather, no input-gate GEMM -- the token-side products are jobs of the step's first grouped launch
+            // (rows gathered from the embedding table by token id), the time-invariant addends are read by the gate kernel
+            RC(step_fwd(&a, w, t, off, off, st, 0, false, s.IT));
+        }
         bool slab_form = false;
         if (big) {
             H2PackJob pj = pack_rows(w.OUTD + (long)t * N * 3 * H, 3 * H, N, 3 * H, w.PK_OUTD);
@@ -1462,9 +1509,7 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
             echr_gemm_desc d = desc_h2(w.PK_OUTD, w.PK_WL, s.LOGITS, a.V1, N, a.V1, 3 * H);
             d.bias = a.b_logit; d.split_k = 1;
             RC(gemm(d, st));
-        } else if (tiles < 400 && (3 * H) % (SAMP_SLABS * 32) == 0) {
-            // few rows: one k loop per tile would be 48 k blocks deep on 79 workgroups.  Four k-slices as a strided batch into four
-            // slabs (plain stores), then one fixed-order sum: still bitwise reproducible, a third of the time
+        } else if (N < SAMP_SLAB_ROWS && (3 * H) % (SAMP_SLABS * 32) == 0) {
             const int ksl = 3 * H / SAMP_SLABS;
             echr_gemm_desc d = desc_nt(w.OUTD + (long)t * N * 3 * H, 3 * H, a.w_logit, 3 * H, s.SLABS, a.V1, N, a.V1, ksl);
             d.batch = SAMP_SLABS; d.bsa = ksl; d.bsb = ksl; d.bsc = (long)N * a.V1; d.split_k = 1;
@@ -1472,7 +1517,7 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
             slab_form = true;
             if (sa->multinomial) {         // the multinomial step reads finished logits: sum the slabs first (the greedy step folds the sum in)
                 const long n = (long)N * a.V1;
-                hipLaunchKernelGGL(slab_sum_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.SLABS, n, a.b_logit, s.LOGITS, n, a.V1);
+                hipLaunchKernelGGL(slab_sum_bias_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.SLABS, n, nsl4, a.b_logit, s.LOGITS, n, a.V1);
                 RC(check_launch("slab_sum_bias"));
             }
         } else {
@@ -1485,7 +1530,7 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
                            sa->temperature, sa->seed, st));
         else
             RC(greedy_step(s.LOGITS, a.V1, N, a.V1, t, L, s.IT, s.UNF, reinterpret_cast<long long*>(sa->seq), sa->seq_logp,
-                           sa->n_unfinished, st, slab_form ? s.SLABS : nullptr, (long)N * a.V1, a.b_logit));
+                           sa->n_unfinished, st, slab_form ? s.SLABS : nullptr, (long)N * a.V1, a.b_logit, nsl4));
     }
     return 0;
 }

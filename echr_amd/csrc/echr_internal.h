@@ -125,6 +125,6 @@ int sample_step(const float* logits, long ld, int N, int V1, int t, int seq_len,
 // slabs != nullptr: logits rows are formed here from four k-slice slabs (+ bias) in a fixed order and written to `logits`
 int greedy_step(float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished,
                 long long* seq, float* seq_logp, int* n_unfinished, hipStream_t st, const float* slabs = nullptr, long slab_stride = 0,
-                const float* bias = nullptr);
+                const float* bias = nullptr, int nslab = 0);
 
 }  // namespace echr
