@@ -289,8 +289,17 @@ __global__ void sum_over_time_kernel(const float* __restrict__ X, long ld, int S
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)N * cols) return;
     const int n = (int)(idx / cols), j = (int)(idx % cols);
+    // eight rows' loads in flight per round (one load per iteration is a chain of S dependent memory latencies); same order of additions
     float s = 0.f;
-    for (int t = 0; t < S; ++t) s += X[((long)t * N + n) * ld + j];
+    int t = 0;
+    for (; t + 8 <= S; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = X[((long)(t + u) * N + n) * ld + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; t < S; ++t) s += X[((long)t * N + n) * ld + j];
     out[(long)n * ld_out + j] = s;
 }
 int sum_over_time(const float* X, long ld, int S, int N, int cols, float* out, long ld_out, hipStream_t st) {
@@ -437,11 +446,21 @@ __global__ __launch_bounds__(256) void nll_loss_kernel(const float* __restrict__
                                                        const float* __restrict__ mask, float* __restrict__ out, int NS, int V1) {
     __shared__ float red[4];
     float s = 0.f, ms = 0.f;
-    for (int i = threadIdx.x; i < NS; i += 256) {
-        const float mk = mask[i];
-        int tg = min(max(load_index(target, i, tgt64), 0), V1 - 1);
-        s -= logp[(long)i * V1 + tg] * mk;
-        ms += mk;
+    // four rows per round: targets and masks first, then the four gathered log-probs in flight together (the gather depends on its target:
+    // one row per iteration is a chain of 2 NS / 256 dependent latencies on the forward's critical path); same order of additions
+    for (int i0 = threadIdx.x; i0 < NS; i0 += 1024) {
+        float mk[4], lv[4];
+        int tg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            mk[u] = i < NS ? mask[i] : 0.f;
+            tg[u] = i < NS ? min(max(load_index(target, i, tgt64), 0), V1 - 1) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + 256 * u; lv[u] = i < NS ? logp[(long)i * V1 + tg[u]] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + 256 * u < NS) { s -= lv[u] * mk[u]; ms += mk[u]; }
     }
     s = block_sum(s, red);
     ms = block_sum(ms, red);
