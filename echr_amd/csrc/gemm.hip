@@ -939,6 +939,100 @@ int h2_pack(const float* src, int rows, int cols, long s_row, long s_col, void* 
     return h2_pack_multi(&j, 1, st);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Native fp32 product for LARGE NT problems (both operands k-contiguous, 16-byte aligned rows): 128 x 128 tile, 4 waves of 64 x 64
+// (2 x 2 v_mfma_f32_32x32x2_f32 tiles), BK = 32, two LDS stages [row][32 + 4] (one barrier per k block: the next block's global loads are in
+// flight during the MFMAs and land in the other stage), fragment reads as ds_read_b128 -- lane (r, kh) takes 4 consecutive k of its row, element
+// j feeds MFMA j of the chunk, A and B use the same k pairing.  The 64 x 64 tile of gemm_f32_kernel needs 32 KB of operand per 0.26 MFLOP and is
+// bound by the CU's L2 -> LDS ingest (~50 GB/s) at 60-88 TF/s on the large shapes; this tile halves the bytes per flop.  Exact fp32 (k-ordered
+// fma chains per slice), same epilogue as gemm_f32_kernel.  Used when the h2 / bf16x3 paths are off (`native_f32` figure of bench.py).
+// ------------------------------------------------------------------------------------------------------
+constexpr int N128_LD = BK + 4;                         // floats per LDS row: 16-byte aligned, conflict-free b128 fragment reads (as rec_gemm)
+constexpr int N128_STAGE = 2 * 128 * N128_LD;           // floats per stage (A tile | B tile)
+__global__ __launch_bounds__(256, 2) void gemm_f32_nt128_kernel(GemmParams pin) {
+    extern __shared__ __attribute__((aligned(16))) float nsm[];
+    int z = blockIdx.z;
+    const GemmParams p = select_group(pin, z);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware tile order (see gemm_f32_kernel)
+        int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int m0 = (bid / p.tiles_n) * 128, n0 = (bid % p.tiles_n) * 128;
+    const int b = z / p.split_k, ks = z % p.split_k;
+    const float* A = p.A + (long)b * p.bsa;
+    const float* B = p.B + (long)b * p.bsb;
+    float* C = p.C + (long)b * p.bsc;
+    const int kt_total = (p.K + BK - 1) / BK;
+    const int kt0 = ks * p.k_tiles_per_split, kt1 = min(kt_total, kt0 + p.k_tiles_per_split);
+    const int kend = min(p.K, kt1 * BK);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // staging: thread -> (row = f >> 3, 4 k at 4 (f & 7)) for f = tid + 256 i, i < 4, per operand; rows beyond M / N are clamped (their
+    // products land in output rows / columns the epilogue does not store), k beyond the slice is zero-filled
+    float4 ra[4], rb[4];
+    auto fetch = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, k = k0 + 4 * (f & 7);
+            const int kk = min(k, p.K - 4);
+            ra[i] = *reinterpret_cast<const float4*>(A + (long)min(m0 + row, p.M - 1) * p.sam + kk);
+            rb[i] = *reinterpret_cast<const float4*>(B + (long)min(n0 + row, p.N - 1) * p.sbn + kk);
+            if (k >= kend) { ra[i] = make_float4(0.f, 0.f, 0.f, 0.f); rb[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+    };
+    auto stash = [&](int stage) {
+        float* As = nsm + stage * N128_STAGE;
+        float* Bs = As + 128 * N128_LD;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, kq = 4 * (f & 7);
+            *reinterpret_cast<float4*>(As + row * N128_LD + kq) = ra[i];
+            *reinterpret_cast<float4*>(Bs + row * N128_LD + kq) = rb[i];
+        }
+    };
+    const int l31 = lane & 31, kh = lane >> 5;
+    if (kt0 < kt1) { fetch(kt0); stash(0); }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int st = (kt - kt0) & 1;
+        if (kt + 1 < kt1) fetch(kt + 1);                         // in flight during the MFMAs below
+        const float* As = nsm + st * N128_STAGE;
+        const float* Bs = As + 128 * N128_LD;
+        const float* ap = As + (wm + l31) * N128_LD + 4 * kh;
+        const float* bp = Bs + (wn + l31) * N128_LD + 4 * kh;
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            float4 a4[2], b4[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a4[i] = *reinterpret_cast<const float4*>(ap + i * 32 * N128_LD + 8 * c);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b4[j] = *reinterpret_cast<const float4*>(bp + j * 32 * N128_LD + 8 * c);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < kt1) stash(st ^ 1);                         // the other stage was last read before the previous barrier
+        __syncthreads();
+    }
+    epilogue<2, 2>(p, acc, C, b, ks, m0, n0, wm, wn, lane);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(const GemmParams& p, bool akc, bool bkc, dim3 grid, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -1022,6 +1116,13 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     const int env_split = config().gemm_split;
     if (h2) { BMs = env_h2_bm; BNs = 128; }
     if (use_split) { BMs = 128; BNs = ((long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch >= 96) ? 128 : 64; }
+    // large exact-fp32 NT products: the 128 x 128 double-buffered kernel (gemm_f32_nt128_kernel) once its tiles fill most of the chip's 512
+    // workgroup slots (measured, tools/nt128_bench.py: 4096^3 129 vs 107 TF/s, logits 87 vs 80, d W_logit 108 vs 93; with fewer tiles --
+    // 160 for the token-side gates, 120 for d OUTD -- the 64 x 64 tile's finer grain wins: 38 vs 71, 71 vs 89 TF/s)
+    static const int nt128_on = getenv("ECHR_GEMM_NT128") ? atoi(getenv("ECHR_GEMM_NT128")) : 1;
+    const bool nt128 = nt128_on && !h2 && !use_split && akc && bkc && p.vecA && p.vecB && d.K % 4 == 0 && d.K >= 64 && !tile_code &&
+                       (long)((maxM + 127) / 128) * ((maxN + 127) / 128) * d.batch * ng >= 384;
+    if (nt128) { BMs = 128; BNs = 128; }
     if (tile_code) {          // tuning override (tools/gemm_bench.py); never set in production
         const char e0 = tile_code;
         if (e0 == '1') { BMs = 128; BNs = 128; } else if (e0 == '6') { BMs = 64; BNs = 64; }
@@ -1059,8 +1160,8 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
                     if (t < best) { best = t; split = sp; }
                 }
             }
-        } else if (d.act == ECHR_ACT_NONE && wgs < (use_split ? 200 : 512) && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
-            split = (int)min((long)kt_total, max(1L, ((use_split ? 400 : 1024) + wgs - 1) / max(wgs, 1L)));
+        } else if (d.act == ECHR_ACT_NONE && wgs < (use_split ? 200 : (nt128 ? 256 : 512)) && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
+            split = (int)min((long)kt_total, max(1L, ((use_split ? 400 : (nt128 ? 512 : 1024)) + wgs - 1) / max(wgs, 1L)));
             if (split > 1 && kt_total / split < 4) split = max(1, kt_total / 4);
         }
     }
@@ -1137,6 +1238,14 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
         else if (ns_sel >= 4) hipLaunchKernelGGL((gemm_h2_kernel<128, 32, 4>), grid, dim3(512), 4 * ST128, st, p);
         else if (ns_sel == 3) hipLaunchKernelGGL((gemm_h2_kernel<128, 32, 3>), grid, dim3(512), 3 * ST128, st, p);
         else hipLaunchKernelGGL((gemm_h2_kernel<128, 32, 2>), grid, dim3(512), 2 * ST128, st, p);
+    }
+    else if (nt128) {
+        static bool attr128 = false;
+        if (!attr128) {
+            attr128 = true;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_nt128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * N128_STAGE * (int)sizeof(float));
+        }
+        hipLaunchKernelGGL(gemm_f32_nt128_kernel, grid, dim3(256), 2 * N128_STAGE * sizeof(float), st, p);
     }
     else if (use_split && BNs == 128) hipLaunchKernelGGL(gemm_split_kernel<128>, grid, dim3(512), 0, st, p);
     else if (use_split) hipLaunchKernelGGL(gemm_split_kernel<64>, grid, dim3(256), 0, st, p);

@@ -30,7 +30,9 @@ def test_library_loaded_on_gpu():
 
 @pytest.mark.parametrize('M,N,K,trans_b', [(64, 64, 32, True), (130, 70, 100, True), (1280, 513, 1536, True),
                                            (64, 2048, 512, True), (200, 96, 500, False), (5, 7, 3, True),
-                                           (257, 5001, 64, True), (64, 500, 2048, False)])
+                                           (257, 5001, 64, True), (64, 500, 2048, False),
+                                           # large NT shapes: the 128 x 128 double-buffered kernel (ragged M / N, K tail, K = 500)
+                                           (1280, 5001, 1536, True), (1300, 1537, 500, True), (4100, 1536, 1284, True), (8192, 512, 500, True)])
 def test_gemm_f32(M, N, K, trans_b):
     from echr_amd import functional as EF
     rs = np.random.RandomState(M * 7 + N)
