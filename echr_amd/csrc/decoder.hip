@@ -1107,13 +1107,14 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
 }
 
 // d W_logit = DLG^T . OUTD (plain overwrite) and d b_logit on packed operands that the caller has prepared
-static int logit_grads(const echr_dec_args* a, const echr_dec_grads* g, const DecWs& w, const DecWsBwd& b, bool z, hipStream_t st) {
+// bias_too = false: the caller folds the column sum of DLG (d b_logit) into a later multi-problem column-sum launch
+static int logit_grads(const echr_dec_args* a, const echr_dec_grads* g, const DecWs& w, const DecWsBwd& b, bool z, hipStream_t st, bool bias_too = true) {
     (void)w;
     const int SN = a->S * a->N;
     echr_gemm_desc d = desc_h2(b.PK_DLGT, b.PK_OUTDT, g->g_w_logit, 3 * a->H, a->V1, 3 * a->H, SN);
     d.split_k = 1;                         // one k slice per tile: a plain overwrite, no read of the (zeroed or stale) 30 MB buffer
     RC(gemm(d, st));
-    return colsum(b.DLG, b.ldg, SN, a->V1, g->g_b_logit, z, st);
+    return bias_too ? colsum(b.DLG, b.ldg, SN, a->V1, g->g_b_logit, z, st) : 0;
 }
 
 extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream) {
@@ -1364,6 +1365,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     // stream order, so the default stays the later fork (part A first)
     const bool async_tail = g->phase == 0 && g->async_tail != 0 && tail().ok && !ov && do_pb;
     hipStream_t sm = st;              // the caller's stream
+    bool bias_pending = false;
     auto part_b = [&]() -> int {
     if (!do_pb) return 0;
     if (async_tail) {
@@ -1372,7 +1374,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         if (h2) {          // the logit-layer gradients deferred above
             H2PackJob pj[2] = {pack_cols(b.DLG, b.ldg, V1, SN, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SN, b.PK_OUTDT)};
             RC(h2_pack_multi(pj, 2, st));
-            RC(logit_grads(a, g, w, b, z, st));
+            RC(logit_grads(a, g, w, b, z, st, !z));          // z: d b_logit rides in the multi-problem column-sum launch behind att_post
+            bias_pending = z;
         }
     }
     // 5. part B: attention parameters (d P_all / d alpha over all timesteps, then ctx2att) and the token embedding
@@ -1381,8 +1384,16 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     const AttDims ad{N, A, Ha, D};
     RC(launch_att_post(ad, w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, b.GAREP, b.GBREP, S, a->rows_disjoint ? 1 : 0, st));
     }
+    if (z) {
+        // accumulate mode: the replicas -> d alpha, d b_alpha, the ctx2att bias gradient (column sums of d P_all) and -- when the logit-layer
+        // gradients were formed on this stream just before -- d b_logit: ONE multi-problem launch instead of four
+        ColsumJob cj[4] = {{b.GAREP, Ha, ALPHA_REP, Ha, g->g_w_alpha, nullptr, nullptr}, {b.GBREP, 1, ALPHA_REP, 1, g->g_b_alpha, nullptr, nullptr},
+                           {b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, nullptr, nullptr}, {b.DLG, b.ldg, SN, V1, g->g_b_logit, nullptr, nullptr}};
+        RC(colsum_multi(cj, bias_pending ? 4 : 3, st));
+    } else {
     RC(colsum(b.GAREP, Ha, ALPHA_REP, Ha, g->g_w_alpha, z, st));        // replicas -> d alpha, d b_alpha (overwrite or accumulate like every
     RC(colsum(b.GBREP, 1, ALPHA_REP, 1, g->g_b_alpha, z, st));          // other parameter gradient)
+    }
     if (h2) {
         H2PackJob pj[2] = {pack_cols(b.DPALL, Ha, Ha, a->Tv, b.PK_DPT), pack_cols(a->c3d, D, D, a->Tv, b.PK_C3DT)};
         RC(h2_pack_multi(pj, 2, st));
@@ -1393,7 +1404,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     }
     d.beta = zb;
     RC(gemm(d, st));
-    RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
+    if (!z) RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
     //    token embedding: dXT = sum_k DG_k . W_ih_k[:, :E], scatter-added into the (caller-zeroed) table gradient
     {
         echr_gemm_desc gx[3];
