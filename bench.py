@@ -191,7 +191,7 @@ def gpu_leg(args, rank, world, local_rank):
                  1: ('att_fwd', 'att_score_kernel + att_context_kernel', 'hbm'),
                  2: ('att_bwd_kernel', 'att_bwd_kernel', 'hbm'),
                  3: ('att_post_kernel', 'att_post_kernel', 'valu'),
-                 9: ('dec_persist_kernels', 'dec_persist_fwd_kernel<true> (forward) and dec_persist_bwd_kernel (reverse): each ONE launch of 256 workgroups '
+                 9: ('dec_persist_kernels', 'dec_persist_fwd_kernel<true, BIG> (forward) and dec_persist_bwd_kernel<BIG> (reverse; BIG = events longer than 129 segments): each ONE launch of 256 workgroups '
                                             '(attention chain on 192, the two plain LSTM streams on 64) covering all S steps', 'mfma'),
                  10: ('sst_persist_kernels', 'sst_persist_fwd_kernel / sst_persist_bwd_kernel: the proposal encoder\'s two-layer LSTM over the video, ONE '
                                              'launch of 64 workgroups per direction (recurrent matrices in registers, batch-1 GEMV chain: latency-bound)', 'hbm')}
@@ -222,6 +222,8 @@ def gpu_leg(args, rank, world, local_rank):
             except Exception:
                 pass
         traffic_commit = traffic.get('_commit') if isinstance(traffic, dict) else None
+        if args.c5 or args.overlap or args.mode != 'train':
+            traffic, mfma_pmc = {}, {}          # the committed counter summaries were collected on the default (c3) workload only
 
         def mfma_busy(name):
             if name == 'dec_persist_kernels':           # time-weighted over the four kernels of the two pairs
