@@ -535,7 +535,7 @@ __global__ void event_gather_bwd_kernel(const float* __restrict__ d_ech, const i
 // slabs != nullptr: the row is first formed from the nslab k-slice slabs of the logits product, four at a time in slab order, + bias -- one fixed
 // order (bitwise reproducible), and written to `logits` by the thread that scans it -- the separate slab-sum launch of every decoder step folded in
 template <int EPT>          // EPT > 0: the row is held in registers (V1 <= 256 EPT; every load of the thread in flight at once); 0: any V1, streamed
-__global__ __launch_bounds__(256) void greedy_step_kernel(float* __restrict__ logits, long ld, int V1, int t, int seq_len,
+__global__ __launch_bounds__(256, 1) void greedy_step_kernel(float* __restrict__ logits, long ld, int V1, int t, int seq_len,
                                                           int* __restrict__ it_next, int* __restrict__ unfinished,
                                                           long long* __restrict__ seq, float* __restrict__ seq_logp,
                                                           int* __restrict__ n_unfinished, const float* __restrict__ slabs, long slab_stride,
@@ -552,18 +552,39 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(float* __restrict__ lo
         // with the row in registers the loads overlap
         if (slabs) {
             // nslab (a multiple of four) k-slice slabs added four at a time in slab order, then the bias: rounds of four slabs' loads in flight
-            float s0[EPT > 0 ? EPT : 1], s1[EPT > 0 ? EPT : 1], s2[EPT > 0 ? EPT : 1], s3[EPT > 0 ? EPT : 1];
-            for (int sb = 0; sb < nslab; sb += 4) {
+            if constexpr (EPT <= 24) {
+                float s0[EPT > 0 ? EPT : 1], s1[EPT > 0 ? EPT : 1], s2[EPT > 0 ? EPT : 1], s3[EPT > 0 ? EPT : 1];
+                for (int sb = 0; sb < nslab; sb += 4) {
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) {
-                    const int j = threadIdx.x + 256 * i;
-                    const float* sp = slabs + (long)sb * slab_stride + (long)n * V1 + (j < V1 ? j : 0);
-                    s0[i] = sp[0]; s1[i] = sp[slab_stride]; s2[i] = sp[2 * slab_stride]; s3[i] = sp[3 * slab_stride];
+                    for (int i = 0; i < EPT; ++i) {
+                        const int j = threadIdx.x + 256 * i;
+                        const float* sp = slabs + (long)sb * slab_stride + (long)n * V1 + (j < V1 ? j : 0);
+                        s0[i] = sp[0]; s1[i] = sp[slab_stride]; s2[i] = sp[2 * slab_stride]; s3[i] = sp[3 * slab_stride];
+                    }
+#pragma unroll
+                    for (int i = 0; i < EPT; ++i) {
+                        const float part = (s0[i] + s1[i]) + (s2[i] + s3[i]);
+                        rv[i] = sb == 0 ? part : rv[i] + part;
+                    }
                 }
+            } else {
+                // long rows: two slabs' loads in flight per round (register budget), the same order of additions
+                float s0[EPT > 0 ? EPT : 1], s1[EPT > 0 ? EPT : 1], pa[EPT > 0 ? EPT : 1];
+                for (int sb = 0; sb < nslab; sb += 4) {
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) {
-                    const float part = (s0[i] + s1[i]) + (s2[i] + s3[i]);
-                    rv[i] = sb == 0 ? part : rv[i] + part;
+                    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                        for (int i = 0; i < EPT; ++i) {
+                            const int j = threadIdx.x + 256 * i;
+                            const float* sp = slabs + (long)(sb + 2 * hf) * slab_stride + (long)n * V1 + (j < V1 ? j : 0);
+                            s0[i] = sp[0]; s1[i] = sp[slab_stride];
+                        }
+#pragma unroll
+                        for (int i = 0; i < EPT; ++i) {
+                            if (hf == 0) pa[i] = s0[i] + s1[i];
+                            else { const float part = pa[i] + (s0[i] + s1[i]); rv[i] = sb == 0 ? part : rv[i] + part; }
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -757,6 +778,8 @@ int greedy_step(float* logits, long ld, int N, int V1, int t, int seq_len, int* 
                                           n_unfinished, slabs, slab_stride, bias, nslab);
     else if (V1 <= 256 * 20) hipLaunchKernelGGL(greedy_step_kernel<20>, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq,
                                                 seq_logp, n_unfinished, slabs, slab_stride, bias, nslab);
+    else if (V1 <= 256 * 48) hipLaunchKernelGGL(greedy_step_kernel<48>, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq,
+                                                seq_logp, n_unfinished, slabs, slab_stride, bias, nslab);          // vocabularies up to 12 288 (ActivityNet Captions: ~10 k)
     else hipLaunchKernelGGL(greedy_step_kernel<0>, dim3(N), dim3(256), 0, st, logits, ld, V1, t, seq_len, it_next, unfinished, seq, seq_logp,
                             n_unfinished, slabs, slab_stride, bias, nslab);
     return check_launch("greedy_step");

@@ -392,6 +392,29 @@ def test_greedy_sample_bit_exact(case):
     assert np.abs(lp.cpu().numpy() - g['sample|logp']).max() < TOL_LOGP
 
 
+@pytest.mark.parametrize('V1', [9001, 13001])
+def test_greedy_sample_large_vocabulary_vs_oracle(V1):
+    """Vocabularies beyond the benchmark's 5001 (ActivityNet Captions has ~10 k words): the arg-max kernel's long-row instantiations (rows of
+    up to 12 288 held in registers; streamed above that) must decode the oracle's sequence, twice the same."""
+    from oracle import echr_ref_cpu as O
+    opt = synth.default_opt(vocab_size=V1 - 1, seq_length=6)
+    params = synth.make_params(opt, 11)
+    vid = synth.make_video(5, 20, 8, V1, seed=3, T_v=40)
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    with torch.no_grad():
+        seq1, lp1 = m(tap, c3d, lda, [], vid['ind'], vid['soi'], mode='eval')
+        seq2, lp2 = m(tap, c3d, lda, [], vid['ind'], vid['soi'], mode='eval')
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        seq_o, lp_o = O.caption_forward(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), None, vid['ind'],
+                                        vid['soi'], mode='eval', seq_length=opt.CG_seq_length)
+    assert torch.equal(seq1, seq2) and torch.equal(lp1, lp2)
+    assert np.array_equal(seq1.cpu().numpy(), seq_o.numpy())
+    assert np.abs(lp1.cpu().numpy() - lp_o.numpy()).max() < TOL_LOGP
+
+
 def test_greedy_sampler_is_bitwise_reproducible():
     """`seq` is an index output: two decodes of the same inputs must agree bit for bit -- sequence, log-probs AND the raw logits of
     the last step (no fp32-atomic split-K anywhere on the sampler path; OldModel_NEW.py:158 takes the lowest index on ties)."""
