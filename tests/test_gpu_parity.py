@@ -616,7 +616,8 @@ def test_flat_arena_path_matches_per_tensor_path(case):
             assert U.grad_close(k, p.grad.cpu().numpy(), 2 * g1[k].cpu().numpy(), 1e-4), k
 
 
-@pytest.mark.parametrize('N,A,T_v,L,V1', [(1, 5, 9, 4, 57), (100, 37, 160, 7, 301), (70, 200, 256, 6, 129), (3, 1, 4, 3, 11)])
+@pytest.mark.parametrize('N,A,T_v,L,V1', [(1, 5, 9, 4, 57), (100, 37, 160, 7, 301), (70, 200, 256, 6, 129), (3, 1, 4, 3, 11),
+                                           (6, 24, 60, 5, 9001)])          # a vocabulary beyond the register-resident row kernels' 5120 columns
 def test_odd_shapes_vs_oracle(N, A, T_v, L, V1):
     """Shapes off the tuned path: N not a multiple of the 64-row MFMA block (N=1, 70, 100), A > 128 (config-5-like 256-segment
     videos), single-slot events, tiny vocabularies -- forward, loss and every gradient against the oracle (train mode)."""
