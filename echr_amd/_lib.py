@@ -19,7 +19,8 @@ class GemmDesc(C.Structure):
                 ('sam', i64), ('sak', i64), ('sbk', i64), ('sbn', i64), ('ldc', i64),
                 ('batch', i32), ('bsa', i64), ('bsb', i64), ('bsc', i64), ('alpha', f32), ('beta', f32),
                 ('bias', c_f), ('bs_bias', i64), ('bias2', c_f), ('addend', c_f), ('add_mod', i32), ('ld_add', i64),
-                ('act', i32), ('aux', c_f), ('ld_aux', i64), ('rowmap_mod', i32), ('rowmap_mul', i32), ('split_k', i32), ('algo', i32)]
+                ('act', i32), ('aux', c_f), ('ld_aux', i64), ('rowmap_mod', i32), ('rowmap_mul', i32), ('split_k', i32), ('algo', i32),
+                ('row_index', c_f), ('row_index_max', i32)]
 
 
 class Dropout(C.Structure):

@@ -36,7 +36,7 @@ Config& config() {
     static Config c = {env_int("ECHR_GEMM_BF16X3", 1), env_int("ECHR_OVERLAP", 0), env_int("ECHR_ATT_SLOTS", 2), env_int("ECHR_CHAINS2", 0),
                        env_int("ECHR_GEMM_H2", 1), env_int("ECHR_PERSIST", 1), env_int("ECHR_PERSIST_STAMPS", 0),
                        getenv("ECHR_GEMM_TILE") ? (int)getenv("ECHR_GEMM_TILE")[0] : 0, env_int("ECHR_GEMM_SPLIT", 0), env_int("ECHR_PERSIST_BWD", 1), env_int("ECHR_PERSIST_SPLIT", 1), env_int("ECHR_PERSIST_H2", 1), env_int("ECHR_PERSIST_MERGE", 1), env_int("ECHR_PERSIST_KGROUPS", 1), env_int("ECHR_TSRM_FORK", 1),
-                       env_int("ECHR_PERSIST_COOP", 0), 0, env_int("ECHR_PERSIST_SPIN_LIMIT", 0), env_int("ECHR_SST_PERSIST", 1), env_int("ECHR_TAIL_EARLY", 0)};
+                       env_int("ECHR_PERSIST_COOP", 0), 0, env_int("ECHR_PERSIST_SPIN_LIMIT", 0), env_int("ECHR_SST_PERSIST", 1), env_int("ECHR_TAIL_EARLY", 0), 0, env_int("ECHR_EMBED_FUSED", 0)};
     return c;
 }
 
@@ -328,6 +328,7 @@ __global__ void embed_scatter_add_kernel(const float* __restrict__ dX, const int
     for (int j = threadIdx.x; j < E; j += blockDim.x) atomicAdd(&gW[(long)t * E + j], dX[(long)row * E + j]);
 }
 int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st) {
+    if (config().diag_skip & 8) return 0;
     hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(rows), dim3(128), 0, st, dX, tok, gW, rows, E, V1);
     return check_launch("embed_scatter_add");
 }
@@ -823,6 +824,7 @@ extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int
     if (int rc = join_tail((hipStream_t)stream)) return rc;
     ECHR_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                  "clamp_adam: buffers must be 16-byte aligned");
+    if (config().diag_skip & 2) return 0;
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
     const long n4 = n >> 2;
@@ -900,6 +902,8 @@ extern "C" int echr_config_set(const char* key, int32_t value) {
     else if (!strcmp(key, "persist_coop")) c.persist_coop = value;
     else if (!strcmp(key, "sst_persist")) c.sst_persist = value;
     else if (!strcmp(key, "tail_early")) c.tail_early = value;
+    else if (!strcmp(key, "diag_skip")) c.diag_skip = value;
+    else if (!strcmp(key, "embed_fused")) c.embed_fused = value;
     else if (!strcmp(key, "persist_inject_timeout")) c.persist_inject_timeout = value;
     else if (!strcmp(key, "persist_spin_limit")) c.persist_spin_limit = value;
     else if (!strcmp(key, "gemm_tile")) c.gemm_tile = value;          // tuning only: ASCII code of the tile selector ('1','6','a','b','c','s'), 0 = heuristics

@@ -489,6 +489,7 @@ static int launch_att_bwd(const AttDims& d, const float* PALL, const float* C3D,
 
 static int launch_att_post(const AttDims& d, const float* PALL, const float* QS, const float* alpha, const float* DSC, const int* ev_start,
                            const int* ev_len, float* DPALL, float* g_alpha, float* g_balpha, int S, int disjoint, hipStream_t st) {
+    if (config().diag_skip & 4) return 0;
     const dim3 grid(d.N, (d.A + 7) / 8), blk(256);
     const size_t sm = ((size_t)TT * d.Ha + TT * 8 + 4 * d.Ha) * sizeof(float);
     switch ((d.Ha + 255) / 256) {
@@ -1156,8 +1157,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     }
     {   // DC | DGCOL | DQ | DASL | DPALL, the split-K / accumulated outputs DXT, g_event and DOUT, the zeroed part of the persistent reverse
         // launch's exchange workspace and, when the caller asks for it (zero_extra), its gradient arena span: one launch
-        float* zp[6] = {b.DC, b.DXT, g->g_event, b.DOUT, nullptr, nullptr};
-        long zn[6] = {b.zero_floats, (long)SN * E, (long)N * a->De, (long)SN * 3 * H, 0, 0};
+        float* zp[7] = {b.DC, b.DXT, g->g_event, b.DOUT, nullptr, nullptr, nullptr};
+        long zn[7] = {b.zero_floats, (long)SN * E, (long)N * a->De, (long)SN * 3 * H, 0, 0, 0};
         int nz = 4;
         if (bwd_persist) { persist_bwd_zero_range(a, b.XWSB, &zp[nz], &zn[nz]); ++nz; }
         if (g->zero_extra && g->zero_extra_count > 0) { zp[nz] = g->zero_extra; zn[nz] = (long)g->zero_extra_count; ++nz; }
@@ -1416,13 +1417,21 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
             }
             RC(h2_pack_multi(pj, 6, st));
         }
+        // "embed_fused" = 1 (off by default): dXT = sum_k DG_k . W_ih_k[:, :E] is not materialised -- the products' epilogues add row (t, n) straight
+        // into the embedding-table gradient row of its token (echr_gemm_desc.row_index).  Measured on one box, alternating runs: 1.94 vs 1.74 ms per
+        // iteration -- every k-slice of every product then sends its atomics to the table, and the 64 <bos> rows of a batch (plus frequent words)
+        // serialise on the same addresses; the dense d XT buffer takes the k-slice atomics without contention and the scatter pass meets each
+        // duplicate once (20 us, `tools/skip_bounds.py`)
+        const bool fused_scatter = config().embed_fused != 0;
         for (int k = 0; k < 3; ++k) {
-            gx[k] = h2 ? desc_h2(b.PK_DG[k], b.PK_WIHT[k], b.DXT, E, SN, E, 4 * H) : desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], b.DXT, E, SN, E, 4 * H);
-            gx[k].split_k = -1; gx[k].beta = 1.f;                // shared output (zeroed with the backward scratch): k-slices of all three add atomically
+            float* out = fused_scatter ? g->g_embed : b.DXT;
+            gx[k] = h2 ? desc_h2(b.PK_DG[k], b.PK_WIHT[k], out, E, SN, E, 4 * H) : desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], out, E, SN, E, 4 * H);
+            gx[k].split_k = -1; gx[k].beta = 1.f;                // shared, pre-zeroed output: everything adds atomically
+            if (fused_scatter) { gx[k].row_index = a->tokens; gx[k].row_index_max = V1 - 1; }
         }
         RC(gemm_grouped(gx, 3, st));
+        if (!fused_scatter) RC(embed_scatter_add(b.DXT, a->tokens, g->g_embed, SN, E, V1, st));
     }
-    RC(embed_scatter_add(b.DXT, a->tokens, g->g_embed, SN, E, V1, st));
     if (async_tail) {
         if (hipEventRecord(tail().done, st) != hipSuccess) { set_error("decoder_bwd: event record failed"); return -5; }
         tail().pending = true;

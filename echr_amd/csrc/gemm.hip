@@ -39,6 +39,7 @@ struct GemmParams {
     const float* addend; int add_mod; long ld_add;
     int act; const float* aux; long ld_aux;
     int rowmap_mod, rowmap_mul;
+    const int* rowidx; int rowidx_max;      // optional output-row scatter: row i accumulates into C[rowidx[i]] (atomic adds, duplicates allowed)
     int split_k, k_tiles_per_split;
     int tiles_m, tiles_n;
     int xcd_n, xr_m, xr_n;      // h2 kernel: XCD grid columns, tiles per XCD rectangle (rows, cols)
@@ -70,8 +71,9 @@ __device__ __forceinline__ void epilogue_elem(const GemmParams& p, float* __rest
     float v = p.alpha * a;
     int orow = row;
     if (p.rowmap_mod > 0) orow = (row % p.rowmap_mod) * p.rowmap_mul + row / p.rowmap_mod;
+    if (p.rowidx) orow = min(max(p.rowidx[row], 0), p.rowidx_max);
     float* dst = C + (long)orow * p.ldc + col;
-    if (p.split_k > 1) {
+    if (p.split_k > 1 || p.rowidx) {
         if (first_split) {
             v += cb;
             if (p.addend) v += p.addend[(long)(row % p.add_mod) * p.ld_add + col];
@@ -929,6 +931,7 @@ int h2_pack_multi(const H2PackJob* jobs, int n, hipStream_t st) {
     a.start[n] = total;
     for (int i = n; i < H2_MAX_JOBS; ++i) { a.job[i] = a.job[0]; a.start[i + 1] = total; }
     a.njobs = n;
+    if (config().diag_skip & 1) return 0;
     ProfScope prof(PROF_PACK, 0.0, bytes, st);
     hipLaunchKernelGGL(h2_pack_kernel, dim3(total), dim3(256), 0, st, a);
     return check_launch("h2_pack");
@@ -1080,6 +1083,9 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     p.addend = d.addend; p.add_mod = d.add_mod; p.ld_add = d.ld_add;
     p.act = d.act; p.aux = d.aux; p.ld_aux = d.ld_aux;
     p.rowmap_mod = d.rowmap_mod; p.rowmap_mul = d.rowmap_mul;
+    p.rowidx = d.row_index; p.rowidx_max = d.row_index_max;
+    ECHR_REQUIRE(!d.row_index || (d.beta == 1.f && d.act == ECHR_ACT_NONE && d.rowmap_mod == 0 && d.row_index_max >= 0),
+                 "gemm: row_index scatters with atomic adds: needs beta = 1 (accumulate), no activation, no row remap");
     p.ngroup = ng;
     int maxN = d.N, maxM = d.M;
     for (int i = 0; i < GEMM_MAXG; ++i) {

@@ -73,6 +73,10 @@ typedef struct {
                      or ECHR_GEMM_H2: A and B point at operands that echr_h2_pack has already rewritten as two block-scaled fp16
                      planes (below); three fp16 MFMA products per k block, fp32-grade accuracy at 5x the fp32 MFMA rate and
                      fp32's byte count (strides are ignored; batch = 1, no activation) */
+    const int32_t* row_index; /* optional output-row scatter: row i of the product is ADDED (fp32 atomics; several rows may share a target) into
+                                 C[clamp(row_index[i], 0, row_index_max)] -- the token-embedding gradient d E[tok] += d X[row] without a
+                                 materialised d X and a scatter pass (OldModel_NEW.py:110 backward).  Needs beta = 1, act = NONE, no rowmap */
+    int32_t row_index_max;
 } echr_gemm_desc;
 
 int echr_gemm_f32(const echr_gemm_desc* d, void* stream);
@@ -390,6 +394,8 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *   "persist_inject_timeout" code  diagnostic: the hand-off wait with this code (attention chain: 100000 * edge + timestep, edge 1 h1 / 2 q / 3 context / 4 d q / 5 d h / 6 d G / 7 d ATT) never completes, so the
  *                      launch aborts through its time-out path (tests/test_gpu_parity.py::test_persistent_abort_path); 0 = off
  *   "sst_persist" 0/1   (default 1, ECHR_SST_PERSIST) proposal encoder's recurrences as one persistent launch per direction (H = 512)
+ *   "embed_fused" 0/1   (default 0, ECHR_EMBED_FUSED) token-embedding gradient through echr_gemm_desc.row_index instead of d XT + scatter pass
+ *                      (measured slower: atomics of all k-slices contend on the <bos> / frequent-word rows)
  *   "tail_early"  0/1   (default 0, ECHR_TAIL_EARLY) fork the asynchronous decoder-backward tail ahead of the LSTM-layer gradient stage
  *   "persist_stamps" 0/1/2 diagnostic phase stamps of the forward (1) / reverse (2) pair, see echr_persist_read_stamps
  *   "gemm_tile", "gemm_split"  tuning overrides of the GEMM tile / split-K heuristics (0 = heuristics; tools/gemm_bench.py only) */

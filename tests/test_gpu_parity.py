@@ -177,6 +177,34 @@ def test_cooperative_persistent_launch_equals_plain_launch():
             assert U.grad_close(k, outs[1][2][k], g, TOL_GRAD), k
 
 
+def test_gemm_row_index_scatter():
+    """echr_gemm_desc.row_index: row i of A . B^T is ADDED into C[row_index[i]] (duplicates allowed, out-of-range indices clamped)."""
+    import ctypes as C
+    from echr_amd import _lib as L
+    lib = L.load()
+    rs = np.random.RandomState(3)
+    M, N, K, R = 300, 96, 64, 40
+    A = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).cuda()
+    B = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32)).cuda()
+    idx = rs.randint(0, R, size=M).astype(np.int32)
+    idx[:30] = 0                                                    # a hot row
+    idx[30] = R + 5                                                 # clamped to R - 1
+    out = torch.ones(R, N, device='cuda')
+    d = L.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.sam, d.sak, d.sbk, d.sbn, d.ldc = K, 1, 1, K, N
+    d.batch, d.alpha, d.beta, d.split_k, d.algo = 1, 1.0, 1.0, -1, 0
+    it = torch.from_numpy(idx).cuda()
+    d.row_index, d.row_index_max = it.data_ptr(), R - 1
+    L.check(lib.echr_gemm_f32(C.byref(d), L.stream_ptr()), 'gemm_f32')
+    ref = np.ones((R, N))
+    prod = A.cpu().numpy().astype(np.float64) @ B.cpu().numpy().astype(np.float64).T
+    for i in range(M):
+        ref[min(idx[i], R - 1)] += prod[i]
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-3
+
+
 def test_position_embedding_matches_reference_numpy():
     from echr_amd import functional as EF
     g = U.gold('position.npz')
