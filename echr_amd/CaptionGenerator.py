@@ -58,7 +58,12 @@ class CaptionGenerator(nn.Module):
         if mode == 'train' and self.overlap_encoder:
             # the decoder's event-independent precompute starts on a second stream and overlaps the event encoder launched next
             prepared = self.lm_model.prepare(video, clip, clip_mask, lm_labels)
-        event = self.get_event_context(tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=ev, _drop=drop)
+        try:
+            event = self.get_event_context(tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=ev, _drop=drop)
+        except Exception:
+            if prepared is not None:
+                EF.decoder_prepare_cancel()      # the second stream still writes the handle's buffers: order them before they are freed
+            raise
         if mode == 'train':
             return self.lm_model(video, event, clip, clip_mask, lm_labels, drop=drop, prepared=prepared)
         return self.lm_model.sample(video, event, clip, clip_mask)

@@ -93,6 +93,7 @@ SYMBOLS = [
     ('echr_decoder_ws_bwd_floats', i64, [C.POINTER(DecArgs)]),
     ('echr_decoder_fwd', i32, [C.POINTER(DecArgs), C.POINTER(Dropout), C.c_void_p]),
     ('echr_decoder_fwd_prepare', i32, [C.POINTER(DecArgs), C.c_void_p]),
+    ('echr_decoder_fwd_prepare_cancel', i32, [C.c_void_p]),
     ('echr_decoder_bwd', i32, [C.POINTER(DecArgs), C.POINTER(DecGrads), C.POINTER(Dropout), C.c_void_p]),
     ('echr_nll_loss_fwd', i32, [c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_nll_loss_bwd', i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),

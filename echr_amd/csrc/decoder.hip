@@ -1025,6 +1025,7 @@ extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
     Prep& pr = prep();
     ECHR_REQUIRE(pr.ok, "decoder_fwd_prepare: stream state unavailable");
     hipStream_t sm = (hipStream_t)stream, st = pr.s;
+    RC(echr_decoder_fwd_prepare_cancel(stream));          // an earlier prepare nobody consumed: order its workspace before anything new
     RC(join_tail(sm));
     RC(hop(sm, pr.fork, st));
     DecWs w = carve_ws(a, a->ws);
@@ -1034,6 +1035,14 @@ extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
     RC(input_gates(a, w, w.XT, 0, a->S, st, true));
     if (hipEventRecord(pr.done, st) != hipSuccess) { set_error("decoder_fwd_prepare: event record failed"); return -5; }
     pr.pending = true; pr.ws = a->ws;
+    return 0;
+}
+
+extern "C" int echr_decoder_fwd_prepare_cancel(void* stream) {
+    Prep& pr = prep();
+    if (!pr.ok || !pr.pending) return 0;
+    pr.pending = false; pr.ws = nullptr;
+    if (hipStreamWaitEvent((hipStream_t)stream, pr.done, 0) != hipSuccess) { set_error("decoder_fwd_prepare_cancel: join failed"); return -5; }
     return 0;
 }
 

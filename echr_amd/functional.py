@@ -248,6 +248,12 @@ def decoder_prepare(video, c3d, ev_start, ev_len, tokens, A, disjoint, params):
     return dict(ws=ws, logp=logp, video=video, c3d=c3d, ps=ps, tokens=tokens, A=A, disjoint=disjoint)
 
 
+def decoder_prepare_cancel():
+    """Drop a decoder_prepare() handle that no forward will consume: the current stream waits for the library's second stream, so the
+    handle's buffers can go back to the allocator."""
+    L.check(L.load().echr_decoder_fwd_prepare_cancel(L.stream_ptr()), 'decoder_fwd_prepare_cancel')
+
+
 class DecoderFunction(torch.autograd.Function):
     """OldModel.forward with the ThreeStream core (OldModel_NEW.py:98-137, :376-401, :801-823): log-probs [N,S,V1]."""
 

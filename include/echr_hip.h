@@ -244,6 +244,9 @@ int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* str
  * that it overlaps the event encoder (echr_event_pool_gather_fwd + echr_tsrm_fwd) the caller runs next on `stream`.  a->event may be
  * NULL here.  The following echr_decoder_fwd call must pass the same workspace with a->prepared = 1; it joins the streams. */
 int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream);
+/* Abandon a prepare whose echr_decoder_fwd will not follow (the caller changed its mind, or failed in between): `stream` waits for the
+ * second stream, so the workspace may be released or reused in `stream` order afterwards.  A no-op when nothing is pending. */
+int echr_decoder_fwd_prepare_cancel(void* stream);
 int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream);
 
 /* ONE decoder timestep with the recurrent state passed in and out: OldModel.get_logprobs_state (models/OldModel_NEW.py:133-137) =

@@ -563,6 +563,26 @@ def test_cpu_tensors_fail_loudly():
           vid['ind'], vid['soi'], mode='train')
 
 
+def test_abandoned_prepare_is_cancelled_and_next_forward_is_unaffected():
+    """The decoder precompute runs on the library's second stream; when the event encoder fails in between (here: a proposal tensor of
+    the wrong width), forward() must cancel it (echr_decoder_fwd_prepare_cancel) and the next, valid call must give the usual result."""
+    from echr_amd import functional as EF
+    opt, params, vid = synth.make_case('c1')
+    m = U.build_gpu_model(opt, params, True)
+    m.set_dropout_state(5)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels = torch.from_numpy(vid['labels'])
+    ref = m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train').detach().clone()
+    m.set_dropout_state(5)
+    with pytest.raises(Exception):
+        m(tap[:, :-3].contiguous(), c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+    EF.decoder_prepare_cancel()          # a second cancel is a no-op
+    m.set_dropout_state(5)
+    out = m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+    assert torch.equal(out, ref)
+
+
 def test_staged_decoder_backward_equals_single_call():
     """echr_dec_grads.phase: late-fusion stage (1), reverse recurrence + LSTM-layer gradients (3), the rest (4) on the same scratch
     must equal the one-call backward (0); the data-parallel early reducer hooks in after stages 1 and 3 and must see the FINAL
