@@ -73,7 +73,8 @@ class SstGrads(C.Structure):
 
 class SampleArgs(C.Structure):
     _fields_ = [('dec', DecArgs), ('seq_len', i32), ('seq', c_f), ('seq_logp', c_f), ('n_unfinished', c_f),
-                ('ws_sample', c_f), ('multinomial', i32), ('temperature', C.c_float), ('seed', C.c_uint64)]
+                ('ws_sample', c_f), ('multinomial', i32), ('temperature', C.c_float), ('seed', C.c_uint64),
+                ('tables', c_f), ('tables_valid', i32)]
 
 
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)
@@ -100,6 +101,7 @@ SYMBOLS = [
     ('echr_nll_loss_fwd_i64', i32, [c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_nll_loss_bwd_i64', i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_sampler_ws_floats', i64, [C.POINTER(DecArgs)]),
+    ('echr_sampler_table_floats', i64, [C.POINTER(DecArgs)]),
     ('echr_decoder_sample', i32, [C.POINTER(SampleArgs), C.c_void_p]),
     ('echr_config_set', i32, [C.c_char_p, i32]),
     ('echr_stream_join', i32, [C.c_void_p]),

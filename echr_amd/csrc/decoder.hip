@@ -1456,7 +1456,20 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
 // ------------------------------------------------------------------------------------------------------
 // greedy sampler (OldModel_NEW.py:139-187, sample_max = 1, eval mode): every step on device
 // ------------------------------------------------------------------------------------------------------
-struct SampWs { float* XT; float* LOGITS; int *IT, *UNF; float* SLABS; long total; };
+struct SampWs { float* XT; float* LOGITS; int *IT, *UNF; float* SLABS; float *TABLES, *PSWS; long total; };
+// parameter-only operands of the persistent greedy decoder (csrc/persist.hip, PersistS): the token-side gate tables, the packed embedding
+// they are made from and the logit-weight image -- cacheable across calls while the parameters do not change (echr_sample_args.tables)
+struct SampTables { float *TG[3], *PK_EMB, *LIMG; long total; };
+static SampTables carve_tables(const echr_dec_args* a, float* base) {
+    SampTables s;
+    long off = 0;
+    auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
+    for (int k = 0; k < 3; ++k) s.TG[k] = take((long)a->V1 * 4 * a->H);
+    s.PK_EMB = take(h2_floats(a->V1, a->E));
+    s.LIMG = take(persist_logit_image_floats());
+    s.total = off;
+    return s;
+}
 // few events (N < SAMP_SLAB_ROWS): one k loop per tile of the per-step logits product would be 48 k blocks deep on 79 workgroups; its K is cut into
 // SAMP_SLABS slices that run as a strided batch into slabs (plain stores), and the arg-max kernel adds the slabs in a fixed order (bitwise
 // reproducible).  Measured alternatives at N = 64 (1 GF, 30.7 MB of weights per step): 8 slices 20 us, 12 slices on the recurrence's grouped
@@ -1474,6 +1487,11 @@ static SampWs carve_samp(const echr_dec_args* a, float* base) {
     s.IT = reinterpret_cast<int*>(take(a->N));
     s.UNF = reinterpret_cast<int*>(take(a->N));
     s.SLABS = take(a->N < SAMP_SLAB_ROWS ? (long)((samp_slabs(a) + 3) / 4 * 4) * a->N * a->V1 : 64);
+    // persistent decoding (csrc/persist.hip, PersistS): token-side gate tables, the packed embedding they are made from, the logit-weight
+    // image and the launch's exchange buffers
+    const bool ps = config().gemm_h2 && persist_sample_eligible(a);
+    s.TABLES = take(ps ? carve_tables(a, nullptr).total : 64);
+    s.PSWS = take(ps ? persist_sample_ws_floats(a->S) : 64);
     s.total = off;
     return s;
 }
@@ -1493,6 +1511,10 @@ __global__ __launch_bounds__(256) void slab_sum_bias_kernel(const float* __restr
     out[i] = v + (bias ? bias[i % V1] : 0.f);
 }
 extern "C" int64_t echr_sampler_ws_floats(const echr_dec_args* a) { return a ? carve_samp(a, nullptr).total : -1; }
+extern "C" int64_t echr_sampler_table_floats(const echr_dec_args* a) {
+    if (!a) return -1;
+    return config().gemm_h2 && persist_sample_eligible(a) ? carve_tables(a, nullptr).total : 0;
+}
 
 extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
     ECHR_REQUIRE(sa, "decoder_sample: null args");
@@ -1517,6 +1539,39 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
     // many events (evaluation: up to 1000 proposals): the per-step token-side gate products and the logits product are 6 + 15 GF -- they run
     // on h2 operands (weights packed once per decode, the step's N rows packed per step; one fixed-order k loop per tile, so the decode stays
     // bitwise reproducible).  Few events: exact fp32 MFMA as before (the products are launch-bound there).
+    if (!sa->multinomial && config().gemm_h2 && persist_sample_eligible(&a)) {
+        // every step on device: one persistent launch per 64 events.  Per call: the time-invariant products, the token-side gate tables
+        // TG_k = embed . W_ih_k[:, :E]^T (+ the stream's biases / video part; the event part of stream 0 stays per event) and the logit image
+        // TG_k = embed . W_ih_k[:, :E]^T (+ stream 1's biases; the event part of stream 0 and the video part of stream 2 stay outside: they
+        // are inputs, not parameters) and the logit image: rebuilt unless the caller's cache is valid
+        const SampTables tb = carve_tables(&a, sa->tables ? sa->tables : s.TABLES);
+        const bool rebuild = !(sa->tables && sa->tables_valid);
+        RC(precompute_static(&a, w, st, rebuild));
+        if (rebuild) {
+            H2PackJob pj = pack_rows(a.embed, E, a.V1, E, tb.PK_EMB);
+            RC(h2_pack_multi(&pj, 1, st));
+            echr_gemm_desc d[3];
+            for (int k = 0; k < 3; ++k) {
+                d[k] = desc_h2(tb.PK_EMB, w.PK_WIH[k], tb.TG[k], 4 * H, a.V1, 4 * H, E);
+                d[k].split_k = 1;
+                if (k == 1) { d[k].bias = a.b_ih[1]; d[k].bias2 = a.b_hh[1]; }
+            }
+            RC(gemm_grouped(d, 3, st));
+            RC(persist_logit_image(a.w_logit, a.V1, tb.LIMG, st));
+        }
+        for (int n0 = 0; n0 < N; n0 += 64) {
+            echr_dec_args p = a;
+            p.N = N - n0 < 64 ? N - n0 : 64;
+            p.ev_start = a.ev_start + n0; p.ev_len = a.ev_len + n0;
+            PersistSampleBufs B;
+            B.PALL = w.PALL; B.EVB0 = w.EVB0 + (long)n0 * 4 * H; B.VIDB = w.VIDB; B.xws = w.XWS;
+            for (int k = 0; k < 3; ++k) B.TG[k] = tb.TG[k];
+            B.limg = tb.LIMG; B.sws = s.PSWS;
+            B.seq = reinterpret_cast<long long*>(sa->seq) + (long)n0 * L; B.seq_logp = sa->seq_logp + (long)n0 * L; B.n_unfinished = sa->n_unfinished;
+            RC(persist_sample(&p, B, st));
+        }
+        return 0;
+    }
     const bool big = config().gemm_h2 && N >= SAMP_SLAB_ROWS;
     RC(precompute_static(&a, w, st, big));
     const int nsl = samp_slabs(&a), nsl4 = (nsl + 3) / 4 * 4;          // slabs are added four at a time: the spare ones stay zero

@@ -17,7 +17,7 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; int persist_coop; int persist_inject_timeout; int persist_spin_limit; int sst_persist; int tail_early; int diag_skip; int embed_fused; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; int persist_coop; int persist_inject_timeout; int persist_spin_limit; int sst_persist; int tail_early; int diag_skip; int embed_fused; int persist_sample; };
 // diag_skip (diagnostic, tools/skip_bounds.py; results are WRONG while a bit is set): 1 = h2 operand packs, 2 = clamp+Adam kernel, 4 = att_post,
 // 8 = embedding scatter-add -- the launch is skipped, which bounds what removing / hiding that work could gain
 Config& config();
@@ -40,6 +40,13 @@ void persist_bwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, lon
 long persist_bwd_ws_floats(int S);
 bool persist_bwd_eligible(const echr_dec_args* a);
 int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
+// greedy decoding on the persistent kernels (64 events per launch, every step on device): see PersistS in csrc/persist.hip
+struct PersistSampleBufs { float* PALL; const float* EVB0; const float* VIDB; float* xws; const float* TG[3]; const float* limg; float* sws; long long* seq; float* seq_logp; int* n_unfinished; };
+long persist_sample_ws_floats(int S);
+long persist_logit_image_floats();
+bool persist_sample_eligible(const echr_dec_args* a);
+int persist_logit_image(const float* w_logit, int V1, float* img, hipStream_t st);
+int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st);
 int persist_check_async();
 void coop_refused(const char* who, const char* why);          // one stderr line the first time a cooperative launch is refused
 // device word that is non-zero from the moment a persistent launch aborts until the host has reported it (persist_check_async):

@@ -173,6 +173,39 @@ __device__ __forceinline__ bool wait_total(const PK& P, u32* line, u32 target, i
     return r;
 }
 
+// two counters in one polling loop (an already satisfied wait still costs a round trip to L2 plus two barriers: ~0.7 us each when taken one
+// after the other)
+template <typename PK>
+__device__ __forceinline__ bool wait_total2(const PK& P, u32* line_a, u32 target_a, u32* line_b, u32 target_b, int* flag, u32 code) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        u32 spins = 0;
+        bool ok = false;
+        for (;;) {
+            u32 v = lane < 2 * SHARDS ? __hip_atomic_load((lane < SHARDS ? line_a : line_b) + (lane & (SHARDS - 1)) * SHSTRIDE, __ATOMIC_RELAXED, ECHR_AGENT) : 0u;
+            v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            const u32 va = __shfl(v, 0), vb = __shfl(v, SHARDS);
+            if (va >= target_a && vb >= target_b && code != P.inject) { ok = true; break; }
+            if ((++spins & 31) == 0) {
+                if (__hip_atomic_load(P.abort_word, __ATOMIC_RELAXED, ECHR_AGENT)) break;
+                if (spins > P.spin_limit) {
+                    if (lane == 0) {
+                        __hip_atomic_store(P.abort_word, code, __ATOMIC_RELAXED, ECHR_AGENT);
+                        __hip_atomic_store(P.host_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) *flag = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool r = *flag != 0;
+    __syncthreads();
+    return r;
+}
+
 // ---- MFMA pieces: one wave multiplies its k range [128 w, 128 w + 128) of a [64 x 512] A operand by 16-column tiles ------------
 // A fragments straight from the exchange buffer: lane (r = l & 15, kq = l >> 4) holds, for row block rb and k chunk c, the
 // float4 A[16 rb + r][128 w + 16 c + 4 kq ..+3]; element j of it feeds MFMA j of the chunk (B uses the same k pairing).
@@ -813,12 +846,37 @@ struct PersistK2 {
     DropCfg dh, dout;
 };
 
+// Greedy decoding inside the forward kernels (SAMP instantiations; OldModel.sample, models/OldModel_NEW.py:139-187): the token fed at step
+// t + 1 is the arg-max of step t's logits, so the three streams can no longer run ahead of each other.  The 64 workgroups of the two plain
+// LSTM streams also compute the logits (80 vocabulary columns each, fp16-pair products against a weight image streamed from L2 / MALL):
+// the h0 / h2 two thirds of the contraction while the attention chain is still busy with its step, the h1 third when that arrives; every
+// workgroup folds its columns into one 64-bit (value, lowest index) key per event with an atomic max -- order-independent, so `seq` is
+// bitwise reproducible -- and the consumers gather the token-side gate pre-activations from a [V1, 4H] table per stream.
+constexpr int LCOLS = 80, LCT = 5;             // vocabulary columns / 16-column MFMA tiles per logits workgroup
+constexpr int LWG = 2 * NS;                    // logits workgroups
+struct PersistS {
+    const float* TG[3];            // [V1][4H] token-side gate pre-activations per stream (stream 1: biases folded in)
+    const float* base0;            // [N][4H] event part of stream 0 (+ biases)
+    const float* base2;            // [4H] video part of stream 2 (+ biases)
+    unsigned long long* KEY;       // [S][64] arg-max keys: ordered(value) << 32 | ~index
+    u32* cnt_tok;                  // [S] counters: logits workgroups that have folded step t
+    const float4* LIMG;            // logit weights as fp16-pair planes [workgroup 64][stream 3][k step 16][tile 5][plane 2][lane 64] x 16 bytes
+    const float* linv;             // [64 * 80] inverse column scales
+    const float* lbias;            // [V1]
+    float* LSE;                    // [S][64 workgroups][64 events][2]: (local maximum, sum of exp(x - local maximum)) for the log-probability
+    float* XC3; float* XS3;        // context partials / exponential sums, one slot per workgroup of an event (summed in a fixed order)
+    u32* cnt2;                     // the attention layout's counters (the logits role waits for h1)
+    const float* XH1;              // its h1 exchange planes
+    int V1;
+};
+
 // BIG: events of up to 258 segments (BASELINE config 5's 256-segment proposals).  An event's first 129 slots live in registers as before;
 // slots [129, 258) form a SECOND set of 43 per workgroup whose P_all / C3D rows are re-read from L2 every step (a 256-row video's operands are
 // 1 MB: L2-resident), scored with the same q and folded into the same split softmax.  Events of <= 129 segments skip it, and the BIG = false
 // instantiation (what shapes with A <= 129 launch) is the previous code unchanged.
-template <bool H2, bool BIG>
-__device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const int bid) {
+template <bool H2, bool BIG, bool SAMP = false>
+__device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const int bid, const PersistS* Q = nullptr) {
+    static_assert(!SAMP || H2, "the sampling form exchanges h1 as fp16 planes");
     if (P.stamps && bid == 0 && threadIdx.x == 0) P.stamps[15] = __builtin_amdgcn_s_memrealtime();          // kernel entry (diagnostic)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float4* wimg = reinterpret_cast<float4*>(lds);
@@ -948,9 +1006,11 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
         float pre[4] = {0.f, 0.f, 0.f, 0.f};
         float mh1 = 1.f, mo1 = 1.f;
         if (is_g1) {
-            const float* grow = P.GATES1 + ((long)t * N + min(gn, N - 1)) * 4 * PH + 8 * lb + gu;
+            if (!SAMP) {
+                const float* grow = P.GATES1 + ((long)t * N + min(gn, N - 1)) * 4 * PH + 8 * lb + gu;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] = grow[g * PH];
+                for (int g = 0; g < 4; ++g) pre[g] = grow[g * PH];
+            }
             mh1 = mask_h(P.dh, gn, 8 * lb + gu, 1, t);
             mo1 = mask_o(P.dout, gn, 8 * lb + gu, 1, t);
         }
@@ -1011,7 +1071,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
             if (srole >= 0) STAMP(srole, 3);
             publish(cnt(C_Q, t));
             if (srole >= 0) STAMP(srole, 4);
-            if (gn < N) *reinterpret_cast<float4*>(P.QS + ((long)t * N + gn) * PH + 32 * cq + c4) = qv;
+            if (!SAMP && gn < N) *reinterpret_cast<float4*>(P.QS + ((long)t * N + gn) * PH + 32 * cq + c4) = qv;
         }
         // ---- attention: scores, (split) softmax, context partial ----
         {
@@ -1152,7 +1212,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                     }
                 }
                 if (lr == 0) sx[grow_] = ssum;
-                {
+                if (!SAMP) {
                     const float xw = lr == 0 ? e[0] : (lr == 1 ? e[1] : e[2]);
                     const int sl = grow_ + 16 * lr;
                     if (lr < PSG && sl < PSL && PSL * ap + sl < alen) st4_sc1(P.WU + ((long)t * PROWS + an) * WU_LD + PSL * ap + sl, xw);
@@ -1180,6 +1240,21 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                     csum[h] = (red[d] + red[PH + d]) + (red[2 * PH + d] + red[3 * PH + d]);
                 }
                 __syncthreads();
+                if (SAMP) {
+                    // decoding: one slot per workgroup of the event, plain stores; the readers add the three slots in slot order (bitwise reproducible)
+                    float* xc = Q->XC3 + (((long)t * 2 + m) * 3 + ap) * XHALF;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int d = tid + 256 * h;
+                        st4_sc1(xc + ((d >> 3) * HR + ar) * 8 + (d & 7), d < D ? csum[h] : 0.f);
+                    }
+                    if (tid == 0) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) sum += sx[g];
+                        st4_sc1(Q->XS3 + ((long)t * PROWS + an) * 3 + ap, sum);
+                    }
+                } else {
                 float* xc = P.XC + ((long)t * 2 + m) * XHALF;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -1191,6 +1266,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
 #pragma unroll
                     for (int g = 0; g < 16; ++g) sum += sx[g];
                     atomicAdd(P.XS + (long)t * PROWS + an, sum);
+                }
                 }
             }
             if (srole >= 0) STAMP(srole, 6);
@@ -1220,7 +1296,11 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                     if (tid < HR) {
                         if (t == 0) cmx[tid] = ld4_sc1(P.XCMAX + HR * m + tid);
                         const int ex = (int)((__float_as_uint(fmaxf(cmx[tid], 1e-30f)) >> 23) & 0xFFu) - 127 + 1;      // |context| < 2^ex
-                        const float ssum = ld4_sc1(P.XS + (long)t * PROWS + HR * m + tid);
+                        float ssum;
+                        if (SAMP) {
+                            const float* xs3 = Q->XS3 + ((long)t * PROWS + HR * m + tid) * 3;
+                            ssum = (ld4_sc1(xs3) + ld4_sc1(xs3 + 1)) + ld4_sc1(xs3 + 2);
+                        } else ssum = ld4_sc1(P.XS + (long)t * PROWS + HR * m + tid);
                         sCt[tid] = ldexpf(1.f, 12 - ex) / ssum;
                         invAt[tid] = ldexpf(1.f, ex - 12);
                     }
@@ -1229,7 +1309,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                     load_afrag32(reinterpret_cast<float4(&)[16]>(a), rc, w, lane);
                 }
                 // normalised context, saved for backward: this workgroup stores features [8 lb, 8 lb + 8) (wave lb / 16, chunk lb % 16)
-                if (8 * lb < D && w == (lb >> 4)) {
+                if (!SAMP && 8 * lb < D && w == (lb >> 4)) {
                     float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (H2) av = ld16_sc1(rc, (u32)(((lb * HR + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4));
                     else {
@@ -1251,7 +1331,15 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
 #pragma unroll
                     for (int s_ = 0; s_ < 8; ++s_) {
                         const u32 off = (u32)((((16 * w + 2 * s_ + (lane >> 5)) * HR + (lane & 31)) * 8) * 4);
-                        const float4 v0 = ld16_bulk(rc, off), v1 = ld16_bulk(rc, off + 16);
+                        float4 v0, v1;
+                        if (SAMP) {
+                            // the event's three partial contexts, added in slot order
+                            const __amdgpu_buffer_rsrc_t r3 = mk_rsrc(Q->XC3 + ((long)t * 2 + m) * 3 * XHALF, 3 * XBH);
+                            const float4 a0 = ld16_bulk(r3, off), a1 = ld16_bulk(r3, off + 16), b0 = ld16_bulk(r3, off + XBH), b1 = ld16_bulk(r3, off + XBH + 16),
+                                         c0 = ld16_bulk(r3, off + 2 * XBH), c1 = ld16_bulk(r3, off + 2 * XBH + 16);
+                            v0 = make_float4((a0.x + b0.x) + c0.x, (a0.y + b0.y) + c0.y, (a0.z + b0.z) + c0.z, (a0.w + b0.w) + c0.w);
+                            v1 = make_float4((a1.x + b1.x) + c1.x, (a1.y + b1.y) + c1.y, (a1.z + b1.z) + c1.z, (a1.w + b1.w) + c1.w);
+                        } else { v0 = ld16_bulk(rc, off); v1 = ld16_bulk(rc, off + 16); }
                         const float x[8] = {v0.x * f, v0.y * f, v0.z * f, v0.w * f, v1.x * f, v1.y * f, v1.z * f, v1.w * f};
                         unsigned hw[8], lw[8];
 #pragma unroll
@@ -1283,6 +1371,20 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                 }
             }
             if (srole >= 0) STAMP(srole, 9);
+            if (SAMP) {
+                // token-side gate pre-activations: row `token` of stream 1's table.  The token (arg-max of step t - 1's logits) is the last
+                // thing this step waits for: everything above depends on h1(t - 1) only
+                u32 tok = 0;
+                if (t > 0) {
+                    if (!wait_total(P, Q->cnt_tok + (long)(t - 1) * CNT_LINE, LWG, flag, 400000u + t)) return;
+                    tok = 0xFFFFFFFFu - (u32)__hip_atomic_load(Q->KEY + (long)(t - 1) * PROWS + min(gn, N - 1), __ATOMIC_RELAXED, ECHR_AGENT);
+                    tok = min(tok, (u32)(Q->V1 - 1));
+                }
+                const float* grow = Q->TG[1] + (long)tok * 4 * PH + 8 * lb + gu;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pre[g] = grow[g * PH];
+                if (srole >= 0) STAMP(srole, 12);
+            }
             acc_to_lds32(acc, red, w, lane);
             __syncthreads();
 #pragma unroll
@@ -1312,6 +1414,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
             if (srole >= 0) STAMP(srole, 10);
             publish(cnt(C_H1, t));          // (its barrier also protects `red` for the next step)
             if (srole >= 0) STAMP(srole, 11);
+            if (SAMP) continue;             // decoding keeps no activations
             if (gn < N) {
                 const int j = 8 * lb + gu;
                 float* go = P.GATES1 + ((long)t * N + gn) * 4 * PH + j;
@@ -1471,6 +1574,390 @@ __device__ __forceinline__ void dec_persist_lstm_h2_body(const PersistK& P, cons
     }
 }
 __global__ __launch_bounds__(256, 1) void dec_persist_lstm_h2_kernel(PersistK P) { dec_persist_lstm_h2_body(P, blockIdx.x); }
+
+// ---- decoding: the two plain LSTM streams (as dec_persist_lstm_h2_body) + the logits role (see PersistS) ----
+// Per step t a workgroup: waits for token t (arg-max of step t - 1), gathers its gate pre-activations from the stream's table, runs its
+// cells and publishes h(t); multiplies the stream's complete h(t) by its W_hh tile (the recurrent part of step t + 1); accumulates its 80
+// logit columns over the h0(t) and h2(t) thirds of the contraction; waits for h1(t), adds that third, folds its columns into the events'
+// keys and publishes.  v_mfma_f32_16x16x32_f16 on fp16-pair operands: 4 row tiles x 5 column tiles, the wave's k range is a quarter of
+// every 512-wide stream block; the four waves' partial tiles are added through LDS, one column tile per round.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, const PersistS& Q, const int bid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float4* wimg = reinterpret_cast<float4*>(lds);                    // 128 KB
+    float* red = reinterpret_cast<float*>(lds + LDS_W);               // 16 KB
+    float* invb = red + 4096;
+    float* scr = invb + 64;
+    int* flag = reinterpret_cast<int*>(lds + LDS_W + LDS_RED + 1024);
+    const int b = bid, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_s0 = b < NS;
+    const int N = P.N, S = P.S, V1 = Q.V1;
+    const int k = is_s0 ? 0 : 2, bs = is_s0 ? b : b - NS, ck = is_s0 ? C_H0 : C_H2, ck_other = is_s0 ? C_H2 : C_H0;
+    float* XH = is_s0 ? P.XH0 : P.XH2;
+    auto cnt = [&](int kind, int t) { return P.cnt + ((long)kind * (S + 1) + t) * CNT_LINE; };
+    auto cnt2 = [&](int kind, int t, int m) { return Q.cnt2 + (((long)kind * (S + 1) + t) * 2 + m) * CNT_LINE; };
+    {
+        auto row = [&](int col) { return ((col >> 3) & 3) * PH + 16 * bs + 8 * (col >> 5) + (col & 7); };
+        fill_bimg_h2(wimg, invb, scr, P.w_hh[k], PH, PH, 2, row, tid);
+    }
+    const int gr = tid >> 3, g8 = tid & 7;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    float rec[4][4], base[4][4];
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+        const int n = 32 * (rd >> 1) + gr, j = 16 * bs + 8 * (rd & 1) + g8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            rec[rd][g] = 0.f;
+            base[rd][g] = k == 0 ? Q.base0[(long)min(n, N - 1) * 4 * PH + g * PH + j] : Q.base2[g * PH + j];
+        }
+    }
+    const u32 XB = PROWS * PH * 4, XBH = HR * PH * 4;
+    const float4* limg = Q.LIMG + (long)b * (3 * 16 * LCT * 2 * 64);
+    const int ev = tid >> 2, q4 = tid & 3;                            // epilogue ownership: event, columns 16 c + 4 q4 .. +3 of every tile
+    float* lsc = reinterpret_cast<float*>(lds + LDS_W + LDS_RED + 1280);      // [80] column scale back to true units, [80] bias
+    float* lbi = lsc + LCOLS;
+    if (tid < LCOLS) {
+        const int gv = LCOLS * b + tid;
+        lsc[tid] = H2_INV_SA * Q.linv[gv];
+        lbi[tid] = gv < V1 ? Q.lbias[gv] : 0.f;
+    }
+    __syncthreads();
+    const bool st_on = b == 0;
+    const int nhalf = N > HR ? 2 : 1;
+    for (int t = 0; t < S; ++t) {
+        if (st_on) STAMP(3, 0);
+        // ---- token t -> gate pre-activations, cells, h(t) ----
+        u32 tok[2] = {0u, 0u};
+        if (t > 0) {
+            if (!wait_total(P, Q.cnt_tok + (long)(t - 1) * CNT_LINE, LWG, flag, 400000u + t)) return;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const u32 x = 0xFFFFFFFFu - (u32)__hip_atomic_load(Q.KEY + (long)(t - 1) * PROWS + min(32 * r + gr, N - 1), __ATOMIC_RELAXED, ECHR_AGENT);
+                tok[r] = min(x, (u32)(V1 - 1));
+            }
+        }
+        if (st_on) STAMP(3, 1);
+        CellOut co[4];
+        {
+            float pre[4][4];
+#pragma unroll
+            for (int rd = 0; rd < 4; ++rd) {
+                const int j = 16 * bs + 8 * (rd & 1) + g8;
+                const float* grow = Q.TG[k] + (long)tok[rd >> 1] * 4 * PH + j;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pre[rd][g] = grow[g * PH];
+            }
+#pragma unroll
+            for (int rd = 0; rd < 4; ++rd) {
+                const int n = 32 * (rd >> 1) + gr, j = 16 * bs + 8 * (rd & 1) + g8;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) pre[rd][g] += base[rd][g] + rec[rd][g];
+                co[rd] = lstm_cell(pre[rd][0], pre[rd][1], pre[rd][2], pre[rd][3], cs[rd], mask_h(P.dh, n, j, k, t), mask_o(P.dout, n, j, k, t));
+                cs[rd] = co[rd].c;
+            }
+        }
+        {
+            unsigned short* sh = reinterpret_cast<unsigned short*>(red);
+#pragma unroll
+            for (int rd = 0; rd < 4; ++rd) {
+                unsigned short hi, lo;
+                split_h2(co[rd].h * H2_SA, hi, lo);           // decoding runs without dropout: the logits' input (hd) and the recurrent input (h) coincide
+                const int row = 32 * (rd >> 1) + gr, cb = rd & 1;
+                sh[((0 * 2 + cb) * 64 + row) * 8 + g8] = hi;
+                sh[((1 * 2 + cb) * 64 + row) * 8 + g8] = lo;
+            }
+            __syncthreads();
+            const int pl = tid >> 7, cb = (tid >> 6) & 1, row = tid & 63;
+            const float4 v = reinterpret_cast<const float4*>(red)[(pl * 2 + cb) * 64 + row];
+            st16_sc1(mk_rsrc(XH + (long)t * PROWS * PH, XB), (u32)((((pl * 64 + 2 * bs + cb) * PROWS) + row) * 16), v);
+        }
+        publish(cnt(ck, t));
+        if (st_on) STAMP(3, 2);
+        // ---- logits of step t: columns [80 b, 80 b + 80) ----
+        f32x4v la[4][LCT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < LCT; ++c) la[i][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        // one k step (32 wide) of stream block kb: 10 B fragments (5 column tiles x 2 planes: static weights, fetched ahead of the hand-off
+        // waits) + 8 A fragments (4 row tiles x 2 planes)
+        // every fragment address = one lane-dependent VGPR offset + a wave-uniform scalar offset (kept in SGPRs / immediates: per-fragment
+        // vector offsets would be hoisted out of the step loop as invariants, a few hundred registers' worth)
+        const int ws = __builtin_amdgcn_readfirstlane(w);
+        const u32 vo_b = (u32)lane * 16u;
+        const u32 vo_a64 = (u32)(((lane >> 4) * PROWS + (lane & 15)) * 16), vo_a32 = (u32)(((lane >> 4) * HR + (lane & 15)) * 16);
+        const __amdgpu_buffer_rsrc_t rl = mk_rsrc(limg, 3 * 16 * LCT * 2 * 64 * 16);
+        auto fetch_b = [&](int kb, int si, float4 (&fb)[LCT][2]) {
+            const u32 so = (u32)(((kb * 16 + 4 * ws + si) * LCT) * 2 * 64 * 16);
+#pragma unroll
+            for (int c = 0; c < LCT; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rl, vo_b, so + (u32)((c * 2 + pl) * 64 * 16), 0);
+                    fb[c][pl] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+        };
+        auto fetch_a = [&](int kb, int si, const float* abase, float4 (&fa)[4][2]) {
+            const int s_ = 4 * ws + si;
+            const __amdgpu_buffer_rsrc_t ra = mk_rsrc(abase, XB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const u32 so = kb == 1 ? (u32)((i >> 1) * XBH + (((pl * 64 + 4 * s_) * HR) + 16 * (i & 1)) * 16)
+                                           : (u32)((((pl * 64 + 4 * s_) * PROWS) + 16 * i) * 16);
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, kb == 1 ? vo_a32 : vo_a64, so, 16);
+                    fa[i][pl] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+        };
+        auto mma = [&](const float4 (&fa)[4][2], const float4 (&fb)[LCT][2]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x8p ah = as_f16x8(fa[i][0]), al = as_f16x8(fa[i][1]);
+#pragma unroll
+                for (int c = 0; c < LCT; ++c) {
+                    const f16x8p bh = as_f16x8(fb[c][0]), bl = as_f16x8(fb[c][1]);
+                    la[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, la[i][c], 0, 0, 0);
+                    la[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, la[i][c], 0, 0, 0);
+                    la[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, la[i][c], 0, 0, 0);
+                }
+            }
+        };
+        {
+            // h0's four k steps, then h2's: four rotating buffers, three steps' loads in flight; the first three steps' weights go out ahead
+            // of the wait for the two streams' h(t)
+            const float* a0 = P.XH0 + (long)t * PROWS * PH;
+            const float* a2 = P.XH2 + (long)t * PROWS * PH;
+            float4 fa0[4][2], fb0[LCT][2], fa1[4][2], fb1[LCT][2], fa2[4][2], fb2[LCT][2];
+            fetch_b(0, 0, fb0); fetch_b(0, 1, fb1);
+            if (!wait_total2(P, cnt(ck, t), NS, cnt(ck_other, t), NS, flag, 1000u * (ck + 1) + t)) return;
+            if (st_on) STAMP(3, 3);
+            fetch_a(0, 0, a0, fa0); fetch_a(0, 1, a0, fa1);
+            // steps 0..7 = (kb, si): (0,0) (0,1) (0,2) (0,3) (2,0) (2,1) (2,2) (2,3); three rotating buffers, two steps' loads in flight
+            fetch_b(0, 2, fb2); fetch_a(0, 2, a0, fa2);
+            mma(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_b(0, 3, fb0); fetch_a(0, 3, a0, fa0);
+            mma(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_b(2, 0, fb1); fetch_a(2, 0, a2, fa1);
+            mma(fa2, fb2);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_b(2, 1, fb2); fetch_a(2, 1, a2, fa2);
+            mma(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_b(2, 2, fb0); fetch_a(2, 2, a2, fa0);
+            mma(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_b(2, 3, fb1); fetch_a(2, 3, a2, fa1);
+            mma(fa2, fb2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa0, fb0);
+            mma(fa1, fb1);
+        }
+        if (st_on) STAMP(3, 4);
+        {
+            // h1's four k steps: all weights ahead of the wait, all of h1's fragments behind it
+            const float* a1 = Q.XH1 + (long)t * 2 * HR * PH;          // both halves: [m][plane][k / 8][32 rows][8 halves] (2 x 64 KB = XB bytes)
+            float4 fa0[4][2], fb0[LCT][2], fa1[4][2], fb1[LCT][2], fa2[4][2], fb2[LCT][2], fb3[LCT][2];
+            fetch_b(1, 0, fb0); fetch_b(1, 1, fb1); fetch_b(1, 2, fb2); fetch_b(1, 3, fb3);
+            if (!wait_total2(P, cnt2(C_H1, t, 0), HG1, cnt2(C_H1, t, nhalf - 1), HG1, flag, 150000u + t)) return;
+            if (st_on) STAMP(3, 5);
+            fetch_a(1, 0, a1, fa0); fetch_a(1, 1, a1, fa1); fetch_a(1, 2, a1, fa2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_a(1, 3, a1, fa0);
+            mma(fa1, fb1); mma(fa2, fb2); mma(fa0, fb3);
+        }
+        if (st_on) STAMP(3, 6);
+        // the four waves' partial tiles -> finished logits of (event ev, 20 columns) per thread
+        float lv[LCT][4];
+#pragma unroll
+        for (int c = 0; c < LCT; ++c) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[w * 1024 + (16 * i + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = la[i][c][r];
+            __syncthreads();
+            const float4 p0 = *reinterpret_cast<const float4*>(red + ev * 16 + 4 * q4), p1 = *reinterpret_cast<const float4*>(red + 1024 + ev * 16 + 4 * q4),
+                         p2 = *reinterpret_cast<const float4*>(red + 2048 + ev * 16 + 4 * q4), p3 = *reinterpret_cast<const float4*>(red + 3072 + ev * 16 + 4 * q4);
+            const float4 sc4 = *reinterpret_cast<const float4*>(lsc + 16 * c + 4 * q4), bi4 = *reinterpret_cast<const float4*>(lbi + 16 * c + 4 * q4);
+            lv[c][0] = ((p0.x + p1.x) + (p2.x + p3.x)) * sc4.x + bi4.x;
+            lv[c][1] = ((p0.y + p1.y) + (p2.y + p3.y)) * sc4.y + bi4.y;
+            lv[c][2] = ((p0.z + p1.z) + (p2.z + p3.z)) * sc4.z + bi4.z;
+            lv[c][3] = ((p0.w + p1.w) + (p2.w + p3.w)) * sc4.w + bi4.w;
+            __syncthreads();
+        }
+        {
+            float mx = -INFINITY;
+            int mi = 0x7fffffff;
+#pragma unroll
+            for (int c = 0; c < LCT; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gv = LCOLS * b + 16 * c + 4 * q4 + e;
+                    if (gv < V1 && lv[c][e] > mx) { mx = lv[c][e]; mi = gv; }          // ascending index per thread: first maximum kept
+                }
+#pragma unroll
+            for (int off = 1; off <= 2; off <<= 1) {
+                const float om = __shfl_xor(mx, off, 64);
+                const int oi = __shfl_xor(mi, off, 64);
+                if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+            }
+            float se = 0.f;
+#pragma unroll
+            for (int c = 0; c < LCT; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gv = LCOLS * b + 16 * c + 4 * q4 + e;
+                    if (gv < V1) se += __expf(lv[c][e] - mx);
+                }
+            se += __shfl_xor(se, 1, 64);
+            se += __shfl_xor(se, 2, 64);
+            if (q4 == 0 && ev < N) {
+                if (mi != 0x7fffffff) {          // (a workgroup past the end of the vocabulary has nothing to fold)
+                    u32 u = __float_as_uint(mx);
+                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);           // order-preserving map of the float onto unsigned
+                    const unsigned long long key = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mi);
+                    __hip_atomic_fetch_max(Q.KEY + (long)t * PROWS + ev, key, __ATOMIC_RELAXED, ECHR_AGENT);
+                }
+                float* lp = Q.LSE + (((long)t * LWG + b) * PROWS + ev) * 2;
+                lp[0] = mx; lp[1] = se;
+            }
+        }
+        publish(Q.cnt_tok + (long)t * CNT_LINE);
+        if (st_on) STAMP(3, 7);
+        // ---- the stream's complete h(t) (waited for above) x W_hh: the recurrent part of step t + 1, behind the token's hand-off ----
+        if (t + 1 < S) {
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc[rb][cb][g] = 0.f;
+            const __amdgpu_buffer_rsrc_t ra = mk_rsrc(XH + (long)t * PROWS * PH, XB);
+            float4 a[8][2][2];
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        a[s_][rb][pl] = ld16_bulk(ra, (u32)((((pl * 64 + 16 * w + 2 * s_ + (lane >> 5)) * PROWS) + 32 * rb + (lane & 31)) * 16));
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_) {
+                const float4* bp = wimg + ((long)(w * 8 + s_) * 2) * 2 * 64 + lane;
+                f16x8p bh[2], bl[2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) { bh[cb] = as_f16x8(bp[(cb * 2) * 64]); bl[cb] = as_f16x8(bp[(cb * 2 + 1) * 64]); }
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const f16x8p ah = as_f16x8(a[s_][rb][0]), al = as_f16x8(a[s_][rb][1]);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cb], acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[cb], acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cb], acc[rb][cb], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int rd = 0; rd < 4; ++rd) {
+                const int rb = rd >> 1, cb = rd & 1;
+                acc_to_lds32(acc[rb][cb], red, w, lane);
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int o = gr * 32 + 8 * g + g8;
+                    rec[rd][g] = (red[o] + red[HR * 32 + o] + red[2 * HR * 32 + o] + red[3 * HR * 32 + o]) * (H2_INV_SA * invb[32 * cb + 8 * g + g8]);
+                }
+                __syncthreads();
+            }
+        }
+        if (st_on) STAMP(3, 8);
+    }
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(256, 1) void dec_persist_sample_kernel(PersistK2 P2, PersistK P1, PersistS Q) {
+    if (blockIdx.x < 2 * HWG) dec_persist_att2_body<true, BIG, true>(P2, blockIdx.x, &Q);
+    else dec_persist_lstm_samp_body(P1, Q, blockIdx.x - 2 * HWG);
+}
+
+// logit weights -> the image the logits role streams: one power-of-two scale per vocabulary column over the whole contraction (3 x 512)
+__global__ __launch_bounds__(256) void logit_scale_kernel(const float* __restrict__ W, int V1, float* __restrict__ sc, float* __restrict__ inv) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;          // one wave per column
+    if (v >= LWG * LCOLS) return;
+    float mx = 0.f;
+    if (v < V1) {
+        const float4* wp = reinterpret_cast<const float4*>(W + (long)v * 3 * PH);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float4 x = wp[lane + 64 * i];
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) {
+        const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
+        int e = (ex == 0 || ex == 255) ? 14 : ex - 127;
+        e = max(e, 14 - 126);
+        sc[v] = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+        inv[v] = ldexpf(1.f, e - 14);
+    }
+}
+__global__ __launch_bounds__(256) void logit_image_kernel(const float* __restrict__ W, int V1, const float* __restrict__ sc, float4* __restrict__ img) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;           // (workgroup, stream block, k step, tile, lane)
+    if (idx >= (long)LWG * 3 * 16 * LCT * 64) return;
+    const int lane = (int)(idx & 63);
+    long r = idx >> 6;
+    const int c = (int)(r % LCT); r /= LCT;
+    const int s_ = (int)(r & 15); r >>= 4;
+    const int kb = (int)(r % 3), b = (int)(r / 3);
+    const int v = LCOLS * b + 16 * c + (lane & 15), kk = PH * kb + 32 * s_ + 8 * (lane >> 4);
+    float xv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (v < V1) {
+        const float4 x0 = *reinterpret_cast<const float4*>(W + (long)v * 3 * PH + kk), x1 = *reinterpret_cast<const float4*>(W + (long)v * 3 * PH + kk + 4);
+        xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+    }
+    const float f = sc[v];
+    unsigned hw[8], lw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { unsigned short hi, lo; split_h2(xv[j] * f, hi, lo); hw[j] = hi; lw[j] = lo; }
+    const long base = ((((long)(b * 3 + kb) * 16 + s_) * LCT + c) * 2) * 64 + lane;
+    reinterpret_cast<uint4*>(img)[base] = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+    reinterpret_cast<uint4*>(img)[base + 64] = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
+}
+
+// keys + per-workgroup (maximum, sum of exponentials) -> seq / seq_logp / the unfinished bookkeeping of OldModel.sample (:171-183): one
+// wave per (event, step).  The emitted token is masked once the event has produced <eos> at this or an earlier step (the network kept
+// consuming the raw arg-max); the sum over the 64 workgroups' partials runs in a fixed butterfly order.
+__global__ __launch_bounds__(64) void sample_finish_kernel(const unsigned long long* __restrict__ KEY, const float* __restrict__ LSE, int N, int L,
+                                                         long long* __restrict__ seq, float* __restrict__ seq_logp, int* __restrict__ n_unfinished) {
+    const int n = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const unsigned long long key = KEY[(long)t * PROWS + n];
+    u32 u = (u32)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    const float M = __uint_as_float(u);
+    const int bi = (int)(0xFFFFFFFFu - (u32)key);
+    const float* lp = LSE + (((long)t * LWG + lane) * PROWS + n) * 2;
+    const float m = lp[0];
+    float s = m > -INFINITY ? lp[1] * expf(m - M) : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    // unfinished after step t <=> every arg-max of steps 0..t is a word (> 0)
+    int ok = 1;
+    for (int j = lane; j <= t; j += 64) ok = ok && ((0xFFFFFFFFu - (u32)KEY[(long)j * PROWS + n]) > 0u);
+    const int un = __all(ok);
+    if (lane == 0) {
+        seq[(long)n * L + t] = un ? bi : 0;
+        seq_logp[(long)n * L + t] = -logf(s);
+        if (un) atomicAdd(&n_unfinished[t + 1], 1);
+    }
+}
 
 // ---- the forward pair as ONE launch: workgroups [0, 2 HWG) run the attention chain, [2 HWG, 2 HWG + 2 NS) the two plain LSTM streams.
 // Two concurrent launches on two HIP streams need two hardware queues; a process that owns more streams than the runtime has queues
@@ -2389,6 +2876,8 @@ static PersistHost& phost() {
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_sample_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
+        good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_sample_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_FWD) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_BWD) == hipSuccess;
         good = good && hipFuncSetAttribute(reinterpret_cast<const void*>(dec_persist_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_BWD) == hipSuccess;
         (void)hipGetLastError();
@@ -2572,6 +3061,111 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     return 0;
 }
 
+
+// ---- greedy decoding on the persistent kernels (SAMP instantiations) ----
+struct PersistLayoutS { long key, cnt, zero_end, lse, xc3, xs3, total; };
+static PersistLayoutS persist_layout_s(int S) {
+    PersistLayoutS L;
+    long off = 0;
+    auto take = [&](long n) { long o = off; off += (n + 63) / 64 * 64; return o; };
+    L.key = take((long)S * PROWS * 2);
+    L.cnt = take((long)S * CNT_LINE);
+    L.zero_end = off;
+    L.lse = take((long)S * LWG * PROWS * 2);
+    L.xc3 = take((long)S * 2 * 3 * HR * PH);
+    L.xs3 = take((long)S * PROWS * 3);
+    L.total = off;
+    return L;
+}
+long persist_sample_ws_floats(int S) { return persist_layout_s(S).total; }
+long persist_logit_image_floats() { return (long)LWG * 3 * 16 * LCT * 2 * 64 * 4 + 2L * LWG * LCOLS; }
+
+// vocabulary within the logits role's 64 x 80 columns, fp16-pair forms on, shapes as the teacher-forced kernel (events are processed 64 per launch)
+bool persist_sample_eligible(const echr_dec_args* a) {
+    echr_dec_args b = *a;
+    b.N = b.N < PROWS ? b.N : PROWS;
+    return config().persist && config().persist_sample && config().persist_h2 && config().persist_split && config().persist_merge && persist_shape_ok(&b) &&
+           a->V1 <= LWG * LCOLS && a->V1 >= 2;
+}
+
+int persist_logit_image(const float* w_logit, int V1, float* img, hipStream_t st) {
+    float* sc = img + (long)LWG * 3 * 16 * LCT * 2 * 64 * 4;
+    float* inv = sc + LWG * LCOLS;
+    hipLaunchKernelGGL(logit_scale_kernel, dim3(LWG * LCOLS / 4), dim3(256), 0, st, w_logit, V1, sc, inv);
+    if (int rc = check_launch("logit_scale")) return rc;
+    const long items = (long)LWG * 3 * 16 * LCT * 64;
+    hipLaunchKernelGGL(logit_image_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, w_logit, V1, sc, reinterpret_cast<float4*>(img));
+    return check_launch("logit_image");
+}
+
+// one launch decodes up to 64 events for a->S steps; `a` describes those events (N <= 64, pointers already offset)
+int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st) {
+    PersistHost& h = phost();
+    ECHR_REQUIRE(h.ok && a->N <= PROWS, "persist_sample: device state unavailable");
+    const PersistLayout L = persist_layout(a->S);
+    const PersistLayout2 L2 = persist_layout2(a->S);
+    const PersistLayoutS LS = persist_layout_s(a->S);
+    const DropCfg off{0u, 0u, 0u, 0u, 1.f, 0};          // decoding runs in eval mode: every dropout multiplier is 1
+    PersistK K;
+    K.N = a->N; K.A = a->A; K.D = a->D; K.S = a->S; K.ld_att = a->E + a->D;
+    for (int k = 0; k < 3; ++k) { K.w_hh[k] = a->w_hh[k]; K.GATES[k] = nullptr; K.CS[k] = nullptr; }
+    K.w_h2a = a->w_h2a; K.b_h2a = a->b_h2a; K.w_att = a->w_ih[1] + a->E; K.w_alpha = a->w_alpha;
+    K.PALL = B.PALL; K.c3d = a->c3d; K.ev_start = a->ev_start; K.ev_len = a->ev_len;
+    K.HS = nullptr; K.OUTD = nullptr; K.QS = nullptr; K.WT = nullptr; K.ATT = nullptr;
+    float* x2 = B.xws;
+    float* x = x2 + L2.total;
+    K.cnt = reinterpret_cast<u32*>(x + L.cnt); K.XC = x + L.xc; K.XS = x + L.xs; K.GRAN = reinterpret_cast<unsigned long long*>(x + L.gran);
+    K.XH1 = x + L.xh1; K.XH0 = x + L.xh0; K.XH2 = x + L.xh2; K.XQ = x + L.xq; K.WU = x + L.wu;
+    K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
+    K.spin_limit = config().persist_spin_limit > 0 ? (u32)config().persist_spin_limit : SPIN_LIMIT; K.inject = (u32)config().persist_inject_timeout;
+    K.dh = off; K.dout = off;
+    K.stamps = nullptr;
+    if (config().persist_stamps == 1) {
+        if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
+        if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
+    }
+    PersistK2 K2;
+    K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
+    K2.w_hh1 = a->w_hh[1]; K2.w_h2a = a->w_h2a; K2.b_h2a = a->b_h2a; K2.w_att = K.w_att; K2.w_alpha = a->w_alpha;
+    K2.PALL = B.PALL; K2.c3d = a->c3d; K2.ev_start = a->ev_start; K2.ev_len = a->ev_len;
+    K2.GATES1 = nullptr; K2.CS1 = nullptr; K2.HS = nullptr; K2.OUTD = nullptr; K2.QS = nullptr; K2.WT = nullptr; K2.ATT = nullptr;
+    K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XC = x2 + L2.xc; K2.XS = x2 + L2.xs; K2.GRAN = reinterpret_cast<unsigned long long*>(x2 + L2.gran);
+    K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
+    K2.abort_word = h.abort_dev; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = off; K2.dout = off;
+    K2.spin_limit = K.spin_limit; K2.inject = K.inject;
+    PersistS Q;
+    for (int k = 0; k < 3; ++k) Q.TG[k] = B.TG[k];
+    Q.base0 = B.EVB0; Q.base2 = B.VIDB;
+    Q.KEY = reinterpret_cast<unsigned long long*>(B.sws + LS.key);
+    Q.cnt_tok = reinterpret_cast<u32*>(B.sws + LS.cnt);
+    Q.LIMG = reinterpret_cast<const float4*>(B.limg);
+    Q.linv = B.limg + (long)LWG * 3 * 16 * LCT * 2 * 64 * 4 + LWG * LCOLS;
+    Q.lbias = a->b_logit;
+    Q.LSE = B.sws + LS.lse; Q.XC3 = B.sws + LS.xc3; Q.XS3 = B.sws + LS.xs3;
+    Q.cnt2 = K2.cnt; Q.XH1 = K2.XH1; Q.V1 = a->V1;
+    if (hipMemsetAsync(x2 + L2.zero_begin, 0, (size_t)(L2.total - L2.zero_begin + L.xc) * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(B.sws, 0, (size_t)LS.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_sample: memset failed"); return -5; }
+    {
+        const double wbytes = 4.0 * (3.0 * 4 * PH * PH + (double)PH * PH + 4.0 * PH * a->D) + 4.0 * a->S * 3.0 * PH * a->V1;      // the logit weights are streamed once per step
+        const double obytes = 4.0 * (double)a->N * a->A * (PH + a->D);
+        ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH) + 2.0 * a->S * PROWS * 3.0 * PH * a->V1, wbytes + obytes, st);
+        const bool big = a->A > PSET2;
+        bool launched = false;
+        if (config().persist_coop) {
+            void* kargs[3] = {&K2, &K, &Q};
+            const void* fn = big ? reinterpret_cast<const void*>(dec_persist_sample_kernel<true>) : reinterpret_cast<const void*>(dec_persist_sample_kernel<false>);
+            if (hipLaunchCooperativeKernel(fn, dim3(2 * HWG + 2 * NS), dim3(256), kargs, LDS_BYTES_FWD, st) == hipSuccess) launched = true;
+            else coop_refused("persist_sample", hipGetErrorString(hipGetLastError()));
+        }
+        if (!launched) {
+            if (big) hipLaunchKernelGGL((dec_persist_sample_kernel<true>), dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K, Q);
+            else hipLaunchKernelGGL((dec_persist_sample_kernel<false>), dim3(2 * HWG + 2 * NS), dim3(256), LDS_BYTES_FWD, st, K2, K, Q);
+            if (int rc = check_launch("dec_persist_sample")) return rc;
+        }
+    }
+    hipLaunchKernelGGL(sample_finish_kernel, dim3(a->N, a->S), dim3(64), 0, st, Q.KEY, Q.LSE, a->N, a->S, B.seq, B.seq_logp, B.n_unfinished);
+    return check_launch("sample_finish");
+}
 
 bool persist_bwd_eligible(const echr_dec_args* a) { return config().persist_bwd && persist_shape_ok(a); }
 

@@ -355,10 +355,15 @@ class DecoderFunction(torch.autograd.Function):
         return (g_video, g_event, None, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
-def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, debug=None, multinomial=False, temperature=1.0, seed=0):
+def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, debug=None, multinomial=False, temperature=1.0, seed=0,
+                  table_cache=None):
     """OldModel.sample (OldModel_NEW.py:139-187) with every step on device; one host sync at the end.  Greedy arg-max by default
     (sample_max = 1); multinomial=True draws each token from softmax(logp / temperature) (:160-168) with the library's Philox stream
     keyed by `seed`.
+
+    `table_cache`: a dict owned by the caller (one per model); the persistent decoder's parameter-only operands (token-side gate tables,
+    logit-weight image) are kept in it and reused while the parameters are unchanged (data pointers, torch version counters and the
+    library's own PARAM_EPOCH).
 
     Returns (seq int64 [N,T], logp fp32 [N,T]) with T <= seq_length, or ([], []) when nothing was generated."""
     lib = L.load()
@@ -373,8 +378,20 @@ def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, de
     seq = torch.empty(N, seq_length, device=dev, dtype=torch.int64)
     slp = torch.empty(N, seq_length, device=dev, dtype=torch.float32)
     nun = torch.empty(seq_length + 1, device=dev, dtype=torch.int32)
+    tables, valid = None, 0
+    if table_cache is not None and not multinomial:
+        nt = lib.echr_sampler_table_floats(C.byref(a))
+        if nt > 0:
+            key = (PARAM_EPOCH[0], nt, str(dev)) + tuple((p.data_ptr(), p._version) for p in params)
+            tables = table_cache.get('tables')
+            if tables is None or tables.numel() != nt or tables.device != dev:
+                tables = table_cache['tables'] = torch.empty(nt, device=dev, dtype=torch.float32)
+                table_cache['key'] = None
+            valid = 1 if table_cache.get('key') == key else 0
+            table_cache['key'] = key
     sa = L.SampleArgs(a, seq_length, L.ptr(seq, torch.int64), L.ptr(slp), L.ptr(nun, torch.int32), L.ptr(wss),
-                      1 if multinomial else 0, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF)
+                      1 if multinomial else 0, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                      L.ptr(tables) if tables is not None else None, valid)
     L.check(lib.echr_decoder_sample(C.byref(sa), L.stream_ptr()), 'decoder_sample')
     counts = nun.cpu().numpy()                 # the only device->host sync of the whole decode
     L.check(lib.echr_check_async(), 'decoder_sample')
@@ -492,9 +509,15 @@ class MaskedNLL(torch.autograd.Function):
         return g_logp
 
 
+# Bumped by every parameter update the library performs through raw pointers (clamp_adam_: torch's per-tensor version counters do not see
+# those writes); part of the key of caches of parameter-derived operands (OldModel.sample's decoding tables).
+PARAM_EPOCH = [0]
+
+
 def clamp_adam_(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip=100.0):
     """In-place fused clamp(+-clip) + Adam over flat fp32 buffers (misc/utils.py:107-111 + optim.Adam)."""
     lib = L.load()
+    PARAM_EPOCH[0] += 1
     L.check(lib.echr_clamp_adam(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), int(step), float(lr), float(beta1),
                                 float(beta2), float(eps), float(clip), L.stream_ptr()), 'clamp_adam')
 

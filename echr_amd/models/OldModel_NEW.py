@@ -201,9 +201,11 @@ class OldModel(nn.Module):
             self._sample_calls = getattr(self, '_sample_calls', 0) + 1
             seed = (self._drop_seed * 0x9E3779B97F4A7C15 + self._sample_calls) & 0xFFFFFFFFFFFFFFFF
         with torch.no_grad():
+            if not hasattr(self, '_sample_tables'):
+                self._sample_tables = {}          # decoding operands derived from the parameters alone, reused across calls (EF.greedy_sample)
             return EF.greedy_sample(video, event, cv.feats, cv.ev_start, cv.ev_len, cv.max_len, self.seq_length,
                                     self.native_params(), multinomial=multinomial, temperature=float(opt.get('temperature', 1.0)),
-                                    seed=seed)
+                                    seed=seed, table_cache=self._sample_tables)
 
 
 class Attention(nn.Module):

@@ -287,8 +287,13 @@ typedef struct {
                                 reproducible per seed, the reference's distribution but not torch.multinomial's random stream */
     float temperature;       /* multinomial only; <= 0 means 1 */
     uint64_t seed;
+    float* tables;           /* optional cache of the parameter-only operands of the persistent greedy decoder (token-side gate tables
+                                embed . W_ih_k[:, :E]^T, logit-weight image): echr_sampler_table_floats floats, owned by the caller.  NULL:
+                                they are rebuilt inside ws_sample on every call (~0.15 ms at V1 = 5001) */
+    int32_t tables_valid;    /* 1: `tables` holds the operands of the CURRENT parameters (skip the rebuild); 0: rebuild into `tables` */
 } echr_sample_args;
 int64_t echr_sampler_ws_floats(const echr_dec_args* a);
+int64_t echr_sampler_table_floats(const echr_dec_args* a);      /* 0 when the persistent decoder does not apply to these shapes / settings */
 int echr_decoder_sample(const echr_sample_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -397,6 +402,8 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *   "persist_inject_timeout" code  diagnostic: the hand-off wait with this code (attention chain: 100000 * edge + timestep, edge 1 h1 / 2 q / 3 context / 4 d q / 5 d h / 6 d G / 7 d ATT) never completes, so the
  *                      launch aborts through its time-out path (tests/test_gpu_parity.py::test_persistent_abort_path); 0 = off
  *   "sst_persist" 0/1   (default 1, ECHR_SST_PERSIST) proposal encoder's recurrences as one persistent launch per direction (H = 512)
+ *   "persist_sample" 0/1 (default 1, ECHR_PERSIST_SAMPLE) greedy decoding (echr_decoder_sample) as one persistent launch per 64 events, every step
+ *                      on device (vocabularies of up to 5120 words, the persistent forward kernel's shapes); 0 = one launch chain per step
  *   "embed_fused" 0/1   (default 0, ECHR_EMBED_FUSED) token-embedding gradient through echr_gemm_desc.row_index instead of d XT + scatter pass
  *                      (measured slower: atomics of all k-slices contend on the <bos> / frequent-word rows)
  *   "tail_early"  0/1   (default 0, ECHR_TAIL_EARLY) fork the asynchronous decoder-backward tail ahead of the LSTM-layer gradient stage

@@ -420,6 +420,76 @@ def test_greedy_sample_bit_exact(case):
     assert np.abs(lp.cpu().numpy() - g['sample|logp']).max() < TOL_LOGP
 
 
+@pytest.mark.parametrize('case', ['c2', 'c2full', 'c3bench'])
+def test_persistent_sampler_equals_launch_per_step_sampler(case):
+    """Greedy decoding as ONE persistent launch (logits role + arg-max keys inside the recurrence kernels) against the launch-per-step
+    form: same sequences, log-probs to rounding."""
+    from echr_amd import _lib
+    lib = _lib.load()
+    opt, params, vid = synth.make_case(case)
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    outs = []
+    try:
+        for flag in (1, 0):
+            lib.echr_config_set(b'persist_sample', flag)
+            with torch.no_grad():
+                seq, lp = m(tap, c3d, lda, [], vid['ind'], vid['soi'], mode='eval')
+            outs.append((seq.cpu().numpy(), lp.cpu().numpy()))
+    finally:
+        lib.echr_config_set(b'persist_sample', 1)
+    assert outs[0][0].shape == outs[1][0].shape and outs[0][0].shape[1] > 1
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.abs(outs[0][1] - outs[1][1]).max() < TOL_LOGP
+
+
+def test_persistent_sampler_table_cache_follows_parameter_updates():
+    """The persistent decoder caches its parameter-only operands (token-side gate tables, logit image) on the model.  A second decode must
+    reuse them (bitwise the same output); an in-place parameter update (torch version counter) and a library optimiser step (raw-pointer
+    write: functional.PARAM_EPOCH) must each invalidate them -- checked against the launch-per-step form on the updated model."""
+    from echr_amd import _lib
+    from echr_amd import functional as EF
+    from echr_amd.optim import ClampAdam
+    lib = _lib.load()
+    opt, params, vid = synth.make_case('c2')
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+
+    def decode(flag=1):
+        lib.echr_config_set(b'persist_sample', flag)
+        try:
+            with torch.no_grad():
+                seq, lp = m(tap, c3d, lda, [], vid['ind'], vid['soi'], mode='eval')
+            return seq.cpu().numpy(), lp.cpu().numpy()
+        finally:
+            lib.echr_config_set(b'persist_sample', 1)
+
+    s1, l1 = decode()
+    cache = m.lm_model._sample_tables
+    assert cache.get('key') is not None and cache['tables'].numel() > 0
+    key1 = cache['key']
+    s2, l2 = decode()
+    assert cache['key'] == key1 and np.array_equal(s1, s2) and np.abs(l1 - l2).max() < 2e-6      # (the event encoder's split-K sums are not bitwise repeatable)
+    with torch.no_grad():
+        m.lm_model.embed.weight.mul_(-1.0)            # in-place update through torch: version counter
+    s3, l3 = decode()
+    assert cache['key'] != key1
+    r3, rl3 = decode(0)
+    assert np.array_equal(s3, r3) and np.abs(l3 - rl3).max() < TOL_LOGP
+    assert not np.array_equal(s3, s1)
+    key3 = cache['key']
+    optim = ClampAdam(m.parameters(), lr=0.05)        # raw-pointer update by the library's fused kernel
+    for p_ in m.parameters():
+        p_.grad = torch.ones_like(p_)
+    optim.step()
+    s4, l4 = decode()
+    assert cache['key'] != key3
+    r4, rl4 = decode(0)
+    assert np.array_equal(s4, r4) and np.abs(l4 - rl4).max() < TOL_LOGP
+
+
 @pytest.mark.parametrize('V1', [9001, 13001])
 def test_greedy_sample_large_vocabulary_vs_oracle(V1):
     """Vocabularies beyond the benchmark's 5001 (ActivityNet Captions has ~10 k words): the arg-max kernel's long-row instantiations (rows of
@@ -443,10 +513,22 @@ def test_greedy_sample_large_vocabulary_vs_oracle(V1):
     assert np.abs(lp1.cpu().numpy() - lp_o.numpy()).max() < TOL_LOGP
 
 
-def test_greedy_sampler_is_bitwise_reproducible():
-    """`seq` is an index output: two decodes of the same inputs must agree bit for bit -- sequence, log-probs AND the raw logits of
-    the last step (no fp32-atomic split-K anywhere on the sampler path; OldModel_NEW.py:158 takes the lowest index on ties)."""
+@pytest.mark.parametrize('persistent', [1, 0])
+def test_greedy_sampler_is_bitwise_reproducible(persistent):
+    """`seq` is an index output: two decodes of the same inputs must agree bit for bit -- sequence, log-probs AND (launch-per-step form) the
+    raw logits of the last step: no fp32-atomic split-K anywhere on the sampler path, the persistent form folds its arg-max through an
+    order-independent 64-bit atomic max and adds the context partials in slot order; OldModel_NEW.py:158 takes the lowest index on ties."""
     from echr_amd import functional as EF
+    from echr_amd import _lib
+    lib = _lib.load()
+    lib.echr_config_set(b'persist_sample', persistent)
+    try:
+        _reproducible(EF, persistent)
+    finally:
+        lib.echr_config_set(b'persist_sample', 1)
+
+
+def _reproducible(EF, persistent):
     opt, params, vid = synth.make_case('c2full')
     m = U.build_gpu_model(opt, params, False)
     dev = torch.device('cuda')
@@ -465,8 +547,11 @@ def test_greedy_sampler_is_bitwise_reproducible():
     for r in runs[1:]:
         assert torch.equal(r['seq_full'], runs[0]['seq_full'])
         assert torch.equal(r['logp_full'], runs[0]['logp_full'])
-        assert torch.equal(r['last_logits'], runs[0]['last_logits'])
-    assert torch.isfinite(runs[0]['last_logits']).all()
+        if not persistent:
+            assert torch.equal(r['last_logits'], runs[0]['last_logits'])
+    if not persistent:
+        assert torch.isfinite(runs[0]['last_logits']).all()
+    assert torch.isfinite(runs[0]['logp_full']).all()
 
 
 def test_sampler_at_eval_size_is_per_event_and_matches_small_batch():
