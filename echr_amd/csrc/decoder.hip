@@ -1530,16 +1530,19 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
     DecWs w = carve_ws(&a, a.ws);
     SampWs s = carve_samp(&a, sa->ws_sample);
     const DropCfg off = make_drop(nullptr, 0.f);
-    RC(fill_zero(w.HS, (long)N * 3 * H, st));
-    for (int k = 0; k < 3; ++k) RC(fill_zero(w.CS[k], (long)N * H, st));
-    RC(fill_zero(reinterpret_cast<float*>(s.IT), N, st));           // <bos> = 0
-    RC(fill_zero(reinterpret_cast<float*>(sa->n_unfinished), L + 1, st));
-    RC(fill_zero(reinterpret_cast<float*>(sa->seq), 2L * N * L, st));
-    RC(fill_zero(sa->seq_logp, (long)N * L, st));
+    const bool persistent = !sa->multinomial && config().gemm_h2 && persist_sample_eligible(&a);
+    {
+        // one fill launch: the launch-per-step form starts from zero state / <bos> = 0 and zero outputs; the persistent form writes every
+        // output element itself and only needs the unfinished counters cleared
+        float* zp[8] = {reinterpret_cast<float*>(sa->n_unfinished), w.HS, w.CS[0], w.CS[1], w.CS[2], reinterpret_cast<float*>(s.IT),
+                        reinterpret_cast<float*>(sa->seq), sa->seq_logp};
+        long zn[8] = {L + 1, (long)N * 3 * H, (long)N * H, (long)N * H, (long)N * H, N, 2L * N * L, (long)N * L};
+        RC(fill_zero_multi(zp, zn, persistent ? 1 : 8, st));
+    }
     // many events (evaluation: up to 1000 proposals): the per-step token-side gate products and the logits product are 6 + 15 GF -- they run
     // on h2 operands (weights packed once per decode, the step's N rows packed per step; one fixed-order k loop per tile, so the decode stays
     // bitwise reproducible).  Few events: exact fp32 MFMA as before (the products are launch-bound there).
-    if (!sa->multinomial && config().gemm_h2 && persist_sample_eligible(&a)) {
+    if (persistent) {
         // every step on device: one persistent launch per 64 events.  Per call: the time-invariant products, the token-side gate tables
         // TG_k = embed . W_ih_k[:, :E]^T (+ the stream's biases / video part; the event part of stream 0 stays per event) and the logit image
         // TG_k = embed . W_ih_k[:, :E]^T (+ stream 1's biases; the event part of stream 0 and the video part of stream 2 stay outside: they

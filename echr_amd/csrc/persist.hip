@@ -206,6 +206,26 @@ __device__ __forceinline__ bool wait_total2(const PK& P, u32* line_a, u32 target
     return r;
 }
 
+// a wait whose counters were sampled EARLIER (peek_issue: the loads ride behind other work, peek_ready: no memory latency left): the usual
+// case -- the producers finished long ago -- then costs two barriers instead of a round trip to L2; otherwise the polling loop takes over
+__device__ __forceinline__ u32 peek_issue(u32* line_a, u32* line_b) {
+    const int lane = threadIdx.x;
+    return lane < 2 * SHARDS ? __hip_atomic_load((lane < SHARDS ? line_a : line_b) + (lane & (SHARDS - 1)) * SHSTRIDE, __ATOMIC_RELAXED, ECHR_AGENT) : 0u;
+}
+template <typename PK>
+__device__ __forceinline__ bool wait_peeked2(const PK& P, u32 peek, u32* line_a, u32 target_a, u32* line_b, u32 target_b, int* flag, u32 code) {
+    if (threadIdx.x < 64) {
+        u32 v = peek;
+        v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        const u32 va = __shfl(v, 0), vb = __shfl(v, SHARDS);
+        if (threadIdx.x == 0) *flag = (va >= target_a && vb >= target_b && code != P.inject) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool r = *flag != 0;
+    __syncthreads();
+    return r ? true : wait_total2(P, line_a, target_a, line_b, target_b, flag, code);
+}
+
 // ---- MFMA pieces: one wave multiplies its k range [128 w, 128 w + 128) of a [64 x 512] A operand by 16-column tiles ------------
 // A fragments straight from the exchange buffer: lane (r = l & 15, kq = l >> 4) holds, for row block rb and k chunk c, the
 // float4 A[16 rb + r][128 w + 16 c + 4 kq ..+3]; element j of it feeds MFMA j of the chunk (B uses the same k pairing).
@@ -863,7 +883,7 @@ struct PersistS {
     const float4* LIMG;            // logit weights as fp16-pair planes [workgroup 64][stream 3][k step 16][tile 5][plane 2][lane 64] x 16 bytes
     const float* linv;             // [64 * 80] inverse column scales
     const float* lbias;            // [V1]
-    float* LSE;                    // [S][64 workgroups][64 events][2]: (local maximum, sum of exp(x - local maximum)) for the log-probability
+    float* LSE;                    // [S][64 events][64 workgroups][2]: (local maximum, sum of exp(x - local maximum)) for the log-probability
     float* XC3; float* XS3;        // context partials / exponential sums, one slot per workgroup of an event (summed in a fixed order)
     u32* cnt2;                     // the attention layout's counters (the logits role waits for h1)
     const float* XH1;              // its h1 exchange planes
@@ -1625,12 +1645,13 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
     __syncthreads();
     const bool st_on = b == 0;
     const int nhalf = N > HR ? 2 : 1;
+    u32 peek_tok = 0;
     for (int t = 0; t < S; ++t) {
         if (st_on) STAMP(3, 0);
         // ---- token t -> gate pre-activations, cells, h(t) ----
         u32 tok[2] = {0u, 0u};
         if (t > 0) {
-            if (!wait_total(P, Q.cnt_tok + (long)(t - 1) * CNT_LINE, LWG, flag, 400000u + t)) return;
+            if (!wait_peeked2(P, peek_tok, Q.cnt_tok + (long)(t - 1) * CNT_LINE, LWG, Q.cnt_tok + (long)(t - 1) * CNT_LINE, LWG, flag, 400000u + t)) return;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const u32 x = 0xFFFFFFFFu - (u32)__hip_atomic_load(Q.KEY + (long)(t - 1) * PROWS + min(32 * r + gr, N - 1), __ATOMIC_RELAXED, ECHR_AGENT);
@@ -1724,6 +1745,7 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
                 }
             }
         };
+        u32 peek_h1 = 0;
         {
             // h0's four k steps, then h2's: four rotating buffers, three steps' loads in flight; the first three steps' weights go out ahead
             // of the wait for the two streams' h(t)
@@ -1753,6 +1775,7 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             fetch_b(2, 3, fb1); fetch_a(2, 3, a2, fa1);
             mma(fa2, fb2);
             __builtin_amdgcn_sched_barrier(0);
+            if (tid < 64) peek_h1 = peek_issue(cnt2(C_H1, t, 0), cnt2(C_H1, t, nhalf - 1));      // h1(t) is usually complete by now: sample its counters behind the last products
             mma(fa0, fb0);
             mma(fa1, fb1);
         }
@@ -1762,7 +1785,7 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             const float* a1 = Q.XH1 + (long)t * 2 * HR * PH;          // both halves: [m][plane][k / 8][32 rows][8 halves] (2 x 64 KB = XB bytes)
             float4 fa0[4][2], fb0[LCT][2], fa1[4][2], fb1[LCT][2], fa2[4][2], fb2[LCT][2], fb3[LCT][2];
             fetch_b(1, 0, fb0); fetch_b(1, 1, fb1); fetch_b(1, 2, fb2); fetch_b(1, 3, fb3);
-            if (!wait_total2(P, cnt2(C_H1, t, 0), HG1, cnt2(C_H1, t, nhalf - 1), HG1, flag, 150000u + t)) return;
+            if (!wait_peeked2(P, peek_h1, cnt2(C_H1, t, 0), HG1, cnt2(C_H1, t, nhalf - 1), HG1, flag, 150000u + t)) return;
             if (st_on) STAMP(3, 5);
             fetch_a(1, 0, a1, fa0); fetch_a(1, 1, a1, fa1); fetch_a(1, 2, a1, fa2);
             __builtin_amdgcn_sched_barrier(0);
@@ -1772,6 +1795,25 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             mma(fa1, fb1); mma(fa2, fb2); mma(fa0, fb3);
         }
         if (st_on) STAMP(3, 6);
+        // the stream's own h(t) for the recurrent product at the end of the step: its 32 fragment loads ride behind the fold
+        float4 ar[8][2][2];
+        auto fetch_r = [&](int s_) {
+            const __amdgpu_buffer_rsrc_t ra = mk_rsrc(XH + (long)t * PROWS * PH, XB);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (u32)(((lane >> 5) * PROWS + (lane & 31)) * 16),
+                                                                          (u32)((((pl * 64 + 16 * ws + 2 * s_) * PROWS) + 32 * rb) * 16), 16);
+                    ar[s_][rb][pl] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < S) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) fetch_r(s_);          // the first half now (register budget), the second behind the publish
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // the four waves' partial tiles -> finished logits of (event ev, 20 columns) per thread
         float lv[LCT][4];
 #pragma unroll
@@ -1823,7 +1865,7 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
                     const unsigned long long key = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mi);
                     __hip_atomic_fetch_max(Q.KEY + (long)t * PROWS + ev, key, __ATOMIC_RELAXED, ECHR_AGENT);
                 }
-                float* lp = Q.LSE + (((long)t * LWG + b) * PROWS + ev) * 2;
+                float* lp = Q.LSE + (((long)t * PROWS + ev) * LWG + b) * 2;
                 lp[0] = mx; lp[1] = se;
             }
         }
@@ -1838,15 +1880,8 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
                 for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                     for (int g = 0; g < 16; ++g) acc[rb][cb][g] = 0.f;
-            const __amdgpu_buffer_rsrc_t ra = mk_rsrc(XH + (long)t * PROWS * PH, XB);
-            float4 a[8][2][2];
 #pragma unroll
-            for (int s_ = 0; s_ < 8; ++s_)
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl)
-                        a[s_][rb][pl] = ld16_bulk(ra, (u32)((((pl * 64 + 16 * w + 2 * s_ + (lane >> 5)) * PROWS) + 32 * rb + (lane & 31)) * 16));
+            for (int s_ = 4; s_ < 8; ++s_) fetch_r(s_);
 #pragma unroll
             for (int s_ = 0; s_ < 8; ++s_) {
                 const float4* bp = wimg + ((long)(w * 8 + s_) * 2) * 2 * 64 + lane;
@@ -1855,7 +1890,7 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
                 for (int cb = 0; cb < 2; ++cb) { bh[cb] = as_f16x8(bp[(cb * 2) * 64]); bl[cb] = as_f16x8(bp[(cb * 2 + 1) * 64]); }
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) {
-                    const f16x8p ah = as_f16x8(a[s_][rb][0]), al = as_f16x8(a[s_][rb][1]);
+                    const f16x8p ah = as_f16x8(ar[s_][rb][0]), al = as_f16x8(ar[s_][rb][1]);
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) {
                         acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cb], acc[rb][cb], 0, 0, 0);
@@ -1864,6 +1899,8 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
                     }
                 }
             }
+            // token t is on its way (this workgroup published its fold above): sample its counter behind the tile sums
+            if (tid < 64) peek_tok = peek_issue(Q.cnt_tok + (long)t * CNT_LINE, Q.cnt_tok + (long)t * CNT_LINE);
 #pragma unroll
             for (int rd = 0; rd < 4; ++rd) {
                 const int rb = rd >> 1, cb = rd & 1;
@@ -1943,7 +1980,7 @@ __global__ __launch_bounds__(64) void sample_finish_kernel(const unsigned long l
     u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
     const float M = __uint_as_float(u);
     const int bi = (int)(0xFFFFFFFFu - (u32)key);
-    const float* lp = LSE + (((long)t * LWG + lane) * PROWS + n) * 2;
+    const float* lp = LSE + (((long)t * PROWS + n) * LWG + lane) * 2;
     const float m = lp[0];
     float s = m > -INFINITY ? lp[1] * expf(m - M) : 0.f;
 #pragma unroll
@@ -3143,8 +3180,12 @@ int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream
     Q.lbias = a->b_logit;
     Q.LSE = B.sws + LS.lse; Q.XC3 = B.sws + LS.xc3; Q.XS3 = B.sws + LS.xs3;
     Q.cnt2 = K2.cnt; Q.XH1 = K2.XH1; Q.V1 = a->V1;
-    if (hipMemsetAsync(x2 + L2.zero_begin, 0, (size_t)(L2.total - L2.zero_begin + L.xc) * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(B.sws, 0, (size_t)LS.zero_end * sizeof(float), st) != hipSuccess) { set_error("persist_sample: memset failed"); return -5; }
+    {
+        // counters, atomically folded buffers and the arg-max keys: one fill launch
+        float* zp[2] = {x2 + L2.zero_begin, B.sws};
+        long zn[2] = {L2.total - L2.zero_begin + L.xc, LS.zero_end};
+        if (int rc = fill_zero_multi(zp, zn, 2, st)) return rc;
+    }
     {
         const double wbytes = 4.0 * (3.0 * 4 * PH * PH + (double)PH * PH + 4.0 * PH * a->D) + 4.0 * a->S * 3.0 * PH * a->V1;      // the logit weights are streamed once per step
         const double obytes = 4.0 * (double)a->N * a->A * (PH + a->D);
