@@ -17,7 +17,7 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; int persist_coop; int persist_inject_timeout; int persist_spin_limit; int sst_persist; int tail_early; int diag_skip; int embed_fused; int persist_sample; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; int persist_coop; int persist_inject_timeout; int persist_spin_limit; int sst_persist; int tail_early; int diag_skip; int embed_fused; int persist_sample; int posemb_rows; int gemm_skinny; };
 // diag_skip (diagnostic, tools/skip_bounds.py; results are WRONG while a bit is set): 1 = h2 operand packs, 2 = clamp+Adam kernel, 4 = att_post,
 // 8 = embedding scatter-add -- the launch is skipped, which bounds what removing / hiding that work could gain
 Config& config();
@@ -61,6 +61,9 @@ int join_tail(hipStream_t st);          // make st wait for an asynchronous deco
 int persist_read_stamps(unsigned long long* dst, int max_entries);
 unsigned long long* persist_stamp_buffer(int S, hipStream_t st);      // diagnostic: [4][S <= 256][16] stamps, zeroed on st (nullptr: unavailable)
 int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st);
+// C[M, Nc <= 16] = A[M, K] . W[Nc, K]^T + bias for very tall A (a stream over A; exact fp32 MFMA, plain stores)
+bool gemm_skinny_ok(int M, int Nc, int K, long lda, long ldw, const float* A, const float* W);
+int gemm_skinny_nt(const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, int M, int Nc, int K, hipStream_t st);
 // h2-packed operands (csrc/gemm.hip: two block-scaled fp16 planes): bytes of the packed image of a [rows x cols] operand (cols =
 // contraction axis), the packing pass, and a multi-operand packing launch
 struct H2PackJob { const float* src; unsigned char* dst; int R, K; long s_row, s_col; };

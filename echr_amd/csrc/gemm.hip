@@ -1050,6 +1050,57 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st);
 int gemm(const echr_gemm_desc& d, hipStream_t st) { return gemm_impl(&d, 1, st); }
 
+// C[M, Nc <= 16] = A[M, K] . W[Nc, K]^T + bias for very tall A (the event encoder's fc2 over N*N pairs: 1 M rows x 512 -> 16): a pure
+// stream over A.  One wave per 16-row tile, v_mfma_f32_16x16x4_f32 (exact fp32); W lives in registers for the whole launch (K / 16 x 4
+// floats per lane); a lane's A fragment of four consecutive MFMAs is ONE float4 (lane (r, kk) holds A[r][16 s + 4 kk + j], j = MFMA
+// index: a fixed permutation of k that W's registers follow), so a row's 64-byte pieces are read once, in order.
+template <int KS>          // K / 16
+__global__ __launch_bounds__(256) void skinny_nt_kernel(const float* __restrict__ A, long lda, const float* __restrict__ W, long ldw,
+                                                        const float* __restrict__ bias, float* __restrict__ C, long ldc, int M, int Nc, int tiles) {
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, kk = lane >> 4;
+    float4 bw[KS];
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_)
+        bw[s_] = r < Nc ? *reinterpret_cast<const float4*>(W + (long)r * ldw + 16 * s_ + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bv = (bias && r < Nc) ? bias[r] : 0.f;
+    for (int tile = blockIdx.x * 4 + w; tile < tiles; tile += gridDim.x * 4) {
+        const long r0 = (long)tile * 16;
+        const float* ap = A + (r0 + r < M ? r0 + r : (long)M - 1) * lda + 4 * kk;
+        float4 av[KS];
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) av[s_] = *reinterpret_cast<const float4*>(ap + 16 * s_);
+        f32x4s acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_].x, bw[s_].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_].y, bw[s_].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_].z, bw[s_].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s_].w, bw[s_].w, acc, 0, 0, 0);
+        }
+        if (r < Nc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long row = r0 + 4 * kk + i;
+                if (row < M) C[row * ldc + r] = acc[i] + bv;
+            }
+        }
+    }
+}
+
+bool gemm_skinny_ok(int M, int Nc, int K, long lda, long ldw, const float* A, const float* W) {
+    return config().gemm_skinny && M >= 4096 && Nc >= 1 && Nc <= 16 && (K == 512 || K == 256) && lda % 4 == 0 && ldw % 4 == 0 && aligned16(A) && aligned16(W);
+}
+int gemm_skinny_nt(const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, int M, int Nc, int K, hipStream_t st) {
+    ECHR_REQUIRE(gemm_skinny_ok(M, Nc, K, lda, ldw, A, W), "gemm_skinny_nt: unsupported shape");
+    const int tiles = (M + 15) / 16;
+    const int grid = tiles / 4 < 2048 ? (tiles + 3) / 4 : 2048;
+    ProfScope prof(PROF_GEMM, 2.0 * M * Nc * K, 4.0 * ((double)M * K + (double)Nc * K + (double)M * Nc), st);
+    if (K == 512) hipLaunchKernelGGL(skinny_nt_kernel<32>, dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, Nc, tiles);
+    else hipLaunchKernelGGL(skinny_nt_kernel<16>, dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, C, ldc, M, Nc, tiles);
+    return check_launch("skinny_nt");
+}
+
 // Up to 4 problems of identical shape/layout/epilogue mode in ONE launch (the three streams' W_ih / W_hh products): fills the
 // chip better than three 640-workgroup grids and pays one launch ramp.  Problems may share C when they accumulate (beta = 1).
 int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st) {

@@ -404,6 +404,10 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *   "sst_persist" 0/1   (default 1, ECHR_SST_PERSIST) proposal encoder's recurrences as one persistent launch per direction (H = 512)
  *   "persist_sample" 0/1 (default 1, ECHR_PERSIST_SAMPLE) greedy decoding (echr_decoder_sample) as one persistent launch per 64 events, every step
  *                      on device (vocabularies of up to 5120 words, the persistent forward kernel's shapes); 0 = one launch chain per step
+ *   "posemb_rows" 0/1   (default 1, ECHR_POSEMB_ROWS) pairwise position embedding with one thread per frequency (contiguous stores); 0 = one
+ *                      thread per 16 frequencies of a pair
+ *   "gemm_skinny" 0/1   (default 1, ECHR_GEMM_SKINNY) the event encoder's fc2 over >= 4096 event pairs (512 -> <= 16 columns) as a streaming
+ *                      16-row-tile kernel instead of the general tiles
  *   "embed_fused" 0/1   (default 0, ECHR_EMBED_FUSED) token-embedding gradient through echr_gemm_desc.row_index instead of d XT + scatter pass
  *                      (measured slower: atomics of all k-slices contend on the <bos> / frequent-word rows)
  *   "tail_early"  0/1   (default 0, ECHR_TAIL_EARLY) fork the asynchronous decoder-backward tail ahead of the LSTM-layer gradient stage

@@ -262,6 +262,43 @@ def test_event_context_tsrm(case, train_mode):
         assert U.relerr(p.grad.cpu().numpy(), P[k].grad.numpy()) < TOL_GRAD, k
 
 
+def test_event_context_many_events_vs_oracle():
+    """More than 64 events (evaluation-style batches: N * N >= 4096 pairs): the pair MLP's fc2 runs on the streaming 16-row-tile kernel and
+    the position embedding on the thread-per-frequency kernel; forward + backward against the oracle, and against the general kernels."""
+    from echr_amd import functional as EF
+    from echr_amd import _lib
+    from oracle import echr_ref_cpu as O
+    lib = _lib.load()
+    opt = synth.default_opt(vocab_size=300, seq_length=6)
+    params = synth.make_params(opt, 5)
+    vid = synth.make_video(80, 24, 8, 301, seed=9, T_v=200)
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    ref = O.event_context(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), vid['ind'], vid['soi'], opt.n_head, None)
+    ev = EF.event_index_tensors(vid['soi'], vid['ind'], dev)
+    tap, c3d = torch.from_numpy(vid['tap']).to(dev), torch.from_numpy(vid['c3d']).to(dev)
+    outs = []
+    try:
+        for flag in (1, 0):
+            lib.echr_config_set(b'gemm_skinny', flag)
+            lib.echr_config_set(b'posemb_rows', flag)
+            out = m.get_event_context(tap, c3d, None, vid['ind'], vid['soi'], _ev=ev, _drop=EF.DropState(U.SEED, U.OFFSET, False))
+            outs.append(out)
+    finally:
+        lib.echr_config_set(b'gemm_skinny', 1)
+        lib.echr_config_set(b'posemb_rows', 1)
+    assert U.relerr(outs[0].detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
+    assert U.relerr(outs[0].detach().cpu().numpy(), outs[1].detach().cpu().numpy()) < 2e-6
+    w = torch.from_numpy(np.random.RandomState(1).standard_normal(tuple(ref.shape)).astype(np.float32))
+    (ref * w).sum().backward()
+    (outs[0] * w.to(dev)).sum().backward()
+    for k, p in m.named_parameters():
+        if not k.startswith('fusion_model.') or P[k].grad is None:
+            continue
+        assert U.relerr(p.grad.cpu().numpy(), P[k].grad.numpy()) < TOL_GRAD, k
+
+
 @pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full', 'c3bench'])
 @pytest.mark.parametrize('train_mode', [False, True])
 def test_full_path_vs_oracle(case, train_mode):
