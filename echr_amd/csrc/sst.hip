@@ -823,21 +823,27 @@ extern "C" int echr_sst_bwd(const echr_sst_args* a, const echr_sst_grads* g, con
         }
         RC(check_launch("sst_wave_bwd"));
     }
-    // parameter gradients (sums over the T rows); h(t-1) pairs with dG(t): rows 1..T-1
+    // parameter gradients (sums over the T rows); h(t-1) pairs with dG(t): rows 1..T-1.  The two layers' products are independent small
+    // GEMMs (20-25 us each, half a chip): layer 0's run on the library's helper stream beside layer 1's
+    hipStream_t s0 = config().tsrm_fork ? aux_fork(st) : nullptr;
+    const bool fork = s0 != nullptr;
+    if (!fork) s0 = st;
     for (int l = 1; l >= 0; --l) {
+        hipStream_t sl = l == 0 ? s0 : st;
         const float* hs = l == 0 ? w.HS[0] : a->tap_feats;
         const float* xin = l == 0 ? a->x : w.H0D;
         const int din = l == 0 ? D : H;
         d = desc_tn(b.DG[l], 4 * H, xin, din, g->g_w_ih[l], din, 4 * H, din, T); d.split_k = -1; d.beta = zb;
-        RC(gemm(d, st));
+        RC(gemm(d, sl));
         if (T > 1) {
             d = desc_tn(b.DG[l] + 4 * H, 4 * H, hs, H, g->g_w_hh[l], H, 4 * H, H, T - 1); d.split_k = -1; d.beta = zb;
-            RC(gemm(d, st));
+            RC(gemm(d, sl));
         } else if (!z) {
-            RC(fill_zero(g->g_w_hh[l], (long)4 * H * H, st));
+            RC(fill_zero(g->g_w_hh[l], (long)4 * H * H, sl));
         }
-        RC(colsum2(b.DG[l], 4 * H, T, 4 * H, g->g_b_ih[l], g->g_b_hh[l], z, st));
+        RC(colsum2(b.DG[l], 4 * H, T, 4 * H, g->g_b_ih[l], g->g_b_hh[l], z, sl));
     }
+    if (fork) RC(aux_join(st));
     return 0;
 }
 
