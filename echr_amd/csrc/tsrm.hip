@@ -181,6 +181,101 @@ __global__ __launch_bounds__(256) void posemb_rows_kernel(const int* __restrict_
     }
 }
 
+// The embedding emitted directly as the h2-packed A operand of the fc1 product (csrc/gemm.hip: chunks [row block 128][k block 32] of two
+// fp16 planes with the slot swizzle baked in, then the inverse scales), and -- when a backward pass may follow -- also as fp32.  |sin|,
+// |cos| <= 1, so one fixed block scale 2^14 serves every row (the format allows any power of two per row and 256-k segment).  A thread owns
+// (pair, 8 consecutive frequencies): four 16-byte slots per plane.  Saves the packing pass over the 2 GB (N = 1000) tensor and, in inference,
+// the fp32 tensor itself.
+constexpr int PK_ROUNDS = 4;          // a block handles PK_ROUNDS x (256 / (Df / 32)) pairs: the frequency table (one float64 pow each) is built once per block
+__global__ __launch_bounds__(256) void posemb_packed_kernel(const int* __restrict__ ev_start, const int* __restrict__ ev_len, float* __restrict__ pos,
+                                                            unsigned char* __restrict__ pk, int N, int Df) {
+    __shared__ double sdc[16 * PK_ROUNDS], sdl[16 * PK_ROUNDS], sfr[256];
+    extern __shared__ __attribute__((aligned(16))) unsigned char pk_lds[];
+    uint4* stage = reinterpret_cast<uint4*>(pk_lds);          // [2 planes][KT][ppr rows][4 slots] x 16 B: one round's packed rows
+    const int F4 = Df / 4, FG = F4 / 8;               // frequency groups per pair (16 at Df = 512)
+    const int ppr = 256 / FG, ppb = ppr * PK_ROUNDS;  // pairs per round / per block
+    const int fg = threadIdx.x % FG, pr = threadIdx.x / FG;
+    const long NN = (long)N * N, p0 = (long)blockIdx.x * ppb;
+    if (threadIdx.x < ppb && p0 + threadIdx.x < NN) {
+        const long ij = p0 + threadIdx.x;
+        const int j = (int)(ij % N), i = (int)(ij / N);
+        const double ci = 0.5 * ((double)ev_start[i] + (double)(ev_start[i] + ev_len[i]));
+        const double cj = 0.5 * ((double)ev_start[j] + (double)(ev_start[j] + ev_len[j]));
+        const float li = (float)ev_len[i], lj = (float)ev_len[j];
+        double dc = fabs((ci - cj) / (double)li);
+        sdc[threadIdx.x] = dc > 1e-3 ? dc : 1e-3;
+        sdl[threadIdx.x] = (double)(float)log((double)__fdiv_rn(lj, li));
+    }
+    if (threadIdx.x < F4) sfr[threadIdx.x] = 100.0 * pow(10000.0, -(4.0 / (double)Df) * (double)threadIdx.x);
+    __syncthreads();
+    double fr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fr[j] = sfr[8 * fg + j];
+    const int KT = Df / 32;
+    const long RB = (NN + 127) / 128;
+    float* inv = reinterpret_cast<float*>(pk + RB * KT * 16384);
+    for (int rd = 0; rd < PK_ROUNDS; ++rd) {
+        const long row0 = p0 + (long)rd * ppr, row = row0 + pr;          // the round's ppr pairs: consecutive rows of ONE 128-row block (ppr divides 128)
+        if (row0 >= NN) return;                                           // uniform over the block
+        const bool live = row < NN;
+        float v[4][8];
+        const double dc = sdc[rd * ppr + pr], dl = sdl[rd * ppr + pr];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sincos_f64arg(dc * fr[j], v[0][j], v[1][j]);
+            sincos_f64arg(dl * fr[j], v[2][j], v[3][j]);
+        }
+        if (pos && live) {
+            float* o = pos + row * Df + 8 * fg;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<float4*>(o + q * F4) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+                *reinterpret_cast<float4*>(o + q * F4 + 4) = make_float4(v[q][4], v[q][5], v[q][6], v[q][7]);
+            }
+        }
+        const long rb = row0 >> 7;
+        const int r = (int)(row & 127);
+        if (rd > 0) __syncthreads();                                      // the previous round's pieces have left the staging buffer
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k0 = q * F4 + 8 * fg, kt = k0 >> 5, sl = ((k0 & 31) >> 3) ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3);
+            unsigned hw[8], lw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xs = v[q][j] * 16384.f;
+                const _Float16 h1 = (_Float16)xs;
+                const _Float16 h2 = (_Float16)(xs - (float)h1);
+                hw[j] = (unsigned)__builtin_bit_cast(unsigned short, h1);
+                lw[j] = (unsigned)__builtin_bit_cast(unsigned short, h2);
+            }
+            uint4* dst = stage + (kt * ppr + pr) * 4 + sl;
+            dst[0] = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
+            dst[KT * ppr * 4] = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
+            if (live && (k0 & 31) == 0) inv[(rb * KT + kt) * 128 + r] = 6.103515625e-05f;          // 2^-14
+        }
+        __syncthreads();
+        // 2 planes x KT k blocks x (ppr x 64 B): piece = 16 B; a wave's 64 pieces are one contiguous ppr x 64-byte run (ppr = 16: 1 KB)
+        const int pieces = 2 * KT * ppr * 4, ppc = ppr * 4;
+        for (int pc = threadIdx.x; pc < pieces; pc += 256) {
+            const int pl = pc / (KT * ppc), kt = (pc / ppc) % KT, within = pc % ppc;
+            if (row0 + within / 4 < NN)
+                *reinterpret_cast<uint4*>(pk + (rb * KT + kt) * 16384 + pl * 8192 + (int)(row0 & 127) * 64 + within * 16) = stage[pc];
+        }
+    }
+}
+
+bool posemb_packed_ok(int N, int Df) {
+    const int F4 = Df / 4;
+    return config().posemb_packed && Df % 32 == 0 && F4 % 8 == 0 && F4 <= 256 && F4 / 8 <= 256 && 256 % (F4 / 8) == 0 && 256 / (F4 / 8) <= 16 && 128 % (256 / (F4 / 8)) == 0 && (F4 % 32) == 0;
+}
+int posemb_packed(const int* ev_start, const int* ev_len, float* pos, float* pk, int N, int Df, hipStream_t st) {
+    const long NN = (long)N * N;
+    const int ppb = PK_ROUNDS * (256 / (Df / 32));
+    hipLaunchKernelGGL(posemb_packed_kernel, dim3((unsigned)((NN + ppb - 1) / ppb)), dim3(256), 2 * (Df / 32) * (256 / (Df / 32)) * 64, st, ev_start, ev_len, pos,
+                       reinterpret_cast<unsigned char*>(pk), N, Df);
+    return check_launch("posemb_packed");
+}
+
 int posemb(const int* ev_start, const int* ev_len, float* pos, int N, int Df, hipStream_t st) {
     if (Df / 4 <= 256 && 256 % (Df / 4) == 0 && config().posemb_rows) {
         const long NN = (long)N * N;
@@ -243,16 +338,19 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
     hipStream_t sp = config().tsrm_fork ? aux_fork(st) : nullptr;
     const bool fork = sp != nullptr;
     if (!fork) sp = st;
+    const bool packed_pos = !x_given && config().gemm_h2 && NN >= 4096 && posemb_packed_ok(N, Df);
     if (!x_given) {
         // event embedding (:44)
         d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1; d.beta = 1.f;
         RC(gemm(d, st));
-        RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, sp));
+        // many pairs: the embedding leaves its kernel already packed for the fc1 product (and as fp32 only if a backward pass may follow)
+        if (packed_pos) RC(posemb_packed(a->ev_start, a->ev_len, a->inference ? nullptr : w.POS, w.PK_POS, N, Df, sp));
+        else RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, sp));
     }
     // fc1 over the N*N event pairs: the one TSRM product big enough for the h2 path (tanh fused in the epilogue)
     if (config().gemm_h2 && NN >= 1024) {
-        H2PackJob pj[2] = {pack_rows(w.POS, Df, NN, Df, w.PK_POS), pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1)};
-        RC(h2_pack_multi(pj, 2, sp));
+        H2PackJob pj[2] = {pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1), pack_rows(w.POS, Df, NN, Df, w.PK_POS)};
+        RC(h2_pack_multi(pj, packed_pos ? 1 : 2, sp));
         d = desc_h2(w.PK_POS, w.PK_WFC1, w.P1, Df, NN, Df, Df);
         d.split_k = 1;
     } else {

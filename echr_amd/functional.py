@@ -166,7 +166,7 @@ class TSRMFunction(torch.autograd.Function):
         ws = torch.empty(lib.echr_tsrm_ws_floats(N, Din, Df, Do, n_head), device=ech.device, dtype=torch.float32)
         out = torch.empty(N, Do, device=ech.device, dtype=torch.float32)
         a = L.TsrmArgs(N, Din, Df, Do, n_head, *[L.ptr(p) for p in ps], L.ptr(ech), L.ptr(ev_start, torch.int32),
-                       L.ptr(ev_len, torch.int32), L.ptr(ws), L.ptr(out))
+                       L.ptr(ev_len, torch.int32), L.ptr(ws), L.ptr(out), 0 if any(ctx.needs_input_grad) else 1)
         d = drop.c()
         L.check(lib.echr_tsrm_fwd(C.byref(a), C.byref(d), L.stream_ptr()), 'tsrm_fwd')
         ctx.save_for_backward(ech, ev_start, ev_len, ws, out, *ps)

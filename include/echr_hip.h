@@ -136,6 +136,8 @@ typedef struct {
     float* ws;
     /* output */
     float* out;                      /* [N,Do] */
+    int32_t inference;               /* echr_tsrm_fwd: 1 = no echr_tsrm_bwd will follow on this workspace (activations that only the backward
+                                        pass reads -- the fp32 position embedding of >= 4096 pairs -- are not materialised) */
 } echr_tsrm_args;
 
 typedef struct {
@@ -406,6 +408,7 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *                      on device (vocabularies of up to 5120 words, the persistent forward kernel's shapes); 0 = one launch chain per step
  *   "posemb_rows" 0/1   (default 1, ECHR_POSEMB_ROWS) pairwise position embedding with one thread per frequency (contiguous stores); 0 = one
  *                      thread per 16 frequencies of a pair
+ *   "posemb_packed" 0/1 (default 1, ECHR_POSEMB_PACKED) >= 4096 event pairs: the position embedding is written directly as the packed fc1 operand
  *   "gemm_skinny" 0/1   (default 1, ECHR_GEMM_SKINNY) the event encoder's fc2 over >= 4096 event pairs (512 -> <= 16 columns) as a streaming
  *                      16-row-tile kernel instead of the general tiles
  *   "embed_fused" 0/1   (default 0, ECHR_EMBED_FUSED) token-embedding gradient through echr_gemm_desc.row_index instead of d XT + scatter pass

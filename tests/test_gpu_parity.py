@@ -264,7 +264,7 @@ def test_event_context_tsrm(case, train_mode):
 
 def test_event_context_many_events_vs_oracle():
     """More than 64 events (evaluation-style batches: N * N >= 4096 pairs): the pair MLP's fc2 runs on the streaming 16-row-tile kernel and
-    the position embedding on the thread-per-frequency kernel; forward + backward against the oracle, and against the general kernels."""
+    the position embedding is written packed for the fc1 product (and as fp32 for the backward pass); forward + backward against the oracle, and against the general kernels."""
     from echr_amd import functional as EF
     from echr_amd import _lib
     from oracle import echr_ref_cpu as O
@@ -281,15 +281,18 @@ def test_event_context_many_events_vs_oracle():
     outs = []
     try:
         for flag in (1, 0):
-            lib.echr_config_set(b'gemm_skinny', flag)
-            lib.echr_config_set(b'posemb_rows', flag)
+            for key in (b'gemm_skinny', b'posemb_rows', b'posemb_packed'):
+                lib.echr_config_set(key, flag)
             out = m.get_event_context(tap, c3d, None, vid['ind'], vid['soi'], _ev=ev, _drop=EF.DropState(U.SEED, U.OFFSET, False))
             outs.append(out)
     finally:
-        lib.echr_config_set(b'gemm_skinny', 1)
-        lib.echr_config_set(b'posemb_rows', 1)
+        for key in (b'gemm_skinny', b'posemb_rows', b'posemb_packed'):
+            lib.echr_config_set(key, 1)
+    with torch.no_grad():          # inference: the fp32 position embedding is never materialised (echr_tsrm_args.inference)
+        out_ng = m.get_event_context(tap, c3d, None, vid['ind'], vid['soi'], _ev=ev, _drop=EF.DropState(U.SEED, U.OFFSET, False))
     assert U.relerr(outs[0].detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
     assert U.relerr(outs[0].detach().cpu().numpy(), outs[1].detach().cpu().numpy()) < 2e-6
+    assert U.relerr(out_ng.cpu().numpy(), outs[0].detach().cpu().numpy()) < 2e-6
     w = torch.from_numpy(np.random.RandomState(1).standard_normal(tuple(ref.shape)).astype(np.float32))
     (ref * w).sum().backward()
     (outs[0] * w.to(dev)).sum().backward()
