@@ -484,6 +484,42 @@ def test_persistent_sampler_equals_launch_per_step_sampler(case):
     assert np.abs(outs[0][1] - outs[1][1]).max() < TOL_LOGP
 
 
+@pytest.mark.parametrize('N,A,V1,min_len', [(1, 7, 301, 7), (5, 40, 301, 4), (33, 129, 1201, 1), (12, 200, 301, 60), (64, 258, 5001, 100), (150, 130, 301, 4)])
+def test_persistent_sampler_edge_shapes_vs_launch_per_step(N, A, V1, min_len):
+    """The persistent greedy decoder at the edges of its shapes: one event, a second half machine with a single row, events past 129 segments
+    (second slot set, BIG instantiation), the largest A, a vocabulary that leaves most logits workgroups without a column, more than 64 events
+    (three launches, the last one partly filled) -- same sequences as the launch-per-step form, log-probs to rounding; and against the oracle for
+    the smallest case."""
+    from echr_amd import _lib
+    lib = _lib.load()
+    opt = synth.default_opt(vocab_size=V1 - 1, seq_length=7)
+    params = synth.make_params(opt, seed=3)
+    vid = synth.make_video(N, A, 9, V1, seed=31 + N + A, min_len=min_len, T_v=max(A + 40, 300))
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    outs = []
+    try:
+        for flag in (1, 0):
+            lib.echr_config_set(b'persist_sample', flag)
+            with torch.no_grad():
+                seq, lp = m(tap, c3d, lda, [], vid['ind'], vid['soi'], mode='eval')
+            outs.append((seq.cpu().numpy(), lp.cpu().numpy()))
+    finally:
+        lib.echr_config_set(b'persist_sample', 1)
+    assert outs[0][0].shape == outs[1][0].shape == (N, outs[0][0].shape[1])
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1] - outs[1][1]).max() < TOL_LOGP
+    if N <= 5:
+        from oracle import echr_ref_cpu as O
+        P = {k: torch.from_numpy(v) for k, v in params.items()}
+        with torch.no_grad():
+            seq_o, lp_o = O.caption_forward(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), None, vid['ind'],
+                                            vid['soi'], mode='eval', seq_length=opt.CG_seq_length)
+        assert np.array_equal(outs[0][0], seq_o.numpy())
+        assert np.abs(outs[0][1] - lp_o.numpy()).max() < TOL_LOGP
+
+
 def test_persistent_sampler_table_cache_follows_parameter_updates():
     """The persistent decoder caches its parameter-only operands (token-side gate tables, logit image) on the model.  A second decode must
     reuse them (bitwise the same output); an in-place parameter update (torch version counter) and a library optimiser step (raw-pointer
