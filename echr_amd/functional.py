@@ -163,6 +163,9 @@ class TSRMFunction(torch.autograd.Function):
         ps = [_f32c(p) for p in params]
         N, Din = ech.shape
         Df, Do = ps[0].shape[0], ps[10].shape[0]
+        if ps[0].shape[1] != Din:
+            raise L.EchrHipError('event features are %d wide, fusion_model.event_emb expects %d (video_dim + hidden_dim: CaptionGenerator.py:121-125)'
+                                 % (Din, ps[0].shape[1]))
         ws = torch.empty(lib.echr_tsrm_ws_floats(N, Din, Df, Do, n_head), device=ech.device, dtype=torch.float32)
         out = torch.empty(N, Do, device=ech.device, dtype=torch.float32)
         a = L.TsrmArgs(N, Din, Df, Do, n_head, *[L.ptr(p) for p in ps], L.ptr(ech), L.ptr(ev_start, torch.int32),

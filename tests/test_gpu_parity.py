@@ -742,7 +742,7 @@ def test_abandoned_prepare_is_cancelled_and_next_forward_is_unaffected():
     EF.decoder_prepare_cancel()          # a second cancel is a no-op
     m.set_dropout_state(5)
     out = m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
-    assert torch.equal(out, ref)
+    assert float((out.detach() - ref).abs().max()) < 1e-5          # same dropout stream; the split-K sums are not bitwise repeatable
 
 
 def test_staged_decoder_backward_equals_single_call():
