@@ -3,7 +3,7 @@
 # Regenerates everything under profiles/ that bench.py's roofline leg and DESIGN.md cite, FROM THE TREE THAT IS RUNNING:
 #   <tag>_pmc_traffic.json / <tag>_pmc_mfma.json (separate --pmc passes, commit hash stored inside), <tag>_rocprof_kernel_stats_final.txt
 #   (rocprofv3 --kernel-trace --stats of the bench command), <tag>_bench_final.json (the bench line, written AFTER the PMC files so that
-#   it carries their traffic numbers), and the same pair for --c5.  Results land in gpurun_out/<tag>_profiles/ (copy them into profiles/).
+#   it carries their traffic numbers), the same pair for --c5, and the greedy decoder's kernel stats / timings / stamps.  Results land in gpurun_out/<tag>_profiles/ (copy them into profiles/).
 tag=${1:-r03}; commit=${2:-unknown}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/${tag}_profiles
@@ -19,8 +19,15 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p
 python3 $root/tools/prof_summary.py $out/prof 15 40 > $out/${tag}_rocprof_kernel_stats_final.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -- python3 $root/bench.py --c5 --steps 12 --warmup 3 --no-cpu --no-roofline --no-native > $out/prof5.log 2>&1
 python3 $root/tools/prof_summary.py $out/prof5 15 40 > $out/${tag}_rocprof_kernel_stats_c5.txt
-rm -rf $out/prof $out/prof5
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profs -- python3 $root/tools/sample_bench.py 64 > $out/profs.log 2>&1
+python3 $root/tools/prof_summary.py $out/profs 7 30 > $out/${tag}_rocprof_kernel_stats_sampler64.txt          # 2 warm-up + 5 timed decodes
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profs2 -- python3 $root/tools/sample_bench.py 1000 > $out/profs2.log 2>&1
+python3 $root/tools/prof_summary.py $out/profs2 7 30 > $out/${tag}_rocprof_kernel_stats_sampler1000.txt
+rm -rf $out/prof $out/prof5 $out/profs $out/profs2
 cd $root
+{ echo "# greedy decode, whole mode='eval' call (tools/sample_bench.py), commit $commit"; timeout -k 10 300 python3 tools/sample_bench.py 64 128 256 512 1000 2>/dev/null | grep N=;
+  echo "# the same with the launch-per-step form (ECHR_PERSIST_SAMPLE=0)"; ECHR_PERSIST_SAMPLE=0 timeout -k 10 300 python3 tools/sample_bench.py 64 128 256 512 1000 2>/dev/null | grep N=;
+  echo "# in-kernel stamps of the persistent decoder (tools/sample_stamps.py)"; timeout -k 10 200 python3 tools/sample_stamps.py 2>/dev/null | grep -v amdgpu; } > $out/${tag}_sampler.txt
 timeout -k 10 400 python3 bench.py > $out/${tag}_bench_final.json 2> $out/bench.err; echo bench_exit=$?
 timeout -k 10 400 python3 bench.py --c5 > $out/${tag}_bench_c5.json 2> $out/bench5.err; echo bench5_exit=$?
 ls -la $out
