@@ -1489,7 +1489,7 @@ static SampWs carve_samp(const echr_dec_args* a, float* base) {
     s.SLABS = take(a->N < SAMP_SLAB_ROWS ? (long)((samp_slabs(a) + 3) / 4 * 4) * a->N * a->V1 : 64);
     // persistent decoding (csrc/persist.hip, PersistS): token-side gate tables, the packed embedding they are made from, the logit-weight
     // image and the launch's exchange buffers
-    const bool ps = config().gemm_h2 && persist_sample_eligible(a);
+    const bool ps = persist_sample_shape_ok(a);          // by shape only: the carving must not depend on switches that can change between calls
     s.TABLES = take(ps ? carve_tables(a, nullptr).total : 64);
     s.PSWS = take(ps ? persist_sample_ws_floats(a->S) : 64);
     s.total = off;
@@ -1513,7 +1513,7 @@ __global__ __launch_bounds__(256) void slab_sum_bias_kernel(const float* __restr
 extern "C" int64_t echr_sampler_ws_floats(const echr_dec_args* a) { return a ? carve_samp(a, nullptr).total : -1; }
 extern "C" int64_t echr_sampler_table_floats(const echr_dec_args* a) {
     if (!a) return -1;
-    return config().gemm_h2 && persist_sample_eligible(a) ? carve_tables(a, nullptr).total : 0;
+    return persist_sample_eligible(a) ? carve_tables(a, nullptr).total : 0;
 }
 
 extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
@@ -1530,7 +1530,7 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
     DecWs w = carve_ws(&a, a.ws);
     SampWs s = carve_samp(&a, sa->ws_sample);
     const DropCfg off = make_drop(nullptr, 0.f);
-    const bool persistent = !sa->multinomial && config().gemm_h2 && persist_sample_eligible(&a);
+    const bool persistent = !sa->multinomial && persist_sample_eligible(&a);
     {
         // one fill launch: the launch-per-step form starts from zero state / <bos> = 0 and zero outputs; the persistent form writes every
         // output element itself and only needs the unfinished counters cleared

@@ -44,6 +44,7 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
 struct PersistSampleBufs { float* PALL; const float* EVB0; const float* VIDB; float* xws; const float* TG[3]; const float* limg; float* sws; long long* seq; float* seq_logp; int* n_unfinished; };
 long persist_sample_ws_floats(int S);
 long persist_logit_image_floats();
+bool persist_sample_shape_ok(const echr_dec_args* a);
 bool persist_sample_eligible(const echr_dec_args* a);
 int persist_logit_image(const float* w_logit, int V1, float* img, hipStream_t st);
 int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st);

@@ -3118,11 +3118,16 @@ long persist_sample_ws_floats(int S) { return persist_layout_s(S).total; }
 long persist_logit_image_floats() { return (long)LWG * 3 * 16 * LCT * 2 * 64 * 4 + 2L * LWG * LCOLS; }
 
 // vocabulary within the logits role's 64 x 80 columns, fp16-pair forms on, shapes as the teacher-forced kernel (events are processed 64 per launch)
-bool persist_sample_eligible(const echr_dec_args* a) {
-    echr_dec_args b = *a;
-    b.N = b.N < PROWS ? b.N : PROWS;
-    return config().persist && config().persist_sample && config().persist_h2 && config().persist_split && config().persist_merge && persist_shape_ok(&b) &&
+// ... by shape alone (what the workspace carving goes by: a switch flipped between the size query and the call must not move the carving) ...
+bool persist_sample_shape_ok(const echr_dec_args* a) {
+    PersistHost& h = phost();
+    return h.ok && h.cus >= NWG && a->N >= 1 && a->A <= 2 * PSET2 && a->H == PH && a->Ha == PH && a->D <= PH && a->D % 4 == 0 && a->D >= 8 && a->S >= 1 &&
            a->V1 <= LWG * LCOLS && a->V1 >= 2;
+}
+// ... and with the switches that select it
+bool persist_sample_eligible(const echr_dec_args* a) {
+    return config().persist && config().persist_sample && config().persist_h2 && config().persist_split && config().persist_merge && config().gemm_h2 &&
+           persist_sample_shape_ok(a);
 }
 
 int persist_logit_image(const float* w_logit, int V1, float* img, hipStream_t st) {
