@@ -1466,7 +1466,7 @@ static SampTables carve_tables(const echr_dec_args* a, float* base) {
     auto take = [&](long n) { float* p = base ? base + off : nullptr; off += rup(n, 64); return p; };
     for (int k = 0; k < 3; ++k) s.TG[k] = take((long)a->V1 * 4 * a->H);
     s.PK_EMB = take(h2_floats(a->V1, a->E));
-    s.LIMG = take(persist_logit_image_floats());
+    s.LIMG = take(persist_logit_image_floats(a->V1));
     s.total = off;
     return s;
 }
@@ -1491,7 +1491,7 @@ static SampWs carve_samp(const echr_dec_args* a, float* base) {
     // image and the launch's exchange buffers
     const bool ps = persist_sample_shape_ok(a);          // by shape only: the carving must not depend on switches that can change between calls
     s.TABLES = take(ps ? carve_tables(a, nullptr).total : 64);
-    s.PSWS = take(ps ? persist_sample_ws_floats(a->S) : 64);
+    s.PSWS = take(ps ? persist_sample_ws_floats(a->S, a->V1) : 64);
     s.total = off;
     return s;
 }

@@ -874,6 +874,7 @@ struct PersistK2 {
 // bitwise reproducible -- and the consumers gather the token-side gate pre-activations from a [V1, 4H] table per stream.
 constexpr int LCOLS = 80, LCT = 5;             // vocabulary columns / 16-column MFMA tiles per logits workgroup
 constexpr int LWG = 2 * NS;                    // logits workgroups
+constexpr int LCHMAX = 3;                      // column chunks of LWG x LCOLS a workgroup can take: vocabularies of up to 15 360 words
 struct PersistS {
     const float* TG[3];            // [V1][4H] token-side gate pre-activations per stream (stream 1: biases folded in)
     const float* base0;            // [N][4H] event part of stream 0 (+ biases)
@@ -887,7 +888,7 @@ struct PersistS {
     float* XC3; float* XS3;        // context partials / exponential sums, one slot per workgroup of an event (summed in a fixed order)
     u32* cnt2;                     // the attention layout's counters (the logits role waits for h1)
     const float* XH1;              // its h1 exchange planes
-    int V1;
+    int V1, nch;                   // nch = ceil(V1 / 5120) column chunks
 };
 
 // BIG: events of up to 258 segments (BASELINE config 5's 256-segment proposals).  An event's first 129 slots live in registers as before;
@@ -1633,12 +1634,11 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
         }
     }
     const u32 XB = PROWS * PH * 4, XBH = HR * PH * 4;
-    const float4* limg = Q.LIMG + (long)b * (3 * 16 * LCT * 2 * 64);
     const int ev = tid >> 2, q4 = tid & 3;                            // epilogue ownership: event, columns 16 c + 4 q4 .. +3 of every tile
-    float* lsc = reinterpret_cast<float*>(lds + LDS_W + LDS_RED + 1280);      // [80] column scale back to true units, [80] bias
-    float* lbi = lsc + LCOLS;
-    if (tid < LCOLS) {
-        const int gv = LCOLS * b + tid;
+    float* lsc = reinterpret_cast<float*>(lds + LDS_W + LDS_RED + 1280);      // [nch][80] column scale back to true units, [nch][80] bias
+    float* lbi = lsc + LCOLS * LCHMAX;
+    if (tid < LCOLS * Q.nch) {
+        const int gv = LCOLS * (b + LWG * (tid / LCOLS)) + tid % LCOLS;
         lsc[tid] = H2_INV_SA * Q.linv[gv];
         lbi[tid] = gv < V1 ? Q.lbias[gv] : 0.f;
     }
@@ -1695,7 +1695,25 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
         }
         publish(cnt(ck, t));
         if (st_on) STAMP(3, 2);
-        // ---- logits of step t: columns [80 b, 80 b + 80) ----
+        // ---- logits of step t: columns [80 vb, 80 vb + 80) of every column chunk (vb = b + 64 ch: vocabularies above 5120 words take a second /
+        //      third pass over the same h operands; only the first chunk's h0 / h2 part runs ahead of h1's arrival) ----
+        float4 ar[8][2][2];
+        const int ws = __builtin_amdgcn_readfirstlane(w);
+        // the stream's own h(t) for the recurrent product at the end of the step: its 32 fragment loads ride behind the fold
+        auto fetch_r = [&](int s_) {
+            const __amdgpu_buffer_rsrc_t ra = mk_rsrc(XH + (long)t * PROWS * PH, XB);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (u32)(((lane >> 5) * PROWS + (lane & 31)) * 16),
+                                                                          (u32)((((pl * 64 + 16 * ws + 2 * s_) * PROWS) + 32 * rb) * 16), 16);
+                    ar[s_][rb][pl] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+        };
+        for (int ch = 0; ch < Q.nch; ++ch) {
+        const int vb = b + LWG * ch;
+        const bool last_ch = ch + 1 == Q.nch;
         f32x4v la[4][LCT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1705,10 +1723,9 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
         // waits) + 8 A fragments (4 row tiles x 2 planes)
         // every fragment address = one lane-dependent VGPR offset + a wave-uniform scalar offset (kept in SGPRs / immediates: per-fragment
         // vector offsets would be hoisted out of the step loop as invariants, a few hundred registers' worth)
-        const int ws = __builtin_amdgcn_readfirstlane(w);
         const u32 vo_b = (u32)lane * 16u;
         const u32 vo_a64 = (u32)(((lane >> 4) * PROWS + (lane & 15)) * 16), vo_a32 = (u32)(((lane >> 4) * HR + (lane & 15)) * 16);
-        const __amdgpu_buffer_rsrc_t rl = mk_rsrc(limg, 3 * 16 * LCT * 2 * 64 * 16);
+        const __amdgpu_buffer_rsrc_t rl = mk_rsrc(Q.LIMG + (long)vb * (3 * 16 * LCT * 2 * 64), 3 * 16 * LCT * 2 * 64 * 16);
         auto fetch_b = [&](int kb, int si, float4 (&fb)[LCT][2]) {
             const u32 so = (u32)(((kb * 16 + 4 * ws + si) * LCT) * 2 * 64 * 16);
 #pragma unroll
@@ -1753,8 +1770,8 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             const float* a2 = P.XH2 + (long)t * PROWS * PH;
             float4 fa0[4][2], fb0[LCT][2], fa1[4][2], fb1[LCT][2], fa2[4][2], fb2[LCT][2];
             fetch_b(0, 0, fb0); fetch_b(0, 1, fb1);
-            if (!wait_total2(P, cnt(ck, t), NS, cnt(ck_other, t), NS, flag, 1000u * (ck + 1) + t)) return;
-            if (st_on) STAMP(3, 3);
+            if (ch == 0 && !wait_total2(P, cnt(ck, t), NS, cnt(ck_other, t), NS, flag, 1000u * (ck + 1) + t)) return;
+            if (st_on && ch == 0) STAMP(3, 3);
             fetch_a(0, 0, a0, fa0); fetch_a(0, 1, a0, fa1);
             // steps 0..7 = (kb, si): (0,0) (0,1) (0,2) (0,3) (2,0) (2,1) (2,2) (2,3); three rotating buffers, two steps' loads in flight
             fetch_b(0, 2, fb2); fetch_a(0, 2, a0, fa2);
@@ -1775,18 +1792,18 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             fetch_b(2, 3, fb1); fetch_a(2, 3, a2, fa1);
             mma(fa2, fb2);
             __builtin_amdgcn_sched_barrier(0);
-            if (tid < 64) peek_h1 = peek_issue(cnt2(C_H1, t, 0), cnt2(C_H1, t, nhalf - 1));      // h1(t) is usually complete by now: sample its counters behind the last products
+            if (ch == 0 && tid < 64) peek_h1 = peek_issue(cnt2(C_H1, t, 0), cnt2(C_H1, t, nhalf - 1));      // h1(t) is usually complete by now: sample its counters behind the last products
             mma(fa0, fb0);
             mma(fa1, fb1);
         }
-        if (st_on) STAMP(3, 4);
+        if (st_on && ch == 0) STAMP(3, 4);
         {
             // h1's four k steps: all weights ahead of the wait, all of h1's fragments behind it
             const float* a1 = Q.XH1 + (long)t * 2 * HR * PH;          // both halves: [m][plane][k / 8][32 rows][8 halves] (2 x 64 KB = XB bytes)
             float4 fa0[4][2], fb0[LCT][2], fa1[4][2], fb1[LCT][2], fa2[4][2], fb2[LCT][2], fb3[LCT][2];
             fetch_b(1, 0, fb0); fetch_b(1, 1, fb1); fetch_b(1, 2, fb2); fetch_b(1, 3, fb3);
-            if (!wait_peeked2(P, peek_h1, cnt2(C_H1, t, 0), HG1, cnt2(C_H1, t, nhalf - 1), HG1, flag, 150000u + t)) return;
-            if (st_on) STAMP(3, 5);
+            if (ch == 0 && !wait_peeked2(P, peek_h1, cnt2(C_H1, t, 0), HG1, cnt2(C_H1, t, nhalf - 1), HG1, flag, 150000u + t)) return;
+            if (st_on && ch == 0) STAMP(3, 5);
             fetch_a(1, 0, a1, fa0); fetch_a(1, 1, a1, fa1); fetch_a(1, 2, a1, fa2);
             __builtin_amdgcn_sched_barrier(0);
             mma(fa0, fb0);
@@ -1794,22 +1811,9 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             fetch_a(1, 3, a1, fa0);
             mma(fa1, fb1); mma(fa2, fb2); mma(fa0, fb3);
         }
-        if (st_on) STAMP(3, 6);
-        // the stream's own h(t) for the recurrent product at the end of the step: its 32 fragment loads ride behind the fold
-        float4 ar[8][2][2];
-        auto fetch_r = [&](int s_) {
-            const __amdgpu_buffer_rsrc_t ra = mk_rsrc(XH + (long)t * PROWS * PH, XB);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (u32)(((lane >> 5) * PROWS + (lane & 31)) * 16),
-                                                                          (u32)((((pl * 64 + 16 * ws + 2 * s_) * PROWS) + 32 * rb) * 16), 16);
-                    ar[s_][rb][pl] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-                }
-        };
+        if (st_on && last_ch) STAMP(3, 6);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < S) {
+        if (last_ch && t + 1 < S) {
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) fetch_r(s_);          // the first half now (register budget), the second behind the publish
         }
@@ -1825,7 +1829,7 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             __syncthreads();
             const float4 p0 = *reinterpret_cast<const float4*>(red + ev * 16 + 4 * q4), p1 = *reinterpret_cast<const float4*>(red + 1024 + ev * 16 + 4 * q4),
                          p2 = *reinterpret_cast<const float4*>(red + 2048 + ev * 16 + 4 * q4), p3 = *reinterpret_cast<const float4*>(red + 3072 + ev * 16 + 4 * q4);
-            const float4 sc4 = *reinterpret_cast<const float4*>(lsc + 16 * c + 4 * q4), bi4 = *reinterpret_cast<const float4*>(lbi + 16 * c + 4 * q4);
+            const float4 sc4 = *reinterpret_cast<const float4*>(lsc + LCOLS * ch + 16 * c + 4 * q4), bi4 = *reinterpret_cast<const float4*>(lbi + LCOLS * ch + 16 * c + 4 * q4);
             lv[c][0] = ((p0.x + p1.x) + (p2.x + p3.x)) * sc4.x + bi4.x;
             lv[c][1] = ((p0.y + p1.y) + (p2.y + p3.y)) * sc4.y + bi4.y;
             lv[c][2] = ((p0.z + p1.z) + (p2.z + p3.z)) * sc4.z + bi4.z;
@@ -1839,7 +1843,7 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             for (int c = 0; c < LCT; ++c)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int gv = LCOLS * b + 16 * c + 4 * q4 + e;
+                    const int gv = LCOLS * vb + 16 * c + 4 * q4 + e;
                     if (gv < V1 && lv[c][e] > mx) { mx = lv[c][e]; mi = gv; }          // ascending index per thread: first maximum kept
                 }
 #pragma unroll
@@ -1853,7 +1857,7 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             for (int c = 0; c < LCT; ++c)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int gv = LCOLS * b + 16 * c + 4 * q4 + e;
+                    const int gv = LCOLS * vb + 16 * c + 4 * q4 + e;
                     if (gv < V1) se += __expf(lv[c][e] - mx);
                 }
             se += __shfl_xor(se, 1, 64);
@@ -1865,10 +1869,11 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
                     const unsigned long long key = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mi);
                     __hip_atomic_fetch_max(Q.KEY + (long)t * PROWS + ev, key, __ATOMIC_RELAXED, ECHR_AGENT);
                 }
-                float* lp = Q.LSE + (((long)t * PROWS + ev) * LWG + b) * 2;
+                float* lp = Q.LSE + (((long)t * PROWS + ev) * (LWG * Q.nch) + vb) * 2;
                 lp[0] = mx; lp[1] = se;
             }
         }
+        }          // column chunks
         publish(Q.cnt_tok + (long)t * CNT_LINE);
         if (st_on) STAMP(3, 7);
         // ---- the stream's complete h(t) (waited for above) x W_hh: the recurrent part of step t + 1, behind the token's hand-off ----
@@ -1925,9 +1930,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_sample_kernel(PersistK2 P2
 }
 
 // logit weights -> the image the logits role streams: one power-of-two scale per vocabulary column over the whole contraction (3 x 512)
-__global__ __launch_bounds__(256) void logit_scale_kernel(const float* __restrict__ W, int V1, float* __restrict__ sc, float* __restrict__ inv) {
+__global__ __launch_bounds__(256) void logit_scale_kernel(const float* __restrict__ W, int V1, int nvb, float* __restrict__ sc, float* __restrict__ inv) {
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;          // one wave per column
-    if (v >= LWG * LCOLS) return;
+    if (v >= nvb * LCOLS) return;
     float mx = 0.f;
     if (v < V1) {
         const float4* wp = reinterpret_cast<const float4*>(W + (long)v * 3 * PH);
@@ -1946,9 +1951,9 @@ __global__ __launch_bounds__(256) void logit_scale_kernel(const float* __restric
         inv[v] = ldexpf(1.f, e - 14);
     }
 }
-__global__ __launch_bounds__(256) void logit_image_kernel(const float* __restrict__ W, int V1, const float* __restrict__ sc, float4* __restrict__ img) {
+__global__ __launch_bounds__(256) void logit_image_kernel(const float* __restrict__ W, int V1, int nvb, const float* __restrict__ sc, float4* __restrict__ img) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;           // (workgroup, stream block, k step, tile, lane)
-    if (idx >= (long)LWG * 3 * 16 * LCT * 64) return;
+    if (idx >= (long)nvb * 3 * 16 * LCT * 64) return;
     const int lane = (int)(idx & 63);
     long r = idx >> 6;
     const int c = (int)(r % LCT); r /= LCT;
@@ -1972,7 +1977,7 @@ __global__ __launch_bounds__(256) void logit_image_kernel(const float* __restric
 // keys + per-workgroup (maximum, sum of exponentials) -> seq / seq_logp / the unfinished bookkeeping of OldModel.sample (:171-183): one
 // wave per (event, step).  The emitted token is masked once the event has produced <eos> at this or an earlier step (the network kept
 // consuming the raw arg-max); the sum over the 64 workgroups' partials runs in a fixed butterfly order.
-__global__ __launch_bounds__(64) void sample_finish_kernel(const unsigned long long* __restrict__ KEY, const float* __restrict__ LSE, int N, int L,
+__global__ __launch_bounds__(64) void sample_finish_kernel(const unsigned long long* __restrict__ KEY, const float* __restrict__ LSE, int N, int L, int nch,
                                                          long long* __restrict__ seq, float* __restrict__ seq_logp, int* __restrict__ n_unfinished) {
     const int n = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
     const unsigned long long key = KEY[(long)t * PROWS + n];
@@ -1980,9 +1985,12 @@ __global__ __launch_bounds__(64) void sample_finish_kernel(const unsigned long l
     u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
     const float M = __uint_as_float(u);
     const int bi = (int)(0xFFFFFFFFu - (u32)key);
-    const float* lp = LSE + (((long)t * PROWS + n) * LWG + lane) * 2;
-    const float m = lp[0];
-    float s = m > -INFINITY ? lp[1] * expf(m - M) : 0.f;
+    float s = 0.f;
+    for (int c = 0; c < nch; ++c) {          // chunk by chunk: a fixed order
+        const float* lp = LSE + (((long)t * PROWS + n) * (LWG * nch) + LWG * c + lane) * 2;
+        const float m = lp[0];
+        s += m > -INFINITY ? lp[1] * expf(m - M) : 0.f;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     // unfinished after step t <=> every arg-max of steps 0..t is a word (> 0)
@@ -3101,28 +3109,30 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
 
 // ---- greedy decoding on the persistent kernels (SAMP instantiations) ----
 struct PersistLayoutS { long key, cnt, zero_end, lse, xc3, xs3, total; };
-static PersistLayoutS persist_layout_s(int S) {
+static inline int logit_chunks(int V1) { return (V1 + LWG * LCOLS - 1) / (LWG * LCOLS); }
+static PersistLayoutS persist_layout_s(int S, int V1) {
+    const int nch = logit_chunks(V1);
     PersistLayoutS L;
     long off = 0;
     auto take = [&](long n) { long o = off; off += (n + 63) / 64 * 64; return o; };
     L.key = take((long)S * PROWS * 2);
     L.cnt = take((long)S * CNT_LINE);
     L.zero_end = off;
-    L.lse = take((long)S * LWG * PROWS * 2);
+    L.lse = take((long)S * LWG * nch * PROWS * 2);
     L.xc3 = take((long)S * 2 * 3 * HR * PH);
     L.xs3 = take((long)S * PROWS * 3);
     L.total = off;
     return L;
 }
-long persist_sample_ws_floats(int S) { return persist_layout_s(S).total; }
-long persist_logit_image_floats() { return (long)LWG * 3 * 16 * LCT * 2 * 64 * 4 + 2L * LWG * LCOLS; }
+long persist_sample_ws_floats(int S, int V1) { return persist_layout_s(S, V1).total; }
+long persist_logit_image_floats(int V1) { const long nvb = (long)LWG * logit_chunks(V1); return nvb * 3 * 16 * LCT * 2 * 64 * 4 + 2L * nvb * LCOLS; }
 
 // vocabulary within the logits role's 64 x 80 columns, fp16-pair forms on, shapes as the teacher-forced kernel (events are processed 64 per launch)
 // ... by shape alone (what the workspace carving goes by: a switch flipped between the size query and the call must not move the carving) ...
 bool persist_sample_shape_ok(const echr_dec_args* a) {
     PersistHost& h = phost();
     return h.ok && h.cus >= NWG && a->N >= 1 && a->A <= 2 * PSET2 && a->H == PH && a->Ha == PH && a->D <= PH && a->D % 4 == 0 && a->D >= 8 && a->S >= 1 &&
-           a->V1 <= LWG * LCOLS && a->V1 >= 2;
+           a->V1 <= LWG * LCOLS * LCHMAX && a->V1 >= 2;
 }
 // ... and with the switches that select it
 bool persist_sample_eligible(const echr_dec_args* a) {
@@ -3131,12 +3141,13 @@ bool persist_sample_eligible(const echr_dec_args* a) {
 }
 
 int persist_logit_image(const float* w_logit, int V1, float* img, hipStream_t st) {
-    float* sc = img + (long)LWG * 3 * 16 * LCT * 2 * 64 * 4;
-    float* inv = sc + LWG * LCOLS;
-    hipLaunchKernelGGL(logit_scale_kernel, dim3(LWG * LCOLS / 4), dim3(256), 0, st, w_logit, V1, sc, inv);
+    const int nvb = LWG * logit_chunks(V1);
+    float* sc = img + (long)nvb * 3 * 16 * LCT * 2 * 64 * 4;
+    float* inv = sc + nvb * LCOLS;
+    hipLaunchKernelGGL(logit_scale_kernel, dim3(nvb * LCOLS / 4), dim3(256), 0, st, w_logit, V1, nvb, sc, inv);
     if (int rc = check_launch("logit_scale")) return rc;
-    const long items = (long)LWG * 3 * 16 * LCT * 64;
-    hipLaunchKernelGGL(logit_image_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, w_logit, V1, sc, reinterpret_cast<float4*>(img));
+    const long items = (long)nvb * 3 * 16 * LCT * 64;
+    hipLaunchKernelGGL(logit_image_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, w_logit, V1, nvb, sc, reinterpret_cast<float4*>(img));
     return check_launch("logit_image");
 }
 
@@ -3146,7 +3157,7 @@ int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream
     ECHR_REQUIRE(h.ok && a->N <= PROWS, "persist_sample: device state unavailable");
     const PersistLayout L = persist_layout(a->S);
     const PersistLayout2 L2 = persist_layout2(a->S);
-    const PersistLayoutS LS = persist_layout_s(a->S);
+    const PersistLayoutS LS = persist_layout_s(a->S, a->V1);
     const DropCfg off{0u, 0u, 0u, 0u, 1.f, 0};          // decoding runs in eval mode: every dropout multiplier is 1
     PersistK K;
     K.N = a->N; K.A = a->A; K.D = a->D; K.S = a->S; K.ld_att = a->E + a->D;
@@ -3181,7 +3192,8 @@ int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream
     Q.KEY = reinterpret_cast<unsigned long long*>(B.sws + LS.key);
     Q.cnt_tok = reinterpret_cast<u32*>(B.sws + LS.cnt);
     Q.LIMG = reinterpret_cast<const float4*>(B.limg);
-    Q.linv = B.limg + (long)LWG * 3 * 16 * LCT * 2 * 64 * 4 + LWG * LCOLS;
+    Q.nch = logit_chunks(a->V1);
+    Q.linv = B.limg + (long)LWG * Q.nch * 3 * 16 * LCT * 2 * 64 * 4 + LWG * Q.nch * LCOLS;
     Q.lbias = a->b_logit;
     Q.LSE = B.sws + LS.lse; Q.XC3 = B.sws + LS.xc3; Q.XS3 = B.sws + LS.xs3;
     Q.cnt2 = K2.cnt; Q.XH1 = K2.XH1; Q.V1 = a->V1;
@@ -3209,7 +3221,7 @@ int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream
             if (int rc = check_launch("dec_persist_sample")) return rc;
         }
     }
-    hipLaunchKernelGGL(sample_finish_kernel, dim3(a->N, a->S), dim3(64), 0, st, Q.KEY, Q.LSE, a->N, a->S, B.seq, B.seq_logp, B.n_unfinished);
+    hipLaunchKernelGGL(sample_finish_kernel, dim3(a->N, a->S), dim3(64), 0, st, Q.KEY, Q.LSE, a->N, a->S, Q.nch, B.seq, B.seq_logp, B.n_unfinished);
     return check_launch("sample_finish");
 }
 

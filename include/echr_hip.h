@@ -405,7 +405,7 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *                      launch aborts through its time-out path (tests/test_gpu_parity.py::test_persistent_abort_path); 0 = off
  *   "sst_persist" 0/1   (default 1, ECHR_SST_PERSIST) proposal encoder's recurrences as one persistent launch per direction (H = 512)
  *   "persist_sample" 0/1 (default 1, ECHR_PERSIST_SAMPLE) greedy decoding (echr_decoder_sample) as one persistent launch per 64 events, every step
- *                      on device (vocabularies of up to 5120 words, the persistent forward kernel's shapes); 0 = one launch chain per step
+ *                      on device (vocabularies of up to 15 360 words, the persistent forward kernel's shapes); 0 = one launch chain per step
  *   "posemb_rows" 0/1   (default 1, ECHR_POSEMB_ROWS) pairwise position embedding with one thread per frequency (contiguous stores); 0 = one
  *                      thread per 16 frequencies of a pair
  *   "posemb_packed" 0/1 (default 1, ECHR_POSEMB_PACKED) >= 4096 event pairs: the position embedding is written directly as the packed fc1 operand
