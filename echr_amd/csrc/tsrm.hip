@@ -138,6 +138,102 @@ static TsrmWsB carve_b(int N, int Din, int Df, int Do, int G, float* base) {
     return w;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Inference over many pairs: fc1 is linear in the embedding, and the embedding of pair (i, j) is [phi(dc_ij) | phi(dl_ij)] with
+// dc_ij = max(|c_i - c_j| / l_i, 1e-3) and dl_ij = log(l_j / l_i) -- functions of the INTEGER triples (|2 c_i - 2 c_j|, l_i) and (l_i, l_j).
+// Segment indices are small integers (proposal lengths <= a few hundred, videos a few hundred segments), so 10^6 pairs share a few 10^4
+// distinct arguments: F_c[key] = W1[:, :Df/2] . phi(dc) + b1 and F_l[key] = W1[:, Df/2:] . phi(dl) are tabulated once (two small GEMMs over
+// the distinct keys), and the per-pair work is tanh(F_c[kc] + F_l[kl]) . W2^T -- two 2-KB row gathers instead of 512 sin / cos and a
+// 512 x 512 product per pair.  Same arithmetic as the dense path up to the order of one addition.
+// ------------------------------------------------------------------------------------------------------
+// phi over the keys of one table: mode 0: key = dcn * Lm1 + l_i (dcn = |2 c_i - 2 c_j|), mode 1: key = l_i * Lm1 + l_j.  out [R, Df / 2] = [sin | cos].
+__global__ __launch_bounds__(256) void pair_phi_kernel(int mode, int Lm1, long R, int Df, float* __restrict__ out) {
+    const int F4 = Df / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= R * F4) return;
+    const int k = (int)(idx % F4);
+    const long key = idx / F4;
+    const int hi = (int)(key / Lm1), lo = (int)(key % Lm1);
+    double x;
+    bool ok;
+    if (mode == 0) {
+        ok = lo >= 1;                                         // l_i
+        const double dc = fabs((0.5 * (double)hi) / (double)(float)(ok ? lo : 1));
+        x = dc > 1e-3 ? dc : 1e-3;
+    } else {
+        ok = hi >= 1 && lo >= 1;                              // l_i, l_j
+        x = (double)(float)log((double)__fdiv_rn((float)(ok ? lo : 1), (float)(ok ? hi : 1)));
+    }
+    float sv = 0.f, cv = 0.f;
+    if (ok) sincos_f64arg(x * (100.0 * pow(10000.0, -(4.0 / (double)Df) * (double)k)), sv, cv);
+    out[key * (Df / 2) + k] = sv;
+    out[key * (Df / 2) + F4 + k] = cv;
+}
+
+// gate[r, :] = W2 . tanh(F_c[kc(r)] + F_l[kl(r)]) + b2 for every pair r = (i, j): skinny_nt_kernel's structure (one wave per 16 pairs,
+// v_mfma_f32_16x16x4_f32, W2 in registers), its A fragments formed on the fly from the two gathered table rows.
+template <int KS>          // Df / 16
+__global__ __launch_bounds__(256) void pair_gate_kernel(const float* __restrict__ FC, const float* __restrict__ FL, const int* __restrict__ ev_start,
+                                                        const int* __restrict__ ev_len, int N, int Lm1, int span, const float* __restrict__ W2, long ldw,
+                                                        const float* __restrict__ bias, float* __restrict__ C, long ldc, int Nc, int tiles) {
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, kk = lane >> 4;
+    const long M = (long)N * N;
+    float4 bw[KS];
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_)
+        bw[s_] = r < Nc ? *reinterpret_cast<const float4*>(W2 + (long)r * ldw + 16 * s_ + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bv = (bias && r < Nc) ? bias[r] : 0.f;
+    for (int tile = blockIdx.x * 4 + w; tile < tiles; tile += gridDim.x * 4) {
+        const long r0 = (long)tile * 16;
+        const long row = r0 + r < M ? r0 + r : M - 1;
+        const int i = (int)(row / N), j = (int)(row % N);
+        // (clamped to the table bounds: bounds that do not cover the events give wrong gates, never a wild read)
+        const int li = min(max(ev_len[i], 0), Lm1 - 1), lj = min(max(ev_len[j], 0), Lm1 - 1);
+        const int c2i = 2 * ev_start[i] + ev_len[i], c2j = 2 * ev_start[j] + ev_len[j];
+        const float* fc = FC + ((long)min(abs(c2i - c2j), span) * Lm1 + li) * (16 * KS) + 4 * kk;
+        const float* fl = FL + ((long)li * Lm1 + lj) * (16 * KS) + 4 * kk;
+        f32x4s acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {          // four quarters of the row: 2 x KS / 4 gathered float4 in flight
+            float4 x[KS / 4], y[KS / 4];
+#pragma unroll
+            for (int s_ = 0; s_ < KS / 4; ++s_) {
+                x[s_] = *reinterpret_cast<const float4*>(fc + 16 * (h * (KS / 4) + s_));
+                y[s_] = *reinterpret_cast<const float4*>(fl + 16 * (h * (KS / 4) + s_));
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < KS / 4; ++s_) {
+                const float4 b4 = bw[h * (KS / 4) + s_];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tanhf(x[s_].x + y[s_].x), b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tanhf(x[s_].y + y[s_].y), b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tanhf(x[s_].z + y[s_].z), b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tanhf(x[s_].w + y[s_].w), b4.w, acc, 0, 0, 0);
+            }
+        }
+        if (r < Nc) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long orow = r0 + 4 * kk + q;
+                if (orow < M) C[orow * ldc + r] = acc[q] + bv;
+            }
+        }
+    }
+}
+
+// rows of the two tables for these bounds, or 0 when the table path does not apply (unknown bounds, too few pairs, tables not much
+// smaller than the pair list, shapes the gate kernel has no instantiation for)
+static long pair_table_rows(const echr_tsrm_args* a, long* rc, long* rl) {
+    const long NN = (long)a->N * a->N;
+    if (!a->inference || !config().pair_tables || a->max_len <= 0 || a->max_span < 0 || NN < 16384 || a->G > 16 || (a->Df != 512 && a->Df != 256) ||
+        !config().gemm_h2)
+        return 0;
+    const long Lm1 = (long)a->max_len + 1;
+    *rc = ((long)a->max_span + 1) * Lm1;
+    *rl = Lm1 * Lm1;
+    return (*rc + *rl) * 2 <= NN ? *rc + *rl : 0;
+}
+
 static int check(const echr_tsrm_args* a, const char* who) {
     ECHR_REQUIRE(a, "%s: null args", who);
     ECHR_REQUIRE(a->N > 0 && a->Din > 0 && a->Df > 0 && a->Do > 0 && a->G > 0, "%s: bad dims", who);
@@ -338,8 +434,42 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
     hipStream_t sp = config().tsrm_fork ? aux_fork(st) : nullptr;
     const bool fork = sp != nullptr;
     if (!fork) sp = st;
-    const bool packed_pos = !x_given && config().gemm_h2 && NN >= 4096 && posemb_packed_ok(N, Df);
-    if (!x_given) {
+    long trc = 0, trl = 0;
+    const long trows = x_given ? 0 : pair_table_rows(a, &trc, &trl);
+    const bool packed_pos = !x_given && !trows && config().gemm_h2 && NN >= 4096 && posemb_packed_ok(N, Df);
+    if (trows) {
+        // inference over many pairs: tabulated fc1 (see pair_phi_kernel).  The tables live in the workspace regions the dense path would
+        // fill (POS: F_c | F_l; P1: phi_c | phi_l and the packed operands) -- (rc + rl) <= N*N / 2 rows, so they fit
+        d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1; d.beta = 1.f;
+        RC(gemm(d, st));
+        const int Lm1 = a->max_len + 1, Kh = Df / 2;
+        float* FCt = w.POS;
+        float* FLt = FCt + trc * Df;
+        float* phc = w.P1;
+        float* phl = phc + trc * Kh;
+        float* pkc = phl + trl * Kh;
+        float* pkl = pkc + h2_floats((int)trc, Kh);
+        float* pkw0 = pkl + h2_floats((int)trl, Kh);
+        float* pkw1 = pkw0 + h2_floats(Df, Kh);
+        ECHR_REQUIRE(pkw1 + h2_floats(Df, Kh) <= w.P1 + NN * Df, "tsrm_fwd: pair tables do not fit the workspace");
+        hipLaunchKernelGGL(pair_phi_kernel, dim3((unsigned)((trc * (Df / 4) + 255) / 256)), dim3(256), 0, sp, 0, Lm1, trc, Df, phc);
+        hipLaunchKernelGGL(pair_phi_kernel, dim3((unsigned)((trl * (Df / 4) + 255) / 256)), dim3(256), 0, sp, 1, Lm1, trl, Df, phl);
+        RC(check_launch("pair_phi"));
+        H2PackJob pj[4] = {pack_rows(phc, Kh, (int)trc, Kh, pkc), pack_rows(phl, Kh, (int)trl, Kh, pkl),
+                           pack_rows(a->w_fc1, Df, Df, Kh, pkw0), pack_rows(a->w_fc1 + Kh, Df, Df, Kh, pkw1)};
+        RC(h2_pack_multi(pj, 4, sp));
+        echr_gemm_desc t2[2] = {desc_h2(pkc, pkw0, FCt, Df, (int)trc, Df, Kh), desc_h2(pkl, pkw1, FLt, Df, (int)trl, Df, Kh)};
+        t2[0].split_k = t2[1].split_k = 1;
+        t2[0].bias = a->b_fc1;          // b1 is added once, in F_c
+        RC(gemm(t2[0], sp));
+        RC(gemm(t2[1], sp));
+        const int tiles = (int)((NN + 15) / 16);
+        const int grid = tiles / 4 < 2048 ? (tiles + 3) / 4 : 2048;
+        if (Df == 512) hipLaunchKernelGGL(pair_gate_kernel<32>, dim3(grid), dim3(256), 0, sp, FCt, FLt, a->ev_start, a->ev_len, N, Lm1, a->max_span, a->w_fc2, (long)Df, a->b_fc2, w.GATE, (long)G, G, tiles);
+        else hipLaunchKernelGGL(pair_gate_kernel<16>, dim3(grid), dim3(256), 0, sp, FCt, FLt, a->ev_start, a->ev_len, N, Lm1, a->max_span, a->w_fc2, (long)Df, a->b_fc2, w.GATE, (long)G, G, tiles);
+        RC(check_launch("pair_gate"));
+    }
+    if (!x_given && !trows) {
         // event embedding (:44)
         d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1; d.beta = 1.f;
         RC(gemm(d, st));
@@ -348,6 +478,8 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
         else RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, sp));
     }
     // fc1 over the N*N event pairs: the one TSRM product big enough for the h2 path (tanh fused in the epilogue)
+    if (trows) {
+    } else {
     if (config().gemm_h2 && NN >= 1024) {
         H2PackJob pj[2] = {pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1), pack_rows(w.POS, Df, NN, Df, w.PK_POS)};
         RC(h2_pack_multi(pj, packed_pos ? 1 : 2, sp));
@@ -363,6 +495,7 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
     } else {
         d = desc_nt(w.P1, Df, a->w_fc2, Df, w.GATE, G, NN, G, Df); d.bias = a->b_fc2; d.split_k = -1; d.beta = 1.f;
         RC(gemm(d, sp));
+    }
     }
     // query / key / (pre-applied) output projection of X: one grouped launch when the three problems have one shape
     {

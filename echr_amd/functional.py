@@ -39,7 +39,10 @@ def event_index_tensors(soi_select_list, ind_select_list, device, n_rows=None):
         raise ValueError('event intervals / anchors fall outside the %d feature rows' % n_rows)
     packed = np.stack([soi[:, 0], lens, ind]).astype(np.int32)
     t = upload(torch.from_numpy(packed), device)
-    return t[0].contiguous(), t[1].contiguous(), t[2].contiguous(), int(lens.max())
+    ev_start, ev_len = t[0].contiguous(), t[1].contiguous()
+    c2 = 2 * soi[:, 0] + lens
+    ev_len.echr_bounds = (int(lens.max()), int(c2.max() - c2.min()))      # host-known index bounds (echr_tsrm_args.max_len / max_span)
+    return ev_start, ev_len, t[2].contiguous(), int(lens.max())
 
 
 def upload(host_tensor, device):
@@ -156,7 +159,9 @@ class TSRMFunction(torch.autograd.Function):
     """MA_Attention8.forward (MA_attention_8_NEW.py:35-49, :101-177)."""
 
     @staticmethod
-    def forward(ctx, ech, ev_start, ev_len, n_head, drop, sink, *params):
+    def forward(ctx, ech, ev_start, ev_len, n_head, drop, sink, bounds, *params):
+        # bounds: None or (inference, max_len, max_span) = echr_tsrm_args' last three fields.  `inference` must be decided by the CALLER
+        # (grad mode is always off inside forward, and needs_input_grad ignores torch.no_grad())
         lib = L.load()
         ctx.sink = sink
         ech = _f32c(ech)
@@ -169,7 +174,7 @@ class TSRMFunction(torch.autograd.Function):
         ws = torch.empty(lib.echr_tsrm_ws_floats(N, Din, Df, Do, n_head), device=ech.device, dtype=torch.float32)
         out = torch.empty(N, Do, device=ech.device, dtype=torch.float32)
         a = L.TsrmArgs(N, Din, Df, Do, n_head, *[L.ptr(p) for p in ps], L.ptr(ech), L.ptr(ev_start, torch.int32),
-                       L.ptr(ev_len, torch.int32), L.ptr(ws), L.ptr(out), 0 if any(ctx.needs_input_grad) else 1)
+                       L.ptr(ev_len, torch.int32), L.ptr(ws), L.ptr(out), *(bounds or (0, 0, 0)))
         d = drop.c()
         L.check(lib.echr_tsrm_fwd(C.byref(a), C.byref(d), L.stream_ptr()), 'tsrm_fwd')
         ctx.save_for_backward(ech, ev_start, ev_len, ws, out, *ps)
@@ -193,7 +198,7 @@ class TSRMFunction(torch.autograd.Function):
         g = L.TsrmGrads(*[L.ptr(x) for x in grads], L.ptr(g_ech), L.ptr(g_out), L.ptr(wsb), zeroed)
         d = drop.c()
         L.check(lib.echr_tsrm_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'tsrm_bwd')
-        return (g_ech, None, None, None, None, None) + tuple(grads)
+        return (g_ech, None, None, None, None, None, None) + tuple(grads)
 
 
 def position_embedding(ev_start, ev_len, d_pos):

@@ -55,7 +55,11 @@ class MA_Attention8(nn.Module):
             ev_start, ev_len = ev_tensors
         if drop is None:
             drop = EF.DropState(training=False)
-        return EF.TSRMFunction.apply(feats, ev_start, ev_len, self.enc_attn.group, drop, self._grad_sink(), *self.native_params())
+        # host-known index bounds (event_index_tensors): they let inference over many pairs tabulate the pair MLP (echr_tsrm_args.max_len / max_span)
+        params = self.native_params()
+        infer = not (torch.is_grad_enabled() and (feats.requires_grad or any(p.requires_grad for p in params)))      # no backward pass can follow
+        return EF.TSRMFunction.apply(feats, ev_start, ev_len, self.enc_attn.group, drop, self._grad_sink(),
+                                     (1 if infer else 0,) + tuple(getattr(ev_len, 'echr_bounds', (0, 0))), *params)
 
     def _grad_sink(self):
         arena = getattr(self, '_echr_arena_ref', None)

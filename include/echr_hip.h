@@ -138,6 +138,9 @@ typedef struct {
     float* out;                      /* [N,Do] */
     int32_t inference;               /* echr_tsrm_fwd: 1 = no echr_tsrm_bwd will follow on this workspace (activations that only the backward
                                         pass reads -- the fp32 position embedding of >= 4096 pairs -- are not materialised) */
+    int32_t max_len, max_span;       /* optional, known to the host from the index lists: max ev_len and max |(2 start_i + len_i) - (2 start_j +
+                                        len_j)| over the events (0 / -1... leave max_len = 0 when unknown).  With `inference` and >= 16384 pairs
+                                        they let the pair MLP run from tables over the distinct (|2 dc|, l_i) and (l_i, l_j) keys */
 } echr_tsrm_args;
 
 typedef struct {
@@ -409,6 +412,7 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *   "posemb_rows" 0/1   (default 1, ECHR_POSEMB_ROWS) pairwise position embedding with one thread per frequency (contiguous stores); 0 = one
  *                      thread per 16 frequencies of a pair
  *   "posemb_packed" 0/1 (default 1, ECHR_POSEMB_PACKED) >= 4096 event pairs: the position embedding is written directly as the packed fc1 operand
+ *   "pair_tables" 0/1   (default 1, ECHR_PAIR_TABLES) inference over >= 16384 event pairs with known index bounds: fc1 tabulated over the distinct keys
  *   "gemm_skinny" 0/1   (default 1, ECHR_GEMM_SKINNY) the event encoder's fc2 over >= 4096 event pairs (512 -> <= 16 columns) as a streaming
  *                      16-row-tile kernel instead of the general tiles
  *   "embed_fused" 0/1   (default 0, ECHR_EMBED_FUSED) token-embedding gradient through echr_gemm_desc.row_index instead of d XT + scatter pass

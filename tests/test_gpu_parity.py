@@ -302,6 +302,43 @@ def test_event_context_many_events_vs_oracle():
         assert U.relerr(p.grad.cpu().numpy(), P[k].grad.numpy()) < TOL_GRAD, k
 
 
+def test_event_context_inference_tables_vs_oracle():
+    """Inference over >= 16384 event pairs (evaluation batches): fc1 of the pair MLP is tabulated over the distinct integer keys
+    (|2 dc|, l_i) and (l_i, l_j) and the gates are formed from two gathered table rows per pair (echr_tsrm_args.inference + max_len / max_span).
+    Against the oracle, against the dense path (grad mode / pair_tables = 0), and with bounds the host did not supply (dense fallback)."""
+    from echr_amd import functional as EF
+    from echr_amd import _lib
+    from oracle import echr_ref_cpu as O
+    lib = _lib.load()
+    opt = synth.default_opt(vocab_size=300, seq_length=6)
+    params = synth.make_params(opt, 7)
+    vid = synth.make_video(200, 24, 8, 301, seed=13, T_v=200, min_len=1)
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        ref = O.event_context(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), vid['ind'], vid['soi'], opt.n_head, None).numpy()
+    ev = EF.event_index_tensors(vid['soi'], vid['ind'], dev)
+    assert ev[1].echr_bounds[0] == 24 and ev[1].echr_bounds[1] > 0
+    tap, c3d = torch.from_numpy(vid['tap']).to(dev), torch.from_numpy(vid['c3d']).to(dev)
+
+    def run():
+        return m.get_event_context(tap, c3d, None, vid['ind'], vid['soi'], _ev=ev, _drop=EF.DropState(U.SEED, U.OFFSET, False))
+    with torch.no_grad():
+        tab = run().cpu().numpy()                      # tables
+        lib.echr_config_set(b'pair_tables', 0)
+        try:
+            dense_ng = run().cpu().numpy()             # dense, inference
+        finally:
+            lib.echr_config_set(b'pair_tables', 1)
+        ev2 = EF.event_index_tensors(vid['soi'], vid['ind'], dev)
+        del ev2[1].echr_bounds                         # a caller that does not know the bounds
+        nob = m.get_event_context(tap, c3d, None, vid['ind'], vid['soi'], _ev=ev2, _drop=EF.DropState(U.SEED, U.OFFSET, False)).cpu().numpy()
+    dense = run().detach().cpu().numpy()               # grad mode: dense, activations kept
+    assert U.relerr(tab, ref) < 1e-5
+    assert U.relerr(tab, dense) < 2e-6 and U.relerr(tab, dense_ng) < 2e-6 and U.relerr(nob, dense) < 2e-6
+
+
 @pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full', 'c3bench'])
 @pytest.mark.parametrize('train_mode', [False, True])
 def test_full_path_vs_oracle(case, train_mode):
