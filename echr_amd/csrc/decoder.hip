@@ -1456,7 +1456,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
 // ------------------------------------------------------------------------------------------------------
 // greedy sampler (OldModel_NEW.py:139-187, sample_max = 1, eval mode): every step on device
 // ------------------------------------------------------------------------------------------------------
-struct SampWs { float* XT; float* LOGITS; int *IT, *UNF; float* SLABS; float *TABLES, *PSWS; long total; };
+struct SampWs { float* XT; float* LOGITS; int *IT, *UNF; float* SLABS; float *TABLES, *PSWS, *PSX; long total; };
 // parameter-only operands of the persistent greedy decoder (csrc/persist.hip, PersistS): the token-side gate tables, the packed embedding
 // they are made from and the logit-weight image -- cacheable across calls while the parameters do not change (echr_sample_args.tables)
 struct SampTables { float *TG[3], *PK_EMB, *LIMG; long total; };
@@ -1491,7 +1491,9 @@ static SampWs carve_samp(const echr_dec_args* a, float* base) {
     // image and the launch's exchange buffers
     const bool ps = persist_sample_shape_ok(a);          // by shape only: the carving must not depend on switches that can change between calls
     s.TABLES = take(ps ? carve_tables(a, nullptr).total : 64);
-    s.PSWS = take(ps ? persist_sample_ws_floats(a->S, a->V1) : 64);
+    const long groups = (a->N + 63) / 64;          // the persistent decoder runs one launch per group of 64 events, each on its own workspaces
+    s.PSWS = take(ps ? groups * persist_sample_ws_floats(a->S, a->V1) : 64);
+    s.PSX = take(ps ? groups * persist_sample_x_floats(a->S) : 64);
     s.total = off;
     return s;
 }
@@ -1562,17 +1564,12 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
             RC(gemm_grouped(d, 3, st));
             RC(persist_logit_image(a.w_logit, a.V1, tb.LIMG, st));
         }
-        for (int n0 = 0; n0 < N; n0 += 64) {
-            echr_dec_args p = a;
-            p.N = N - n0 < 64 ? N - n0 : 64;
-            p.ev_start = a.ev_start + n0; p.ev_len = a.ev_len + n0;
-            PersistSampleBufs B;
-            B.PALL = w.PALL; B.EVB0 = w.EVB0 + (long)n0 * 4 * H; B.VIDB = w.VIDB; B.xws = w.XWS;
-            for (int k = 0; k < 3; ++k) B.TG[k] = tb.TG[k];
-            B.limg = tb.LIMG; B.sws = s.PSWS;
-            B.seq = reinterpret_cast<long long*>(sa->seq) + (long)n0 * L; B.seq_logp = sa->seq_logp + (long)n0 * L; B.n_unfinished = sa->n_unfinished;
-            RC(persist_sample(&p, B, st));
-        }
+        PersistSampleBufs B;
+        B.PALL = w.PALL; B.EVB0 = w.EVB0; B.VIDB = w.VIDB; B.xws = s.PSX;
+        for (int k = 0; k < 3; ++k) B.TG[k] = tb.TG[k];
+        B.limg = tb.LIMG; B.sws = s.PSWS;
+        B.seq = reinterpret_cast<long long*>(sa->seq); B.seq_logp = sa->seq_logp; B.n_unfinished = sa->n_unfinished;
+        RC(persist_sample(&a, B, st));
         return 0;
     }
     const bool big = config().gemm_h2 && N >= SAMP_SLAB_ROWS;

@@ -42,7 +42,8 @@ bool persist_bwd_eligible(const echr_dec_args* a);
 int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
 // greedy decoding on the persistent kernels (64 events per launch, every step on device): see PersistS in csrc/persist.hip
 struct PersistSampleBufs { float* PALL; const float* EVB0; const float* VIDB; float* xws; const float* TG[3]; const float* limg; float* sws; long long* seq; float* seq_logp; int* n_unfinished; };
-long persist_sample_ws_floats(int S, int V1);
+long persist_sample_ws_floats(int S, int V1);          // per group of 64 events
+long persist_sample_x_floats(int S);                   // per group of 64 events
 long persist_logit_image_floats(int V1);
 bool persist_sample_shape_ok(const echr_dec_args* a);
 bool persist_sample_eligible(const echr_dec_args* a);

@@ -1977,9 +1977,13 @@ __global__ __launch_bounds__(256) void logit_image_kernel(const float* __restric
 // keys + per-workgroup (maximum, sum of exponentials) -> seq / seq_logp / the unfinished bookkeeping of OldModel.sample (:171-183): one
 // wave per (event, step).  The emitted token is masked once the event has produced <eos> at this or an earlier step (the network kept
 // consuming the raw arg-max); the sum over the 64 workgroups' partials runs in a fixed butterfly order.
-__global__ __launch_bounds__(64) void sample_finish_kernel(const unsigned long long* __restrict__ KEY, const float* __restrict__ LSE, int N, int L, int nch,
+__global__ __launch_bounds__(64) void sample_finish_kernel(const unsigned long long* __restrict__ KEY, const float* __restrict__ LSE, int N, int L, int nch, long stride_s,
                                                          long long* __restrict__ seq, float* __restrict__ seq_logp, int* __restrict__ n_unfinished) {
-    const int n = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const int ng = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const int n = ng & (PROWS - 1);
+    KEY += (long)(ng / PROWS) * (stride_s / 2);          // the event's group of 64 has its own keys / partials
+    LSE += (long)(ng / PROWS) * stride_s;
+    seq += (long)(ng - n) * L; seq_logp += (long)(ng - n) * L;
     const unsigned long long key = KEY[(long)t * PROWS + n];
     u32 u = (u32)(key >> 32);
     u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
@@ -3125,6 +3129,20 @@ static PersistLayoutS persist_layout_s(int S, int V1) {
     return L;
 }
 long persist_sample_ws_floats(int S, int V1) { return persist_layout_s(S, V1).total; }
+long persist_sample_x_floats(int S) { return persist_layout(S).total + persist_layout2(S).total; }          // one group's exchange workspace (both layouts)
+
+// two zero ranges per event group, `stride` floats apart from group to group: blocks [0, per) of a group cover range A then range B
+__global__ __launch_bounds__(256) void fill_zero_groups_kernel(float* __restrict__ a, long na, long stride_a, float* __restrict__ b, long nb, long stride_b, int per) {
+    const int g = blockIdx.x / per, i = blockIdx.x % per;
+    const int ba = (int)((na + 4095) / 4096);
+    float* p = i < ba ? a + (long)g * stride_a : b + (long)g * stride_b;
+    const long n = i < ba ? na : nb, base = (long)(i < ba ? i : i - ba) * 4096;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long j = base + k * 256 + threadIdx.x;
+        if (j < n) p[j] = 0.f;
+    }
+}
 long persist_logit_image_floats(int V1) { const long nvb = (long)LWG * logit_chunks(V1); return nvb * 3 * 16 * LCT * 2 * 64 * 4 + 2L * nvb * LCOLS; }
 
 // vocabulary within the logits role's 64 x 80 columns, fp16-pair forms on, shapes as the teacher-forced kernel (events are processed 64 per launch)
@@ -3151,10 +3169,40 @@ int persist_logit_image(const float* w_logit, int V1, float* img, hipStream_t st
     return check_launch("logit_image");
 }
 
-// one launch decodes up to 64 events for a->S steps; `a` describes those events (N <= 64, pointers already offset)
+// One launch per group of 64 events (back to back on `st`; every group has its own copy of the exchange workspaces, so ONE fill launch ahead
+// of the first and ONE finishing launch behind the last serve all of them).  B.xws / B.sws: groups x persist_sample_x_floats / _ws_floats.
+static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st);
 int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st) {
     PersistHost& h = phost();
-    ECHR_REQUIRE(h.ok && a->N <= PROWS, "persist_sample: device state unavailable");
+    ECHR_REQUIRE(h.ok && a->N >= 1, "persist_sample: device state unavailable");
+    const PersistLayout L = persist_layout(a->S);
+    const PersistLayout2 L2 = persist_layout2(a->S);
+    const PersistLayoutS LS = persist_layout_s(a->S, a->V1);
+    const int groups = (a->N + PROWS - 1) / PROWS;
+    const long sx = persist_sample_x_floats(a->S), ss = LS.total;
+    {
+        // counters, atomically folded buffers and the arg-max keys of every group
+        const long zx = L2.total - L2.zero_begin + L.xc, zs = LS.zero_end;
+        const long per = (zx + 4095) / 4096 + (zs + 4095) / 4096;
+        hipLaunchKernelGGL(fill_zero_groups_kernel, dim3((unsigned)(per * groups)), dim3(256), 0, st, B.xws + L2.zero_begin, zx, sx, B.sws, zs, ss, (int)per);
+        if (int rc = check_launch("fill_zero_groups")) return rc;
+    }
+    for (int g = 0; g < groups; ++g) {
+        echr_dec_args p = *a;
+        const int n0 = PROWS * g;
+        p.N = a->N - n0 < PROWS ? a->N - n0 : PROWS;
+        p.ev_start = a->ev_start + n0; p.ev_len = a->ev_len + n0;
+        PersistSampleBufs Bg = B;
+        Bg.EVB0 = B.EVB0 + (long)n0 * 4 * PH; Bg.xws = B.xws + (long)g * sx; Bg.sws = B.sws + (long)g * ss;
+        if (int rc = persist_sample_group(&p, Bg, st)) return rc;
+    }
+    hipLaunchKernelGGL(sample_finish_kernel, dim3(a->N, a->S), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(B.sws + LS.key), B.sws + LS.lse, a->N, a->S,
+                       logit_chunks(a->V1), ss, B.seq, B.seq_logp, B.n_unfinished);
+    return check_launch("sample_finish");
+}
+static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st) {
+    PersistHost& h = phost();
+    ECHR_REQUIRE(h.ok && a->N <= PROWS, "persist_sample_group: device state unavailable");
     const PersistLayout L = persist_layout(a->S);
     const PersistLayout2 L2 = persist_layout2(a->S);
     const PersistLayoutS LS = persist_layout_s(a->S, a->V1);
@@ -3198,12 +3246,6 @@ int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream
     Q.LSE = B.sws + LS.lse; Q.XC3 = B.sws + LS.xc3; Q.XS3 = B.sws + LS.xs3;
     Q.cnt2 = K2.cnt; Q.XH1 = K2.XH1; Q.V1 = a->V1;
     {
-        // counters, atomically folded buffers and the arg-max keys: one fill launch
-        float* zp[2] = {x2 + L2.zero_begin, B.sws};
-        long zn[2] = {L2.total - L2.zero_begin + L.xc, LS.zero_end};
-        if (int rc = fill_zero_multi(zp, zn, 2, st)) return rc;
-    }
-    {
         const double wbytes = 4.0 * (3.0 * 4 * PH * PH + (double)PH * PH + 4.0 * PH * a->D) + 4.0 * a->S * 3.0 * PH * a->V1;      // the logit weights are streamed once per step
         const double obytes = 4.0 * (double)a->N * a->A * (PH + a->D);
         ProfScope prof(PROF_PERSIST, 2.0 * a->S * PROWS * PH * (double)(3 * 4 * PH + PH + 4 * PH) + 2.0 * a->S * PROWS * 3.0 * PH * a->V1, wbytes + obytes, st);
@@ -3221,8 +3263,7 @@ int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream
             if (int rc = check_launch("dec_persist_sample")) return rc;
         }
     }
-    hipLaunchKernelGGL(sample_finish_kernel, dim3(a->N, a->S), dim3(64), 0, st, Q.KEY, Q.LSE, a->N, a->S, Q.nch, B.seq, B.seq_logp, B.n_unfinished);
-    return check_launch("sample_finish");
+    return 0;
 }
 
 bool persist_bwd_eligible(const echr_dec_args* a) { return config().persist_bwd && persist_shape_ok(a); }
