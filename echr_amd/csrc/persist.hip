@@ -1825,10 +1825,12 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[w * 1024 + (16 * i + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = la[i][c][r];
+                for (int r = 0; r < 4; ++r)          // [row tile i][r][lane group][16 columns, 4-float groups XOR-ed with r]: a wave's store covers 64 distinct banks,
+                    red[w * 1024 + ((i * 4 + r) * 4 + (lane >> 4)) * 16 + ((lane & 15) ^ (r << 2))] = la[i][c][r];      // and so do the float4 reads below
             __syncthreads();
-            const float4 p0 = *reinterpret_cast<const float4*>(red + ev * 16 + 4 * q4), p1 = *reinterpret_cast<const float4*>(red + 1024 + ev * 16 + 4 * q4),
-                         p2 = *reinterpret_cast<const float4*>(red + 2048 + ev * 16 + 4 * q4), p3 = *reinterpret_cast<const float4*>(red + 3072 + ev * 16 + 4 * q4);
+            const int ro = (((ev >> 4) * 4 + (ev & 3)) * 4 + ((ev >> 2) & 3)) * 16 + 4 * (q4 ^ (ev & 3));          // event ev = 16 i + 4 group + r
+            const float4 p0 = *reinterpret_cast<const float4*>(red + ro), p1 = *reinterpret_cast<const float4*>(red + 1024 + ro),
+                         p2 = *reinterpret_cast<const float4*>(red + 2048 + ro), p3 = *reinterpret_cast<const float4*>(red + 3072 + ro);
             const float4 sc4 = *reinterpret_cast<const float4*>(lsc + LCOLS * ch + 16 * c + 4 * q4), bi4 = *reinterpret_cast<const float4*>(lbi + LCOLS * ch + 16 * c + 4 * q4);
             lv[c][0] = ((p0.x + p1.x) + (p2.x + p3.x)) * sc4.x + bi4.x;
             lv[c][1] = ((p0.y + p1.y) + (p2.y + p3.y)) * sc4.y + bi4.y;
