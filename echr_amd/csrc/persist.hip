@@ -874,6 +874,7 @@ struct PersistK2 {
 // bitwise reproducible -- and the consumers gather the token-side gate pre-activations from a [V1, 4H] table per stream.
 constexpr int LCOLS = 80, LCT = 5;             // vocabulary columns / 16-column MFMA tiles per logits workgroup
 constexpr int LWG = 2 * NS;                    // logits workgroups
+constexpr u32 STOP_ALL_FINISHED = 0x7FFFFFF0u;          // written to the launch's abort word: not an error (see persist_sample_group)
 constexpr int LCHMAX = 3;                      // column chunks of LWG x LCOLS a workgroup can take: vocabularies of up to 15 360 words
 struct PersistS {
     const float* TG[3];            // [V1][4H] token-side gate pre-activations per stream (stream 1: biases folded in)
@@ -889,6 +890,7 @@ struct PersistS {
     u32* cnt2;                     // the attention layout's counters (the logits role waits for h1)
     const float* XH1;              // its h1 exchange planes
     int V1, nch;                   // nch = ceil(V1 / 5120) column chunks
+    int force_eos;                 // diagnostic (tests): > 0 = the logits of steps >= force_eos - 1 are overridden in favour of <eos> (column 0) for every event
 };
 
 // BIG: events of up to 258 segments (BASELINE config 5's 256-segment proposals).  An event's first 129 slots live in registers as before;
@@ -1646,6 +1648,8 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
     const bool st_on = b == 0;
     const int nhalf = N > HR ? 2 : 1;
     u32 peek_tok = 0;
+    int* stopf = flag + 1;
+    bool unf[2] = {gr < N, 32 + gr < N};          // rows past the batch count as finished
     for (int t = 0; t < S; ++t) {
         if (st_on) STAMP(3, 0);
         // ---- token t -> gate pre-activations, cells, h(t) ----
@@ -1659,6 +1663,21 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             }
         }
         if (st_on) STAMP(3, 1);
+        if (t > 0) {
+            // OldModel.sample's stop (:171-180): unfinished &= token > 0; when no event of the group is unfinished any more, nothing of step t
+            // or later is ever emitted -- every workgroup of this role sees all 64 tokens and reaches the same verdict; the others leave
+            // through their wait loops
+            unf[0] = unf[0] && tok[0] > 0u;
+            unf[1] = unf[1] && tok[1] > 0u;
+            if (tid == 0) *stopf = 0;
+            __syncthreads();
+            if (unf[0] || unf[1]) *stopf = 1;
+            __syncthreads();
+            if (*stopf == 0) {
+                if (tid == 0) __hip_atomic_store(P.abort_word, STOP_ALL_FINISHED, __ATOMIC_RELAXED, ECHR_AGENT);
+                return;
+            }
+        }
         CellOut co[4];
         {
             float pre[4][4];
@@ -1838,6 +1857,7 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             lv[c][3] = ((p0.w + p1.w) + (p2.w + p3.w)) * sc4.w + bi4.w;
             __syncthreads();
         }
+        if (Q.force_eos > 0 && t + 1 >= Q.force_eos && vb == 0 && q4 == 0) lv[0][0] = 1e30f;          // diagnostic: column 0 wins from this step on
         {
             float mx = -INFINITY;
             int mi = 0x7fffffff;
@@ -1980,7 +2000,7 @@ __global__ __launch_bounds__(256) void logit_image_kernel(const float* __restric
 // wave per (event, step).  The emitted token is masked once the event has produced <eos> at this or an earlier step (the network kept
 // consuming the raw arg-max); the sum over the 64 workgroups' partials runs in a fixed butterfly order.
 __global__ __launch_bounds__(64) void sample_finish_kernel(const unsigned long long* __restrict__ KEY, const float* __restrict__ LSE, int N, int L, int nch, long stride_s,
-                                                         long long* __restrict__ seq, float* __restrict__ seq_logp, int* __restrict__ n_unfinished) {
+                                                         long long* __restrict__ seq, float* __restrict__ seq_logp, int* __restrict__ n_unfinished, const u32* __restrict__ stop_words) {
     const int ng = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
     const int n = ng & (PROWS - 1);
     KEY += (long)(ng / PROWS) * (stride_s / 2);          // the event's group of 64 has its own keys / partials
@@ -2005,8 +2025,9 @@ __global__ __launch_bounds__(64) void sample_finish_kernel(const unsigned long l
     const int un = __all(ok);
     if (lane == 0) {
         seq[(long)n * L + t] = un ? bi : 0;
-        seq_logp[(long)n * L + t] = -logf(s);
+        seq_logp[(long)n * L + t] = key ? -logf(s) : 0.f;          // (steps behind an early stop were never computed: their columns are trimmed by the caller)
         if (un) atomicAdd(&n_unfinished[t + 1], 1);
+        if (ng == 0 && t == 0) n_unfinished[0] = stop_words[0] == STOP_ALL_FINISHED ? 1 : 0;          // [0] is otherwise unused: 1 = group 0's launch stopped early
     }
 }
 
@@ -3114,7 +3135,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
 
 
 // ---- greedy decoding on the persistent kernels (SAMP instantiations) ----
-struct PersistLayoutS { long key, cnt, zero_end, lse, xc3, xs3, total; };
+struct PersistLayoutS { long key, cnt, stop, zero_end, lse, xc3, xs3, total; };
 static inline int logit_chunks(int V1) { return (V1 + LWG * LCOLS - 1) / (LWG * LCOLS); }
 static PersistLayoutS persist_layout_s(int S, int V1) {
     const int nch = logit_chunks(V1);
@@ -3123,6 +3144,7 @@ static PersistLayoutS persist_layout_s(int S, int V1) {
     auto take = [&](long n) { long o = off; off += (n + 63) / 64 * 64; return o; };
     L.key = take((long)S * PROWS * 2);
     L.cnt = take((long)S * CNT_LINE);
+    L.stop = take(64);
     L.zero_end = off;
     L.lse = take((long)S * LWG * nch * PROWS * 2);
     L.xc3 = take((long)S * 2 * 3 * HR * PH);
@@ -3199,7 +3221,7 @@ int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream
         if (int rc = persist_sample_group(&p, Bg, st)) return rc;
     }
     hipLaunchKernelGGL(sample_finish_kernel, dim3(a->N, a->S), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(B.sws + LS.key), B.sws + LS.lse, a->N, a->S,
-                       logit_chunks(a->V1), ss, B.seq, B.seq_logp, B.n_unfinished);
+                       logit_chunks(a->V1), ss, B.seq, B.seq_logp, B.n_unfinished, reinterpret_cast<const u32*>(B.sws + LS.stop));
     return check_launch("sample_finish");
 }
 static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st) {
@@ -3219,7 +3241,11 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
     float* x = x2 + L2.total;
     K.cnt = reinterpret_cast<u32*>(x + L.cnt); K.XC = x + L.xc; K.XS = x + L.xs; K.GRAN = reinterpret_cast<unsigned long long*>(x + L.gran);
     K.XH1 = x + L.xh1; K.XH0 = x + L.xh0; K.XH2 = x + L.xh2; K.XQ = x + L.xq; K.WU = x + L.wu;
-    K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
+    // the group's own word serves as the launch's abort word: a hand-off time-out writes its code there (and to the host flag, as everywhere),
+    // and the decoder itself writes STOP_ALL_FINISHED there once every event of the group has emitted <eos> -- every wait loop then lets its
+    // workgroup leave, which is exactly OldModel.sample's `break` (models/OldModel_NEW.py:179-180)
+    u32* stopw = reinterpret_cast<u32*>(B.sws + LS.stop);
+    K.abort_word = stopw; K.host_flag = h.flag_dev;
     K.spin_limit = config().persist_spin_limit > 0 ? (u32)config().persist_spin_limit : SPIN_LIMIT; K.inject = (u32)config().persist_inject_timeout;
     K.dh = off; K.dout = off;
     K.stamps = nullptr;
@@ -3234,7 +3260,7 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
     K2.GATES1 = nullptr; K2.CS1 = nullptr; K2.HS = nullptr; K2.OUTD = nullptr; K2.QS = nullptr; K2.WT = nullptr; K2.ATT = nullptr;
     K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XC = x2 + L2.xc; K2.XS = x2 + L2.xs; K2.GRAN = reinterpret_cast<unsigned long long*>(x2 + L2.gran);
     K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
-    K2.abort_word = h.abort_dev; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = off; K2.dout = off;
+    K2.abort_word = stopw; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = off; K2.dout = off;
     K2.spin_limit = K.spin_limit; K2.inject = K.inject;
     PersistS Q;
     for (int k = 0; k < 3; ++k) Q.TG[k] = B.TG[k];
@@ -3243,6 +3269,7 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
     Q.cnt_tok = reinterpret_cast<u32*>(B.sws + LS.cnt);
     Q.LIMG = reinterpret_cast<const float4*>(B.limg);
     Q.nch = logit_chunks(a->V1);
+    Q.force_eos = config().persist_sample_force_eos;
     Q.linv = B.limg + (long)LWG * Q.nch * 3 * 16 * LCT * 2 * 64 * 4 + LWG * Q.nch * LCOLS;
     Q.lbias = a->b_logit;
     Q.LSE = B.sws + LS.lse; Q.XC3 = B.sws + LS.xc3; Q.XS3 = B.sws + LS.xs3;

@@ -408,6 +408,7 @@ def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, de
         o = (N * E + 63) // 64 * 64
         debug['last_logits'] = wss[o:o + N * V1].view(N, V1).clone()
         debug['seq_full'], debug['logp_full'] = seq.clone(), slp.clone()
+        debug['stopped_early'] = int(counts[0])      # persistent decoder: 1 = every event had emitted <eos> before seq_length and the launch stopped there
     T = seq_length
     for t in range(1, seq_length + 1):        # OldModel_NEW.py:179-180: stop at the first step with nobody unfinished
         if counts[t] == 0:

@@ -557,6 +557,56 @@ def test_persistent_sampler_edge_shapes_vs_launch_per_step(N, A, V1, min_len):
         assert np.abs(outs[0][1] - lp_o.numpy()).max() < TOL_LOGP
 
 
+@pytest.mark.parametrize('N', [3, 64, 100])
+def test_persistent_sampler_stops_when_every_event_has_finished(N):
+    """OldModel.sample breaks out of its loop once no event is unfinished (models/OldModel_NEW.py:171-180); the persistent decoder then stops
+    its launch (its workgroups leave through their wait loops).  The synthetic initialisation never ends a caption between the first and the
+    last step (checked with the oracle: the <eos> margin is smallest at step 1), so the diagnostic `persist_sample_force_eos` = k lets <eos>
+    win from step k - 1 on: the decode must return exactly the first k - 1 columns of the free-running decode, report the early stop, raise
+    no error, and leave the next decode undisturbed.  A model whose <eos> bias ends every caption at once gives ([], []) on both forms."""
+    from echr_amd import _lib
+    from echr_amd import functional as EF
+    from echr_amd.models.OldModel_NEW import ClipView
+    lib = _lib.load()
+    opt, params, _ = synth.make_case('c2')
+    V1 = params['lm_model.logit.bias'].shape[0]
+    vid = synth.make_video(N, 40, 21, V1, seed=5, T_v=120)
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    with torch.no_grad():
+        ev = EF.event_index_tensors(vid['soi'], vid['ind'], dev)
+        event = m.get_event_context(tap, c3d, lda, vid['ind'], vid['soi'], _ev=ev, _drop=m.lm_model.next_drop_state())
+
+        def decode():
+            dbg = {}
+            out = EF.greedy_sample(lda, event, c3d, ev[0], ev[1], ev[3], m.lm_model.seq_length, m.lm_model.native_params(), debug=dbg)
+            return out, dbg
+        (free_seq, free_lp), dbg = decode()
+        assert free_seq.shape == (N, opt.CG_seq_length) and dbg['stopped_early'] == 0
+        for k in (2, 7):
+            lib.echr_config_set(b'persist_sample_force_eos', k)
+            try:
+                (seq, lp), dbg = decode()
+            finally:
+                lib.echr_config_set(b'persist_sample_force_eos', 0)
+            assert lib.echr_check_async() == 0
+            assert dbg['stopped_early'] == 1
+            assert tuple(seq.shape) == (N, k - 1)
+            assert torch.equal(seq, free_seq[:, :k - 1]) and torch.equal(lp, free_lp[:, :k - 1])
+        (again, again_lp), dbg = decode()
+        assert torch.equal(again, free_seq) and torch.equal(again_lp, free_lp) and dbg['stopped_early'] == 0
+        # every caption ends at its first token: nothing is generated, on both forms
+        m.lm_model.logit.bias.data[0] += 500.0
+        for flag in (1, 0):
+            lib.echr_config_set(b'persist_sample', flag)
+            try:
+                out = m.lm_model.sample(lda, event, ClipView(c3d, ev[0], ev[1], ev[3], False), None)
+            finally:
+                lib.echr_config_set(b'persist_sample', 1)
+            assert len(out[0]) == 0 and len(out[1]) == 0
+
+
 def test_persistent_sampler_table_cache_follows_parameter_updates():
     """The persistent decoder caches its parameter-only operands (token-side gate tables, logit image) on the model.  A second decode must
     reuse them (bitwise the same output); an in-place parameter update (torch version counter) and a library optimiser step (raw-pointer
