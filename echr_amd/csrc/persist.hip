@@ -1997,37 +1997,48 @@ __global__ __launch_bounds__(256) void logit_image_kernel(const float* __restric
 }
 
 // keys + per-workgroup (maximum, sum of exponentials) -> seq / seq_logp / the unfinished bookkeeping of OldModel.sample (:171-183): one
-// wave per (event, step).  The emitted token is masked once the event has produced <eos> at this or an earlier step (the network kept
-// consuming the raw arg-max); the sum over the 64 workgroups' partials runs in a fixed butterfly order.
-__global__ __launch_bounds__(64) void sample_finish_kernel(const unsigned long long* __restrict__ KEY, const float* __restrict__ LSE, int N, int L, int nch, long stride_s,
-                                                         long long* __restrict__ seq, float* __restrict__ seq_logp, int* __restrict__ n_unfinished, const u32* __restrict__ stop_words) {
-    const int ng = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+// workgroup per event; wave 0 turns the event's L tokens into the unfinished flags with one ballot (unfinished after step t <=> every
+// arg-max of steps 0..t is a word: the network kept consuming the raw arg-max, only the emitted token is masked), then the four waves share
+// the steps: the sum over the 64 x nch logits workgroups' partials runs in a fixed butterfly order.  L <= 64 (checked by the caller).
+__global__ __launch_bounds__(256) void sample_finish_kernel(const unsigned long long* __restrict__ KEY, const float* __restrict__ LSE, int N, int L, int nch, long stride_s,
+                                                          long long* __restrict__ seq, float* __restrict__ seq_logp, int* __restrict__ n_unfinished, const u32* __restrict__ stop_words) {
+    __shared__ unsigned long long skey[64];
+    __shared__ unsigned long long sun;
+    const int ng = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int n = ng & (PROWS - 1);
     KEY += (long)(ng / PROWS) * (stride_s / 2);          // the event's group of 64 has its own keys / partials
     LSE += (long)(ng / PROWS) * stride_s;
     seq += (long)(ng - n) * L; seq_logp += (long)(ng - n) * L;
-    const unsigned long long key = KEY[(long)t * PROWS + n];
-    u32 u = (u32)(key >> 32);
-    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
-    const float M = __uint_as_float(u);
-    const int bi = (int)(0xFFFFFFFFu - (u32)key);
-    float s = 0.f;
-    for (int c = 0; c < nch; ++c) {          // chunk by chunk: a fixed order
-        const float* lp = LSE + (((long)t * PROWS + n) * (LWG * nch) + LWG * c + lane) * 2;
-        const float m = lp[0];
-        s += m > -INFINITY ? lp[1] * expf(m - M) : 0.f;
+    if (w == 0) {
+        const unsigned long long key = lane < L ? KEY[(long)lane * PROWS + n] : 0ull;
+        skey[lane] = key;
+        const unsigned long long word = __ballot(lane < L && (0xFFFFFFFFu - (u32)key) > 0u);      // bit t: the arg-max of step t is a word
+        if (lane == 0) sun = word;
     }
+    __syncthreads();
+    const unsigned long long word = sun;
+    for (int t = w; t < L; t += 4) {
+        const unsigned long long key = skey[t];
+        u32 u = (u32)(key >> 32);
+        u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+        const float M = __uint_as_float(u);
+        const int bi = (int)(0xFFFFFFFFu - (u32)key);
+        float s = 0.f;
+        for (int c = 0; c < nch; ++c) {          // chunk by chunk: a fixed order
+            const float* lp = LSE + (((long)t * PROWS + n) * (LWG * nch) + LWG * c + lane) * 2;
+            const float m = lp[0];
+            s += m > -INFINITY ? lp[1] * expf(m - M) : 0.f;
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    // unfinished after step t <=> every arg-max of steps 0..t is a word (> 0)
-    int ok = 1;
-    for (int j = lane; j <= t; j += 64) ok = ok && ((0xFFFFFFFFu - (u32)KEY[(long)j * PROWS + n]) > 0u);
-    const int un = __all(ok);
-    if (lane == 0) {
-        seq[(long)n * L + t] = un ? bi : 0;
-        seq_logp[(long)n * L + t] = key ? -logf(s) : 0.f;          // (steps behind an early stop were never computed: their columns are trimmed by the caller)
-        if (un) atomicAdd(&n_unfinished[t + 1], 1);
-        if (ng == 0 && t == 0) n_unfinished[0] = stop_words[0] == STOP_ALL_FINISHED ? 1 : 0;          // [0] is otherwise unused: 1 = group 0's launch stopped early
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const unsigned long long need = t == 63 ? ~0ull : ((2ull << t) - 1ull);
+        const int un = (word & need) == need;
+        if (lane == 0) {
+            seq[(long)n * L + t] = un ? bi : 0;
+            seq_logp[(long)n * L + t] = key ? -logf(s) : 0.f;          // (steps behind an early stop were never computed: their columns are trimmed by the caller)
+            if (un) atomicAdd(&n_unfinished[t + 1], 1);
+            if (ng == 0 && t == 0) n_unfinished[0] = stop_words[0] == STOP_ALL_FINISHED ? 1 : 0;          // [0] is otherwise unused: 1 = group 0's launch stopped early
+        }
     }
 }
 
@@ -3173,7 +3184,7 @@ long persist_logit_image_floats(int V1) { const long nvb = (long)LWG * logit_chu
 // ... by shape alone (what the workspace carving goes by: a switch flipped between the size query and the call must not move the carving) ...
 bool persist_sample_shape_ok(const echr_dec_args* a) {
     PersistHost& h = phost();
-    return h.ok && h.cus >= NWG && a->N >= 1 && a->A <= 2 * PSET2 && a->H == PH && a->Ha == PH && a->D <= PH && a->D % 4 == 0 && a->D >= 8 && a->S >= 1 &&
+    return h.ok && h.cus >= NWG && a->N >= 1 && a->A <= 2 * PSET2 && a->H == PH && a->Ha == PH && a->D <= PH && a->D % 4 == 0 && a->D >= 8 && a->S >= 1 && a->S <= 64 &&
            a->V1 <= LWG * LCOLS * LCHMAX && a->V1 >= 2;
 }
 // ... and with the switches that select it
@@ -3220,7 +3231,7 @@ int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream
         Bg.EVB0 = B.EVB0 + (long)n0 * 4 * PH; Bg.xws = B.xws + (long)g * sx; Bg.sws = B.sws + (long)g * ss;
         if (int rc = persist_sample_group(&p, Bg, st)) return rc;
     }
-    hipLaunchKernelGGL(sample_finish_kernel, dim3(a->N, a->S), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(B.sws + LS.key), B.sws + LS.lse, a->N, a->S,
+    hipLaunchKernelGGL(sample_finish_kernel, dim3(a->N), dim3(256), 0, st, reinterpret_cast<const unsigned long long*>(B.sws + LS.key), B.sws + LS.lse, a->N, a->S,
                        logit_chunks(a->V1), ss, B.seq, B.seq_logp, B.n_unfinished, reinterpret_cast<const u32*>(B.sws + LS.stop));
     return check_launch("sample_finish");
 }
