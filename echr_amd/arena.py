@@ -30,7 +30,10 @@ class ParamArena(object):
         self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
         self.index = {}
         self._zeroed = []
-        self.whole_zero_pass = False         # True from the moment a backward Function zero-filled the WHOLE arena until that backward pass ends
+        # id of the autograd graph task (backward pass) in which a backward Function zero-filled the WHOLE arena, None otherwise.  The flag is
+        # only trusted inside that very pass: an end-of-pass callback clears it, but callbacks do not run when a later node raises, so a
+        # stale value must never make the next pass skip its zero fill (whole_zero_pass compares with the running pass's id)
+        self._whole_zero_task = None
         self.deferred_clamp = None           # clip value of a clip_gradient call that was left to the fused step kernel (optim.ClampAdam)
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
@@ -81,8 +84,22 @@ class ParamArena(object):
             self.zero_unused_grads(keep=True)
             EF.clamp_(self.flat_g, clip)
 
+    @staticmethod
+    def _task_id():
+        tid = torch._C._current_graph_task_id()
+        return tid if tid >= 0 else None
+
+    @property
+    def whole_zero_pass(self):
+        """True while the backward pass that zero-filled the whole arena is still the one running."""
+        return self._whole_zero_task is not None and self._whole_zero_task == self._task_id()
+
+    @whole_zero_pass.setter
+    def whole_zero_pass(self, on):
+        self._whole_zero_task = self._task_id() if on else None
+
     def end_backward_pass(self):
-        self.whole_zero_pass = False
+        self._whole_zero_task = None
 
     def note_zeroed(self, lo, hi):
         """A backward Function zero-filled flat_g[lo:hi] this step (GradSink.take)."""
@@ -107,3 +124,4 @@ class ParamArena(object):
             self.flat_g[lo:hi].zero_()
         if not keep:
             self._zeroed = []
+            self._whole_zero_task = None      # (a pass that raised never ran its end-of-pass callback)

@@ -23,6 +23,9 @@
 //     exchange their local maxima through 8-byte {tag, value} granules (exact max-shifted softmax).
 // Products are exact fp32 (v_mfma_f32_16x16x4_f32).  Saved activations (GATES, CS, HS, OUTD, QS, WT, ATT) are written in the layouts
 // the backward pass and the batched projections expect, off the critical path (after the hand-off is published).
+#include <atomic>
+#include <functional>
+#include <mutex>
 #include "echr_common.h"
 #include "echr_internal.h"
 
@@ -891,6 +894,9 @@ struct PersistS {
     const float* XH1;              // its h1 exchange planes
     int V1, nch;                   // nch = ceil(V1 / 5120) column chunks
     int force_eos;                 // diagnostic (tests): > 0 = the logits of steps >= force_eos - 1 are overridden in favour of <eos> (column 0) for every event
+    int stop_early;                // 1 = leave the launch once no event of the group is unfinished.  Only when the call has ONE group: OldModel.sample breaks when
+                                   // ALL events have finished and keeps appending the raw max log-prob of finished rows until then (OldModel_NEW.py:179-183), so with
+                                   // several groups every group computes every step and the host trims at the first step nobody is unfinished at
 };
 
 // BIG: events of up to 258 segments (BASELINE config 5's 256-segment proposals).  An event's first 129 slots live in registers as before;
@@ -1663,7 +1669,7 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
             }
         }
         if (st_on) STAMP(3, 1);
-        if (t > 0) {
+        if (t > 0 && Q.stop_early) {
             // OldModel.sample's stop (:171-180): unfinished &= token > 0; when no event of the group is unfinished any more, nothing of step t
             // or later is ever emitted -- every workgroup of this role sees all 64 tokens and reaches the same verdict; the others leave
             // through their wait loops
@@ -2936,13 +2942,13 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(PersistB P2, Pe
 // ---- host side -----------------------------------------------------------------------------------------------------------
 struct PersistHost { u32* abort_dev = nullptr; u32* flag_host = nullptr; u32* flag_dev = nullptr; int cus = 0; bool ok = false; bool init = false; unsigned long long* stamps = nullptr; int stamps_S = 0;
                      hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-static PersistHost& phost() {
-    static PersistHost h;
-    if (!h.init) {
+// one state block per device, created once (std::call_once: autograd's device threads or a user thread may make the first call concurrently)
+constexpr int MAX_DEVICES = 16;
+static void phost_init(PersistHost& h, int dev) {
+    {
         h.init = true;
-        int dev = 0;
         hipDeviceProp_t prop;
-        bool good = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
+        bool good = hipGetDeviceProperties(&prop, dev) == hipSuccess;
         if (good) h.cus = prop.multiProcessorCount;
         good = good && hipMalloc(&h.abort_dev, 256) == hipSuccess && hipMemset(h.abort_dev, 0, 256) == hipSuccess;
         good = good && hipHostMalloc(&h.flag_host, 64, hipHostMallocMapped) == hipSuccess;
@@ -2966,7 +2972,14 @@ static PersistHost& phost() {
         (void)hipGetLastError();
         h.ok = good;
     }
-    return h;
+}
+static PersistHost& phost() {
+    static PersistHost hosts[MAX_DEVICES + 1];          // [MAX_DEVICES]: "no such device" (ok stays false)
+    static std::once_flag once[MAX_DEVICES];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { (void)hipGetLastError(); return hosts[MAX_DEVICES]; }
+    std::call_once(once[dev], phost_init, std::ref(hosts[dev]), dev);
+    return hosts[dev];
 }
 // the second stream of the two-launch form, created on first use only: every HIP stream of a process competes for the runtime's few
 // hardware queues (a fifth active stream made the whole iteration 2x slower on this path), and the default one-launch form needs none
@@ -3001,12 +3014,13 @@ unsigned* persist_host_flag() {
 int persist_check_async() {
     // The library's helper streams, events and the abort word (phost / tail / prep / side) are process-wide and live on the device that was
     // current at the first call: a call from another device would mix foreign-device streams and memory, so it is refused.
-    static int first_dev = -1;
+    // (the persistent kernels' own state above is per device; the helper streams of decoder.hip / tsrm.hip / sst.hip are not)
+    static std::atomic<int> first_dev{-1};
     int dev = -1;
     if (hipGetDevice(&dev) == hipSuccess) {
-        if (first_dev < 0) first_dev = dev;
-        else if (dev != first_dev) {
-            set_error("libechr_hip.so keeps per-process helper state on device %d (one process per GPU); the current device is %d", first_dev, dev);
+        int expect = -1;
+        if (!first_dev.compare_exchange_strong(expect, dev) && expect != dev) {
+            set_error("libechr_hip.so keeps per-process helper state on device %d (one process per GPU); the current device is %d", expect, dev);
             return -18;   // -EXDEV
         }
     }
@@ -3206,7 +3220,7 @@ int persist_logit_image(const float* w_logit, int V1, float* img, hipStream_t st
 
 // One launch per group of 64 events (back to back on `st`; every group has its own copy of the exchange workspaces, so ONE fill launch ahead
 // of the first and ONE finishing launch behind the last serve all of them).  B.xws / B.sws: groups x persist_sample_x_floats / _ws_floats.
-static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st);
+static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs& B, bool stop_early, hipStream_t st);
 int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st) {
     PersistHost& h = phost();
     ECHR_REQUIRE(h.ok && a->N >= 1, "persist_sample: device state unavailable");
@@ -3229,13 +3243,13 @@ int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream
         p.ev_start = a->ev_start + n0; p.ev_len = a->ev_len + n0;
         PersistSampleBufs Bg = B;
         Bg.EVB0 = B.EVB0 + (long)n0 * 4 * PH; Bg.xws = B.xws + (long)g * sx; Bg.sws = B.sws + (long)g * ss;
-        if (int rc = persist_sample_group(&p, Bg, st)) return rc;
+        if (int rc = persist_sample_group(&p, Bg, groups == 1, st)) return rc;
     }
     hipLaunchKernelGGL(sample_finish_kernel, dim3(a->N), dim3(256), 0, st, reinterpret_cast<const unsigned long long*>(B.sws + LS.key), B.sws + LS.lse, a->N, a->S,
                        logit_chunks(a->V1), ss, B.seq, B.seq_logp, B.n_unfinished, reinterpret_cast<const u32*>(B.sws + LS.stop));
     return check_launch("sample_finish");
 }
-static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st) {
+static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs& B, bool stop_early, hipStream_t st) {
     PersistHost& h = phost();
     ECHR_REQUIRE(h.ok && a->N <= PROWS, "persist_sample_group: device state unavailable");
     const PersistLayout L = persist_layout(a->S);
@@ -3281,6 +3295,7 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
     Q.LIMG = reinterpret_cast<const float4*>(B.limg);
     Q.nch = logit_chunks(a->V1);
     Q.force_eos = config().persist_sample_force_eos;
+    Q.stop_early = stop_early ? 1 : 0;
     Q.linv = B.limg + (long)LWG * Q.nch * 3 * 16 * LCT * 2 * 64 * 4 + LWG * Q.nch * LCOLS;
     Q.lbias = a->b_logit;
     Q.LSE = B.sws + LS.lse; Q.XC3 = B.sws + LS.xc3; Q.XS3 = B.sws + LS.xs3;

@@ -10,6 +10,7 @@
 // mixes its own dgo-column slice of XW -- same math, 1/G of the flops, fp32 rounding differs at 1e-7.
 #include <cmath>
 #include "echr_common.h"
+#include <atomic>
 #include "echr_internal.h"
 
 namespace echr {
@@ -542,9 +543,14 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
     const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
     if (fork) RC(aux_join(st));
     const size_t sm_rows = (size_t)N * (G + 1) * sizeof(float);
-    static bool rows_attr = false;
-    if (N >= 128 && sm_rows <= 150 * 1024) {
-        if (!rows_attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tsrm_softmax_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); rows_attr = true; }
+    // 0 = not asked yet, 1 = the device grants the row kernel's dynamic LDS, 2 = refused (then the per-(row, head) kernel serves every size)
+    static std::atomic<int> rows_attr{0};
+    if (N >= 128 && sm_rows <= 150 * 1024 && rows_attr.load(std::memory_order_relaxed) == 0) {
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(tsrm_softmax_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        rows_attr.store(ok ? 1 : 2, std::memory_order_relaxed);
+    }
+    if (N >= 128 && sm_rows <= 150 * 1024 && rows_attr.load(std::memory_order_relaxed) == 1) {
         hipLaunchKernelGGL(tsrm_softmax_rows_kernel, dim3(N), dim3(256), sm_rows, st, w.GATE, w.AFF, w.WSM, w.WD, N, G, dc);
     } else {
         hipLaunchKernelGGL(tsrm_softmax_fwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, w.WD, N, G, dc);

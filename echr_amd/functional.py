@@ -396,13 +396,15 @@ def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, de
                 tables = table_cache['tables'] = torch.empty(nt, device=dev, dtype=torch.float32)
                 table_cache['key'] = None
             valid = 1 if table_cache.get('key') == key else 0
-            table_cache['key'] = key
+            table_cache['key'] = None      # marked valid again only once this call has completed without an error
     sa = L.SampleArgs(a, seq_length, L.ptr(seq, torch.int64), L.ptr(slp), L.ptr(nun, torch.int32), L.ptr(wss),
                       1 if multinomial else 0, float(temperature), int(seed) & 0xFFFFFFFFFFFFFFFF,
                       L.ptr(tables) if tables is not None else None, valid)
     L.check(lib.echr_decoder_sample(C.byref(sa), L.stream_ptr()), 'decoder_sample')
     counts = nun.cpu().numpy()                 # the only device->host sync of the whole decode
     L.check(lib.echr_check_async(), 'decoder_sample')
+    if tables is not None:
+        table_cache['key'] = key
     if debug is not None:                      # tests: the raw logits [N,V1] of the last decoder step (sampler workspace: XT | LOGITS | ...)
         E, V1 = ps[0].shape[1], ps[0].shape[0]
         o = (N * E + 63) // 64 * 64

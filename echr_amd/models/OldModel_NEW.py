@@ -122,6 +122,28 @@ class OldModel(nn.Module):
         self.__dict__['_native_params'] = self._native_params_now()          # Parameter OBJECTS are stable (.data may move into an arena)
         return self.__dict__['_native_params']
 
+    def invalidate_native_caches(self):
+        """Forget the cached Parameter tuple and the greedy decoder's parameter-derived tables.  Called by everything of nn.Module that can
+        REPLACE Parameter objects or rewrite their storage behind torch's version counters (`_apply`: .to / .cuda / to_empty; load_state_dict,
+        also with assign=True; pickling).  Code that re-assigns a sub-module's Parameter by hand (weight tying, pruning) or writes through
+        `.data` must call it too."""
+        self.__dict__.pop('_native_params', None)
+        self.__dict__.pop('_sample_tables', None)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_native_caches()
+        return super(OldModel, self)._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_native_caches()
+        return super(OldModel, self)._load_from_state_dict(*args, **kwargs)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)          # the caches hold Parameter references / a large device tensor: neither belongs in a pickle or a deepcopy
+        d.pop('_native_params', None)
+        d.pop('_sample_tables', None)
+        return d
+
     def _native_params_now(self):
         c = self.core
         a = c.attention
@@ -201,7 +223,7 @@ class OldModel(nn.Module):
             self._sample_calls = getattr(self, '_sample_calls', 0) + 1
             seed = (self._drop_seed * 0x9E3779B97F4A7C15 + self._sample_calls) & 0xFFFFFFFFFFFFFFFF
         with torch.no_grad():
-            if not hasattr(self, '_sample_tables'):
+            if '_sample_tables' not in self.__dict__:
                 self._sample_tables = {}          # decoding operands derived from the parameters alone, reused across calls (EF.greedy_sample)
             return EF.greedy_sample(video, event, cv.feats, cv.ev_start, cv.ev_len, cv.max_len, self.seq_length,
                                     self.native_params(), multinomial=multinomial, temperature=float(opt.get('temperature', 1.0)),

@@ -114,6 +114,7 @@ class ClampAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         if self.arena is not None:
             self.arena.deferred_clamp = None
+            self.arena.end_backward_pass()
         return super(ClampAdam, self).zero_grad(set_to_none)
 
     @torch.no_grad()

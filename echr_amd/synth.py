@@ -190,3 +190,27 @@ def make_case(name, param_seed=0):
     vid = make_video(V1=opt.CG_vocab_size + 1, video_dim=opt.video_dim, hidden_dim=opt.hidden_dim,
                      lda_dim=opt.lda_dim, **c['video'])
     return opt, make_params(opt, param_seed), vid
+
+
+# Greedy-decoding cases whose captions END AT DIFFERENT STEPS (OldModel_NEW.py:171-183: per-row `unfinished` state).  With the plain
+# synthetic initialisation a caption ends at its first word or never; here the token embedding is scaled up (the recurrences become
+# token-driven, so the <eos> margin moves from step to step) and the <eos> row of the logit layer is widened.  The event lists of the
+# fixtures (tests/golden/case_eosmix.npz: `soi`, `ind`) are selections / re-orderings of the video made here, chosen by
+# tools/make_golden.py from the reference's own decode: 'b' puts the 64 earliest-finishing events first (one 64-event group is done
+# long before the others), 'c' keeps only events that finish (the whole batch stops before seq_length).
+EOSMIX = {
+    'a': dict(N=64, seed=109, eos_scale=2.0),
+    'b': dict(N=150, seed=322, eos_scale=2.5),
+    'c': dict(N=150, seed=322, eos_scale=2.5),
+}
+
+
+def make_eosmix(name, A=24, embed_scale=10.0):
+    """(opt, params, video) of a mixed-finish decoding case at the ECHR widths (V1 = 5001, seq_length 19)."""
+    c = EOSMIX[name]
+    opt = default_opt(vocab_size=5000, seq_length=19)
+    params = make_params(opt, 0)
+    params['lm_model.embed.weight'] = (params['lm_model.embed.weight'] * np.float32(embed_scale)).astype(np.float32)
+    params['lm_model.logit.weight'][0] *= np.float32(c['eos_scale'])
+    vid = make_video(c['N'], A, 21, 5001, seed=c['seed'], T_v=4 * A)
+    return opt, params, vid

@@ -59,6 +59,19 @@ def test_greedy_sample(case):
     assert np.abs(lp.numpy() - g['sample|logp']).max() < 1e-5
 
 
+@pytest.mark.parametrize('name', ['a', 'b', 'c'])
+def test_greedy_sample_mixed_finish(name):
+    """Events that emit <eos> at different steps (OldModel_NEW.py:171-183): the oracle against the reference's seq / seqLogprobs."""
+    opt, params, vid = synth.make_eosmix(name)
+    g = U.gold('case_eosmix.npz')
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        seq, lp = O.caption_forward(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), None,
+                                    g[name + '|ind'], g[name + '|soi'], 'eval', None, opt.n_head, opt.CG_seq_length)
+    assert np.array_equal(seq.numpy(), g[name + '|seq']) and (g[name + '|seq'] == 0).any()
+    assert np.abs(lp.numpy() - g[name + '|logp']).max() < 1e-5
+
+
 def test_adam_restatement():
     g = U.gold('adam.npz')
     p, m, v = g['p0'].copy(), np.zeros_like(g['p0']), np.zeros_like(g['p0'])

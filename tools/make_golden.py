@@ -254,6 +254,86 @@ def do_c5():
     print('  wrote case_c5.npz (%d arrays)' % len(out))
 
 
+def do_eosmix():
+    """Greedy decoding where events finish at DIFFERENT steps (OldModel_NEW.py:171-183): the reference's own `seq` / `seqLogprobs` on
+    synth.make_eosmix inputs.  The event lists are chosen here from the reference's decode and stored in the fixture."""
+    import io
+    import contextlib
+    out = {}
+
+    def decode(m, vid, soi, ind):
+        tap, c3d, lda = (torch.from_numpy(vid[k]) for k in ('tap', 'c3d', 'lda'))
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            return m(tap, c3d, lda, [], ind, soi.tolist(), mode='eval')
+
+    def raw_decode(m, vid, soi, ind, S):
+        """The un-masked arg-max chain of every row over all S+1 steps (what the network consumes, :158,171) + top-1/top-2 margins."""
+        tap, c3d, lda = (torch.from_numpy(vid[k]) for k in ('tap', 'c3d', 'lda'))
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            video = m.get_video_context(tap, c3d, lda, ind, soi.tolist())
+            event = m.get_event_context(tap, c3d, lda, ind, soi.tolist())
+            clip, mask = m.get_clip_context(tap, c3d, lda, ind, soi.tolist())
+            lm = m.lm_model
+            state = lm.init_hidden(video, event, clip)
+            it = torch.zeros(len(soi), dtype=torch.long)
+            toks, margins = [], []
+            for t in range(S + 1):
+                lp, state = lm.get_logprobs_state(it, video, event, clip, mask, state)
+                top = lp.topk(2, dim=1)
+                it = top.indices[:, 0]
+                toks.append(it.numpy())
+                margins.append((top.values[:, 0] - top.values[:, 1]).numpy())
+        return np.stack(toks, 1), np.stack(margins, 1)
+
+    for name in ('a', 'b', 'c'):
+        opt, params, vid = synth.make_eosmix(name)
+        m = build_ref(opt, params)
+        m.eval()
+        soi, ind = vid['soi'], vid['ind']
+        S = opt.CG_seq_length
+        if name in ('b', 'c'):
+            toks, _ = raw_decode(m, vid, soi, ind, S)
+            fin = np.array([(np.nonzero(r == 0)[0][0] if (r == 0).any() else 99) for r in toks])
+            order = np.argsort(fin, kind='stable')
+            if name == 'b':          # the 64 earliest finishers first, the rest in their original order
+                first = order[:64]
+                rest = np.array([i for i in range(len(soi)) if i not in set(first.tolist())])
+                sel = np.concatenate([first, rest])
+            else:                    # only events that finish, re-checked below on the smaller batch (the event encoder sees the set)
+                sel = order[:48]
+            soi, ind = soi[sel], ind[sel]
+        toks, margins = raw_decode(m, vid, soi, ind, S)
+        fin = np.array([(np.nonzero(r == 0)[0][0] if (r == 0).any() else 99) for r in toks])
+        seq, slp = decode(m, vid, soi, ind)
+        P = {k: torch.from_numpy(v) for k, v in params.items()}
+        with torch.no_grad():
+            oseq, oslp = O.caption_forward(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), None,
+                                           ind, soi, 'eval', None, opt.n_head, S)
+        assert torch.equal(seq, oseq), 'oracle greedy seq differs'
+        assert float((slp - oslp).abs().max()) < 2e-5
+        T = seq.shape[1]
+        nz = seq.numpy() == 0
+        print('[eosmix/%s] N %d seq %s | finish steps: %d distinct, never %d, min margin %.2e | zeros %d | oracle max|dlogp| %.2e'
+              % (name, len(soi), tuple(seq.shape), len(set(fin.tolist())), int((fin == 99).sum()), margins[:, :T + 1].min(), int(nz.sum()),
+                 float((slp - oslp).abs().max())))
+        assert len(set(fin.tolist())) >= 3 and margins[:, :T + 1].min() > 2e-5
+        if name == 'a':
+            assert (fin == 99).any() and T == S
+        if name == 'b':
+            g0 = fin[:64].max()
+            print('   group 0 done after step %d, groups 1/2 run to %d' % (g0, T))
+            assert g0 + 3 < T and (fin[64:] == 99).any()
+        if name == 'c':
+            assert (fin < 99).all() and T < S, (fin, T)
+        out[name + '|soi'] = soi.astype(np.int64)
+        out[name + '|ind'] = ind.astype(np.int64)
+        out[name + '|seq'] = seq.numpy().astype(np.int64)
+        out[name + '|logp'] = slp.numpy()
+        out[name + '|min_margin'] = np.float64(margins[:, :T + 1].min())
+    np.savez_compressed(os.path.join(GOLD, 'case_eosmix.npz'), **out)
+    print('wrote case_eosmix.npz')
+
+
 def do_position():
     RefMA = models.MA_Attention8
     out = {}
@@ -410,12 +490,12 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', nargs='*', default=['tiny', 'c1', 'c2', 'c2full', 'c3bench'])
     ap.add_argument('--skip-aux', action='store_true')
-    ap.add_argument('--only', choices=['position', 'adam', 'proposals', 'checkpoint', 'sst', 'c5'], help='regenerate one auxiliary fixture only')
+    ap.add_argument('--only', choices=['position', 'adam', 'proposals', 'checkpoint', 'sst', 'c5', 'eosmix'], help='regenerate one auxiliary fixture only')
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     if a.only:
-        {'position': do_position, 'adam': do_adam, 'proposals': do_proposals, 'checkpoint': do_checkpoint, 'sst': do_sst, 'c5': do_c5}[a.only]()
+        {'position': do_position, 'adam': do_adam, 'proposals': do_proposals, 'checkpoint': do_checkpoint, 'sst': do_sst, 'c5': do_c5, 'eosmix': do_eosmix}[a.only]()
         sys.exit(0)
     if not a.skip_aux:
         do_position()
@@ -424,5 +504,6 @@ if __name__ == '__main__':
         do_checkpoint()
         do_sst()
         do_c5()
+        do_eosmix()
     for c in a.cases:
         do_case(c)
