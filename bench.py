@@ -101,11 +101,28 @@ def gpu_leg(args, rank, world, local_rank):
             pred = model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
             return crit(pred, tgt, msk)
 
+    # the whole iteration as ONE library call (echr_train_step: include/echr_hip.h, echr_amd/fused.py) instead of ~75 ctypes calls and four
+    # autograd nodes; single-process default.  With several ranks the autograd path keeps the staged early all-reduce, unless --fused asks
+    # for the one-call form there too (backward inside the call, then ONE collective, then clip + step)
+    fused = None
+    want_fused = args.fused == 'on' or (args.fused == 'auto' and not use_dist)
+    if want_fused and arena is not None and not args.c5 and args.mode == 'train':
+        from echr_amd.fused import FusedTrainStep
+        fused = FusedTrainStep(model, optim, grad_clip=opt.grad_clip)
+
     def iteration():
         if args.c5:
             return c5_iteration()
         if args.mode == 'fwd':
             return fwd_only()
+        if fused is not None:
+            if not use_dist:
+                return fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk)
+            loss = fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, step=False)
+            parallel.allreduce_gradients(model, force=True)
+            clip_gradient(optim, opt.grad_clip)
+            optim.step()
+            return loss
         optim.zero_grad()
         pred = model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
         loss = crit(pred, tgt, msk)
@@ -272,7 +289,8 @@ def gpu_leg(args, rank, world, local_rank):
         # MFMA-bound kernels: 157.3 TF (native fp32 MFMA: gemm_f32, rec_gemm), 2500/3 TF (gemm_h2: three fp16 MFMA products per
         # fp32-grade product), 2500/6 TF (gemm_split: six bf16 products).
         roof['other_kernels'] = {k: line(k) for k in stats if k != dom and line(k) is not None}
-    return dt, final_loss, roof, native
+    host_path = 'echr_train_step (one library call per iteration)' if fused is not None else 'autograd Functions (one ctypes call per fused region)'
+    return dt, final_loss, roof, native, host_path
 
 
 def cpu_model_name():
@@ -407,6 +425,8 @@ def main():
     ap.add_argument('--c5', action='store_true', help='BASELINE config 5: SST proposal encoder over a 256-segment video + caption '
                     'path with proposals of up to 256 segments, joint fwd+bwd+Adam (extra line; the headline metric is the default)')
     ap.add_argument('--no-arena', action='store_true', help='per-tensor gradients/optimiser instead of the flat arena')
+    ap.add_argument('--fused', choices=['auto', 'on', 'off'], default=os.environ.get('ECHR_BENCH_FUSED', 'auto'),
+                    help='one echr_train_step call per iteration instead of the autograd path (auto: on for one process, off with several ranks)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-native', action='store_true', help='skip the second timed figure on the native fp32 MFMA path')
@@ -443,16 +463,25 @@ def main():
     if world != args.gpus:
         sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus %d`, which launches the ranks itself, or under '
                  'torch.distributed.run --nproc-per-node %d)' % (args.gpus, world, args.gpus, args.gpus))
+    dp_info = {}
     if world > 1:
         # several ranks may share CUs with collective kernels (and, in the one-GPU rehearsal, with each other): the persistent recurrences
         # are launched cooperatively, so a grid only starts once all of its workgroups can be resident
+        # -- but only where something else CAN hold CUs while a persistent pair runs: ranks sharing one device (the rehearsal).  With one
+        # device per rank every collective of an iteration is behind the reverse recurrence (EarlyReducer: `defer_first`, hand-over after
+        # the recurrence) and is waited for before clamp + Adam, i.e. before the next forward pair in stream order, so no collective
+        # kernel is ever resident beside a pair and the plain launch (25 us per pair cheaper) is safe.
         from echr_amd import _lib
-        _lib.load().echr_config_set(b'persist_coop', int(os.environ.get('ECHR_PERSIST_COOP', '1')))
+        shared_device = os.environ.get('ECHR_BENCH_ONE_GPU') == '1'
+        coop = int(os.environ.get('ECHR_PERSIST_COOP', '1' if shared_device or os.environ.get('ECHR_DP_DEFER_FIRST', '1') == '0' else '0'))
+        _lib.load().echr_config_set(b'persist_coop', coop)
+        dp_info.update(persist_coop=coop, dp_algo=__import__('echr_amd.parallel', fromlist=['choose_algo']).choose_algo(world),
+                       dp_overlap=os.environ.get('ECHR_DP_OVERLAP', '1') != '0' and args.fused != 'on')
         if os.environ.get('ECHR_BENCH_ONE_GPU') == '1' and os.environ.get('ECHR_BENCH_PERSIST', '0') == '0':
             # rehearsal with every rank on ONE device: two 256-workgroup persistent grids must not share it -> launch-per-phase recurrences
             _lib.load().echr_config_set(b'persist', 0)
             _lib.load().echr_config_set(b'persist_bwd', 0)
-    dt, loss, roof, native = gpu_leg(args, rank, world, local_rank)
+    dt, loss, roof, native, host_path = gpu_leg(args, rank, world, local_rank)
     if rank == 0:
         value = args.steps * S_STEPS * world / dt
         workload = '%s: %d events x %d seg x 500-d C3D (%s), S=%d decoder timesteps, V1=%d, %s, one video per GPU' % (
@@ -471,8 +500,10 @@ def main():
             'data': 'synthetic',
             'config': {'workload': workload,
                        'global_events': N_EV * world, 'timesteps_per_step': S_STEPS, 'parallelism': 'dp%d' % world,
-                       'final_loss': round(loss, 5)},
+                       'final_loss': round(loss, 5),
+                       'host_path': host_path},
         }
+        out['config'].update(dp_info)
         if native is not None:
             out['native_f32'] = native
         if roof is not None:

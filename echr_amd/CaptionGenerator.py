@@ -29,6 +29,10 @@ class CaptionGenerator(nn.Module):
             raise NotImplementedError('the HIP path implements the ECHR recipe: video_context_type=VL, event_context_type=ER3, '
                                       'clip_context_type=CC (experiments/train_ECHR.sh)')
 
+    def _require_live_decoder(self):
+        if type(self.lm_model).__name__ != 'ThreestreamModel':
+            self.lm_model.forward()          # raises: parameter-container decoders (show_attend_tell) never run
+
     def build_arena(self):
         """Pack parameters and gradients into flat device buffers (echr_amd/arena.py).  Call after .cuda(); enables the
         single-launch fused optimiser step and the single-bucket gradient all-reduce."""
@@ -47,6 +51,7 @@ class CaptionGenerator(nn.Module):
     def forward(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, mode='train'):
         if mode not in ('train', 'eval'):
             raise NotImplementedError("mode=%r: only 'train' and 'eval' are live in the reference as shipped (SURVEY section 2 row 12)" % (mode,))
+        self._require_live_decoder()
         if not c3d_feats.is_cuda:
             raise EF.L.EchrHipError('CaptionGenerator runs on the GPU only: move the module and its inputs with .cuda()')
         ev = EF.event_index_tensors(soi_select_list, ind_select_list, c3d_feats.device, min(c3d_feats.shape[0], tap_feats.shape[0]))

@@ -77,9 +77,20 @@ class SampleArgs(C.Structure):
                 ('tables', c_f), ('tables_valid', i32)]
 
 
+class TrainStepArgs(C.Structure):
+    _fields_ = [('tsrm', TsrmArgs), ('tsrm_g', TsrmGrads), ('dec', DecArgs), ('dec_g', DecGrads), ('drop', Dropout),
+                ('tap', c_f), ('Ht', i32), ('g_tap', c_f), ('host_index', C.c_void_p),
+                ('nll_target', c_f), ('nll_target_i64', i32), ('nll_mask', c_f), ('g_loss', c_f), ('loss', c_f),
+                ('ws', c_f), ('ws_floats', i64), ('flat_g', c_f), ('n_flat', i64),
+                ('flat_p', c_f), ('adam_m', c_f), ('adam_v', c_f), ('adam_step', i32),
+                ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('clip', f32),
+                ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32)]
+
+
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ('echr_version', i32, []),
+    ('echr_abi_sizeof', i64, [C.c_char_p]),
     ('echr_last_error', C.c_char_p, []),
     ('echr_check_async', i32, []),
     ('echr_gemm_f32', i32, [C.POINTER(GemmDesc), C.c_void_p]),
@@ -122,9 +133,15 @@ SYMBOLS = [
     ('echr_h2_pack', i32, [c_f, i32, i32, i64, i64, C.c_void_p, C.c_void_p]),
     ('echr_top_proposals', i32, [c_f, c_f, i32, i32, i32, f32, c_f, c_f, c_f, c_f, C.c_void_p]),
     ('echr_top_proposals_nms', i32, [c_f, i32, i32, i32, C.c_double, c_f, c_f, c_f, c_f, C.c_void_p]),
+    ('echr_train_step_ws_floats', i64, [C.POINTER(TrainStepArgs)]),
+    ('echr_train_step', i32, [C.POINTER(TrainStepArgs), C.c_void_p]),
     ('echr_clamp', i32, [c_f, i64, f32, C.c_void_p]),
     ('echr_clamp_adam', i32, [c_f, c_f, c_f, c_f, i64, i32, C.c_double, C.c_double, C.c_double, C.c_double, f32, C.c_void_p]),
 ]
+
+ABI_STRUCTS = {'echr_gemm_desc': GemmDesc, 'echr_dropout': Dropout, 'echr_tsrm_args': TsrmArgs, 'echr_tsrm_grads': TsrmGrads,
+               'echr_dec_args': DecArgs, 'echr_dec_grads': DecGrads, 'echr_sample_args': SampleArgs, 'echr_sst_args': SstArgs,
+               'echr_sst_grads': SstGrads, 'echr_train_step_args': TrainStepArgs}
 
 _lib = None
 
@@ -148,6 +165,10 @@ def load():
         fn.argtypes = args
     if lib.echr_version() != 1:
         raise EchrHipError('libechr_hip.so ABI version %d != 1' % lib.echr_version())
+    for cname, cls in ABI_STRUCTS.items():      # the ctypes restatement of every argument struct against the library's own sizeof
+        if lib.echr_abi_sizeof(cname.encode()) != C.sizeof(cls):
+            raise EchrHipError('%s: ctypes layout is %d bytes, libechr_hip.so says %d -- rebuild the library (python __graft_entry__.py build)'
+                               % (cname, C.sizeof(cls), lib.echr_abi_sizeof(cname.encode())))
     _lib = lib
     return lib
 

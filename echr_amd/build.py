@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libechr_hip.so')
-SOURCES = ['gemm.hip', 'core.hip', 'decoder.hip', 'persist.hip', 'tsrm.hip', 'sst.hip', 'proposals.hip']
+SOURCES = ['gemm.hip', 'core.hip', 'decoder.hip', 'persist.hip', 'tsrm.hip', 'sst.hip', 'proposals.hip', 'step.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function']
 
 

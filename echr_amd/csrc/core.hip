@@ -791,6 +791,14 @@ int greedy_step(float* logits, long ld, int N, int V1, int t, int seq_len, int* 
 using namespace echr;
 
 extern "C" int echr_version(void) { return ECHR_ABI_VERSION; }
+extern "C" int64_t echr_abi_sizeof(const char* name) {
+    if (!name) return -1;
+#define ECHR_SZ(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T)
+    ECHR_SZ(echr_gemm_desc); ECHR_SZ(echr_dropout); ECHR_SZ(echr_tsrm_args); ECHR_SZ(echr_tsrm_grads); ECHR_SZ(echr_dec_args); ECHR_SZ(echr_dec_grads);
+    ECHR_SZ(echr_sample_args); ECHR_SZ(echr_sst_args); ECHR_SZ(echr_sst_grads); ECHR_SZ(echr_train_step_args);
+#undef ECHR_SZ
+    return -1;
+}
 extern "C" const char* echr_last_error(void) { return g_err; }
 
 extern "C" int echr_event_pool_gather_fwd(const float* c3d, const float* tap, const int32_t* ev_start, const int32_t* ev_len,

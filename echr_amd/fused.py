@@ -1,0 +1,179 @@
+"""One training iteration of the caption path as ONE library call (echr_train_step, include/echr_hip.h).
+
+Reference protocol (train.py:281-317, m_batch = 1):
+    optimizer.zero_grad(); pred = cg_model(tap_feats, c3d_feats, lda_feats, labels, ind, soi, mode='train')
+    loss = crit(pred, labels[:, 1:], masks[:, 1:]); loss.backward(); clip_gradient(optimizer, c); optimizer.step()
+`FusedTrainStep(model, optimizer)(...)` is that sequence without autograd: Python fills one argument struct (pointers are stable: flat
+parameter / gradient arena, one persistent workspace), packs the index vectors, and makes ONE ctypes call; the library sequences the
+same entry points the autograd Functions of echr_amd/functional.py call.  The autograd path stays the general one (gradient
+accumulation, other consumers of the log-probs, joint training of the proposal encoder, hooks); both produce the same update
+(tests/test_gpu_parity.py::test_fused_train_step_equals_autograd_path).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import functional as EF
+from .models.OldModel_NEW import n_decoder_steps
+from .optim import ClampAdam
+
+
+class FusedTrainStep(object):
+    LOSS_SLOTS = 16
+
+    def __init__(self, model, optimizer, grad_clip=None):
+        if not isinstance(optimizer, ClampAdam) or optimizer.arena is None:
+            raise ValueError('FusedTrainStep needs echr_amd.optim.ClampAdam built with the flat arena (model.build_arena())')
+        arena = optimizer.arena
+        if getattr(model, '_echr_arena', None) is not arena or not arena.params_in_arena():
+            raise ValueError('the optimiser\'s arena is not the model\'s (call model.build_arena() after .cuda(), pass it to ClampAdam)')
+        if not hasattr(model, 'fusion_model'):
+            raise NotImplementedError('the fused step implements the ECHR recipe (event_context_type ER3 + TSRM8)')
+        if len(optimizer.param_groups) != 1 or {id(p) for p in optimizer.param_groups[0]['params']} != {id(p) for p in arena.params}:
+            raise ValueError('the optimiser must hold exactly the model\'s parameters in one group')
+        self.model, self.optim, self.arena = model, optimizer, arena
+        self.grad_clip = grad_clip if grad_clip is not None else optimizer.grad_clip
+        self.lib = L.load()
+        self.dev = arena.flat_p.device
+        self.a = L.TrainStepArgs()
+        self.ws = None
+        self.one = torch.ones(1, device=self.dev, dtype=torch.float32)
+        self.loss_ring = torch.zeros(self.LOSS_SLOTS, 2, device=self.dev, dtype=torch.float32)
+        self.calls = 0
+        self._fill_static()
+
+    # ---- pointers that never change: parameters and their gradient slots ------------------------------------------------------
+    def _fill_static(self):
+        a, m, ar = self.a, self.model, self.arena
+        gp = lambda p: ar.flat_g.data_ptr() + 4 * ar.offsets[ar.slot(p)]
+        lm, fm = m.lm_model, m.fusion_model
+        tp = fm.native_params()
+        tsrm_params = (fm.event_emb.weight, fm.event_emb.bias, fm.enc_attn.pair_pos_fc1.weight, fm.enc_attn.pair_pos_fc1.bias,
+                       fm.enc_attn.pair_pos_fc2.weight, fm.enc_attn.pair_pos_fc2.bias, fm.enc_attn.query_1.weight, fm.enc_attn.query_1.bias,
+                       fm.enc_attn.key_1.weight, fm.enc_attn.key_1.bias, fm.enc_attn.linear_out_1.weight, fm.enc_attn.linear_out_1.bias)
+        for name, p, v in zip(EF.TSRM_PARAMS, tsrm_params, tp):
+            setattr(a.tsrm, name, L.ptr(v))
+            setattr(a.tsrm_g, 'g_' + name, gp(p))
+        a.tsrm.Din, a.tsrm.Df, a.tsrm.Do, a.tsrm.G = tp[0].shape[1], tp[0].shape[0], tp[10].shape[0], fm.enc_attn.group
+        ps = lm.native_params()
+        (embed, w_logit, b_logit, wi0, wi1, wi2, wh0, wh1, wh2, bi0, bi1, bi2, bh0, bh1, bh2, w_c2a, b_c2a, w_h2a, b_h2a, w_alpha, b_alpha) = ps
+        d, g = a.dec, a.dec_g
+        d.embed, d.w_logit, d.b_logit = L.ptr(embed), L.ptr(w_logit), L.ptr(b_logit)
+        d.w_ih, d.w_hh = L.ptr3((wi0, wi1, wi2), 'w_ih'), L.ptr3((wh0, wh1, wh2), 'w_hh')
+        d.b_ih, d.b_hh = L.ptr3((bi0, bi1, bi2), 'b_ih'), L.ptr3((bh0, bh1, bh2), 'b_hh')
+        d.w_c2a, d.b_c2a, d.w_h2a, d.b_h2a, d.w_alpha, d.b_alpha = (L.ptr(x) for x in (w_c2a, b_c2a, w_h2a, b_h2a, w_alpha, b_alpha))
+        g.g_embed, g.g_w_logit, g.g_b_logit = gp(embed), gp(w_logit), gp(b_logit)
+        g.g_w_ih = (L.c_f * 3)(gp(wi0), gp(wi1), gp(wi2))
+        g.g_w_hh = (L.c_f * 3)(gp(wh0), gp(wh1), gp(wh2))
+        g.g_b_ih = (L.c_f * 3)(gp(bi0), gp(bi1), gp(bi2))
+        g.g_b_hh = (L.c_f * 3)(gp(bh0), gp(bh1), gp(bh2))
+        g.g_w_c2a, g.g_b_c2a, g.g_w_h2a, g.g_b_h2a, g.g_w_alpha, g.g_b_alpha = (gp(x) for x in (w_c2a, b_c2a, w_h2a, b_h2a, w_alpha, b_alpha))
+        d.H, d.E, d.Ha, d.V1 = wh0.shape[1], embed.shape[1], w_c2a.shape[0], embed.shape[0]
+        d.D = w_c2a.shape[1]
+        d.De, d.Dv = wi0.shape[1] - d.E, wi2.shape[1] - d.E
+        if wi1.shape[1] != d.E + d.D or a.tsrm.Do != d.De:
+            raise ValueError('LSTM input widths do not match the contexts')
+        a.flat_g, a.n_flat, a.flat_p = ar.flat_g.data_ptr(), ar.total, ar.flat_p.data_ptr()
+        a.g_loss = self.one.data_ptr()
+        self._keep = (tp, ps)          # (fusion_model.native_params() builds a view of linear_out_1.weight: keep it alive)
+        self._epoch_ptrs = (ar.flat_p.data_ptr(), ar.flat_g.data_ptr())
+
+    def _flat_state(self):
+        o = self.optim
+        if o._flat is None:
+            if any(o.state[p] for p in self.arena.params):
+                raise RuntimeError('per-tensor optimiser state exists (resumed run on the per-tensor path): load it with ClampAdam.load_state_dict '
+                                   'on an arena optimiser, or use the autograd path')
+            o._flat = dict(step=0, m=torch.zeros_like(self.arena.flat_p), v=torch.zeros_like(self.arena.flat_p))
+        return o._flat
+
+    def __call__(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step=True, forward_only=False):
+        """One iteration; returns the loss as a 0-d device tensor (no host sync).  `targets` / `masks`: what the reference hands its
+        criterion (labels[:, 1:], masks[:, 1:]), host or device tensors.  step=False stops after the backward pass and exposes the
+        gradients as `.grad` views of the arena (data-parallel reduce, inspection); the caller then steps the optimiser itself."""
+        a, m, ar, lib = self.a, self.model, self.arena, self.lib
+        if not c3d_feats.is_cuda:
+            raise L.EchrHipError('FusedTrainStep runs on the GPU only')
+        if (ar.flat_p.data_ptr(), ar.flat_g.data_ptr()) != self._epoch_ptrs or not ar.params_in_arena():
+            raise RuntimeError('the parameter arena moved since this FusedTrainStep was built')
+        soi = np.asarray(soi_select_list, dtype=np.int64).reshape(-1, 2)
+        ind = np.asarray(ind_select_list, dtype=np.int64).reshape(-1)
+        lens = soi[:, 1] - soi[:, 0]
+        N = len(soi)
+        Tv = min(c3d_feats.shape[0], tap_feats.shape[0])
+        if N == 0 or lens.min() <= 0:
+            raise ValueError('every event needs at least one segment (soi=%s)' % (soi.tolist(),))
+        if len(ind) != N:
+            raise ValueError('ind_select_list and soi_select_list differ in length (%d vs %d)' % (len(ind), N))
+        if soi.min() < 0 or soi[:, 1].max() > Tv or ind.min() < 0 or ind.max() >= Tv:
+            raise ValueError('event intervals / anchors fall outside the %d feature rows' % Tv)
+        labels = lm_labels.numpy() if isinstance(lm_labels, torch.Tensor) and not lm_labels.is_cuda else np.asarray(lm_labels.cpu() if isinstance(lm_labels, torch.Tensor) else lm_labels)
+        S = n_decoder_steps(labels)
+        if S == 0:
+            raise ValueError('label tensor needs at least two columns')
+        if labels.shape[0] != N:
+            raise ValueError('labels have %d rows for %d events' % (labels.shape[0], N))
+        host = np.empty((3 + S) * N, dtype=np.int32)
+        host[:N], host[N:2 * N], host[2 * N:3 * N] = soi[:, 0], lens, ind
+        host[3 * N:] = labels[:, :S].T.reshape(-1)
+        c3d, tap, lda = EF._f32c(c3d_feats), EF._f32c(tap_feats), EF._f32c(lda_feats)
+        tgt = targets if targets.is_cuda else EF.upload(targets, self.dev)
+        msk = masks if masks.is_cuda else EF.upload(masks, self.dev)
+        tgt = EF._nll_target(tgt, S)
+        msk = msk[:, :S].to(torch.float32).contiguous()
+        d = a.dec
+        a.tsrm.N = d.N = N
+        d.A, d.Tv, d.S, d.rows_disjoint = int(lens.max()), c3d.shape[0], S, 1 if EF.rows_disjoint(soi) else 0
+        if c3d.shape[1] != d.D or lda.numel() != d.Dv or tap.shape[1] + d.D != a.tsrm.Din:
+            raise L.EchrHipError('feature widths do not match the model (c3d %d, lda %d, tap %d)' % (c3d.shape[1], lda.numel(), tap.shape[1]))
+        d.c3d, d.video, a.tap, a.Ht = c3d.data_ptr(), lda.data_ptr(), tap.data_ptr(), tap.shape[1]
+        a.host_index = host.ctypes.data
+        a.nll_target, a.nll_target_i64, a.nll_mask = tgt.data_ptr(), 1 if tgt.dtype == torch.int64 else 0, msk.data_ptr()
+        drop = m.lm_model.next_drop_state(m.fusion_model.enc_attn.dropout.p)
+        drop.training = m.training
+        a.drop = drop.c()
+        need = lib.echr_train_step_ws_floats(C.byref(a))
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = None                     # (released in stream order by the caching allocator)
+            self.ws = torch.empty(need, device=self.dev, dtype=torch.float32)
+        a.ws, a.ws_floats = self.ws.data_ptr(), self.ws.numel()
+        slot = self.loss_ring[self.calls % self.LOSS_SLOTS]
+        self.calls += 1
+        a.loss = slot.data_ptr()
+        a.overlap_encoder = 1 if m.overlap_encoder else 0
+        a.forward_only = 1 if forward_only else 0
+        a.do_step = 1 if (step and not forward_only) else 0
+        o = self.optim
+        if not forward_only:
+            for p in ar.params:                # the arena is rewritten from scratch: stale .grad views must not survive as "accumulated" gradients
+                if p.grad is not None:
+                    p.grad = None
+            ar.deferred_clamp = None
+            ar.end_backward_pass()
+        if a.do_step:
+            st = self._flat_state()
+            group = o.param_groups[0]
+            clip = o.pending_clip if o.pending_clip is not None else self.grad_clip
+            o.pending_clip = None
+            a.adam_m, a.adam_v, a.adam_step = st['m'].data_ptr(), st['v'].data_ptr(), st['step'] + 1
+            a.lr, (a.beta1, a.beta2), a.eps = group['lr'], group['betas'], group['eps']
+            a.clip = float('inf') if clip is None else float(clip)
+        L.check(lib.echr_train_step(C.byref(a), L.stream_ptr()), 'train_step')
+        if a.do_step:
+            st['step'] += 1
+            EF.PARAM_EPOCH[0] += 1
+            ar._zeroed = []
+        elif not forward_only:
+            # gradients are final in stream order: expose them the way the autograd path does (views of the arena); never-used
+            # parameters keep .grad None (their slots are zero)
+            unused = getattr(self, '_unused', None)
+            if unused is None:
+                unused = self._unused = {id(p) for p in list(m.lm_model.core.fusion_layer.parameters()) + list(m.fusion_model.h2a_layer.parameters())}
+            for i, p in enumerate(ar.params):
+                if id(p) not in unused:
+                    p.grad = ar.grad_view(i)
+            ar._zeroed = [(0, ar.total)]
+        return slot[0]

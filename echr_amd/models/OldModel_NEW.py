@@ -277,6 +277,59 @@ class ThreestreamModel(OldModel):
         self.core = ThreeStream_Core(opt)
 
 
+class ShowAttendTellCore(nn.Module):
+    """Parameter container with the reference's layout (OldModel_NEW.py:190-216): nn.LSTM(E + input_dim, H, num_layers, bias=False) +
+    the additive-attention projections.  No arithmetic: see ShowAttendTellModel."""
+
+    def __init__(self, opt):
+        super(ShowAttendTellCore, self).__init__()
+        self.opt = opt
+        t = opt.CG_input_feats_type
+        self.CG_input_dim = (opt.video_context_dim if 'V' in t else 0) + (opt.event_context_dim if 'E' in t else 0) + \
+                            (opt.clip_context_dim if 'C' in t else 0)                                        # :219-227
+        self.rnn = getattr(nn, opt.CG_rnn_type.upper())(opt.CG_input_encoding_size + self.CG_input_dim, opt.CG_rnn_size, opt.CG_num_layers,
+                                                        bias=False, dropout=opt.CG_drop_prob)
+        if opt.CG_att_hid_size > 0:
+            self.ctx2att = nn.Linear(opt.clip_context_dim, opt.CG_att_hid_size)
+            self.h2att = nn.Linear(opt.CG_rnn_size, opt.CG_att_hid_size)
+            self.alpha_net = nn.Linear(opt.CG_att_hid_size, 1)
+        else:
+            self.ctx2att = nn.Linear(opt.clip_context_dim, 1)
+            self.h2att = nn.Linear(opt.CG_rnn_size, 1)
+
+
+class ShowAttendTellModel(nn.Module):
+    """`caption_model='show_attend_tell'` (models/__init__.py:7-8, OldModel_NEW.py:1009-1012) as a PARAMETER CONTAINER: constructible,
+    state_dict-compatible with the reference (embed, logit [V+1, H], core.rnn.*, core.ctx2att / h2att / alpha_net), movable, savable.
+    experiments/train_SST.sh selects it while it trains the proposal encoder with the captioner idle (train.py:291-295), so that recipe
+    can build its cg_model through this package and write / read the reference's checkpoints.  Its arithmetic is an ablation outside the
+    ECHR hot path: forward / sample raise."""
+
+    def __init__(self, opt):
+        super(ShowAttendTellModel, self).__init__()
+        self.opt = opt
+        self.vocab_size, self.seq_length, self.ss_prob = opt.CG_vocab_size, opt.CG_seq_length, 0.0
+        self.rnn_size, self.num_layers = opt.CG_rnn_size, opt.CG_num_layers
+        t = opt.CG_init_feats_type
+        init_dim = (opt.video_context_dim if 'V' in t else 0) + (opt.event_context_dim if 'E' in t else 0) + (opt.clip_context_dim if 'C' in t else 0)
+        if init_dim:
+            self.init_linear = nn.Linear(init_dim, self.num_layers * self.rnn_size)                          # :36-37
+        self.embed = nn.Embedding(self.vocab_size + 1, opt.CG_input_encoding_size)
+        self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)                                           # :49-51
+        self.dropout = nn.Dropout(opt.CG_drop_prob)
+        with torch.no_grad():                                                                                # init_weights :66-70
+            self.embed.weight.uniform_(-0.1, 0.1)
+            self.logit.bias.zero_()
+            self.logit.weight.uniform_(-0.1, 0.1)
+        self.core = ShowAttendTellCore(opt)
+
+    def _idle(self, *a, **k):
+        raise NotImplementedError("caption_model='show_attend_tell' is a parameter container here (the recipe that selects it, "
+                                  "experiments/train_SST.sh, never runs the captioner); the HIP path implements 'three_stream'")
+
+    forward = sample = get_logprobs_state = _idle
+
+
 def _ablation(name):
     class _Unsupported(nn.Module):
         def __init__(self, *a, **k):
@@ -285,8 +338,8 @@ def _ablation(name):
     return _Unsupported
 
 
-# names the reference's models/__init__.py imports (models/__init__.py:1); only ThreestreamModel is live
-for _n in ('ShowAttendTellModel', 'AllImgModel', 'H3Model', 'TwostreamModel', 'Twostream_jump_Model', 'TwostreamModel_3LSTM',
+# names the reference's models/__init__.py imports (models/__init__.py:1); ThreestreamModel is live, ShowAttendTellModel holds parameters
+for _n in ('AllImgModel', 'H3Model', 'TwostreamModel', 'Twostream_jump_Model', 'TwostreamModel_3LSTM',
            'H3denseModel', 'H3denaddModel', 'ThreestreamModel_2stream', 'ThreestreamModel_2stream_LDA',
            'ThreestreamModel_2stream_CC'):
     globals()[_n] = _ablation(_n)

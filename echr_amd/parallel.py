@@ -13,16 +13,30 @@ import torch
 import torch.distributed as dist
 
 
+def choose_algo(world, algo=None):
+    """The ONE switch for the gradient collective: explicit `algo`, else ECHR_DP_ALGO, else by world size.  'auto': two ranks share one
+    xGMI link whatever the algorithm -> 'allreduce'; from four ranks on a ring all-reduce is bound by ONE of the 7 links of a GPU while
+    reduce-scatter + all-gather spreads 1/R of the buffer over R - 1 distinct links -> 'rs_ag'.  Unmeasured on
+    hardware (this build never had more than one GPU): ECHR_DP_ALGO=allreduce / rs_ag overrides, bench.py prints the choice."""
+    algo = algo or os.environ.get('ECHR_DP_ALGO', 'auto')
+    if algo == 'auto':
+        algo = 'rs_ag' if world >= 4 else 'allreduce'
+    if algo not in ('allreduce', 'rs_ag'):
+        raise ValueError('ECHR_DP_ALGO must be auto, allreduce or rs_ag (got %r)' % (algo,))
+    return algo
+
+
 def reduce_sum_(flat, group=None, algo=None, async_op=False):
     """SUM over ranks of a flat fp32 buffer, in place.
 
-    algo 'allreduce' (default): one dist.all_reduce -- RCCL picks ring / tree / direct itself.
+    algo None: choose_algo (ECHR_DP_ALGO, default by world size).
+    algo 'allreduce': one dist.all_reduce -- RCCL picks ring / tree / direct itself.
     algo 'rs_ag' (or ECHR_DP_ALGO=rs_ag): reduce-scatter + all-gather on the same buffer (on a fully connected
     xGMI node each GPU then exchanges 1/R of the buffer with each of its R-1 peers over R-1 distinct links, instead of pushing the
     whole buffer around a ring whose every hop is bound by ONE link).  Needs numel % R == 0 (the arena is 64-float aligned, so R = 2,
     4, 8 always qualify); otherwise it falls back to all_reduce.  Returns a work handle when async_op (rs_ag is synchronous)."""
-    algo = algo or os.environ.get('ECHR_DP_ALGO', 'allreduce')
     world = dist.get_world_size(group)
+    algo = choose_algo(world, algo)
     if algo == 'rs_ag' and world > 1 and flat.numel() % world == 0 and flat.is_contiguous():
         rank = dist.get_rank(group)
         n = flat.numel() // world

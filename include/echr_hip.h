@@ -28,6 +28,9 @@ extern "C" {
 #define ECHR_ABI_VERSION 1
 
 int echr_version(void);
+/* sizeof() of an argument struct of this header by its type name ("echr_dec_args", ...), -1 for an unknown name: lets a binding that
+ * restates the structs (ctypes, cgo, JNI) check its layout against the library it loaded */
+int64_t echr_abi_sizeof(const char* name);
 const char* echr_last_error(void);
 /* Asynchronous failures.  The persistent recurrence kernels (csrc/persist.hip) bound every inter-workgroup wait; when one gives up the
  * launch drains, a device word stays set (echr_clamp_adam / echr_clamp then skip their update, so no parameter is touched by the
@@ -369,6 +372,49 @@ int echr_top_proposals_nms(const float* scores, int32_t T, int32_t K, int32_t to
  * ---------------------------------------------------------------------------------------------- */
 int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
                     double beta2, double eps, float clip, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One training iteration of the caption path as ONE call.  Replaces the per-iteration protocol of train.py:281-317 around the hot
+ * path -- zero_grad; cg_model(tap_feats, c3d_feats, lda_feats, labels, ind, soi, 'train') (CaptionGenerator.py:17-30);
+ * LanguageModelCriterion (misc/utils.py:66-75); backward; clip_gradient; optimizer.step() -- for m_batch = 1 with the caption
+ * model's parameters and gradients in flat buffers.  The entry sequences the library's own pieces (event pooling, TSRM encoder,
+ * decoder forward / backward with the fused criterion gradient, clamp + Adam) on `stream`; the host pays one call instead of ~75.
+ *
+ * The caller fills: the parameter pointers and shapes of `tsrm` / `dec` (N, A, Tv, S, rows_disjoint included), dec.c3d, dec.video,
+ * the gradient pointers of `tsrm_g` / `dec_g` (views of flat_g; dec_g.g_video optional), `drop`, and the fields below.  Every
+ * other pointer of the four embedded structs (index vectors, event context, tokens, workspaces, log-probs, upstream gradients) is
+ * set by the library from `ws`.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    echr_tsrm_args tsrm;
+    echr_tsrm_grads tsrm_g;
+    echr_dec_args dec;
+    echr_dec_grads dec_g;
+    echr_dropout drop;
+    const float* tap;              /* [Tv,Ht] proposal-encoder states (tap_feats) */
+    int32_t Ht;
+    float* g_tap;                  /* optional [Tv,Ht], zero-filled by the caller: receives d loss / d tap_feats (joint training); NULL = tap is data */
+    const int32_t* host_index;     /* HOST memory (any kind; copied into a pinned ring inside the call):
+                                      ev_start[N] | ev_len[N] | ind[N] | tokens[S*N] (time-major input tokens, labels[:, t]) */
+    const void* nll_target;        /* device [N,S] targets (labels[:, 1:1+S]), int64 or int32 */
+    int32_t nll_target_i64;
+    const float* nll_mask;         /* device [N,S] */
+    const float* g_loss;           /* device scalar: d objective / d loss (1 for plain training) */
+    float* loss;                   /* device [2]: out = (loss, sum(mask)) */
+    float* ws;                     /* workspace, echr_train_step_ws_floats floats, 256-byte aligned */
+    int64_t ws_floats;
+    float* flat_g;                 /* the gradient arena (n_flat floats): zero-filled by the call, then accumulated into */
+    int64_t n_flat;
+    float *flat_p, *adam_m, *adam_v; /* parameter arena and Adam moments (do_step = 1) */
+    int32_t adam_step;             /* 1-based step count of THIS update */
+    double lr, beta1, beta2, eps;
+    float clip;                    /* clip_gradient value (inf = none) */
+    int32_t do_step;               /* 0: stop after the backward pass (the caller reduces / inspects flat_g and steps itself) */
+    int32_t overlap_encoder;       /* 1: the decoder forward's event-independent part runs on the library's second stream beside the event encoder */
+    int32_t forward_only;          /* 1: stop after the criterion (validation loss, eval_utils.py:148-152) */
+} echr_train_step_args;
+int64_t echr_train_step_ws_floats(const echr_train_step_args* a);
+int echr_train_step(const echr_train_step_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optional per-kernel-class timing (HIP events recorded on the launch stream around every launch of the

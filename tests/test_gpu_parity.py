@@ -1011,6 +1011,98 @@ def test_flat_arena_path_matches_per_tensor_path(case):
             assert U.grad_close(k, p.grad.cpu().numpy(), 2 * g1[k].cpu().numpy(), 1e-4), k
 
 
+@pytest.mark.parametrize('case', ['c1', 'c2'])
+def test_fused_train_step_equals_autograd_path(case):
+    """echr_train_step (one library call per iteration: zero_grad, forward, criterion, backward, clip_gradient, Adam -- train.py:281-317)
+    against the autograd path on a twin model: same losses, same parameters and Adam moments after three iterations (train mode, same
+    dropout stream), same gradients with step=False, same validation loss with forward_only; then both paths mixed on one model."""
+    from echr_amd.fused import FusedTrainStep
+    from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+    from echr_amd.optim import ClampAdam
+    opt, params, vid = synth.make_case(case)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    tgt, msk = labels[:, 1:].to(dev), masks[:, 1:].to(dev)
+    crit = LanguageModelCriterion()
+
+    def make():
+        m = U.build_gpu_model(opt, params, True)
+        o = ClampAdam(m.parameters(), lr=1e-3, arena=m.build_arena())
+        return m, o
+
+    def autograd_iteration(m, o, step=True):
+        o.zero_grad()
+        loss = crit(m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), tgt, msk)
+        loss.backward()
+        clip_gradient(o, 0.05)
+        if step:
+            o.step()
+        return float(loss)
+
+    ma, oa = make()
+    mb, ob = make()
+    fb = FusedTrainStep(mb, ob, grad_clip=0.05)
+    lr = 1e-3
+    # ONE step from identical states.  Split-K / scatter sums use fp32 atomics, so two evaluations of the same gradient differ in the last
+    # bits (~1e-7 of the tensor's max-norm) whichever path runs, and Adam's first update is lr * g / (|g| + eps): insensitive to that noise
+    # where |g| is resolvable, a coin flip of +-lr where the gradient itself is rounding noise
+    la = autograd_iteration(ma, oa)
+    lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:]))      # host targets / masks: uploaded inside
+    assert abs(la - lb) < 1e-6 * abs(la), (la, lb)
+    assert ob._flat['step'] == 1 and oa._flat['step'] == 1
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        dp = (pa.detach() - pb.detach()).abs()
+        assert float(dp.max()) <= 2.01 * lr, k
+        if pa.grad is not None and k not in U.NOISE_ONLY:          # (alpha_net.bias: the true gradient is exactly zero, both sides hold noise)
+            g = pa.grad.abs()
+            solid = g > 1e-4 * g.max()
+            if bool(solid.any()):
+                assert float(dp[solid].max()) < 0.02 * lr, (k, float(dp[solid].max()))
+    # the trajectories stay together (noise is amplified by Adam from step to step, so the gate widens)
+    for it in range(3):
+        la = autograd_iteration(ma, oa)
+        lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk))
+        assert abs(la - lb) < 1e-3 * abs(la), (it, la, lb)
+    assert ob._flat['step'] == 4 and oa._flat['step'] == 4
+    # from here on the twins are re-synchronised before every comparison
+    def sync():
+        with torch.no_grad():
+            mb._echr_arena.flat_p.copy_(ma._echr_arena.flat_p)
+            ob._flat['m'].copy_(oa._flat['m']); ob._flat['v'].copy_(oa._flat['v'])
+        ma.set_dropout_state(U.SEED, 40); mb.set_dropout_state(U.SEED, 40)
+    sync()
+    # gradients only (data-parallel protocol: reduce, then clip + step by the caller)
+    autograd_iteration(ma, oa, step=False)
+    lb = fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, step=False)
+    assert mb._echr_arena.grads_in_arena()
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert (pa.grad is None) == (pb.grad is None), k
+        if pa.grad is not None:
+            assert U.grad_close(k, pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), 2e-5), (k, U.relerr(pb.grad.cpu().numpy(), pa.grad.cpu().numpy()))
+    clip_gradient(ob, 0.05)
+    ob.step()
+    oa.step()
+    sync()
+    # validation loss (eval mode, no backward): forward_only
+    ma.eval(); mb.eval()
+    with torch.no_grad():
+        va = float(crit(ma(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), tgt, msk))
+    vb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, forward_only=True))
+    assert abs(va - vb) < 1e-5 * abs(va)
+    # the two paths interleaved on ONE model: an autograd iteration after a fused one (stale .grad views, arena bookkeeping) and back
+    ma.train(); mb.train()
+    sync()
+    la = autograd_iteration(ma, oa)
+    lb = autograd_iteration(mb, ob)
+    assert abs(la - lb) < 2e-6 * abs(la)
+    sync()
+    la = autograd_iteration(ma, oa)
+    lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk))
+    assert abs(la - lb) < 2e-6 * abs(la)
+    assert oa._flat['step'] == ob._flat['step']
+
+
 def test_backward_pass_that_raises_does_not_poison_the_next_one():
     """The decoder's backward zero-fills the whole gradient arena once per pass and tells the later Functions of THAT pass so.  When a later
     node raises, autograd's end-of-pass callbacks do not run; the next pass must still zero-fill (the flag is tied to the graph task it was
@@ -1605,8 +1697,10 @@ def test_two_rank_data_parallel_on_one_gpu(tmp_path, overlap):
             assert U.grad_close(k, r0['grad|' + k], p.grad.detach().cpu().numpy(), 1e-5), k     # SUM over ranks == accumulation, no 1/R
 
 
-def test_bench_two_rank_rehearsal_on_one_gpu():
-    """The WHOLE multi-rank bench path on the one-GPU box: `python bench.py --gpus 2` launches its own two ranks (gloo transport, both on
+@pytest.mark.parametrize('fused', ['auto', 'on'])
+def test_bench_two_rank_rehearsal_on_one_gpu(fused):
+    """(fused = 'on': every rank's iteration as one echr_train_step call up to the backward pass, then ONE collective, clip + step.)
+    The WHOLE multi-rank bench path on the one-GPU box: `python bench.py --gpus 2` launches its own two ranks (gloo transport, both on
     cuda:0, launch-per-phase recurrences), runs warm-up + timed steps with the staged early reducer, takes the MAX over ranks and prints
     ONE JSON line whose value is the whole-job rate."""
     import json
@@ -1616,11 +1710,13 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     env = dict(os.environ, ECHR_BENCH_BACKEND='gloo', ECHR_BENCH_ONE_GPU='1')
     env.pop('WORLD_SIZE', None)
     r = subprocess.run([_sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu', '--no-native',
-                        '--no-roofline'], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+                        '--no-roofline', '--fused', fused], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
+    assert out['config']['host_path'].startswith('echr_train_step' if fused == 'on' else 'autograd')
+    assert out['config']['dp_algo'] == 'allreduce' and out['config']['persist_coop'] == 1      # two ranks: one link; a shared device: cooperative launches
     assert out['n_gpus'] == 2 and out['steps'] == 4 and out['scaling'] == 'weak' and out['config']['global_events'] == 128
     assert out['value'] > 0 and abs(out['value'] - 4 * 20 * 2 / (out['ms_per_step'] * 4 / 1e3)) < 0.01 * out['value']
     assert np.isfinite(out['config']['final_loss'])

@@ -40,9 +40,13 @@ def test_factories_and_unsupported_variants():
     from echr_amd import models
     opt = synth.default_opt()
     echr_amd.CaptionGenerator(copy.copy(opt))
-    bad = synth.default_opt(caption_model='show_attend_tell')
+    idle = models.setup_lm(synth.default_opt(caption_model='show_attend_tell', clip_context_dim=500))     # a parameter container (train_SST.sh)
     with pytest.raises(NotImplementedError):
-        models.setup_lm(bad)
+        idle.forward()
+    with pytest.raises(NotImplementedError):
+        models.H3Model(opt)                                                     # the other ablation decoders stay unsupported
+    with pytest.raises(Exception):
+        models.setup_lm(synth.default_opt(caption_model='nope'))
     with pytest.raises(Exception):
         models.setup_fusion(synth.default_opt(fusion_model='nope'))
     sst = models.setup_tap(opt)
@@ -150,3 +154,28 @@ def test_host_side_proposal_utilities_match_reference_fixture():
     for i in range(3):
         info = [{'re_score': float(x), 'id': j} for j, x in enumerate(g['r%d|scores' % i])]
         assert [v['id'] for v in EU.reranking(info)] == list(g['r%d|kept' % i])
+
+
+def test_show_attend_tell_recipe_builds_a_state_dict_compatible_container():
+    """experiments/train_SST.sh:4 builds cg_model with caption_model='show_attend_tell' (CG_num_layers 3, ER3 / VL / CC) while only the proposal
+    encoder trains (train.py:291-295).  The drop-in constructs it, with the reference's state_dict names and shapes (printed from the
+    reference: models/OldModel_NEW.py:190-216,1009-1012), and refuses to run it."""
+    import echr_amd
+    opt = synth.default_opt(vocab_size=30, seq_length=5, caption_model='show_attend_tell', CG_num_layers=3)
+    m = echr_amd.CaptionGenerator(opt)
+    sd = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    expect = {'lm_model.embed.weight': (31, 512), 'lm_model.logit.weight': (31, 512), 'lm_model.logit.bias': (31,),
+              'lm_model.core.rnn.weight_ih_l0': (2048, 512), 'lm_model.core.rnn.weight_hh_l0': (2048, 512),
+              'lm_model.core.rnn.weight_ih_l1': (2048, 512), 'lm_model.core.rnn.weight_hh_l1': (2048, 512),
+              'lm_model.core.rnn.weight_ih_l2': (2048, 512), 'lm_model.core.rnn.weight_hh_l2': (2048, 512),
+              'lm_model.core.ctx2att.weight': (512, 500), 'lm_model.core.ctx2att.bias': (512,),
+              'lm_model.core.h2att.weight': (512, 512), 'lm_model.core.h2att.bias': (512,),
+              'lm_model.core.alpha_net.weight': (1, 512), 'lm_model.core.alpha_net.bias': (1,)}
+    lm = {k: v for k, v in sd.items() if k.startswith('lm_model.')}
+    assert lm == expect, set(lm.items()) ^ set(expect.items())
+    assert any(k.startswith('fusion_model.') for k in sd)                       # ER3 + TSRM8: the event encoder is built as in the reference
+    m.load_state_dict(m.state_dict())
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(4, 512), torch.zeros(4, 500), torch.zeros(100), torch.zeros(1, 3, dtype=torch.long), [1], [[0, 2]], mode='train')
+    opt2 = synth.default_opt(vocab_size=30, seq_length=5, caption_model='show_attend_tell', CG_num_layers=2, CG_input_feats_type='E')
+    assert tuple(echr_amd.CaptionGenerator(opt2).state_dict()['lm_model.core.rnn.weight_ih_l0'].shape) == (2048, 1024)

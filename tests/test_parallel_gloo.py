@@ -1,6 +1,8 @@
 """CPU, world_size 2 (gloo): the data-parallel gradient exchange is a SUM all-reduce without 1/R, so that R ranks x 1
 video == the reference's m_batch = R accumulation (train.py:281-283,313-317)."""
 import os
+
+import pytest
 import socket
 
 import numpy as np
@@ -216,3 +218,17 @@ def test_bench_launches_its_own_ranks():
     env2.pop('ECHR_BENCH_DRYRUN')
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env2, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'launches the ranks itself' in r.stderr
+
+
+def test_collective_choice_by_world_size(monkeypatch):
+    """parallel.choose_algo: one switch (ECHR_DP_ALGO) over all-reduce vs reduce-scatter + all-gather, default by world size."""
+    from echr_amd import parallel
+    monkeypatch.delenv('ECHR_DP_ALGO', raising=False)
+    assert [parallel.choose_algo(w) for w in (1, 2, 4, 8)] == ['allreduce', 'allreduce', 'rs_ag', 'rs_ag']
+    monkeypatch.setenv('ECHR_DP_ALGO', 'allreduce')
+    assert parallel.choose_algo(8) == 'allreduce'
+    monkeypatch.setenv('ECHR_DP_ALGO', 'rs_ag')
+    assert parallel.choose_algo(2) == 'rs_ag' and parallel.choose_algo(2, 'allreduce') == 'allreduce'
+    monkeypatch.setenv('ECHR_DP_ALGO', 'ring')
+    with pytest.raises(ValueError):
+        parallel.choose_algo(2)

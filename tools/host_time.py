@@ -14,7 +14,13 @@ optim = ClampAdam(model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.opt
 tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
 labels = torch.from_numpy(vid['labels'])
 tgt = labels[:, 1:].to(dev); msk = torch.from_numpy(vid['masks'])[:, 1:].to(dev)
+fused = None
+if 'autograd' not in sys.argv:          # default: the one-call iteration (echr_train_step); `autograd` measures the autograd path
+    from echr_amd.fused import FusedTrainStep
+    fused = FusedTrainStep(model, optim, grad_clip=opt.grad_clip)
 def iteration():
+    if fused is not None:
+        return fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk)
     optim.zero_grad()
     pred = model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
     loss = crit(pred, tgt, msk)
