@@ -48,6 +48,7 @@ constexpr int CNT_LINE = SHARDS * SHSTRIDE;              // u32 per counter
 enum { C_H1 = 0, C_Q = 1, C_C = 2, C_H0 = 3, C_H2 = 4, C_KINDS = 5 };
 constexpr u32 SPIN_LIMIT = 4000000;                      // ~ seconds
 constexpr int WU_LD = 264;                               // unnormalised attention weights per event: up to 2 x 129 slots (second slot set, below)
+constexpr int NCB = 2, NCBB = 3;                         // row buffers of the BIG kernels' C3D stream: forward / reverse (what their registers hold without spilling)
 constexpr int PSET2 = 3 * PSL;                           // first slot of an event's SECOND slot set (events longer than 129 segments)
 constexpr int LDS_W = 128 * 1024, LDS_WA = 64 * 1024, LDS_RED = 16 * 1024, LDS_RED_ATT = 32 * 1024 + 2048 + 2048 + 256;
 constexpr int LDS_BYTES_LSTM = LDS_W + LDS_RED + 256, LDS_BYTES_ATT = LDS_WA + LDS_RED_ATT + 256;
@@ -101,6 +102,11 @@ __device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t r, u32 off) {
 // too: no faster, the consumers of one operand do not share its fetch through L2)
 __device__ __forceinline__ float4 ld16_bulk(__amdgpu_buffer_rsrc_t r, u32 off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// read-only operands (C3D rows): default cache policy
+__device__ __forceinline__ float4 ld16_plain(__amdgpu_buffer_rsrc_t r, u32 off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, u32 off, float4 v) {
@@ -857,6 +863,7 @@ __device__ __forceinline__ void fill_bimg_h2(float4* img, float* inv_scale, floa
 
 
 struct PersistK2 {
+    unsigned c3d_bytes;            // bytes of the whole [Tv, D] feature tensor (buffer-resource bound of the BIG kernels' C3D row stream)
     int N, A, D, S, ld_att;
     const float* w_hh1; const float* w_h2a; const float* b_h2a; const float* w_att; const float* w_alpha;
     const float* PALL; const float* c3d; const int* ev_start; const int* ev_len;
@@ -930,10 +937,14 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
     //      set-up phases overlap (both are chains of dependent memory latencies) ----
     const int ar = lb / 3, ap = lb - 3 * ar, an = HR * m + ar;    // row within the half, third, event
     const bool att_live = an < N;
-    const int grow_ = 4 * w + (lane >> 4), lr = lane & 15;
+    int grow_ = 4 * w + (lane >> 4), lr = lane & 15;          // (not const: the BIG instantiation re-derives their dependants every step, below)
     int alen = 0;
     long row0 = 0;
-    float4 Pr[PSG][8], Cr[PSG][8];
+    // BIG: e^{2p} of BOTH slot sets stays in registers (Pr, Pr2) and the C3D rows of both sets are streamed from L2 every step through three
+    // row buffers -- their addresses do not depend on the step, so a step requests its first rows before it waits for q.  (The first cut kept
+    // set 1's P_all and C3D rows resident and re-read set 2's P_all AND C3D rows behind the q hop: two chains of dependent L2 round trips per
+    // step and 392 B of scratch per lane.)
+    float4 Pr[PSG][8], Cr[BIG ? 1 : PSG][8], Pr2[BIG ? PSG : 1][8];
     bool use_max = false;
     {
         float asum = 0.f;
@@ -956,17 +967,29 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
                 Pr[i][h] = *reinterpret_cast<const float4*>(pr + 4 * h);
-                const int d = 32 * lr + 4 * h;
-                float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
-                if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                Cr[i][h] = v;
+                if constexpr (!BIG) {
+                    const int d = 32 * lr + 4 * h;
+                    float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
+                    if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    Cr[i][h] = v;
+                }
+            }
+            if constexpr (BIG) {
+                const int a2 = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);          // (clamped: only read by events longer than 129 segments)
+                const float* pr2 = P.PALL + (row0 + a2) * PH + 32 * lr;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) Pr2[i][h] = *reinterpret_cast<const float4*>(pr2 + 4 * h);
             }
         }
     } else {
 #pragma unroll
         for (int i = 0; i < PSG; ++i)
 #pragma unroll
-            for (int h = 0; h < 8; ++h) Pr[i][h] = Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int h = 0; h < 8; ++h) {
+                Pr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (!BIG) Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                else Pr2[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
     }
     if (is_g1) {
         auto row = [&](int cc) { return (cc >> 3) * PH + 8 * lb + (cc & 7); };       // tile column cc = gate * 8 + unit
@@ -982,35 +1005,41 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
         if (H2) fill_bimg_h2(wimg, invbA, scr, P.w_h2a, PH, PH, 1, row, tid);
         else fill_bimg32(wimg, P.w_h2a, PH, PH, row, tid);
     }
+    auto exp2x = [](const float4 pv) {
+        return make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
+                           __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
+    };
     if (att_live) {
 #pragma unroll
         for (int i = 0; i < PSG; ++i)
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                const float4 pv = Pr[i][h];
-                Pr[i][h] = make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
-                                       __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
+                Pr[i][h] = exp2x(Pr[i][h]);
+                if constexpr (BIG) Pr2[i][h] = exp2x(Pr2[i][h]);
             }
     }
     if (H2 && att_live) {
         // bound on |context| of this event = max |C3D| over its slots: one atomic max per workgroup (non-negative floats order like uints);
         // complete for every reader by the first context hand-off
         float mx = 0.f;
+        if constexpr (!BIG) {
 #pragma unroll
-        for (int i = 0; i < PSG; ++i)
+            for (int i = 0; i < PSG; ++i)
 #pragma unroll
-            for (int h = 0; h < 8; ++h) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(Cr[i][h].x), fabsf(Cr[i][h].y))), fmaxf(fabsf(Cr[i][h].z), fabsf(Cr[i][h].w)));
-        if (BIG && alen > PSET2) {          // the second slot set's rows bound the context too
+                for (int h = 0; h < 8; ++h) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(Cr[i][h].x), fabsf(Cr[i][h].y))), fmaxf(fabsf(Cr[i][h].z), fabsf(Cr[i][h].w)));
+        } else {
+            for (int set = 0; set < (alen > PSET2 ? 2 : 1); ++set) {
 #pragma unroll
-            for (int i = 0; i < PSG; ++i) {
-                const int sl = grow_ + 16 * i;
-                const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
-                const float* cr = P.c3d + (row0 + a) * D;
+                for (int i = 0; i < PSG; ++i) {
+                    const int sl = grow_ + 16 * i;
+                    const int a = min(PSET2 * set + PSL * ap + min(sl, PSL - 1), alen - 1);
+                    const float* cr = P.c3d + (row0 + a) * D;
 #pragma unroll
-                for (int h = 0; h < 8; ++h) {
-                    const int d = 32 * lr + 4 * h;
-                    const float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
-                    if (d < D) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    for (int h = 0; h < 8; ++h) {
+                        const int d = 32 * lr + 4 * h;
+                        const float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
+                        if (d < D) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    }
                 }
             }
         }
@@ -1028,6 +1057,12 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
     if (P.stamps && b == 0 && tid == 0) P.stamps[14] = __builtin_amdgcn_s_memrealtime();          // set-up done
 
     for (int t = 0; t < S; ++t) {
+        if constexpr (BIG) {
+            // every register counts here (both e^{2p} sets are resident): what is cheap to re-derive from the lane's coordinates -- row
+            // offsets, validity predicates, exchange addresses -- must not be hoisted out of the step loop and kept (the compiler then
+            // spills them and reloads from scratch every step); redefining the coordinates per step makes their dependants loop-variant
+            asm volatile("" : "+v"(grow_), "+v"(lr), "+v"(alen), "+v"(row0));
+        }
         if (srole >= 0) STAMP(srole, 0);
         f32x16 acc;
 #pragma unroll
@@ -1075,6 +1110,9 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
             if (srole >= 0) STAMP(srole, 1);
             if (H2) {
                 h1_fetch();
+                // BIG: with both e^{2p} sets resident the scheduler otherwise issues ONE fragment load per MFMA group (16 dependent round
+                // trips: 4.3 us instead of 1.5); the barrier keeps all 16 loads ahead of the first MFMA
+                if constexpr (BIG) __builtin_amdgcn_sched_barrier(0);
                 h1_product();
             } else {
                 float4 a[16];
@@ -1104,6 +1142,20 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
         }
         // ---- attention: scores, (split) softmax, context partial ----
         {
+            // BIG: row buffers of the C3D stream (slot group g of 0..5 = set g / 3, rows grow_ + 16 (g % 3))
+            float4 cbuf[BIG ? NCB : 1][8];
+            // (buffer loads over the whole feature tensor: one 32-bit offset per row + immediates -- with 64-bit global addresses the
+            // compiler hoists 96 loop-invariant address registers out of the step loop and spills; reads past a row's end land in the next row
+            // and are masked at use, reads past the tensor's end return zero)
+            const __amdgpu_buffer_rsrc_t rc3 = mk_rsrc(P.c3d, P.c3d_bytes);
+            auto fetch_c = [&](int g, float4 (&dst)[8]) {
+                const int sl = grow_ + 16 * (g % PSG);
+                const int a = min(PSET2 * (g / PSG) + PSL * ap + min(sl, PSL - 1), alen - 1);
+                const u32 off = (u32)(((row0 + a) * D + 32 * lr) * 4);
+#pragma unroll
+                for (int h = 0; h < 8; ++h) dst[h] = ld16_plain(rc3, off + 16 * h);
+            };
+            const int ng = has2 ? 2 * PSG : PSG;          // slot groups of this workgroup (uniform)
             if (!wait_total(P, cnt(C_Q, t), HQ, flag, 200000u + t)) return;
             if (srole >= 0) STAMP(srole, 5);
             if (att_live) {
@@ -1111,6 +1163,13 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                 float4 q[8];
 #pragma unroll
                 for (int h = 0; h < 8; ++h) q[h] = ld16_sc1(rq, (u32)((((4 * lr + (h >> 1)) * HR + ar) * 8 + 4 * (h & 1)) * 4));
+                if constexpr (BIG) {
+                    // the first C3D rows are requested BEHIND the q loads: they are not needed before every score is formed (pure register work),
+                    // which covers their latency.  (Requested ahead of the wait for q they land earlier still, but they then share the
+                    // hand-off path with the q workgroups' h1 fetch, which is the critical one: q product 1.5 -> 4.6 us.)
+#pragma unroll
+                    for (int g = 0; g < NCB; ++g) fetch_c(g, cbuf[g]);
+                }
                 float asum = 0.f;
 #pragma unroll
                 for (int h = 0; h < 8; ++h) {
@@ -1134,36 +1193,24 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                     const bool valid = sl < PSL && PSL * ap + sl < alen;
                     e[i] = valid ? v : -INFINITY;
                 }
-                // second slot set (BIG, events longer than 129 segments): same scores from P_all rows fetched now (L2-resident)
+                // second slot set (BIG, events longer than 129 segments): the same scores from its own e^{2p} registers
                 float e2[PSG] = {-INFINITY, -INFINITY, -INFINITY};
-                if (has2) {
-                    // two slots' rows in flight: slot i + 1 is fetched while slot i is scored
-                    float4 pv[2][8];
-                    auto fetch_p = [&](int i, float4 (&dst)[8]) {
-                        const int sl = grow_ + 16 * i;
-                        const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
-                        const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
+                if constexpr (BIG) {
+                    if (has2) {
 #pragma unroll
-                        for (int h = 0; h < 8; ++h) dst[h] = *reinterpret_cast<const float4*>(pr + 4 * h);
-                    };
-                    fetch_p(0, pv[0]);
+                        for (int i = 0; i < PSG; ++i) {
+                            const int sl = grow_ + 16 * i;
+                            float v = 0.f;
 #pragma unroll
-                    for (int i = 0; i < PSG; ++i) {
-                        if (i + 1 < PSG) fetch_p(i + 1, pv[(i + 1) & 1]);
-                        const int sl = grow_ + 16 * i;
-                        float v = 0.f;
-#pragma unroll
-                        for (int h = 0; h < 8; ++h) {
-                            const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
-                            const float4 pp = pv[i & 1][h];
-                            const float4 ep = make_float4(__expf(2.f * fminf(fmaxf(pp.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pp.y, -43.f), 43.f)),
-                                                          __expf(2.f * fminf(fmaxf(pp.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pp.w, -43.f), 43.f)));
-                            v += a4.x * __builtin_amdgcn_rcpf(fmaf(ep.x, q[h].x, 1.f)) + a4.y * __builtin_amdgcn_rcpf(fmaf(ep.y, q[h].y, 1.f)) +
-                                 a4.z * __builtin_amdgcn_rcpf(fmaf(ep.z, q[h].z, 1.f)) + a4.w * __builtin_amdgcn_rcpf(fmaf(ep.w, q[h].w, 1.f));
+                            for (int h = 0; h < 8; ++h) {
+                                const float4 a4 = *reinterpret_cast<const float4*>(sal + 32 * lr + 4 * h);
+                                v += a4.x * __builtin_amdgcn_rcpf(fmaf(Pr2[i][h].x, q[h].x, 1.f)) + a4.y * __builtin_amdgcn_rcpf(fmaf(Pr2[i][h].y, q[h].y, 1.f)) +
+                                     a4.z * __builtin_amdgcn_rcpf(fmaf(Pr2[i][h].z, q[h].z, 1.f)) + a4.w * __builtin_amdgcn_rcpf(fmaf(Pr2[i][h].w, q[h].w, 1.f));
+                            }
+                            v = row16_sum(fmaf(-2.f, v, asum));
+                            const bool valid = sl < PSL && PSET2 + PSL * ap + sl < alen;
+                            e2[i] = valid ? v : -INFINITY;
                         }
-                        v = row16_sum(fmaf(-2.f, v, asum));
-                        const bool valid = sl < PSL && PSET2 + PSL * ap + sl < alen;
-                        e2[i] = valid ? v : -INFINITY;
                     }
                 }
                 float shift = 0.f;
@@ -1206,37 +1253,32 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                 float4 cx[8];
 #pragma unroll
                 for (int h = 0; h < 8; ++h) cx[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int i = 0; i < PSG; ++i) {
-                    const float x = __expf(e[i] - shift);          // exp(-inf) = 0 for slots past the event's end
-                    e[i] = x;
-                    ssum += x;
-#pragma unroll
-                    for (int h = 0; h < 8; ++h) {
-                        cx[h].x += x * Cr[i][h].x; cx[h].y += x * Cr[i][h].y; cx[h].z += x * Cr[i][h].z; cx[h].w += x * Cr[i][h].w;
-                    }
-                }
-                if (has2) {
-                    float4 cv[2][8];
-                    auto fetch_c = [&](int i, float4 (&dst)[8]) {
-                        const int sl = grow_ + 16 * i;
-                        const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
-                        const float* cr = P.c3d + (row0 + a) * D;
-#pragma unroll
-                        for (int h = 0; h < 8; ++h) dst[h] = *reinterpret_cast<const float4*>(cr + min(32 * lr + 4 * h, D - 4));
-                    };
-                    fetch_c(0, cv[0]);
+                if constexpr (!BIG) {
 #pragma unroll
                     for (int i = 0; i < PSG; ++i) {
-                        if (i + 1 < PSG) fetch_c(i + 1, cv[(i + 1) & 1]);
-                        const float x = __expf(e2[i] - shift);
-                        e2[i] = x;
+                        const float x = __expf(e[i] - shift);          // exp(-inf) = 0 for slots past the event's end
+                        e[i] = x;
                         ssum += x;
 #pragma unroll
                         for (int h = 0; h < 8; ++h) {
-                            float4 c4 = cv[i & 1][h];
-                            if (32 * lr + 4 * h >= D) c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                            cx[h].x += x * c4.x; cx[h].y += x * c4.y; cx[h].z += x * c4.z; cx[h].w += x * c4.w;
+                            cx[h].x += x * Cr[i][h].x; cx[h].y += x * Cr[i][h].y; cx[h].z += x * Cr[i][h].z; cx[h].w += x * Cr[i][h].w;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 2 * PSG; ++g) {
+                        if (g < ng) {
+                            float& eg = g < PSG ? e[g % PSG] : e2[g % PSG];
+                            const float x = __expf(eg - shift);
+                            eg = x;
+                            ssum += x;
+#pragma unroll
+                            for (int h = 0; h < 8; ++h) {
+                                float4 c4 = cbuf[g % NCB][h];
+                                if (32 * lr + 4 * h >= D) c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                                cx[h].x += x * c4.x; cx[h].y += x * c4.y; cx[h].z += x * c4.z; cx[h].w += x * c4.w;
+                            }
+                            if (g + NCB < ng) fetch_c(g + NCB, cbuf[g % NCB]);          // the buffer just consumed takes the row NCB groups ahead
                         }
                     }
                 }
@@ -1299,7 +1341,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                 }
             }
             if (srole >= 0) STAMP(srole, 6);
-            if (H2 && is_g1 && t > 0) {
+            if (!BIG && H2 && is_g1 && t > 0) {
                 // the gate workgroups' h1(t-1) fetch (16 loads per lane) goes out behind the context atomics and stays in flight across
                 // the publish (q(t) complete => the q workgroups have consumed all of h1(t-1), so it is complete and visible here too)
                 h1_fetch();
@@ -1309,7 +1351,13 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
             }
             if (srole >= 0) STAMP(srole, 7);
         }
-        if (H2 && is_g1 && t > 0) h1_product();
+        if (H2 && is_g1 && t > 0) {
+            if (BIG) {                    // BIG: fetched here, not across the context publish -- the 64 fragment registers hold the second e^{2p} set
+                h1_fetch();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            h1_product();
+        }
         // ---- phase C: attended-context columns + gate math; the new h1 goes to the next step ----
         if (is_g1) {
             if (!wait_total(P, cnt(C_C, t), HWG, flag, 300000u + t)) return;
@@ -2099,6 +2147,7 @@ static PersistLayoutB persist_layout_b(int S) {
 long persist_bwd_ws_floats(int S);
 
 struct PersistB {
+    unsigned c3d_bytes;            // bytes of the whole [Tv, D] feature tensor (BIG kernels' C3D row stream)
     int N, A, D, S, ld_att;
     const float* w_hh[3]; const float* w_h2a; const float* w_att; const float* w_alpha;
     const float* PALL; const float* c3d; const int* ev_start; const int* ev_len;
@@ -2620,7 +2669,7 @@ __device__ __forceinline__ void fill_bimg32_t(float4* img, const float* W, long 
     }
 }
 
-template <bool BIG>          // BIG: events of up to 258 segments, second slot set re-read from L2 every step (see dec_persist_att2_body)
+template <bool BIG>          // BIG: events of up to 258 segments: e^{2p} of both slot sets in registers, C3D rows streamed from L2 (see dec_persist_att2_body)
 __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, const int bid) {
     if (P.stamps && bid == 0 && threadIdx.x == 0) P.stamps[15] = __builtin_amdgcn_s_memrealtime();          // kernel entry (diagnostic)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -2644,11 +2693,15 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
     }
     const int ar = lb / 3, ap = lb - 3 * ar, an = HR * m + ar;
     const bool att_live = an < N;
-    const int grow_ = 4 * w + (lane >> 4), lr = lane & 15;
+    int grow_ = 4 * w + (lane >> 4), lr = lane & 15;          // (not const: see the step loop of the BIG instantiation)
     int alen = 0;
     long row0 = 0;
-    float4 Pr[PSG][8], Cr[PSG][8];
+    float4 Pr[PSG][8], Cr[BIG ? 1 : PSG][8], Pr2[BIG ? PSG : 1][8];
     for (int j = tid; j < PH; j += 256) sal[j] = P.w_alpha[j];
+    auto exp2x = [](const float4 pv) {
+        return make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
+                           __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
+    };
     if (att_live) {
         alen = P.ev_len[an];
         row0 = P.ev_start[an];
@@ -2660,20 +2713,30 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
             const float* cr = P.c3d + (row0 + a) * D;
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                const float4 pv = *reinterpret_cast<const float4*>(pr + 4 * h);
-                Pr[i][h] = make_float4(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)),
-                                       __expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)));
-                const int d = 32 * lr + 4 * h;
-                float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
-                if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                Cr[i][h] = v;
+                Pr[i][h] = exp2x(*reinterpret_cast<const float4*>(pr + 4 * h));
+                if constexpr (!BIG) {
+                    const int d = 32 * lr + 4 * h;
+                    float4 v = *reinterpret_cast<const float4*>(cr + min(d, D - 4));
+                    if (d >= D) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    Cr[i][h] = v;
+                }
+            }
+            if constexpr (BIG) {
+                const int a2 = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);          // (clamped: only read by events longer than 129 segments)
+                const float* pr2 = P.PALL + (row0 + a2) * PH + 32 * lr;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) Pr2[i][h] = exp2x(*reinterpret_cast<const float4*>(pr2 + 4 * h));
             }
         }
     } else {
 #pragma unroll
         for (int i = 0; i < PSG; ++i)
 #pragma unroll
-            for (int h = 0; h < 8; ++h) Pr[i][h] = Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int h = 0; h < 8; ++h) {
+                Pr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (!BIG) Cr[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                else Pr2[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
     }
     __syncthreads();
     const bool has2 = BIG && att_live && alen > PSET2;           // uniform over the workgroup
@@ -2686,6 +2749,7 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
     if (P.stamps && b == 0 && tid == 0) P.stamps[14] = __builtin_amdgcn_s_memrealtime();          // set-up done
 
     for (int t = S - 1; t >= -1; --t) {
+        if constexpr (BIG) asm volatile("" : "+v"(grow_), "+v"(lr), "+v"(alen), "+v"(row0));          // see dec_persist_att2_body
         if (srole >= 0) BSTAMP(srole, 0);
         // ============ GD: d h1(t) -> d G1(t); at t = -1 only d q(0) is copied out ============
         if (is_gd) {
@@ -2769,6 +2833,7 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
             if (!wait_total(P, cnt(CB_DG, t), HGD, flag, 600000u + t)) return;
             if (srole >= 0) BSTAMP(srole, 6);
             load_afrag32(pa, mk_rsrc(P.XDG + ((long)t * 2 + m) * XSTEPH + (long)pks * XHALF, XBH), w, lane);
+            if constexpr (BIG) __builtin_amdgcn_sched_barrier(0);          // all 16 fragment loads ahead of the first MFMA (see dec_persist_att2_body)
             p_tile(0);
         }
         // ============ attention backward of step t (all workgroups) ============
@@ -2791,6 +2856,17 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
                 }
                 for (int d = tid; d < PH; d += 256) sat[d] = d < D ? P.ATT[((long)t * N + an) * D + d] : 0.f;
             }
+            // BIG: the C3D rows of both slot sets are streamed from L2 through NCBB row buffers
+            float4 cbuf[BIG ? NCBB : 1][8];
+            const __amdgpu_buffer_rsrc_t rc3 = mk_rsrc(P.c3d, P.c3d_bytes);
+            auto fetch_c = [&](int g, float4 (&dst)[8]) {
+                const int sl = grow_ + 16 * (g % PSG);
+                const int a = min(PSET2 * (g / PSG) + PSL * ap + min(sl, PSL - 1), alen - 1);
+                const u32 off = (u32)(((row0 + a) * D + 32 * lr) * 4);
+#pragma unroll
+                for (int h = 0; h < 8; ++h) dst[h] = ld16_plain(rc3, off + 16 * h);
+            };
+            const int ng = has2 ? 2 * PSG : PSG;
             if (!wait_total(P, cnt(CB_DA, t), HP, flag, 700000u + t)) return;
             if (srole >= 0) BSTAMP(srole, 10);
             if (att_live) {
@@ -2799,81 +2875,75 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
                 float s0 = 0.f;
 #pragma unroll
                 for (int h = 0; h < 8; ++h) da[h] = ld16_sc1(ra, (u32)((((4 * lr + (h >> 1)) * HR + ar) * 8 + 4 * (h & 1)) * 4));
+                if constexpr (BIG) {
+                    // the first C3D rows go out behind the d ATT loads (requested ahead of the wait they would share the hand-off path with
+                    // the product workgroups' fragment fetch, which is on the critical path: d ATT tile 2.6 -> 5.9 us)
+#pragma unroll
+                    for (int g = 0; g < NCBB; ++g) fetch_c(g, cbuf[g]);
+                }
 #pragma unroll
                 for (int h = 0; h < 8; ++h) {
                     const float4 at = *reinterpret_cast<const float4*>(sat + 32 * lr + 4 * h);
                     s0 += at.x * da[h].x + at.y * da[h].y + at.z * da[h].z + at.w * da[h].w;
                 }
                 s0 = row16_sum(s0);
-                float dsc[PSG];
+                float dsc[PSG], dsc2[PSG] = {0.f, 0.f, 0.f};
+                if constexpr (!BIG) {
 #pragma unroll
-                for (int i = 0; i < PSG; ++i) {
-                    float dw = 0.f;
+                    for (int i = 0; i < PSG; ++i) {
+                        float dw = 0.f;
 #pragma unroll
-                    for (int h = 0; h < 8; ++h) dw += Cr[i][h].x * da[h].x + Cr[i][h].y * da[h].y + Cr[i][h].z * da[h].z + Cr[i][h].w * da[h].w;
-                    dw = row16_sum(dw);
-                    dsc[i] = wt[i] * (dw - s0);
+                        for (int h = 0; h < 8; ++h) dw += Cr[i][h].x * da[h].x + Cr[i][h].y * da[h].y + Cr[i][h].z * da[h].z + Cr[i][h].w * da[h].w;
+                        dw = row16_sum(dw);
+                        dsc[i] = wt[i] * (dw - s0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PSG; ++i) dsc[i] = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 2 * PSG; ++g) {
+                        if (g < ng) {
+                            float dw = 0.f;
+#pragma unroll
+                            for (int h = 0; h < 8; ++h) {
+                                float4 c4 = cbuf[g % NCBB][h];
+                                if (32 * lr + 4 * h >= D) c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                                dw += c4.x * da[h].x + c4.y * da[h].y + c4.z * da[h].z + c4.w * da[h].w;
+                            }
+                            if (g + NCBB < ng) fetch_c(g + NCBB, cbuf[g % NCBB]);
+                            dw = row16_sum(dw);
+                            if (g < PSG) dsc[g % PSG] = wt[g % PSG] * (dw - s0);
+                            else dsc2[g % PSG] = wt2[g % PSG] * (dw - s0);
+                        }
+                    }
                 }
                 {
                     const float xw = lr == 0 ? dsc[0] : (lr == 1 ? dsc[1] : dsc[2]);
                     const int sl = grow_ + 16 * lr;
                     if (lr < PSG && sl < PSL && PSL * ap + sl < alen) P.DSC[((long)t * N + an) * P.A + PSL * ap + sl] = xw;
                 }
-                // second slot set: d score from C3D rows fetched now, then its share of d q from the P_all rows (one slot's rows in flight at a time)
+                // second slot set: its share of d q from its own e^{2p} registers
                 float4 s2[8];
 #pragma unroll
                 for (int h = 0; h < 8; ++h) s2[h] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (has2) {
-                    float dsc2[PSG];
-                    float4 xv[2][8];
-                    auto fetch_c = [&](int i, float4 (&dst)[8]) {
-                        const int sl = grow_ + 16 * i;
-                        const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
-                        const float* cr = P.c3d + (row0 + a) * D;
-#pragma unroll
-                        for (int h = 0; h < 8; ++h) dst[h] = *reinterpret_cast<const float4*>(cr + min(32 * lr + 4 * h, D - 4));
-                    };
-                    auto fetch_p = [&](int i, float4 (&dst)[8]) {
-                        const int sl = grow_ + 16 * i;
-                        const int a = min(PSET2 + PSL * ap + min(sl, PSL - 1), alen - 1);
-                        const float* pr = P.PALL + (row0 + a) * PH + 32 * lr;
-#pragma unroll
-                        for (int h = 0; h < 8; ++h) dst[h] = *reinterpret_cast<const float4*>(pr + 4 * h);
-                    };
-                    fetch_c(0, xv[0]);
-#pragma unroll
-                    for (int i = 0; i < PSG; ++i) {
-                        if (i + 1 < PSG) fetch_c(i + 1, xv[(i + 1) & 1]);
-                        else fetch_p(0, xv[(i + 1) & 1]);                  // the first P_all row rides behind the last C3D row
-                        float dw = 0.f;
-#pragma unroll
-                        for (int h = 0; h < 8; ++h) {
-                            float4 c4 = xv[i & 1][h];
-                            if (32 * lr + 4 * h >= D) c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                            dw += c4.x * da[h].x + c4.y * da[h].y + c4.z * da[h].z + c4.w * da[h].w;
-                        }
-                        dw = row16_sum(dw);
-                        dsc2[i] = wt2[i] * (dw - s0);
-                    }
                     {
                         const float xw2 = lr == 3 ? dsc2[0] : (lr == 4 ? dsc2[1] : dsc2[2]);
                         const int sl2 = grow_ + 16 * (lr - 3);
                         if (lr >= 3 && lr < 3 + PSG && sl2 < PSL && PSET2 + PSL * ap + sl2 < alen) P.DSC[((long)t * N + an) * P.A + PSET2 + PSL * ap + sl2] = xw2;
                     }
-#pragma unroll
-                    for (int i = 0; i < PSG; ++i) {
-                        // slot i's P_all row sits in buffer (PSG + i) & 1 (slot 0 was fetched into buffer PSG & 1 above)
-                        if (i + 1 < PSG) fetch_p(i + 1, xv[(PSG + i + 1) & 1]);
+                    if constexpr (BIG) {
 #pragma unroll
                         for (int h = 0; h < 8; ++h) {
-                            const float4 pv = xv[(PSG + i) & 1][h];
-                            const float4 eq = make_float4(__expf(2.f * fminf(fmaxf(q[h].x, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].y, -43.f), 43.f)),
-                                                          __expf(2.f * fminf(fmaxf(q[h].z, -43.f), 43.f)), __expf(2.f * fminf(fmaxf(q[h].w, -43.f), 43.f)));
-                            float r;
-                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv.x, -43.f), 43.f)), eq.x, 1.f)); s2[h].x += dsc2[i] * (r - r * r);
-                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv.y, -43.f), 43.f)), eq.y, 1.f)); s2[h].y += dsc2[i] * (r - r * r);
-                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv.z, -43.f), 43.f)), eq.z, 1.f)); s2[h].z += dsc2[i] * (r - r * r);
-                            r = __builtin_amdgcn_rcpf(fmaf(__expf(2.f * fminf(fmaxf(pv.w, -43.f), 43.f)), eq.w, 1.f)); s2[h].w += dsc2[i] * (r - r * r);
+                            const float4 eq = exp2x(q[h]);
+#pragma unroll
+                            for (int i = 0; i < PSG; ++i) {
+                                float r;
+                                r = __builtin_amdgcn_rcpf(fmaf(Pr2[i][h].x, eq.x, 1.f)); s2[h].x += dsc2[i] * (r - r * r);
+                                r = __builtin_amdgcn_rcpf(fmaf(Pr2[i][h].y, eq.y, 1.f)); s2[h].y += dsc2[i] * (r - r * r);
+                                r = __builtin_amdgcn_rcpf(fmaf(Pr2[i][h].z, eq.z, 1.f)); s2[h].z += dsc2[i] * (r - r * r);
+                                r = __builtin_amdgcn_rcpf(fmaf(Pr2[i][h].w, eq.w, 1.f)); s2[h].w += dsc2[i] * (r - r * r);
+                            }
                         }
                     }
                 }
@@ -2924,6 +2994,12 @@ __device__ __forceinline__ void dec_persist_att_bwd2_body(const PersistB& P, con
         // the d h1 tile (W_hh1 columns) of the fragments fetched above: its consumers (the gate-gradient workgroups of step t-1) take
         // it after their d q product, so it runs here instead of holding back this workgroup's attention role
         if (is_p && t > 0) {
+            // BIG: the fragments are fetched again here (the tile is off the critical path) instead of staying live across the attention role --
+            // their 64 registers hold the second e^{2p} set
+            if constexpr (BIG) {
+                load_afrag32(pa, mk_rsrc(P.XDG + ((long)t * 2 + m) * XSTEPH + (long)pks * XHALF, XBH), w, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             p_tile(1);
             if (srole >= 0) BSTAMP(srole, 9);
         }
@@ -3104,7 +3180,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     if (split) {
         K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
         K2.w_hh1 = a->w_hh[1]; K2.w_h2a = a->w_h2a; K2.b_h2a = a->b_h2a; K2.w_att = K.w_att; K2.w_alpha = a->w_alpha;
-        K2.PALL = B.PALL; K2.c3d = a->c3d; K2.ev_start = a->ev_start; K2.ev_len = a->ev_len;
+        K2.PALL = B.PALL; K2.c3d = a->c3d; K2.ev_start = a->ev_start; K2.ev_len = a->ev_len; K2.c3d_bytes = (unsigned)((size_t)a->Tv * a->D * 4);
         K2.GATES1 = B.GATES[1]; K2.CS1 = B.CS[1]; K2.HS = B.HS; K2.OUTD = B.OUTD; K2.QS = B.QS; K2.WT = B.WT; K2.ATT = B.ATT;
         K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XC = x2 + L2.xc; K2.XS = x2 + L2.xs; K2.GRAN = reinterpret_cast<unsigned long long*>(x2 + L2.gran);
         K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
@@ -3281,7 +3357,7 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
     PersistK2 K2;
     K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
     K2.w_hh1 = a->w_hh[1]; K2.w_h2a = a->w_h2a; K2.b_h2a = a->b_h2a; K2.w_att = K.w_att; K2.w_alpha = a->w_alpha;
-    K2.PALL = B.PALL; K2.c3d = a->c3d; K2.ev_start = a->ev_start; K2.ev_len = a->ev_len;
+    K2.PALL = B.PALL; K2.c3d = a->c3d; K2.ev_start = a->ev_start; K2.ev_len = a->ev_len; K2.c3d_bytes = (unsigned)((size_t)a->Tv * a->D * 4);
     K2.GATES1 = nullptr; K2.CS1 = nullptr; K2.HS = nullptr; K2.OUTD = nullptr; K2.QS = nullptr; K2.WT = nullptr; K2.ATT = nullptr;
     K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XC = x2 + L2.xc; K2.XS = x2 + L2.xs; K2.GRAN = reinterpret_cast<unsigned long long*>(x2 + L2.gran);
     K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
@@ -3338,7 +3414,7 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
     K.N = a->N; K.A = a->A; K.D = a->D; K.S = a->S; K.ld_att = a->E + a->D;
     for (int k = 0; k < 3; ++k) { K.w_hh[k] = a->w_hh[k]; K.GATES[k] = B.GATES[k]; K.CS[k] = B.CS[k]; K.DG[k] = B.DG[k]; }
     K.w_h2a = a->w_h2a; K.w_att = a->w_ih[1] + a->E; K.w_alpha = a->w_alpha;
-    K.PALL = B.PALL; K.c3d = a->c3d; K.ev_start = a->ev_start; K.ev_len = a->ev_len;
+    K.PALL = B.PALL; K.c3d = a->c3d; K.ev_start = a->ev_start; K.ev_len = a->ev_len; K.c3d_bytes = (unsigned)((size_t)a->Tv * a->D * 4);
     K.QS = B.QS; K.WT = B.WT; K.ATT = B.ATT; K.DOUT = B.DOUT; K.DQ = B.DQ; K.DSC = B.DSC;
     const bool split = config().persist_split != 0;
     const PersistLayoutB2 L2 = persist_layout_b2(a->S);

@@ -14,14 +14,15 @@ from echr_amd import _lib
 from echr_amd.misc.utils import LanguageModelCriterion
 
 lib = _lib.load()
-opt, params, vid = bench.make_workload(0, False)
+C5 = 'c5' in sys.argv          # BASELINE config 5's proposals (4..256 segments: the BIG instantiations); tap_feats are synthetic here
+opt, params, vid = bench.make_workload(0, False, C5)
 dev = torch.device('cuda')
 model = echr_amd.CaptionGenerator(opt)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
 model = model.to(dev).train()
 tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
 labels = torch.from_numpy(vid['labels'])
-BWD = len(sys.argv) > 1 and sys.argv[1] == 'bwd'
+BWD = 'bwd' in sys.argv
 crit = LanguageModelCriterion()
 tgt, msk = labels[:, 1:].to(dev), torch.from_numpy(vid['masks'])[:, 1:].to(dev)
 for it in range(4):
