@@ -1110,9 +1110,9 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
             if (srole >= 0) STAMP(srole, 1);
             if (H2) {
                 h1_fetch();
-                // BIG: with both e^{2p} sets resident the scheduler otherwise issues ONE fragment load per MFMA group (16 dependent round
-                // trips: 4.3 us instead of 1.5); the barrier keeps all 16 loads ahead of the first MFMA
-                if constexpr (BIG) __builtin_amdgcn_sched_barrier(0);
+                // all 16 fragment loads ahead of the first MFMA: left alone the scheduler interleaves them with the MFMA groups (four in flight:
+                // 1.5 us; in the BIG instantiation, short of registers, ONE per group: 16 dependent round trips, 4.3 us; all of them: 1.25 us)
+                __builtin_amdgcn_sched_barrier(0);
                 h1_product();
             } else {
                 float4 a[16];
@@ -1365,10 +1365,29 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
             f32x16 accc;
 #pragma unroll
             for (int g = 0; g < 16; ++g) accc[g] = 0.f;
+            float4 av_pre = make_float4(0.f, 0.f, 0.f, 0.f);          // (teacher-forced h2 form) this lane's piece of the context, stored behind the hand-off
+            float ssum_l = 1.f;
             {
                 const __amdgpu_buffer_rsrc_t rc = mk_rsrc(P.XC + ((long)t * 2 + m) * XHALF, XBH);
                 float4 a[H2 ? 1 : 16];
-                if (H2) {
+                // teacher-forced h2 form: the 16 context fragments of this wave are requested FIRST, so that their round trip overlaps the
+                // table phase (a dependent load + a barrier) and the saved-context store below instead of following them (context product
+                // 3.6 -> 2.x us per step; not in the BIG instantiation, whose registers hold the second e^{2p} set)
+                constexpr bool CPRE = H2 && !SAMP && !BIG;
+                float4 cv[CPRE ? 8 : 1][2];
+                if constexpr (CPRE) {
+#pragma unroll
+                    for (int s_ = 0; s_ < 8; ++s_) {
+                        const u32 off = (u32)((((16 * w + 2 * s_ + (lane >> 5)) * HR + (lane & 31)) * 8) * 4);
+                        cv[s_][0] = ld16_bulk(rc, off); cv[s_][1] = ld16_bulk(rc, off + 16);
+                    }
+                    // ... and with them the sum of exponentials of this lane's row: the conversion factor is formed per lane, so only the first
+                    // step (where the bounds on |context| become known) goes through the table phase and its barrier
+                    ssum_l = ld4_sc1(P.XS + (long)t * PROWS + HR * m + (lane & 31));
+                    // the piece of the context this wave saves for the backward pass rides along; its store waits until h1 has been handed on
+                    if (8 * lb < D && w == (lb >> 4)) av_pre = ld16_sc1(rc, (u32)(((lb * HR + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4));
+                }
+                if (H2 && (!CPRE || t == 0)) {
                     // per-row tables: conversion factor 2^(12 - e_r) / s_r (e_r from the bound on |context|) and its inverse scale
                     if (tid < HR) {
                         if (t == 0) cmx[tid] = ld4_sc1(P.XCMAX + HR * m + tid);
@@ -1382,11 +1401,11 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                         invAt[tid] = ldexpf(1.f, ex - 12);
                     }
                     __syncthreads();
-                } else {
+                } else if (!H2) {
                     load_afrag32(reinterpret_cast<float4(&)[16]>(a), rc, w, lane);
                 }
                 // normalised context, saved for backward: this workgroup stores features [8 lb, 8 lb + 8) (wave lb / 16, chunk lb % 16)
-                if (!SAMP && 8 * lb < D && w == (lb >> 4)) {
+                if (!SAMP && !CPRE && 8 * lb < D && w == (lb >> 4)) {
                     float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (H2) av = ld16_sc1(rc, (u32)(((lb * HR + (lane & 31)) * 8 + 4 * (lane >> 5)) * 4));
                     else {
@@ -1396,7 +1415,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                     }
                     const int n = HR * m + (lane & 31), d0 = 8 * lb + 4 * (lane >> 5);
                     if (n < N && d0 < D) {
-                        const float is = 1.0f / ld4_sc1(P.XS + (long)t * PROWS + n);
+                        const float is = 1.0f / (CPRE ? ssum_l : ld4_sc1(P.XS + (long)t * PROWS + n));
                         *reinterpret_cast<float4*>(P.ATT + ((long)t * N + n) * D + d0) = make_float4(av.x * is, av.y * is, av.z * is, av.w * is);
                     }
                 }
@@ -1404,7 +1423,11 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                     // fp32 context -> fp16 pair fragments on the fly: chunk c = 2 s + kh' holds k = 128 w + 8 c + 4 kh .. ; the 32x32x16 A
                     // fragment of k step s wants lane (r, kh): k = 128 w + 16 s + 8 kh + j, j < 8 = the two float4 of chunk 2 s + kh held by
                     // lanes (r, 0) and (r, 1) -> re-read them in that shape from the exchange buffer instead: 8 consecutive floats per lane
-                    const float f = sCt[lane & 31];
+                    float f;
+                    if constexpr (CPRE) {
+                        const int ex = (int)((__float_as_uint(fmaxf(cmx[lane & 31], 1e-30f)) >> 23) & 0xFFu) - 127 + 1;
+                        f = ldexpf(1.f, 12 - ex) / ssum_l;
+                    } else f = sCt[lane & 31];
 #pragma unroll
                     for (int s_ = 0; s_ < 8; ++s_) {
                         const u32 off = (u32)((((16 * w + 2 * s_ + (lane >> 5)) * HR + (lane & 31)) * 8) * 4);
@@ -1416,7 +1439,8 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                                          c0 = ld16_bulk(r3, off + 2 * XBH), c1 = ld16_bulk(r3, off + 2 * XBH + 16);
                             v0 = make_float4((a0.x + b0.x) + c0.x, (a0.y + b0.y) + c0.y, (a0.z + b0.z) + c0.z, (a0.w + b0.w) + c0.w);
                             v1 = make_float4((a1.x + b1.x) + c1.x, (a1.y + b1.y) + c1.y, (a1.z + b1.z) + c1.z, (a1.w + b1.w) + c1.w);
-                        } else { v0 = ld16_bulk(rc, off); v1 = ld16_bulk(rc, off + 16); }
+                        } else if constexpr (CPRE) { v0 = cv[s_][0]; v1 = cv[s_][1]; }
+                        else { v0 = ld16_bulk(rc, off); v1 = ld16_bulk(rc, off + 16); }
                         const float x[8] = {v0.x * f, v0.y * f, v0.z * f, v0.w * f, v1.x * f, v1.y * f, v1.z * f, v1.w * f};
                         unsigned hw[8], lw[8];
 #pragma unroll
@@ -1492,6 +1516,14 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
             publish(cnt(C_H1, t));          // (its barrier also protects `red` for the next step)
             if (srole >= 0) STAMP(srole, 11);
             if (SAMP) continue;             // decoding keeps no activations
+            if constexpr (H2 && !SAMP && !BIG) {
+                // normalised context, saved for backward: this workgroup stores features [8 lb, 8 lb + 8) (wave lb / 16, chunk lb % 16)
+                const int n = HR * m + (lane & 31), d0 = 8 * lb + 4 * (lane >> 5);
+                if (8 * lb < D && w == (lb >> 4) && n < N && d0 < D) {
+                    const float is = 1.0f / ssum_l;
+                    *reinterpret_cast<float4*>(P.ATT + ((long)t * N + n) * D + d0) = make_float4(av_pre.x * is, av_pre.y * is, av_pre.z * is, av_pre.w * is);
+                }
+            }
             if (gn < N) {
                 const int j = 8 * lb + gu;
                 float* go = P.GATES1 + ((long)t * N + gn) * 4 * PH + j;
