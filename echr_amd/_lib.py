@@ -48,7 +48,7 @@ class DecArgs(C.Structure):
                 ('w_ih', c_f * 3), ('w_hh', c_f * 3), ('b_ih', c_f * 3), ('b_hh', c_f * 3),
                 ('w_c2a', c_f), ('b_c2a', c_f), ('w_h2a', c_f), ('b_h2a', c_f), ('w_alpha', c_f), ('b_alpha', c_f),
                 ('c3d', c_f), ('ev_start', c_f), ('ev_len', c_f), ('event', c_f), ('video', c_f), ('tokens', c_f),
-                ('ws', c_f), ('logp', c_f), ('prepared', i32)]
+                ('ws', c_f), ('logp', c_f), ('prepared', i32), ('train', i32), ('zero_extra', c_f), ('zero_extra_count', i64)]
 
 
 class DecGrads(C.Structure):
@@ -57,7 +57,7 @@ class DecGrads(C.Structure):
                 ('g_w_c2a', c_f), ('g_b_c2a', c_f), ('g_w_h2a', c_f), ('g_b_h2a', c_f), ('g_w_alpha', c_f), ('g_b_alpha', c_f),
                 ('g_event', c_f), ('g_video', c_f), ('g_logp', c_f),
                 ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f), ('zeroed', i32), ('phase', i32), ('async_tail', i32), ('nll_msum', c_f),
-                ('zero_extra', c_f), ('zero_extra_count', i64), ('nll_target_i64', i32)]
+                ('zero_extra', c_f), ('zero_extra_count', i64), ('nll_target_i64', i32), ('dlg_ready', i32)]
 
 
 class SstArgs(C.Structure):

@@ -442,6 +442,71 @@ int logsoftmax_bwd(const float* logp, const float* G, const void* target, int tg
     return check_launch("logsoftmax_bwd");
 }
 
+// log-softmax + masked NLL + its gradient in ONE pass over the logits (echr_train_step: nothing else reads the log-probs, so they are never
+// written): block = row (n, t) of the [N,S,ld] logits held in registers -> lse; d logits row (time-major t*N+n, leading dimension ldo, zero
+// padded) = (onehot(target) - softmax) * gv with gv = -mask[n,t] / (sum(mask) + 1e-6) * g_loss (misc/utils.py:66-75 and its backward);
+// row_loss[t*N+n] = -logp[target] * mask[n,t].  Every block sums the N*S mask entries itself (same fixed order everywhere).
+template <int EPT>
+__global__ __launch_bounds__(256) void logsoftmax_nll_dlg_kernel(const float* __restrict__ X, long ld, const void* __restrict__ target, int tgt64,
+                                                                 const float* __restrict__ mask, const float* __restrict__ g_loss, float* __restrict__ out,
+                                                                 long ldo, float* __restrict__ row_loss, float* __restrict__ msum_out, int N, int S, int V1) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;             // time-major row = t*N + n
+    const int t = row / N, n = row % N;
+    const float* x = X + ((long)n * S + t) * ld;
+    float v[EPT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int j = threadIdx.x + i * 256;
+        v[i] = j < V1 ? x[j] : -INFINITY;
+        m = fmaxf(m, v[i]);
+    }
+    float ms = 0.f;
+    for (int i = threadIdx.x; i < N * S; i += 256) ms += mask[i];
+    const int tg = min(max(load_index(target, n * S + t, tgt64), 0), V1 - 1);
+    const float mk = mask[n * S + t];
+    m = block_max(m, red);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) s += ((int)threadIdx.x + i * 256 < V1) ? expf(v[i] - m) : 0.f;
+    s = block_sum(s, red);
+    ms = block_sum(ms, red);
+    const float lse = m + logf(s);
+    const float gv = -mk / (ms + 1e-6f) * g_loss[0];
+    float* o = out + (long)row * ldo;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int j = threadIdx.x + i * 256;
+        if (j < V1) {
+            const float lp = v[i] - lse;
+            o[j] = (j == tg ? gv : 0.f) - expf(lp) * gv;
+            if (j == tg) row_loss[row] = -lp * mk;
+        } else if (j < ldo) o[j] = 0.f;
+    }
+    if (row == 0 && threadIdx.x == 0) msum_out[0] = ms;
+}
+// loss[0] = sum(row_loss) / (msum + 1e-6), loss[1] = msum: one block, fixed order
+__global__ __launch_bounds__(256) void nll_rows_sum_kernel(const float* __restrict__ row_loss, int NS, const float* __restrict__ msum, float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < NS; i += 256) s += row_loss[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) { loss[0] = s / (msum[0] + 1e-6f); loss[1] = msum[0]; }
+}
+bool logsoftmax_nll_dlg_ok(int V1, long ldo) { return ldo <= 256 * 40; }
+int logsoftmax_nll_dlg(const float* X, long ld, const void* target, int tgt64, const float* mask, const float* g_loss, float* out, long ldo,
+                       float* row_loss, float* msum_out, int N, int S, int V1, hipStream_t st) {
+    if (ldo <= 256 * 8) hipLaunchKernelGGL(logsoftmax_nll_dlg_kernel<8>, dim3(N * S), dim3(256), 0, st, X, ld, target, tgt64, mask, g_loss, out, ldo, row_loss, msum_out, N, S, V1);
+    else if (ldo <= 256 * 20) hipLaunchKernelGGL(logsoftmax_nll_dlg_kernel<20>, dim3(N * S), dim3(256), 0, st, X, ld, target, tgt64, mask, g_loss, out, ldo, row_loss, msum_out, N, S, V1);
+    else hipLaunchKernelGGL(logsoftmax_nll_dlg_kernel<40>, dim3(N * S), dim3(256), 0, st, X, ld, target, tgt64, mask, g_loss, out, ldo, row_loss, msum_out, N, S, V1);
+    return check_launch("logsoftmax_nll_dlg");
+}
+int nll_rows_sum(const float* row_loss, int NS, const float* msum, float* loss, hipStream_t st) {
+    hipLaunchKernelGGL(nll_rows_sum_kernel, dim3(1), dim3(256), 0, st, row_loss, NS, msum, loss);
+    return check_launch("nll_rows_sum");
+}
+
 // masked NLL (misc/utils.py:66-75): out[0] = loss, out[1] = sum(mask)
 __global__ __launch_bounds__(256) void nll_loss_kernel(const float* __restrict__ logp, const void* __restrict__ target, int tgt64,
                                                        const float* __restrict__ mask, float* __restrict__ out, int NS, int V1) {

@@ -715,6 +715,7 @@ struct DecWs {
     float *QACC;                 // [S,N,Ha] atomic accumulation target of q (teacher-forced path)
     float *PK_C3D, *PK_WC, *PK_WIH[3], *PK_WL, *PK_XT, *PK_OUTD;     // h2-packed GEMM operands of the forward pass
     float *XWS;                  // exchange buffers + counters of the persistent recurrence kernel (csrc/persist.hip)
+    float *PK_WLT;               // W_logit^T packed for the backward's d OUTD product (echr_dec_args.train: packed with the forward operands)
     int nq, ng[3];
     long total;
 };
@@ -749,12 +750,13 @@ static DecWs carve_ws(const echr_dec_args* a, float* base) {
     w.PK_XT = take(h2_floats((int)(S * N), a->E));
     w.PK_OUTD = take(h2_floats((int)(S * N), 3 * a->H));
     w.XWS = take(persist_fwd_ws_floats((int)S));
+    w.PK_WLT = take(h2_floats(3 * a->H, a->V1));
     w.total = off;
     return w;
 }
 
 struct DecWsBwd {
-    float *DLG, *DOUT, *DG[3], *DC, *DSC, *DQ, *DPALL, *DGSUM[3], *DGCOL[3], *DXT, *MSUM;
+    float *DLG, *DOUT, *DG[3], *DC, *DSC, *DQ, *DPALL, *DGSUM[3], *DGCOL[3], *DXT, *MSUM, *ROWL;
     float *WT_HH[3], *WT_ATT, *WT_H2A;      // transposed weights: the backward recurrence runs as NT products too
     float *WLT, *DLGT, *OUTDT;               // W_logit^T [3H, ldg], DLG^T [V1, snp], OUTD^T [3H, snp]: NT operands for the split GEMM
     // h2-packed operands of the backward GEMMs (suffix T: packed from the transposed view, i.e. contraction over rows of the source)
@@ -788,6 +790,7 @@ static DecWsBwd carve_ws_bwd(const echr_dec_args* a, float* base) {
     for (int k = 0; k < 3; ++k) w.DGSUM[k] = take(N * 4 * H);
     w.DXT = take(S * N * a->E);
     w.MSUM = take(64);
+    w.ROWL = take(S * N);
     for (int k = 0; k < 3; ++k) w.WT_HH[k] = take(H * 4 * H);
     w.WT_ATT = take((long)a->D * 4 * H);
     w.WT_H2A = take(H * (long)a->Ha);
@@ -837,10 +840,11 @@ static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t
     if (!(parts & 1)) goto event_part;
     if (config().gemm_h2) {
         // every time-invariant GEMM operand of the forward pass is packed by one launch
-        H2PackJob pj[6] = {pack_rows(a->c3d, a->D, a->Tv, a->D, w.PK_C3D), pack_rows(a->w_c2a, a->D, a->Ha, a->D, w.PK_WC),
+        H2PackJob pj[7] = {pack_rows(a->c3d, a->D, a->Tv, a->D, w.PK_C3D), pack_rows(a->w_c2a, a->D, a->Ha, a->D, w.PK_WC),
                            pack_rows(a->w_logit, 3 * H, a->V1, 3 * H, w.PK_WL), pack_rows(a->w_ih[0], E + a->De, 4 * H, E, w.PK_WIH[0]),
-                           pack_rows(a->w_ih[1], E + a->D, 4 * H, E, w.PK_WIH[1]), pack_rows(a->w_ih[2], E + a->Dv, 4 * H, E, w.PK_WIH[2])};
-        RC(h2_pack_multi(pj, teacher_forced ? 6 : 2, st));      // the sampler's per-step products stay on the skinny-GEMM path
+                           pack_rows(a->w_ih[1], E + a->D, 4 * H, E, w.PK_WIH[1]), pack_rows(a->w_ih[2], E + a->Dv, 4 * H, E, w.PK_WIH[2]),
+                           pack_cols(a->w_logit, 3 * H, 3 * H, a->V1, w.PK_WLT)};      // (train: the backward's operand, off its critical path)
+        RC(h2_pack_multi(pj, teacher_forced ? (a->train ? 7 : 6) : 2, st));      // the sampler's per-step products stay on the skinny-GEMM path
         d = desc_h2(w.PK_C3D, w.PK_WC, w.PALL, a->Ha, a->Tv, a->Ha, a->D);
     } else {
         d = desc_nt(a->c3d, a->D, a->w_c2a, a->D, w.PALL, a->Ha, a->Tv, a->Ha, a->D);
@@ -1011,10 +1015,11 @@ static int decoder_fill(const echr_dec_args* a, const DecWs& w, hipStream_t st) 
     const int N = a->N, S = a->S, H = a->H;
     // h(-1) = c(-1) = 0 (init_hidden, :75-78), the atomic q accumulators and the split-K target EVB0 -- and the zeroed part of the persistent
     // launch's exchange workspace (counters, accumulated buffers): one launch
-    float* zp[7] = {w.HS, w.CS[0], w.CS[1], w.CS[2], w.QACC, w.EVB0, nullptr};
-    long zn[7] = {(long)N * 3 * H, (long)N * H, (long)N * H, (long)N * H, (long)S * N * a->Ha, (long)N * 4 * H, 0};
+    float* zp[8] = {w.HS, w.CS[0], w.CS[1], w.CS[2], w.QACC, w.EVB0, nullptr, nullptr};
+    long zn[8] = {(long)N * 3 * H, (long)N * H, (long)N * H, (long)N * H, (long)S * N * a->Ha, (long)N * 4 * H, 0, 0};
     int n = 6;
-    if (fwd_uses_persist(a)) { persist_fwd_zero_range(a, w.XWS, &zp[6], &zn[6]); n = 7; }
+    if (fwd_uses_persist(a)) { persist_fwd_zero_range(a, w.XWS, &zp[n], &zn[n]); ++n; }
+    if (a->zero_extra && a->zero_extra_count > 0) { zp[n] = a->zero_extra; zn[n] = (long)a->zero_extra_count; ++n; }      // the caller's gradient arena
     return fill_zero_multi(zp, zn, n, st);
 }
 
@@ -1046,7 +1051,21 @@ extern "C" int echr_decoder_fwd_prepare_cancel(void* stream) {
     return 0;
 }
 
-extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream) {
+static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, void* stream, const echr_dec_grads* fz, bool* fused_out);
+extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream) { return decoder_fwd_impl(a, drop, stream, nullptr, nullptr); }
+namespace echr {
+int decoder_fwd_fused(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, bool* fused) {
+    return decoder_fwd_impl(a, drop, stream, g, fused);
+}
+int decoder_fused_loss(const echr_dec_args* a, const echr_dec_grads* g, float* loss, hipStream_t st) {
+    const DecWsBwd b = carve_ws_bwd(a, g->ws_bwd);
+    return nll_rows_sum(b.ROWL, a->S * a->N, b.MSUM, loss, st);
+}
+}  // namespace echr
+// fz != nullptr: the criterion is fused behind the logits product (echr_train_step) -- the logits are turned into d logits in ws_bwd and
+// per-row loss terms by ONE pass instead of log-softmax, NLL and log-softmax backward passes; the log-probs are never materialised
+static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, void* stream, const echr_dec_grads* fz, bool* fused_out) {
+    if (fused_out) *fused_out = false;
     RC(persist_check_async());
     RC(join_tail((hipStream_t)stream));
     RC(check_dims(a, "decoder_fwd"));
@@ -1085,6 +1104,13 @@ extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop
         }
         d.bias = a->b_logit; d.rowmap_mod = N; d.rowmap_mul = S;
         RC(gemm(d, q));
+        if (fz && t0 == 0 && t1 == S && fz->nll_target && fz->nll_mask && fz->g_loss && fz->ws_bwd) {
+            const DecWsBwd b = carve_ws_bwd(a, fz->ws_bwd);
+            if (logsoftmax_nll_dlg_ok(a->V1, b.ldg)) {
+                if (fused_out) *fused_out = true;
+                return logsoftmax_nll_dlg(a->logp, a->V1, fz->nll_target, fz->nll_target_i64, fz->nll_mask, fz->g_loss, b.DLG, b.ldg, b.ROWL, b.MSUM, N, S, a->V1, q);
+            }
+        }
         return logsoftmax_rows(a->logp, a->V1, N, S, t0, t1 - t0, a->V1, q);
     };
     const bool two = config().chains2 == 1 && side().ok && S >= 2;     // streams 0/2 recur on the side stream
@@ -1132,7 +1158,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     RC(join_tail((hipStream_t)stream));
     RC(check_dims(a, "decoder_bwd"));
     ECHR_REQUIRE(g && a->ws && g->ws_bwd && a->logp, "decoder_bwd: missing buffers");
-    ECHR_REQUIRE(g->g_logp || (g->nll_target && g->nll_mask && g->g_loss), "decoder_bwd: need g_logp or the fused NLL inputs");
+    ECHR_REQUIRE(g->dlg_ready || g->g_logp || (g->nll_target && g->nll_mask && g->g_loss), "decoder_bwd: need g_logp or the fused NLL inputs");
     hipStream_t st = (hipStream_t)stream;
     const int N = a->N, S = a->S, H = a->H, E = a->E, Ha = a->Ha, A = a->A, D = a->D, V1 = a->V1;
     const int SN = S * N;
@@ -1152,8 +1178,10 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     const bool bwd_persist = !overlap_enabled() && !(config().chains2 == 1 && side().ok && S >= 2) && persist_bwd_eligible(a);
     // 1. d logits (time-major, padded leading dimension)
     if (do_a) {
-    if (!g->g_logp && !g->nll_msum) RC(colsum(g->nll_mask, 1, N * S, 1, b.MSUM, false, st));
-    RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_target_i64, g->nll_mask, g->g_loss, g->nll_msum ? g->nll_msum : b.MSUM, b.DLG, b.ldg, N, S, V1, st));
+    if (!g->dlg_ready) {          // (echr_train_step formed d logits in the pass that read the logits)
+        if (!g->g_logp && !g->nll_msum) RC(colsum(g->nll_mask, 1, N * S, 1, b.MSUM, false, st));
+        RC(logsoftmax_bwd(a->logp, g->g_logp, g->nll_target, g->nll_target_i64, g->nll_mask, g->g_loss, g->nll_msum ? g->nll_msum : b.MSUM, b.DLG, b.ldg, N, S, V1, st));
+    }
     // scratch that is accumulated into, and the transposed recurrent weights (every d h / d ATT product of the reverse recurrence
     // then has the same NT form as forward): two launches, independent of everything above
     // (the persistent reverse launch builds its weight images from the untransposed matrices: nothing to transpose then; the test is the
@@ -1188,16 +1216,18 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         // with an asynchronous tail (phase 0) the logit-layer gradients, which nothing in the backward pass reads, are formed on the tail
         // stream beside the launch-bound rest of the backward instead of in front of the reverse recurrence
         const bool defer_wl = g->phase == 0 && g->async_tail != 0 && tail().ok;
+        // (a->train: W_logit^T was packed with the forward operands; otherwise here)
+        const float* pk_wlt = a->train ? w.PK_WLT : b.PK_WLT;
         if (defer_wl) {
             H2PackJob pj[2] = {pack_rows(b.DLG, b.ldg, SN, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
-            RC(h2_pack_multi(pj, 2, st));
+            RC(h2_pack_multi(pj, a->train ? 1 : 2, st));
         } else {
             H2PackJob pj[4] = {pack_cols(b.DLG, b.ldg, V1, SN, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SN, b.PK_OUTDT),
                                pack_rows(b.DLG, b.ldg, SN, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
-            RC(h2_pack_multi(pj, 4, st));
+            RC(h2_pack_multi(pj, a->train ? 3 : 4, st));
             RC(logit_grads(a, g, w, b, z, st));
         }
-        d = desc_h2(b.PK_DLG, b.PK_WLT, b.DOUT, 3 * H, SN, 3 * H, V1);
+        d = desc_h2(b.PK_DLG, pk_wlt, b.DOUT, 3 * H, SN, 3 * H, V1);
         d.beta = 1.f;                          // DOUT was zeroed above: the k slices add atomically, no fill launch
         RC(gemm(d, st));
     } else {

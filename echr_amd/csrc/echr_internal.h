@@ -134,6 +134,15 @@ int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int 
 int logsoftmax_rows(float* X, long ld, int N, int S, int t0, int nt, int cols, hipStream_t st);
 int logsoftmax_bwd(const float* logp, const float* G, const void* target, int tgt64, const float* mask, const float* g_loss,
                    const float* mask_sum, float* out, long ldo, int N, int S, int V1, hipStream_t st);
+// log-softmax + masked NLL + d logits in one pass over the logits (echr_train_step); rows_sum turns the per-row terms into (loss, sum(mask))
+bool logsoftmax_nll_dlg_ok(int V1, long ldo);
+int logsoftmax_nll_dlg(const float* X, long ld, const void* target, int tgt64, const float* mask, const float* g_loss, float* out, long ldo,
+                       float* row_loss, float* msum_out, int N, int S, int V1, hipStream_t st);
+int nll_rows_sum(const float* row_loss, int NS, const float* msum, float* loss, hipStream_t st);
+// echr_decoder_fwd with the criterion fused behind the logits product: g carries nll_target / nll_mask / g_loss / ws_bwd; d logits land in ws_bwd
+// (echr_dec_grads.dlg_ready = 1 for the echr_decoder_bwd that follows); returns through *fused whether the fused form applied
+int decoder_fwd_fused(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, bool* fused);
+int decoder_fused_loss(const echr_dec_args* a, const echr_dec_grads* g, float* loss, hipStream_t st);
 int sample_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished, long long* seq,
                 float* seq_logp, int* n_unfinished, float temperature, unsigned long long seed, hipStream_t st);
 // slabs != nullptr: logits rows are formed here from four k-slice slabs (+ bias) in a fixed order and written to `logits`

@@ -97,6 +97,9 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     echr_dec_args d = a->dec;
     d.ev_start = ev_start; d.ev_len = ev_len; d.tokens = tokens;
     d.ws = ws + L.dec_ws; d.logp = ws + L.logp; d.event = nullptr; d.prepared = 0;
+    d.train = a->forward_only ? 0 : 1;
+    // the gradient arena is zero-filled by the forward's first fill launch (beside the event encoder), not in front of the reverse recurrence
+    d.zero_extra = a->forward_only ? nullptr : a->flat_g; d.zero_extra_count = a->n_flat;
     // CaptionGenerator.forward (:23-30): the decoder's event-independent part starts on the library's second stream and overlaps the event encoder
     if (a->overlap_encoder) RC(echr_decoder_fwd_prepare(&d, stream));
     echr_tsrm_args t = a->tsrm;
@@ -106,24 +109,33 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     if (!rc) rc = echr_tsrm_fwd(&t, &a->drop, stream);                                                                       // :129
     if (rc) { if (a->overlap_encoder) (void)echr_decoder_fwd_prepare_cancel(stream); return rc; }
     d.event = ws + L.event; d.prepared = a->overlap_encoder ? 1 : 0;
-    RC(echr_decoder_fwd(&d, &a->drop, stream));                                                                              // :30
-    // LanguageModelCriterion (misc/utils.py:66-75): loss[0] = loss, loss[1] = sum(mask)
-    if (a->nll_target_i64) RC(echr_nll_loss_fwd_i64(d.logp, static_cast<const int64_t*>(a->nll_target), a->nll_mask, a->loss, N, S, d.V1, stream));
-    else RC(echr_nll_loss_fwd(d.logp, static_cast<const int32_t*>(a->nll_target), a->nll_mask, a->loss, N, S, d.V1, stream));
-    if (a->forward_only) return 0;
-
-    // backward (train.py:313): criterion gradient in fused form; the whole gradient arena is zero-filled by the backward's first fill launch
     echr_dec_grads g = a->dec_g;
     g.g_event = ws + L.g_event; g.g_logp = nullptr;
     g.nll_target = static_cast<const int32_t*>(a->nll_target); g.nll_target_i64 = a->nll_target_i64; g.nll_mask = a->nll_mask;
     g.g_loss = a->g_loss; g.nll_msum = a->loss + 1;
     g.ws_bwd = ws + L.dec_ws_bwd; g.zeroed = 1; g.phase = 0; g.async_tail = 1;
-    g.zero_extra = a->flat_g; g.zero_extra_count = a->n_flat;
+    // forward (:30) + LanguageModelCriterion (misc/utils.py:66-75).  Training: log-softmax, criterion and its gradient are ONE pass over the
+    // logits (d logits land in the backward workspace, the log-probs are never written; the loss is summed behind the backward pass, where
+    // this stream waits for the helper stream anyway).  forward_only: the plain log-softmax + criterion, loss[0] = loss, loss[1] = sum(mask)
+    bool fused_nll = false;
+    if (a->forward_only) RC(echr_decoder_fwd(&d, &a->drop, stream));
+    else RC(decoder_fwd_fused(&d, &g, &a->drop, stream, &fused_nll));
+    if (!fused_nll) {
+        if (a->nll_target_i64) RC(echr_nll_loss_fwd_i64(d.logp, static_cast<const int64_t*>(a->nll_target), a->nll_mask, a->loss, N, S, d.V1, stream));
+        else RC(echr_nll_loss_fwd(d.logp, static_cast<const int32_t*>(a->nll_target), a->nll_mask, a->loss, N, S, d.V1, stream));
+    }
+    if (a->forward_only) return 0;
+    g.dlg_ready = fused_nll ? 1 : 0;
+    if (fused_nll) g.nll_msum = nullptr;
+
+    // backward (train.py:313): criterion gradient in fused form
+    g.zero_extra = nullptr; g.zero_extra_count = 0;
     RC(echr_decoder_bwd(&d, &g, &a->drop, stream));
     echr_tsrm_grads tg = a->tsrm_g;
     tg.g_ech = ws + L.g_ech; tg.g_out = ws + L.g_event; tg.ws_bwd = ws + L.tsrm_ws_bwd; tg.zeroed = 1;
     RC(echr_tsrm_bwd(&t, &tg, &a->drop, stream));
     if (a->g_tap) RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, a->dec.D, a->Ht, stream));
+    if (fused_nll) RC(decoder_fused_loss(&d, &g, a->loss, st));
     RC(echr_stream_join(stream));          // the decoder backward's asynchronous tail: every gradient is final in `stream` order now
     if (a->do_step)                        // clip_gradient + Adam (misc/utils.py:107-111, train.py:315-317)
         RC(echr_clamp_adam(a->flat_p, a->flat_g, a->adam_m, a->adam_v, a->n_flat, a->adam_step, a->lr, a->beta1, a->beta2, a->eps, a->clip, stream));

@@ -218,7 +218,7 @@ DEC_PARAMS = ('embed', 'w_logit', 'b_logit',
               'w_c2a', 'b_c2a', 'w_h2a', 'b_h2a', 'w_alpha', 'b_alpha')
 
 
-def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint=False, n_de=None, prepared=0):
+def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint=False, n_de=None, prepared=0, train=0):
     (embed, w_logit, b_logit, wi0, wi1, wi2, wh0, wh1, wh2, bi0, bi1, bi2, bh0, bh1, bh2, w_c2a, b_c2a, w_h2a, b_h2a,
      w_alpha, b_alpha) = ps
     N, De = event.shape if event is not None else n_de
@@ -236,7 +236,7 @@ def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, d
                      L.ptr(w_c2a), L.ptr(b_c2a), L.ptr(w_h2a), L.ptr(b_h2a), L.ptr(w_alpha), L.ptr(b_alpha),
                      L.ptr(c3d), L.ptr(ev_start, torch.int32), L.ptr(ev_len, torch.int32), L.ptr(event), L.ptr(video),
                      L.ptr(tokens, torch.int32) if tokens is not None else None, L.ptr(ws), L.ptr(logp) if logp is not None else None,
-                     int(prepared))
+                     int(prepared), int(train), None, 0)
 
 
 def decoder_prepare(video, c3d, ev_start, ev_len, tokens, A, disjoint, params):
@@ -249,11 +249,13 @@ def decoder_prepare(video, c3d, ev_start, ev_len, tokens, A, disjoint, params):
     V1, E = ps[0].shape
     De = ps[3].shape[1] - E                       # layer0.weight_ih is [4H, E + event_context_dim]
     logp = torch.empty(N, S, V1, device=c3d.device, dtype=torch.float32)
-    a = _dec_args(ps, c3d, ev_start, ev_len, None, video, tokens, A, S, None, logp, disjoint, n_de=(N, De))
+    # echr_dec_args.train: a backward pass can follow (decided here: grad mode is off inside the Function's forward)
+    train = 1 if (torch.is_grad_enabled() and any(p.requires_grad for p in params)) else 0
+    a = _dec_args(ps, c3d, ev_start, ev_len, None, video, tokens, A, S, None, logp, disjoint, n_de=(N, De), train=train)
     ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=c3d.device, dtype=torch.float32)
     a.ws = L.ptr(ws)
     L.check(lib.echr_decoder_fwd_prepare(C.byref(a), L.stream_ptr()), 'decoder_fwd_prepare')
-    return dict(ws=ws, logp=logp, video=video, c3d=c3d, ps=ps, tokens=tokens, A=A, disjoint=disjoint)
+    return dict(ws=ws, logp=logp, video=video, c3d=c3d, ps=ps, tokens=tokens, A=A, disjoint=disjoint, train=train)
 
 
 def decoder_prepare_cancel():
@@ -273,26 +275,28 @@ class DecoderFunction(torch.autograd.Function):
         S, N = tokens.shape
         if prep is not None:          # decoder_prepare() already ran the event-independent part on this workspace
             video, c3d, ps, logp, ws = prep['video'], prep['c3d'], prep['ps'], prep['logp'], prep['ws']
-            a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint, prepared=1)
+            train = prep['train']
+            a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint, prepared=1, train=train)
         else:
             video, c3d = _f32c(video), _f32c(c3d)
             ps = [_f32c(p) for p in params]
             V1 = ps[0].shape[0]
             logp = torch.empty(N, S, V1, device=event.device, dtype=torch.float32)
-            a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, None, logp, disjoint)
+            train = 1 if any(ctx.needs_input_grad) else 0
+            a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, None, logp, disjoint, train=train)
             ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=event.device, dtype=torch.float32)
             a.ws = L.ptr(ws)
         d = drop.c()
         L.check(lib.echr_decoder_fwd(C.byref(a), C.byref(d), L.stream_ptr()), 'decoder_fwd')
         ctx.save_for_backward(video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps)
-        ctx.meta = (A, S, drop, disjoint)
+        ctx.meta = (A, S, drop, disjoint, train)
         return logp
 
     @staticmethod
     def backward(ctx, g_logp):
         lib = L.load()
         video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps = ctx.saved_tensors
-        A, S, drop, disjoint = ctx.meta
+        A, S, drop, disjoint, train = ctx.meta
         # criterion gradient left here in sparse form by MaskedNLL.backward (LanguageModelCriterion on this node's output)
         pend = ctx.__dict__.pop('_echr_pending_nll', None)     # one entry per LanguageModelCriterion applied to this node's output
         fused = None
@@ -316,7 +320,7 @@ class DecoderFunction(torch.autograd.Function):
             grads[0].zero_()                                 # embedding table gradient is scatter-added
         g_event = torch.empty_like(event)
         g_video = torch.empty_like(video) if ctx.needs_input_grad[0] else None
-        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint)
+        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint, train=train)
         wsb = torch.empty(lib.echr_decoder_ws_bwd_floats(C.byref(a)), device=event.device, dtype=torch.float32)
         gp = [L.ptr(x) for x in grads]
         g = L.DecGrads(gp[0], gp[1], gp[2], (L.c_f * 3)(*gp[3:6]), (L.c_f * 3)(*gp[6:9]), (L.c_f * 3)(*gp[9:12]),

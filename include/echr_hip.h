@@ -198,6 +198,13 @@ typedef struct {
     /* output: log-probs [N,S,V1] */
     float* logp;
     int32_t prepared;                          /* echr_decoder_fwd only: 1 = echr_decoder_fwd_prepare already ran on this workspace */
+    int32_t train;                             /* 1 = echr_decoder_bwd will follow on this workspace: what only the backward pass reads and depends on
+                                                  parameters alone (the transposed h2 image of W_logit for d OUTD = d logits . W_logit) is packed by the
+                                                  forward's own packing launch, off the critical path in front of the reverse recurrence.  Pass the
+                                                  SAME value to echr_decoder_fwd_prepare / echr_decoder_fwd / echr_decoder_bwd.  0: the backward packs it */
+    float* zero_extra;                         /* echr_decoder_fwd / _prepare, optional: a range the caller wants zero-filled before the backward pass (its
+                                                  gradient arena), folded into the forward's first fill launch; NULL = none */
+    int64_t zero_extra_count;                  /* floats */
 } echr_dec_args;
 
 typedef struct {
@@ -239,6 +246,8 @@ typedef struct {
     int64_t zero_extra_count;                  /* floats */
     int32_t nll_target_i64;                    /* 1: nll_target points at int64 indices (the reference's LongTensor labels as they are: no
                                                   conversion pass), 0: int32 */
+    int32_t dlg_ready;                         /* 1: d logits already sit in ws_bwd (echr_train_step forms them in the pass that reads the logits:
+                                                  log-softmax + criterion + its gradient in one kernel); callers of echr_decoder_bwd leave it 0 */
 } echr_dec_grads;
 
 /* make `stream` wait for an asynchronous decoder-backward tail (echr_dec_grads.async_tail); no-op when none is pending */
