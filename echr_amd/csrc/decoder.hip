@@ -15,6 +15,7 @@
 //  * Because ss_prob == 0 (:36), the token/context halves of every W_ih product are batched over all
 //    S*N rows before the recurrence; only W_hh.h and the attended-context columns are sequential.
 #include <cstdlib>
+#include <cstring>
 #include "echr_common.h"
 #include "echr_internal.h"
 
@@ -66,16 +67,28 @@ static Side& side() {
 // backward pass depends on) can run on a second stream while autograd continues with the event encoder's / proposal encoder's
 // backward on the caller's stream.  The caller joins with echr_stream_join (the Python side does it in an end-of-backward callback);
 // every later library entry that takes a stream joins first as a safety net.
-struct Tail { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr, fork2 = nullptr, done2 = nullptr; bool ok = false, init = false, pending = false; };
+static bool helper_stream_create(hipStream_t* s) {
+    const char* e = getenv("ECHR_HELPER_PRIO");
+    if (e && !strcmp(e, "low")) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && hipStreamCreateWithPriority(s, hipStreamNonBlocking, least) == hipSuccess) return true;
+        (void)hipGetLastError();
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess;
+}
+struct Tail { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr, fork2 = nullptr, done2 = nullptr, done3 = nullptr; bool ok = false, init = false, pending = false, pending3 = false; };
 static Tail& tail() {
     static Tail t;
     if (!t.init) {
         t.init = true;
-        bool good = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess;
+        // (ECHR_HELPER_PRIO=low: least priority -- the helper streams carry chip-filling throughput kernels whose workgroups otherwise delay the
+        // dispatch of the caller's stream's small latency-bound kernels running beside them; A/B switch)
+        bool good = helper_stream_create(&t.s);
         good = good && hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
         good = good && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
         good = good && hipEventCreateWithFlags(&t.fork2, hipEventDisableTiming) == hipSuccess;
         good = good && hipEventCreateWithFlags(&t.done2, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.done3, hipEventDisableTiming) == hipSuccess;
         t.ok = good;
     }
     return t;
@@ -96,6 +109,10 @@ int join_tail(hipStream_t st) {
     if (t.ok && t.pending) {
         t.pending = false;
         if (hipStreamWaitEvent(st, t.done, 0) != hipSuccess) { set_error("stream join failed"); return -5; }
+    }
+    if (t.ok && t.pending3) {          // the LSTM-layer gradient stage of an echr_decoder_bwd with async_tail = 2 (on the prepare stream)
+        t.pending3 = false;
+        if (hipStreamWaitEvent(st, t.done3, 0) != hipSuccess) { set_error("stream join failed"); return -5; }
     }
     return 0;
 }
@@ -998,13 +1015,29 @@ static Prep& prep() {
     static Prep t;
     if (!t.init) {
         t.init = true;
-        bool good = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess;
+        bool good = helper_stream_create(&t.s);
         good = good && hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
         good = good && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
         t.ok = good;
     }
     return t;
 }
+// the prepare stream outside a forward pass (idle during the backward pass): a second helper stream for work that is independent of what the
+// caller's stream and the tail stream carry (the event encoder's position-MLP gradients, csrc/tsrm.hip).  fork: it continues after everything
+// queued on `from`; join: `to` waits for what was queued on it since.  nullptr / no-op when unavailable or when a prepare is pending.
+namespace echr {
+hipStream_t aux2_fork(hipStream_t from) {
+    Prep& pr = prep();
+    if (!pr.ok || pr.pending) return nullptr;
+    if (hipEventRecord(pr.fork, from) != hipSuccess || hipStreamWaitEvent(pr.s, pr.fork, 0) != hipSuccess) return nullptr;
+    return pr.s;
+}
+int aux2_join(hipStream_t to) {
+    Prep& pr = prep();
+    if (hipEventRecord(pr.done, pr.s) != hipSuccess || hipStreamWaitEvent(to, pr.done, 0) != hipSuccess) { set_error("stream join failed"); return -5; }
+    return 0;
+}
+}  // namespace echr
 // will echr_decoder_fwd run the persistent forward launch on these arguments (same test as there)?
 static bool fwd_uses_persist(const echr_dec_args* a) {
     const bool two = config().chains2 == 1 && side().ok && a->S >= 2;
@@ -1074,6 +1107,7 @@ static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, vo
     const int N = a->N, S = a->S, H = a->H, E = a->E;
     DecWs w = carve_ws(a, a->ws);
     const DropCfg dh = make_drop(drop, drop ? drop->p_h : 0.f), dout = make_drop(drop, drop ? drop->p_out : 0.f);
+    bool evb0_pending = false;
     if (a->prepared) {
         // echr_decoder_fwd_prepare already ran everything that does not need the event context on the library's second stream
         Prep& pr = prep();
@@ -1081,9 +1115,12 @@ static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, vo
         pr.pending = false;
         if (hipStreamWaitEvent(st, pr.done, 0) != hipSuccess) { set_error("decoder_fwd: join failed"); return -5; }
         RC(precompute_static(a, w, st, true, true, 2));
-        const long n4 = (long)S * N * H;            // 4H / 4 float4 per row
-        hipLaunchKernelGGL(add_bcast_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.GATES[0], w.EVB0, (long)S * N, (long)N, H);
-        RC(check_launch("add_bcast_rows"));
+        evb0_pending = fwd_uses_persist(a) && persist_fwd_adds_evb0();      // the persistent launch's LSTM role adds the event part itself
+        if (!evb0_pending) {
+            const long n4 = (long)S * N * H;            // 4H / 4 float4 per row
+            hipLaunchKernelGGL(add_bcast_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, w.GATES[0], w.EVB0, (long)S * N, (long)N, H);
+            RC(check_launch("add_bcast_rows"));
+        }
     } else {
         RC(decoder_fill(a, w, st));
         RC(precompute_static(a, w, st, true, true));
@@ -1122,6 +1159,7 @@ static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, vo
         for (int k = 0; k < 3; ++k) { pb.GATES[k] = w.GATES[k]; pb.CS[k] = w.CS[k]; }
         pb.HS = w.HS; pb.OUTD = w.OUTD; pb.QS = w.QS; pb.WT = w.WT; pb.ATT = w.ATT; pb.PALL = w.PALL; pb.xws = w.XWS;
         pb.prezeroed = true;                    // decoder_fill covered the exchange workspace's zeroed part
+        if (evb0_pending) pb.EVB0 = w.EVB0;
         RC(persist_fwd(a, pb, dh, dout, st));
     } else if (two) {
         RC(hop(st, side().fork, side().s));
@@ -1361,8 +1399,58 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     }
     // 4. batched parameter gradients, part A: everything of the three LSTM layers (core.layer0..2) -- final after this block, so a
     //    data-parallel caller can start reducing them (phase 3) while part B runs
+    // async_tail = 2: only d event (what the caller's next backward kernels, the event encoder's, wait for) is formed on the caller's stream,
+    // first; the rest of part A -- nine transposing packs, the grouped weight-gradient product, bias sums, the context halves of W_ih: ~0.13 ms
+    // -- moves to the prepare stream (idle during a backward pass) and is joined by echr_stream_join like the tail
+    hipStream_t sa2 = nullptr;
     auto part_a = [&]() -> int {
     if (!do_rec) return 0;
+    if (g->phase == 0 && g->async_tail == 2 && z && h2 && !ov && tail().ok) {
+        RC(sum_over_time(b.DG[0], 4 * H, S, N, 4 * H, b.DGSUM[0], 4 * H, st));
+        d = desc_nn(b.DGSUM[0], 4 * H, a->w_ih[0] + E, cin[0], g->g_event, a->De, N, a->De, 4 * H);
+        d.split_k = -1; d.beta = 1.f;
+        RC(gemm(d, st));
+        sa2 = aux2_fork(st);
+        if (sa2) {
+            RC(wgrad_chunk(0, S, 1.f, sa2));
+            const ColsumJob cj[4] = {{b.DQ, Ha, SN, Ha, g->g_b_h2a, nullptr, nullptr},
+                                     {b.DG[0], 4 * H, SN, 4 * H, g->g_b_ih[0], g->g_b_hh[0], nullptr},
+                                     {b.DG[1], 4 * H, SN, 4 * H, g->g_b_ih[1], g->g_b_hh[1], nullptr},
+                                     {b.DG[2], 4 * H, SN, 4 * H, g->g_b_ih[2], g->g_b_hh[2], b.DGCOL[2]}};
+            RC(colsum_multi(cj, 4, sa2));
+            d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);
+            d.beta = zb; d.split_k = -1;
+            RC(gemm(d, sa2));
+            d = desc_tn(b.DGCOL[2], 4 * H, a->video, a->Dv, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, 1);
+            RC(gemm(d, sa2));
+            if (g->g_video) {
+                d = desc_nn(b.DGCOL[2], 4 * H, a->w_ih[2] + E, cin[2], g->g_video, a->Dv, 1, a->Dv, 4 * H);
+                d.split_k = -1;
+                RC(gemm(d, sa2));
+            }
+            if (hipEventRecord(tail().done3, sa2) != hipSuccess) { set_error("decoder_bwd: event record failed"); return -5; }
+            tail().pending3 = true;
+            return 0;
+        }
+        // (no second helper stream: the rest follows on the caller's stream; d event is already there)
+        RC(wgrad_chunk(0, S, 1.f, st));
+        const ColsumJob cj[4] = {{b.DQ, Ha, SN, Ha, g->g_b_h2a, nullptr, nullptr},
+                                 {b.DG[0], 4 * H, SN, 4 * H, g->g_b_ih[0], g->g_b_hh[0], nullptr},
+                                 {b.DG[1], 4 * H, SN, 4 * H, g->g_b_ih[1], g->g_b_hh[1], nullptr},
+                                 {b.DG[2], 4 * H, SN, 4 * H, g->g_b_ih[2], g->g_b_hh[2], b.DGCOL[2]}};
+        RC(colsum_multi(cj, 4, st));
+        d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);
+        d.beta = zb; d.split_k = -1;
+        RC(gemm(d, st));
+        d = desc_tn(b.DGCOL[2], 4 * H, a->video, a->Dv, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, 1);
+        RC(gemm(d, st));
+        if (g->g_video) {
+            d = desc_nn(b.DGCOL[2], 4 * H, a->w_ih[2] + E, cin[2], g->g_video, a->Dv, 1, a->Dv, 4 * H);
+            d.split_k = -1;
+            RC(gemm(d, st));
+        }
+        return 0;
+    }
     if (ov) RC(hop(sq, side().join, st));                     // chunk [th,S) and the logit gradients are complete
     RC(wgrad_chunk(0, th_b, (ov || z) ? 1.f : 0.f, st));      // W_hh_k, W_ih_k[:, :E], W_ih1[:, E:], W_h2a: sums over timesteps
     //    bias gradients b_h2a and per stream b_ih = b_hh = column sums of DG_k over all S*N rows (stream 2's also as the plain vector

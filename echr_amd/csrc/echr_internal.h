@@ -30,7 +30,9 @@ bool deterministic_gemm();
 
 // persistent (one launch for all timesteps) recurrence of the decoder, csrc/persist.hip
 struct DropCfg;
-struct PersistFwdBufs { float* GATES[3]; float* CS[3]; float *HS, *OUTD, *QS, *WT, *ATT, *PALL, *xws; bool prezeroed = false; };
+struct PersistFwdBufs { float* GATES[3]; float* CS[3]; float *HS, *OUTD, *QS, *WT, *ATT, *PALL, *xws; bool prezeroed = false;
+                        const float* EVB0 = nullptr; };      // EVB0: event part of stream 0's gates, still to be added (persist_fwd_adds_evb0)
+bool persist_fwd_adds_evb0();          // the persistent forward launch can add EVB0 itself (fp16-pair LSTM role)
 void persist_fwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, long* count);
 long persist_fwd_ws_floats(int S);
 bool persist_fwd_eligible(const echr_dec_args* a);
@@ -59,6 +61,8 @@ unsigned* persist_host_flag();          // device view of the host-mapped flag p
 // after everything queued on `from` and returns it, `aux_join` makes `to` wait for what was queued on it since
 hipStream_t aux_fork(hipStream_t from);          // nullptr when unavailable
 int aux_join(hipStream_t to);
+hipStream_t aux2_fork(hipStream_t from);         // the same on the decoder's prepare stream (idle during a backward pass); nullptr when unavailable
+int aux2_join(hipStream_t to);
 int join_tail(hipStream_t st);          // make st wait for an asynchronous decoder-backward tail (decoder.hip); no-op when none is pending
 int persist_read_stamps(unsigned long long* dst, int max_entries);
 unsigned long long* persist_stamp_buffer(int S, hipStream_t st);      // diagnostic: [4][S <= 256][16] stamps, zeroed on st (nullptr: unavailable)

@@ -77,6 +77,7 @@ static PersistLayout persist_layout(int S) {
 long persist_fwd_ws_floats(int S);
 
 struct PersistK {
+    const float* evb0;             // optional [N][4H]: event part of stream 0's gate pre-activations, added by the LSTM role itself (nullptr: GATES[0] already holds it)
     int N, A, D, S, ld_att;
     const float* w_hh[3]; const float* w_h2a; const float* b_h2a; const float* w_att; const float* w_alpha;
     const float* PALL; const float* c3d; const int* ev_start; const int* ev_len;
@@ -1579,6 +1580,14 @@ __device__ __forceinline__ void dec_persist_lstm_h2_body(const PersistK& P, cons
     // gate-math ownership in round (rb, cb): thread -> (row 32 rb + (tid >> 3), unit 16 bs + 8 cb + (tid & 7))
     const int gr = tid >> 3, g8 = tid & 7;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    // stream 0: the event part of the gate pre-activations (time-invariant) is added here instead of by a pass over GATES[0] in front of the launch
+    float evb[4][4];
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+        const int n = 32 * (rd >> 1) + gr, j = 16 * bs + 8 * (rd & 1) + g8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) evb[rd][g] = (k == 0 && P.evb0) ? P.evb0[(long)min(n, N - 1) * 4 * PH + g * PH + j] : 0.f;
+    }
     const u32 XB = PROWS * PH * 4;
     const bool st_on = b == 0;
     for (int t = 0; t < S; ++t) {
@@ -1589,7 +1598,7 @@ __device__ __forceinline__ void dec_persist_lstm_h2_body(const PersistK& P, cons
             const int n = 32 * (rd >> 1) + gr, j = 16 * bs + 8 * (rd & 1) + g8;
             const float* grow = P.GATES[k] + ((long)t * N + min(n, N - 1)) * 4 * PH + j;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[rd][g] = grow[g * PH];
+            for (int g = 0; g < 4; ++g) pre[rd][g] = grow[g * PH] + evb[rd][g];
             mh[rd] = mask_h(P.dh, n, j, k, t);
             mo[rd] = mask_o(P.dout, n, j, k, t);
         }
@@ -3194,6 +3203,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     K.w_h2a = a->w_h2a; K.b_h2a = a->b_h2a; K.w_att = a->w_ih[1] + a->E; K.w_alpha = a->w_alpha;
     K.PALL = B.PALL; K.c3d = a->c3d; K.ev_start = a->ev_start; K.ev_len = a->ev_len;
     K.HS = B.HS; K.OUTD = B.OUTD; K.QS = B.QS; K.WT = B.WT; K.ATT = B.ATT;
+    K.evb0 = config().persist_h2 ? B.EVB0 : nullptr;          // (only the fp16-pair LSTM role adds it: see persist_fwd_adds_evb0)
     const bool split = config().persist_split != 0;
     const PersistLayout2 L2 = persist_layout2(a->S);
     float* x2 = B.xws;                                  // version-2 layout first (its zeroed region last), version 1 behind it
@@ -3369,7 +3379,7 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
     for (int k = 0; k < 3; ++k) { K.w_hh[k] = a->w_hh[k]; K.GATES[k] = nullptr; K.CS[k] = nullptr; }
     K.w_h2a = a->w_h2a; K.b_h2a = a->b_h2a; K.w_att = a->w_ih[1] + a->E; K.w_alpha = a->w_alpha;
     K.PALL = B.PALL; K.c3d = a->c3d; K.ev_start = a->ev_start; K.ev_len = a->ev_len;
-    K.HS = nullptr; K.OUTD = nullptr; K.QS = nullptr; K.WT = nullptr; K.ATT = nullptr;
+    K.HS = nullptr; K.OUTD = nullptr; K.QS = nullptr; K.WT = nullptr; K.ATT = nullptr; K.evb0 = nullptr;
     float* x2 = B.xws;
     float* x = x2 + L2.total;
     K.cnt = reinterpret_cast<u32*>(x + L.cnt); K.XC = x + L.xc; K.XS = x + L.xs; K.GRAN = reinterpret_cast<unsigned long long*>(x + L.gran);
@@ -3429,6 +3439,10 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
     return 0;
 }
 
+bool persist_fwd_adds_evb0() {
+    static const bool off = [] { const char* e = getenv("ECHR_EVB0_FOLD"); return e && e[0] == '0'; }();      // A/B switch (tools/ab_env.sh)
+    return config().persist_h2 != 0 && !off;
+}
 bool persist_bwd_eligible(const echr_dec_args* a) { return config().persist_bwd && persist_shape_ok(a); }
 
 void persist_bwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, long* count) {

@@ -6,6 +6,7 @@
 // clamp + Adam); what this file adds is the sequencing that echr_amd/functional.py + autograd otherwise do from Python -- ~75 ctypes
 // calls, four autograd nodes and their callbacks per iteration, 1.2 ms of host time against 1.75 ms of GPU time -- as host C++:
 // one call, the index vectors staged through a pinned ring, every buffer carved from one caller-owned workspace.
+#include <cstdlib>
 #include <cstring>
 
 #include "echr_common.h"
@@ -14,6 +15,11 @@
 namespace echr {
 
 static inline long up64(long n) { return (n + 63) / 64 * 64; }
+// echr_dec_grads.async_tail of the step's backward: 2 (default) = only d event on the caller's stream, 1 = the tail alone (ECHR_ASYNC_LEVEL: A/B)
+static int async_level() {
+    static const int lv = [] { const char* e = getenv("ECHR_ASYNC_LEVEL"); return (e && e[0] == '1') ? 1 : 2; }();
+    return lv;
+}
 
 struct StepWs { long idx, ech, tsrm_ws, event, logp, dec_ws, dec_ws_bwd, g_event, g_ech, tsrm_ws_bwd, total; };
 
@@ -113,7 +119,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     g.g_event = ws + L.g_event; g.g_logp = nullptr;
     g.nll_target = static_cast<const int32_t*>(a->nll_target); g.nll_target_i64 = a->nll_target_i64; g.nll_mask = a->nll_mask;
     g.g_loss = a->g_loss; g.nll_msum = a->loss + 1;
-    g.ws_bwd = ws + L.dec_ws_bwd; g.zeroed = 1; g.phase = 0; g.async_tail = 1;
+    g.ws_bwd = ws + L.dec_ws_bwd; g.zeroed = 1; g.phase = 0; g.async_tail = async_level();
     // forward (:30) + LanguageModelCriterion (misc/utils.py:66-75).  Training: log-softmax, criterion and its gradient are ONE pass over the
     // logits (d logits land in the backward workspace, the log-probs are never written; the loss is summed behind the backward pass, where
     // this stream waits for the helper stream anyway).  forward_only: the plain log-softmax + criterion, loss[0] = loss, loss[1] = sum(mask)

@@ -9,6 +9,7 @@
 // weight is applied to the features first (XW = X . Wout^T, one [N,Df]x[Df,Do] GEMM) and each head then
 // mixes its own dgo-column slice of XW -- same math, 1/G of the flops, fp32 rounding differs at 1e-7.
 #include <cmath>
+#include <cstdlib>
 #include "echr_common.h"
 #include <atomic>
 #include "echr_internal.h"
@@ -591,6 +592,28 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
     hipLaunchKernelGGL(tsrm_softmax_bwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, b.DWD, b.DGATE, b.DAFF, N, G, dc);
     RC(check_launch("tsrm_softmax_bwd"));
+    // The position-MLP gradients (d W_fc2, d P1, d W_fc1: 4.3 GF over the N^2 pairs) depend on d GATE alone: they run on the decoder's
+    // prepare stream -- idle during a backward pass -- beside the query / key / embedding chain below (ten dependent small launches)
+    static const bool fork2_off = [] { const char* e = getenv("ECHR_TSRM_FORK2"); return e && e[0] == '0'; }();      // A/B switch
+    hipStream_t sp = (config().tsrm_fork && !fork2_off) ? aux2_fork(st) : nullptr;
+    const bool fork2 = sp != nullptr;
+    if (!fork2) sp = st;
+    {
+        // position MLP (depends on d GATE only)
+        d = desc_tn(b.DGATE, G, w.P1, Df, g->g_w_fc2, Df, G, Df, NN); d.beta = zb; d.split_k = -1;
+        RC(gemm(d, sp));
+        d = desc_nn(b.DGATE, G, a->w_fc2, Df, b.DP1, Df, NN, Df, G); d.act = ECHR_ACT_MUL_DTANH; d.aux = w.P1; d.ld_aux = Df;
+        RC(gemm(d, sp));
+        if (config().gemm_h2 && NN >= 1024) {
+            H2PackJob pj[2] = {pack_cols(b.DP1, Df, Df, NN, b.PK_DP1T), pack_cols(w.POS, Df, Df, NN, b.PK_POST)};
+            RC(h2_pack_multi(pj, 2, sp));
+            d = desc_h2(b.PK_DP1T, b.PK_POST, g->g_w_fc1, Df, Df, Df, NN);
+        } else {
+            d = desc_tn(b.DP1, Df, w.POS, Df, g->g_w_fc1, Df, Df, Df, NN); d.split_k = -1;
+        }
+        d.beta = zb;
+        RC(gemm(d, sp));
+    }
     // dQ_g = scale * dAFF_g . K_g ; dK_g = scale * dAFF_g^T . Q_g
     d = desc_nn(b.DAFF, N, w.K, Df, b.DQ, Df, N, dgq, N);
     d.batch = G; d.bsa = (long)NN; d.bsb = dgq; d.bsc = dgq; d.alpha = scale;
@@ -618,23 +641,10 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
         if (Do == Df) RC(gemm_grouped(w3, 3, st));
         else for (int i = 0; i < 3; ++i) RC(gemm(w3[i], st));
     }
-    // position MLP
-    d = desc_tn(b.DGATE, G, w.P1, Df, g->g_w_fc2, Df, G, Df, NN); d.beta = zb; d.split_k = -1;
-    RC(gemm(d, st));
-    d = desc_nn(b.DGATE, G, a->w_fc2, Df, b.DP1, Df, NN, Df, G); d.act = ECHR_ACT_MUL_DTANH; d.aux = w.P1; d.ld_aux = Df;
-    RC(gemm(d, st));
-    if (config().gemm_h2 && NN >= 1024) {
-        H2PackJob pj[2] = {pack_cols(b.DP1, Df, Df, NN, b.PK_DP1T), pack_cols(w.POS, Df, Df, NN, b.PK_POST)};
-        RC(h2_pack_multi(pj, 2, st));
-        d = desc_h2(b.PK_DP1T, b.PK_POST, g->g_w_fc1, Df, Df, Df, NN);
-    } else {
-        d = desc_tn(b.DP1, Df, w.POS, Df, g->g_w_fc1, Df, Df, Df, NN); d.split_k = -1;
-    }
-    d.beta = zb;
-    RC(gemm(d, st));
     // event embedding
     d = desc_tn(b.DX, Df, a->ech, Din, g->g_w_emb, Din, Df, Din, N); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
+    if (fork2) RC(aux2_join(st));
     // bias gradients: all six column sums in one launch when the gradient buffers accumulate
     if (z) {
         const ColsumJob cj[6] = {{g->g_out, Do, N, Do, g->g_b_out, nullptr, nullptr}, {b.DQ, Df, N, Df, g->g_b_q, nullptr, nullptr},

@@ -66,6 +66,7 @@ def rows_disjoint(soi_select_list):
 
 
 FUSED_NLL = [os.environ.get('ECHR_FUSED_NLL', '1') != '0']        # see MaskedNLL.backward
+ASYNC_LEVEL = [1 if os.environ.get('ECHR_ASYNC_LEVEL', '2') == '1' else 2]
 ASYNC_TAIL = [os.environ.get('ECHR_ASYNC_TAIL', '1') != '0']        # decoder backward: run the last stage on a second stream (arena path); tests may switch it off
 
 
@@ -351,6 +352,10 @@ class DecoderFunction(torch.autograd.Function):
             # (not when a parameter hook would read those gradients inside the backward pass, nor under create_graph, where autograd may
             # clone them: the gradients must then be final when this Function returns)
             g.async_tail = 1 if (zeroed and ASYNC_TAIL[0] and not ctx.sink.has_hooks() and not torch.is_grad_enabled()) else 0
+            if g.async_tail and hook is None and ASYNC_LEVEL[0] == 2:
+                # no data-parallel hand-over waits for the LSTM-layer gradients: only d event is formed on this stream, the rest of that stage
+                # runs on the library's second helper stream and is joined with the tail by the end-of-backward callback
+                g.async_tail = 2
             L.check(lib.echr_decoder_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'decoder_bwd')
             if hook is not None:
                 # data parallel, one-call form: the LSTM-layer gradients (and everything else part A of the backward produced) are final in

@@ -237,7 +237,10 @@ typedef struct {
                                                   overlap it; the logit-layer gradients are formed there too.  The caller MUST call
                                                   echr_stream_join(stream) before anything reads g_w_logit, g_b_logit, g_w_c2a,
                                                   g_b_c2a, g_w_alpha, g_b_alpha, g_embed or frees ws / ws_bwd (every library entry that takes a
-                                                  stream joins first as a safety net). */
+                                                  stream joins first as a safety net).
+                                                  2 = additionally only g_event (and what it needs) is formed on `stream`; every other gradient
+                                                  of the three LSTM layers (g_w_ih, g_w_hh, g_b_ih, g_b_hh, g_w_h2a, g_b_h2a, g_video) is formed on
+                                                  a second library-owned stream and is final only after echr_stream_join as well (needs zeroed = 1) */
     const float* nll_msum;                     /* fused criterion path, optional: device pointer to sum(nll_mask) (the second output of
                                                   echr_nll_loss_fwd); NULL = the library sums the mask itself */
     float* zero_extra;                         /* optional: a range the caller wants zero-filled before any gradient is written (its gradient
