@@ -106,7 +106,7 @@ def gpu_leg(args, rank, world, local_rank):
     # for the one-call form there too (backward inside the call, then ONE collective, then clip + step)
     fused = None
     want_fused = args.fused == 'on' or (args.fused == 'auto' and not use_dist)
-    if want_fused and arena is not None and not args.c5 and args.mode == 'train':
+    if want_fused and arena is not None and not args.c5:
         from echr_amd.fused import FusedTrainStep
         fused = FusedTrainStep(model, optim, grad_clip=opt.grad_clip)
 
@@ -114,6 +114,8 @@ def gpu_leg(args, rank, world, local_rank):
         if args.c5:
             return c5_iteration()
         if args.mode == 'fwd':
+            if fused is not None:          # forward + criterion only (BASELINE config 2), same one-call entry
+                return fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, forward_only=True)
             return fwd_only()
         if fused is not None:
             if not use_dist:
@@ -221,26 +223,26 @@ def gpu_leg(args, rank, world, local_rank):
         lib.echr_prof_enable(0)
         # HBM traffic per launch cannot be collected inside a timed run (PMC needs rocprofv3 --pmc in separate passes): it is read from
         # the committed summary of the SAME command (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.json); null when absent
-        traffic, traffic_src = {}, None
-        for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
-            try:
-                traffic = json.load(open(os.path.join(ROOT, 'profiles', name)))
-                traffic_src = 'profiles/' + name
-                break
-            except Exception:
-                pass
-        # MFMA activity (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles of the dispatch) likewise comes from the committed --pmc pass of the
-        # same command (tools/pmc_mfma.sh -> profiles/r02_pmc_mfma.json)
-        mfma_pmc = {}
-        for name in ('r03_pmc_mfma.json', 'r02_pmc_mfma.json'):
-            try:
-                mfma_pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
-                break
-            except Exception:
-                pass
+        # (one pair of files per workload: `_c5` for --c5; other variants -- overlapping rows, forward only -- carry no counters)
+        sfx = '_c5' if args.c5 else ''
+        traffic, traffic_src, mfma_pmc = {}, None, {}
+        if not (args.overlap or args.mode != 'train'):
+            for name in ['r04_pmc_traffic%s.json' % sfx] + ([] if args.c5 else ['r03_pmc_traffic.json', 'r02_pmc_traffic.json']):
+                try:
+                    traffic = json.load(open(os.path.join(ROOT, 'profiles', name)))
+                    traffic_src = 'profiles/' + name
+                    break
+                except Exception:
+                    pass
+            # MFMA activity (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles of the dispatch) likewise comes from the committed --pmc pass of the
+            # same command (tools/pmc_mfma.sh -> profiles/r04_pmc_mfma.json)
+            for name in ['r04_pmc_mfma%s.json' % sfx] + ([] if args.c5 else ['r03_pmc_mfma.json', 'r02_pmc_mfma.json']):
+                try:
+                    mfma_pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
+                    break
+                except Exception:
+                    pass
         traffic_commit = traffic.get('_commit') if isinstance(traffic, dict) else None
-        if args.c5 or args.overlap or args.mode != 'train':
-            traffic, mfma_pmc = {}, {}          # the committed counter summaries were collected on the default (c3) workload only
 
         def mfma_busy(name):
             if name == 'dec_persist_kernels':           # time-weighted over the four kernels of the two pairs

@@ -4,7 +4,7 @@
 #   <tag>_pmc_traffic.json / <tag>_pmc_mfma.json (separate --pmc passes, commit hash stored inside), <tag>_rocprof_kernel_stats_final.txt
 #   (rocprofv3 --kernel-trace --stats of the bench command), <tag>_bench_final.json (the bench line, written AFTER the PMC files so that
 #   it carries their traffic numbers), the same pair for --c5, and the greedy decoder's kernel stats / timings / stamps.  Results land in gpurun_out/<tag>_profiles/ (copy them into profiles/).
-tag=${1:-r03}; commit=${2:-unknown}
+tag=${1:-r04}; commit=${2:-unknown}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/${tag}_profiles
 rm -rf $out; mkdir -p $out
@@ -14,6 +14,12 @@ python3 tools/pmc_traffic_summary.py gpurun_out/${tag}_pmc_traffic_raw $commit >
 bash tools/pmc_mfma.sh ${tag}_pmc_mfma_raw > $out/pmc_mfma.log 2>&1
 python3 tools/pmc_mfma_summary.py gpurun_out/${tag}_pmc_mfma_raw $commit > $out/${tag}_pmc_mfma.json && cp $out/${tag}_pmc_mfma.json profiles/
 rm -rf gpurun_out/${tag}_pmc_traffic_raw gpurun_out/${tag}_pmc_mfma_raw
+# the same two counter sets on BASELINE config 5 (bench.py --c5: the BIG persistent kernels, the proposal encoder's persistent kernels)
+bash tools/pmc_traffic.sh ${tag}_pmc_traffic_raw5 --c5 > $out/pmc_traffic_c5.log 2>&1
+python3 tools/pmc_traffic_summary.py gpurun_out/${tag}_pmc_traffic_raw5 $commit > $out/${tag}_pmc_traffic_c5.json && cp $out/${tag}_pmc_traffic_c5.json profiles/
+bash tools/pmc_mfma.sh ${tag}_pmc_mfma_raw5 --c5 > $out/pmc_mfma_c5.log 2>&1
+python3 tools/pmc_mfma_summary.py gpurun_out/${tag}_pmc_mfma_raw5 $commit > $out/${tag}_pmc_mfma_c5.json && cp $out/${tag}_pmc_mfma_c5.json profiles/
+rm -rf gpurun_out/${tag}_pmc_traffic_raw5 gpurun_out/${tag}_pmc_mfma_raw5
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $root/bench.py --steps 12 --warmup 3 --no-cpu --no-roofline --no-native > $out/prof.log 2>&1
 python3 $root/tools/prof_summary.py $out/prof 15 40 > $out/${tag}_rocprof_kernel_stats_final.txt
@@ -30,4 +36,11 @@ cd $root
   echo "# in-kernel stamps of the persistent decoder (tools/sample_stamps.py)"; timeout -k 10 200 python3 tools/sample_stamps.py 2>/dev/null | grep -v amdgpu; } > $out/${tag}_sampler.txt
 timeout -k 10 400 python3 bench.py > $out/${tag}_bench_final.json 2> $out/bench.err; echo bench_exit=$?
 timeout -k 10 400 python3 bench.py --c5 > $out/${tag}_bench_c5.json 2> $out/bench5.err; echo bench5_exit=$?
+# BASELINE config 2 (forward + criterion only, train-mode dropout): bench line and kernel stats
+timeout -k 10 300 python3 bench.py --mode fwd --no-cpu > $out/${tag}_bench_c2.json 2> $out/bench2.err; echo bench2_exit=$?
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof2 -- python3 $root/bench.py --mode fwd --steps 12 --warmup 3 --no-cpu --no-roofline --no-native > $out/prof2.log 2>&1
+python3 $root/tools/prof_summary.py $out/prof2 15 30 > $out/${tag}_rocprof_kernel_stats_c2.txt; rm -rf $out/prof2
+cd $root
+timeout -k 10 120 python3 tools/host_time.py > $out/${tag}_host_time.txt 2>&1; timeout -k 10 120 python3 tools/host_time.py autograd >> $out/${tag}_host_time.txt 2>&1
 ls -la $out
