@@ -36,7 +36,7 @@ Config& config() {
     static Config c = {env_int("ECHR_GEMM_BF16X3", 1), env_int("ECHR_OVERLAP", 0), env_int("ECHR_ATT_SLOTS", 2), env_int("ECHR_CHAINS2", 0),
                        env_int("ECHR_GEMM_H2", 1), env_int("ECHR_PERSIST", 1), env_int("ECHR_PERSIST_STAMPS", 0),
                        getenv("ECHR_GEMM_TILE") ? (int)getenv("ECHR_GEMM_TILE")[0] : 0, env_int("ECHR_GEMM_SPLIT", 0), env_int("ECHR_PERSIST_BWD", 1), env_int("ECHR_PERSIST_SPLIT", 1), env_int("ECHR_PERSIST_H2", 1), env_int("ECHR_PERSIST_MERGE", 1), env_int("ECHR_PERSIST_KGROUPS", 1), env_int("ECHR_TSRM_FORK", 1),
-                       env_int("ECHR_PERSIST_COOP", 0), 0, env_int("ECHR_PERSIST_SPIN_LIMIT", 0), env_int("ECHR_SST_PERSIST", 1), env_int("ECHR_TAIL_EARLY", 0), 0, env_int("ECHR_EMBED_FUSED", 0), env_int("ECHR_PERSIST_SAMPLE", 1), env_int("ECHR_POSEMB_ROWS", 1), env_int("ECHR_GEMM_SKINNY", 1), env_int("ECHR_POSEMB_PACKED", 1), env_int("ECHR_PAIR_TABLES", 1), 0};
+                       env_int("ECHR_PERSIST_COOP", 0), 0, env_int("ECHR_PERSIST_SPIN_LIMIT", 0), env_int("ECHR_SST_PERSIST", 1), env_int("ECHR_TAIL_EARLY", 0), 0, env_int("ECHR_EMBED_FUSED", 0), env_int("ECHR_PERSIST_SAMPLE", 1), env_int("ECHR_POSEMB_ROWS", 1), env_int("ECHR_GEMM_SKINNY", 1), env_int("ECHR_POSEMB_PACKED", 1), env_int("ECHR_PAIR_TABLES", 1), 0, env_int("ECHR_PERSIST_SAMPLE_MAX", 512)};
     return c;
 }
 
@@ -983,6 +983,7 @@ extern "C" int echr_config_set(const char* key, int32_t value) {
     else if (!strcmp(key, "posemb_packed")) c.posemb_packed = value;
     else if (!strcmp(key, "pair_tables")) c.pair_tables = value;
     else if (!strcmp(key, "persist_sample_force_eos")) c.persist_sample_force_eos = value;
+    else if (!strcmp(key, "persist_sample_max")) c.persist_sample_max = value;
     else if (!strcmp(key, "persist_inject_timeout")) c.persist_inject_timeout = value;
     else if (!strcmp(key, "persist_spin_limit")) c.persist_spin_limit = value;
     else if (!strcmp(key, "gemm_tile")) c.gemm_tile = value;          // tuning only: ASCII code of the tile selector ('1','6','a','b','c','s'), 0 = heuristics

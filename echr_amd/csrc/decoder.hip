@@ -977,14 +977,15 @@ static int step_fwd(const echr_dec_args* a, const DecWs& w, int t, const DropCfg
 }
 
 // input-side gate pre-activations for `rows` = nt*N token rows starting at timestep t0
-static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, int t0, int nt, hipStream_t st, bool no_evb0 = false, bool force_h2 = false) {
+static int input_gates(const echr_dec_args* a, const DecWs& w, const float* xt, int t0, int nt, hipStream_t st, bool no_evb0 = false, bool force_h2 = false,
+                       bool xt_packed = false) {
     const int N = a->N, H = a->H, E = a->E;
     const int rows = nt * N;
     const int cin[3] = {E + a->De, E + a->D, E + a->Dv};
     echr_gemm_desc d[3];
     // the teacher-forced call (all S*N token rows at once), or a sampler step over many events (force_h2: PK_WIH packed by the caller)
     const bool h2 = config().gemm_h2 && ((xt == w.XT && t0 == 0 && nt == a->S) || force_h2);
-    if (h2) {
+    if (h2 && !xt_packed) {
         H2PackJob pj = pack_rows(xt, E, rows, E, w.PK_XT);
         RC(h2_pack_multi(&pj, 1, st));
     }
@@ -1574,7 +1575,9 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
 // ------------------------------------------------------------------------------------------------------
 // greedy sampler (OldModel_NEW.py:139-187, sample_max = 1, eval mode): every step on device
 // ------------------------------------------------------------------------------------------------------
-struct SampWs { float* XT; float* LOGITS; int *IT, *UNF; float* SLABS; float *TABLES, *PSWS, *PSX; long total; };
+struct SampWs { float* XT; float* LOGITS; int *IT, *UNF; float* SLABS; float *TABLES, *PSWS, *PSX;
+                // many events, launch-per-step form: h2 images of the recurrent weights (packed once per decode) and of the step's h / context rows
+                float *PK_WHH[3], *PK_WH2A, *PK_WATT, *PK_H[3], *PK_ATT; long total; };
 // parameter-only operands of the persistent greedy decoder (csrc/persist.hip, PersistS): the token-side gate tables, the packed embedding
 // they are made from and the logit-weight image -- cacheable across calls while the parameters do not change (echr_sample_args.tables)
 struct SampTables { float *TG[3], *PK_EMB, *LIMG; long total; };
@@ -1612,8 +1615,75 @@ static SampWs carve_samp(const echr_dec_args* a, float* base) {
     const long groups = (a->N + 63) / 64;          // the persistent decoder runs one launch per group of 64 events, each on its own workspaces
     s.PSWS = take(ps ? groups * persist_sample_ws_floats(a->S, a->V1) : 64);
     s.PSX = take(ps ? groups * persist_sample_x_floats(a->S) : 64);
+    const bool bigw = a->N >= SAMP_SLAB_ROWS;          // (by shape only)
+    for (int k = 0; k < 3; ++k) s.PK_WHH[k] = take(bigw ? h2_floats(4 * a->H, a->H) : 64);
+    s.PK_WH2A = take(bigw ? h2_floats(a->Ha, a->H) : 64);
+    s.PK_WATT = take(bigw ? h2_floats(4 * a->H, a->D) : 64);
+    for (int k = 0; k < 3; ++k) s.PK_H[k] = take(bigw ? h2_floats(a->N, a->H) : 64);
+    s.PK_ATT = take(bigw ? h2_floats(a->N, a->D) : 64);
     s.total = off;
     return s;
+}
+// which form echr_decoder_sample takes for greedy decoding: the persistent launches (one per 64 events: latency-optimal, 22 us per step and
+// group) up to "persist_sample_max" events, beyond that -- evaluation over hundreds of proposals -- one batched launch chain per step
+// whose products all run as h2 GEMMs over the N rows (throughput-optimal: the 16 groups of N = 1000 would queue up behind each other)
+static bool sample_uses_persistent(const echr_dec_args* a) {
+    if (!persist_sample_eligible(a)) return false;
+    const int mx = config().persist_sample_max;
+    return !(config().gemm_h2 && mx > 0 && a->N > mx && a->N >= SAMP_SLAB_ROWS);
+}
+
+// One decoder timestep over MANY events (evaluation: hundreds of proposals; launch-per-step greedy decoding).  step_fwd's grouped skinny
+// products are built for N <= 64 rows (K split over workgroups, fp32 MFMA: 94 us per launch at N = 1000); here every product is an h2 GEMM over
+// the N rows with ONE fixed-order k loop per tile (bitwise reproducible): GATES[k][t] (which holds the token-side pre-activations) += h_k(t-1) .
+// W_hh_k^T and q(t) += h1(t-1) . W_h2a^T (its own zero-filled slab) as one grouped launch, then the attention kernels, then GATES[1][t] += ctx . W_ih1[:, E:]^T.
+static int step_fwd_big(const echr_dec_args* a, const DecWs& w, const SampWs& s, int t, const DropCfg& dh, const DropCfg& dout, hipStream_t st) {
+    const int N = a->N, H = a->H, Ha = a->Ha, A = a->A, D = a->D;
+    const float* hprev = w.HS + (long)t * N * 3 * H;          // [N,3H] h of step t-1 (zeros at t = 0)
+    const long gs = (long)N * 4 * H, qs = (long)N * Ha;
+    (void)hprev;
+    float* qt = w.QACC + (long)t * qs;          // this step's q: its own zero-filled slab (the caller cleared QACC once), so the product accumulates
+    if (t > 0) {          // (h(-1) = 0: nothing to add at the first step; q = 0 then, the score kernel adds b_h2a)
+        echr_gemm_desc g4[4];          // the caller packed h(t-1) of the three streams with the step's token embeddings
+        for (int k = 0; k < 3; ++k) g4[k] = desc_h2(s.PK_H[k], s.PK_WHH[k], w.GATES[k] + (long)t * gs, 4 * H, N, 4 * H, H);
+        g4[3] = desc_h2(s.PK_H[1], s.PK_WH2A, qt, Ha, N, Ha, H);
+        for (int i = 0; i < 4; ++i) { g4[i].beta = 1.f; g4[i].split_k = 1; }
+        RC(gemm_grouped(g4, 4, st));
+    }
+    float* q = w.QS + (long)t * N * Ha;
+    float* sc = w.SC + (long)t * N * A;
+    float* wt = w.WT + (long)t * N * A;
+    float* att = w.ATT + (long)t * N * D;
+    {
+        const double rows = (double)N * A;
+        ProfScope prof(PROF_ATT_FWD, 2.0 * rows * (Ha + D), 4.0 * (rows * (Ha + D + 2) + (double)N * (Ha + D)), st);
+        const AttDims ad{N, A, Ha, D};
+        RC(launch_att_score(ad, w.PALL, qt, 1, qs, a->b_h2a, q, a->w_alpha, a->b_alpha, a->ev_start, a->ev_len, sc, st));
+        hipLaunchKernelGGL(att_context_kernel, dim3(N, (D + 127) / 128), dim3(256), (((A + 31) & ~31) + 8 * 128) * sizeof(float), st, a->c3d, sc,
+                           a->ev_start, a->ev_len, wt, att, A, D);
+        RC(check_launch("att_context"));
+    }
+    {
+        H2PackJob pj = pack_rows(att, D, N, D, s.PK_ATT);
+        RC(h2_pack_multi(&pj, 1, st));
+        echr_gemm_desc d = desc_h2(s.PK_ATT, s.PK_WATT, w.GATES[1] + (long)t * gs, 4 * H, N, 4 * H, D);
+        d.beta = 1.f; d.split_k = 1;
+        RC(gemm(d, st));
+    }
+    LstmPtrs P;
+    for (int k = 0; k < 3; ++k) {
+        P.gates[k] = w.GATES[k] + (long)t * gs;
+        P.slab[k] = w.GSL[k];
+        P.nslab[k] = 0;
+        P.base[k] = nullptr; P.base2[k] = nullptr; P.bmod[k] = 1;
+        P.c_prev[k] = w.CS[k] + (long)t * N * H;
+        P.c_new[k] = w.CS[k] + (long)(t + 1) * N * H;
+        P.kmap[k] = k;
+    }
+    P.slab_stride = gs;
+    hipLaunchKernelGGL(lstm_pointwise_fwd_kernel, dim3((N * H + 255) / 256, 3), dim3(256), 0, st, P,
+                       w.HS + (long)(t + 1) * N * 3 * H, w.OUTD + (long)t * N * 3 * H, N, H, t, dh, dout);
+    return check_launch("lstm_pointwise_fwd");
 }
 
 // LOGITS = (...((S0 + S1) + (S2 + S3)) + ((S4 + S5) + (S6 + S7)) ...) + bias: the k-slices of the logits product in groups of four, one fixed
@@ -1633,7 +1703,7 @@ __global__ __launch_bounds__(256) void slab_sum_bias_kernel(const float* __restr
 extern "C" int64_t echr_sampler_ws_floats(const echr_dec_args* a) { return a ? carve_samp(a, nullptr).total : -1; }
 extern "C" int64_t echr_sampler_table_floats(const echr_dec_args* a) {
     if (!a) return -1;
-    return persist_sample_eligible(a) ? carve_tables(a, nullptr).total : 0;
+    return sample_uses_persistent(a) ? carve_tables(a, nullptr).total : 0;
 }
 
 extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
@@ -1650,7 +1720,7 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
     DecWs w = carve_ws(&a, a.ws);
     SampWs s = carve_samp(&a, sa->ws_sample);
     const DropCfg off = make_drop(nullptr, 0.f);
-    const bool persistent = !sa->multinomial && persist_sample_eligible(&a);
+    const bool persistent = !sa->multinomial && sample_uses_persistent(&a);
     {
         // one fill launch: the launch-per-step form starts from zero state / <bos> = 0 and zero outputs; the persistent form writes every
         // output element itself and only needs the unfinished counters cleared
@@ -1692,13 +1762,26 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
     }
     const bool big = config().gemm_h2 && N >= SAMP_SLAB_ROWS;
     RC(precompute_static(&a, w, st, big));
+    if (big) RC(fill_zero(w.QACC, (long)L * N * a.Ha, st));          // q(t) slabs of step_fwd_big
+    if (big) {          // recurrent weights as h2 operands, once per decode
+        H2PackJob pj[5] = {pack_rows(a.w_hh[0], H, 4 * H, H, s.PK_WHH[0]), pack_rows(a.w_hh[1], H, 4 * H, H, s.PK_WHH[1]),
+                           pack_rows(a.w_hh[2], H, 4 * H, H, s.PK_WHH[2]), pack_rows(a.w_h2a, H, a.Ha, H, s.PK_WH2A),
+                           pack_rows(a.w_ih[1] + E, E + a.D, 4 * H, a.D, s.PK_WATT)};
+        RC(h2_pack_multi(pj, 5, st));
+    }
     const int nsl = samp_slabs(&a), nsl4 = (nsl + 3) / 4 * 4;          // slabs are added four at a time: the spare ones stay zero
     if (N < SAMP_SLAB_ROWS && nsl4 > nsl) RC(fill_zero(s.SLABS + (long)nsl * N * a.V1, (long)(nsl4 - nsl) * N * a.V1, st));
     for (int t = 0; t < L; ++t) {
         if (big) {
             RC(embed_gather(a.embed, s.IT, s.XT, N, E, a.V1, st));
-            RC(input_gates(&a, w, s.XT, t, 1, st, false, true));
-            RC(step_fwd(&a, w, t, off, off, st));
+            {   // the step's h2 operands in ONE pack launch: the token embeddings and the three streams' h(t-1)
+                const float* hprev = w.HS + (long)t * N * 3 * H;
+                H2PackJob pj[4] = {pack_rows(s.XT, E, N, E, w.PK_XT), pack_rows(hprev, 3 * H, N, H, s.PK_H[0]), pack_rows(hprev + H, 3 * H, N, H, s.PK_H[1]),
+                                   pack_rows(hprev + 2 * H, 3 * H, N, H, s.PK_H[2])};
+                RC(h2_pack_multi(pj, t > 0 ? 4 : 1, st));
+            }
+            RC(input_gates(&a, w, s.XT, t, 1, st, false, true, true));
+            RC(step_fwd_big(&a, w, s, t, off, off, st));
         } else {
             // few events: no embedding gather, no input-gate GEMM -- the token-side products are jobs of the step's first grouped launch
             // (rows gathered from the embedding table by token id), the time-invariant addends are read by the gate kernel

@@ -470,6 +470,9 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *   "posemb_rows" 0/1   (default 1, ECHR_POSEMB_ROWS) pairwise position embedding with one thread per frequency (contiguous stores); 0 = one
  *                      thread per 16 frequencies of a pair
  *   "posemb_packed" 0/1 (default 1, ECHR_POSEMB_PACKED) >= 4096 event pairs: the position embedding is written directly as the packed fc1 operand
+ *   "persist_sample_max" n (default 512, ECHR_PERSIST_SAMPLE_MAX) greedy decoding of more than n events takes one batched launch chain per step (every
+ *                      product an h2 GEMM over the N rows, fixed-order k loops: bitwise reproducible) instead of one persistent launch per 64 events;
+ *                      0 = always the persistent form
  *   "persist_sample_force_eos" k  diagnostic: the persistent greedy decoder's logits of steps >= k - 1 favour <eos> for every event, so the launch takes
  *                      its early-stop path at a known step (tests); 0 = off
  *   "pair_tables" 0/1   (default 1, ECHR_PAIR_TABLES) inference over >= 16384 event pairs with known index bounds: fc1 tabulated over the distinct keys

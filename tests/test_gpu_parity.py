@@ -653,6 +653,43 @@ def test_persistent_sampler_edge_shapes_vs_launch_per_step(N, A, V1, min_len):
         assert np.abs(outs[0][1] - lp_o.numpy()).max() < TOL_LOGP
 
 
+def test_many_event_decode_batched_form_vs_oracle_and_persistent():
+    """Greedy decoding of MORE than `persist_sample_max` (default 512; 256 here) events -- evaluation over hundreds of proposals -- takes one batched launch chain
+    per step whose recurrent, context and logits products are h2 GEMMs over the N rows (fixed-order k loops: bitwise reproducible).  Same `seq`
+    as the oracle and as the persistent form (one launch per 64 events), log-probs to rounding."""
+    from echr_amd import _lib
+    from oracle import echr_ref_cpu as O
+    lib = _lib.load()
+    opt = synth.default_opt(vocab_size=1200, seq_length=9)
+    params = synth.make_params(opt, seed=4)
+    N = 300
+    vid = synth.make_video(N, 20, 11, 1201, seed=91, T_v=90)
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+
+    def decode(mx):
+        try:
+            lib.echr_config_set(b'persist_sample_max', mx)
+            with torch.no_grad():
+                seq, lp = m(tap, c3d, lda, [], vid['ind'], vid['soi'], mode='eval')
+            return seq.cpu().numpy(), lp.cpu().numpy()
+        finally:
+            lib.echr_config_set(b'persist_sample_max', 512)
+
+    sb, lb = decode(256)          # batched form (300 > 256)
+    sb2, lb2 = decode(256)
+    sp, lpp = decode(0)           # persistent form
+    assert sb.shape == (N, sb.shape[1]) and sb.shape[1] > 1
+    assert np.array_equal(sb, sb2) and np.abs(lb - lb2).max() < 2e-6          # (the event encoder's split-K sums in front of the decoder are not bitwise repeatable)
+    assert np.array_equal(sb, sp) and np.abs(lb - lpp).max() < TOL_LOGP
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        so, lo = O.caption_forward(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), None, vid['ind'], vid['soi'],
+                                   mode='eval', seq_length=opt.CG_seq_length)
+    assert np.array_equal(sb, so.numpy()) and np.abs(lb - lo.numpy()).max() < TOL_LOGP
+
+
 @pytest.mark.parametrize('N', [3, 64, 100])
 def test_persistent_sampler_stops_when_every_event_has_finished(N):
     """OldModel.sample breaks out of its loop once no event is unfinished (models/OldModel_NEW.py:171-180); the persistent decoder then stops
