@@ -40,5 +40,13 @@ if pk:
                                       fetch_bytes_per_launch=round(sum(out[k]['fetch_bytes_per_launch'] * out[k]['launches'] for k in pk) / (2 * pairs)),
                                       write_bytes_per_launch=round(sum(out[k]['write_bytes_per_launch'] * out[k]['launches'] for k in pk) / (2 * pairs)))
     out['dec_persist_kernels']['hbm_bytes_per_launch'] = out['dec_persist_kernels']['fetch_bytes_per_launch'] + out['dec_persist_kernels']['write_bytes_per_launch']
+# the proposal encoder's persistent pair (forward, reverse): one class in bench.py, two launches per iteration
+sk = [k for k in out if k.startswith('sst_persist')]
+if sk:
+    n = sum(out[k]['launches'] for k in sk)
+    out['sst_persist_kernels'] = dict(launches=n, members=sk,
+                                      fetch_bytes_per_launch=round(sum(out[k]['fetch_bytes_per_launch'] * out[k]['launches'] for k in sk) / n),
+                                      write_bytes_per_launch=round(sum(out[k]['write_bytes_per_launch'] * out[k]['launches'] for k in sk) / n))
+    out['sst_persist_kernels']['hbm_bytes_per_launch'] = out['sst_persist_kernels']['fetch_bytes_per_launch'] + out['sst_persist_kernels']['write_bytes_per_launch']
 out['_commit'] = sys.argv[2] if len(sys.argv) > 2 else None          # the tree these counters were collected from
 print(json.dumps(out, indent=1))
