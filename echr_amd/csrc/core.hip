@@ -325,6 +325,12 @@ __global__ void embed_scatter_add_kernel(const float* __restrict__ dX, const int
     const int row = blockIdx.x;
     int t = tok[row];
     t = min(max(t, 0), V1 - 1);
+    // Rows whose gradient is exactly zero add nothing: the label positions behind a caption's end (zero-padded labels, train.py:298: half of
+    // all (t, n) positions at S = 20) all carry token 0, and their 512-wide atomics serialise on the <bos> / padding row of the table while
+    // contributing 0.  One block-wide test skips them (NaN counts as non-zero and still propagates).
+    int any = 0;
+    for (int j = threadIdx.x; j < E; j += blockDim.x) any |= dX[(long)row * E + j] != 0.f;
+    if (!__syncthreads_or(any)) return;
     for (int j = threadIdx.x; j < E; j += blockDim.x) atomicAdd(&gW[(long)t * E + j], dX[(long)row * E + j]);
 }
 int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st) {
