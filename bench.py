@@ -68,6 +68,7 @@ def gpu_leg(args, rank, world, local_rank):
     labels = torch.from_numpy(vid['labels'])                       # host copy: step count needs no device sync
     tgt = labels[:, 1:].to(dev)
     msk = torch.from_numpy(vid['masks'])[:, 1:].to(dev)
+    tgt_h, msk_h = labels[:, 1:].numpy(), vid['masks'][:, 1:]
 
     if args.c5:
         from echr_amd import models as EM
@@ -115,12 +116,13 @@ def gpu_leg(args, rank, world, local_rank):
             return c5_iteration()
         if args.mode == 'fwd':
             if fused is not None:          # forward + criterion only (BASELINE config 2), same one-call entry
-                return fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, forward_only=True)
+                return fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, forward_only=True)
             return fwd_only()
         if fused is not None:
+            # (criterion inputs handed over on the host, as the reference's loader produces them: they travel with the index vectors)
             if not use_dist:
-                return fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk)
-            loss = fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, step=False)
+                return fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h)
+            loss = fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False)
             parallel.allreduce_gradients(model, force=True)
             clip_gradient(optim, opt.grad_clip)
             optim.step()

@@ -57,7 +57,7 @@ class DecGrads(C.Structure):
                 ('g_w_c2a', c_f), ('g_b_c2a', c_f), ('g_w_h2a', c_f), ('g_b_h2a', c_f), ('g_w_alpha', c_f), ('g_b_alpha', c_f),
                 ('g_event', c_f), ('g_video', c_f), ('g_logp', c_f),
                 ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f), ('zeroed', i32), ('phase', i32), ('async_tail', i32), ('nll_msum', c_f),
-                ('zero_extra', c_f), ('zero_extra_count', i64), ('nll_target_i64', i32), ('dlg_ready', i32)]
+                ('zero_extra', c_f), ('zero_extra_count', i64), ('nll_target_i64', i32), ('dlg_ready', i32), ('active_rows', c_f), ('n_active', i32)]
 
 
 class SstArgs(C.Structure):
@@ -84,7 +84,7 @@ class TrainStepArgs(C.Structure):
                 ('ws', c_f), ('ws_floats', i64), ('flat_g', c_f), ('n_flat', i64),
                 ('flat_p', c_f), ('adam_m', c_f), ('adam_v', c_f), ('adam_step', i32),
                 ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('clip', f32),
-                ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32)]
+                ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32)]
 
 
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)

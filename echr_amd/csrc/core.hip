@@ -455,11 +455,15 @@ int logsoftmax_bwd(const float* logp, const float* G, const void* target, int tg
 template <int EPT>
 __global__ __launch_bounds__(256) void logsoftmax_nll_dlg_kernel(const float* __restrict__ X, long ld, const void* __restrict__ target, int tgt64,
                                                                  const float* __restrict__ mask, const float* __restrict__ g_loss, float* __restrict__ out,
-                                                                 long ldo, float* __restrict__ row_loss, float* __restrict__ msum_out, int N, int S, int V1) {
+                                                                 long ldo, float* __restrict__ row_loss, float* __restrict__ msum_out, int N, int S, int V1,
+                                                                 const int* __restrict__ act) {
     __shared__ float red[4];
-    const int row = blockIdx.x;             // time-major row = t*N + n
-    const int t = row / N, n = row % N;
-    const float* x = X + ((long)n * S + t) * ld;
+    // act != nullptr: block i handles the compacted row i = time-major row act[i] (only rows whose mask is non-zero exist: the logits arrive
+    // as [n_active, ld], d logits / row_loss leave in the same compact order)
+    const int row = blockIdx.x;             // output row
+    const int tm = act ? act[row] : row;    // time-major row = t*N + n
+    const int t = tm / N, n = tm % N;
+    const float* x = act ? X + (long)row * ld : X + ((long)n * S + t) * ld;
     float v[EPT];
     float m = -INFINITY;
 #pragma unroll
@@ -502,10 +506,11 @@ __global__ __launch_bounds__(256) void nll_rows_sum_kernel(const float* __restri
 }
 bool logsoftmax_nll_dlg_ok(int V1, long ldo) { return ldo <= 256 * 40; }
 int logsoftmax_nll_dlg(const float* X, long ld, const void* target, int tgt64, const float* mask, const float* g_loss, float* out, long ldo,
-                       float* row_loss, float* msum_out, int N, int S, int V1, hipStream_t st) {
-    if (ldo <= 256 * 8) hipLaunchKernelGGL(logsoftmax_nll_dlg_kernel<8>, dim3(N * S), dim3(256), 0, st, X, ld, target, tgt64, mask, g_loss, out, ldo, row_loss, msum_out, N, S, V1);
-    else if (ldo <= 256 * 20) hipLaunchKernelGGL(logsoftmax_nll_dlg_kernel<20>, dim3(N * S), dim3(256), 0, st, X, ld, target, tgt64, mask, g_loss, out, ldo, row_loss, msum_out, N, S, V1);
-    else hipLaunchKernelGGL(logsoftmax_nll_dlg_kernel<40>, dim3(N * S), dim3(256), 0, st, X, ld, target, tgt64, mask, g_loss, out, ldo, row_loss, msum_out, N, S, V1);
+                       float* row_loss, float* msum_out, int N, int S, int V1, hipStream_t st, const int* act, int n_active) {
+    const int rows = act ? n_active : N * S;
+    if (ldo <= 256 * 8) hipLaunchKernelGGL(logsoftmax_nll_dlg_kernel<8>, dim3(rows), dim3(256), 0, st, X, ld, target, tgt64, mask, g_loss, out, ldo, row_loss, msum_out, N, S, V1, act);
+    else if (ldo <= 256 * 20) hipLaunchKernelGGL(logsoftmax_nll_dlg_kernel<20>, dim3(rows), dim3(256), 0, st, X, ld, target, tgt64, mask, g_loss, out, ldo, row_loss, msum_out, N, S, V1, act);
+    else hipLaunchKernelGGL(logsoftmax_nll_dlg_kernel<40>, dim3(rows), dim3(256), 0, st, X, ld, target, tgt64, mask, g_loss, out, ldo, row_loss, msum_out, N, S, V1, act);
     return check_launch("logsoftmax_nll_dlg");
 }
 int nll_rows_sum(const float* row_loss, int NS, const float* msum, float* loss, hipStream_t st) {

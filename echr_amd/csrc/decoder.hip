@@ -1085,21 +1085,22 @@ extern "C" int echr_decoder_fwd_prepare_cancel(void* stream) {
     return 0;
 }
 
-static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, void* stream, const echr_dec_grads* fz, bool* fused_out);
-extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream) { return decoder_fwd_impl(a, drop, stream, nullptr, nullptr); }
+static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, void* stream, const echr_dec_grads* fz, bool* fused_out, bool* compact_out);
+extern "C" int echr_decoder_fwd(const echr_dec_args* a, const echr_dropout* drop, void* stream) { return decoder_fwd_impl(a, drop, stream, nullptr, nullptr, nullptr); }
 namespace echr {
-int decoder_fwd_fused(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, bool* fused) {
-    return decoder_fwd_impl(a, drop, stream, g, fused);
+int decoder_fwd_fused(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, bool* fused, bool* compact) {
+    return decoder_fwd_impl(a, drop, stream, g, fused, compact);
 }
 int decoder_fused_loss(const echr_dec_args* a, const echr_dec_grads* g, float* loss, hipStream_t st) {
     const DecWsBwd b = carve_ws_bwd(a, g->ws_bwd);
-    return nll_rows_sum(b.ROWL, a->S * a->N, b.MSUM, loss, st);
+    return nll_rows_sum(b.ROWL, (g->active_rows && g->n_active > 0) ? g->n_active : a->S * a->N, b.MSUM, loss, st);
 }
 }  // namespace echr
 // fz != nullptr: the criterion is fused behind the logits product (echr_train_step) -- the logits are turned into d logits in ws_bwd and
 // per-row loss terms by ONE pass instead of log-softmax, NLL and log-softmax backward passes; the log-probs are never materialised
-static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, void* stream, const echr_dec_grads* fz, bool* fused_out) {
+static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, void* stream, const echr_dec_grads* fz, bool* fused_out, bool* compact_out) {
     if (fused_out) *fused_out = false;
+    if (compact_out) *compact_out = false;
     RC(persist_check_async());
     RC(join_tail((hipStream_t)stream));
     RC(check_dims(a, "decoder_fwd"));
@@ -1131,6 +1132,23 @@ static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, vo
     // late fusion: logits = OUTD . W_logit^T + b, written [N,S,V1], then row log-softmax in place.  Timesteps [0,th) are
     // projected on the side stream while the recurrence of [th,S) is still running.
     auto logits_chunk = [&](int t0, int t1, hipStream_t q) -> int {
+        // echr_train_step with the criterion's active rows: logits only for the rows that can reach the loss (compact [n_active, V1] in the
+        // log-prob buffer, which nothing else reads on that path), then log-softmax + criterion + d logits in one pass over them
+        if (fz && fz->active_rows && fz->n_active > 0 && config().gemm_h2 && t0 == 0 && t1 == S && fz->nll_target && fz->nll_mask && fz->g_loss && fz->ws_bwd) {
+            const DecWsBwd b = carve_ws_bwd(a, fz->ws_bwd);
+            if (logsoftmax_nll_dlg_ok(a->V1, b.ldg)) {
+                H2PackJob pj = pack_rows(w.OUTD, 3 * H, fz->n_active, 3 * H, w.PK_OUTD);
+                pj.gather = fz->active_rows;
+                RC(h2_pack_multi(&pj, 1, q));
+                echr_gemm_desc dc = desc_h2(w.PK_OUTD, w.PK_WL, a->logp, a->V1, fz->n_active, a->V1, 3 * H);
+                dc.split_k = 1; dc.bias = a->b_logit;
+                RC(gemm(dc, q));
+                if (fused_out) *fused_out = true;
+                if (compact_out) *compact_out = true;
+                return logsoftmax_nll_dlg(a->logp, a->V1, fz->nll_target, fz->nll_target_i64, fz->nll_mask, fz->g_loss, b.DLG, b.ldg, b.ROWL, b.MSUM, N, S, a->V1, q,
+                                          fz->active_rows, fz->n_active);
+            }
+        }
         echr_gemm_desc d = desc_nt(w.OUTD + (long)t0 * N * 3 * H, 3 * H, a->w_logit, 3 * H, a->logp + (long)t0 * a->V1, a->V1,
                                    (t1 - t0) * N, a->V1, 3 * H);
         d.algo = ECHR_GEMM_BF16X3;
@@ -1185,7 +1203,7 @@ static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, vo
 // bias_too = false: the caller folds the column sum of DLG (d b_logit) into a later multi-problem column-sum launch
 static int logit_grads(const echr_dec_args* a, const echr_dec_grads* g, const DecWs& w, const DecWsBwd& b, bool z, hipStream_t st, bool bias_too = true) {
     (void)w;
-    const int SN = a->S * a->N;
+    const int SN = (g->dlg_ready && g->active_rows && g->n_active > 0) ? g->n_active : a->S * a->N;          // (compacted rows: see echr_decoder_bwd)
     echr_gemm_desc d = desc_h2(b.PK_DLGT, b.PK_OUTDT, g->g_w_logit, 3 * a->H, a->V1, 3 * a->H, SN);
     d.split_k = 1;                         // one k slice per tile: a plain overwrite, no read of the (zeroed or stale) 30 MB buffer
     RC(gemm(d, st));
@@ -1207,6 +1225,11 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     const int cin[3] = {E + a->De, E + D, E + a->Dv};
     const bool z = g->zeroed != 0;             // gradient buffers pre-zeroed by the caller: accumulate, no fills
     const float zb = z ? 1.f : 0.f;
+    // echr_train_step's compacted late-fusion stage: d logits exist for the SNc rows with a non-zero criterion mask only (rows act[i])
+    const bool compact = g->dlg_ready && g->active_rows && g->n_active > 0;
+    const int SNc = compact ? g->n_active : SN;
+    const int* act = compact ? g->active_rows : nullptr;
+    ECHR_REQUIRE(!compact || (config().gemm_h2 && g->phase == 0 && g->async_tail != 0), "decoder_bwd: active_rows needs the h2 path and the asynchronous tail");
 
     ECHR_REQUIRE(g->phase >= 0 && g->phase <= 4, "decoder_bwd: phase must be 0..4");
     // stages: late fusion | reverse recurrence + LSTM-layer gradients (part A) | attention + embedding gradients (part B)
@@ -1258,16 +1281,18 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         // (a->train: W_logit^T was packed with the forward operands; otherwise here)
         const float* pk_wlt = a->train ? w.PK_WLT : b.PK_WLT;
         if (defer_wl) {
-            H2PackJob pj[2] = {pack_rows(b.DLG, b.ldg, SN, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
+            H2PackJob pj[2] = {pack_rows(b.DLG, b.ldg, SNc, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
             RC(h2_pack_multi(pj, a->train ? 1 : 2, st));
         } else {
+            ECHR_REQUIRE(!compact, "decoder_bwd: active_rows needs the deferred logit-layer gradients");
             H2PackJob pj[4] = {pack_cols(b.DLG, b.ldg, V1, SN, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SN, b.PK_OUTDT),
                                pack_rows(b.DLG, b.ldg, SN, V1, b.PK_DLG), pack_cols(a->w_logit, 3 * H, 3 * H, V1, b.PK_WLT)};
             RC(h2_pack_multi(pj, a->train ? 3 : 4, st));
             RC(logit_grads(a, g, w, b, z, st));
         }
-        d = desc_h2(b.PK_DLG, pk_wlt, b.DOUT, 3 * H, SN, 3 * H, V1);
+        d = desc_h2(b.PK_DLG, pk_wlt, b.DOUT, 3 * H, SNc, 3 * H, V1);
         d.beta = 1.f;                          // DOUT was zeroed above: the k slices add atomically, no fill launch
+        if (compact) { d.row_index = act; d.row_index_max = SN - 1; }          // compacted row i is row act[i] of d OUTD (the others stay zero)
         RC(gemm(d, st));
     } else {
     RC(transpose(b.DLG, b.ldg, b.DLGT, b.snp, SN, V1, (int)b.snp, sq));
@@ -1501,7 +1526,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         st = tail().s;
         RC(hop(sm, tail().fork, st));
         if (h2) {          // the logit-layer gradients deferred above
-            H2PackJob pj[2] = {pack_cols(b.DLG, b.ldg, V1, SN, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SN, b.PK_OUTDT)};
+            H2PackJob pj[2] = {pack_cols(b.DLG, b.ldg, V1, SNc, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SNc, b.PK_OUTDT)};
+            pj[1].gather = act;          // (compact: the contraction runs over the active rows of OUTD)
             RC(h2_pack_multi(pj, 2, st));
             RC(logit_grads(a, g, w, b, z, st, !z));          // z: d b_logit rides in the multi-problem column-sum launch behind att_post
             bias_pending = z;
@@ -1517,7 +1543,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         // accumulate mode: the replicas -> d alpha, d b_alpha, the ctx2att bias gradient (column sums of d P_all) and -- when the logit-layer
         // gradients were formed on this stream just before -- d b_logit: ONE multi-problem launch instead of four
         ColsumJob cj[4] = {{b.GAREP, Ha, ALPHA_REP, Ha, g->g_w_alpha, nullptr, nullptr}, {b.GBREP, 1, ALPHA_REP, 1, g->g_b_alpha, nullptr, nullptr},
-                           {b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, nullptr, nullptr}, {b.DLG, b.ldg, SN, V1, g->g_b_logit, nullptr, nullptr}};
+                           {b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, nullptr, nullptr}, {b.DLG, b.ldg, SNc, V1, g->g_b_logit, nullptr, nullptr}};
         RC(colsum_multi(cj, bias_pending ? 4 : 3, st));
     } else {
     RC(colsum(b.GAREP, Ha, ALPHA_REP, Ha, g->g_w_alpha, z, st));        // replicas -> d alpha, d b_alpha (overwrite or accumulate like every

@@ -72,7 +72,8 @@ bool gemm_skinny_ok(int M, int Nc, int K, long lda, long ldw, const float* A, co
 int gemm_skinny_nt(const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, int M, int Nc, int K, hipStream_t st);
 // h2-packed operands (csrc/gemm.hip: two block-scaled fp16 planes): bytes of the packed image of a [rows x cols] operand (cols =
 // contraction axis), the packing pass, and a multi-operand packing launch
-struct H2PackJob { const float* src; unsigned char* dst; int R, K; long s_row, s_col; };
+struct H2PackJob { const float* src; unsigned char* dst; int R, K; long s_row, s_col;
+                   const int* gather = nullptr; };      // optional: source row i (the strided axis: operand rows of a row pack, k of a transposing one) is read from row gather[i]
 long h2_bytes(int rows, int cols);
 int h2_pack(const float* src, int rows, int cols, long s_row, long s_col, void* dst, hipStream_t st);
 int h2_pack_multi(const H2PackJob* jobs, int n, hipStream_t st);
@@ -141,11 +142,11 @@ int logsoftmax_bwd(const float* logp, const float* G, const void* target, int tg
 // log-softmax + masked NLL + d logits in one pass over the logits (echr_train_step); rows_sum turns the per-row terms into (loss, sum(mask))
 bool logsoftmax_nll_dlg_ok(int V1, long ldo);
 int logsoftmax_nll_dlg(const float* X, long ld, const void* target, int tgt64, const float* mask, const float* g_loss, float* out, long ldo,
-                       float* row_loss, float* msum_out, int N, int S, int V1, hipStream_t st);
+                       float* row_loss, float* msum_out, int N, int S, int V1, hipStream_t st, const int* act = nullptr, int n_active = 0);
 int nll_rows_sum(const float* row_loss, int NS, const float* msum, float* loss, hipStream_t st);
 // echr_decoder_fwd with the criterion fused behind the logits product: g carries nll_target / nll_mask / g_loss / ws_bwd; d logits land in ws_bwd
 // (echr_dec_grads.dlg_ready = 1 for the echr_decoder_bwd that follows); returns through *fused whether the fused form applied
-int decoder_fwd_fused(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, bool* fused);
+int decoder_fwd_fused(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, bool* fused, bool* compact);
 int decoder_fused_loss(const echr_dec_args* a, const echr_dec_grads* g, float* loss, hipStream_t st);
 int sample_step(const float* logits, long ld, int N, int V1, int t, int seq_len, int* it_next, int* unfinished, long long* seq,
                 float* seq_logp, int* n_unfinished, float temperature, unsigned long long seed, hipStream_t st);

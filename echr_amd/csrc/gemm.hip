@@ -547,7 +547,8 @@ __global__ __launch_bounds__(256) void h2_pack_kernel(H2PackArgs args) {
     if (jb.s_col == 1) {
         const bool vec = aligned && (jb.s_row & 3) == 0;
         const int r = r0 + row;
-        const float* srow = src + (long)min(r, jb.R - 1) * jb.s_row;
+        const int rs = min(r, jb.R - 1);
+        const float* srow = src + (long)(jb.gather ? jb.gather[rs] : rs) * jb.s_row;
 #pragma unroll
         for (int c = 0; c < H2_SEG; ++c) {
             const int k = (kt0 + c) * BK + 8 * sl;
@@ -584,13 +585,13 @@ __global__ __launch_bounds__(256) void h2_pack_kernel(H2PackArgs args) {
                 for (int i = 0; i < 2; ++i) {
                     const int f = tid + i * 256, k = f >> 4, rr = (f & 15) * 4;
                     x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k0 + k < jb.K) x[i] = *reinterpret_cast<const float4*>(src + (long)(k0 + k) * jb.s_col + rh + rr);
+                    if (k0 + k < jb.K) x[i] = *reinterpret_cast<const float4*>(src + (long)(jb.gather ? jb.gather[k0 + k] : k0 + k) * jb.s_col + rh + rr);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int f = tid + i * 256, k = f >> 6, rr = f & 63;
-                    xs[i] = (rh + rr < jb.R && k0 + k < jb.K) ? src[(long)(k0 + k) * jb.s_col + rh + rr] : 0.f;
+                    xs[i] = (rh + rr < jb.R && k0 + k < jb.K) ? src[(long)(jb.gather ? jb.gather[k0 + k] : k0 + k) * jb.s_col + rh + rr] : 0.f;
                 }
             }
         };

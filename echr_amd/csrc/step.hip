@@ -29,7 +29,7 @@ static StepWs carve_step(const echr_train_step_args* a) {
     auto take = [&](long n) { long o = off; off += up64(n); return o; };
     const echr_tsrm_args& t = a->tsrm;
     const echr_dec_args& d = a->dec;
-    w.idx = take((long)(3 + d.S) * d.N);                  // int32: ev_start | ev_len | ind | tokens [S,N]
+    w.idx = take((long)(3 + 4 * d.S) * d.N);              // int32: ev_start | ev_len | ind | tokens [S,N] | active rows [<= S*N] | targets [N,S] | mask fp32 [N,S]
     w.ech = take((long)t.N * t.Din);
     w.tsrm_ws = take(echr_tsrm_ws_floats(t.N, t.Din, t.Df, t.Do, t.G));
     w.event = take((long)t.N * t.Do);
@@ -87,8 +87,7 @@ using namespace echr;
 extern "C" int64_t echr_train_step_ws_floats(const echr_train_step_args* a) { return a ? carve_step(a).total : -1; }
 
 extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
-    ECHR_REQUIRE(a && a->ws && a->host_index && a->loss && a->g_loss && a->nll_target && a->nll_mask && a->tap && a->flat_g,
-                 "train_step: missing buffers");
+    ECHR_REQUIRE(a && a->ws && a->host_index && a->loss && a->g_loss && a->tap && a->flat_g, "train_step: missing buffers");
     ECHR_REQUIRE(a->tsrm.N == a->dec.N && a->tsrm.Do == a->dec.De && a->tsrm.Din == a->dec.D + a->Ht, "train_step: encoder / decoder shapes disagree");
     ECHR_REQUIRE(!a->do_step || (a->flat_p && a->adam_m && a->adam_v && a->adam_step >= 1), "train_step: optimiser state missing");
     hipStream_t st = (hipStream_t)stream;
@@ -97,8 +96,19 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     float* ws = a->ws;
     const int N = a->dec.N, S = a->dec.S;
     int32_t* idx = reinterpret_cast<int32_t*>(ws + L.idx);
-    RC(stage_indices(a->host_index, idx, sizeof(int32_t) * (size_t)(3 + S) * N, st));
-    const int32_t *ev_start = idx, *ev_len = idx + N, *ind = idx + 2 * N, *tokens = idx + 3 * N;
+    ECHR_REQUIRE(a->n_active >= 0 && a->n_active <= S * N, "train_step: n_active out of range");
+    const size_t n_idx = (size_t)(3 + S) * N + (size_t)a->n_active + (a->host_nll ? 2 * (size_t)S * N : 0);
+    RC(stage_indices(a->host_index, idx, sizeof(int32_t) * n_idx, st));
+    const int32_t *ev_start = idx, *ev_len = idx + N, *ind = idx + 2 * N, *tokens = idx + 3 * N, *active = idx + (3 + S) * N;
+    const void* nll_target = a->nll_target;
+    const float* nll_mask = a->nll_mask;
+    int nll_i64 = a->nll_target_i64;
+    if (a->host_nll) {          // targets / mask came with the index vectors
+        nll_target = active + a->n_active;
+        nll_mask = reinterpret_cast<const float*>(active + a->n_active + (size_t)S * N);
+        nll_i64 = 0;
+    }
+    ECHR_REQUIRE(nll_target && nll_mask, "train_step: criterion targets / mask missing");
 
     echr_dec_args d = a->dec;
     d.ev_start = ev_start; d.ev_len = ev_len; d.tokens = tokens;
@@ -117,22 +127,24 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     d.event = ws + L.event; d.prepared = a->overlap_encoder ? 1 : 0;
     echr_dec_grads g = a->dec_g;
     g.g_event = ws + L.g_event; g.g_logp = nullptr;
-    g.nll_target = static_cast<const int32_t*>(a->nll_target); g.nll_target_i64 = a->nll_target_i64; g.nll_mask = a->nll_mask;
+    g.nll_target = static_cast<const int32_t*>(nll_target); g.nll_target_i64 = nll_i64; g.nll_mask = nll_mask;
+    g.active_rows = a->n_active > 0 ? active : nullptr; g.n_active = a->n_active;
     g.g_loss = a->g_loss; g.nll_msum = a->loss + 1;
     g.ws_bwd = ws + L.dec_ws_bwd; g.zeroed = 1; g.phase = 0; g.async_tail = async_level();
     // forward (:30) + LanguageModelCriterion (misc/utils.py:66-75).  Training: log-softmax, criterion and its gradient are ONE pass over the
     // logits (d logits land in the backward workspace, the log-probs are never written; the loss is summed behind the backward pass, where
     // this stream waits for the helper stream anyway).  forward_only: the plain log-softmax + criterion, loss[0] = loss, loss[1] = sum(mask)
-    bool fused_nll = false;
+    bool fused_nll = false, compact = false;
     if (a->forward_only) RC(echr_decoder_fwd(&d, &a->drop, stream));
-    else RC(decoder_fwd_fused(&d, &g, &a->drop, stream, &fused_nll));
+    else RC(decoder_fwd_fused(&d, &g, &a->drop, stream, &fused_nll, &compact));
     if (!fused_nll) {
-        if (a->nll_target_i64) RC(echr_nll_loss_fwd_i64(d.logp, static_cast<const int64_t*>(a->nll_target), a->nll_mask, a->loss, N, S, d.V1, stream));
-        else RC(echr_nll_loss_fwd(d.logp, static_cast<const int32_t*>(a->nll_target), a->nll_mask, a->loss, N, S, d.V1, stream));
+        if (nll_i64) RC(echr_nll_loss_fwd_i64(d.logp, static_cast<const int64_t*>(nll_target), nll_mask, a->loss, N, S, d.V1, stream));
+        else RC(echr_nll_loss_fwd(d.logp, static_cast<const int32_t*>(nll_target), nll_mask, a->loss, N, S, d.V1, stream));
     }
     if (a->forward_only) return 0;
     g.dlg_ready = fused_nll ? 1 : 0;
     if (fused_nll) g.nll_msum = nullptr;
+    if (!compact) { g.active_rows = nullptr; g.n_active = 0; }          // (the forward kept all rows: vocabulary beyond the register-resident kernels, h2 off)
 
     // backward (train.py:313): criterion gradient in fused form
     g.zero_extra = nullptr; g.zero_extra_count = 0;

@@ -21,6 +21,10 @@ from .models.OldModel_NEW import n_decoder_steps
 from .optim import ClampAdam
 
 
+import os
+MASKED_ROWS = [os.environ.get('ECHR_MASKED_ROWS', '1') != '0']          # late-fusion stage on the rows with a non-zero criterion mask only
+
+
 class FusedTrainStep(object):
     LOSS_SLOTS = 16
 
@@ -116,14 +120,36 @@ class FusedTrainStep(object):
             raise ValueError('label tensor needs at least two columns')
         if labels.shape[0] != N:
             raise ValueError('labels have %d rows for %d events' % (labels.shape[0], N))
-        host = np.empty((3 + S) * N, dtype=np.int32)
-        host[:N], host[N:2 * N], host[2 * N:3 * N] = soi[:, 0], lens, ind
-        host[3 * N:] = labels[:, :S].T.reshape(-1)
         c3d, tap, lda = EF._f32c(c3d_feats), EF._f32c(tap_feats), EF._f32c(lda_feats)
-        tgt = targets if targets.is_cuda else EF.upload(targets, self.dev)
-        msk = masks if masks.is_cuda else EF.upload(masks, self.dev)
-        tgt = EF._nll_target(tgt, S)
-        msk = msk[:, :S].to(torch.float32).contiguous()
+        # Criterion inputs.  On the host (numpy / CPU tensors, as the reference's loader hands them over, train.py:273-279): they travel with
+        # the index vectors, and the rows whose mask is non-zero are listed -- the masked-out label positions behind a caption's end cannot
+        # reach the loss (misc/utils.py:66-75 multiplies by the mask), so training forms logits, d logits and the logit-layer products on the
+        # active rows only (ECHR_MASKED_ROWS=0: all rows).  On the device: used in place, all rows.
+        host_nll = not (isinstance(targets, torch.Tensor) and targets.is_cuda) and not (isinstance(masks, torch.Tensor) and masks.is_cuda)
+        act = None
+        if host_nll:
+            tg_h = np.ascontiguousarray(np.asarray(targets)[:, :S], dtype=np.int32)
+            mk_h = np.ascontiguousarray(np.asarray(masks)[:, :S], dtype=np.float32)
+            if tg_h.shape != (N, S) or mk_h.shape != (N, S):
+                raise ValueError('targets / masks must be [N, >= S] (got %s, %s)' % (tuple(np.asarray(targets).shape), tuple(np.asarray(masks).shape)))
+            if MASKED_ROWS[0] and not forward_only:
+                act = np.flatnonzero(mk_h.T.reshape(-1) != 0).astype(np.int32)          # time-major rows t*N + n, ascending
+                if act.size == 0 or act.size == N * S:
+                    act = None
+        n_act = 0 if act is None else int(act.size)
+        host = np.empty((3 + S) * N + n_act + (2 * N * S if host_nll else 0), dtype=np.int32)
+        host[:N], host[N:2 * N], host[2 * N:3 * N] = soi[:, 0], lens, ind
+        host[3 * N:(3 + S) * N] = labels[:, :S].T.reshape(-1)
+        o = (3 + S) * N
+        if n_act:
+            host[o:o + n_act] = act
+        if host_nll:
+            host[o + n_act:o + n_act + N * S] = tg_h.reshape(-1)
+            host[o + n_act + N * S:] = mk_h.reshape(-1).view(np.int32)
+            tgt = msk = None
+        else:
+            tgt = EF._nll_target(targets if targets.is_cuda else EF.upload(targets, self.dev), S)
+            msk = (masks if masks.is_cuda else EF.upload(masks, self.dev))[:, :S].to(torch.float32).contiguous()
         d = a.dec
         a.tsrm.N = d.N = N
         d.A, d.Tv, d.S, d.rows_disjoint = int(lens.max()), c3d.shape[0], S, 1 if EF.rows_disjoint(soi) else 0
@@ -131,7 +157,12 @@ class FusedTrainStep(object):
             raise L.EchrHipError('feature widths do not match the model (c3d %d, lda %d, tap %d)' % (c3d.shape[1], lda.numel(), tap.shape[1]))
         d.c3d, d.video, a.tap, a.Ht = c3d.data_ptr(), lda.data_ptr(), tap.data_ptr(), tap.shape[1]
         a.host_index = host.ctypes.data
-        a.nll_target, a.nll_target_i64, a.nll_mask = tgt.data_ptr(), 1 if tgt.dtype == torch.int64 else 0, msk.data_ptr()
+        a.n_active, a.host_nll = n_act, 1 if host_nll else 0
+        if host_nll:
+            a.nll_target, a.nll_target_i64, a.nll_mask = None, 0, None
+        else:
+            a.nll_target, a.nll_target_i64, a.nll_mask = tgt.data_ptr(), 1 if tgt.dtype == torch.int64 else 0, msk.data_ptr()
+        self.last_active_rows = n_act
         drop = m.lm_model.next_drop_state(m.fusion_model.enc_attn.dropout.p)
         drop.training = m.training
         a.drop = drop.c()

@@ -251,6 +251,11 @@ typedef struct {
                                                   conversion pass), 0: int32 */
     int32_t dlg_ready;                         /* 1: d logits already sit in ws_bwd (echr_train_step forms them in the pass that reads the logits:
                                                   log-softmax + criterion + its gradient in one kernel); callers of echr_decoder_bwd leave it 0 */
+    const int32_t* active_rows;                /* echr_train_step only (with dlg_ready): the n_active time-major rows t*N + n whose criterion mask is
+                                                  non-zero, ascending.  Rows outside carry exactly zero d logits (misc/utils.py:66-75: the mask
+                                                  multiplies the log-prob), so the late-fusion products run on the compacted rows: logits and d logits
+                                                  exist as [n_active, V1], d OUTD is scattered back by row, d W_logit contracts over n_active rows */
+    int32_t n_active;
 } echr_dec_grads;
 
 /* make `stream` wait for an asynchronous decoder-backward tail (echr_dec_grads.async_tail); no-op when none is pending */
@@ -407,7 +412,8 @@ typedef struct {
     int32_t Ht;
     float* g_tap;                  /* optional [Tv,Ht], zero-filled by the caller: receives d loss / d tap_feats (joint training); NULL = tap is data */
     const int32_t* host_index;     /* HOST memory (any kind; copied into a pinned ring inside the call):
-                                      ev_start[N] | ev_len[N] | ind[N] | tokens[S*N] (time-major input tokens, labels[:, t]) */
+                                      ev_start[N] | ev_len[N] | ind[N] | tokens[S*N] (time-major input tokens, labels[:, t])
+                                      | active[n_active] (below) | and, with host_nll = 1, targets int32 [N*S] | mask fp32 [N*S] */
     const void* nll_target;        /* device [N,S] targets (labels[:, 1:1+S]), int64 or int32 */
     int32_t nll_target_i64;
     const float* nll_mask;         /* device [N,S] */
@@ -424,6 +430,10 @@ typedef struct {
     int32_t do_step;               /* 0: stop after the backward pass (the caller reduces / inspects flat_g and steps itself) */
     int32_t overlap_encoder;       /* 1: the decoder forward's event-independent part runs on the library's second stream beside the event encoder */
     int32_t forward_only;          /* 1: stop after the criterion (validation loss, eval_utils.py:148-152) */
+    int32_t n_active;              /* > 0: host_index carries the n_active time-major rows t*N + n with a non-zero criterion mask (ascending);
+                                      training then forms logits, d logits and the logit-layer products on those rows only (the masked-out
+                                      label positions behind a caption's end -- half of all rows at S = 20 -- cannot reach the loss).  0: all rows */
+    int32_t host_nll;              /* 1: targets and mask travel in host_index too (nll_target / nll_mask are ignored) */
 } echr_train_step_args;
 int64_t echr_train_step_ws_floats(const echr_train_step_args* a);
 int echr_train_step(const echr_train_step_args* a, void* stream);

@@ -1087,6 +1087,7 @@ def test_fused_train_step_equals_autograd_path(case):
     la = autograd_iteration(ma, oa)
     lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:]))      # host targets / masks: uploaded inside
     assert abs(la - lb) < 1e-6 * abs(la), (la, lb)
+    assert 0 < fb.last_active_rows < labels.shape[0] * (labels.shape[1] - 1)          # host masks: the late-fusion stage ran on the active rows only
     assert ob._flat['step'] == 1 and oa._flat['step'] == 1
     for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         dp = (pa.detach() - pb.detach()).abs()
@@ -1112,9 +1113,21 @@ def test_fused_train_step_equals_autograd_path(case):
     # gradients only (data-parallel protocol: reduce, then clip + step by the caller)
     autograd_iteration(ma, oa, step=False)
     lb = fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, step=False)
+    assert fb.last_active_rows == 0                                                 # device tensors: all rows
     assert mb._echr_arena.grads_in_arena()
     for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         assert (pa.grad is None) == (pb.grad is None), k
+        if pa.grad is not None:
+            assert U.grad_close(k, pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), 2e-5), (k, U.relerr(pb.grad.cpu().numpy(), pa.grad.cpu().numpy()))
+    clip_gradient(ob, 0.05)
+    ob.step()
+    oa.step()
+    sync()
+    # the same gradient comparison with the criterion inputs on the host (active rows only)
+    autograd_iteration(ma, oa, step=False)
+    fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:].numpy(), masks[:, 1:].numpy(), step=False)
+    assert fb.last_active_rows > 0
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         if pa.grad is not None:
             assert U.grad_close(k, pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), 2e-5), (k, U.relerr(pb.grad.cpu().numpy(), pa.grad.cpu().numpy()))
     clip_gradient(ob, 0.05)
