@@ -55,6 +55,14 @@ struct PinRing {
 };
 static PinRing& ring() { static PinRing r; return r; }
 
+__global__ __launch_bounds__(256) void stage_copy_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = __builtin_nontemporal_load(src + i);
+}
+static bool stage_kernel_ok() {
+    static const bool on = [] { const char* e = getenv("ECHR_STAGE_KERNEL"); return !(e && e[0] == '0'); }();      // A/B switch
+    return on;
+}
 static int stage_indices(const int32_t* host, int32_t* dev, size_t bytes, hipStream_t st) {
     PinRing& r = ring();
     const int s = r.next;
@@ -69,11 +77,19 @@ static int stage_indices(const int32_t* host, int32_t* dev, size_t bytes, hipStr
     }
     if (!r.done[s] && hipEventCreateWithFlags(&r.done[s], hipEventDisableTiming) != hipSuccess) { set_error("train_step: event create failed"); return -5; }
     memcpy(r.buf[s], host, bytes);
-    if (hipMemcpyAsync(dev, r.buf[s], bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(r.done[s], st) != hipSuccess) {
+    // the pinned buffer is read by a copy KERNEL (host-coherent memory is device-visible at the same address): an in-stream launch of ~3 us.
+    // hipMemcpyAsync takes the DMA-engine path for transfers of this size (~19 KB), whose start-up latency (tens of us) sat at the head of
+    // every iteration in front of everything else
+    const int n = (int)(bytes / 4);
+    if (stage_kernel_ok()) {
+        hipLaunchKernelGGL(stage_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<const int32_t*>(r.buf[s]), dev, n);
+        if (hipGetLastError() != hipSuccess) { set_error("train_step: index upload failed"); return -5; }
+    } else if (hipMemcpyAsync(dev, r.buf[s], bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
         (void)hipGetLastError();
         set_error("train_step: index upload failed");
         return -5;
     }
+    if (hipEventRecord(r.done[s], st) != hipSuccess) { (void)hipGetLastError(); set_error("train_step: index upload failed"); return -5; }
     r.used[s] = true;
     return 0;
 }
