@@ -6,6 +6,7 @@
 // clamp + Adam); what this file adds is the sequencing that echr_amd/functional.py + autograd otherwise do from Python -- ~75 ctypes
 // calls, four autograd nodes and their callbacks per iteration, 1.2 ms of host time against 1.75 ms of GPU time -- as host C++:
 // one call, the index vectors staged through a pinned ring, every buffer carved from one caller-owned workspace.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -102,6 +103,41 @@ using namespace echr;
 
 extern "C" int64_t echr_train_step_ws_floats(const echr_train_step_args* a) { return a ? carve_step(a).total : -1; }
 
+// diagnostic (ECHR_STEP_TIMING=1): HIP events at the phase boundaries of the call on the caller's stream; every 50th call prints the averages
+struct StepTiming { hipEvent_t e[5][8] = {}; int calls = 0; bool on = false, init = false; double acc[4] = {0, 0, 0, 0}; int n = 0; };
+static StepTiming& step_timing() {
+    static StepTiming t;
+    if (!t.init) {
+        t.init = true;
+        const char* e = getenv("ECHR_STEP_TIMING");
+        t.on = e && e[0] == '1';
+        if (t.on) for (auto& row : t.e) for (auto& ev : row) if (hipEventCreate(&ev) != hipSuccess) t.on = false;
+    }
+    return t;
+}
+static void step_mark(int k, hipStream_t st) {
+    StepTiming& t = step_timing();
+    if (t.on) (void)hipEventRecord(t.e[k][t.calls % 8], st);
+}
+static void step_timing_end() {
+    StepTiming& t = step_timing();
+    if (!t.on) return;
+    const int slot = (t.calls + 1) % 8;          // the oldest recorded call: long finished
+    if (t.calls >= 8) {
+        float ms;
+        bool ok = true;
+        double d[4];
+        for (int k = 0; k < 4 && ok; ++k) { ok = hipEventElapsedTime(&ms, t.e[k][slot], t.e[k + 1][slot]) == hipSuccess; d[k] = ms; }
+        if (ok) { for (int k = 0; k < 4; ++k) t.acc[k] += d[k]; ++t.n; } else (void)hipGetLastError();
+    }
+    ++t.calls;
+    if (t.n && t.calls % 50 == 0) {
+        fprintf(stderr, "[train_step] encoder + forward (to d logits) %.3f ms | decoder backward on this stream %.3f | event encoder backward + joins %.3f | clamp + Adam %.3f\n",
+                t.acc[0] / t.n, t.acc[1] / t.n, t.acc[2] / t.n, t.acc[3] / t.n);
+        t.acc[0] = t.acc[1] = t.acc[2] = t.acc[3] = 0; t.n = 0;
+    }
+}
+
 extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     ECHR_REQUIRE(a && a->ws && a->host_index && a->loss && a->g_loss && a->tap && a->flat_g, "train_step: missing buffers");
     ECHR_REQUIRE(a->tsrm.N == a->dec.N && a->tsrm.Do == a->dec.De && a->tsrm.Din == a->dec.D + a->Ht, "train_step: encoder / decoder shapes disagree");
@@ -111,6 +147,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     ECHR_REQUIRE(a->ws_floats >= L.total, "train_step: workspace holds %lld floats, %ld needed (echr_train_step_ws_floats)", (long long)a->ws_floats, L.total);
     float* ws = a->ws;
     const int N = a->dec.N, S = a->dec.S;
+    step_mark(0, st);
     int32_t* idx = reinterpret_cast<int32_t*>(ws + L.idx);
     ECHR_REQUIRE(a->n_active >= 0 && a->n_active <= S * N, "train_step: n_active out of range");
     const size_t n_idx = (size_t)(3 + S) * N + (size_t)a->n_active + (a->host_nll ? 2 * (size_t)S * N : 0);
@@ -158,6 +195,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
         else RC(echr_nll_loss_fwd(d.logp, static_cast<const int32_t*>(nll_target), nll_mask, a->loss, N, S, d.V1, stream));
     }
     if (a->forward_only) return 0;
+    step_mark(1, st);
     g.dlg_ready = fused_nll ? 1 : 0;
     if (fused_nll) g.nll_msum = nullptr;
     if (!compact) { g.active_rows = nullptr; g.n_active = 0; }          // (the forward kept all rows: vocabulary beyond the register-resident kernels, h2 off)
@@ -165,13 +203,17 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     // backward (train.py:313): criterion gradient in fused form
     g.zero_extra = nullptr; g.zero_extra_count = 0;
     RC(echr_decoder_bwd(&d, &g, &a->drop, stream));
+    step_mark(2, st);
     echr_tsrm_grads tg = a->tsrm_g;
     tg.g_ech = ws + L.g_ech; tg.g_out = ws + L.g_event; tg.ws_bwd = ws + L.tsrm_ws_bwd; tg.zeroed = 1;
     RC(echr_tsrm_bwd(&t, &tg, &a->drop, stream));
     if (a->g_tap) RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, a->dec.D, a->Ht, stream));
     if (fused_nll) RC(decoder_fused_loss(&d, &g, a->loss, st));
     RC(echr_stream_join(stream));          // the decoder backward's asynchronous tail: every gradient is final in `stream` order now
+    step_mark(3, st);
     if (a->do_step)                        // clip_gradient + Adam (misc/utils.py:107-111, train.py:315-317)
         RC(echr_clamp_adam(a->flat_p, a->flat_g, a->adam_m, a->adam_v, a->n_flat, a->adam_step, a->lr, a->beta1, a->beta2, a->eps, a->clip, stream));
+    step_mark(4, st);
+    step_timing_end();
     return 0;
 }
