@@ -321,9 +321,9 @@ int embed_gather(const float* W, const int* tok, float* out, int rows, int E, in
     return check_launch("embed_gather");
 }
 __global__ void embed_scatter_add_kernel(const float* __restrict__ dX, const int* __restrict__ tok, float* __restrict__ gW,
-                                         int rows, int E, int V1) {
+                                         int rows, int E, int V1, const int* __restrict__ rowmap) {
     const int row = blockIdx.x;
-    int t = tok[row];
+    int t = tok[rowmap ? rowmap[row] : row];          // (rowmap: dX holds the listed positions only)
     t = min(max(t, 0), V1 - 1);
     // Rows whose gradient is exactly zero add nothing: the label positions behind a caption's end (zero-padded labels, train.py:298: half of
     // all (t, n) positions at S = 20) all carry token 0, and their 512-wide atomics serialise on the <bos> / padding row of the table while
@@ -333,9 +333,9 @@ __global__ void embed_scatter_add_kernel(const float* __restrict__ dX, const int
     if (!__syncthreads_or(any)) return;
     for (int j = threadIdx.x; j < E; j += blockDim.x) atomicAdd(&gW[(long)t * E + j], dX[(long)row * E + j]);
 }
-int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st) {
+int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st, const int* rowmap) {
     if (config().diag_skip & 8) return 0;
-    hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(rows), dim3(128), 0, st, dX, tok, gW, rows, E, V1);
+    hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(rows), dim3(128), 0, st, dX, tok, gW, rows, E, V1, rowmap);
     return check_launch("embed_scatter_add");
 }
 

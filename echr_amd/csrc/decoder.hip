@@ -1229,6 +1229,11 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     const bool compact = g->dlg_ready && g->active_rows && g->n_active > 0;
     const int SNc = compact ? g->n_active : SN;
     const int* act = compact ? g->active_rows : nullptr;
+    // the recurrent weight gradients / d XT on the active rows too (ECHR_COMPACT_REC=0: all S*N rows, for A/B runs)
+    static const bool rec_env = [] { const char* e = getenv("ECHR_COMPACT_REC"); return !(e && e[0] == '0'); }();
+    const bool crec = compact && rec_env;
+    const int SNr = crec ? SNc : SN;
+    const int* actr = crec ? act : nullptr;
     ECHR_REQUIRE(!compact || (config().gemm_h2 && g->phase == 0 && g->async_tail != 0), "decoder_bwd: active_rows needs the h2 path and the asynchronous tail");
 
     ECHR_REQUIRE(g->phase >= 0 && g->phase <= 4, "decoder_bwd: phase must be 0..4");
@@ -1326,16 +1331,18 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
             pj[6] = pack_cols(w.XT, E, E, SN, b.PK_XTT);
             pj[7] = pack_cols(w.ATT, D, D, SN, b.PK_ATTT);
             pj[8] = pack_cols(b.DQ, Ha, Ha, SN, b.PK_DQT);
+            if (crec)          // rows behind a caption's end carry d G = d q = 0 exactly: the contraction runs over the active rows only
+                for (int i = 0; i < 9; ++i) { pj[i].K = SNr; pj[i].gather = actr; }
             RC(h2_pack_multi(pj, 9, q));
             // the seven products that contract d G_k^T over the S*N rows (W_hh x3, W_ih[:, :E] x3, W_ih1[:, E:]) share M = 4H and K, the W_h2a
             // gradient shares K: ONE grouped launch of 8 x 64 tile slots fills the chip in a single round (they were five launches)
             echr_gemm_desc g7[8];
             for (int k = 0; k < 3; ++k) {
-                g7[k] = desc_h2(b.PK_DGT[k], b.PK_HT[k], g->g_w_hh[k], H, 4 * H, H, SN);
-                g7[3 + k] = desc_h2(b.PK_DGT[k], b.PK_XTT, g->g_w_ih[k], cin[k], 4 * H, E, SN);
+                g7[k] = desc_h2(b.PK_DGT[k], b.PK_HT[k], g->g_w_hh[k], H, 4 * H, H, SNr);
+                g7[3 + k] = desc_h2(b.PK_DGT[k], b.PK_XTT, g->g_w_ih[k], cin[k], 4 * H, E, SNr);
             }
-            g7[6] = desc_h2(b.PK_DGT[1], b.PK_ATTT, g->g_w_ih[1] + E, cin[1], 4 * H, D, SN);
-            g7[7] = desc_h2(b.PK_DQT, b.PK_HT[1], g->g_w_h2a, H, Ha, H, SN);      // d q^T . h1 (M = Ha): same K, rides along
+            g7[6] = desc_h2(b.PK_DGT[1], b.PK_ATTT, g->g_w_ih[1] + E, cin[1], 4 * H, D, SNr);
+            g7[7] = desc_h2(b.PK_DQT, b.PK_HT[1], g->g_w_h2a, H, Ha, H, SNr);      // d q^T . h1 (M = Ha): same K, rides along
             for (int i = 0; i < 8; ++i) g7[i].beta = beta;
             return gemm_grouped(g7, 8, q);
         }
@@ -1566,7 +1573,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         if (h2) {
             H2PackJob pj[6];
             for (int k = 0; k < 3; ++k) {
-                pj[k] = pack_rows(b.DG[k], 4 * H, SN, 4 * H, b.PK_DG[k]);
+                pj[k] = pack_rows(b.DG[k], 4 * H, SNr, 4 * H, b.PK_DG[k]);
+                pj[k].gather = actr;          // (compact: d XT is formed for the active rows only, row i of it belongs to position act[i])
                 pj[3 + k] = pack_cols(a->w_ih[k], cin[k], E, 4 * H, b.PK_WIHT[k]);
             }
             RC(h2_pack_multi(pj, 6, st));
@@ -1579,12 +1587,12 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         const bool fused_scatter = config().embed_fused != 0;
         for (int k = 0; k < 3; ++k) {
             float* out = fused_scatter ? g->g_embed : b.DXT;
-            gx[k] = h2 ? desc_h2(b.PK_DG[k], b.PK_WIHT[k], out, E, SN, E, 4 * H) : desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], out, E, SN, E, 4 * H);
+            gx[k] = h2 ? desc_h2(b.PK_DG[k], b.PK_WIHT[k], out, E, SNr, E, 4 * H) : desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], out, E, SN, E, 4 * H);
             gx[k].split_k = -1; gx[k].beta = 1.f;                // shared, pre-zeroed output: everything adds atomically
             if (fused_scatter) { gx[k].row_index = a->tokens; gx[k].row_index_max = V1 - 1; }
         }
         RC(gemm_grouped(gx, 3, st));
-        if (!fused_scatter) RC(embed_scatter_add(b.DXT, a->tokens, g->g_embed, SN, E, V1, st));
+        if (!fused_scatter) RC(embed_scatter_add(b.DXT, a->tokens, g->g_embed, h2 ? SNr : SN, E, V1, st, h2 ? actr : nullptr));
     }
     if (async_tail) {
         if (hipEventRecord(tail().done, st) != hipSuccess) { set_error("decoder_bwd: event record failed"); return -5; }

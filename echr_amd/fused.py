@@ -133,7 +133,11 @@ class FusedTrainStep(object):
             if tg_h.shape != (N, S) or mk_h.shape != (N, S):
                 raise ValueError('targets / masks must be [N, >= S] (got %s, %s)' % (tuple(np.asarray(targets).shape), tuple(np.asarray(masks).shape)))
             if MASKED_ROWS[0] and not forward_only:
-                act = np.flatnonzero(mk_h.T.reshape(-1) != 0).astype(np.int32)          # time-major rows t*N + n, ascending
+                # active = up to the LAST non-zero mask entry of each caption: a position behind it reaches neither the loss nor, through
+                # the recurrence, any earlier gradient, so every gradient of the reverse recurrence is exactly zero there and the
+                # weight-gradient products skip those rows as well (a zero inside a caption stays listed: later steps feed back into it)
+                live = np.flip(np.logical_or.accumulate(np.flip(mk_h != 0, 1), 1), 1)
+                act = np.flatnonzero(live.T.reshape(-1)).astype(np.int32)               # time-major rows t*N + n, ascending
                 if act.size == 0 or act.size == N * S:
                     act = None
         n_act = 0 if act is None else int(act.size)

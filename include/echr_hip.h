@@ -251,10 +251,12 @@ typedef struct {
                                                   conversion pass), 0: int32 */
     int32_t dlg_ready;                         /* 1: d logits already sit in ws_bwd (echr_train_step forms them in the pass that reads the logits:
                                                   log-softmax + criterion + its gradient in one kernel); callers of echr_decoder_bwd leave it 0 */
-    const int32_t* active_rows;                /* echr_train_step only (with dlg_ready): the n_active time-major rows t*N + n whose criterion mask is
-                                                  non-zero, ascending.  Rows outside carry exactly zero d logits (misc/utils.py:66-75: the mask
-                                                  multiplies the log-prob), so the late-fusion products run on the compacted rows: logits and d logits
-                                                  exist as [n_active, V1], d OUTD is scattered back by row, d W_logit contracts over n_active rows */
+    const int32_t* active_rows;                /* echr_train_step only (with dlg_ready): the n_active time-major rows t*N + n with t <= the last
+                                                  timestep at which caption n's criterion mask is non-zero, ascending.  Rows outside carry exactly zero
+                                                  d logits (misc/utils.py:66-75: the mask multiplies the log-prob) and, as nothing later in the caption
+                                                  feeds back into them, exactly zero d gates / d q, so the late-fusion products run on the compacted
+                                                  rows (logits and d logits exist as [n_active, V1], d OUTD is scattered back by row, d W_logit contracts
+                                                  over n_active rows) and the recurrent weight gradients and d XT contract / run over the same rows */
     int32_t n_active;
 } echr_dec_grads;
 

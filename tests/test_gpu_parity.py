@@ -1068,9 +1068,9 @@ def test_fused_train_step_equals_autograd_path(case):
         o = ClampAdam(m.parameters(), lr=1e-3, arena=m.build_arena())
         return m, o
 
-    def autograd_iteration(m, o, step=True):
+    def autograd_iteration(m, o, step=True, mask=None):
         o.zero_grad()
-        loss = crit(m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), tgt, msk)
+        loss = crit(m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), tgt, msk if mask is None else mask)
         loss.backward()
         clip_gradient(o, 0.05)
         if step:
@@ -1127,6 +1127,19 @@ def test_fused_train_step_equals_autograd_path(case):
     autograd_iteration(ma, oa, step=False)
     fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:].numpy(), masks[:, 1:].numpy(), step=False)
     assert fb.last_active_rows > 0
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        if pa.grad is not None:
+            assert U.grad_close(k, pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), 2e-5), (k, U.relerr(pb.grad.cpu().numpy(), pa.grad.cpu().numpy()))
+    # ... and with holes in the mask (a zero INSIDE a caption: its position still receives gradient through the recurrence from the later
+    # steps, so it stays on the active list -- the list runs up to each caption's last non-zero entry)
+    holed = masks[:, 1:].clone()
+    holed[:, 1] = 0
+    holed[::2, 0] = 0
+    sync()
+    autograd_iteration(ma, oa, step=False, mask=holed.to(dev))
+    fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:].numpy(), holed.numpy(), step=False)
+    last = np.where(holed.numpy().any(1), holed.shape[1] - np.argmax(holed.numpy()[:, ::-1] != 0, 1), 0)
+    assert fb.last_active_rows == int(last.sum()) > int((holed != 0).sum())
     for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         if pa.grad is not None:
             assert U.grad_close(k, pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), 2e-5), (k, U.relerr(pb.grad.cpu().numpy(), pa.grad.cpu().numpy()))
