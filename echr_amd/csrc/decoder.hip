@@ -412,6 +412,9 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < PSLOTS; ++i) {
                 const float dsc = sds[tt * 8 + wave * PSLOTS + i];
+                // d score is exactly zero at every position behind a caption's end (about 40% of all (t, n) at S = 20) and contributes nothing:
+                // the slot is wave-uniform, so the skip costs one scalar branch
+                if ((__builtin_amdgcn_readfirstlane(__float_as_int(dsc)) << 1) == 0) continue;
                 dsum += dsc;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {

@@ -104,7 +104,7 @@ using namespace echr;
 extern "C" int64_t echr_train_step_ws_floats(const echr_train_step_args* a) { return a ? carve_step(a).total : -1; }
 
 // diagnostic (ECHR_STEP_TIMING=1): HIP events at the phase boundaries of the call on the caller's stream; every 50th call prints the averages
-struct StepTiming { hipEvent_t e[5][8] = {}; int calls = 0; bool on = false, init = false; double acc[4] = {0, 0, 0, 0}; int n = 0; };
+struct StepTiming { hipEvent_t e[6][8] = {}; int calls = 0; bool on = false, init = false; double acc[5] = {0, 0, 0, 0, 0}; int n = 0; };
 static StepTiming& step_timing() {
     static StepTiming t;
     if (!t.init) {
@@ -126,15 +126,16 @@ static void step_timing_end() {
     if (t.calls >= 8) {
         float ms;
         bool ok = true;
-        double d[4];
-        for (int k = 0; k < 4 && ok; ++k) { ok = hipEventElapsedTime(&ms, t.e[k][slot], t.e[k + 1][slot]) == hipSuccess; d[k] = ms; }
-        if (ok) { for (int k = 0; k < 4; ++k) t.acc[k] += d[k]; ++t.n; } else (void)hipGetLastError();
+        double d[5];
+        for (int k = 0; k < 5 && ok; ++k) { ok = hipEventElapsedTime(&ms, t.e[k][slot], t.e[k + 1][slot]) == hipSuccess; d[k] = ms; }
+        if (ok) { for (int k = 0; k < 5; ++k) t.acc[k] += d[k]; ++t.n; } else (void)hipGetLastError();
     }
     ++t.calls;
     if (t.n && t.calls % 50 == 0) {
-        fprintf(stderr, "[train_step] encoder + forward (to d logits) %.3f ms | decoder backward on this stream %.3f | event encoder backward + joins %.3f | clamp + Adam %.3f\n",
-                t.acc[0] / t.n, t.acc[1] / t.n, t.acc[2] / t.n, t.acc[3] / t.n);
-        t.acc[0] = t.acc[1] = t.acc[2] = t.acc[3] = 0; t.n = 0;
+        fprintf(stderr, "[train_step] encoder + forward (to d logits) %.3f ms | decoder backward on this stream %.3f | event encoder backward %.3f | wait for the helper streams %.3f | clamp + Adam %.3f\n",
+                t.acc[0] / t.n, t.acc[1] / t.n, t.acc[2] / t.n, t.acc[3] / t.n, t.acc[4] / t.n);
+        for (double& x : t.acc) x = 0;
+        t.n = 0;
     }
 }
 
@@ -209,11 +210,12 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     RC(echr_tsrm_bwd(&t, &tg, &a->drop, stream));
     if (a->g_tap) RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, a->dec.D, a->Ht, stream));
     if (fused_nll) RC(decoder_fused_loss(&d, &g, a->loss, st));
-    RC(echr_stream_join(stream));          // the decoder backward's asynchronous tail: every gradient is final in `stream` order now
     step_mark(3, st);
+    RC(echr_stream_join(stream));          // the decoder backward's asynchronous tail: every gradient is final in `stream` order now
+    step_mark(4, st);
     if (a->do_step)                        // clip_gradient + Adam (misc/utils.py:107-111, train.py:315-317)
         RC(echr_clamp_adam(a->flat_p, a->flat_g, a->adam_m, a->adam_v, a->n_flat, a->adam_step, a->lr, a->beta1, a->beta2, a->eps, a->clip, stream));
-    step_mark(4, st);
+    step_mark(5, st);
     step_timing_end();
     return 0;
 }

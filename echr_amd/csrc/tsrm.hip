@@ -137,6 +137,145 @@ __global__ __launch_bounds__(64) void tsrm_softmax_bwd_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Few events (training: N <= 64 per video): the per-head attention of MA_attention_8_NEW.py:138-160 in ONE launch forward and TWO backward,
+// one wave per (event row, head).  At N = 64, dg = 32 a head is 64 x 64 x 32 -- 0.26 MFLOP per product: the batched GEMM launches these
+// replace (forward: Q K^T, softmax, WD . XW; backward: d WD, d XW, softmax', d Q, d K) were three / five dependent launches of ~1 us of
+// arithmetic each on the iteration's critical chains, each one a 16-workgroup grid that exposes every memory latency.  Here lane = the other
+// event j: its K_j / XW_j row sits in registers (requested up front, with everything else the wave will read: ONE latency round), the row's
+// own operand is wave-uniform (scalar loads), the softmax runs across the lanes, and the products that contract over j go through a 64-float
+// LDS row (lane = (feature, half of j)).  N * G = 1024 independent waves spread over the chip.
+// ------------------------------------------------------------------------------------------------------
+constexpr int HEAD_MAXN = 64, HEAD_DG = 32;
+__device__ __forceinline__ void head_row32(const float* __restrict__ p, float (&r)[HEAD_DG], bool on) {
+#pragma unroll
+    for (int v = 0; v < HEAD_DG / 4; ++v) {
+        const float4 x = on ? *reinterpret_cast<const float4*>(p + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[4 * v] = x.x; r[4 * v + 1] = x.y; r[4 * v + 2] = x.z; r[4 * v + 3] = x.w;
+    }
+}
+// column c = lane & 31 of rows half*32 .. half*32+31 (half = lane >> 5) of a [N, ld] matrix: 128-byte coalesced per half and row
+__device__ __forceinline__ void head_col32(const float* __restrict__ p, long ld, int N, int lane, float (&r)[HEAD_DG]) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < HEAD_DG; ++u) {
+        const int j = h * 32 + u;
+        r[u] = j < N ? p[(long)j * ld + c] : 0.f;
+    }
+}
+// sum_j row[j] * col[j][c] with row in LDS and the lane's 32 column entries in registers; complete in every lane
+__device__ __forceinline__ float head_contract(const float* srow, const float (&col)[HEAD_DG], int lane) {
+    const float4* s4 = reinterpret_cast<const float4*>(srow + (lane >> 5) * 32);
+    float o = 0.f;
+#pragma unroll
+    for (int v = 0; v < HEAD_DG / 4; ++v) {
+        const float4 x = s4[v];
+        o = fmaf(x.x, col[4 * v], o); o = fmaf(x.y, col[4 * v + 1], o); o = fmaf(x.z, col[4 * v + 2], o); o = fmaf(x.w, col[4 * v + 3], o);
+    }
+    return o + __shfl_xor(o, 32);
+}
+__global__ __launch_bounds__(64) void tsrm_rowhead_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ XW,
+                                                              const float* __restrict__ GATE, const float* __restrict__ b_out,
+                                                              float* __restrict__ AFF, float* __restrict__ WSM, float* __restrict__ WD,
+                                                              float* __restrict__ OUT, int N, int Df, int Do, int G, float scale, DropCfg dc) {
+    __shared__ __attribute__((aligned(16))) float sw[HEAD_MAXN];
+    constexpr int DG = HEAD_DG;
+    const int r = blockIdx.x, g = blockIdx.y, j = threadIdx.x;
+    const bool on = j < N;
+    const float gate = on ? GATE[((long)r * N + j) * G + g] : 0.f;
+    float kj[DG], xw[DG];
+    head_row32(K + (long)j * Df + g * DG, kj, on);
+    head_col32(XW + g * DG, Do, N, j, xw);
+    const float* __restrict__ qr = Q + (long)r * Df + g * DG;          // wave-uniform
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < DG; ++k) acc = fmaf(qr[k], kj[k], acc);
+    const float aff = scale * acc;
+    // gated softmax over j (the arithmetic of tsrm_softmax_fwd_kernel)
+    const float v = on ? gate * aff : -INFINITY;
+    const float m = wave_max(v);
+    const float e = on ? expf(v - m) : 0.f;
+    const float inv = 1.f / wave_sum(e);
+    const float w = e * inv;
+    const float wd = on ? w * drop_mult(dc, (unsigned)(((long)r * G + g) * N + j), 0u, SITE_TSRM) : 0.f;
+    if (on) {
+        const long o = ((long)g * N + r) * N + j;
+        AFF[o] = aff;
+        WSM[o] = w;
+        WD[o] = wd;
+    }
+    sw[j] = wd;
+    __syncthreads();
+    // OUT[r, g*DG + c] = sum_j WD[r][j] XW[j][c] + b_out
+    const float o = head_contract(sw, xw, j);
+    if (j < DG) OUT[(long)r * Do + g * DG + j] = o + (b_out ? b_out[g * DG + j] : 0.f);
+}
+// backward, row side: d OUT_r -> d WD[r][:] -> softmax' -> d GATE[r, :, g], d AFF[g][r][:], d Q[r]
+__global__ __launch_bounds__(64) void tsrm_rowhead_bwd_kernel(const float* __restrict__ DOUT, const float* __restrict__ K, const float* __restrict__ XW,
+                                                              const float* __restrict__ GATE, const float* __restrict__ AFF, const float* __restrict__ WSM,
+                                                              float* __restrict__ DGATE, float* __restrict__ DAFF, float* __restrict__ DQ,
+                                                              int N, int Df, int Do, int G, float scale, DropCfg dc) {
+    __shared__ __attribute__((aligned(16))) float sw[HEAD_MAXN];
+    constexpr int DG = HEAD_DG;
+    const int r = blockIdx.x, g = blockIdx.y, j = threadIdx.x;
+    const bool on = j < N;
+    const long base = ((long)g * N + r) * N;
+    const long go = ((long)r * N + j) * G + g;
+    const float gate = on ? GATE[go] : 0.f;
+    const float wsm = on ? WSM[base + j] : 0.f;
+    const float aff = on ? AFF[base + j] : 0.f;
+    float xj[DG], kc[DG];
+    head_row32(XW + (long)j * Do + g * DG, xj, on);
+    head_col32(K + g * DG, Df, N, j, kc);
+    const float* __restrict__ dr = DOUT + (long)r * Do + g * DG;       // wave-uniform
+    float dwd = 0.f;
+#pragma unroll
+    for (int c = 0; c < DG; ++c) dwd = fmaf(dr[c], xj[c], dwd);
+    // the arithmetic of tsrm_softmax_bwd_kernel
+    const float dw = on ? dwd * drop_mult(dc, (unsigned)(((long)r * G + g) * N + j), 0u, SITE_TSRM) : 0.f;
+    const float s = wave_sum(wsm * dw);
+    const float ds = wsm * (dw - s);
+    const float daff = on ? ds * gate : 0.f;
+    if (on) {
+        DGATE[go] = ds * aff;
+        DAFF[base + j] = daff;
+    }
+    sw[j] = daff;
+    __syncthreads();
+    const float o = head_contract(sw, kc, j);
+    if (j < DG) DQ[(long)r * Df + g * DG + j] = scale * o;
+}
+// backward, column side: d XW[j] = sum_i WD[i][j] d OUT[i],  d K[j] = scale * sum_i d AFF[i][j] Q[i]   (one wave per (j, head); lane = i for
+// the two column gathers, lane = (feature, half of i) for the contraction)
+__global__ __launch_bounds__(64) void tsrm_colhead_bwd_kernel(const float* __restrict__ DOUT, const float* __restrict__ Q, const float* __restrict__ WD,
+                                                              const float* __restrict__ DAFF, float* __restrict__ DXW, float* __restrict__ DK,
+                                                              int N, int Df, int Do, int G, float scale) {
+    __shared__ __attribute__((aligned(16))) float sw[2][HEAD_MAXN];
+    constexpr int DG = HEAD_DG;
+    const int jc = blockIdx.x, g = blockIdx.y, i = threadIdx.x;
+    const long o = ((long)g * N + i) * N + jc;
+    const float wd = i < N ? WD[o] : 0.f;
+    const float da = i < N ? DAFF[o] : 0.f;
+    float dc[DG], qc[DG];
+    head_col32(DOUT + g * DG, Do, N, i, dc);
+    head_col32(Q + g * DG, Df, N, i, qc);
+    sw[0][i] = wd;
+    sw[1][i] = da;
+    __syncthreads();
+    const float dx = head_contract(sw[0], dc, i);
+    const float dk = head_contract(sw[1], qc, i);
+    if (i < DG) {
+        DXW[(long)jc * Do + g * DG + i] = dx;
+        DK[(long)jc * Df + g * DG + i] = scale * dk;
+    }
+}
+// the fused per-head kernels serve N <= 64 events with heads of 32 features: the reference's 512 / 16 (MA_attention_8_NEW.py:14-22)
+// (ECHR_TSRM_HEADS=0: the batched-GEMM form, for A/B runs)
+static bool head_fused_ok(int N, int Df, int Do, int G) {
+    static const bool off = [] { const char* e = getenv("ECHR_TSRM_HEADS"); return e && e[0] == '0'; }();
+    return !off && N <= HEAD_MAXN && Df == G * HEAD_DG && Do == G * HEAD_DG;
+}
+
 static inline long rup(long x, long a) { return (x + a - 1) / a * a; }
 
 struct TsrmWs { float *X, *POS, *P1, *GATE, *Q, *K, *XW, *AFF, *WSM, *WD, *PK_POS, *PK_WFC1; long total, zero_floats; };
@@ -537,11 +676,18 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
         if (Do == Df) RC(gemm_grouped(q3, 3, st));
         else for (int i = 0; i < 3; ++i) RC(gemm(q3[i], st));
     }
+    const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
+    if (head_fused_ok(N, Df, Do, G)) {
+        // few events: affinities, gated softmax, dropout and the weighted sum in one launch, one wave per (event, head) (:138-160)
+        if (fork) RC(aux_join(st));
+        hipLaunchKernelGGL(tsrm_rowhead_fwd_kernel, dim3(N, G), dim3(64), 0, st, w.Q, w.K, w.XW, w.GATE, a->b_out, w.AFF, w.WSM, w.WD, a->out,
+                           N, Df, Do, G, 1.0f / sqrtf((float)dgq), dc);
+        return check_launch("tsrm_rowhead_fwd");
+    }
     // per-head scaled affinities AFF[g] = Q_g . K_g^T / sqrt(dgq)   (:138-140)
     d = desc_nt(w.Q, Df, w.K, Df, w.AFF, N, N, N, dgq);
     d.batch = G; d.bsa = dgq; d.bsb = dgq; d.bsc = (long)NN; d.alpha = 1.0f / sqrtf((float)dgq);
     RC(gemm(d, st));
-    const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
     if (fork) RC(aux_join(st));
     const size_t sm_rows = (size_t)N * (G + 1) * sizeof(float);
     // 0 = not asked yet, 1 = the device grants the row kernel's dynamic LDS, 2 = refused (then the per-(row, head) kernel serves every size)
@@ -582,6 +728,15 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
         const long zn[2] = {(long)N * Df, (long)N * Din};
         RC(fill_zero_multi(zp, zn, g->g_ech ? 2 : 1, st));
     }
+    const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
+    const bool heads = head_fused_ok(N, Df, Do, G);
+    if (heads) {
+        // few events: d WD, the softmax backward and d Q per (event, head) wave; then d XW and d K per (column, head) wave
+        hipLaunchKernelGGL(tsrm_rowhead_bwd_kernel, dim3(N, G), dim3(64), 0, st, g->g_out, w.K, w.XW, w.GATE, w.AFF, w.WSM, b.DGATE, b.DAFF, b.DQ,
+                           N, Df, Do, G, scale, dc);
+        hipLaunchKernelGGL(tsrm_colhead_bwd_kernel, dim3(N, G), dim3(64), 0, st, g->g_out, w.Q, w.WD, b.DAFF, b.DXW, b.DK, N, Df, Do, G, scale);
+        RC(check_launch("tsrm_rowhead_bwd"));
+    } else {
     // dWD_g = dOUT_g . XW_g^T ; dXW_g = WD_g^T . dOUT_g
     d = desc_nt(g->g_out, Do, w.XW, Do, b.DWD, N, N, N, dgo);
     d.batch = G; d.bsa = dgo; d.bsb = dgo; d.bsc = (long)NN;
@@ -589,9 +744,9 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     d = desc_tn(w.WD, N, g->g_out, Do, b.DXW, Do, N, dgo, N);
     d.batch = G; d.bsa = (long)NN; d.bsb = dgo; d.bsc = dgo;
     RC(gemm(d, st));
-    const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
     hipLaunchKernelGGL(tsrm_softmax_bwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, b.DWD, b.DGATE, b.DAFF, N, G, dc);
     RC(check_launch("tsrm_softmax_bwd"));
+    }
     // The position-MLP gradients (d W_fc2, d P1, d W_fc1: 4.3 GF over the N^2 pairs) depend on d GATE alone: they run on the decoder's
     // prepare stream -- idle during a backward pass -- beside the query / key / embedding chain below (ten dependent small launches)
     static const bool fork2_off = [] { const char* e = getenv("ECHR_TSRM_FORK2"); return e && e[0] == '0'; }();      // A/B switch
@@ -615,12 +770,14 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
         RC(gemm(d, sp));
     }
     // dQ_g = scale * dAFF_g . K_g ; dK_g = scale * dAFF_g^T . Q_g
+    if (!heads) {
     d = desc_nn(b.DAFF, N, w.K, Df, b.DQ, Df, N, dgq, N);
     d.batch = G; d.bsa = (long)NN; d.bsb = dgq; d.bsc = dgq; d.alpha = scale;
     RC(gemm(d, st));
     d = desc_tn(b.DAFF, N, w.Q, Df, b.DK, Df, N, dgq, N);
     d.batch = G; d.bsa = (long)NN; d.bsb = dgq; d.bsc = dgq; d.alpha = scale;
     RC(gemm(d, st));
+    }
     // dX = dQ . Wq + dK . Wk + dXW . Wout: three problems adding into one output -> one grouped launch
     {
         echr_gemm_desc x3[3];
