@@ -308,6 +308,36 @@ int sum_over_time(const float* X, long ld, int S, int N, int cols, float* out, l
     return check_launch("sum_over_time");
 }
 
+// ---- rank-1 products of the scene-context path (one video vector per batch: OldModel_NEW.py:808-818 feeds it to stream 2 every step) ----
+// C[r, c] = x[r] * y[c] (+ C[r, c] when accumulate): the K = 1 "product" d W_ih2[:, E:] = colsum(d G_2)^T . video
+__global__ __launch_bounds__(256) void rank1_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ C, long ldc,
+                                                    int M, int N, int accumulate) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * N) return;
+    const int r = (int)(idx / N), c = (int)(idx % N);
+    const float v = x[r] * y[c];
+    C[(long)r * ldc + c] = accumulate ? C[(long)r * ldc + c] + v : v;
+}
+int rank1_update(const float* x, const float* y, float* C, long ldc, int M, int N, bool accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(rank1_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, st, x, y, C, ldc, M, N, accumulate ? 1 : 0);
+    return check_launch("rank1_update");
+}
+// out[c] = sum_r x[r] * W[r, c]  (M rows, N <= a few hundred columns): one workgroup per 64 columns, 4 row groups reduced through LDS
+__global__ __launch_bounds__(256) void vec_mat_kernel(const float* __restrict__ x, const float* __restrict__ W, long ldw, float* __restrict__ out, int M, int N) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < N)
+        for (int r = part; r < M; r += 4) s = fmaf(x[r], W[(long)r * ldw + c], s);
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < N) out[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+int vec_mat(const float* x, const float* W, long ldw, float* out, int M, int N, hipStream_t st) {
+    hipLaunchKernelGGL(vec_mat_kernel, dim3((N + 63) / 64), dim3(256), 0, st, x, W, ldw, out, M, N);
+    return check_launch("vec_mat");
+}
+
 // ---- embedding gather / scatter-add ----------------------------------------------------------------
 __global__ void embed_gather_kernel(const float* __restrict__ W, const int* __restrict__ tok, float* __restrict__ out,
                                     int rows, int E, int V1) {

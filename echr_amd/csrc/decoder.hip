@@ -1457,13 +1457,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
             d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);
             d.beta = zb; d.split_k = -1;
             RC(gemm(d, sa2));
-            d = desc_tn(b.DGCOL[2], 4 * H, a->video, a->Dv, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, 1);
-            RC(gemm(d, sa2));
-            if (g->g_video) {
-                d = desc_nn(b.DGCOL[2], 4 * H, a->w_ih[2] + E, cin[2], g->g_video, a->Dv, 1, a->Dv, 4 * H);
-                d.split_k = -1;
-                RC(gemm(d, sa2));
-            }
+            RC(rank1_update(b.DGCOL[2], a->video, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, false, sa2));          // K = 1: no GEMM launch
+            if (g->g_video) RC(vec_mat(b.DGCOL[2], a->w_ih[2] + E, cin[2], g->g_video, 4 * H, a->Dv, sa2));
             if (hipEventRecord(tail().done3, sa2) != hipSuccess) { set_error("decoder_bwd: event record failed"); return -5; }
             tail().pending3 = true;
             return 0;
@@ -1478,13 +1473,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);
         d.beta = zb; d.split_k = -1;
         RC(gemm(d, st));
-        d = desc_tn(b.DGCOL[2], 4 * H, a->video, a->Dv, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, 1);
-        RC(gemm(d, st));
-        if (g->g_video) {
-            d = desc_nn(b.DGCOL[2], 4 * H, a->w_ih[2] + E, cin[2], g->g_video, a->Dv, 1, a->Dv, 4 * H);
-            d.split_k = -1;
-            RC(gemm(d, st));
-        }
+        RC(rank1_update(b.DGCOL[2], a->video, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, false, st));
+        if (g->g_video) RC(vec_mat(b.DGCOL[2], a->w_ih[2] + E, cin[2], g->g_video, 4 * H, a->Dv, st));
         return 0;
     }
     if (ov) RC(hop(sq, side().join, st));                     // chunk [th,S) and the logit gradients are complete
@@ -1513,13 +1503,8 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     d = desc_nn(b.DGSUM[0], 4 * H, a->w_ih[0] + E, cin[0], g->g_event, a->De, N, a->De, 4 * H);
     d.split_k = -1; d.beta = 1.f;                                // zeroed with the backward scratch above
     RC(gemm(d, st));
-    d = desc_tn(b.DGCOL[2], 4 * H, a->video, a->Dv, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, 1);
-    RC(gemm(d, st));
-    if (g->g_video) {
-        d = desc_nn(b.DGCOL[2], 4 * H, a->w_ih[2] + E, cin[2], g->g_video, a->Dv, 1, a->Dv, 4 * H);
-        d.split_k = -1;
-        RC(gemm(d, st));
-    }
+    RC(rank1_update(b.DGCOL[2], a->video, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, false, st));
+    if (g->g_video) RC(vec_mat(b.DGCOL[2], a->w_ih[2] + E, cin[2], g->g_video, 4 * H, a->Dv, st));
     return 0;
     };
     // phase 0 + async_tail: nothing downstream in the backward pass needs part B's outputs -> second stream, joined by the caller.  Its three
