@@ -82,6 +82,18 @@ def gpu_leg(args, rank, world, local_rank):
         tl, tm, tw = (torch.from_numpy(vid[k]).to(dev) for k in ('tap_labels', 'tap_masks', 'w1'))
 
     def c5_iteration():      # train.py's joint 'tap_cg' iteration: SST -> caption path -> lambda1*tap_loss + lambda2*cg_loss
+        if fused is not None:
+            # the caption side as ONE library call (forward, criterion, backward, clip, Adam); d loss / d tap_feats comes back in g_tap and is
+            # backpropagated into the proposal encoder together with its own loss (same sums as loss.backward() of the joint loss)
+            tap_optim.zero_grad()
+            tap_feats, props = tap_model(c3d)
+            g_tap = torch.zeros_like(tap_feats)
+            cg_loss = fused(tap_feats.detach(), c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, tap_grad=g_tap)
+            tap_loss = 0.01 * tap_crit(props, tm, tl, tw)
+            torch.autograd.backward([tap_loss, tap_feats], [None, g_tap])
+            clip_gradient(tap_optim, opt.grad_clip)
+            tap_optim.step()
+            return tap_loss.detach() + cg_loss
         optim.zero_grad()
         tap_optim.zero_grad()
         tap_feats, props = tap_model(c3d)
@@ -107,7 +119,7 @@ def gpu_leg(args, rank, world, local_rank):
     # for the one-call form there too (backward inside the call, then ONE collective, then clip + step)
     fused = None
     want_fused = args.fused == 'on' or (args.fused == 'auto' and not use_dist)
-    if want_fused and arena is not None and not args.c5:
+    if want_fused and arena is not None and not (args.c5 and use_dist):
         from echr_amd.fused import FusedTrainStep
         fused = FusedTrainStep(model, optim, grad_clip=opt.grad_clip)
 

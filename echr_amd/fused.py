@@ -94,10 +94,14 @@ class FusedTrainStep(object):
             o._flat = dict(step=0, m=torch.zeros_like(self.arena.flat_p), v=torch.zeros_like(self.arena.flat_p))
         return o._flat
 
-    def __call__(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step=True, forward_only=False):
+    def __call__(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step=True, forward_only=False,
+                 tap_grad=None):
         """One iteration; returns the loss as a 0-d device tensor (no host sync).  `targets` / `masks`: what the reference hands its
         criterion (labels[:, 1:], masks[:, 1:]), host or device tensors.  step=False stops after the backward pass and exposes the
-        gradients as `.grad` views of the arena (data-parallel reduce, inspection); the caller then steps the optimiser itself."""
+        gradients as `.grad` views of the arena (data-parallel reduce, inspection); the caller then steps the optimiser itself.
+        `tap_grad`: a zero-filled float32 device tensor shaped like `tap_feats` that receives d loss / d tap_feats (added in place) -- the
+        joint 'tap_cg' iteration of train.py:300-313 backpropagates it into the proposal encoder together with its own loss:
+        `torch.autograd.backward([tap_loss, tap_feats], [None, tap_grad])`."""
         a, m, ar, lib = self.a, self.model, self.arena, self.lib
         if not c3d_feats.is_cuda:
             raise L.EchrHipError('FusedTrainStep runs on the GPU only')
@@ -160,6 +164,12 @@ class FusedTrainStep(object):
         if c3d.shape[1] != d.D or lda.numel() != d.Dv or tap.shape[1] + d.D != a.tsrm.Din:
             raise L.EchrHipError('feature widths do not match the model (c3d %d, lda %d, tap %d)' % (c3d.shape[1], lda.numel(), tap.shape[1]))
         d.c3d, d.video, a.tap, a.Ht = c3d.data_ptr(), lda.data_ptr(), tap.data_ptr(), tap.shape[1]
+        if tap_grad is not None and not forward_only:
+            if not (tap_grad.is_cuda and tap_grad.dtype == torch.float32 and tap_grad.is_contiguous() and tuple(tap_grad.shape) == tuple(tap.shape)):
+                raise ValueError('tap_grad must be a contiguous float32 device tensor shaped like tap_feats %s' % (tuple(tap.shape),))
+            a.g_tap = tap_grad.data_ptr()
+        else:
+            a.g_tap = None
         a.host_index = host.ctypes.data
         a.n_active, a.host_nll = n_act, 1 if host_nll else 0
         if host_nll:

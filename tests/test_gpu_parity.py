@@ -1164,6 +1164,17 @@ def test_fused_train_step_equals_autograd_path(case):
     lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk))
     assert abs(la - lb) < 2e-6 * abs(la)
     assert oa._flat['step'] == ob._flat['step']
+    # the joint 'tap_cg' iteration (train.py:300-313): d loss / d tap_feats comes back through `tap_grad` for the proposal encoder
+    sync()
+    tap_leaf = tap.clone().requires_grad_(True)
+    oa.zero_grad()
+    crit(ma(tap_leaf, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), tgt, msk).backward()
+    g_tap = torch.zeros_like(tap)
+    fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], step=False, tap_grad=g_tap)
+    assert float(tap_leaf.grad.abs().max()) > 0
+    assert U.grad_close('tap_feats', g_tap.cpu().numpy(), tap_leaf.grad.cpu().numpy(), 2e-5), U.relerr(g_tap.cpu().numpy(), tap_leaf.grad.cpu().numpy())
+    with pytest.raises(ValueError):
+        fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, step=False, tap_grad=torch.zeros(3, device=dev))
 
 
 def test_backward_pass_that_raises_does_not_poison_the_next_one():
