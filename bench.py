@@ -88,7 +88,8 @@ def gpu_leg(args, rank, world, local_rank):
             tap_optim.zero_grad()
             tap_feats, props = tap_model(c3d)
             g_tap = torch.zeros_like(tap_feats)
-            cg_loss = fused(tap_feats.detach(), c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, tap_grad=g_tap)
+            cg_loss = fused(tap_feats.detach(), c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, tap_grad=g_tap,
+                            defer_update=os.environ.get('ECHR_DEFER_UPDATE', '1') != '0')
             tap_loss = 0.01 * tap_crit(props, tm, tl, tw)
             torch.autograd.backward([tap_loss, tap_feats], [None, g_tap])
             clip_gradient(tap_optim, opt.grad_clip)

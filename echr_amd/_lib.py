@@ -84,7 +84,7 @@ class TrainStepArgs(C.Structure):
                 ('ws', c_f), ('ws_floats', i64), ('flat_g', c_f), ('n_flat', i64),
                 ('flat_p', c_f), ('adam_m', c_f), ('adam_v', c_f), ('adam_step', i32),
                 ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('clip', f32),
-                ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32)]
+                ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32), ('defer_update', i32)]
 
 
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)

@@ -1041,6 +1041,22 @@ int aux2_join(hipStream_t to) {
     if (hipEventRecord(pr.done, pr.s) != hipSuccess || hipStreamWaitEvent(to, pr.done, 0) != hipSuccess) { set_error("stream join failed"); return -5; }
     return 0;
 }
+// echr_train_step's joint mode (step.hip): the helper streams keep working after the call returns
+bool helpers_available() { return tail().ok && prep().ok && !prep().pending; }
+hipStream_t aux2_stream() { return prep().ok ? prep().s : nullptr; }
+hipStream_t helpers_merge_to_tail() {          // the tail stream continues behind everything queued on the prepare stream; returns the tail stream
+    Tail& t = tail();
+    Prep& pr = prep();
+    if (hipEventRecord(pr.done, pr.s) != hipSuccess || hipStreamWaitEvent(t.s, pr.done, 0) != hipSuccess) { set_error("stream join failed"); return nullptr; }
+    return t.s;
+}
+int tail_publish() {                           // what the tail stream carries now is what echr_stream_join / the next library call waits for
+    Tail& t = tail();
+    if (hipEventRecord(t.done, t.s) != hipSuccess) { set_error("event record failed"); return -5; }
+    t.pending = true;
+    t.pending3 = false;
+    return 0;
+}
 }  // namespace echr
 // will echr_decoder_fwd run the persistent forward launch on these arguments (same test as there)?
 static bool fwd_uses_persist(const echr_dec_args* a) {
@@ -1219,6 +1235,15 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     RC(check_dims(a, "decoder_bwd"));
     ECHR_REQUIRE(g && a->ws && g->ws_bwd && a->logp, "decoder_bwd: missing buffers");
     ECHR_REQUIRE(g->dlg_ready || g->g_logp || (g->nll_target && g->nll_mask && g->g_loss), "decoder_bwd: need g_logp or the fused NLL inputs");
+    return decoder_bwd_parts(a, g, drop, stream, 0);
+}
+
+// part 0: the whole call.  echr_train_step's joint mode (d tap_feats wanted early, step.hip) issues it in two pieces: 1 = what runs on the
+// caller's stream (late fusion, reverse recurrence, d event), 2 = what runs on the library's helper streams (every other gradient) -- forked
+// from the caller's stream where the second call is made, i.e. behind the event encoder's backward.  Pieces need async_tail = 2.
+int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, int part) {
+    ECHR_REQUIRE(part == 0 || (g->phase == 0 && g->async_tail == 2 && g->zeroed && config().gemm_h2 && tail().ok && !overlap_enabled()),
+                 "decoder_bwd: the two-piece form needs phase 0, async_tail 2, zeroed gradients, the h2 path and the helper streams");
     hipStream_t st = (hipStream_t)stream;
     const int N = a->N, S = a->S, H = a->H, E = a->E, Ha = a->Ha, A = a->A, D = a->D, V1 = a->V1;
     const int SN = S * N;
@@ -1241,9 +1266,10 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
 
     ECHR_REQUIRE(g->phase >= 0 && g->phase <= 4, "decoder_bwd: phase must be 0..4");
     // stages: late fusion | reverse recurrence + LSTM-layer gradients (part A) | attention + embedding gradients (part B)
-    const bool do_a = g->phase == 0 || g->phase == 1;
-    const bool do_rec = g->phase == 0 || g->phase == 2 || g->phase == 3;
-    const bool do_pb = g->phase == 0 || g->phase == 2 || g->phase == 4;
+    const bool do_a = (g->phase == 0 || g->phase == 1) && part != 2;
+    const bool do_rec_main = (g->phase == 0 || g->phase == 2 || g->phase == 3) && part != 2;          // the reverse recurrence itself
+    const bool do_rec = g->phase == 0 || g->phase == 2 || g->phase == 3;                                // ... and its batched parameter gradients
+    const bool do_pb = (g->phase == 0 || g->phase == 2 || g->phase == 4) && part != 1;
     // the reverse recurrence of this call runs as the persistent launch (same test as stage 3 applies)
     const bool bwd_persist = !overlap_enabled() && !(config().chains2 == 1 && side().ok && S >= 2) && persist_bwd_eligible(a);
     // 1. d logits (time-major, padded leading dimension)
@@ -1411,7 +1437,7 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
         return 0;
     };
     const bool two = !ov && config().chains2 == 1 && side().ok && S >= 2;
-    if (!do_rec) {
+    if (!do_rec_main) {
     } else if (!ov && !two && persist_bwd_eligible(a)) {
         // the whole reverse recurrence in two concurrent persistent launches (csrc/persist.hip)
         PersistBwdBufs pb;
@@ -1442,10 +1468,13 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
     auto part_a = [&]() -> int {
     if (!do_rec) return 0;
     if (g->phase == 0 && g->async_tail == 2 && z && h2 && !ov && tail().ok) {
+        if (part != 2) {
         RC(sum_over_time(b.DG[0], 4 * H, S, N, 4 * H, b.DGSUM[0], 4 * H, st));
         d = desc_nn(b.DGSUM[0], 4 * H, a->w_ih[0] + E, cin[0], g->g_event, a->De, N, a->De, 4 * H);
         d.split_k = -1; d.beta = 1.f;
         RC(gemm(d, st));
+        }
+        if (part == 1) return 0;
         sa2 = aux2_fork(st);
         if (sa2) {
             RC(wgrad_chunk(0, S, 1.f, sa2));

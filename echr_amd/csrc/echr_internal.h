@@ -63,6 +63,12 @@ hipStream_t aux_fork(hipStream_t from);          // nullptr when unavailable
 int aux_join(hipStream_t to);
 hipStream_t aux2_fork(hipStream_t from);         // the same on the decoder's prepare stream (idle during a backward pass); nullptr when unavailable
 int aux2_join(hipStream_t to);
+bool helpers_available();
+hipStream_t aux2_stream();
+hipStream_t helpers_merge_to_tail();
+int tail_publish();
+int tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr_dropout* drop, void* stream, int part);
+int decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, int part);
 int join_tail(hipStream_t st);          // make st wait for an asynchronous decoder-backward tail (decoder.hip); no-op when none is pending
 int persist_read_stamps(unsigned long long* dst, int max_entries);
 unsigned long long* persist_stamp_buffer(int S, hipStream_t st);      // diagnostic: [4][S <= 256][16] stamps, zeroed on st (nullptr: unavailable)

@@ -144,6 +144,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     ECHR_REQUIRE(a->tsrm.N == a->dec.N && a->tsrm.Do == a->dec.De && a->tsrm.Din == a->dec.D + a->Ht, "train_step: encoder / decoder shapes disagree");
     ECHR_REQUIRE(!a->do_step || (a->flat_p && a->adam_m && a->adam_v && a->adam_step >= 1), "train_step: optimiser state missing");
     hipStream_t st = (hipStream_t)stream;
+    RC(join_tail(st));          // (a deferred update of the previous call: it reads the index region this call is about to restage)
     const StepWs L = carve_step(a);
     ECHR_REQUIRE(a->ws_floats >= L.total, "train_step: workspace holds %lld floats, %ld needed (echr_train_step_ws_floats)", (long long)a->ws_floats, L.total);
     float* ws = a->ws;
@@ -203,6 +204,26 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
 
     // backward (train.py:313): criterion gradient in fused form
     g.zero_extra = nullptr; g.zero_extra_count = 0;
+    if (a->defer_update && a->g_tap && a->do_step && g.async_tail == 2 && fused_nll && config().gemm_h2 && helpers_available()) {
+        // Joint 'tap_cg' iteration (train.py:300-313): the proposal encoder's backward -- a 64-workgroup persistent launch that leaves three
+        // quarters of the chip idle -- waits for d tap_feats alone.  The chain that leads to it (late fusion, reverse recurrence, d event,
+        // the event encoder's attention backward, d ech) runs first and alone on the caller's stream; every parameter gradient and the
+        // clamp + Adam update follow on the helper streams, forked behind it, and are NOT joined here: they overlap whatever the caller
+        // queues next.  echr_stream_join (and the next echr_train_step / decoder call) waits for them.
+        echr_tsrm_grads tg = a->tsrm_g;
+        tg.g_ech = ws + L.g_ech; tg.g_out = ws + L.g_event; tg.ws_bwd = ws + L.tsrm_ws_bwd; tg.zeroed = 1;
+        RC(decoder_bwd_parts(&d, &g, &a->drop, stream, 1));
+        RC(tsrm_bwd_parts(&t, &tg, &a->drop, stream, 1));
+        RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, a->dec.D, a->Ht, stream));
+        RC(decoder_fused_loss(&d, &g, a->loss, st));
+        RC(decoder_bwd_parts(&d, &g, &a->drop, stream, 2));
+        hipStream_t s2 = aux2_stream();
+        RC(tsrm_bwd_parts(&t, &tg, &a->drop, s2, 2));
+        hipStream_t ts = helpers_merge_to_tail();
+        if (!ts) return -5;
+        RC(echr_clamp_adam(a->flat_p, a->flat_g, a->adam_m, a->adam_v, a->n_flat, a->adam_step, a->lr, a->beta1, a->beta2, a->eps, a->clip, ts));
+        return tail_publish();
+    }
     RC(echr_decoder_bwd(&d, &g, &a->drop, stream));
     step_mark(2, st);
     echr_tsrm_grads tg = a->tsrm_g;

@@ -711,8 +711,16 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
 }
 
 extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr_dropout* drop, void* stream) {
+    return tsrm_bwd_parts(a, g, drop, stream, 0);
+}
+// part 0: the whole backward.  echr_train_step's joint mode (step.hip) wants d ech -- the gradient the proposal encoder waits for -- as early
+// as possible: part 1 = the chain that leads to it (per-head attention backward, d X, d ech) on `stream`; part 2 = every parameter gradient
+// (position MLP, projections, embedding, biases), issued later on a helper stream passed as `stream`.  Parts need zeroed gradient buffers.
+int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr_dropout* drop, void* stream, int part) {
     RC(check(a, "tsrm_bwd"));
     ECHR_REQUIRE(g && g->g_out && g->ws_bwd, "tsrm_bwd: missing buffers");
+    ECHR_REQUIRE(part == 0 || (g->zeroed && g->g_ech), "tsrm_bwd: the two-piece form needs zeroed gradient buffers and g_ech");
+    const bool main_part = part != 2, rest_part = part != 1;
     hipStream_t st = (hipStream_t)stream;
     const int N = a->N, Din = a->Din, Df = a->Df, Do = a->Do, G = a->G;
     const int NN = N * N, dgq = Df / G, dgo = Do / G;
@@ -723,13 +731,14 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     const bool z = g->zeroed != 0;             // gradient buffers pre-zeroed by the caller: accumulate, no fills
     const float zb = z ? 1.f : 0.f;
     if (!z) RC(colsum(g->g_out, Do, N, Do, g->g_b_out, false, st));
+    const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
+    const bool heads = head_fused_ok(N, Df, Do, G);
+    if (main_part) {
     {   // accumulated (split-K) outputs zeroed by one launch: dX and, when requested, d ech
         float* zp[2] = {b.DX, g->g_ech};
         const long zn[2] = {(long)N * Df, (long)N * Din};
         RC(fill_zero_multi(zp, zn, g->g_ech ? 2 : 1, st));
     }
-    const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
-    const bool heads = head_fused_ok(N, Df, Do, G);
     if (heads) {
         // few events: d WD, the softmax backward and d Q per (event, head) wave; then d XW and d K per (column, head) wave
         hipLaunchKernelGGL(tsrm_rowhead_bwd_kernel, dim3(N, G), dim3(64), 0, st, g->g_out, w.K, w.XW, w.GATE, w.AFF, w.WSM, b.DGATE, b.DAFF, b.DQ,
@@ -747,13 +756,14 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     hipLaunchKernelGGL(tsrm_softmax_bwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, b.DWD, b.DGATE, b.DAFF, N, G, dc);
     RC(check_launch("tsrm_softmax_bwd"));
     }
+    }
     // The position-MLP gradients (d W_fc2, d P1, d W_fc1: 4.3 GF over the N^2 pairs) depend on d GATE alone: they run on the decoder's
     // prepare stream -- idle during a backward pass -- beside the query / key / embedding chain below (ten dependent small launches)
     static const bool fork2_off = [] { const char* e = getenv("ECHR_TSRM_FORK2"); return e && e[0] == '0'; }();      // A/B switch
-    hipStream_t sp = (config().tsrm_fork && !fork2_off) ? aux2_fork(st) : nullptr;
+    hipStream_t sp = (config().tsrm_fork && !fork2_off && part == 0) ? aux2_fork(st) : nullptr;
     const bool fork2 = sp != nullptr;
     if (!fork2) sp = st;
-    {
+    if (rest_part) {
         // position MLP (depends on d GATE only)
         d = desc_tn(b.DGATE, G, w.P1, Df, g->g_w_fc2, Df, G, Df, NN); d.beta = zb; d.split_k = -1;
         RC(gemm(d, sp));
@@ -770,7 +780,7 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
         RC(gemm(d, sp));
     }
     // dQ_g = scale * dAFF_g . K_g ; dK_g = scale * dAFF_g^T . Q_g
-    if (!heads) {
+    if (!heads && main_part) {
     d = desc_nn(b.DAFF, N, w.K, Df, b.DQ, Df, N, dgq, N);
     d.batch = G; d.bsa = (long)NN; d.bsb = dgq; d.bsc = dgq; d.alpha = scale;
     RC(gemm(d, st));
@@ -779,7 +789,7 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
     RC(gemm(d, st));
     }
     // dX = dQ . Wq + dK . Wk + dXW . Wout: three problems adding into one output -> one grouped launch
-    {
+    if (main_part) {
         echr_gemm_desc x3[3];
         x3[0] = desc_nn(b.DQ, Df, a->w_q, Df, b.DX, Df, N, Df, Df);
         x3[1] = desc_nn(b.DK, Df, a->w_k, Df, b.DX, Df, N, Df, Df);
@@ -787,6 +797,10 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
         for (int i = 0; i < 3; ++i) { x3[i].split_k = -1; x3[i].beta = 1.f; }      // dX zeroed above
         if (Do == Df && Df > 32) RC(gemm_grouped(x3, 3, st));
         else for (int i = 0; i < 3; ++i) RC(gemm(x3[i], st));
+        if (part == 1) {          // d ech right behind d X: nothing else of this call is on the way
+            d = desc_nn(b.DX, Df, a->w_emb, Din, g->g_ech, Din, N, Din, Df); d.split_k = -1; d.beta = 1.f;
+            return gemm(d, st);
+        }
     }
     // projection weights (three same-shaped products of X^T)
     {
@@ -815,7 +829,7 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
         RC(colsum(b.DP1, Df, NN, Df, g->g_b_fc1, false, st));
         RC(colsum(b.DX, Df, N, Df, g->g_b_emb, false, st));
     }
-    if (g->g_ech) {
+    if (g->g_ech && part == 0) {
         d = desc_nn(b.DX, Df, a->w_emb, Din, g->g_ech, Din, N, Din, Df); d.split_k = -1; d.beta = 1.f;
         RC(gemm(d, st));
     }

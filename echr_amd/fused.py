@@ -49,6 +49,10 @@ class FusedTrainStep(object):
         self.calls = 0
         self._fill_static()
 
+    def join(self):
+        """Make the current stream wait for a deferred update (defer_update=True); no-op otherwise."""
+        L.check(self.lib.echr_stream_join(L.stream_ptr()), 'stream_join')
+
     # ---- pointers that never change: parameters and their gradient slots ------------------------------------------------------
     def _fill_static(self):
         a, m, ar = self.a, self.model, self.arena
@@ -95,13 +99,16 @@ class FusedTrainStep(object):
         return o._flat
 
     def __call__(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step=True, forward_only=False,
-                 tap_grad=None):
+                 tap_grad=None, defer_update=False):
         """One iteration; returns the loss as a 0-d device tensor (no host sync).  `targets` / `masks`: what the reference hands its
         criterion (labels[:, 1:], masks[:, 1:]), host or device tensors.  step=False stops after the backward pass and exposes the
         gradients as `.grad` views of the arena (data-parallel reduce, inspection); the caller then steps the optimiser itself.
         `tap_grad`: a zero-filled float32 device tensor shaped like `tap_feats` that receives d loss / d tap_feats (added in place) -- the
         joint 'tap_cg' iteration of train.py:300-313 backpropagates it into the proposal encoder together with its own loss:
-        `torch.autograd.backward([tap_loss, tap_feats], [None, tap_grad])`."""
+        `torch.autograd.backward([tap_loss, tap_feats], [None, tap_grad])`.  `defer_update=True` (with tap_grad and step): the call returns
+        once tap_grad and the loss are final in stream order; the parameter gradients and the Adam update finish on the library's helper
+        streams beside the proposal encoder's backward.  The next call joins by itself; call `join()` before touching the model's parameters
+        in any other way (saving, evaluating, the autograd path)."""
         a, m, ar, lib = self.a, self.model, self.arena, self.lib
         if not c3d_feats.is_cuda:
             raise L.EchrHipError('FusedTrainStep runs on the GPU only')
@@ -170,6 +177,7 @@ class FusedTrainStep(object):
             a.g_tap = tap_grad.data_ptr()
         else:
             a.g_tap = None
+        a.defer_update = 1 if (defer_update and tap_grad is not None and step and not forward_only) else 0
         a.host_index = host.ctypes.data
         a.n_active, a.host_nll = n_act, 1 if host_nll else 0
         if host_nll:
@@ -182,6 +190,7 @@ class FusedTrainStep(object):
         a.drop = drop.c()
         need = lib.echr_train_step_ws_floats(C.byref(a))
         if self.ws is None or self.ws.numel() < need:
+            self.join()                        # (a deferred update may still be reading the old workspace on the helper streams)
             self.ws = None                     # (released in stream order by the caching allocator)
             self.ws = torch.empty(need, device=self.dev, dtype=torch.float32)
         a.ws, a.ws_floats = self.ws.data_ptr(), self.ws.numel()

@@ -436,6 +436,11 @@ typedef struct {
                                       training then forms logits, d logits and the logit-layer products on those rows only (the masked-out
                                       label positions behind a caption's end -- half of all rows at S = 20 -- cannot reach the loss).  0: all rows */
     int32_t host_nll;              /* 1: targets and mask travel in host_index too (nll_target / nll_mask are ignored) */
+    int32_t defer_update;          /* 1 (with g_tap and do_step): joint 'tap_cg' iteration -- the call returns as soon as g_tap and the loss are
+                                      final in `stream` order; the parameter gradients and the clamp + Adam update complete on library-owned
+                                      streams beside whatever the caller queues next (the proposal encoder's backward, train.py:313).  The
+                                      caller MUST call echr_stream_join(stream) before reading parameters or gradients or freeing ws;
+                                      the next echr_train_step joins by itself */
 } echr_train_step_args;
 int64_t echr_train_step_ws_floats(const echr_train_step_args* a);
 int echr_train_step(const echr_train_step_args* a, void* stream);

@@ -1175,6 +1175,30 @@ def test_fused_train_step_equals_autograd_path(case):
     assert U.grad_close('tap_feats', g_tap.cpu().numpy(), tap_leaf.grad.cpu().numpy(), 2e-5), U.relerr(g_tap.cpu().numpy(), tap_leaf.grad.cpu().numpy())
     with pytest.raises(ValueError):
         fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, step=False, tap_grad=torch.zeros(3, device=dev))
+    # ... and with the deferred update: tap_grad and the loss are final on return, the parameter gradients and Adam finish on the helper
+    # streams (joined by join() / the next call); same update as the autograd iteration from the same state
+    sync()
+    la = autograd_iteration(ma, oa)
+    g_ref = torch.zeros_like(tap)
+    fb2_tap = torch.zeros_like(tap)
+    lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], tap_grad=fb2_tap, defer_update=True))
+    assert abs(la - lb) < 2e-6 * abs(la)
+    assert U.grad_close('tap_feats', fb2_tap.cpu().numpy(), g_tap.cpu().numpy(), 1e-3)          # (same state up to one Adam step of noise-level drift)
+    fb.join()
+    assert oa._flat['step'] == ob._flat['step']
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        dp = (pa.detach() - pb.detach()).abs()
+        assert float(dp.max()) <= 2.01 * lr, k
+        if pa.grad is not None and k not in U.NOISE_ONLY:
+            gg = pa.grad.abs()
+            solid = gg > 1e-4 * gg.max()
+            if bool(solid.any()):
+                assert float(dp[solid].max()) < 0.02 * lr, (k, float(dp[solid].max()))
+    # two deferred iterations back to back (the second call joins the first by itself), then an ordinary one
+    for _ in range(2):
+        fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], tap_grad=torch.zeros_like(tap), defer_update=True)
+    lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk))
+    assert np.isfinite(lb)
 
 
 def test_backward_pass_that_raises_does_not_poison_the_next_one():
