@@ -86,11 +86,15 @@ def gpu_leg(args, rank, world, local_rank):
             # the caption side as ONE library call (forward, criterion, backward, clip, Adam); d loss / d tap_feats comes back in g_tap and is
             # backpropagated into the proposal encoder together with its own loss (same sums as loss.backward() of the joint loss)
             tap_optim.zero_grad()
+            early = os.environ.get('ECHR_EARLY_PREPARE', '1') != '0'
+            if early:          # the caption side's tap-independent part starts now and runs beside the proposal encoder's forward
+                fused.prepare(c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h)
             tap_feats, props = tap_model(c3d)
             g_tap = torch.zeros_like(tap_feats)
+            tap_loss = 0.01 * tap_crit(props, tm, tl, tw)          # (queued before the caption side: nothing of it waits for g_tap)
+            defer = os.environ.get('ECHR_DEFER_UPDATE', '1') != '0'
             cg_loss = fused(tap_feats.detach(), c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, tap_grad=g_tap,
-                            defer_update=os.environ.get('ECHR_DEFER_UPDATE', '1') != '0')
-            tap_loss = 0.01 * tap_crit(props, tm, tl, tw)
+                            defer_update=defer, prepared=early)
             torch.autograd.backward([tap_loss, tap_feats], [None, g_tap])
             clip_gradient(tap_optim, opt.grad_clip)
             tap_optim.step()

@@ -84,7 +84,7 @@ class TrainStepArgs(C.Structure):
                 ('ws', c_f), ('ws_floats', i64), ('flat_g', c_f), ('n_flat', i64),
                 ('flat_p', c_f), ('adam_m', c_f), ('adam_v', c_f), ('adam_step', i32),
                 ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('clip', f32),
-                ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32), ('defer_update', i32)]
+                ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32), ('prepared', i32), ('defer_update', i32)]
 
 
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)
@@ -135,6 +135,7 @@ SYMBOLS = [
     ('echr_top_proposals_nms', i32, [c_f, i32, i32, i32, C.c_double, c_f, c_f, c_f, c_f, C.c_void_p]),
     ('echr_train_step_ws_floats', i64, [C.POINTER(TrainStepArgs)]),
     ('echr_train_step', i32, [C.POINTER(TrainStepArgs), C.c_void_p]),
+    ('echr_train_step_prepare', i32, [C.POINTER(TrainStepArgs), C.c_void_p]),
     ('echr_clamp', i32, [c_f, i64, f32, C.c_void_p]),
     ('echr_clamp_adam', i32, [c_f, c_f, c_f, c_f, i64, i32, C.c_double, C.c_double, C.c_double, C.c_double, f32, C.c_void_p]),
 ]

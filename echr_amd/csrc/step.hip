@@ -139,8 +139,58 @@ static void step_timing_end() {
     }
 }
 
+// joint mode: the helper streams' work of one call
+struct JointPending { echr_dec_args d; echr_dec_grads g; echr_tsrm_args t; echr_tsrm_grads tg; echr_dropout drop; echr_train_step_args args; };
+// every parameter gradient (decoder: helper streams forked from `src`; event encoder: behind them on the prepare stream), then clamp + Adam on
+// the tail stream, published for echr_stream_join
+static int joint_finish(JointPending& jp, hipStream_t src) {
+    RC(decoder_bwd_parts(&jp.d, &jp.g, &jp.drop, src, 2));
+    hipStream_t s2 = aux2_stream();
+    RC(tsrm_bwd_parts(&jp.t, &jp.tg, &jp.drop, s2, 2));
+    hipStream_t ts = helpers_merge_to_tail();
+    if (!ts) return -5;
+    const echr_train_step_args& a = jp.args;
+    RC(echr_clamp_adam(a.flat_p, a.flat_g, a.adam_m, a.adam_v, a.n_flat, a.adam_step, a.lr, a.beta1, a.beta2, a.eps, a.clip, ts));
+    return tail_publish();
+}
+
+// the decoder arguments of one call (shared by echr_train_step_prepare and echr_train_step: both must describe the same launch)
+static echr_dec_args step_dec_args(const echr_train_step_args* a, const StepWs& L, const int32_t* idx) {
+    const int N = a->dec.N;
+    echr_dec_args d = a->dec;
+    d.ev_start = idx; d.ev_len = idx + N; d.tokens = idx + 3 * N;
+    d.ws = a->ws + L.dec_ws; d.logp = a->ws + L.logp; d.event = nullptr; d.prepared = 0;
+    d.train = a->forward_only ? 0 : 1;
+    // the gradient arena is zero-filled by the forward's first fill launch (beside the event encoder), not in front of the reverse recurrence
+    d.zero_extra = a->forward_only ? nullptr : a->flat_g; d.zero_extra_count = a->n_flat;
+    return d;
+}
+static size_t step_index_count(const echr_train_step_args* a) {
+    return (size_t)(3 + a->dec.S) * a->dec.N + (size_t)a->n_active + (a->host_nll ? 2 * (size_t)a->dec.S * a->dec.N : 0);
+}
+
+// Optional first half of echr_train_step for the joint 'tap_cg' iteration (train.py:300-313): everything of the call that does not read
+// tap_feats -- index staging and the decoder's event-independent part (attention projections of the video, token-side gates, operand packs,
+// the gradient-arena fill) -- is started on the library's prepare stream BEFORE the caller queues the proposal encoder's forward, a 64-workgroup
+// persistent launch that leaves three quarters of the chip idle.  The following echr_train_step takes the same arguments plus prepared = 1
+// (tap / g_tap may be filled in only then).
+extern "C" int echr_train_step_prepare(const echr_train_step_args* a, void* stream) {
+    ECHR_REQUIRE(a && a->ws && a->host_index && a->flat_g, "train_step_prepare: missing buffers");
+    ECHR_REQUIRE(a->overlap_encoder, "train_step_prepare: needs overlap_encoder = 1");
+    hipStream_t st = (hipStream_t)stream;
+    RC(join_tail(st));
+    const StepWs L = carve_step(a);
+    ECHR_REQUIRE(a->ws_floats >= L.total, "train_step_prepare: workspace holds %lld floats, %ld needed (echr_train_step_ws_floats)", (long long)a->ws_floats, L.total);
+    ECHR_REQUIRE(a->n_active >= 0 && a->n_active <= a->dec.S * a->dec.N, "train_step: n_active out of range");
+    int32_t* idx = reinterpret_cast<int32_t*>(a->ws + L.idx);
+    RC(stage_indices(a->host_index, idx, sizeof(int32_t) * step_index_count(a), st));
+    echr_dec_args d = step_dec_args(a, L, idx);
+    return echr_decoder_fwd_prepare(&d, stream);
+}
+
 extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     ECHR_REQUIRE(a && a->ws && a->host_index && a->loss && a->g_loss && a->tap && a->flat_g, "train_step: missing buffers");
+    ECHR_REQUIRE(!a->prepared || a->overlap_encoder, "train_step: prepared = 1 needs overlap_encoder = 1");
     ECHR_REQUIRE(a->tsrm.N == a->dec.N && a->tsrm.Do == a->dec.De && a->tsrm.Din == a->dec.D + a->Ht, "train_step: encoder / decoder shapes disagree");
     ECHR_REQUIRE(!a->do_step || (a->flat_p && a->adam_m && a->adam_v && a->adam_step >= 1), "train_step: optimiser state missing");
     hipStream_t st = (hipStream_t)stream;
@@ -152,8 +202,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     step_mark(0, st);
     int32_t* idx = reinterpret_cast<int32_t*>(ws + L.idx);
     ECHR_REQUIRE(a->n_active >= 0 && a->n_active <= S * N, "train_step: n_active out of range");
-    const size_t n_idx = (size_t)(3 + S) * N + (size_t)a->n_active + (a->host_nll ? 2 * (size_t)S * N : 0);
-    RC(stage_indices(a->host_index, idx, sizeof(int32_t) * n_idx, st));
+    if (!a->prepared) RC(stage_indices(a->host_index, idx, sizeof(int32_t) * step_index_count(a), st));
     const int32_t *ev_start = idx, *ev_len = idx + N, *ind = idx + 2 * N, *tokens = idx + 3 * N, *active = idx + (3 + S) * N;
     const void* nll_target = a->nll_target;
     const float* nll_mask = a->nll_mask;
@@ -165,14 +214,9 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     }
     ECHR_REQUIRE(nll_target && nll_mask, "train_step: criterion targets / mask missing");
 
-    echr_dec_args d = a->dec;
-    d.ev_start = ev_start; d.ev_len = ev_len; d.tokens = tokens;
-    d.ws = ws + L.dec_ws; d.logp = ws + L.logp; d.event = nullptr; d.prepared = 0;
-    d.train = a->forward_only ? 0 : 1;
-    // the gradient arena is zero-filled by the forward's first fill launch (beside the event encoder), not in front of the reverse recurrence
-    d.zero_extra = a->forward_only ? nullptr : a->flat_g; d.zero_extra_count = a->n_flat;
+    echr_dec_args d = step_dec_args(a, L, idx);
     // CaptionGenerator.forward (:23-30): the decoder's event-independent part starts on the library's second stream and overlaps the event encoder
-    if (a->overlap_encoder) RC(echr_decoder_fwd_prepare(&d, stream));
+    if (a->overlap_encoder && !a->prepared) RC(echr_decoder_fwd_prepare(&d, stream));
     echr_tsrm_args t = a->tsrm;
     t.ech = ws + L.ech; t.ev_start = ev_start; t.ev_len = ev_len; t.ws = ws + L.tsrm_ws; t.out = ws + L.event;
     t.inference = 0; t.max_len = 0; t.max_span = 0;
@@ -216,13 +260,12 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
         RC(tsrm_bwd_parts(&t, &tg, &a->drop, stream, 1));
         RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, a->dec.D, a->Ht, stream));
         RC(decoder_fused_loss(&d, &g, a->loss, st));
-        RC(decoder_bwd_parts(&d, &g, &a->drop, stream, 2));
-        hipStream_t s2 = aux2_stream();
-        RC(tsrm_bwd_parts(&t, &tg, &a->drop, s2, 2));
-        hipStream_t ts = helpers_merge_to_tail();
-        if (!ts) return -5;
-        RC(echr_clamp_adam(a->flat_p, a->flat_g, a->adam_m, a->adam_v, a->n_flat, a->adam_step, a->lr, a->beta1, a->beta2, a->eps, a->clip, ts));
-        return tail_publish();
+        JointPending jp;
+        jp.d = d; jp.g = g; jp.t = t; jp.tg = tg; jp.drop = a->drop; jp.args = *a;
+        // (issuing the helper work only after the caller has queued the proposal encoder's backward -- a second entry point, tried -- is worse:
+        // 3.21 vs 3.00 ms on c5.  The host needs ~0.5 ms to get from here to that launch anyway, the helpers fill exactly that gap, and a
+        // persistent recurrence that shares its CUs with GEMM workgroups from its first step on loses more than the gap is worth)
+        return joint_finish(jp, st);
     }
     RC(echr_decoder_bwd(&d, &g, &a->drop, stream));
     step_mark(2, st);

@@ -98,8 +98,16 @@ class FusedTrainStep(object):
             o._flat = dict(step=0, m=torch.zeros_like(self.arena.flat_p), v=torch.zeros_like(self.arena.flat_p))
         return o._flat
 
+    def prepare(self, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks):
+        """Joint 'tap_cg' iteration (train.py:300-313), optional first half: everything of the iteration that does not read tap_feats (index
+        staging, the decoder's event-independent part, the gradient-arena fill) starts on the library's prepare stream and runs beside the
+        proposal encoder's forward queued next.  Follow with `self(tap_feats, <the same arguments>, prepared=True, ...)`."""
+        self._setup(None, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, True, False, None, False)
+        L.check(self.lib.echr_train_step_prepare(C.byref(self.a), L.stream_ptr()), 'train_step_prepare')
+        self._prepared = True
+
     def __call__(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step=True, forward_only=False,
-                 tap_grad=None, defer_update=False):
+                 tap_grad=None, defer_update=False, prepared=False):
         """One iteration; returns the loss as a 0-d device tensor (no host sync).  `targets` / `masks`: what the reference hands its
         criterion (labels[:, 1:], masks[:, 1:]), host or device tensors.  step=False stops after the backward pass and exposes the
         gradients as `.grad` views of the arena (data-parallel reduce, inspection); the caller then steps the optimiser itself.
@@ -108,7 +116,40 @@ class FusedTrainStep(object):
         `torch.autograd.backward([tap_loss, tap_feats], [None, tap_grad])`.  `defer_update=True` (with tap_grad and step): the call returns
         once tap_grad and the loss are final in stream order; the parameter gradients and the Adam update finish on the library's helper
         streams beside the proposal encoder's backward.  The next call joins by itself; call `join()` before touching the model's parameters
-        in any other way (saving, evaluating, the autograd path)."""
+        in any other way (saving, evaluating, the autograd path).  `prepared=True`: `prepare()` ran with the same arguments."""
+        a, lib = self.a, self.lib
+        if prepared:
+            if not getattr(self, '_prepared', False) or not step or forward_only:
+                raise RuntimeError('prepared=True needs a preceding prepare() and a full training step')
+            self._prepared = False
+            self._set_tap(EF._f32c(tap_feats), tap_grad, defer_update, True, False)
+            a.prepared = 1
+            slot, st = self._slot, self._state
+        else:
+            if getattr(self, '_prepared', False):
+                raise RuntimeError('prepare() must be followed by a call with prepared=True')
+            slot, st = self._setup(tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step, forward_only,
+                                   tap_grad, defer_update)
+            a.prepared = 0
+        L.check(lib.echr_train_step(C.byref(a), L.stream_ptr()), 'train_step')
+        return self._finish(slot, st, forward_only)
+
+    def _set_tap(self, tap, tap_grad, defer_update, step, forward_only):
+        a, d = self.a, self.a.dec
+        if tap.shape[1] + d.D != a.tsrm.Din or tap.shape[0] < self._tv_needed:
+            raise L.EchrHipError('tap_feats %s do not match the model / the event anchors' % (tuple(tap.shape),))
+        a.tap, a.Ht = tap.data_ptr(), tap.shape[1]
+        self._tap_keep = tap
+        if tap_grad is not None and not forward_only:
+            if not (tap_grad.is_cuda and tap_grad.dtype == torch.float32 and tap_grad.is_contiguous() and tuple(tap_grad.shape) == tuple(tap.shape)):
+                raise ValueError('tap_grad must be a contiguous float32 device tensor shaped like tap_feats %s' % (tuple(tap.shape),))
+            a.g_tap = tap_grad.data_ptr()
+        else:
+            a.g_tap = None
+        a.defer_update = 1 if (defer_update and tap_grad is not None and step and not forward_only) else 0
+
+    def _setup(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step, forward_only,
+               tap_grad, defer_update):
         a, m, ar, lib = self.a, self.model, self.arena, self.lib
         if not c3d_feats.is_cuda:
             raise L.EchrHipError('FusedTrainStep runs on the GPU only')
@@ -118,7 +159,7 @@ class FusedTrainStep(object):
         ind = np.asarray(ind_select_list, dtype=np.int64).reshape(-1)
         lens = soi[:, 1] - soi[:, 0]
         N = len(soi)
-        Tv = min(c3d_feats.shape[0], tap_feats.shape[0])
+        Tv = c3d_feats.shape[0] if tap_feats is None else min(c3d_feats.shape[0], tap_feats.shape[0])
         if N == 0 or lens.min() <= 0:
             raise ValueError('every event needs at least one segment (soi=%s)' % (soi.tolist(),))
         if len(ind) != N:
@@ -131,7 +172,9 @@ class FusedTrainStep(object):
             raise ValueError('label tensor needs at least two columns')
         if labels.shape[0] != N:
             raise ValueError('labels have %d rows for %d events' % (labels.shape[0], N))
-        c3d, tap, lda = EF._f32c(c3d_feats), EF._f32c(tap_feats), EF._f32c(lda_feats)
+        c3d, lda = EF._f32c(c3d_feats), EF._f32c(lda_feats)
+        tap = None if tap_feats is None else EF._f32c(tap_feats)
+        self._tv_needed = int(max(soi[:, 1].max(), ind.max() + 1))
         # Criterion inputs.  On the host (numpy / CPU tensors, as the reference's loader hands them over, train.py:273-279): they travel with
         # the index vectors, and the rows whose mask is non-zero are listed -- the masked-out label positions behind a caption's end cannot
         # reach the loss (misc/utils.py:66-75 multiplies by the mask), so training forms logits, d logits and the logit-layer products on the
@@ -168,16 +211,14 @@ class FusedTrainStep(object):
         d = a.dec
         a.tsrm.N = d.N = N
         d.A, d.Tv, d.S, d.rows_disjoint = int(lens.max()), c3d.shape[0], S, 1 if EF.rows_disjoint(soi) else 0
-        if c3d.shape[1] != d.D or lda.numel() != d.Dv or tap.shape[1] + d.D != a.tsrm.Din:
-            raise L.EchrHipError('feature widths do not match the model (c3d %d, lda %d, tap %d)' % (c3d.shape[1], lda.numel(), tap.shape[1]))
-        d.c3d, d.video, a.tap, a.Ht = c3d.data_ptr(), lda.data_ptr(), tap.data_ptr(), tap.shape[1]
-        if tap_grad is not None and not forward_only:
-            if not (tap_grad.is_cuda and tap_grad.dtype == torch.float32 and tap_grad.is_contiguous() and tuple(tap_grad.shape) == tuple(tap.shape)):
-                raise ValueError('tap_grad must be a contiguous float32 device tensor shaped like tap_feats %s' % (tuple(tap.shape),))
-            a.g_tap = tap_grad.data_ptr()
+        if c3d.shape[1] != d.D or lda.numel() != d.Dv:
+            raise L.EchrHipError('feature widths do not match the model (c3d %d, lda %d)' % (c3d.shape[1], lda.numel()))
+        d.c3d, d.video = c3d.data_ptr(), lda.data_ptr()
+        self._keep = (c3d, lda, host)
+        if tap is None:                        # prepare(): tap_feats arrive with the second half
+            a.tap, a.Ht, a.g_tap, a.defer_update = None, a.tsrm.Din - d.D, None, 0
         else:
-            a.g_tap = None
-        a.defer_update = 1 if (defer_update and tap_grad is not None and step and not forward_only) else 0
+            self._set_tap(tap, tap_grad, defer_update, step, forward_only)
         a.host_index = host.ctypes.data
         a.n_active, a.host_nll = n_act, 1 if host_nll else 0
         if host_nll:
@@ -215,7 +256,13 @@ class FusedTrainStep(object):
             a.adam_m, a.adam_v, a.adam_step = st['m'].data_ptr(), st['v'].data_ptr(), st['step'] + 1
             a.lr, (a.beta1, a.beta2), a.eps = group['lr'], group['betas'], group['eps']
             a.clip = float('inf') if clip is None else float(clip)
-        L.check(lib.echr_train_step(C.byref(a), L.stream_ptr()), 'train_step')
+        else:
+            st = None
+        self._slot, self._state = slot, st
+        return slot, st
+
+    def _finish(self, slot, st, forward_only):
+        a, m, ar = self.a, self.model, self.arena
         if a.do_step:
             st['step'] += 1
             EF.PARAM_EPOCH[0] += 1

@@ -436,6 +436,7 @@ typedef struct {
                                       training then forms logits, d logits and the logit-layer products on those rows only (the masked-out
                                       label positions behind a caption's end -- half of all rows at S = 20 -- cannot reach the loss).  0: all rows */
     int32_t host_nll;              /* 1: targets and mask travel in host_index too (nll_target / nll_mask are ignored) */
+    int32_t prepared;              /* 1: echr_train_step_prepare already ran with these arguments (see there) */
     int32_t defer_update;          /* 1 (with g_tap and do_step): joint 'tap_cg' iteration -- the call returns as soon as g_tap and the loss are
                                       final in `stream` order; the parameter gradients and the clamp + Adam update complete on library-owned
                                       streams beside whatever the caller queues next (the proposal encoder's backward, train.py:313).  The
@@ -444,6 +445,11 @@ typedef struct {
 } echr_train_step_args;
 int64_t echr_train_step_ws_floats(const echr_train_step_args* a);
 int echr_train_step(const echr_train_step_args* a, void* stream);
+/* Optional first half for the joint 'tap_cg' iteration (train.py:300-313): stages the index vectors and starts everything of the call that
+ * does not read tap_feats (the decoder's event-independent part, the gradient-arena fill) on the library's prepare stream, so that it runs
+ * beside the proposal encoder's forward the caller queues next.  Takes the arguments of the following echr_train_step (tap, g_tap, loss
+ * slots may still be unset), which must then pass prepared = 1 and the same workspace.  Needs overlap_encoder = 1. */
+int echr_train_step_prepare(const echr_train_step_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optional per-kernel-class timing (HIP events recorded on the launch stream around every launch of the

@@ -1199,6 +1199,21 @@ def test_fused_train_step_equals_autograd_path(case):
         fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], tap_grad=torch.zeros_like(tap), defer_update=True)
     lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk))
     assert np.isfinite(lb)
+    # the two-call form: prepare() (everything that does not read tap_feats, started before the proposal encoder's forward) + prepared=True
+    sync()
+    la = autograd_iteration(ma, oa)
+    fb.prepare(c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:])
+    filler = (torch.randn(256, 256, device=dev) @ torch.randn(256, 256, device=dev)).sum()          # (the caller's own work in between)
+    with pytest.raises(RuntimeError):
+        fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk)                                  # prepare() must be followed by prepared=True
+    lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], tap_grad=torch.zeros_like(tap), defer_update=True,
+                  prepared=True))
+    fb.join()
+    assert abs(la - lb) < 2e-6 * abs(la) and bool(torch.isfinite(filler))
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert float((pa.detach() - pb.detach()).abs().max()) <= 2.01 * lr, k
+    with pytest.raises(RuntimeError):
+        fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, prepared=True)                   # no prepare() before
 
 
 def test_backward_pass_that_raises_does_not_poison_the_next_one():
