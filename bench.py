@@ -172,8 +172,16 @@ def gpu_leg(args, rank, world, local_rank):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = iteration()
+    t_issue = time.perf_counter() - t0          # host time to issue the timed steps (the GPU may still be working)
     fence()
     dt = time.perf_counter() - t0
+    say('host issue time %.3f ms per step (GPU-inclusive %.3f)' % (1e3 * t_issue / args.steps, 1e3 * dt / args.steps))
+    if os.environ.get('ECHR_HOST_PROBE') == '1':          # diagnostic: host time of one iteration issued into an empty queue
+        ts = []
+        for _ in range(10):
+            torch.cuda.synchronize(); t1 = time.perf_counter(); iteration(); ts.append(time.perf_counter() - t1)
+        torch.cuda.synchronize()
+        say('host time of one iteration issued into an empty queue: min %.3f ms, median %.3f ms' % (1e3 * min(ts), 1e3 * sorted(ts)[5]))
     if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
