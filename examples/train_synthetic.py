@@ -90,8 +90,10 @@ def main(argv=None):
     cg_crit, tap_crit = utils.LanguageModelCriterion(), utils.TAPModelCriterion()
     # 'pre_cg' mode (train_ECHR.sh) with m_batch = 1: the whole iteration around the caption model -- zero_grad, forward, criterion,
     # backward, clip_gradient, step (train.py:281-317) -- is ONE library call
+    # 'tap_cg' mode with m_batch = 1: the caption side is the same call; d loss / d tap_feats comes back in tap_grad and goes into the proposal
+    # encoder together with its own loss, cg_model's parameter gradients + Adam finish on the library's helper streams meanwhile
     fused = None
-    if not a.joint and a.m_batch == 1 and not a.no_fused:
+    if a.m_batch == 1 and not a.no_fused:
         from echr_amd.fused import FusedTrainStep
         fused = FusedTrainStep(cg_model, cg_opt, grad_clip=opt.grad_clip)
     loader = make_loader(opt, 8, a.events, a.segments, opt.CG_seq_length + 2)
@@ -100,6 +102,21 @@ def main(argv=None):
         v = loader[it % len(loader)]
         set_lr_for_epoch(cg_opt, opt.lr, it // len(loader))
         c3d, lda = torch.from_numpy(v['c3d']).to(dev), torch.from_numpy(v['lda']).to(dev)
+        if fused is not None and a.joint:
+            tap_opt.zero_grad()
+            tap_feats, pred_proposals = tap_model(c3d)
+            tap_loss = 0.01 * tap_crit(pred_proposals, torch.from_numpy(v['tap_masks']).to(dev), torch.from_numpy(v['tap_labels']).to(dev),
+                                       torch.from_numpy(v['w1']).to(dev))                       # lambda1 (opts.py:194-196); lambda2 = 1
+            g_tap = torch.zeros_like(tap_feats)
+            cg_loss = fused(tap_feats.detach(), c3d, lda, v['labels'], v['ind'], v['soi'], torch.from_numpy(v['labels'])[:, 1:],
+                            torch.from_numpy(v['masks'])[:, 1:], tap_grad=g_tap, defer_update=True)
+            torch.autograd.backward([tap_loss, tap_feats], [None, g_tap])
+            utils.clip_gradient(tap_opt, opt.grad_clip)
+            tap_opt.step()
+            history.append(float(cg_loss))
+            if not a.quiet and (it % 5 == 0 or it == start + a.iters - 1):
+                print('iter %3d  cg_loss %.4f' % (it, history[-1]), flush=True)
+            continue
         if fused is not None:
             with torch.no_grad():
                 tap_feats, _ = tap_model(c3d)
@@ -132,6 +149,8 @@ def main(argv=None):
         history.append(float(cg_loss.detach()))
         if not a.quiet and (it % 5 == 0 or it == start + a.iters - 1):
             print('iter %3d  cg_loss %.4f' % (it, history[-1]), flush=True)
+    if fused is not None:
+        fused.join()                                                              # a deferred update of the last iteration
     cg_model.eval()
     with torch.no_grad():
         v = loader[0]
