@@ -575,27 +575,38 @@ __global__ __launch_bounds__(256) void h2_pack_kernel(H2PackArgs args) {
         __shared__ float tile[2][H2_ROWS / 2][BK + 1];       // two tiles: chunk c + 1 is written while chunk c is read
         const int rh = r0 + 64 * half;
         const bool vec = aligned && (jb.s_col & 3) == 0 && rh + 64 <= jb.R;
-        // the next chunk's loads are in flight while this one is transposed.  vec: float4 = 4 consecutive rows of one k
-        float4 x[2];
+        // vec (float4 = 4 consecutive rows of one k): ALL of the segment's loads are requested up front -- a workgroup then has 16 KB in
+        // flight instead of 2 (with ~2 workgroups per CU on the weight-gradient packs the kernel was bound by load latency: 2 TB/s);
+        // gathered k indices are fetched first, one dependent round for the whole segment.  Otherwise: the next chunk's loads are in
+        // flight while this one is transposed
+        float4 xa[H2_SEG][2];
         float xs[8];
-        auto fetch = [&](int c) {
-            const int k0 = (kt0 + c) * BK;
-            if (vec) {
+        if (vec) {
+            int gk[H2_SEG][2];
+#pragma unroll
+            for (int c = 0; c < H2_SEG; ++c)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int f = tid + i * 256, k = f >> 4, rr = (f & 15) * 4;
-                    x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k0 + k < jb.K) x[i] = *reinterpret_cast<const float4*>(src + (long)(jb.gather ? jb.gather[k0 + k] : k0 + k) * jb.s_col + rh + rr);
+                    const int k = (kt0 + c) * BK + ((tid + i * 256) >> 4);
+                    gk[c][i] = (c < nch && k < jb.K) ? (jb.gather ? jb.gather[k] : k) : -1;
                 }
-            } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int f = tid + i * 256, k = f >> 6, rr = f & 63;
-                    xs[i] = (rh + rr < jb.R && k0 + k < jb.K) ? src[(long)(jb.gather ? jb.gather[k0 + k] : k0 + k) * jb.s_col + rh + rr] : 0.f;
+            for (int c = 0; c < H2_SEG; ++c)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int rr = ((tid + i * 256) & 15) * 4;
+                    xa[c][i] = gk[c][i] >= 0 ? *reinterpret_cast<const float4*>(src + (long)gk[c][i] * jb.s_col + rh + rr) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+        }
+        auto fetch = [&](int c) {
+            const int k0 = (kt0 + c) * BK;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = tid + i * 256, k = f >> 6, rr = f & 63;
+                xs[i] = (rh + rr < jb.R && k0 + k < jb.K) ? src[(long)(jb.gather ? jb.gather[k0 + k] : k0 + k) * jb.s_col + rh + rr] : 0.f;
             }
         };
-        fetch(0);
+        if (!vec) fetch(0);
 #pragma unroll
         for (int c = 0; c < H2_SEG; ++c) {
             if (c < nch) {                 // nch is uniform over the workgroup
@@ -604,7 +615,7 @@ __global__ __launch_bounds__(256) void h2_pack_kernel(H2PackArgs args) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int f = tid + i * 256, k = f >> 4, rr = (f & 15) * 4;
-                        tl[rr][k] = x[i].x; tl[rr + 1][k] = x[i].y; tl[rr + 2][k] = x[i].z; tl[rr + 3][k] = x[i].w;
+                        tl[rr][k] = xa[c][i].x; tl[rr + 1][k] = xa[c][i].y; tl[rr + 2][k] = xa[c][i].z; tl[rr + 3][k] = xa[c][i].w;
                     }
                 } else {
 #pragma unroll
@@ -612,8 +623,8 @@ __global__ __launch_bounds__(256) void h2_pack_kernel(H2PackArgs args) {
                         const int f = tid + i * 256;
                         tl[f & 63][f >> 6] = xs[i];
                     }
+                    if (c + 1 < nch) fetch(c + 1);
                 }
-                if (c + 1 < nch) fetch(c + 1);
                 __syncthreads();           // tile c complete; tile (c - 1) & 1 == (c + 1) & 1 was last read before this barrier
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[c][j] = tl[row & 63][8 * sl + j];
@@ -1254,6 +1265,7 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
         if (split == 1) p.beta = d.beta;
     } else if (accumulate && split == 1) p.beta = 1.f;
     dim3 grid(p.tiles_m * p.tiles_n, 1, d.batch * split * ng);
+    if (config().diag_skip & (h2 ? 32 : 16)) return 0;          // diagnostic (tools/skip_bounds.py): the product is not launched, results are wrong
     static const bool log_on = getenv("ECHR_GEMM_LOG") != nullptr;
     if (log_on) fprintf(stderr, "[gemm] M=%d N=%d K=%d batch=%d %s%s tile=%dx%d split=%d algo=%s wgs=%d\n", d.M, d.N, d.K, d.batch, akc ? "N" : "T",
                         bkc ? "T" : "N", BMs, BNs, split, h2 ? "h2" : use_split ? "bf16x3" : "f32", (int)(grid.x * grid.z));

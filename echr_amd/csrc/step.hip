@@ -203,7 +203,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     int32_t* idx = reinterpret_cast<int32_t*>(ws + L.idx);
     ECHR_REQUIRE(a->n_active >= 0 && a->n_active <= S * N, "train_step: n_active out of range");
     if (!a->prepared) RC(stage_indices(a->host_index, idx, sizeof(int32_t) * step_index_count(a), st));
-    const int32_t *ev_start = idx, *ev_len = idx + N, *ind = idx + 2 * N, *tokens = idx + 3 * N, *active = idx + (3 + S) * N;
+    const int32_t *ev_start = idx, *ev_len = idx + N, *ind = idx + 2 * N, *active = idx + (3 + S) * N;          // (tokens at idx + 3 N: step_dec_args)
     const void* nll_target = a->nll_target;
     const float* nll_mask = a->nll_mask;
     int nll_i64 = a->nll_target_i64;

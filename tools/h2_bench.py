@@ -49,7 +49,8 @@ def timeit(fn, reps=20):
 SHAPES = [('logits', 1280, 5001, 1536), ('dOUT', 1280, 1536, 5001), ('g_w_logit', 5001, 1536, 1280), ('gin', 1280, 2048, 512),
           ('dXT', 1280, 512, 2048), ('g_w_hh', 2048, 512, 1280), ('g_w_c2a', 512, 500, 8192), ('pall', 8192, 512, 500),
           ('fc1', 4096, 512, 512), ('big', 4096, 4096, 4096), ('odd', 77, 130, 45), ('gin_x3', 3840, 2048, 512),
-          ('wg_x3', 6144, 512, 1280), ('dx_x3', 1280, 1536, 2048), ('fc1_eval', 1000000, 512, 512)]
+          ('wg_x3', 6144, 512, 1280), ('dx_x3', 1280, 1536, 2048), ('fc1_eval', 1000000, 512, 512),
+          ('logits_c', 762, 5001, 1536), ('dOUT_c', 762, 1536, 5001), ('g_w_logit_c', 5001, 1536, 762)]      # _c: the active rows of the bench workload
 if __name__ == '__main__':
     only = os.environ.get('H2_ONLY')
     for name, M, N, K in SHAPES:

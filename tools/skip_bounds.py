@@ -21,12 +21,13 @@ labels = torch.from_numpy(vid['labels'])
 tgt, msk = labels[:, 1:].to(dev), torch.from_numpy(vid['masks'])[:, 1:].to(dev)
 
 
-def iteration():
-    optim.zero_grad()
-    loss = crit(model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), tgt, msk)
-    loss.backward()
-    clip_gradient(optim, opt.grad_clip)
-    optim.step()
+from echr_amd.fused import FusedTrainStep
+fused = FusedTrainStep(model, optim, grad_clip=opt.grad_clip)
+tgt_h, msk_h = labels[:, 1:].numpy(), vid['masks'][:, 1:]
+
+
+def iteration():          # the product path: one library call per iteration
+    fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h)
 
 
 def timed(n=300):
@@ -40,7 +41,8 @@ def timed(n=300):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for name, bits in (('h2 operand packs (10 launches)', 1), ('clamp+Adam', 2), ('att_post', 4), ('embedding scatter-add', 8), ('all four', 15)):
+for name, bits in (('h2 operand packs (10 launches)', 1), ('clamp+Adam', 2), ('att_post', 4), ('embedding scatter-add', 8), ('all four', 15),
+                   ('fp32-path products (12 launches)', 16), ('h2 products (10 launches)', 32), ('packs + h2 products', 33)):
     lib.echr_config_set(b'diag_skip', 0)
     a = timed()
     lib.echr_config_set(b'diag_skip', bits)
