@@ -804,10 +804,13 @@ __device__ __forceinline__ f16x8p as_f16x8(float4 v) { return __builtin_bit_cast
 // inv_scale[col] receives 2^(e - 14).  scratch: ncb * 32 floats of LDS for the column scales.
 template <typename RowFn>
 __device__ __forceinline__ void fill_bimg_h2(float4* img, float* inv_scale, float* scratch, const float* W, long ld, int K, int ncb, RowFn row_of, int tid) {
-    const int ncol = 32 * ncb;
-    // column maxima: 8 threads per column, 64 k each, all 16 loads of a thread in flight together (K % 4 == 0, rows 16-byte aligned)
-    for (int c0 = 0; c0 < ncol; c0 += 32) {
-        const int col = c0 + (tid >> 3), qk = tid & 7;
+    // ONE pass over the slice: 8 threads per column hold its 512 k (64 each, all 16 loads of a thread in flight together; K % 4 == 0, rows
+    // 16-byte aligned), agree on the column's scale through three lane exchanges, and each converts its own 8 groups of 8 consecutive k --
+    // one 16-byte image slot per plane and group.  (The first cut found the maxima in one pass and re-read the slice in image order in a
+    // second: two dependent rounds of global loads per image in front of the first timestep.)
+    (void)scratch;
+    for (int c0 = 0; c0 < 32 * ncb; c0 += 32) {
+        const int cl = tid >> 3, col = c0 + cl, qk = tid & 7, cb = c0 >> 5;
         const float* wp = W + (long)row_of(col) * ld + 64 * qk;
         float4 v[16];
 #pragma unroll
@@ -818,35 +821,15 @@ __device__ __forceinline__ void fill_bimg_h2(float4* img, float* inv_scale, floa
         mx = fmaxf(mx, __shfl_xor(mx, 1));
         mx = fmaxf(mx, __shfl_xor(mx, 2));
         mx = fmaxf(mx, __shfl_xor(mx, 4));
-        if (qk == 0) {
-            const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
-            int e = (ex == 0 || ex == 255) ? 14 : ex - 127;
-            e = max(e, 14 - 126);
-            scratch[col] = __uint_as_float((unsigned)(127 + 14 - e) << 23);
-            inv_scale[col] = ldexpf(1.f, e - 14);
-        }
-    }
-    __syncthreads();
-    // (w, s, cb, lane) -> both planes; 8 items per thread and pass, their 16 loads in flight together
-    const int total = 4 * 8 * ncb * 64;
-    for (int base0 = 0; base0 < total; base0 += 8 * 256) {
-        float4 x[8][2];
+        const int ex = (int)((__float_as_uint(mx) >> 23) & 0xFFu);
+        int e = (ex == 0 || ex == 255) ? 14 : ex - 127;
+        e = max(e, 14 - 126);
+        const float sc = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+        if (qk == 0) inv_scale[col] = ldexpf(1.f, e - 14);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = base0 + tid + 256 * i;
-            const int lane = idx & 63, cb = (idx >> 6) % ncb, s_ = ((idx >> 6) / ncb) & 7, w = (idx >> 6) / ncb / 8;
-            const int col = 32 * cb + (lane & 31), k = 128 * w + 16 * s_ + 8 * (lane >> 5);
-            const float* wp = W + (long)row_of(col) * ld + k;
-            x[i][0] = (idx < total && k < K) ? *reinterpret_cast<const float4*>(wp) : make_float4(0.f, 0.f, 0.f, 0.f);
-            x[i][1] = (idx < total && k + 4 < K) ? *reinterpret_cast<const float4*>(wp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = base0 + tid + 256 * i;
-            if (idx >= total) continue;
-            const int lane = idx & 63, cb = (idx >> 6) % ncb, s_ = ((idx >> 6) / ncb) & 7, w = (idx >> 6) / ncb / 8;
-            const float sc = scratch[32 * cb + (lane & 31)];
-            const float xv[8] = {x[i][0].x, x[i][0].y, x[i][0].z, x[i][0].w, x[i][1].x, x[i][1].y, x[i][1].z, x[i][1].w};
+        for (int i = 0; i < 8; ++i) {          // k = 64 qk + 8 i .. + 7  ->  (w, s, kh) = (k / 128, (k % 128) / 16, (k % 16) / 8)
+            const int w = qk >> 1, s_ = (qk & 1) * 4 + (i >> 1), kh = i & 1;
+            const float xv[8] = {v[2 * i].x, v[2 * i].y, v[2 * i].z, v[2 * i].w, v[2 * i + 1].x, v[2 * i + 1].y, v[2 * i + 1].z, v[2 * i + 1].w};
             unsigned hw[8], lw[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -854,7 +837,7 @@ __device__ __forceinline__ void fill_bimg_h2(float4* img, float* inv_scale, floa
                 split_h2(xv[j] * sc, hi, lo);
                 hw[j] = hi; lw[j] = lo;
             }
-            const long base = (((long)(w * 8 + s_) * ncb + cb) * 2) * 64 + lane;
+            const long base = (((long)(w * 8 + s_) * ncb + cb) * 2) * 64 + cl + 32 * kh;
             reinterpret_cast<uint4*>(img)[base] = make_uint4(hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16), hw[4] | (hw[5] << 16), hw[6] | (hw[7] << 16));
             reinterpret_cast<uint4*>(img)[base + 64] = make_uint4(lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16), lw[4] | (lw[5] << 16), lw[6] | (lw[7] << 16));
         }
@@ -956,6 +939,8 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
         use_max = (sx[0] + sx[1] + sx[2] + sx[3]) > ALPHA_SAFE;
         __syncthreads();
     }
+    auto sst_ = [&](int i) { if (P.stamps && b == 0 && tid == 0) P.stamps[(i >> 1) * 16 + 12 + (i & 1)] = __builtin_amdgcn_s_memrealtime(); };
+    sst_(0);
     if (att_live) {
         alen = P.ev_len[an];
         row0 = P.ev_start[an];
@@ -992,11 +977,14 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                 else Pr2[i][h] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
     }
+    sst_(1);
     if (is_g1) {
         auto row = [&](int cc) { return (cc >> 3) * PH + 8 * lb + (cc & 7); };       // tile column cc = gate * 8 + unit
         if (H2) {
             fill_bimg_h2(wimg, invbA, scr, P.w_hh1, PH, PH, 1, row, tid);
+            sst_(2);
             fill_bimg_h2(wimg + 4096, invbC, scr, P.w_att, P.ld_att, D, 1, row, tid);
+            sst_(3);
         } else {
             fill_bimg32(wimg, P.w_hh1, PH, PH, row, tid);
             fill_bimg32(wimg + 4096, P.w_att, P.ld_att, D, row, tid);
@@ -1047,6 +1035,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
         mx = wave_max(mx);
         if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(P.XCMAX) + an, __float_as_uint(mx));
     }
+    sst_(4);
     __syncthreads();
     const bool has2 = BIG && att_live && alen > PSET2;           // uniform over the workgroup
 

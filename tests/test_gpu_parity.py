@@ -1188,7 +1188,8 @@ def test_fused_train_step_equals_autograd_path(case):
     assert oa._flat['step'] == ob._flat['step']
     for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         dp = (pa.detach() - pb.detach()).abs()
-        assert float(dp.max()) <= 2.01 * lr, k
+        if k not in U.NOISE_ONLY:          # (a noise-only gradient against several steps of Adam history: |m^ / sqrt(v^)| is not bounded by 1)
+            assert float(dp.max()) <= 2.01 * lr, k
         if pa.grad is not None and k not in U.NOISE_ONLY:
             gg = pa.grad.abs()
             solid = gg > 1e-4 * gg.max()
@@ -1211,7 +1212,7 @@ def test_fused_train_step_equals_autograd_path(case):
     fb.join()
     assert abs(la - lb) < 2e-6 * abs(la) and bool(torch.isfinite(filler))
     for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
-        assert float((pa.detach() - pb.detach()).abs().max()) <= 2.01 * lr, k
+        assert k in U.NOISE_ONLY or float((pa.detach() - pb.detach()).abs().max()) <= 2.01 * lr, k
     with pytest.raises(RuntimeError):
         fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, prepared=True)                   # no prepare() before
 

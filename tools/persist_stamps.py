@@ -56,6 +56,10 @@ raw = st[0, 0]
 first = st[0, S - 1, 0] if BWD else st[0, 0, 0]
 last = st[0, 0, 0] if BWD else st[0, S - 1, 0]
 print('workgroup 0: set-up %.2f us (entry -> ready), ready -> first step stamp %.2f us, first -> last step stamp %.2f us' % (raw[14] - raw[15], first - raw[14], last - first))
+if not BWD:
+    sub = [st[0, i >> 1, 12 + (i & 1)] for i in range(5)]
+    print('   set-up split: alpha %.2f | operand loads issued %.2f | W_hh1 image %.2f | W_att image %.2f | e^2p + context bound %.2f | barrier %.2f' % (
+        sub[0] - raw[15], sub[1] - sub[0], sub[2] - sub[1], sub[3] - sub[2], sub[4] - sub[3], raw[14] - sub[4]))
 for role, rn in rl:
     a = st[role]
     if BWD:
