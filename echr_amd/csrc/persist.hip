@@ -2195,15 +2195,20 @@ struct PersistB {
 
 // B image of one 16-column tile whose source is k-strided: element (k, cc) = W[k * ld_k + cc] for k < K, cc < ncols; zero elsewhere
 __device__ __forceinline__ void fill_bimg_t(float4* img, const float* W, long ld_k, int K, int ncols, int tid) {
-    for (int idx = tid; idx < 4 * 8 * 64; idx += 256) {
+    // all 32 loads of a thread are requested before the first LDS store (the rolled loop waited for each group of four: eight dependent
+    // memory round trips per image in front of the first timestep)
+    float v[8][4];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = tid + 256 * it;
         const int lane = idx & 63, c = (idx >> 6) & 7, w = idx >> 9;
         const int cc = lane & 15, kq = lane >> 4;
         const int k = 128 * w + 16 * c + 4 * kq;
-        float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (k + j < K && cc < ncols) ? W[(long)(k + j) * ld_k + cc] : 0.f;
-        img[idx] = make_float4(v[0], v[1], v[2], v[3]);
+        for (int j = 0; j < 4; ++j) v[it][j] = (k + j < K && cc < ncols) ? W[(long)(k + j) * ld_k + cc] : 0.f;
     }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) img[tid + 256 * it] = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
 }
 
 struct CellGrad { float4 dg[4]; float4 dc; };
