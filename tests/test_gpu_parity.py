@@ -1217,6 +1217,41 @@ def test_fused_train_step_equals_autograd_path(case):
         fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, prepared=True)                   # no prepare() before
 
 
+def test_deferred_update_survives_changing_shapes():
+    """Joint-mode iterations (defer_update: parameter gradients + Adam finish on the helper streams after the call returns) alternating between
+    two workloads of different sizes on ONE model: the workspace is re-allocated while a deferred update may still be running (the step joins
+    first), the index ring is restaged -- the losses must equal those of the same sequence run with the update joined inside the call."""
+    from echr_amd.fused import FusedTrainStep
+    from echr_amd.optim import ClampAdam
+    dev = torch.device('cuda')
+    cases = [synth.make_case(c) for c in ('c2', 'c1', 'c2full', 'c1', 'c2')]
+    opt, params, _ = cases[0]
+
+    def run(defer):
+        m = U.build_gpu_model(opt, params, True)
+        m.set_dropout_state(U.SEED, 7)
+        o = ClampAdam(m.parameters(), lr=1e-3, arena=m.build_arena())
+        f = FusedTrainStep(m, o, grad_clip=0.05)
+        losses, taps = [], []
+        for _, _, vid in cases * 2:
+            tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+            labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+            g = torch.zeros_like(tap)
+            losses.append(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], tap_grad=g, defer_update=defer))
+            taps.append(g)
+        f.join()
+        torch.cuda.synchronize()
+        return [float(x) for x in losses], [float(t.abs().sum()) for t in taps], m
+
+    la, ta, ma = run(False)
+    lb, tb, mb = run(True)
+    for i, (x, y) in enumerate(zip(la, lb)):
+        assert abs(x - y) <= 2e-4 * abs(x), (i, x, y)          # (same trajectory up to atomic-order noise amplified by Adam over ten steps)
+    for x, y in zip(ta, tb):
+        assert abs(x - y) <= 2e-3 * abs(x) + 1e-12
+    assert la[-1] < la[0]
+
+
 def test_backward_pass_that_raises_does_not_poison_the_next_one():
     """The decoder's backward zero-fills the whole gradient arena once per pass and tells the later Functions of THAT pass so.  When a later
     node raises, autograd's end-of-pass callbacks do not run; the next pass must still zero-fill (the flag is tied to the graph task it was
