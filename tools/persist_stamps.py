@@ -72,6 +72,10 @@ for role, rn in rl:
             continue
         if i == 12 and not BWD:
             prev_i = 5
+        if (a[3:S - 1, i] == 0).any() or (a[3:S - 1, prev_i] == 0).any():          # a stamp this instantiation does not write
+            if not (a[3:S - 1, i] == 0).any():
+                prev_i = i
+            continue
         d = (a[3:S - 1, i] - a[3:S - 1, prev_i]).mean()
         out.append('%s %.2f' % (names[role][i], d))
         prev_i = i

@@ -34,6 +34,9 @@ cd $root
 { echo "# greedy decode, whole mode='eval' call (tools/sample_bench.py), commit $commit"; timeout -k 10 300 python3 tools/sample_bench.py 64 128 256 512 1000 2>/dev/null | grep N=;
   echo "# the same with the launch-per-step form (ECHR_PERSIST_SAMPLE=0)"; ECHR_PERSIST_SAMPLE=0 timeout -k 10 300 python3 tools/sample_bench.py 64 128 256 512 1000 2>/dev/null | grep N=;
   echo "# in-kernel stamps of the persistent decoder (tools/sample_stamps.py)"; timeout -k 10 200 python3 tools/sample_stamps.py 2>/dev/null | grep -v amdgpu; } > $out/${tag}_sampler.txt
+{ echo "# in-kernel phase stamps of the persistent recurrences (tools/persist_stamps.py), commit $commit"; echo "## c3 forward"; timeout -k 10 200 python3 tools/persist_stamps.py 2>/dev/null | grep -v amdgpu;
+  echo "## c3 reverse"; timeout -k 10 200 python3 tools/persist_stamps.py bwd 2>/dev/null | grep -v amdgpu; echo "## c5 (BIG) forward"; timeout -k 10 200 python3 tools/persist_stamps.py c5 2>/dev/null | grep -v amdgpu;
+  echo "## c5 (BIG) reverse"; timeout -k 10 200 python3 tools/persist_stamps.py c5 bwd 2>/dev/null | grep -v amdgpu; } > $out/${tag}_persist_stamps.txt
 timeout -k 10 400 python3 bench.py > $out/${tag}_bench_final.json 2> $out/bench.err; echo bench_exit=$?
 timeout -k 10 400 python3 bench.py --c5 > $out/${tag}_bench_c5.json 2> $out/bench5.err; echo bench5_exit=$?
 # BASELINE config 2 (forward + criterion only, train-mode dropout): bench line and kernel stats
