@@ -872,9 +872,7 @@ static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t
     }
     d.bias = a->b_c2a;
     RC(gemm(d, st));
-    d = desc_nt(a->video, a->Dv, a->w_ih[2] + E, E + a->Dv, w.VIDB, 4 * H, 1, 4 * H, a->Dv);
-    d.bias = a->b_ih[2]; d.bias2 = a->b_hh[2];
-    RC(gemm(d, st));
+    RC(row_matvec(a->video, a->w_ih[2] + E, E + a->Dv, a->b_ih[2], a->b_hh[2], w.VIDB, 4 * H, a->Dv, st));      // (M = 1: no GEMM launch)
 event_part:
     if (parts & 2) {
         d = desc_nt(a->event, a->De, a->w_ih[0] + E, E + a->De, w.EVB0, 4 * H, a->N, 4 * H, a->De);

@@ -141,6 +141,7 @@ int transpose_multi(const TransposeJob* jobs, int n, hipStream_t st);           
 // out[c, r] = in[r, c] for r < rows, c < cols; rows..rows_pad-1 of the output's row are zero-filled (k padding)
 int transpose(const float* in, long ld_in, float* out, long ld_out, int rows, int cols, int rows_pad, hipStream_t st);
 int embed_gather(const float* W, const int* tok, float* out, int rows, int E, int V1, hipStream_t st);
+int row_matvec(const float* x, const float* W, long ldw, const float* b1, const float* b2, float* out, int N, int K, hipStream_t st);
 int rank1_update(const float* x, const float* y, float* C, long ldc, int M, int N, bool accumulate, hipStream_t st);
 int vec_mat(const float* x, const float* W, long ldw, float* out, int M, int N, hipStream_t st);
 int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st, const int* rowmap = nullptr);
