@@ -132,6 +132,7 @@ class FusedTrainStep(object):
                                    tap_grad, defer_update)
             a.prepared = 0
         L.check(lib.echr_train_step(C.byref(a), L.stream_ptr()), 'train_step')
+        self._pending_deferred = bool(a.defer_update)
         return self._finish(slot, st, forward_only)
 
     def _set_tap(self, tap, tap_grad, defer_update, step, forward_only):
@@ -151,6 +152,11 @@ class FusedTrainStep(object):
     def _setup(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step, forward_only,
                tap_grad, defer_update):
         a, m, ar, lib = self.a, self.model, self.arena, self.lib
+        if getattr(self, '_pending_deferred', False):
+            # a deferred update may still be reading the previous call's inputs (c3d, the staged indices) on the library's streams: order this
+            # stream behind it BEFORE the references below are dropped and torch's allocator may hand that memory to someone else
+            self.join()
+            self._pending_deferred = False
         if not c3d_feats.is_cuda:
             raise L.EchrHipError('FusedTrainStep runs on the GPU only')
         if (ar.flat_p.data_ptr(), ar.flat_g.data_ptr()) != self._epoch_ptrs or not ar.params_in_arena():
