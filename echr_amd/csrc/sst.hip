@@ -828,6 +828,24 @@ extern "C" int echr_sst_bwd(const echr_sst_args* a, const echr_sst_grads* g, con
     hipStream_t s0 = config().tsrm_fork ? aux_fork(st) : nullptr;
     const bool fork = s0 != nullptr;
     if (!fork) s0 = st;
+    if (z && T > 1 && fork) {
+        // zeroed gradient buffers (the arena path): the two recurrent products share their shape (4H x H over T - 1 rows) -> one grouped launch
+        // on this stream beside the two input products on the helper stream, and ONE column-sum launch for both layers' biases
+        // (four GEMM + two column-sum launches on two streams before)
+        echr_gemm_desc gh[2];
+        for (int l = 0; l < 2; ++l) {
+            gh[l] = desc_tn(b.DG[l] + 4 * H, 4 * H, l == 0 ? w.HS[0] : a->tap_feats, H, g->g_w_hh[l], H, 4 * H, H, T - 1);
+            gh[l].split_k = -1; gh[l].beta = 1.f;
+        }
+        RC(gemm_grouped(gh, 2, st));
+        d = desc_tn(b.DG[0], 4 * H, a->x, D, g->g_w_ih[0], D, 4 * H, D, T); d.split_k = -1; d.beta = 1.f;
+        RC(gemm(d, s0));
+        d = desc_tn(b.DG[1], 4 * H, w.H0D, H, g->g_w_ih[1], H, 4 * H, H, T); d.split_k = -1; d.beta = 1.f;
+        RC(gemm(d, s0));
+        const ColsumJob cj[2] = {{b.DG[0], 4 * H, T, 4 * H, g->g_b_ih[0], g->g_b_hh[0], nullptr}, {b.DG[1], 4 * H, T, 4 * H, g->g_b_ih[1], g->g_b_hh[1], nullptr}};
+        RC(colsum_multi(cj, 2, st));
+        return aux_join(st);
+    }
     for (int l = 1; l >= 0; --l) {
         hipStream_t sl = l == 0 ? s0 : st;
         const float* hs = l == 0 ? w.HS[0] : a->tap_feats;
