@@ -1316,6 +1316,36 @@ def test_odd_shapes_vs_oracle(N, A, T_v, L, V1):
             assert U.grad_close(k, grads[k], g, TOL_GRAD), (k, U.relerr(grads[k], g))
 
 
+@pytest.mark.parametrize('N,A,T_v,L,V1', [(1, 5, 9, 4, 57), (3, 1, 4, 3, 11), (70, 200, 256, 6, 129), (6, 24, 60, 5, 9001), (64, 129, 200, 12, 301),
+                                           (33, 130, 260, 9, 2049)])
+def test_fused_step_odd_shapes_vs_oracle(N, A, T_v, L, V1):
+    """The one-call iteration (echr_train_step: active rows, fused criterion, three-stream tail) on shapes off the tuned path -- a single
+    event, single-slot events, N > 64 (launch-per-step recurrences), a vocabulary beyond the register-resident criterion kernel, the
+    129 / 130-segment boundary of the BIG instantiations: loss, every parameter gradient and d tap_feats against the oracle (train mode)."""
+    from echr_amd.fused import FusedTrainStep
+    from echr_amd.optim import ClampAdam
+    opt = synth.default_opt(vocab_size=V1 - 1, seq_length=L - 2)
+    params = synth.make_params(opt, 3)
+    vid = synth.make_video(N, A, L, V1, seed=N * 7 + A, T_v=T_v, min_len=1)
+    rpred, rloss, rgrads = U.run_oracle(opt, params, vid, True)
+    dev = torch.device('cuda')
+    m = U.build_gpu_model(opt, params, True)
+    o = ClampAdam(m.parameters(), lr=1e-3, arena=m.build_arena())
+    f = FusedTrainStep(m, o, grad_clip=None)
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    g_tap = torch.zeros_like(tap)
+    loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], step=False, tap_grad=g_tap))
+    assert abs(loss - rloss) < TOL_LOSS * abs(rloss), (loss, rloss)
+    grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else None) for k, p in m.named_parameters()}
+    for k, g in rgrads.items():
+        if g is None:
+            assert grads[k] is None, k
+        else:
+            assert U.grad_close(k, grads[k], g, TOL_GRAD), (k, U.relerr(grads[k], g))
+    assert bool(torch.isfinite(g_tap).all()) and float(g_tap.abs().max()) > 0
+
+
 def test_gemm_path_switches_do_not_change_results_beyond_tolerance():
     """echr_config_set('gemm_h2' / 'gemm_bf16x3'): the packed fp16-pair products, the bf16-plane split products and the native
     fp32 MFMA products agree to ~1e-6 on the whole forward/backward path."""
