@@ -1012,7 +1012,7 @@ extern "C" int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a) { return a
 extern "C" int echr_stream_join(void* stream) { return join_tail((hipStream_t)stream); }
 
 // ---- event-independent part of the decoder forward, ahead of (and concurrent with) the event encoder ----
-struct Prep { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr; bool ok = false, init = false, pending = false; const void* ws = nullptr; };
+struct Prep { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr, fill_done = nullptr; bool ok = false, init = false, pending = false, fill_pending = false; const void* ws = nullptr; };
 static Prep& prep() {
     static Prep t;
     if (!t.init) {
@@ -1020,6 +1020,7 @@ static Prep& prep() {
         bool good = helper_stream_create(&t.s);
         good = good && hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
         good = good && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.fill_done, hipEventDisableTiming) == hipSuccess;
         t.ok = good;
     }
     return t;
@@ -1062,7 +1063,7 @@ static bool fwd_uses_persist(const echr_dec_args* a) {
     const bool ov = !two && overlap_enabled() && a->S >= 4;
     return persist_fwd_eligible(a) && !ov && !two;
 }
-static int decoder_fill(const echr_dec_args* a, const DecWs& w, hipStream_t st) {
+static int decoder_fill(const echr_dec_args* a, const DecWs& w, hipStream_t st, bool with_extra = true) {
     const int N = a->N, S = a->S, H = a->H;
     // h(-1) = c(-1) = 0 (init_hidden, :75-78), the atomic q accumulators and the split-K target EVB0 -- and the zeroed part of the persistent
     // launch's exchange workspace (counters, accumulated buffers): one launch
@@ -1070,7 +1071,7 @@ static int decoder_fill(const echr_dec_args* a, const DecWs& w, hipStream_t st) 
     long zn[8] = {(long)N * 3 * H, (long)N * H, (long)N * H, (long)N * H, (long)S * N * a->Ha, (long)N * 4 * H, 0, 0};
     int n = 6;
     if (fwd_uses_persist(a)) { persist_fwd_zero_range(a, w.XWS, &zp[n], &zn[n]); ++n; }
-    if (a->zero_extra && a->zero_extra_count > 0) { zp[n] = a->zero_extra; zn[n] = (long)a->zero_extra_count; ++n; }      // the caller's gradient arena
+    if (with_extra && a->zero_extra && a->zero_extra_count > 0) { zp[n] = a->zero_extra; zn[n] = (long)a->zero_extra_count; ++n; }      // the caller's gradient arena
     return fill_zero_multi(zp, zn, n, st);
 }
 
@@ -1085,12 +1086,22 @@ extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
     RC(join_tail(sm));
     RC(hop(sm, pr.fork, st));
     DecWs w = carve_ws(a, a->ws);
-    RC(decoder_fill(a, w, st));
+    // the caller's gradient arena (echr_train_step: 87 MB) is zero-filled LAST on this stream, behind the event this call publishes: nothing of
+    // the forward pass waits for it -- a fill has no LDS and a handful of registers, so it also fits beside the recurrence's workgroups -- and
+    // echr_decoder_bwd waits for it on entry.  -10 us per iteration against the fill in front (ECHR_ARENA_FILL_LATE=0, A/B: 1.540 vs 1.550 ms)
+    static const bool late_fill = [] { const char* e = getenv("ECHR_ARENA_FILL_LATE"); return !(e && e[0] == '0'); }();
+    const bool late = late_fill && a->zero_extra && a->zero_extra_count > 0;
+    RC(decoder_fill(a, w, st, !late));
     RC(precompute_static(a, w, st, true, true, 1));
     RC(embed_gather(a->embed, a->tokens, w.XT, a->S * a->N, a->E, a->V1, st));
     RC(input_gates(a, w, w.XT, 0, a->S, st, true));
     if (hipEventRecord(pr.done, st) != hipSuccess) { set_error("decoder_fwd_prepare: event record failed"); return -5; }
     pr.pending = true; pr.ws = a->ws;
+    if (late) {          // the caller's gradient arena: behind everything the forward recurrence waits for
+        RC(fill_zero(a->zero_extra, (long)a->zero_extra_count, st));
+        if (hipEventRecord(pr.fill_done, st) != hipSuccess) { set_error("decoder_fwd_prepare: event record failed"); return -5; }
+        pr.fill_pending = true;
+    }
     return 0;
 }
 
@@ -1240,6 +1251,10 @@ extern "C" int echr_decoder_bwd(const echr_dec_args* a, const echr_dec_grads* g,
 // caller's stream (late fusion, reverse recurrence, d event), 2 = what runs on the library's helper streams (every other gradient) -- forked
 // from the caller's stream where the second call is made, i.e. behind the event encoder's backward.  Pieces need async_tail = 2.
 int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, int part) {
+    if (prep().fill_pending) {
+        prep().fill_pending = false;
+        if (hipStreamWaitEvent((hipStream_t)stream, prep().fill_done, 0) != hipSuccess) { set_error("decoder_bwd: stream wait failed"); return -5; }
+    }
     ECHR_REQUIRE(part == 0 || (g->phase == 0 && g->async_tail == 2 && g->zeroed && config().gemm_h2 && tail().ok && !overlap_enabled()),
                  "decoder_bwd: the two-piece form needs phase 0, async_tail 2, zeroed gradients, the h2 path and the helper streams");
     hipStream_t st = (hipStream_t)stream;
