@@ -1075,6 +1075,42 @@ static int decoder_fill(const echr_dec_args* a, const DecWs& w, hipStream_t st, 
     return fill_zero_multi(zp, zn, n, st);
 }
 
+// the backward pass's zero-initialised scratch: DC | DGCOL | DHACC | DQ | DASL | DPALL, the split-K / accumulated outputs DXT, g_event and DOUT,
+// the zeroed part of the persistent reverse launch's exchange workspace and, when the caller asks for it (zero_extra), its gradient arena span
+static int bwd_scratch_ranges(const echr_dec_args* a, const echr_dec_grads* g, const DecWsBwd& b, bool bwd_persist, float** zp, long* zn) {
+    const long SN = (long)a->S * a->N;
+    zp[0] = b.DC; zn[0] = b.zero_floats;
+    zp[1] = b.DXT; zn[1] = SN * a->E;
+    zp[2] = g->g_event; zn[2] = (long)a->N * a->De;
+    zp[3] = b.DOUT; zn[3] = SN * 3 * a->H;
+    int nz = 4;
+    if (bwd_persist) { persist_bwd_zero_range(a, b.XWSB, &zp[nz], &zn[nz]); ++nz; }
+    if (g->zero_extra && g->zero_extra_count > 0) { zp[nz] = g->zero_extra; zn[nz] = (long)g->zero_extra_count; ++nz; }
+    return nz;
+}
+// the backward workspace whose scratch fill echr_train_step has already queued behind the decoder's prepare (nullptr: none)
+static const void*& scratch_ahead() { static const void* p = nullptr; return p; }
+namespace echr {
+// echr_train_step, right after echr_decoder_fwd_prepare: the backward pass's scratch fill (32 MB) joins the gradient-arena fill at the end of
+// the prepare stream -- long before the backward pass, beside the forward recurrence -- instead of being a launch of its own between the two
+// recurrences; echr_decoder_bwd then skips its fill (it waits for the prepare stream's fill event on entry anyway)
+int decoder_bwd_scratch_ahead(const echr_dec_args* a, const echr_dec_grads* g) {
+    Prep& pr = prep();
+    static const bool off = [] { const char* e = getenv("ECHR_SCRATCH_AHEAD"); return e && e[0] == '0'; }();
+    if (off || !pr.ok || !pr.pending || !pr.fill_pending || pr.ws != a->ws || !g->ws_bwd || !g->g_event || overlap_enabled()) return 0;
+    const DecWsBwd b = carve_ws_bwd(a, g->ws_bwd);
+    const bool bwd_persist = !(config().chains2 == 1 && side().ok && a->S >= 2) && persist_bwd_eligible(a);
+    float* zp[FILL_MAX_JOBS];
+    long zn[FILL_MAX_JOBS];
+    echr_dec_grads gz = *g;
+    gz.zero_extra = nullptr; gz.zero_extra_count = 0;
+    const int nz = bwd_scratch_ranges(a, &gz, b, bwd_persist, zp, zn);
+    RC(fill_zero_multi(zp, zn, nz, pr.s));
+    if (hipEventRecord(pr.fill_done, pr.s) != hipSuccess) { set_error("event record failed"); return -5; }
+    scratch_ahead() = g->ws_bwd;
+    return 0;
+}
+}  // namespace echr
 extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
     RC(persist_check_async());
     RC(check_dims(a, "decoder_fwd_prepare"));
@@ -1082,6 +1118,7 @@ extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
     Prep& pr = prep();
     ECHR_REQUIRE(pr.ok, "decoder_fwd_prepare: stream state unavailable");
     hipStream_t sm = (hipStream_t)stream, st = pr.s;
+    scratch_ahead() = nullptr;          // (a train step whose backward never ran)
     RC(echr_decoder_fwd_prepare_cancel(stream));          // an earlier prepare nobody consumed: order its workspace before anything new
     RC(join_tail(sm));
     RC(hop(sm, pr.fork, st));
@@ -1301,15 +1338,16 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
                                     {a->w_h2a, H, b.WT_H2A, Ha, Ha, H}};
         RC(transpose_multi(tj, 5, st));
     }
-    {   // DC | DGCOL | DQ | DASL | DPALL, the split-K / accumulated outputs DXT, g_event and DOUT, the zeroed part of the persistent reverse
-        // launch's exchange workspace and, when the caller asks for it (zero_extra), its gradient arena span: one launch
-        float* zp[7] = {b.DC, b.DXT, g->g_event, b.DOUT, nullptr, nullptr, nullptr};
-        long zn[7] = {b.zero_floats, (long)SN * E, (long)N * a->De, (long)SN * 3 * H, 0, 0, 0};
-        int nz = 4;
-        if (bwd_persist) { persist_bwd_zero_range(a, b.XWSB, &zp[nz], &zn[nz]); ++nz; }
-        if (g->zero_extra && g->zero_extra_count > 0) { zp[nz] = g->zero_extra; zn[nz] = (long)g->zero_extra_count; ++nz; }
+    if (scratch_ahead() == g->ws_bwd && g->dlg_ready) {
+        // echr_train_step queued this fill behind the decoder's prepare (decoder_bwd_scratch_ahead); this stream waited for it on entry
+        if (g->zero_extra && g->zero_extra_count > 0) RC(fill_zero(g->zero_extra, (long)g->zero_extra_count, st));
+    } else {
+        float* zp[FILL_MAX_JOBS];
+        long zn[FILL_MAX_JOBS];
+        const int nz = bwd_scratch_ranges(a, g, b, bwd_persist, zp, zn);
         RC(fill_zero_multi(zp, zn, nz, st));
     }
+    scratch_ahead() = nullptr;
     }
     // 2. late fusion gradients: the weight/bias gradients do not feed the recurrence -> side stream
     const bool ov = overlap_enabled() && S >= 4 && g->phase == 0;

@@ -68,6 +68,7 @@ hipStream_t aux2_stream();
 hipStream_t helpers_merge_to_tail();
 int tail_publish();
 int tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr_dropout* drop, void* stream, int part);
+int decoder_bwd_scratch_ahead(const echr_dec_args* a, const echr_dec_grads* g);
 int decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, int part);
 int join_tail(hipStream_t st);          // make st wait for an asynchronous decoder-backward tail (decoder.hip); no-op when none is pending
 int persist_read_stamps(unsigned long long* dst, int max_entries);

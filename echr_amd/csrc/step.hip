@@ -230,6 +230,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     g.active_rows = a->n_active > 0 ? active : nullptr; g.n_active = a->n_active;
     g.g_loss = a->g_loss; g.nll_msum = a->loss + 1;
     g.ws_bwd = ws + L.dec_ws_bwd; g.zeroed = 1; g.phase = 0; g.async_tail = async_level();
+    if (!a->forward_only && a->overlap_encoder) RC(decoder_bwd_scratch_ahead(&d, &g));          // the backward's scratch fill: behind the prepare chain, not between the recurrences
     // forward (:30) + LanguageModelCriterion (misc/utils.py:66-75).  Training: log-softmax, criterion and its gradient are ONE pass over the
     // logits (d logits land in the backward workspace, the log-probs are never written; the loss is summed behind the backward pass, where
     // this stream waits for the helper stream anyway).  forward_only: the plain log-softmax + criterion, loss[0] = loss, loss[1] = sum(mask)
