@@ -338,20 +338,20 @@ int vec_mat(const float* x, const float* W, long ldw, float* out, int M, int N, 
     return check_launch("vec_mat");
 }
 
-// out[c] = sum_k x[k] * W[c, k] + b1[c] + b2[c]  (one input row against N weight rows of K <= a few hundred contiguous floats): one wave per 16
-// outputs, a quarter wave per output -- the scene-context gate bias W_ih2[:, E:] . video + b_ih2 + b_hh2 without a GEMM launch
+// out[c] = sum_k x[k] * W[c, k] + b1[c] + b2[c]  (one input row against N weight rows of K <= a few hundred contiguous floats): one WAVE per
+// output (the lanes stride k, one reduction) -- the scene-context gate bias W_ih2[:, E:] . video + b_ih2 + b_hh2 without a GEMM launch.  (A
+// quarter wave per output walked 25 dependent loads: 14 us on the decoder's prepare chain.)
 __global__ __launch_bounds__(256) void row_matvec_kernel(const float* __restrict__ x, const float* __restrict__ W, long ldw, const float* __restrict__ b1,
                                                          const float* __restrict__ b2, float* __restrict__ out, int N, int K) {
-    const int c = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     float s = 0.f;
     if (c < N)
-        for (int k = q; k < K; k += 4) s = fmaf(x[k], W[(long)c * ldw + k], s);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (c < N && q == 0) out[c] = s + (b1 ? b1[c] : 0.f) + (b2 ? b2[c] : 0.f);
+        for (int k = lane; k < K; k += 64) s = fmaf(x[k], W[(long)c * ldw + k], s);
+    s = wave_sum(s);
+    if (c < N && lane == 0) out[c] = s + (b1 ? b1[c] : 0.f) + (b2 ? b2[c] : 0.f);
 }
 int row_matvec(const float* x, const float* W, long ldw, const float* b1, const float* b2, float* out, int N, int K, hipStream_t st) {
-    hipLaunchKernelGGL(row_matvec_kernel, dim3((N + 63) / 64), dim3(256), 0, st, x, W, ldw, b1, b2, out, N, K);
+    hipLaunchKernelGGL(row_matvec_kernel, dim3((N + 3) / 4), dim3(256), 0, st, x, W, ldw, b1, b2, out, N, K);
     return check_launch("row_matvec");
 }
 
