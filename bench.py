@@ -47,112 +47,283 @@ def make_workload(rank, overlap, c5=False):
     return opt, params, vid
 
 
+class Workload(object):
+    """One timed configuration: model, optimiser, inputs and the closure that issues ONE iteration of it.
+    kind 'train' = BASELINE config 3 (the headline), 'fwd' = config 2 (forward + criterion), 'c5' = config 5 (SST + caption path, joint)."""
+
+    def __init__(self, args, kind, rank, dev, use_dist):
+        import echr_amd
+        from echr_amd import parallel
+        from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+        from echr_amd.optim import ClampAdam
+        self.kind, self.args, self.use_dist = kind, args, use_dist
+        c5 = kind == 'c5'
+        opt, params, vid = make_workload(rank, args.overlap, c5)
+        self.opt, self.vid = opt, vid
+        model = echr_amd.CaptionGenerator(opt)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        self.model = model = model.to(dev).train()
+        crit = LanguageModelCriterion()
+        arena = None if args.no_arena else model.build_arena()      # flat parameter/gradient buffers: 1-launch Adam, 1-bucket all-reduce
+        optim = ClampAdam(model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon, arena=arena)
+        tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+        labels = torch.from_numpy(vid['labels'])                       # host copy: step count needs no device sync
+        tgt = labels[:, 1:].to(dev)
+        msk = torch.from_numpy(vid['masks'])[:, 1:].to(dev)
+        tgt_h, msk_h = labels[:, 1:].numpy(), vid['masks'][:, 1:]
+        ind, soi = vid['ind'], vid['soi']
+
+        # the whole iteration as ONE library call (echr_train_step: include/echr_hip.h, echr_amd/fused.py) instead of ~75 ctypes calls and four
+        # autograd nodes -- for EVERY world size: with several ranks the call stops behind the backward pass (step=False) and hands the
+        # gradient ranges that are final early to the collective stream while its tail still runs (fused.DataParallelStep)
+        fused = dp = None
+        if args.fused != 'off' and arena is not None and not (c5 and use_dist):
+            from echr_amd.fused import FusedTrainStep
+            fused = FusedTrainStep(model, optim, grad_clip=opt.grad_clip)
+            if use_dist and kind == 'train':
+                from echr_amd.fused import DataParallelStep
+                dp = DataParallelStep(fused, overlap=os.environ.get('ECHR_DP_OVERLAP', '1') != '0')
+        elif use_dist and arena is not None and os.environ.get('ECHR_DP_OVERLAP', '1') != '0':
+            parallel.enable_overlap(model)       # autograd path: LSTM-layer gradients are reduced while the backward tail runs
+        self.fused, self.dp = fused, dp
+        self.active_rows = None
+
+        if c5:
+            from echr_amd import models as EM
+            from echr_amd.misc.utils import TAPModelCriterion
+            torch.manual_seed(0)
+            tap_model = EM.setup_tap(opt).to(dev)
+            tap_model.train()
+            tap_arena = None if args.no_arena else tap_model.build_arena()
+            tap_optim = ClampAdam(tap_model.parameters(), lr=opt.lr, arena=tap_arena)
+            tap_crit = TAPModelCriterion()
+            tl, tm, tw = (torch.from_numpy(vid[k]).to(dev) for k in ('tap_labels', 'tap_masks', 'w1'))
+
+            def iteration():      # train.py's joint 'tap_cg' iteration: SST -> caption path -> lambda1*tap_loss + lambda2*cg_loss
+                if fused is not None:
+                    # the caption side as ONE library call (forward, criterion, backward, clip, Adam); d loss / d tap_feats comes back in g_tap and
+                    # is backpropagated into the proposal encoder together with its own loss (same sums as loss.backward() of the joint loss)
+                    tap_optim.zero_grad()
+                    early = os.environ.get('ECHR_EARLY_PREPARE', '1') != '0'
+                    if early:          # the caption side's tap-independent part starts now and runs beside the proposal encoder's forward
+                        fused.prepare(c3d, lda, labels, ind, soi, tgt_h, msk_h)
+                    tap_feats, props = tap_model(c3d)
+                    g_tap = torch.zeros_like(tap_feats)
+                    tap_loss = 0.01 * tap_crit(props, tm, tl, tw)          # (queued before the caption side: nothing of it waits for g_tap)
+                    defer = os.environ.get('ECHR_DEFER_UPDATE', '1') != '0'
+                    cg_loss = fused(tap_feats.detach(), c3d, lda, labels, ind, soi, tgt_h, msk_h, tap_grad=g_tap, defer_update=defer, prepared=early)
+                    torch.autograd.backward([tap_loss, tap_feats], [None, g_tap])
+                    clip_gradient(tap_optim, opt.grad_clip)
+                    tap_optim.step()
+                    return tap_loss.detach() + cg_loss
+                optim.zero_grad()
+                tap_optim.zero_grad()
+                tap_feats, props = tap_model(c3d)
+                pred = model(tap_feats, c3d, lda, labels, ind, soi, mode='train')
+                loss = 0.01 * tap_crit(props, tm, tl, tw) + crit(pred, tgt, msk)
+                loss.backward()
+                if use_dist:
+                    parallel.allreduce_gradients(model, force=True)
+                    parallel.allreduce_gradients(tap_model, force=True)
+                clip_gradient(optim, opt.grad_clip)
+                clip_gradient(tap_optim, opt.grad_clip)
+                optim.step()
+                tap_optim.step()
+                return loss
+        elif kind == 'fwd':
+            def iteration():
+                if fused is not None:          # forward + criterion only (BASELINE config 2), same one-call entry
+                    return fused(tap, c3d, lda, labels, ind, soi, tgt_h, msk_h, forward_only=True)
+                with torch.no_grad():
+                    return crit(model(tap, c3d, lda, labels, ind, soi, mode='train'), tgt, msk)
+        else:
+            def iteration():
+                if dp is not None:
+                    return dp(tap, c3d, lda, labels, ind, soi, tgt_h, msk_h)
+                if fused is not None:
+                    # (criterion inputs handed over on the host, as the reference's loader produces them: they travel with the index vectors)
+                    return fused(tap, c3d, lda, labels, ind, soi, tgt_h, msk_h)
+                optim.zero_grad()
+                pred = model(tap, c3d, lda, labels, ind, soi, mode='train')
+                loss = crit(pred, tgt, msk)
+                loss.backward()
+                if use_dist:
+                    parallel.allreduce_gradients(model, force=True)        # SUM over ranks == reference m_batch accumulation
+                clip_gradient(optim, opt.grad_clip)
+                optim.step()
+                return loss
+        self.iteration = iteration
+
+    def host_path(self):
+        if self.dp is not None:
+            return 'echr_train_step + early range collectives'
+        return 'echr_train_step (one library call per iteration)' if self.fused is not None else 'autograd Functions (one ctypes call per fused region)'
+
+    def describe(self, args):
+        if self.kind == 'c5':
+            return ('c5: SST (2-layer LSTM 500->512, K=256) over one 256-segment video + caption path on %d proposals of 4..256 '
+                    'segments, S=%d, V1=%d, joint fwd+bwd+clamp+Adam, one video per GPU' % (N_EV, S_STEPS, V1))
+        return '%s: %d events x %d seg x 500-d C3D (%s), S=%d decoder timesteps, V1=%d, %s, one video per GPU' % (
+            'c3' if self.kind == 'train' else 'c2', N_EV, A_SEG, 'T_v=160 overlapping' if args.overlap else 'disjoint rows, T_v=8192',
+            S_STEPS, V1, 'fwd+bwd+clamp+Adam' if self.kind == 'train' else 'forward + loss only (train-mode dropout)')
+
+    def active_rows_str(self):
+        """Label positions that can reach the loss (up to each caption's last non-zero mask entry) of all N x S: what the late-fusion and
+        weight-gradient products of a training iteration run on; the CPU baseline computes all rows."""
+        mk = self.vid['masks'][:, 1:1 + S_STEPS] != 0
+        live = np.flip(np.logical_or.accumulate(np.flip(mk, 1), 1), 1)
+        return '%d/%d' % (int(live.sum()), mk.size)
+
+
+def timed_regions(iteration, steps, regions, fence, world, dev, use_dist):
+    """`regions` back-to-back timed regions of exactly `steps` iterations, each bracketed by barrier + torch.cuda.synchronize() on both sides
+    and reduced with MAX over ranks; returns the per-region wall times [s], the host issue time of the first region and the last loss."""
+    out, t_issue, loss = [], None, None
+    for r in range(regions):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = iteration()
+        if t_issue is None:
+            t_issue = time.perf_counter() - t0          # host time to issue the timed steps (the GPU may still be working)
+        fence()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out.append(dt)
+    return out, t_issue, loss
+
+
+def region_stats(times, steps, world):
+    ms = sorted(1e3 * t / steps for t in times)
+    med = float(np.median(ms))
+    return dict(ms_per_step=round(med, 3), value=round(1e3 * S_STEPS * world / med, 1),
+                regions=dict(n=len(ms), steps_each=steps, ms_per_step_min=round(ms[0], 3), ms_per_step_median=round(med, 3), ms_per_step_max=round(ms[-1], 3)))
+
+
+# kernel classes of libechr_hip.so (echr_prof_read kinds) -> (name, rocprof kernel symbol, bound)
+PROF_KINDS = {0: ('gemm_f32_kernel', 'gemm_f32_kernel<*> (all tile/layout instantiations)', 'mfma'),
+              7: ('gemm_h2_kernel', 'gemm_h2m16_kernel<2> (v_mfma_f32_16x16x32_f16) + gemm_h2_kernel<128, 32, 2> (many-way split-K products)', 'mfma'),
+              6: ('gemm_split_kernel', 'gemm_split_kernel', 'mfma'),
+              4: ('rec_gemm_kernel', 'rec_gemm_kernel', 'mfma'),
+              8: ('h2_pack_kernel', 'h2_pack_kernel', 'hbm'),
+              1: ('att_fwd', 'att_score_kernel + att_context_kernel', 'hbm'),
+              2: ('att_bwd_kernel', 'att_bwd_kernel', 'hbm'),
+              3: ('att_post_kernel', 'att_post_kernel', 'valu'),
+              9: ('dec_persist_kernels', 'dec_persist_fwd_kernel<true, BIG> (forward) and dec_persist_bwd_kernel<BIG> (reverse; BIG = events longer than 129 segments): each ONE launch of 256 workgroups '
+                                         '(attention chain on 192, the two plain LSTM streams on 64) covering all S steps', 'mfma'),
+              10: ('sst_persist_kernels', 'sst_persist_fwd_kernel / sst_persist_bwd_kernel: the proposal encoder\'s two-layer LSTM over the video, ONE '
+                                          'launch of 64 workgroups per direction (recurrent matrices in registers, batch-1 GEMV chain: latency-bound)', 'hbm')}
+
+
+def roofline_pass(wl, args, rank, fence, brief=False):
+    """Instrumented pass over the same iterations: HIP events around every launch of each kernel class, on the stream the kernel is launched
+    on.  EVERY rank runs the iterations (they contain the gradient collectives); only rank 0 instruments and reports."""
+    from echr_amd import _lib
+    lib = _lib.load()
+    n_it = max(2, min(args.steps, 5))
+    if rank == 0:
+        lib.echr_prof_enable(1)
+    for _ in range(n_it):
+        wl.iteration()
+    fence()
+    if rank != 0:
+        return None
+    stats = {}
+    for k, (name, sym, bound) in PROF_KINDS.items():
+        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        lib.echr_prof_read(k, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n))
+        stats[name] = dict(ms=ms.value, flops=fl.value, bytes=by.value, launches=n.value, sym=sym, bound=bound)
+    lib.echr_prof_enable(0)
+    # HBM traffic per launch cannot be collected inside a timed run (PMC needs rocprofv3 --pmc in separate passes): it is read from the
+    # committed summary of the SAME command (tools/pmc_traffic.sh -> profiles/rNN_pmc_traffic*.json); null when absent
+    # (one pair of files per workload: `_c5` for config 5; other variants -- overlapping rows, forward only -- carry no counters)
+    sfx = '_c5' if wl.kind == 'c5' else ''
+    traffic, traffic_src, mfma_pmc = {}, None, {}
+    if not (args.overlap or wl.kind == 'fwd'):
+        for rnd in ('r05', 'r04', 'r03', 'r02'):
+            name = '%s_pmc_traffic%s.json' % (rnd, sfx)
+            try:
+                traffic = json.load(open(os.path.join(ROOT, 'profiles', name)))
+                traffic_src = 'profiles/' + name
+                break
+            except Exception:
+                pass
+        # MFMA activity (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles of the dispatch) likewise comes from the committed --pmc pass of the
+        # same command (tools/pmc_mfma.sh -> profiles/rNN_pmc_mfma*.json)
+        for rnd in ('r05', 'r04', 'r03', 'r02'):
+            try:
+                mfma_pmc = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc_mfma%s.json' % (rnd, sfx))))
+                break
+            except Exception:
+                pass
+    traffic_commit = traffic.get('_commit') if isinstance(traffic, dict) else None
+
+    def mfma_busy(name):
+        if name == 'dec_persist_kernels':           # time-weighted over the four kernels of the two pairs
+            ks = [v for k, v in mfma_pmc.items() if k.startswith('dec_persist') and isinstance(v, dict) and v.get('mfma_busy_frac') is not None]
+            tot = sum(v['avg_us'] * v['launches'] for v in ks)
+            return round(sum(v['mfma_busy_frac'] * v['avg_us'] * v['launches'] for v in ks) / tot, 4) if tot else None
+        v = mfma_pmc.get(name)
+        return v.get('mfma_busy_frac') if isinstance(v, dict) else None
+
+    # HIP-event pairs around a short launch add a fixed cost per launch (the second record waits for the first to retire):
+    # measured here on an idle stream and subtracted, so that avg_launch_us agrees with rocprofv3's kernel durations
+    ev_ms, ev_n = C.c_double(), C.c_int64()
+    lib.echr_prof_event_overhead(C.byref(ev_ms), C.byref(ev_n))
+    ev_us = 1e3 * ev_ms.value / max(ev_n.value, 1)
+
+    def line(name):
+        st = stats[name]
+        if st['launches'] == 0 or st['ms'] <= 0:
+            return None
+        ms = max(st['ms'] - 1e-3 * ev_us * st['launches'], 1e-6)
+        if st['bound'] == 'mfma':
+            # fp32-grade products: native fp32 MFMA, or 3 fp16 (h2) / 6 bf16 (split) MFMA products per product -> the ceiling of
+            # the ALGORITHMIC rate is the 16-bit dense MFMA peak divided by the products spent per fp32-grade product
+            peak = {'gemm_h2_kernel': MFMA_16BIT_PEAK_TFLOPS / 3, 'gemm_split_kernel': MFMA_16BIT_PEAK_TFLOPS / 6}.get(name, MFMA_F32_PEAK_TFLOPS)
+            ach, peak, unit = st['flops'] / (ms * 1e-3) / 1e12, round(peak, 1), 'TFLOP/s'
+        elif st['bound'] == 'valu':
+            # transcendental-bound pass: 6 flops per (slot, feature, timestep) counted against the fp32 vector peak (= the fp32 MFMA peak)
+            ach, peak, unit = st['flops'] / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
+        else:
+            ach, peak, unit = st['bytes'] / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
+        tr = traffic.get(name) or next((v for k, v in traffic.items() if k.startswith(name + '<')), None)
+        tr = tr if isinstance(tr, dict) else None
+        tb = (tr or {}).get('hbm_bytes_per_launch')
+        alg = st['bytes'] / st['launches'] if st['bytes'] > 0 else None
+        out = dict(bound='mfma' if st['bound'] == 'valu' else st['bound'], kernel=st['sym'] if not brief else name, achieved=round(ach, 2), peak=peak, unit=unit,
+                   frac=round(ach / peak, 4), traffic=tb)
+        if brief:
+            out.update(avg_launch_us=round(1e3 * ms / st['launches'], 2), launches_per_step=st['launches'] / n_it, ms_per_step=round(ms / n_it, 3))
+            return out
+        out.update(traffic_source=traffic_src if tb else None, traffic_commit=traffic_commit if tb else None,
+                   algorithmic_bytes_per_launch=round(alg) if alg else None,
+                   traffic_over_algorithmic=round(tb / alg, 2) if (tb and alg) else None,
+                   mfma_busy_frac_pmc=mfma_busy(name),
+                   avg_launch_us=round(1e3 * ms / st['launches'], 2), event_overhead_us_subtracted=round(ev_us, 2),
+                   launches_per_step=st['launches'] / n_it, ms_per_step=round(ms / n_it, 3))
+        return out
+
+    dom = max(stats, key=lambda k: stats[k]['ms'])
+    roof = line(dom)
+    # `achieved` = algorithmic flops (2MNK) or bytes per launch / HIP-event duration on the launch stream; `peak` for the
+    # MFMA-bound kernels: 157.3 TF (native fp32 MFMA: gemm_f32, rec_gemm), 2500/3 TF (gemm_h2: three fp16 MFMA products per
+    # fp32-grade product), 2500/6 TF (gemm_split: six bf16 products).
+    if not brief:
+        roof['other_kernels'] = {k: line(k) for k in stats if k != dom and line(k) is not None}
+    return roof
+
+
 def gpu_leg(args, rank, world, local_rank):
-    import echr_amd
-    from echr_amd import _lib, parallel
-    from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
-    from echr_amd.optim import ClampAdam
+    from echr_amd import _lib
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     use_dist = dist.is_available() and dist.is_initialized()
-    opt, params, vid = make_workload(rank, args.overlap, args.c5)
-    model = echr_amd.CaptionGenerator(opt)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
-    model = model.to(dev).train()
-    crit = LanguageModelCriterion()
-    arena = None if args.no_arena else model.build_arena()      # flat parameter/gradient buffers: 1-launch Adam, 1-bucket all-reduce
-    if use_dist and arena is not None and os.environ.get('ECHR_DP_OVERLAP', '1') != '0':
-        parallel.enable_overlap(model)       # logit-layer gradients (35 % of the bytes) are reduced while the reverse recurrence runs
-    optim = ClampAdam(model.parameters(), lr=opt.lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon, arena=arena)
-    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
-    labels = torch.from_numpy(vid['labels'])                       # host copy: step count needs no device sync
-    tgt = labels[:, 1:].to(dev)
-    msk = torch.from_numpy(vid['masks'])[:, 1:].to(dev)
-    tgt_h, msk_h = labels[:, 1:].numpy(), vid['masks'][:, 1:]
-
-    if args.c5:
-        from echr_amd import models as EM
-        from echr_amd.misc.utils import TAPModelCriterion
-        torch.manual_seed(0)
-        tap_model = EM.setup_tap(opt).to(dev)
-        tap_model.train()
-        tap_arena = None if args.no_arena else tap_model.build_arena()
-        tap_optim = ClampAdam(tap_model.parameters(), lr=opt.lr, arena=tap_arena)
-        tap_crit = TAPModelCriterion()
-        tl, tm, tw = (torch.from_numpy(vid[k]).to(dev) for k in ('tap_labels', 'tap_masks', 'w1'))
-
-    def c5_iteration():      # train.py's joint 'tap_cg' iteration: SST -> caption path -> lambda1*tap_loss + lambda2*cg_loss
-        if fused is not None:
-            # the caption side as ONE library call (forward, criterion, backward, clip, Adam); d loss / d tap_feats comes back in g_tap and is
-            # backpropagated into the proposal encoder together with its own loss (same sums as loss.backward() of the joint loss)
-            tap_optim.zero_grad()
-            early = os.environ.get('ECHR_EARLY_PREPARE', '1') != '0'
-            if early:          # the caption side's tap-independent part starts now and runs beside the proposal encoder's forward
-                fused.prepare(c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h)
-            tap_feats, props = tap_model(c3d)
-            g_tap = torch.zeros_like(tap_feats)
-            tap_loss = 0.01 * tap_crit(props, tm, tl, tw)          # (queued before the caption side: nothing of it waits for g_tap)
-            defer = os.environ.get('ECHR_DEFER_UPDATE', '1') != '0'
-            cg_loss = fused(tap_feats.detach(), c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, tap_grad=g_tap,
-                            defer_update=defer, prepared=early)
-            torch.autograd.backward([tap_loss, tap_feats], [None, g_tap])
-            clip_gradient(tap_optim, opt.grad_clip)
-            tap_optim.step()
-            return tap_loss.detach() + cg_loss
-        optim.zero_grad()
-        tap_optim.zero_grad()
-        tap_feats, props = tap_model(c3d)
-        pred = model(tap_feats, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
-        loss = 0.01 * tap_crit(props, tm, tl, tw) + crit(pred, tgt, msk)
-        loss.backward()
-        if use_dist:
-            parallel.allreduce_gradients(model, force=True)
-            parallel.allreduce_gradients(tap_model, force=True)
-        clip_gradient(optim, opt.grad_clip)
-        clip_gradient(tap_optim, opt.grad_clip)
-        optim.step()
-        tap_optim.step()
-        return loss
-
-    def fwd_only():
-        with torch.no_grad():
-            pred = model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
-            return crit(pred, tgt, msk)
-
-    # the whole iteration as ONE library call (echr_train_step: include/echr_hip.h, echr_amd/fused.py) instead of ~75 ctypes calls and four
-    # autograd nodes; single-process default.  With several ranks the autograd path keeps the staged early all-reduce, unless --fused asks
-    # for the one-call form there too (backward inside the call, then ONE collective, then clip + step)
-    fused = None
-    want_fused = args.fused == 'on' or (args.fused == 'auto' and not use_dist)
-    if want_fused and arena is not None and not (args.c5 and use_dist):
-        from echr_amd.fused import FusedTrainStep
-        fused = FusedTrainStep(model, optim, grad_clip=opt.grad_clip)
-
-    def iteration():
-        if args.c5:
-            return c5_iteration()
-        if args.mode == 'fwd':
-            if fused is not None:          # forward + criterion only (BASELINE config 2), same one-call entry
-                return fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, forward_only=True)
-            return fwd_only()
-        if fused is not None:
-            # (criterion inputs handed over on the host, as the reference's loader produces them: they travel with the index vectors)
-            if not use_dist:
-                return fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h)
-            loss = fused(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False)
-            parallel.allreduce_gradients(model, force=True)
-            clip_gradient(optim, opt.grad_clip)
-            optim.step()
-            return loss
-        optim.zero_grad()
-        pred = model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
-        loss = crit(pred, tgt, msk)
-        loss.backward()
-        if use_dist:
-            parallel.allreduce_gradients(model, force=True)        # SUM over ranks == reference m_batch accumulation
-        clip_gradient(optim, opt.grad_clip)
-        optim.step()
-        return loss
+    kind = 'c5' if args.c5 else ('fwd' if args.mode == 'fwd' else 'train')
+    wl = Workload(args, kind, rank, dev, use_dist)
 
     def fence():
         if use_dist:
@@ -165,161 +336,64 @@ def gpu_leg(args, rank, world, local_rank):
 
     say('model ready; warm-up')
     for i in range(args.warmup):
-        loss = iteration()
+        wl.iteration()
         torch.cuda.synchronize()
         say('warm-up %d done' % i)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = iteration()
-    t_issue = time.perf_counter() - t0          # host time to issue the timed steps (the GPU may still be working)
-    fence()
-    dt = time.perf_counter() - t0
-    say('host issue time %.3f ms per step (GPU-inclusive %.3f)' % (1e3 * t_issue / args.steps, 1e3 * dt / args.steps))
+    times, t_issue, loss = timed_regions(wl.iteration, args.steps, args.regions, fence, world, dev, use_dist)
+    head = region_stats(times, args.steps, world)
+    say('host issue time %.3f ms per step; timed regions (ms per step): %s' % (1e3 * t_issue / args.steps, ' '.join('%.3f' % (1e3 * t / args.steps) for t in times)))
     if os.environ.get('ECHR_HOST_PROBE') == '1':          # diagnostic: host time of one iteration issued into an empty queue
         ts = []
         for _ in range(10):
-            torch.cuda.synchronize(); t1 = time.perf_counter(); iteration(); ts.append(time.perf_counter() - t1)
+            torch.cuda.synchronize(); t1 = time.perf_counter(); wl.iteration(); ts.append(time.perf_counter() - t1)
         torch.cuda.synchronize()
         say('host time of one iteration issued into an empty queue: min %.3f ms, median %.3f ms' % (1e3 * min(ts), 1e3 * sorted(ts)[5]))
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     final_loss = float(loss.item())
-    say('timed region done: %.3f s for %d steps' % (dt, args.steps))
 
     # second timed figure with every large projection on the NATIVE fp32 MFMA path (no fp16-pair / bf16-plane emulation)
     native = None
-    if not args.no_native and args.mode == 'train' and not args.c5:
+    if not args.no_native and kind == 'train':
         lib = _lib.load()
-        lib.echr_config_set(b'gemm_h2', 0)
-        lib.echr_config_set(b'persist_h2', 0)
-        lib.echr_config_set(b'gemm_bf16x3', 0)
+        for k in (b'gemm_h2', b'persist_h2', b'gemm_bf16x3'):
+            lib.echr_config_set(k, 0)
         for _ in range(2):
-            iteration()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            iteration()
-        fence()
-        dtn = time.perf_counter() - t0
-        lib.echr_config_set(b'gemm_h2', 1)
-        lib.echr_config_set(b'persist_h2', 1)
-        lib.echr_config_set(b'gemm_bf16x3', 1)
-        if use_dist:
-            t = torch.tensor([dtn], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtn = float(t.item())
-        native = dict(value=round(args.steps * S_STEPS * world / dtn, 1), unit='timesteps/s', ms_per_step=round(1e3 * dtn / args.steps, 3),
+            wl.iteration()
+        tn, _, _ = timed_regions(wl.iteration, args.steps, min(args.regions, 3), fence, world, dev, use_dist)
+        for k in (b'gemm_h2', b'persist_h2', b'gemm_bf16x3'):
+            lib.echr_config_set(k, 1)
+        st = region_stats(tn, args.steps, world)
+        native = dict(value=st['value'], unit='timesteps/s', ms_per_step=st['ms_per_step'], regions=st['regions'],
                       note='same workload with gemm_h2=0, gemm_bf16x3=0, persist_h2=0: every product on v_mfma_f32_* (exact fp32 MFMA)')
         for _ in range(2):
-            iteration()
+            wl.iteration()
         fence()
 
     roof = None
     if not args.no_roofline:
-        # second, instrumented pass over the same iterations: HIP events around every launch of each kernel class.  EVERY rank runs
-        # the iterations (they contain the gradient collectives); only rank 0 instruments and reports.
-        lib = _lib.load()
-        if rank == 0:
-            lib.echr_prof_enable(1)
-        for _ in range(max(2, min(args.steps, 5))):
-            iteration()
-        fence()
-    if rank == 0 and not args.no_roofline:
-        # kernel classes of libechr_hip.so (echr_prof_read kinds) -> (name, rocprof kernel symbol, bound)
-        kinds = {0: ('gemm_f32_kernel', 'gemm_f32_kernel<*> (all tile/layout instantiations)', 'mfma'),
-                 7: ('gemm_h2_kernel', 'gemm_h2m16_kernel<2> (v_mfma_f32_16x16x32_f16) + gemm_h2_kernel<128, 32, 2> (many-way split-K products)', 'mfma'),
-                 6: ('gemm_split_kernel', 'gemm_split_kernel', 'mfma'),
-                 4: ('rec_gemm_kernel', 'rec_gemm_kernel', 'mfma'),
-                 8: ('h2_pack_kernel', 'h2_pack_kernel', 'hbm'),
-                 1: ('att_fwd', 'att_score_kernel + att_context_kernel', 'hbm'),
-                 2: ('att_bwd_kernel', 'att_bwd_kernel', 'hbm'),
-                 3: ('att_post_kernel', 'att_post_kernel', 'valu'),
-                 9: ('dec_persist_kernels', 'dec_persist_fwd_kernel<true, BIG> (forward) and dec_persist_bwd_kernel<BIG> (reverse; BIG = events longer than 129 segments): each ONE launch of 256 workgroups '
-                                            '(attention chain on 192, the two plain LSTM streams on 64) covering all S steps', 'mfma'),
-                 10: ('sst_persist_kernels', 'sst_persist_fwd_kernel / sst_persist_bwd_kernel: the proposal encoder\'s two-layer LSTM over the video, ONE '
-                                             'launch of 64 workgroups per direction (recurrent matrices in registers, batch-1 GEMV chain: latency-bound)', 'hbm')}
-        n_it = max(2, min(args.steps, 5))
-        stats = {}
-        for k, (name, sym, bound) in kinds.items():
-            ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
-            lib.echr_prof_read(k, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n))
-            stats[name] = dict(ms=ms.value, flops=fl.value, bytes=by.value, launches=n.value, sym=sym, bound=bound)
-        lib.echr_prof_enable(0)
-        # HBM traffic per launch cannot be collected inside a timed run (PMC needs rocprofv3 --pmc in separate passes): it is read from
-        # the committed summary of the SAME command (tools/pmc_traffic.sh -> profiles/r02_pmc_traffic.json); null when absent
-        # (one pair of files per workload: `_c5` for --c5; other variants -- overlapping rows, forward only -- carry no counters)
-        sfx = '_c5' if args.c5 else ''
-        traffic, traffic_src, mfma_pmc = {}, None, {}
-        if not (args.overlap or args.mode != 'train'):
-            for name in ['r04_pmc_traffic%s.json' % sfx] + ([] if args.c5 else ['r03_pmc_traffic.json', 'r02_pmc_traffic.json']):
-                try:
-                    traffic = json.load(open(os.path.join(ROOT, 'profiles', name)))
-                    traffic_src = 'profiles/' + name
-                    break
-                except Exception:
-                    pass
-            # MFMA activity (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles of the dispatch) likewise comes from the committed --pmc pass of the
-            # same command (tools/pmc_mfma.sh -> profiles/r04_pmc_mfma.json)
-            for name in ['r04_pmc_mfma%s.json' % sfx] + ([] if args.c5 else ['r03_pmc_mfma.json', 'r02_pmc_mfma.json']):
-                try:
-                    mfma_pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
-                    break
-                except Exception:
-                    pass
-        traffic_commit = traffic.get('_commit') if isinstance(traffic, dict) else None
+        roof = roofline_pass(wl, args, rank, fence)
 
-        def mfma_busy(name):
-            if name == 'dec_persist_kernels':           # time-weighted over the four kernels of the two pairs
-                ks = [v for k, v in mfma_pmc.items() if k.startswith('dec_persist') and isinstance(v, dict) and v.get('mfma_busy_frac') is not None]
-                tot = sum(v['avg_us'] * v['launches'] for v in ks)
-                return round(sum(v['mfma_busy_frac'] * v['avg_us'] * v['launches'] for v in ks) / tot, 4) if tot else None
-            v = mfma_pmc.get(name)
-            return v.get('mfma_busy_frac') if isinstance(v, dict) else None
-
-        # HIP-event pairs around a short launch add a fixed cost per launch (the second record waits for the first to retire):
-        # measured here on an idle stream and subtracted, so that avg_launch_us agrees with rocprofv3's kernel durations
-        ev_ms, ev_n = C.c_double(), C.c_int64()
-        lib.echr_prof_event_overhead(C.byref(ev_ms), C.byref(ev_n))
-        ev_us = 1e3 * ev_ms.value / max(ev_n.value, 1)
-
-        def line(name):
-            st = stats[name]
-            if st['launches'] == 0 or st['ms'] <= 0:
-                return None
-            ms = max(st['ms'] - 1e-3 * ev_us * st['launches'], 1e-6)
-            if st['bound'] == 'mfma':
-                # fp32-grade products: native fp32 MFMA, or 3 fp16 (h2) / 6 bf16 (split) MFMA products per product -> the ceiling of
-                # the ALGORITHMIC rate is the 16-bit dense MFMA peak divided by the products spent per fp32-grade product
-                peak = {'gemm_h2_kernel': MFMA_16BIT_PEAK_TFLOPS / 3, 'gemm_split_kernel': MFMA_16BIT_PEAK_TFLOPS / 6}.get(name, MFMA_F32_PEAK_TFLOPS)
-                ach, peak, unit = st['flops'] / (ms * 1e-3) / 1e12, round(peak, 1), 'TFLOP/s'
-            elif st['bound'] == 'valu':
-                # transcendental-bound pass: 6 flops per (slot, feature, timestep) counted against the fp32 vector peak (= the fp32 MFMA peak)
-                ach, peak, unit = st['flops'] / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, 'TFLOP/s'
-            else:
-                ach, peak, unit = st['bytes'] / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
-            tr = traffic.get(name) or next((v for k, v in traffic.items() if k.startswith(name + '<')), None)
-            tr = tr if isinstance(tr, dict) else None
-            tb = (tr or {}).get('hbm_bytes_per_launch')
-            alg = st['bytes'] / st['launches'] if st['bytes'] > 0 else None
-            return dict(bound='mfma' if st['bound'] == 'valu' else st['bound'], kernel=st['sym'], achieved=round(ach, 2), peak=peak, unit=unit,
-                        frac=round(ach / peak, 4), traffic=tb, traffic_source=traffic_src if tb else None, traffic_commit=traffic_commit if tb else None,
-                        algorithmic_bytes_per_launch=round(alg) if alg else None,
-                        traffic_over_algorithmic=round(tb / alg, 2) if (tb and alg) else None,
-                        mfma_busy_frac_pmc=mfma_busy(name),
-                        avg_launch_us=round(1e3 * ms / st['launches'], 2), event_overhead_us_subtracted=round(ev_us, 2),
-                        launches_per_step=st['launches'] / n_it, ms_per_step=round(ms / n_it, 3))
-
-        dom = max(stats, key=lambda k: stats[k]['ms'])
-        roof = line(dom)
-        # `achieved` = algorithmic flops (2MNK) or bytes per launch / HIP-event duration on the launch stream; `peak` for the
-        # MFMA-bound kernels: 157.3 TF (native fp32 MFMA: gemm_f32, rec_gemm), 2500/3 TF (gemm_h2: three fp16 MFMA products per
-        # fp32-grade product), 2500/6 TF (gemm_split: six bf16 products).
-        roof['other_kernels'] = {k: line(k) for k in stats if k != dom and line(k) is not None}
-    host_path = 'echr_train_step (one library call per iteration)' if fused is not None else 'autograd Functions (one ctypes call per fused region)'
-    return dt, final_loss, roof, native, host_path
+    # the other single-GPU configurations of BASELINE.json in the same process: config 2 (forward + criterion only, same one-call entry) and
+    # config 5 (SST proposal encoder + caption path, joint iteration) -- each with its own timed regions and its dominant kernel's roofline
+    others = None
+    if kind == 'train' and world == 1 and not args.no_others and not args.overlap:
+        others = {}
+        for name, k2 in (('c2', 'fwd'), ('c5', 'c5')):
+            w2 = Workload(args, k2, rank, dev, use_dist)
+            for _ in range(max(3, args.warmup // 2)):
+                w2.iteration()
+            t2, _, l2 = timed_regions(w2.iteration, args.steps, args.regions, fence, world, dev, use_dist)
+            st = region_stats(t2, args.steps, world)
+            rf = None if args.no_roofline else roofline_pass(w2, args, rank, fence, brief=True)
+            others[name] = dict(metric='caption-decoder timesteps/sec (%s)' % ('fwd only' if k2 == 'fwd' else 'SST + decoder, joint fwd+bwd'),
+                                value=st['value'], unit='timesteps/s', ms_per_step=st['ms_per_step'], regions=st['regions'],
+                                workload=w2.describe(args), final_loss=round(float(l2.item()), 5), host_path=w2.host_path(), roofline=rf)
+            if hasattr(w2.fused, 'join'):
+                w2.fused.join()
+            torch.cuda.synchronize()
+            del w2
+            say('%s: %.3f ms per step' % (name, st['ms_per_step']))
+    return dict(head=head, loss=final_loss, roof=roof, native=native, host_path=wl.host_path(), workload=wl.describe(args),
+                active_rows=wl.active_rows_str() if kind != 'fwd' else None, others=others)
 
 
 def cpu_model_name():
@@ -455,7 +529,9 @@ def main():
                     'path with proposals of up to 256 segments, joint fwd+bwd+Adam (extra line; the headline metric is the default)')
     ap.add_argument('--no-arena', action='store_true', help='per-tensor gradients/optimiser instead of the flat arena')
     ap.add_argument('--fused', choices=['auto', 'on', 'off'], default=os.environ.get('ECHR_BENCH_FUSED', 'auto'),
-                    help='one echr_train_step call per iteration instead of the autograd path (auto: on for one process, off with several ranks)')
+                    help='one echr_train_step call per iteration (auto = on, for every world size) or the autograd path (off)')
+    ap.add_argument('--regions', type=int, default=5, help='back-to-back timed regions of --steps iterations each; ms_per_step = their median')
+    ap.add_argument('--no-others', action='store_true', help='skip the config-2 / config-5 lines measured after the headline (other_configs)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-native', action='store_true', help='skip the second timed figure on the native fp32 MFMA path')
@@ -494,49 +570,50 @@ def main():
                  'torch.distributed.run --nproc-per-node %d)' % (args.gpus, world, args.gpus, args.gpus))
     dp_info = {}
     if world > 1:
-        # several ranks may share CUs with collective kernels (and, in the one-GPU rehearsal, with each other): the persistent recurrences
-        # are launched cooperatively, so a grid only starts once all of its workgroups can be resident
-        # -- but only where something else CAN hold CUs while a persistent pair runs: ranks sharing one device (the rehearsal).  With one
-        # device per rank every collective of an iteration is behind the reverse recurrence (EarlyReducer: `defer_first`, hand-over after
-        # the recurrence) and is waited for before clamp + Adam, i.e. before the next forward pair in stream order, so no collective
-        # kernel is ever resident beside a pair and the plain launch (25 us per pair cheaper) is safe.
+        # With several ranks the persistent recurrences are launched cooperatively: a grid only starts once all of its workgroups can be
+        # resident, so a hand-off wait never depends on a workgroup that found no CU because a collective kernel (or, in the one-GPU
+        # rehearsal, another rank's grid) holds it.  By construction every collective of an iteration sits behind the reverse recurrence
+        # (hand-over events) and is waited for before clamp + Adam, so nothing should ever be resident beside a pair and the plain launch
+        # (25 us per pair cheaper) would do -- but that has never been validated on a real multi-GPU run, so the
+        # cooperative launch stays the multi-rank default (ECHR_PERSIST_COOP=0 to measure the plain one).
         from echr_amd import _lib
-        shared_device = os.environ.get('ECHR_BENCH_ONE_GPU') == '1'
-        coop = int(os.environ.get('ECHR_PERSIST_COOP', '1' if shared_device or os.environ.get('ECHR_DP_DEFER_FIRST', '1') == '0' else '0'))
+        coop = int(os.environ.get('ECHR_PERSIST_COOP', '1'))
         _lib.load().echr_config_set(b'persist_coop', coop)
         dp_info.update(persist_coop=coop, dp_algo=__import__('echr_amd.parallel', fromlist=['choose_algo']).choose_algo(world),
-                       dp_overlap=os.environ.get('ECHR_DP_OVERLAP', '1') != '0' and args.fused != 'on')
+                       dp_overlap=os.environ.get('ECHR_DP_OVERLAP', '1') != '0')
         if os.environ.get('ECHR_BENCH_ONE_GPU') == '1' and os.environ.get('ECHR_BENCH_PERSIST', '0') == '0':
             # rehearsal with every rank on ONE device: two 256-workgroup persistent grids must not share it -> launch-per-phase recurrences
             _lib.load().echr_config_set(b'persist', 0)
             _lib.load().echr_config_set(b'persist_bwd', 0)
-    dt, loss, roof, native, host_path = gpu_leg(args, rank, world, local_rank)
+    res = gpu_leg(args, rank, world, local_rank)
     if rank == 0:
-        value = args.steps * S_STEPS * world / dt
-        workload = '%s: %d events x %d seg x 500-d C3D (%s), S=%d decoder timesteps, V1=%d, %s, one video per GPU' % (
-            'c3' if args.mode == 'train' else 'c2', N_EV, A_SEG, 'T_v=160 overlapping' if args.overlap else 'disjoint rows, T_v=8192',
-            S_STEPS, V1, 'fwd+bwd+clamp+Adam' if args.mode == 'train' else 'forward + loss only (train-mode dropout)')
-        if args.c5:
-            workload = ('c5: SST (2-layer LSTM 500->512, K=256) over one 256-segment video + caption path on %d proposals of 4..256 '
-                        'segments, S=%d, V1=%d, joint fwd+bwd+clamp+Adam, one video per GPU' % (N_EV, S_STEPS, V1))
+        head = res['head']
         out = {
-            'metric': 'caption-decoder timesteps/sec (fwd+bwd)' if args.mode == 'train' else 'caption-decoder timesteps/sec (fwd only)', 'value': round(value, 1), 'unit': 'timesteps/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
+            'metric': 'caption-decoder timesteps/sec (fwd+bwd)' if args.mode == 'train' else 'caption-decoder timesteps/sec (fwd only)', 'value': head['value'], 'unit': 'timesteps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (storage and accumulation are fp32; the reverse recurrences use native fp32 MFMAs; the 11 large batched projections '
                      'and the forward recurrences run as fp16-pair "h2" MFMA emulation: 2 scaled fp16 planes per operand, 3 products, fp32 '
-                     'accumulate, error <= native fp32 MFMA vs float64; native_f32 = the same run with every product on fp32 MFMAs)',
+                     'accumulate; parity-gated at 1e-5 on random-init AND peaked-softmax fixtures; native_f32 = the same run with every product on fp32 MFMAs)',
             'data': 'synthetic',
-            'config': {'workload': workload,
+            'config': {'workload': res['workload'],
                        'global_events': N_EV * world, 'timesteps_per_step': S_STEPS, 'parallelism': 'dp%d' % world,
-                       'final_loss': round(loss, 5),
-                       'host_path': host_path},
+                       'final_loss': round(res['loss'], 5),
+                       'host_path': res['host_path'],
+                       'timed_regions': head['regions']},
         }
+        if res['active_rows']:
+            out['config']['active_rows'] = res['active_rows']
         out['config'].update(dp_info)
-        if native is not None:
-            out['native_f32'] = native
-        if roof is not None:
-            out['roofline'] = roof
+        if res['native'] is not None:
+            out['native_f32'] = res['native']
+            out['config']['native_f32'] = {k: res['native'][k] for k in ('value', 'ms_per_step')}
+        if res['others']:
+            # (also under `config`: a consumer that keeps only the contract's keys still sees them)
+            out['other_configs'] = res['others']
+            out['config']['other_configs'] = res['others']
+        if res['roof'] is not None:
+            out['roofline'] = res['roof']
         if world == 1 and not args.no_cpu and args.mode == 'train':
             out['cpu_baseline'] = cpu_leg(args)
         print(json.dumps(out), flush=True)

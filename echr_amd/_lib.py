@@ -84,7 +84,8 @@ class TrainStepArgs(C.Structure):
                 ('ws', c_f), ('ws_floats', i64), ('flat_g', c_f), ('n_flat', i64),
                 ('flat_p', c_f), ('adam_m', c_f), ('adam_v', c_f), ('adam_step', i32),
                 ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('clip', f32),
-                ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32), ('prepared', i32), ('defer_update', i32)]
+                ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32), ('prepared', i32), ('defer_update', i32),
+                ('handover', i32)]
 
 
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)
@@ -93,6 +94,7 @@ SYMBOLS = [
     ('echr_abi_sizeof', i64, [C.c_char_p]),
     ('echr_last_error', C.c_char_p, []),
     ('echr_check_async', i32, []),
+    ('echr_async_skipped_updates', i64, []),
     ('echr_gemm_f32', i32, [C.POINTER(GemmDesc), C.c_void_p]),
     ('echr_event_pool_gather_fwd', i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_event_pool_gather_bwd', i32, [c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
@@ -136,6 +138,7 @@ SYMBOLS = [
     ('echr_train_step_ws_floats', i64, [C.POINTER(TrainStepArgs)]),
     ('echr_train_step', i32, [C.POINTER(TrainStepArgs), C.c_void_p]),
     ('echr_train_step_prepare', i32, [C.POINTER(TrainStepArgs), C.c_void_p]),
+    ('echr_handover_wait', i32, [i32, C.c_void_p]),
     ('echr_clamp', i32, [c_f, i64, f32, C.c_void_p]),
     ('echr_clamp_adam', i32, [c_f, c_f, c_f, c_f, i64, i32, C.c_double, C.c_double, C.c_double, C.c_double, f32, C.c_void_p]),
 ]
@@ -144,6 +147,7 @@ ABI_STRUCTS = {'echr_gemm_desc': GemmDesc, 'echr_dropout': Dropout, 'echr_tsrm_a
                'echr_dec_args': DecArgs, 'echr_dec_grads': DecGrads, 'echr_sample_args': SampleArgs, 'echr_sst_args': SstArgs,
                'echr_sst_grads': SstGrads, 'echr_train_step_args': TrainStepArgs}
 
+ABI_VERSION = 2          # include/echr_hip.h ECHR_ABI_VERSION
 _lib = None
 
 
@@ -164,8 +168,8 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.echr_version() != 1:
-        raise EchrHipError('libechr_hip.so ABI version %d != 1' % lib.echr_version())
+    if lib.echr_version() != ABI_VERSION:
+        raise EchrHipError('libechr_hip.so ABI version %d != %d -- rebuild the library (python __graft_entry__.py build)' % (lib.echr_version(), ABI_VERSION))
     for cname, cls in ABI_STRUCTS.items():      # the ctypes restatement of every argument struct against the library's own sizeof
         if lib.echr_abi_sizeof(cname.encode()) != C.sizeof(cls):
             raise EchrHipError('%s: ctypes layout is %d bytes, libechr_hip.so says %d -- rebuild the library (python __graft_entry__.py build)'

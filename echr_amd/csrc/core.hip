@@ -787,7 +787,10 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
                                                          const unsigned* __restrict__ abort_word) {
     // a persistent recurrence launch of this iteration gave up (hand-off timeout): its gradients are garbage, so the update is skipped;
     // the host reports -ETIME at its next library call (persist_check_async)
-    if (abort_word && *abort_word) return;
+    if (abort_word && *abort_word) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(const_cast<unsigned*>(abort_word) + ABORT_SKIPPED_WORD, 1u);          // counted for echr_async_skipped_updates
+        return;
+    }
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -821,7 +824,10 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
 }
 
 __global__ void clamp_kernel(float* g, long n, float clip, const unsigned* __restrict__ abort_word) {
-    if (abort_word && *abort_word) return;
+    if (abort_word && *abort_word) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(const_cast<unsigned*>(abort_word) + ABORT_SKIPPED_WORD, 1u);
+        return;
+    }
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = clamp_keep_nan(g[i], clip);
 }
@@ -1010,6 +1016,7 @@ extern "C" int echr_prof_event_overhead(double* ms, int64_t* n) {
 }
 
 extern "C" int echr_check_async(void) { return persist_check_async(); }
+extern "C" int64_t echr_async_skipped_updates(void) { return (int64_t)persist_take_skipped_updates(); }
 
 extern "C" int echr_persist_read_stamps(uint64_t* dst, int32_t max_entries) {
     return persist_read_stamps(reinterpret_cast<unsigned long long*>(dst), max_entries);

@@ -117,6 +117,40 @@ int join_tail(hipStream_t st) {
     return 0;
 }
 
+// Data-parallel hand-over points (echr_train_step_args.handover, echr_handover_wait): events recorded where a contiguous range of the
+// gradient arena becomes final long before the backward pass ends -- the logit layer's gradients on the tail stream right behind their
+// product, the three LSTM layers' gradients on the prepare stream behind the grouped weight-gradient product.
+struct Handover { hipEvent_t ev[2] = {nullptr, nullptr}; bool valid[2] = {false, false}; bool want = false, init = false, ok = false; };
+static Handover& handover() {
+    static Handover h;
+    if (!h.init) {
+        h.init = true;
+        h.ok = hipEventCreateWithFlags(&h.ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h.ev[1], hipEventDisableTiming) == hipSuccess;
+        if (!h.ok) (void)hipGetLastError();
+    }
+    return h;
+}
+void handover_request(bool on) {
+    Handover& h = handover();
+    h.want = on && h.ok;
+    h.valid[0] = h.valid[1] = false;
+}
+void handover_close() { handover().want = false; }
+static int handover_mark(int which, hipStream_t on) {
+    Handover& h = handover();
+    if (!h.want) return 0;
+    if (hipEventRecord(h.ev[which], on) != hipSuccess) { set_error("decoder_bwd: hand-over event record failed"); return -5; }
+    h.valid[which] = true;
+    return 0;
+}
+extern "C" int echr_handover_wait(int which, void* stream) {
+    ECHR_REQUIRE(which == ECHR_HANDOVER_LOGIT || which == ECHR_HANDOVER_LSTM, "handover_wait: which must be 0 (logit layer) or 1 (LSTM layers)");
+    Handover& h = handover();
+    if (!h.ok || !h.valid[which]) return 1;
+    if (hipStreamWaitEvent((hipStream_t)stream, h.ev[which], 0) != hipSuccess) { (void)hipGetLastError(); set_error("handover_wait: stream wait failed"); return -5; }
+    return 0;
+}
+
 static bool overlap_enabled() {
     // measured neutral on the c3 workload (the recurrent GEMM's two 67 KB-LDS workgroups per CU leave no room for a
     // co-resident throughput GEMM, so the overlap only trades places): opt-in (ECHR_OVERLAP=1 / echr_config_set)
@@ -1541,6 +1575,7 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
             if (g->g_video) RC(vec_mat(b.DGCOL[2], a->w_ih[2] + E, cin[2], g->g_video, 4 * H, a->Dv, sa2));
             if (hipEventRecord(tail().done3, sa2) != hipSuccess) { set_error("decoder_bwd: event record failed"); return -5; }
             tail().pending3 = true;
+            RC(handover_mark(ECHR_HANDOVER_LSTM, sa2));          // every gradient of core.layer0..2 is final here
             return 0;
         }
         // (no second helper stream: the rest follows on the caller's stream; d event is already there)
@@ -1604,8 +1639,12 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
             H2PackJob pj[2] = {pack_cols(b.DLG, b.ldg, V1, SNc, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SNc, b.PK_OUTDT)};
             pj[1].gather = act;          // (compact: the contraction runs over the active rows of OUTD)
             RC(h2_pack_multi(pj, 2, st));
-            RC(logit_grads(a, g, w, b, z, st, !z));          // z: d b_logit rides in the multi-problem column-sum launch behind att_post
-            bias_pending = z;
+            // z: d b_logit rides in the multi-problem column-sum launch behind att_post -- unless the logit layer's range is handed over to a
+            // data-parallel collective right here (then the bias sum is formed with the product, so the whole range is final)
+            const bool ho = handover().want;
+            RC(logit_grads(a, g, w, b, z, st, !z || ho));
+            bias_pending = z && !ho;
+            RC(handover_mark(ECHR_HANDOVER_LOGIT, st));
         }
     }
     // 5. part B: attention parameters (d P_all / d alpha over all timesteps, then ctx2att) and the token embedding
@@ -1652,7 +1691,9 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
         // iteration -- every k-slice of every product then sends its atomics to the table, and the 64 <bos> rows of a batch (plus frequent words)
         // serialise on the same addresses; the dense d XT buffer takes the k-slice atomics without contention and the scatter pass meets each
         // duplicate once (20 us, `tools/skip_bounds.py`)
-        const bool fused_scatter = config().embed_fused != 0;
+        // (with compacted rows the products' row i is position act[i]: the scatter through `rowmap` handles that, the fused epilogue -- indexed
+        // by the compact row -- would not, so the switch is ignored there)
+        const bool fused_scatter = config().embed_fused != 0 && !actr;
         for (int k = 0; k < 3; ++k) {
             float* out = fused_scatter ? g->g_embed : b.DXT;
             gx[k] = h2 ? desc_h2(b.PK_DG[k], b.PK_WIHT[k], out, E, SNr, E, 4 * H) : desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], out, E, SN, E, 4 * H);

@@ -52,10 +52,13 @@ bool persist_sample_eligible(const echr_dec_args* a);
 int persist_logit_image(const float* w_logit, int V1, float* img, hipStream_t st);
 int persist_sample(const echr_dec_args* a, const PersistSampleBufs& B, hipStream_t st);
 int persist_check_async();
+long long persist_take_skipped_updates();          // updates the optimiser kernels skipped under the abort the last -62 reported (cleared by the read)
 void coop_refused(const char* who, const char* why);          // one stderr line the first time a cooperative launch is refused
 // device word that is non-zero from the moment a persistent launch aborts until the host has reported it (persist_check_async):
 // kernels that would apply results (clamp_adam, clamp) skip their update while it is set; nullptr when the state is unavailable
 const unsigned* persist_abort_word();
+// word of the 256-byte abort block in which the optimiser kernels count the updates they skipped while the abort word was set
+constexpr int ABORT_SKIPPED_WORD = 16;
 unsigned* persist_host_flag();          // device view of the host-mapped flag persist_check_async reads (nullptr when unavailable)
 // the library's helper stream outside a backward pass (the one the asynchronous decoder-backward tail uses): `aux_fork` makes it continue
 // after everything queued on `from` and returns it, `aux_join` makes `to` wait for what was queued on it since
@@ -70,6 +73,8 @@ int tail_publish();
 int tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr_dropout* drop, void* stream, int part);
 int decoder_bwd_scratch_ahead(const echr_dec_args* a, const echr_dec_grads* g);
 int decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, int part);
+void handover_close();                   // stop recording; the recorded events stay valid for echr_handover_wait
+void handover_request(bool on);          // the next decoder backward records the data-parallel hand-over events (decoder.hip)
 int join_tail(hipStream_t st);          // make st wait for an asynchronous decoder-backward tail (decoder.hip); no-op when none is pending
 int persist_read_stamps(unsigned long long* dst, int max_entries);
 unsigned long long* persist_stamp_buffer(int S, hipStream_t st);      // diagnostic: [4][S <= 256][16] stamps, zeroed on st (nullptr: unavailable)

@@ -3122,6 +3122,9 @@ unsigned* persist_host_flag() {
     return h.ok ? h.flag_dev : nullptr;
 }
 
+static std::atomic<long long> g_skipped_updates{0};
+long long persist_take_skipped_updates() { return g_skipped_updates.exchange(0); }
+
 int persist_check_async() {
     // The library's helper streams, events and the abort word (phost / tail / prep / side) are process-wide and live on the device that was
     // current at the first call: a call from another device would mix foreign-device streams and memory, so it is refused.
@@ -3139,6 +3142,12 @@ int persist_check_async() {
     if (h.ok && h.flag_host[0]) {
         const u32 code = h.flag_host[0];
         h.flag_host[0] = 0;
+        // error path: let everything queued behind the aborted launch retire (the optimiser kernels among it skip and count themselves),
+        // then read the count and clear the block
+        (void)hipDeviceSynchronize();
+        u32 skipped = 0;
+        if (hipMemcpy(&skipped, h.abort_dev + ABORT_SKIPPED_WORD, sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); skipped = 0; }
+        g_skipped_updates.fetch_add(skipped);
         (void)hipMemset(h.abort_dev, 0, 256);
         // codes: attention chain 100000 * edge + timestep (edge 1 h1, 2 q, 3 context; reverse: 4 d q, 5 d h, 6 d G, 7 d ATT); plain LSTM streams
         // 1000 / 5000 / 7000 * (counter kind + 1) + timestep; 9000 + timestep: the softmax max exchange

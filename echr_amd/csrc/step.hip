@@ -249,6 +249,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
 
     // backward (train.py:313): criterion gradient in fused form
     g.zero_extra = nullptr; g.zero_extra_count = 0;
+    handover_request(false);          // (hand-over points of an earlier call are void from here on)
     if (a->defer_update && a->g_tap && a->do_step && g.async_tail == 2 && fused_nll && config().gemm_h2 && helpers_available()) {
         // Joint 'tap_cg' iteration (train.py:300-313): the proposal encoder's backward -- a 64-workgroup persistent launch that leaves three
         // quarters of the chip idle -- waits for d tap_feats alone.  The chain that leads to it (late fusion, reverse recurrence, d event,
@@ -268,7 +269,10 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
         // persistent recurrence that shares its CUs with GEMM workgroups from its first step on loses more than the gap is worth)
         return joint_finish(jp, st);
     }
-    RC(echr_decoder_bwd(&d, &g, &a->drop, stream));
+    handover_request(a->handover && !a->do_step);
+    rc = echr_decoder_bwd(&d, &g, &a->drop, stream);
+    handover_close();          // (the events stay valid for echr_handover_wait; later backward passes do not re-record them)
+    RC(rc);
     step_mark(2, st);
     echr_tsrm_grads tg = a->tsrm_g;
     tg.g_ech = ws + L.g_ech; tg.g_out = ws + L.g_event; tg.ws_bwd = ws + L.tsrm_ws_bwd; tg.zeroed = 1;

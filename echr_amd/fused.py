@@ -106,8 +106,15 @@ class FusedTrainStep(object):
         L.check(self.lib.echr_train_step_prepare(C.byref(self.a), L.stream_ptr()), 'train_step_prepare')
         self._prepared = True
 
+    def cancel_prepare(self):
+        """Abandon a prepare() whose second half will not follow (the caller's code between the two raised): the prepare stream's work is
+        ordered before the workspace can be reused and the object accepts ordinary calls again."""
+        if getattr(self, '_prepared', False):
+            self._prepared = False
+            L.check(self.lib.echr_decoder_fwd_prepare_cancel(L.stream_ptr()), 'decoder_fwd_prepare_cancel')
+
     def __call__(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step=True, forward_only=False,
-                 tap_grad=None, defer_update=False, prepared=False):
+                 tap_grad=None, defer_update=False, prepared=False, handover=False):
         """One iteration; returns the loss as a 0-d device tensor (no host sync).  `targets` / `masks`: what the reference hands its
         criterion (labels[:, 1:], masks[:, 1:]), host or device tensors.  step=False stops after the backward pass and exposes the
         gradients as `.grad` views of the arena (data-parallel reduce, inspection); the caller then steps the optimiser itself.
@@ -116,8 +123,17 @@ class FusedTrainStep(object):
         `torch.autograd.backward([tap_loss, tap_feats], [None, tap_grad])`.  `defer_update=True` (with tap_grad and step): the call returns
         once tap_grad and the loss are final in stream order; the parameter gradients and the Adam update finish on the library's helper
         streams beside the proposal encoder's backward.  The next call joins by itself; call `join()` before touching the model's parameters
-        in any other way (saving, evaluating, the autograd path).  `prepared=True`: `prepare()` ran with the same arguments."""
+        in any other way (saving, evaluating, the autograd path).  `prepared=True`: `prepare()` ran with the same arguments.
+        `handover=True` (with step=False): the backward pass records the data-parallel hand-over points (echr_handover_wait; DataParallelStep)."""
         a, lib = self.a, self.lib
+        rc = lib.echr_check_async()
+        if rc:
+            # a persistent launch of an EARLIER iteration gave up: the optimiser kernels queued behind it skipped their updates (parameters
+            # and moments untouched) while this object already counted those steps -- wind the count back, then report
+            st = self.optim._flat
+            if st is not None:
+                st['step'] = max(0, st['step'] - int(lib.echr_async_skipped_updates()))
+            L.check(rc, 'train_step (asynchronous failure of an earlier call)')
         if prepared:
             if not getattr(self, '_prepared', False) or not step or forward_only:
                 raise RuntimeError('prepared=True needs a preceding prepare() and a full training step')
@@ -131,8 +147,11 @@ class FusedTrainStep(object):
             slot, st = self._setup(tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step, forward_only,
                                    tap_grad, defer_update)
             a.prepared = 0
-        L.check(lib.echr_train_step(C.byref(a), L.stream_ptr()), 'train_step')
+        a.handover = 1 if (handover and not step and not forward_only) else 0
+        # (set BEFORE the call: if it fails half-way, helper-stream work may already be queued, and the next _setup must join it before it
+        # drops the references to this call's inputs)
         self._pending_deferred = bool(a.defer_update)
+        L.check(lib.echr_train_step(C.byref(a), L.stream_ptr()), 'train_step')
         return self._finish(slot, st, forward_only)
 
     def _set_tap(self, tap, tap_grad, defer_update, step, forward_only):
@@ -220,7 +239,9 @@ class FusedTrainStep(object):
         if c3d.shape[1] != d.D or lda.numel() != d.Dv:
             raise L.EchrHipError('feature widths do not match the model (c3d %d, lda %d)' % (c3d.shape[1], lda.numel()))
         d.c3d, d.video = c3d.data_ptr(), lda.data_ptr()
-        self._keep = (c3d, lda, host)
+        # (tgt / msk: converted copies that only the argument struct's raw pointers reference -- after prepare() the caller allocates
+        # before the second half reads them, so they must stay alive until the next _setup)
+        self._keep = (c3d, lda, host, tgt, msk)
         if tap is None:                        # prepare(): tap_feats arrive with the second half
             a.tap, a.Ht, a.g_tap, a.defer_update = None, a.tsrm.Din - d.D, None, 0
         else:
@@ -284,3 +305,69 @@ class FusedTrainStep(object):
                     p.grad = ar.grad_view(i)
             ar._zeroed = [(0, ar.total)]
         return slot[0]
+
+
+class DataParallelStep(object):
+    """One data-parallel iteration on the one-call path: the SAME host path for every world size.
+
+    rank r:  echr_train_step(step=False, handover) on its own video  ->  SUM over ranks of the flat gradient arena  ->  clip_gradient + Adam,
+    identically on every rank -- the reference's m_batch accumulation (train.py:281-283 sums the per-video gradients, :313-317 clamps the sum
+    and steps once) with the m_batch videos on R ranks: SUM without 1/R, clamp AFTER the reduce.
+
+    The exchange is staged: the backward pass inside the call hands over two contiguous arena ranges long before its last kernel -- the
+    logit layer (35 % of the gradient bytes, final ~0.1 ms behind the reverse recurrence, on the library's tail stream) and the three LSTM
+    layers (39 %, final behind the grouped weight-gradient product on its prepare stream).  For each, a side stream waits for the library's
+    hand-over event (echr_handover_wait) and the range's collective is queued from it (torch.distributed orders its collective stream
+    behind the CURRENT stream), so it runs beside the rest of the tail and the event encoder's backward; the remaining ranges (event
+    encoder + embedding, attention: 26 %) follow from the caller's stream.  Every collective starts behind the reverse recurrence and is
+    waited for before clamp + Adam, i.e. before the next iteration's forward recurrence: no collective kernel is ever resident beside a
+    persistent pair.  `overlap=False`: ONE collective on the whole arena behind the call."""
+
+    def __init__(self, fused, group=None, overlap=True, algo=None):
+        from . import parallel
+        self.P, self.fused, self.group, self.overlap, self.algo = parallel, fused, group, bool(overlap), algo
+        ar, lm = fused.arena, fused.model.lm_model
+        core = lm.core
+        lstm = [p for k in range(3) for p in getattr(core, 'layer%d' % k).parameters()]
+        self.ranges = []
+        for which, params in ((0, [lm.logit.weight, lm.logit.bias]), (1, lstm)):
+            slots = sorted(ar.slot(p) for p in params)
+            if slots == list(range(slots[0], slots[-1] + 1)):          # one contiguous arena range (it is, for the reference's module order)
+                self.ranges.append((which,) + tuple(ar.span(slots)))
+        self.side = [torch.cuda.Stream(device=fused.dev) for _ in self.ranges] if self.overlap else []
+        self.n_collectives = 0
+        self.n_early = 0
+
+    def __call__(self, *args, **kw):
+        P, f, ar = self.P, self.fused, self.fused.arena
+        import torch.distributed as dist
+        active = dist.is_available() and dist.is_initialized()
+        loss = f(*args, step=False, handover=self.overlap and active, **kw)
+        n = 0
+        if active:
+            pend = []
+            if self.overlap:
+                for (which, lo, hi), s in zip(self.ranges, self.side):
+                    with torch.cuda.stream(s):
+                        rc = f.lib.echr_handover_wait(which, L.stream_ptr())
+                        if rc < 0:
+                            L.check(rc, 'handover_wait')
+                        if rc == 0:          # (1: this configuration recorded no hand-over point -- the range joins the remainder below)
+                            pend.append((lo, hi, P.reduce_sum_(ar.flat_g[lo:hi], self.group, self.algo, async_op=True)))
+            self.n_early = len(pend)
+            pos = 0
+            for lo, hi, _ in sorted(pend, key=lambda t: t[0]) + [(ar.total, ar.total, None)]:
+                if lo > pos:
+                    P.reduce_sum_(ar.flat_g[pos:lo], self.group, self.algo)
+                    n += 1
+                pos = max(pos, hi)
+            for _, _, w in pend:
+                w.wait()          # the caller's stream continues behind the early collectives
+            n += len(pend)
+        self.n_collectives = n
+        o = f.optim
+        if f.grad_clip is not None:
+            from .misc.utils import clip_gradient
+            clip_gradient(o, f.grad_clip)          # (recorded; the clamp itself is fused into the step kernel)
+        o.step()
+        return loss

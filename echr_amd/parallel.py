@@ -26,26 +26,45 @@ def choose_algo(world, algo=None):
     return algo
 
 
+class _Works(object):
+    """The work handles of one logical SUM (all-reduce: one; reduce-scatter + all-gather: two, plus the shard they exchange through)."""
+
+    def __init__(self, works, keep=None, then=None, algo='allreduce'):
+        self.works, self.keep, self.then, self.algo = [w for w in works if w is not None], keep, then, algo
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        if self.then is not None:          # (a second collective that could not be queued behind the first asynchronously: see reduce_sum_)
+            self.then()
+        self.keep = self.then = None
+
+
 def reduce_sum_(flat, group=None, algo=None, async_op=False):
     """SUM over ranks of a flat fp32 buffer, in place.
 
-    algo None: choose_algo (ECHR_DP_ALGO, default by world size).
+    algo None: choose_algo (ECHR_DP_ALGO, default by world size: 'allreduce' for 2 ranks, 'rs_ag' from 4).
     algo 'allreduce': one dist.all_reduce -- RCCL picks ring / tree / direct itself.
     algo 'rs_ag' (or ECHR_DP_ALGO=rs_ag): reduce-scatter + all-gather on the same buffer (on a fully connected
     xGMI node each GPU then exchanges 1/R of the buffer with each of its R-1 peers over R-1 distinct links, instead of pushing the
-    whole buffer around a ring whose every hop is bound by ONE link).  Needs numel % R == 0 (the arena is 64-float aligned, so R = 2,
-    4, 8 always qualify); otherwise it falls back to all_reduce.  Returns a work handle when async_op (rs_ag is synchronous)."""
+    whole buffer around a ring whose every hop is bound by ONE link).  Needs numel % R == 0 (the arena and every range of it that the
+    early reducers hand over are 64-float aligned, so R = 2, 4, 8 always qualify); otherwise it falls back to all_reduce.
+    async_op: returns an object with .wait() (both collectives of rs_ag are queued asynchronously, in order, on the collective stream);
+    otherwise None."""
     world = dist.get_world_size(group)
     algo = choose_algo(world, algo)
     if algo == 'rs_ag' and world > 1 and flat.numel() % world == 0 and flat.is_contiguous():
-        rank = dist.get_rank(group)
         n = flat.numel() // world
         shard = torch.empty(n, device=flat.device, dtype=flat.dtype)
-        dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
-        dist.all_gather_into_tensor(flat, shard, group=group)
-        del rank
-        return None
-    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        w1 = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op and dist.get_backend(group) != 'nccl':
+            # only RCCL orders two asynchronous collectives (its stream does); gloo runs them on worker threads, where the all-gather
+            # could read the shard before the reduce-scatter has written it -> the all-gather follows at wait()
+            return _Works([w1], shard, lambda: dist.all_gather_into_tensor(flat, shard, group=group), 'rs_ag')
+        w2 = dist.all_gather_into_tensor(flat, shard, group=group, async_op=async_op)
+        return _Works([w1, w2], shard, None, 'rs_ag') if async_op else None
+    w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return _Works([w]) if async_op else None
 
 
 def live_grads(module):
@@ -120,7 +139,7 @@ class EarlyReducer(object):
         lo, hi = ar.span(slots)
         if any(lo < phi and plo < hi for plo, phi, _ in self.pending):
             return                      # overlaps a range already in flight (second backward in one step): final collective
-        work = dist.all_reduce(ar.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        work = reduce_sum_(ar.flat_g[lo:hi], self.group, None, async_op=True)          # choose_algo: rs_ag from 4 ranks (ranges are 64-float aligned)
         self.pending.append((lo, hi, work))
         self.early_ids.update(id(p) for p in params)
 
@@ -167,7 +186,7 @@ def enable_overlap(module, group=None, auto_arm=True, defer_first=None, staged=N
 
 def allreduce_gradients(module, group=None, bucket_bytes=64 << 20, force=False, algo=None):
     """Sum the gradients over ranks in a few large flat buckets (xGMI is point-to-point: few large messages).
-    algo: None (ECHR_DP_ALGO, default 'allreduce') | 'allreduce' | 'rs_ag' -- see reduce_sum_."""
+    algo: None (choose_algo: ECHR_DP_ALGO, else 'allreduce' for 2 ranks and 'rs_ag' from 4) | 'allreduce' | 'rs_ag' -- see reduce_sum_."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return 0
     arena = getattr(module, '_echr_arena', None)

@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define ECHR_ABI_VERSION 1
+/* 2 (round 5): echr_train_step_args.handover, echr_handover_wait, echr_async_skipped_updates; round 4 had grown the decoder's
+ * argument struct (train, zero_extra, zero_extra_count) and its gradient struct (dlg_ready, active_rows, n_active) under version 1.  A binding that restates
+ * the structs MUST also compare its sizeof() of each with echr_abi_sizeof(): the version alone does not describe the layouts. */
+#define ECHR_ABI_VERSION 2
 
 int echr_version(void);
 /* sizeof() of an argument struct of this header by its type name ("echr_dec_args", ...), -1 for an unknown name: lets a binding that
@@ -37,6 +40,9 @@ const char* echr_last_error(void);
  * invalid gradients) and the NEXT library call that takes a stream returns -ETIME (-62) once, naming the edge and timestep.
  * echr_check_async() is that check on its own, for callers that want it right after a synchronisation point: 0 or -62. */
 int echr_check_async(void);
+/* Number of echr_clamp_adam / echr_clamp launches that skipped their update because of the asynchronous failure the last -62 reported
+ * (read once: the count is cleared).  A caller that keeps its own optimiser step count winds it back by this many steps. */
+int64_t echr_async_skipped_updates(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense fp32 projection on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
@@ -442,6 +448,12 @@ typedef struct {
                                       streams beside whatever the caller queues next (the proposal encoder's backward, train.py:313).  The
                                       caller MUST call echr_stream_join(stream) before reading parameters or gradients or freeing ws;
                                       the next echr_train_step joins by itself */
+    int32_t handover;              /* 1 (with do_step = 0): data-parallel hand-over points.  The backward pass records an event where the
+                                      logit layer's gradients (g_w_logit, g_b_logit) become final and one where the three LSTM layers'
+                                      gradients (g_w_ih / g_w_hh / g_b_ih / g_b_hh) do -- both long before the call's last kernel -- so the
+                                      caller can start the collectives on those ranges of flat_g while the rest of the backward tail runs:
+                                      echr_handover_wait(which, s) makes stream s wait for the point (train.py:281-283,313-317: the reference
+                                      sums m_batch gradients before one clamp + step; the data-parallel form sums over ranks) */
 } echr_train_step_args;
 int64_t echr_train_step_ws_floats(const echr_train_step_args* a);
 int echr_train_step(const echr_train_step_args* a, void* stream);
@@ -450,6 +462,11 @@ int echr_train_step(const echr_train_step_args* a, void* stream);
  * beside the proposal encoder's forward the caller queues next.  Takes the arguments of the following echr_train_step (tap, g_tap, loss
  * slots may still be unset), which must then pass prepared = 1 and the same workspace.  Needs overlap_encoder = 1. */
 int echr_train_step_prepare(const echr_train_step_args* a, void* stream);
+/* Hand-over points of the LAST echr_train_step issued with handover = 1 (which: 0 = logit layer, 1 = LSTM layers): makes `stream` wait
+ * until that range of flat_g is final.  0 = `stream` now waits; 1 = the call recorded no such point (a configuration without the
+ * asynchronous tail: the range is final when the call's own stream reaches its end, like every other); < 0 error. */
+enum { ECHR_HANDOVER_LOGIT = 0, ECHR_HANDOVER_LSTM = 1 };
+int echr_handover_wait(int which, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optional per-kernel-class timing (HIP events recorded on the launch stream around every launch of the

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     rank, world, port, out, overlap = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5] == '1'
+    fused_mode = sys.argv[5] in ('fused', 'fused1')          # the one-call path: echr_train_step + hand-over collectives ('fused1': ONE collective)
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', port
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import echr_amd
@@ -36,12 +37,24 @@ def main():
         parallel.enable_overlap(model)
     optim = ClampAdam(model.parameters(), lr=1e-3, arena=arena)
     crit = LanguageModelCriterion()
+    if fused_mode:
+        from echr_amd.fused import DataParallelStep, FusedTrainStep
+        dp = DataParallelStep(FusedTrainStep(model, optim, grad_clip=0.05), overlap=sys.argv[5] == 'fused')
+    n_early = -1
     for step in range(2):
         vid = synth.make_video(2, 16, 11, opt.CG_vocab_size + 1, seed=500 + 10 * step + rank, T_v=40, video_dim=opt.video_dim,
                                hidden_dim=opt.hidden_dim, lda_dim=opt.video_context_dim)
         tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
         labels = torch.from_numpy(vid['labels'])
         model.set_dropout_state(U.SEED, U.OFFSET + 10 * step + rank)
+        if fused_mode:
+            # host-side criterion inputs, as bench.py hands them over (active-row compaction inside the call)
+            dp(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:].numpy(), vid['masks'][:, 1:])
+            n, n_early = dp.n_collectives, dp.n_early
+            if step == 0:
+                torch.cuda.synchronize()          # (clamp + Adam read the gradient arena, they do not write it)
+                grads = {'grad|' + k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+            continue
         optim.zero_grad()
         loss = crit(model(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), labels[:, 1:].to(dev),
                     torch.from_numpy(vid['masks'])[:, 1:].to(dev))
@@ -53,7 +66,7 @@ def main():
         clip_gradient(optim, 0.05)
         optim.step()
     torch.cuda.synchronize()
-    np.savez(out, n_collectives=n, **grads, **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    np.savez(out, n_collectives=n, n_early=n_early, **grads, **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
     dist.destroy_process_group()
 
 

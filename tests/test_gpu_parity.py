@@ -25,7 +25,7 @@ TOL_GRAD = 1e-5     # relative to the tensor's max-norm
 def test_library_loaded_on_gpu():
     from echr_amd import _lib
     lib = _lib.load()
-    assert lib.echr_version() == 1
+    assert lib.echr_version() == 2
 
 
 @pytest.mark.parametrize('M,N,K,trans_b', [(64, 64, 32, True), (130, 70, 100, True), (1280, 513, 1536, True),
@@ -1829,7 +1829,7 @@ def test_eval_flow_sst_to_captions_vs_oracle(nms):
         assert rec['sentence'] == [int(t) for t in seq_o[i].numpy() if t > 0]
 
 
-@pytest.mark.parametrize('overlap', [False, True, 'staged'])
+@pytest.mark.parametrize('overlap', [False, True, 'staged', 'fused', 'fused_coop', 'fused1'])
 def test_two_rank_data_parallel_on_one_gpu(tmp_path, overlap):
     """Two data-parallel ranks (separate processes, gloo transport, both on cuda:0) run two optimiser steps on different videos:
     both ranks must end with IDENTICAL parameters, equal to one process that accumulates the two videos' gradients before each
@@ -1846,13 +1846,19 @@ def test_two_rank_data_parallel_on_one_gpu(tmp_path, overlap):
     # real data-parallel runs use) -- two plain 256-workgroup persistent grids must never share a device
     # 'staged': the three-stage decoder backward (ECHR_DP_STAGED=1: logit- and LSTM-layer ranges early); True: the one-call backward with the
     # LSTM-layer range reduced early (the default form)
-    env = dict(os.environ, ECHR_DP_WORKER_COOP='1' if overlap is True else '0', ECHR_DP_STAGED='1' if overlap == 'staged' else '0')
-    procs = [subprocess.Popen([_sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), str(r), '2', port, outs[r], '1' if overlap else '0'],
+    # 'fused' / 'fused_coop': the ONE host path of bench.py for every world size -- echr_train_step(step=False, handover) per rank, the logit- and
+    # LSTM-layer ranges handed to the collective stream from the library's hand-over events while the backward tail still runs, then the
+    # remainder, clip + step (fused.DataParallelStep); launch-per-phase recurrences / cooperative persistent ones.  'fused1': one collective
+    mode = {False: '0', True: '1', 'staged': '1', 'fused': 'fused', 'fused_coop': 'fused', 'fused1': 'fused1'}[overlap]
+    env = dict(os.environ, ECHR_DP_WORKER_COOP='1' if overlap in (True, 'fused_coop') else '0', ECHR_DP_STAGED='1' if overlap == 'staged' else '0')
+    procs = [subprocess.Popen([_sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), str(r), '2', port, outs[r], mode],
                               cwd=root, env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     r0, r1 = np.load(outs[0]), np.load(outs[1])
-    assert int(r0['n_collectives']) == {False: 1, True: 3, 'staged': 4}[overlap]
+    assert int(r0['n_collectives']) == {False: 1, True: 3, 'staged': 4, 'fused': 4, 'fused_coop': 4, 'fused1': 1}[overlap]
+    if overlap in ('fused', 'fused_coop'):
+        assert int(r0['n_early']) == 2          # both hand-over points were recorded and used
     for k in synth.state_dict_shapes(synth.make_case('c1')[0]):
         assert np.array_equal(r0[k], r1[k]), k                               # replicas stay bitwise identical after two steps
     # one process accumulating the two videos' gradients of step 0 (same initial parameters)
@@ -1876,9 +1882,10 @@ def test_two_rank_data_parallel_on_one_gpu(tmp_path, overlap):
             assert U.grad_close(k, r0['grad|' + k], p.grad.detach().cpu().numpy(), 1e-5), k     # SUM over ranks == accumulation, no 1/R
 
 
-@pytest.mark.parametrize('fused', ['auto', 'on'])
+@pytest.mark.parametrize('fused', ['auto', 'off'])
 def test_bench_two_rank_rehearsal_on_one_gpu(fused):
-    """(fused = 'on': every rank's iteration as one echr_train_step call up to the backward pass, then ONE collective, clip + step.)
+    """(fused = 'auto': every rank's iteration as one echr_train_step call up to the backward pass with the early range collectives started
+    from its hand-over events, then clip + step -- the same host path as the single-rank line; 'off': the autograd path + EarlyReducer.)
     The WHOLE multi-rank bench path on the one-GPU box: `python bench.py --gpus 2` launches its own two ranks (gloo transport, both on
     cuda:0, launch-per-phase recurrences), runs warm-up + timed steps with the staged early reducer, takes the MAX over ranks and prints
     ONE JSON line whose value is the whole-job rate."""
@@ -1894,7 +1901,8 @@ def test_bench_two_rank_rehearsal_on_one_gpu(fused):
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out['config']['host_path'].startswith('echr_train_step' if fused == 'on' else 'autograd')
+    assert out['config']['host_path'].startswith('echr_train_step + early range collectives' if fused == 'auto' else 'autograd')
+    assert out['config']['dp_overlap'] is True
     assert out['config']['dp_algo'] == 'allreduce' and out['config']['persist_coop'] == 1      # two ranks: one link; a shared device: cooperative launches
     assert out['n_gpus'] == 2 and out['steps'] == 4 and out['scaling'] == 'weak' and out['config']['global_events'] == 128
     assert out['value'] > 0 and abs(out['value'] - 4 * 20 * 2 / (out['ms_per_step'] * 4 / 1e3)) < 0.01 * out['value']

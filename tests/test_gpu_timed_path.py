@@ -1,0 +1,201 @@
+"""The path bench.py TIMES, at the configurations it is timed at, held directly to the reference's fixtures and to the oracle (-m gpu).
+
+bench.py's headline iteration is `FusedTrainStep` (echr_train_step: host-side targets / masks -> active-row compaction, fused criterion,
+three-stream backward tail, clamp + Adam inside the call) on the `c3bench` layout; its other lines are the forward-only form of the same
+entry (BASELINE config 2) and the joint 'tap_cg' form (`prepare` + `tap_grad` + `defer_update`, BASELINE config 5).  The tests of
+tests/test_gpu_parity.py pin the autograd path at those sizes and the one-call path on small shapes; these pin the one-call path itself:
+  reference protocol: train.py:281-317 (zero_grad, forward, criterion, backward, clip_gradient, Adam), misc/utils.py:66-75, :107-111.
+"""
+import numpy as np
+import pytest
+import torch
+
+from echr_amd import synth
+from oracle import summary as SM
+from tests import util as U
+from tests.test_gpu_parity import TOL_GRAD, TOL_LOSS
+
+pytestmark = pytest.mark.gpu
+
+
+def _fused(opt, params, train_mode=True, lr=None, clip=None):
+    from echr_amd.fused import FusedTrainStep
+    from echr_amd.optim import ClampAdam
+    m = U.build_gpu_model(opt, params, train_mode)
+    o = ClampAdam(m.parameters(), lr=opt.lr if lr is None else lr, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon,
+                  arena=m.build_arena())
+    return m, o, FusedTrainStep(m, o, grad_clip=clip)
+
+
+def _device_inputs(vid):
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels = torch.from_numpy(vid['labels'])
+    # exactly what bench.py hands the call (bench.py: tgt_h, msk_h): numpy views of labels[:, 1:] / masks[:, 1:] on the HOST
+    return tap, c3d, lda, labels, labels[:, 1:].numpy(), vid['masks'][:, 1:]
+
+
+def _check_grad_summaries(g, mode, grads, tag='|grad|'):
+    for key, v in SM.summarize_grads(grads).items():
+        ref = g[mode + tag + key]
+        name = key.split('|')[0]
+        if name in U.NOISE_ONLY:
+            assert np.abs(np.asarray(v)).max() < 1e-6 and np.abs(np.asarray(ref)).max() < 1e-6, (key, v, ref)
+            continue
+        scale = max(float(g[mode + tag + name + '|linf']), U.GRAD_FLOOR)
+        if key.endswith('|l2') or key.endswith('|linf'):
+            assert abs(float(v) - float(ref)) < TOL_GRAD * max(abs(float(ref)), U.GRAD_FLOOR), (key, float(v), float(ref))
+        else:
+            assert np.abs(v - ref).max() < TOL_GRAD * scale, (key, np.abs(v - ref).max() / scale)
+
+
+@pytest.mark.parametrize('case', ['c3bench', 'c2full', 'c2'])
+def test_timed_path_loss_and_gradients_vs_reference_fixture_and_oracle(case):
+    """(a) echr_train_step with step=False at the timed layout: the loss and the gradient summaries against the REFERENCE's own outputs
+    (case_<name>.npz, train mode with the injected dropout masks), then every gradient element against the oracle."""
+    opt, params, vid = synth.make_case(case)
+    g = U.gold('case_%s.npz' % case)
+    m, o, f = _fused(opt, params)
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False))
+    torch.cuda.synchronize()
+    assert 0 < f.last_active_rows < tgt_h.size                    # the compacted (active-row) form ran, as in the timed region
+    assert abs(loss - float(g['train|loss'])) < TOL_LOSS * abs(float(g['train|loss'])), (loss, float(g['train|loss']))
+    grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else None) for k, p in m.named_parameters()}
+    _check_grad_summaries(g, 'train', grads)
+    _, rloss, rgrads = U.run_oracle(opt, params, vid, True)
+    assert abs(loss - rloss) < TOL_LOSS * abs(rloss)
+    for k, rg in rgrads.items():
+        if rg is None:
+            assert grads[k] is None, k
+        else:
+            assert U.grad_close(k, grads[k], rg, TOL_GRAD), (k, U.relerr(grads[k], rg))
+
+
+@pytest.mark.parametrize('case', ['c3bench', 'c2full'])
+def test_timed_path_one_optimizer_step_vs_oracle(case):
+    """(b) ONE full iteration exactly as bench.py issues it (step=True: clamp + Adam inside the call, grad_clip and lr of the recipe):
+    parameters and Adam moments against the oracle's clamp_adam_step applied to the ORACLE's gradients (misc/utils.py:107-111 +
+    torch.optim.Adam, train.py:315-317)."""
+    from oracle import echr_ref_cpu as O
+    opt, params, vid = synth.make_case(case)
+    m, o, f = _fused(opt, params, clip=opt.grad_clip)
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h))
+    torch.cuda.synchronize()
+    _, rloss, rgrads = U.run_oracle(opt, params, vid, True)
+    assert abs(loss - rloss) < TOL_LOSS * abs(rloss)
+    assert o._flat['step'] == 1
+    ar = m._echr_arena
+    lr = opt.lr
+    for i, (k, p) in enumerate(m.named_parameters()):
+        assert ar.params[i] is p
+        lo, n = ar.offsets[i], p.numel()
+        mom = o._flat['m'][lo:lo + n].view(p.shape).cpu().numpy()
+        var = o._flat['v'][lo:lo + n].view(p.shape).cpu().numpy()
+        new = p.detach().cpu().numpy()
+        if rgrads[k] is None:             # never-used parameters: untouched, like torch.optim.Adam skipping grad None
+            assert np.array_equal(new, params[k]) and not mom.any() and not var.any(), k
+            continue
+        rp, rm, rv = (torch.from_numpy(x.copy()) for x in (params[k], np.zeros_like(params[k]), np.zeros_like(params[k])))
+        O.clamp_adam_step(rp, torch.from_numpy(rgrads[k]), rm, rv, 1, lr, opt.optim_alpha, opt.optim_beta, opt.optim_epsilon, opt.grad_clip)
+        if k in U.NOISE_ONLY:             # the true gradient is exactly zero: the update is a coin flip of +-lr on both sides
+            assert np.abs(new - params[k]).max() <= 1.01 * lr
+            continue
+        assert U.grad_close(k, mom, rm.numpy(), TOL_GRAD), (k, 'exp_avg', U.relerr(mom, rm.numpy()))
+        gmax = float(np.abs(rgrads[k]).max())
+        assert np.abs(var - rv.numpy()).max() <= 2.5 * TOL_GRAD * max(float(rv.max()), 1e-3 * U.GRAD_FLOOR ** 2) + 1e-20, (k, 'exp_avg_sq')
+        dgpu, dref = new - params[k], rp.numpy() - params[k]
+        assert np.abs(dgpu).max() <= 1.01 * lr and np.abs(dgpu - dref).max() <= 2.01 * lr, k
+        # Adam's first update is lr * g / (|g| + eps): where |g| is resolvable against the noise of its tensor the two sides agree closely
+        solid = np.abs(rgrads[k]) > 1e-4 * gmax
+        if solid.any():
+            assert np.abs(dgpu - dref)[solid].max() < 0.02 * lr, (k, np.abs(dgpu - dref)[solid].max() / lr)
+
+
+@pytest.mark.parametrize('case', ['c3bench', 'c2full'])
+@pytest.mark.parametrize('train_mode', [True, False])
+def test_timed_path_forward_only_loss_vs_reference_fixture(case, train_mode):
+    """(c) bench.py --mode fwd (BASELINE config 2): forward + criterion through the same one-call entry, against the reference's loss
+    (train mode: the injected dropout masks; eval mode: dropout off)."""
+    opt, params, vid = synth.make_case(case)
+    g = U.gold('case_%s.npz' % case)
+    m, o, f = _fused(opt, params, train_mode)
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, forward_only=True))
+    ref = float(g[('train' if train_mode else 'eval') + '|loss'])
+    assert abs(loss - ref) < TOL_LOSS * abs(ref), (loss, ref)
+    assert o._flat is None or o._flat['step'] == 0
+    assert all(p.grad is None for p in m.parameters())
+
+
+@pytest.mark.parametrize('train_mode', [True, False])
+def test_timed_joint_iteration_vs_reference_fixture(train_mode):
+    """(d) bench.py --c5 (BASELINE config 5, train.py:300-313): `prepare()` before the proposal encoder's forward, the caption side as one
+    call with `tap_grad` + `defer_update` + `prepared`, then `autograd.backward([tap_loss, tap_feats], [None, tap_grad])` into the SST --
+    both losses, the caption model's gradients and the SST's gradients against the reference's own (case_c5.npz).  The call steps the
+    optimiser; with no clip and the gradients read back from the arena behind the join, the update does not disturb what is compared."""
+    from echr_amd import models as EM
+    from echr_amd.misc.utils import TAPModelCriterion
+    opt, params, sst_params, vid = synth.make_c5()
+    g = U.gold('case_c5.npz')
+    mode = 'train' if train_mode else 'eval'
+    m, o, f = _fused(opt, params, train_mode, lr=1e-9)
+    dev = torch.device('cuda')
+    tapm = EM.setup_tap(opt)
+    tapm.load_state_dict({k: torch.from_numpy(v) for k, v in sst_params.items()})
+    tapm = tapm.to(dev)
+    tapm.eval()                                          # the fixture's SST runs without inter-layer dropout
+    _, c3d, lda, labels, tgt_h, msk_h = _device_inputs(dict(vid, tap=np.zeros((1, 1), np.float32)))
+    tl, tm, tw = (torch.from_numpy(vid[k]) for k in ('tap_labels', 'tap_masks', 'w1'))
+    f.prepare(c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h)
+    tap_feats, props = tapm(c3d)
+    g_tap = torch.zeros_like(tap_feats)
+    tap_loss = TAPModelCriterion()(props, tm, tl, tw)
+    cg_loss = f(tap_feats.detach(), c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, tap_grad=g_tap, defer_update=True, prepared=True)
+    assert opt.lambda2 == 1.0                            # (the call backpropagates 1 * cg_loss; the fixture's joint loss is lambda1 * tap + lambda2 * cg)
+    torch.autograd.backward([opt.lambda1 * tap_loss, tap_feats], [None, g_tap])
+    f.join()
+    torch.cuda.synchronize()
+    assert abs(float(tap_loss) - float(g[mode + '|tap_loss'])) < TOL_LOSS * abs(float(g[mode + '|tap_loss']))
+    assert abs(float(cg_loss) - float(g[mode + '|cg_loss'])) < TOL_LOSS * abs(float(g[mode + '|cg_loss'])), (float(cg_loss), float(g[mode + '|cg_loss']))
+    assert np.abs(tap_feats.detach().cpu().numpy()[::8, ::16] - g['tap_feats|slice']).max() < 1e-5
+    ar = m._echr_arena
+    unused = {'lm_model.core.fusion_layer.weight', 'lm_model.core.fusion_layer.bias', 'fusion_model.h2a_layer.weight', 'fusion_model.h2a_layer.bias'}
+    grads = {}
+    for i, (k, p) in enumerate(m.named_parameters()):
+        gv = ar.grad_view(i).detach().cpu().numpy()
+        if k in unused:
+            assert not gv.any(), k
+            grads[k] = None
+        else:
+            grads[k] = gv
+    _check_grad_summaries(g, mode, grads)
+    _check_grad_summaries(g, mode, {k: p.grad.detach().cpu().numpy() for k, p in tapm.named_parameters()}, tag='|sstgrad|')
+
+
+def test_prepare_keeps_device_criterion_inputs_alive():
+    """`prepare()` with DEVICE targets / masks: the converted (contiguous) copies are only referenced by raw pointers in the argument
+    struct; allocations the caller makes between `prepare()` and the `prepared=True` call must not be able to recycle them."""
+    opt, params, vid = synth.make_case('c2')
+    dev = torch.device('cuda')
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    tgt_d, msk_d = torch.from_numpy(np.ascontiguousarray(tgt_h)).to(dev), torch.from_numpy(np.ascontiguousarray(msk_h)).to(dev)
+
+    def run(device_inputs):
+        m, o, f = _fused(opt, params, lr=1e-9)
+        a = (tgt_d, msk_d) if device_inputs else (tgt_h, msk_h)
+        f.prepare(c3d, lda, labels, vid['ind'], vid['soi'], *a)
+        junk = [torch.full((tgt_d.numel(),), 7, device=dev, dtype=tgt_d.dtype) for _ in range(8)]        # same sizes as the temporaries
+        junk += [torch.full((msk_d.numel(),), 3.0, device=dev) for _ in range(8)]
+        g_tap = torch.zeros_like(tap)
+        loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], *a, tap_grad=g_tap, prepared=True))
+        f.join()
+        torch.cuda.synchronize()
+        del junk
+        return loss, m._echr_arena.flat_g.clone()
+
+    lh, gh = run(False)
+    ld, gd = run(True)
+    assert abs(lh - ld) < 2e-6 * abs(lh), (lh, ld)
+    assert float((gh - gd).abs().max()) <= 2e-5 * float(gh.abs().max())

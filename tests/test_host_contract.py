@@ -62,7 +62,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.echr_version() == 1
+    assert lib.echr_version() == 2
 
 
 def test_philox_known_answer_and_mask_rate():

@@ -57,11 +57,13 @@ def test_allreduce_is_sum_over_ranks_and_skips_unused_params():
         assert np.allclose(a + b, s0, atol=1e-6) and np.allclose(s0, s1)     # SUM, no averaging; identical on every rank
 
 
-def _worker_early(rank, world, port, q):
-    """Arena path with the early (overlapped) collective: hook on the middle layer, then the remainder at the end."""
+def _worker_early(rank, world, port, q, algo='auto'):
+    """Arena path with the early (overlapped) collective: hook on the middle layer, then the remainder at the end.
+    algo 'rs_ag': the early ranges (64-float aligned arena slots) go through reduce-scatter + all-gather, as choose_algo picks from 4 ranks on."""
     from echr_amd.arena import ParamArena
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    os.environ['ECHR_DP_ALGO'] = algo
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 3))
@@ -82,17 +84,19 @@ def _worker_early(rank, world, port, q):
     red.hook([net[0].weight])                      # a second early range, adjacent to nothing in flight
     red.hook([net[1].bias])                        # overlaps a range in flight: must be ignored
     assert len(red.pending) == 2
+    assert all(w.algo == ('rs_ag' if algo == 'rs_ag' else 'allreduce') for _, _, w in red.pending)          # rs_ag: reduce-scatter + all-gather per range
     n = parallel.allreduce_gradients(net)
     q.put((rank, n, [g.numpy() for g in local], [p.grad.numpy().copy() for p in parallel.live_grads(net)], arena.flat_g.numpy().copy()))
     dist.destroy_process_group()
 
 
-def test_early_reducer_equals_single_allreduce():
+@pytest.mark.parametrize('algo', ['auto', 'rs_ag'])
+def test_early_reducer_equals_single_allreduce(algo):
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker_early, args=(r, world, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker_early, args=(r, world, port, q, algo)) for r in range(world)]
     for p in ps:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
