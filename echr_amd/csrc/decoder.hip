@@ -93,9 +93,15 @@ static Tail& tail() {
     }
     return t;
 }
+// Several forks from one point of the caller's stream can share ONE recorded event (each hipEventRecord is a barrier packet the caller's
+// next kernel queues behind: three of them in front of the event encoder's first kernel cost ~10 us).  fork_event(ev): the forks that
+// follow wait for `ev` (already recorded on the caller's stream, nothing queued since) instead of recording their own; fork_event(nullptr) ends it.
+static hipEvent_t& fork_event_slot() { static hipEvent_t e = nullptr; return e; }
+void fork_event(hipEvent_t ev) { fork_event_slot() = ev; }
 hipStream_t aux_fork(hipStream_t from) {
     Tail& t = tail();
     if (!t.ok) return nullptr;
+    if (hipEvent_t fe = fork_event_slot()) return hipStreamWaitEvent(t.s, fe, 0) == hipSuccess ? t.s : nullptr;
     if (hipEventRecord(t.fork2, from) != hipSuccess || hipStreamWaitEvent(t.s, t.fork2, 0) != hipSuccess) return nullptr;
     return t.s;
 }
@@ -1046,7 +1052,7 @@ extern "C" int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a) { return a
 extern "C" int echr_stream_join(void* stream) { return join_tail((hipStream_t)stream); }
 
 // ---- event-independent part of the decoder forward, ahead of (and concurrent with) the event encoder ----
-struct Prep { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr, fill_done = nullptr; bool ok = false, init = false, pending = false, fill_pending = false; const void* ws = nullptr; };
+struct Prep { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr, fill_done = nullptr, fill0 = nullptr; bool ok = false, init = false, pending = false, fill_pending = false; const void* ws = nullptr; };
 static Prep& prep() {
     static Prep t;
     if (!t.init) {
@@ -1055,6 +1061,7 @@ static Prep& prep() {
         good = good && hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
         good = good && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
         good = good && hipEventCreateWithFlags(&t.fill_done, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.fill0, hipEventDisableTiming) == hipSuccess;
         t.ok = good;
     }
     return t;
@@ -1072,6 +1079,15 @@ hipStream_t aux2_fork(hipStream_t from) {
 int aux2_join(hipStream_t to) {
     Prep& pr = prep();
     if (hipEventRecord(pr.done, pr.s) != hipSuccess || hipStreamWaitEvent(to, pr.done, 0) != hipSuccess) { set_error("stream join failed"); return -5; }
+    return 0;
+}
+// what the prepare stream carries now (work forked onto it by aux2_fork) is part of what echr_stream_join / the next library call waits for
+int aux2_publish() {
+    Prep& pr = prep();
+    Tail& t = tail();
+    if (!pr.ok || !t.ok) { set_error("aux2_publish: helper streams unavailable"); return -5; }
+    if (hipEventRecord(t.done3, pr.s) != hipSuccess) { set_error("aux2_publish: event record failed"); return -5; }
+    t.pending3 = true;
     return 0;
 }
 // echr_train_step's joint mode (step.hip): the helper streams keep working after the call returns
@@ -1155,7 +1171,9 @@ extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
     scratch_ahead() = nullptr;          // (a train step whose backward never ran)
     RC(echr_decoder_fwd_prepare_cancel(stream));          // an earlier prepare nobody consumed: order its workspace before anything new
     RC(join_tail(sm));
-    RC(hop(sm, pr.fork, st));
+    if (hipEvent_t fe = fork_event_slot()) {
+        if (hipStreamWaitEvent(st, fe, 0) != hipSuccess) { set_error("decoder_fwd_prepare: stream fork failed"); return -5; }
+    } else RC(hop(sm, pr.fork, st));
     DecWs w = carve_ws(a, a->ws);
     // the caller's gradient arena (echr_train_step: 87 MB) is zero-filled LAST on this stream, behind the event this call publishes: nothing of
     // the forward pass waits for it -- a fill has no LDS and a handful of registers, so it also fits beside the recurrence's workgroups -- and
@@ -1163,6 +1181,9 @@ extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
     static const bool late_fill = [] { const char* e = getenv("ECHR_ARENA_FILL_LATE"); return !(e && e[0] == '0'); }();
     const bool late = late_fill && a->zero_extra && a->zero_extra_count > 0;
     RC(decoder_fill(a, w, st, !late));
+    // (the event-context gate product of echr_decoder_fwd accumulates into EVB0, zeroed by this fill: it waits for THIS event, not for the
+    // whole chain below -- the product then runs beside the chain's last GEMM instead of behind it)
+    if (hipEventRecord(pr.fill0, st) != hipSuccess) { set_error("decoder_fwd_prepare: event record failed"); return -5; }
     RC(precompute_static(a, w, st, true, true, 1));
     RC(embed_gather(a->embed, a->tokens, w.XT, a->S * a->N, a->E, a->V1, st));
     RC(input_gates(a, w, w.XT, 0, a->S, st, true));
@@ -1214,8 +1235,15 @@ static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, vo
         Prep& pr = prep();
         ECHR_REQUIRE(pr.ok && pr.pending && pr.ws == a->ws, "decoder_fwd: prepared = 1 without a matching echr_decoder_fwd_prepare on this workspace");
         pr.pending = false;
+        static const bool evb0_first = [] { const char* e = getenv("ECHR_EVB0_FIRST"); return !(e && e[0] == '0'); }();      // A/B switch
+        if (evb0_first) {
+            if (hipStreamWaitEvent(st, pr.fill0, 0) != hipSuccess) { set_error("decoder_fwd: join failed"); return -5; }
+            RC(precompute_static(a, w, st, true, true, 2));
+            if (hipStreamWaitEvent(st, pr.done, 0) != hipSuccess) { set_error("decoder_fwd: join failed"); return -5; }
+        } else {
         if (hipStreamWaitEvent(st, pr.done, 0) != hipSuccess) { set_error("decoder_fwd: join failed"); return -5; }
         RC(precompute_static(a, w, st, true, true, 2));
+        }
         evb0_pending = fwd_uses_persist(a) && persist_fwd_adds_evb0();      // the persistent launch's LSTM role adds the event part itself
         if (!evb0_pending) {
             const long n4 = (long)S * N * H;            // 4H / 4 float4 per row
@@ -1549,6 +1577,41 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     // async_tail = 2: only d event (what the caller's next backward kernels, the event encoder's, wait for) is formed on the caller's stream,
     // first; the rest of part A -- nine transposing packs, the grouped weight-gradient product, bias sums, the context halves of W_ih: ~0.13 ms
     // -- moves to the prepare stream (idle during a backward pass) and is joined by echr_stream_join like the tail
+    static const int dxt_stream = [] { const char* e = getenv("ECHR_DXT_STREAM"); return (e && e[0] == '1') ? 1 : 2; }();
+    bool dxt_done = false;
+    //    token embedding: dXT = sum_k DG_k . W_ih_k[:, :E], scatter-added into the (caller-zeroed) table gradient.  Reads what the recurrence
+    //    left (DG) and parameters only, so the chain can ride on either helper stream (ECHR_DXT_STREAM: 1 = tail stream, 2 = prepare stream
+    //    behind the LSTM-layer stage -- whichever leaves the three streams of the backward tail ending together)
+    auto dxt_chain = [&](hipStream_t q) -> int {
+        dxt_done = true;
+        echr_gemm_desc gx[3];
+        if (h2) {
+            H2PackJob pj[6];
+            for (int k = 0; k < 3; ++k) {
+                pj[k] = pack_rows(b.DG[k], 4 * H, SNr, 4 * H, b.PK_DG[k]);
+                pj[k].gather = actr;          // (compact: d XT is formed for the active rows only, row i of it belongs to position act[i])
+                pj[3 + k] = pack_cols(a->w_ih[k], cin[k], E, 4 * H, b.PK_WIHT[k]);
+            }
+            RC(h2_pack_multi(pj, 6, q));
+        }
+        // "embed_fused" = 1 (off by default): dXT = sum_k DG_k . W_ih_k[:, :E] is not materialised -- the products' epilogues add row (t, n) straight
+        // into the embedding-table gradient row of its token (echr_gemm_desc.row_index).  Measured on one box, alternating runs: 1.94 vs 1.74 ms per
+        // iteration -- every k-slice of every product then sends its atomics to the table, and the 64 <bos> rows of a batch (plus frequent words)
+        // serialise on the same addresses; the dense d XT buffer takes the k-slice atomics without contention and the scatter pass meets each
+        // duplicate once (20 us, `tools/skip_bounds.py`)
+        // (with compacted rows the products' row i is position act[i]: the scatter through `rowmap` handles that, the fused epilogue -- indexed
+        // by the compact row -- would not, so the switch is ignored there)
+        const bool fused_scatter = config().embed_fused != 0 && !actr;
+        for (int k = 0; k < 3; ++k) {
+            float* out = fused_scatter ? g->g_embed : b.DXT;
+            gx[k] = h2 ? desc_h2(b.PK_DG[k], b.PK_WIHT[k], out, E, SNr, E, 4 * H) : desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], out, E, SN, E, 4 * H);
+            gx[k].split_k = -1; gx[k].beta = 1.f;                // shared, pre-zeroed output: everything adds atomically
+            if (fused_scatter) { gx[k].row_index = a->tokens; gx[k].row_index_max = V1 - 1; }
+        }
+        RC(gemm_grouped(gx, 3, q));
+        if (!fused_scatter) RC(embed_scatter_add(b.DXT, a->tokens, g->g_embed, h2 ? SNr : SN, E, V1, q, h2 ? actr : nullptr));
+        return 0;
+    };
     hipStream_t sa2 = nullptr;
     auto part_a = [&]() -> int {
     if (!do_rec) return 0;
@@ -1573,9 +1636,10 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
             RC(gemm(d, sa2));
             RC(rank1_update(b.DGCOL[2], a->video, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, false, sa2));          // K = 1: no GEMM launch
             if (g->g_video) RC(vec_mat(b.DGCOL[2], a->w_ih[2] + E, cin[2], g->g_video, 4 * H, a->Dv, sa2));
+            RC(handover_mark(ECHR_HANDOVER_LSTM, sa2));          // every gradient of core.layer0..2 is final here
+            if (dxt_stream == 2 && do_pb && !dxt_done) RC(dxt_chain(sa2));
             if (hipEventRecord(tail().done3, sa2) != hipSuccess) { set_error("decoder_bwd: event record failed"); return -5; }
             tail().pending3 = true;
-            RC(handover_mark(ECHR_HANDOVER_LSTM, sa2));          // every gradient of core.layer0..2 is final here
             return 0;
         }
         // (no second helper stream: the rest follows on the caller's stream; d event is already there)
@@ -1674,35 +1738,7 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     d.beta = zb;
     RC(gemm(d, st));
     if (!z) RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
-    //    token embedding: dXT = sum_k DG_k . W_ih_k[:, :E], scatter-added into the (caller-zeroed) table gradient
-    {
-        echr_gemm_desc gx[3];
-        if (h2) {
-            H2PackJob pj[6];
-            for (int k = 0; k < 3; ++k) {
-                pj[k] = pack_rows(b.DG[k], 4 * H, SNr, 4 * H, b.PK_DG[k]);
-                pj[k].gather = actr;          // (compact: d XT is formed for the active rows only, row i of it belongs to position act[i])
-                pj[3 + k] = pack_cols(a->w_ih[k], cin[k], E, 4 * H, b.PK_WIHT[k]);
-            }
-            RC(h2_pack_multi(pj, 6, st));
-        }
-        // "embed_fused" = 1 (off by default): dXT = sum_k DG_k . W_ih_k[:, :E] is not materialised -- the products' epilogues add row (t, n) straight
-        // into the embedding-table gradient row of its token (echr_gemm_desc.row_index).  Measured on one box, alternating runs: 1.94 vs 1.74 ms per
-        // iteration -- every k-slice of every product then sends its atomics to the table, and the 64 <bos> rows of a batch (plus frequent words)
-        // serialise on the same addresses; the dense d XT buffer takes the k-slice atomics without contention and the scatter pass meets each
-        // duplicate once (20 us, `tools/skip_bounds.py`)
-        // (with compacted rows the products' row i is position act[i]: the scatter through `rowmap` handles that, the fused epilogue -- indexed
-        // by the compact row -- would not, so the switch is ignored there)
-        const bool fused_scatter = config().embed_fused != 0 && !actr;
-        for (int k = 0; k < 3; ++k) {
-            float* out = fused_scatter ? g->g_embed : b.DXT;
-            gx[k] = h2 ? desc_h2(b.PK_DG[k], b.PK_WIHT[k], out, E, SNr, E, 4 * H) : desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], out, E, SN, E, 4 * H);
-            gx[k].split_k = -1; gx[k].beta = 1.f;                // shared, pre-zeroed output: everything adds atomically
-            if (fused_scatter) { gx[k].row_index = a->tokens; gx[k].row_index_max = V1 - 1; }
-        }
-        RC(gemm_grouped(gx, 3, st));
-        if (!fused_scatter) RC(embed_scatter_add(b.DXT, a->tokens, g->g_embed, h2 ? SNr : SN, E, V1, st, h2 ? actr : nullptr));
-    }
+    if (!dxt_done) RC(dxt_chain(st));
     if (async_tail) {
         if (hipEventRecord(tail().done, st) != hipSuccess) { set_error("decoder_bwd: event record failed"); return -5; }
         tail().pending = true;

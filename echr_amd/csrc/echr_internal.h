@@ -62,14 +62,18 @@ constexpr int ABORT_SKIPPED_WORD = 16;
 unsigned* persist_host_flag();          // device view of the host-mapped flag persist_check_async reads (nullptr when unavailable)
 // the library's helper stream outside a backward pass (the one the asynchronous decoder-backward tail uses): `aux_fork` makes it continue
 // after everything queued on `from` and returns it, `aux_join` makes `to` wait for what was queued on it since
+void fork_event(hipEvent_t ev);                  // forks that follow wait for `ev` (the caller's stream's last record) instead of recording their own; nullptr ends it
 hipStream_t aux_fork(hipStream_t from);          // nullptr when unavailable
 int aux_join(hipStream_t to);
 hipStream_t aux2_fork(hipStream_t from);         // the same on the decoder's prepare stream (idle during a backward pass); nullptr when unavailable
 int aux2_join(hipStream_t to);
+int aux2_publish();                             // instead of a join: echr_stream_join / the next library call wait for what the prepare stream carries now
 bool helpers_available();
 hipStream_t aux2_stream();
 hipStream_t helpers_merge_to_tail();
 int tail_publish();
+int tsrm_position_early(const echr_tsrm_args* a, hipStream_t from);          // echr_train_step: start the event encoder's position branch right behind the index staging
+void tsrm_bwd_defer_join(bool on);          // echr_train_step: the position branch's stream is joined by echr_stream_join, not inside echr_tsrm_bwd
 int tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr_dropout* drop, void* stream, int part);
 int decoder_bwd_scratch_ahead(const echr_dec_args* a, const echr_dec_grads* g);
 int decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, int part);

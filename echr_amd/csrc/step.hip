@@ -55,6 +55,7 @@ struct PinRing {
     int next = 0;
 };
 static PinRing& ring() { static PinRing r; return r; }
+static hipEvent_t& ring_last() { static hipEvent_t e = nullptr; return e; }          // the event behind the last staging copy
 
 __global__ __launch_bounds__(256) void stage_copy_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -92,6 +93,7 @@ static int stage_indices(const int32_t* host, int32_t* dev, size_t bytes, hipStr
     }
     if (hipEventRecord(r.done[s], st) != hipSuccess) { (void)hipGetLastError(); set_error("train_step: index upload failed"); return -5; }
     r.used[s] = true;
+    ring_last() = r.done[s];
     return 0;
 }
 
@@ -215,14 +217,22 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     ECHR_REQUIRE(nll_target && nll_mask, "train_step: criterion targets / mask missing");
 
     echr_dec_args d = step_dec_args(a, L, idx);
-    // CaptionGenerator.forward (:23-30): the decoder's event-independent part starts on the library's second stream and overlaps the event encoder
-    if (a->overlap_encoder && !a->prepared) RC(echr_decoder_fwd_prepare(&d, stream));
     echr_tsrm_args t = a->tsrm;
     t.ech = ws + L.ech; t.ev_start = ev_start; t.ev_len = ev_len; t.ws = ws + L.tsrm_ws; t.out = ws + L.event;
     t.inference = 0; t.max_len = 0; t.max_span = 0;
+    // the event encoder's position branch (pair embedding -> fc1 -> fc2 gates: indices and parameters only) starts right behind the staging
+    // CaptionGenerator.forward (:23-30): the decoder's event-independent part starts on the library's second stream and overlaps the event encoder
+    if (a->overlap_encoder && !a->prepared) {
+        static const bool one_event = [] { const char* e = getenv("ECHR_ONE_FORK_EVENT"); return !(e && e[0] == '0'); }();      // A/B switch
+        if (one_event) fork_event(ring_last());          // both forks hang off the staging copy's event: no further record in front of event pooling
+        int rc2 = tsrm_position_early(&t, st);
+        if (!rc2) rc2 = echr_decoder_fwd_prepare(&d, stream);
+        fork_event(nullptr);
+        RC(rc2);
+    }
     int rc = echr_event_pool_gather_fwd(a->dec.c3d, a->tap, ev_start, ev_len, ind, ws + L.ech, N, a->dec.D, a->Ht, stream);       // :106-128
     if (!rc) rc = echr_tsrm_fwd(&t, &a->drop, stream);                                                                       // :129
-    if (rc) { if (a->overlap_encoder) (void)echr_decoder_fwd_prepare_cancel(stream); return rc; }
+    if (rc) { (void)tsrm_position_early(nullptr, nullptr); if (a->overlap_encoder) (void)echr_decoder_fwd_prepare_cancel(stream); return rc; }
     d.event = ws + L.event; d.prepared = a->overlap_encoder ? 1 : 0;
     echr_dec_grads g = a->dec_g;
     g.g_event = ws + L.g_event; g.g_logp = nullptr;
@@ -275,8 +285,12 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     RC(rc);
     step_mark(2, st);
     echr_tsrm_grads tg = a->tsrm_g;
-    tg.g_ech = ws + L.g_ech; tg.g_out = ws + L.g_event; tg.ws_bwd = ws + L.tsrm_ws_bwd; tg.zeroed = 1;
-    RC(echr_tsrm_bwd(&t, &tg, &a->drop, stream));
+    // d ech (the gradient of the event encoder's INPUT rows) only matters when d tap_feats is asked for: c3d features are data
+    tg.g_ech = a->g_tap ? ws + L.g_ech : nullptr; tg.g_out = ws + L.g_event; tg.ws_bwd = ws + L.tsrm_ws_bwd; tg.zeroed = 1;
+    tsrm_bwd_defer_join(true);          // (this call's workspace outlives the echr_stream_join below)
+    rc = echr_tsrm_bwd(&t, &tg, &a->drop, stream);
+    tsrm_bwd_defer_join(false);
+    RC(rc);
     if (a->g_tap) RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, a->dec.D, a->Ht, stream));
     if (fused_nll) RC(decoder_fused_loss(&d, &g, a->loss, st));
     step_mark(3, st);

@@ -584,12 +584,70 @@ extern "C" int echr_tsrm_attn_fwd(const echr_tsrm_args* a, const float* roi_feat
     return tsrm_fwd_impl(a, drop, stream, roi_feat, pos_emb);
 }
 
+// the dense position branch (:39-41, :108-116): pair embedding -> fc1 (+ tanh) -> fc2 gates, on stream sp.  Independent of the event features.
+static int position_branch(const echr_tsrm_args* a, const TsrmWs& w, bool do_posemb, bool packed_pos, hipStream_t sp) {
+    const int N = a->N, Df = a->Df, G = a->G, NN = N * N;
+    echr_gemm_desc d;
+    if (do_posemb) {
+        // many pairs: the embedding leaves its kernel already packed for the fc1 product (and as fp32 only if a backward pass may follow)
+        if (packed_pos) RC(posemb_packed(a->ev_start, a->ev_len, a->inference ? nullptr : w.POS, w.PK_POS, N, Df, sp));
+        else RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, sp));
+    }
+    // fc1 over the N*N event pairs: the one TSRM product big enough for the h2 path (tanh fused in the epilogue)
+    if (config().gemm_h2 && NN >= 1024) {
+        H2PackJob pj[2] = {pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1), pack_rows(w.POS, Df, NN, Df, w.PK_POS)};
+        RC(h2_pack_multi(pj, packed_pos ? 1 : 2, sp));
+        d = desc_h2(w.PK_POS, w.PK_WFC1, w.P1, Df, NN, Df, Df);
+        d.split_k = 1;
+    } else {
+        d = desc_nt(w.POS, Df, a->w_fc1, Df, w.P1, Df, NN, Df, Df);
+    }
+    d.bias = a->b_fc1; d.act = ECHR_ACT_TANH;
+    RC(gemm(d, sp));
+    if (gemm_skinny_ok(NN, G, Df, Df, Df, w.P1, a->w_fc2)) {
+        RC(gemm_skinny_nt(w.P1, Df, a->w_fc2, Df, a->b_fc2, w.GATE, G, NN, G, Df, sp));          // many pairs: a stream over the fc1 activations
+    } else {
+        d = desc_nt(w.P1, Df, a->w_fc2, Df, w.GATE, G, NN, G, Df); d.bias = a->b_fc2; d.split_k = -1; d.beta = 1.f;
+        RC(gemm(d, sp));
+    }
+    return 0;
+}
+
+// echr_train_step: the position branch depends on the index vectors and the parameters only, so it is started on the helper stream as soon
+// as the indices are staged -- ahead of event pooling and of the decoder's prepare chain -- instead of inside echr_tsrm_fwd (it is the longer
+// of the event encoder's two chains: ~85 us against ~55 us; started ~40 us earlier, the per-head attention no longer waits for it).  Only the
+// form that STORES its gates (skinny fc2 product): echr_tsrm_fwd's zero fill then leaves GATE alone.  The following echr_tsrm_fwd on the same
+// workspace picks the branch up (and joins it); any other call forgets it.
+static const void* g_pos_early_ws = nullptr;
+int echr::tsrm_position_early(const echr_tsrm_args* a, hipStream_t from) {
+    g_pos_early_ws = nullptr;
+    static const bool off = [] { const char* e = getenv("ECHR_TSRM_EARLY"); return e && e[0] == '0'; }();      // A/B switch
+    if (off || !config().tsrm_fork || !a || a->inference || !a->ws || !a->ev_start || !a->ev_len) return 0;
+    const int N = a->N, Df = a->Df, G = a->G, NN = N * N;
+    if (N <= 0 || Df <= 0 || G <= 0 || Df % 4 != 0) return 0;
+    TsrmWs w = carve(N, a->Din, Df, a->Do, G, a->ws);
+    if (!gemm_skinny_ok(NN, G, Df, Df, Df, w.P1, a->w_fc2)) return 0;
+    hipStream_t sp = aux_fork(from);
+    if (!sp) return 0;
+    const bool packed_pos = config().gemm_h2 && NN >= 4096 && posemb_packed_ok(N, Df);
+    RC(position_branch(a, w, true, packed_pos, sp));
+    g_pos_early_ws = a->ws;
+    return 0;
+}
+
 static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void* stream, const float* x_given, const float* pos_given) {
     hipStream_t st = (hipStream_t)stream;
     const int N = a->N, Din = a->Din, Df = a->Df, Do = a->Do, G = a->G;
     const int NN = N * N, dgq = Df / G, dgo = Do / G;
     TsrmWs w = carve(N, Din, Df, Do, G, a->ws);
     echr_gemm_desc d;
+    const bool early = !x_given && !a->inference && g_pos_early_ws == a->ws;      // tsrm_position_early already runs the position branch
+    g_pos_early_ws = nullptr;
+    if (early) {          // X and Q | K | XW: the split-K products below accumulate into zeros; GATE is being STORED by the early branch
+        float* zp[2] = {w.X, w.Q};
+        const long zn[2] = {(long)(w.GATE - w.X), (long)((w.X + w.zero_floats) - w.Q)};
+        RC(fill_zero_multi(zp, zn, 2, st));
+    } else
     RC(fill_zero(w.X, w.zero_floats, st));           // X | GATE | Q | K | XW: the split-K products below accumulate into zeros
     if (x_given) {
         if (hipMemcpyAsync(w.X, x_given, (size_t)N * Df * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
@@ -600,9 +658,9 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
     }
     // pairwise position features -> per-head gates (:39-41, :108-116): independent of the event features, so the branch runs on the
     // library's helper stream beside the embedding / query / key products (it needs the zero fill above: GATE accumulates)
-    hipStream_t sp = config().tsrm_fork ? aux_fork(st) : nullptr;
-    const bool fork = sp != nullptr;
-    if (!fork) sp = st;
+    hipStream_t sp = (config().tsrm_fork && !early) ? aux_fork(st) : nullptr;
+    const bool fork = sp != nullptr || early;
+    if (!sp) sp = st;
     long trc = 0, trl = 0;
     const long trows = x_given ? 0 : pair_table_rows(a, &trc, &trl);
     const bool packed_pos = !x_given && !trows && config().gemm_h2 && NN >= 4096 && posemb_packed_ok(N, Df);
@@ -642,30 +700,8 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
         // event embedding (:44)
         d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1; d.beta = 1.f;
         RC(gemm(d, st));
-        // many pairs: the embedding leaves its kernel already packed for the fc1 product (and as fp32 only if a backward pass may follow)
-        if (packed_pos) RC(posemb_packed(a->ev_start, a->ev_len, a->inference ? nullptr : w.POS, w.PK_POS, N, Df, sp));
-        else RC(posemb(a->ev_start, a->ev_len, w.POS, N, Df, sp));
     }
-    // fc1 over the N*N event pairs: the one TSRM product big enough for the h2 path (tanh fused in the epilogue)
-    if (trows) {
-    } else {
-    if (config().gemm_h2 && NN >= 1024) {
-        H2PackJob pj[2] = {pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1), pack_rows(w.POS, Df, NN, Df, w.PK_POS)};
-        RC(h2_pack_multi(pj, packed_pos ? 1 : 2, sp));
-        d = desc_h2(w.PK_POS, w.PK_WFC1, w.P1, Df, NN, Df, Df);
-        d.split_k = 1;
-    } else {
-        d = desc_nt(w.POS, Df, a->w_fc1, Df, w.P1, Df, NN, Df, Df);
-    }
-    d.bias = a->b_fc1; d.act = ECHR_ACT_TANH;
-    RC(gemm(d, sp));
-    if (gemm_skinny_ok(NN, G, Df, Df, Df, w.P1, a->w_fc2)) {
-        RC(gemm_skinny_nt(w.P1, Df, a->w_fc2, Df, a->b_fc2, w.GATE, G, NN, G, Df, sp));          // many pairs: a stream over the fc1 activations
-    } else {
-        d = desc_nt(w.P1, Df, a->w_fc2, Df, w.GATE, G, NN, G, Df); d.bias = a->b_fc2; d.split_k = -1; d.beta = 1.f;
-        RC(gemm(d, sp));
-    }
-    }
+    if (!trows && !early) RC(position_branch(a, w, !x_given, packed_pos, sp));
     // query / key / (pre-applied) output projection of X: one grouped launch when the three problems have one shape
     {
         echr_gemm_desc q3[3];
@@ -716,6 +752,8 @@ extern "C" int echr_tsrm_bwd(const echr_tsrm_args* a, const echr_tsrm_grads* g, 
 // part 0: the whole backward.  echr_train_step's joint mode (step.hip) wants d ech -- the gradient the proposal encoder waits for -- as early
 // as possible: part 1 = the chain that leads to it (per-head attention backward, d X, d ech) on `stream`; part 2 = every parameter gradient
 // (position MLP, projections, embedding, biases), issued later on a helper stream passed as `stream`.  Parts need zeroed gradient buffers.
+static bool g_tsrm_nojoin = false;
+void echr::tsrm_bwd_defer_join(bool on) { g_tsrm_nojoin = on; }
 int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr_dropout* drop, void* stream, int part) {
     RC(check(a, "tsrm_bwd"));
     ECHR_REQUIRE(g && g->g_out && g->ws_bwd, "tsrm_bwd: missing buffers");
@@ -759,7 +797,9 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
     }
     // The position-MLP gradients (d W_fc2, d P1, d W_fc1: 4.3 GF over the N^2 pairs) depend on d GATE alone: they run on the decoder's
     // prepare stream -- idle during a backward pass -- beside the query / key / embedding chain below (ten dependent small launches)
-    static const bool fork2_off = [] { const char* e = getenv("ECHR_TSRM_FORK2"); return e && e[0] == '0'; }();      // A/B switch
+    // (round 5: off by default.  With the token-embedding chain on the prepare stream behind the LSTM-layer stage (decoder.hip, ECHR_DXT_STREAM)
+    // the three streams of the backward tail end together when THIS stream keeps the position MLP: 1.48 vs 1.54 ms per iteration, same box)
+    static const bool fork2_off = [] { const char* e = getenv("ECHR_TSRM_FORK2"); return !(e && e[0] == '1'); }();      // A/B switch
     hipStream_t sp = (config().tsrm_fork && !fork2_off && part == 0) ? aux2_fork(st) : nullptr;
     const bool fork2 = sp != nullptr;
     if (!fork2) sp = st;
@@ -815,8 +855,20 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
     // event embedding
     d = desc_tn(b.DX, Df, a->ech, Din, g->g_w_emb, Din, Df, Din, N); d.beta = zb; d.split_k = -1;
     RC(gemm(d, st));
+    // bias gradients: all six column sums in one launch when the gradient buffers accumulate.  With the position branch forked onto the
+    // prepare stream its two sums (d b_fc2, d b_fc1: over the N^2 pair rows it just produced) run THERE, behind the products, and this stream
+    // does not join: nothing later on it reads the branch's outputs, and echr_stream_join / the next library call wait for the prepare
+    // stream's event -- the caller's chain then ends with its own last product instead of with the branch's (it used to: join, six sums, d ech).
+    // Only for callers that keep the workspaces alive until that join (echr_train_step: tsrm_bwd_defer_join); the plain entry joins here
+    if (z && fork2 && g_tsrm_nojoin) {
+        const ColsumJob cp[2] = {{b.DGATE, G, NN, G, g->g_b_fc2, nullptr, nullptr}, {b.DP1, Df, NN, Df, g->g_b_fc1, nullptr, nullptr}};
+        RC(colsum_multi(cp, 2, sp));
+        RC(aux2_publish());
+        const ColsumJob cj[4] = {{g->g_out, Do, N, Do, g->g_b_out, nullptr, nullptr}, {b.DQ, Df, N, Df, g->g_b_q, nullptr, nullptr},
+                                 {b.DK, Df, N, Df, g->g_b_k, nullptr, nullptr},        {b.DX, Df, N, Df, g->g_b_emb, nullptr, nullptr}};
+        RC(colsum_multi(cj, 4, st));
+    } else {
     if (fork2) RC(aux2_join(st));
-    // bias gradients: all six column sums in one launch when the gradient buffers accumulate
     if (z) {
         const ColsumJob cj[6] = {{g->g_out, Do, N, Do, g->g_b_out, nullptr, nullptr}, {b.DQ, Df, N, Df, g->g_b_q, nullptr, nullptr},
                                  {b.DK, Df, N, Df, g->g_b_k, nullptr, nullptr},        {b.DGATE, G, NN, G, g->g_b_fc2, nullptr, nullptr},
@@ -828,6 +880,7 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
         RC(colsum(b.DGATE, G, NN, G, g->g_b_fc2, false, st));
         RC(colsum(b.DP1, Df, NN, Df, g->g_b_fc1, false, st));
         RC(colsum(b.DX, Df, N, Df, g->g_b_emb, false, st));
+    }
     }
     if (g->g_ech && part == 0) {
         d = desc_nn(b.DX, Df, a->w_emb, Din, g->g_ech, Din, N, Din, Df); d.split_k = -1; d.beta = 1.f;

@@ -214,3 +214,28 @@ def make_eosmix(name, A=24, embed_scale=10.0):
     params['lm_model.logit.weight'][0] *= np.float32(c['eos_scale'])
     vid = make_video(c['N'], A, 21, 5001, seed=c['seed'], T_v=4 * A)
     return opt, params, vid
+
+
+# Training in the PEAKED regime: a trained captioner's softmax puts > 0.9 of its mass on one word at most positions, so d logits =
+# softmax - onehot spans dozens of binades inside one row (and inside one 256-wide k segment of the h2 operand format), which the
+# random-initialisation cases (near-uniform softmax) never exercise.  Weights cannot be trained here and shipped (fixtures store no
+# weights), so the regime is constructed: the logit layer is scaled up (every row's soft-max collapses onto its arg-max) and the token
+# embedding too (token-driven recurrences: the peak moves from step to step); the CAPTIONS are then chosen so that most positions'
+# target IS that arg-max -- tools/make_golden.py do_peaked runs the reference's own teacher-forced forward (train mode, the build's
+# dropout masks) to its fixed point and stores labels / masks in tests/golden/case_peaked.npz; one row in ten keeps a random word
+# (a confidently wrong prediction: loss terms of ~100, d logits of -1 / +1).
+PEAKED = dict(N=64, A=128, L=21, seed=77, logit_scale=60.0, embed_scale=10.0, wrong_every=10)
+
+
+def make_peaked(labels=None, masks=None):
+    """(opt, params, video) of the peaked-softmax training case at the ECHR widths (N64 x A<=128 ragged, S = 20, V1 = 5001).  `labels` /
+    `masks`: the fixture's captions (tests/golden/case_peaked.npz); without them the video carries random captions (what do_peaked starts from)."""
+    c = PEAKED
+    opt = default_opt(vocab_size=5000, seq_length=c['L'] - 2)
+    params = make_params(opt, 0)
+    params['lm_model.logit.weight'] = (params['lm_model.logit.weight'] * np.float32(c['logit_scale'])).astype(np.float32)
+    params['lm_model.embed.weight'] = (params['lm_model.embed.weight'] * np.float32(c['embed_scale'])).astype(np.float32)
+    vid = make_video(c['N'], c['A'], c['L'], 5001, seed=c['seed'])
+    if labels is not None:
+        vid['labels'], vid['masks'] = np.asarray(labels, np.int64).copy(), np.asarray(masks, np.float32).copy()
+    return opt, params, vid

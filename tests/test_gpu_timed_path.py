@@ -199,3 +199,77 @@ def test_prepare_keeps_device_criterion_inputs_alive():
     ld, gd = run(True)
     assert abs(lh - ld) < 2e-6 * abs(lh), (lh, ld)
     assert float((gh - gd).abs().max()) <= 2e-5 * float(gh.abs().max())
+
+
+# ---- training parity in the PEAKED regime (synth.PEAKED, tests/golden/case_peaked.npz) --------------------------------------------------
+# Logits reach +-200 and log-probs -370 there (fp32 ulp 3e-5): two CORRECT fp32 evaluations differ by ~1e-4 in a log-prob and by 4-5e-6 of
+# a gradient tensor's max-norm (tests/test_oracle_golden.py::test_peaked_regime_noise_floor_of_fp32_itself: the reference's arithmetic on 8
+# threads vs 1 thread; against float64 1.25e-4 / 5e-6).  Gates: log-probs 1e-3 absolute (= 3e-6 of their magnitude, 10x that noise, 30x
+# inside north_star's 1e-4 relative); loss TOL_LOSS; gradients TOL_GRAD (1e-5) on the default (h2) path -- i.e. at 2x the reference's own
+# noise -- and 3e-5 for the alternative product paths.
+TOL_LOGP_PEAKED = 1e-3
+TOL_GRAD_PEAKED_ALT = 3e-5
+
+def _peaked():
+    g = U.gold('case_peaked.npz')
+    opt, params, vid = synth.make_peaked(g['labels'], g['masks'])
+    return g, opt, params, vid
+
+
+@pytest.mark.parametrize('train_mode', [True, False])
+def test_peaked_regime_full_path_vs_oracle_and_reference(train_mode):
+    """Forward + criterion + backward where the softmax is PEAKED (top-1 probability > 0.9 on 70 % of the active rows in train mode, one
+    target in ten confidently wrong): d logits = softmax - onehot then spans > 2^40 inside a row and inside a 256-wide k segment of the
+    fp16-pair ("h2") operand format of the default configuration.  Every log-prob and every gradient element against the oracle; loss and
+    summaries against the reference's own outputs (OldModel_NEW.py:136, misc/utils.py:66-75)."""
+    g, opt, params, vid = _peaked()
+    mode = 'train' if train_mode else 'eval'
+    pred, loss, grads, _ = U.run_gpu(opt, params, vid, train_mode)
+    rpred, rloss, rgrads = U.run_oracle(opt, params, vid, train_mode)
+    if train_mode:
+        act = vid['masks'][:, 1:1 + pred.shape[1]] > 0
+        assert (np.exp(rpred.max(2))[act] > 0.9).mean() > 0.6
+    assert np.abs(pred - rpred).max() < TOL_LOGP_PEAKED, np.abs(pred - rpred).max()
+    assert abs(loss - rloss) < TOL_LOSS * abs(rloss) and abs(loss - float(g[mode + '|loss'])) < TOL_LOSS * abs(float(g[mode + '|loss']))
+    s = SM.summarize_logp(pred)
+    safe = g[mode + '|logp|margin'] > 1e-3
+    assert np.array_equal(s['argmax'][safe], g[mode + '|logp|argmax'][safe])
+    for k, rg in rgrads.items():
+        if rg is None:
+            assert grads[k] is None, k
+        else:
+            assert U.grad_close(k, grads[k], rg, TOL_GRAD), (k, U.relerr(grads[k], rg))
+    _check_grad_summaries(g, mode, grads)
+
+
+def test_peaked_regime_timed_path_vs_reference():
+    """The same regime through echr_train_step (the path bench.py times: active-row compaction, criterion fused into the logits pass, h2
+    operands packed from the compacted d logits): loss and gradients against the reference's fixture and the oracle, then one full step."""
+    g, opt, params, vid = _peaked()
+    m, o, f = _fused(opt, params)
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False))
+    torch.cuda.synchronize()
+    assert 0 < f.last_active_rows < tgt_h.size
+    assert abs(loss - float(g['train|loss'])) < TOL_LOSS * abs(float(g['train|loss'])), (loss, float(g['train|loss']))
+    grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else None) for k, p in m.named_parameters()}
+    _check_grad_summaries(g, 'train', grads)
+    _, rloss, rgrads = U.run_oracle(opt, params, vid, True)
+    for k, rg in rgrads.items():
+        if rg is not None:
+            assert U.grad_close(k, grads[k], rg, TOL_GRAD), (k, U.relerr(grads[k], rg))
+    # the three product paths agree in this regime too (h2 default above; exact three-plane bf16 split; native fp32 MFMAs)
+    from echr_amd import _lib
+    lib = _lib.load()
+    try:
+        for cfg in ((0, 1), (0, 0)):
+            lib.echr_config_set(b'gemm_h2', cfg[0]); lib.echr_config_set(b'gemm_bf16x3', cfg[1]); lib.echr_config_set(b'persist_h2', cfg[0])
+            m.set_dropout_state(U.SEED, U.OFFSET)
+            l2 = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False))
+            torch.cuda.synchronize()
+            assert abs(l2 - rloss) < TOL_LOSS * abs(rloss), (cfg, l2, rloss)
+            for k, p in m.named_parameters():
+                if rgrads[k] is not None:
+                    assert U.grad_close(k, p.grad.detach().cpu().numpy(), rgrads[k], TOL_GRAD_PEAKED_ALT), (cfg, k, U.relerr(p.grad.detach().cpu().numpy(), rgrads[k]))
+    finally:
+        lib.echr_config_set(b'gemm_h2', 1); lib.echr_config_set(b'gemm_bf16x3', 1); lib.echr_config_set(b'persist_h2', 1)

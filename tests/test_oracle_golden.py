@@ -47,6 +47,44 @@ def test_config_summaries(case):
         assert np.allclose(v, ref, rtol=1e-4, atol=1e-7 * (1 + np.abs(ref).max())), key
 
 
+def test_peaked_regime_summaries():
+    """The oracle on the peaked-softmax training case (synth.PEAKED; captions from the fixture) against the reference's own summaries."""
+    g = U.gold('case_peaked.npz')
+    opt, params, vid = synth.make_peaked(g['labels'], g['masks'])
+    pred, loss, grads = U.run_oracle(opt, params, vid, True)
+    assert float(g['train|top1_gt_0.9']) > 0.6                      # the regime the case exists for
+    assert abs(loss - float(g['train|loss'])) < 1e-5 * abs(float(g['train|loss']))
+    s = SM.summarize_logp(pred)
+    assert np.abs(s['slice'] - g['train|logp|slice']).max() < 1e-6 * np.abs(g['train|logp|slice']).max()
+    assert np.array_equal(s['argmax'], g['train|logp|argmax'])
+    for key, v in SM.summarize_grads(grads).items():
+        ref = g['train|grad|' + key]
+        assert np.allclose(v, ref, rtol=1e-4, atol=1e-7 * (1 + np.abs(ref).max())), key
+
+
+def test_peaked_regime_noise_floor_of_fp32_itself():
+    """What ANY fp32 evaluation of the peaked case is worth: the oracle (= the reference's arithmetic, torch CPU fp32) on 8 threads against
+    itself on 1 thread -- a different summation order in the same library.  Logits reach +-200 there, so log-probs move by ~1e-4 and
+    gradients by ~4e-6 of their tensor's max-norm between two CORRECT fp32 runs (against float64: 1.25e-4 / 5e-6).  The GPU gates of
+    tests/test_gpu_timed_path.py for this case sit on these figures."""
+    g = U.gold('case_peaked.npz')
+    opt, params, vid = synth.make_peaked(g['labels'], g['masks'])
+    n0 = torch.get_num_threads()
+    try:
+        torch.set_num_threads(max(2, min(8, n0)))
+        pa, la, ga = U.run_oracle(opt, params, vid, True)
+        torch.set_num_threads(1)
+        pb, lb, gb = U.run_oracle(opt, params, vid, True)
+    finally:
+        torch.set_num_threads(n0)
+    dlogp = float(np.abs(pa - pb).max())
+    dgrad = max(U.relerr(ga[k], gb[k], U.GRAD_FLOOR) for k in ga if ga[k] is not None and k not in U.NOISE_ONLY)
+    print('peaked case, fp32 8 threads vs 1 thread: max|dlogp| %.2e, worst gradient %.2e of its max-norm' % (dlogp, dgrad))
+    assert dlogp < 1e-3 and dgrad < 3e-5 and abs(la - lb) < 1e-5 * abs(la)
+    if n0 >= 2:
+        assert dlogp > 1e-6          # (the case really is in the regime where fp32 summation order shows)
+
+
 @pytest.mark.parametrize('case', ['tiny', 'c1'])
 def test_greedy_sample(case):
     opt, params, vid = synth.make_case(case)

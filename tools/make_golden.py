@@ -254,6 +254,67 @@ def do_c5():
     print('  wrote case_c5.npz (%d arrays)' % len(out))
 
 
+def do_peaked():
+    """Training parity in the peaked-softmax regime (synth.PEAKED): captions = the fixed point of the REFERENCE's own teacher-forced arg-max
+    under the build's train-mode dropout masks (step t's output depends on labels[:, <= t] only, so S sweeps reach it), one row in ten with a
+    random (confidently wrong) word; then the usual eval / train summaries of the reference on those captions, and the oracle checked
+    against it."""
+    opt, params, vid = synth.make_peaked()
+    c = synth.PEAKED
+    m = build_ref(opt, params)
+    labels = vid['labels'].copy()
+    N, L = labels.shape
+    rs = np.random.RandomState(c['seed'] + 1)
+    cap_len = (labels[:, 1:] != 0).sum(1)                 # the random captions' lengths are kept
+    wrong = rs.randint(1, 5001, size=labels.shape)
+    is_wrong = rs.randint(0, c['wrong_every'], size=labels.shape) == 0
+    tap, c3d, lda = (torch.from_numpy(vid[k]) for k in ('tap', 'c3d', 'lda'))
+    for sweep in range(L):
+        m.train()
+        orig = F.dropout
+        F.dropout = MaskFeeder(opt.CG_drop_prob)
+        try:
+            with torch.no_grad():
+                pred = m(tap, c3d, lda, torch.from_numpy(labels), vid['ind'], vid['soi'].tolist(), mode='train').numpy()
+        finally:
+            F.dropout = orig
+        new = labels.copy()
+        S = pred.shape[1]
+        pp = pred.copy()
+        pp[:, :, 0] = -np.inf                            # a word inside a caption is never <eos>
+        am = pp.argmax(2)                                 # [N, S]: the model's word for position t + 1
+        for n in range(N):
+            for t in range(min(S, cap_len[n])):
+                new[n, t + 1] = wrong[n, t + 1] if is_wrong[n, t + 1] else am[n, t]
+        changed = int((new != labels).sum())
+        labels = new
+        print('[peaked] sweep %d: %d labels changed' % (sweep, changed))
+        if changed == 0:
+            break
+    assert changed == 0, 'no fixed point'
+    vid['labels'] = labels
+    out = {'labels': labels, 'masks': vid['masks']}
+    for mode in ('eval', 'train'):
+        pred, loss, grads = run_ref(m, vid, mode == 'train', opt)
+        opred, oloss, ograds = run_oracle(opt, params, vid, mode == 'train')
+        dev = max(rel(ograds[k], grads[k]) for k in grads if grads[k] is not None)
+        act = vid['masks'][:, 1:1 + pred.shape[1]] > 0
+        p1 = np.exp(pred.max(2))[act]
+        tgt = np.take_along_axis(pred, labels[:, 1:1 + pred.shape[1], None], 2)[:, :, 0]
+        print('[peaked/%s] loss %.6f | top-1 prob > 0.9 on %.0f %% of the active rows, target prob > 0.9 on %.0f %%, min logp %.1f | oracle-vs-ref: '
+              'max|dlogp| %.2e  dloss %.2e  max rel grad %.2e' % (mode, loss, 100 * (p1 > 0.9).mean(), 100 * (np.exp(tgt)[act] > 0.9).mean(),
+                                                                 pred.min(), np.abs(opred - pred).max(), abs(oloss - loss), dev))
+        assert np.abs(opred - pred).max() < 1e-6 * np.abs(pred).max() + 2e-5 and abs(oloss - loss) < 1e-5 * abs(loss) and dev < 1e-4
+        out[mode + '|loss'] = np.float64(loss)
+        out[mode + '|top1_gt_0.9'] = np.float64((p1 > 0.9).mean())
+        for k, v in SM.summarize_logp(pred).items():
+            out[mode + '|logp|' + k] = v
+        for k, v in SM.summarize_grads(grads).items():
+            out[mode + '|grad|' + k] = v
+    np.savez_compressed(os.path.join(GOLD, 'case_peaked.npz'), **out)
+    print('  wrote case_peaked.npz (%d arrays)' % len(out))
+
+
 def do_eosmix():
     """Greedy decoding where events finish at DIFFERENT steps (OldModel_NEW.py:171-183): the reference's own `seq` / `seqLogprobs` on
     synth.make_eosmix inputs.  The event lists are chosen here from the reference's decode and stored in the fixture."""
@@ -490,12 +551,12 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', nargs='*', default=['tiny', 'c1', 'c2', 'c2full', 'c3bench'])
     ap.add_argument('--skip-aux', action='store_true')
-    ap.add_argument('--only', choices=['position', 'adam', 'proposals', 'checkpoint', 'sst', 'c5', 'eosmix'], help='regenerate one auxiliary fixture only')
+    ap.add_argument('--only', choices=['position', 'adam', 'proposals', 'checkpoint', 'sst', 'c5', 'eosmix', 'peaked'], help='regenerate one auxiliary fixture only')
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     if a.only:
-        {'position': do_position, 'adam': do_adam, 'proposals': do_proposals, 'checkpoint': do_checkpoint, 'sst': do_sst, 'c5': do_c5, 'eosmix': do_eosmix}[a.only]()
+        {'position': do_position, 'adam': do_adam, 'proposals': do_proposals, 'checkpoint': do_checkpoint, 'sst': do_sst, 'c5': do_c5, 'eosmix': do_eosmix, 'peaked': do_peaked}[a.only]()
         sys.exit(0)
     if not a.skip_aux:
         do_position()
@@ -505,5 +566,6 @@ if __name__ == '__main__':
         do_sst()
         do_c5()
         do_eosmix()
+        do_peaked()
     for c in a.cases:
         do_case(c)

@@ -14,6 +14,7 @@ for r in rows[a:b]:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     g = (s - prev) / 1e3; d = (e - s) / 1e3
     busy += d; gap += max(g, 0)
-    print('%9.1f  dur %7.1f  gap %6.1f  %s' % ((s - t0) / 1e3, d, g, r['Kernel_Name'][:70]))
+    q = r.get('Stream_Id') or r.get('Queue_Id') or ''
+    print('%9.1f  end %7.1f  dur %6.1f  gap %6.1f  q%-3s %s' % ((s - t0) / 1e3, (e - t0) / 1e3, d, g, q, r['Kernel_Name'].replace('echr::', '').replace('void ', '')[:60]))
     prev = max(prev, e)
 print('launches %d busy %.1f us gaps %.1f us span %.1f us' % (b - a, busy, gap, (prev - t0) / 1e3))
