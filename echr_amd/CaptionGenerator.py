@@ -25,9 +25,9 @@ class CaptionGenerator(nn.Module):
             self.fusion_model = models.setup_fusion(opt)
         self.lm_model = models.setup_lm(opt)
         self.overlap_encoder = os.environ.get('ECHR_OVERLAP_ENCODER', '1') != '0'        # 'train' mode: run the decoder's event-independent precompute concurrently with the event encoder
-        if opt.video_context_type != 'VL' or opt.event_context_type != 'ER3' or opt.clip_context_type != 'CC':
-            raise NotImplementedError('the HIP path implements the ECHR recipe: video_context_type=VL, event_context_type=ER3, '
-                                      'clip_context_type=CC (experiments/train_ECHR.sh)')
+        if not any(k in opt.video_context_type for k in ('VL', 'VC', 'VH')) or opt.event_context_type != 'ER3' or opt.clip_context_type != 'CC':
+            raise NotImplementedError('the HIP path implements the ECHR recipe: video_context_type from VL / VC / VH (any combination), '
+                                      'event_context_type=ER3, clip_context_type=CC (experiments/train_ECHR.sh)')
 
     def _require_live_decoder(self):
         if type(self.lm_model).__name__ != 'ThreestreamModel':
@@ -85,8 +85,19 @@ class CaptionGenerator(nn.Module):
         opt.clip_context_dim = (opt.video_dim if 'CC' in ct else 0) + (opt.hidden_dim if 'CH' in ct else 0)
 
     def get_video_context(self, tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list):
-        """'VL': the LDA topic vector as is (CaptionGenerator.py:87-104)."""
-        return lda_feats
+        """Scene context (CaptionGenerator.py:87-104): 'VL' the LDA topic vector as is, 'VC' / 'VH' the mean over all T_v rows of the C3D
+        features / the proposal encoder's states (echr_col_mean_fwd), concatenated in that order."""
+        vt = self.opt.video_context_type
+        if vt == 'VL':
+            return lda_feats
+        parts = []
+        if 'VL' in vt:
+            parts.append(EF._f32c(lda_feats).reshape(-1))
+        if 'VC' in vt:
+            parts.append(EF.ColMean.apply(c3d_feats))
+        if 'VH' in vt:
+            parts.append(EF.ColMean.apply(tap_feats))
+        return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
 
     def get_event_context(self, tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=None, _drop=None):
         """'ER3': TSRM over cat(mean-pooled C3D, SST state at the anchor) (CaptionGenerator.py:106-130)."""

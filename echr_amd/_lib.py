@@ -98,6 +98,8 @@ SYMBOLS = [
     ('echr_gemm_f32', i32, [C.POINTER(GemmDesc), C.c_void_p]),
     ('echr_event_pool_gather_fwd', i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_event_pool_gather_bwd', i32, [c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
+    ('echr_col_mean_fwd', i32, [c_f, i32, i32, i64, c_f, C.c_void_p]),
+    ('echr_col_mean_bwd', i32, [c_f, i32, i32, i64, c_f, C.c_void_p]),
     ('echr_tsrm_ws_floats', i64, [i32, i32, i32, i32, i32]),
     ('echr_tsrm_ws_bwd_floats', i64, [i32, i32, i32, i32, i32]),
     ('echr_tsrm_fwd', i32, [C.POINTER(TsrmArgs), C.POINTER(Dropout), C.c_void_p]),

@@ -930,6 +930,32 @@ extern "C" int64_t echr_abi_sizeof(const char* name) {
 }
 extern "C" const char* echr_last_error(void) { return g_err; }
 
+// ---- scene context 'VC' / 'VH' (CaptionGenerator.py:95-99): the mean over all T_v rows of c3d_feats / tap_feats ----
+__global__ __launch_bounds__(256) void col_scale_kernel(float* __restrict__ v, int n, float s) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] *= s;
+}
+// gx[t, :] += g[:] / T  (the mean's gradient, broadcast over the rows)
+__global__ __launch_bounds__(256) void col_mean_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx, int rows, int cols, long ld, float inv) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    gx[(long)r * ld + c] += g[c] * inv;
+}
+extern "C" int echr_col_mean_fwd(const float* x, int32_t rows, int32_t cols, int64_t ld, float* out, void* stream) {
+    ECHR_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "col_mean_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = colsum(x, (long)ld, rows, cols, out, false, st)) return rc;
+    hipLaunchKernelGGL(col_scale_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, out, cols, 1.0f / (float)rows);
+    return check_launch("col_mean_fwd");
+}
+extern "C" int echr_col_mean_bwd(const float* g, int32_t rows, int32_t cols, int64_t ld, float* gx, void* stream) {
+    ECHR_REQUIRE(g && gx && rows > 0 && cols > 0 && ld >= cols, "col_mean_bwd: bad arguments");
+    const long n = (long)rows * cols;
+    hipLaunchKernelGGL(col_mean_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, gx, rows, cols, (long)ld, 1.0f / (float)rows);
+    return check_launch("col_mean_bwd");
+}
+
 extern "C" int echr_event_pool_gather_fwd(const float* c3d, const float* tap, const int32_t* ev_start, const int32_t* ev_len,
                                           const int32_t* ind, float* ech, int32_t N, int32_t D, int32_t Ht, void* stream) {
     ECHR_REQUIRE(c3d && tap && ev_start && ev_len && ind && ech && N > 0 && D > 0 && Ht > 0, "event_pool_gather_fwd: bad arguments");

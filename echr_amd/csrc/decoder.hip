@@ -1616,6 +1616,15 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     auto part_a = [&]() -> int {
     if (!do_rec) return 0;
     if (g->phase == 0 && g->async_tail == 2 && z && h2 && !ov && tail().ok) {
+        // Both helper streams fork RIGHT BEHIND the reverse recurrence, off ONE recorded event (ECHR_FORK_FIRST=0: behind d event, one record
+        // each): the two records used to sit between the d event product and everything that follows on all three streams (~15 us of an idle
+        // chip).  The prepare stream then forms its own copy of the per-event gate-gradient sums (6 us) instead of waiting for this stream's
+        static const bool fork_first = [] { const char* e = getenv("ECHR_FORK_FIRST"); return !(e && e[0] == '0'); }();      // A/B switch
+        const bool ff = fork_first && part == 0;
+        if (ff) {
+            sa2 = aux2_fork(st);
+            if (sa2) fork_event(prep().fork);          // part B's fork waits for the same event
+        }
         if (part != 2) {
         RC(sum_over_time(b.DG[0], 4 * H, S, N, 4 * H, b.DGSUM[0], 4 * H, st));
         d = desc_nn(b.DGSUM[0], 4 * H, a->w_ih[0] + E, cin[0], g->g_event, a->De, N, a->De, 4 * H);
@@ -1623,7 +1632,9 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
         RC(gemm(d, st));
         }
         if (part == 1) return 0;
-        sa2 = aux2_fork(st);
+        if (!ff) sa2 = aux2_fork(st);
+        const float* dgsum0 = b.DGSUM[0];
+        if (sa2 && ff) { RC(sum_over_time(b.DG[0], 4 * H, S, N, 4 * H, b.DGSUM[1], 4 * H, sa2)); dgsum0 = b.DGSUM[1]; }
         if (sa2) {
             RC(wgrad_chunk(0, S, 1.f, sa2));
             const ColsumJob cj[4] = {{b.DQ, Ha, SN, Ha, g->g_b_h2a, nullptr, nullptr},
@@ -1631,7 +1642,7 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
                                      {b.DG[1], 4 * H, SN, 4 * H, g->g_b_ih[1], g->g_b_hh[1], nullptr},
                                      {b.DG[2], 4 * H, SN, 4 * H, g->g_b_ih[2], g->g_b_hh[2], b.DGCOL[2]}};
             RC(colsum_multi(cj, 4, sa2));
-            d = desc_tn(b.DGSUM[0], 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);
+            d = desc_tn(dgsum0, 4 * H, a->event, a->De, g->g_w_ih[0] + E, cin[0], 4 * H, a->De, N);
             d.beta = zb; d.split_k = -1;
             RC(gemm(d, sa2));
             RC(rank1_update(b.DGCOL[2], a->video, g->g_w_ih[2] + E, cin[2], 4 * H, a->Dv, false, sa2));          // K = 1: no GEMM launch
@@ -1698,7 +1709,9 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     if (!do_pb) return 0;
     if (async_tail) {
         st = tail().s;
-        RC(hop(sm, tail().fork, st));
+        if (hipEvent_t fe = fork_event_slot()) {          // (forked with the prepare stream, right behind the reverse recurrence)
+            if (hipStreamWaitEvent(st, fe, 0) != hipSuccess) { set_error("decoder_bwd: stream fork failed"); return -5; }
+        } else RC(hop(sm, tail().fork, st));
         if (h2) {          // the logit-layer gradients deferred above
             H2PackJob pj[2] = {pack_cols(b.DLG, b.ldg, V1, SNc, b.PK_DLGT), pack_cols(w.OUTD, 3 * H, 3 * H, SNc, b.PK_OUTDT)};
             pj[1].gather = act;          // (compact: the contraction runs over the active rows of OUTD)
@@ -1746,9 +1759,11 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     }
     return 0;
     };
-    if (async_tail && config().tail_early) { RC(part_b()); RC(part_a()); }
-    else { RC(part_a()); RC(part_b()); }
-    return 0;
+    int rcp;
+    if (async_tail && config().tail_early) { rcp = part_b(); if (!rcp) rcp = part_a(); }
+    else { rcp = part_a(); if (!rcp) rcp = part_b(); }
+    fork_event(nullptr);
+    return rcp;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -265,6 +265,25 @@ def decoder_prepare_cancel():
     L.check(L.load().echr_decoder_fwd_prepare_cancel(L.stream_ptr()), 'decoder_fwd_prepare_cancel')
 
 
+class ColMean(torch.autograd.Function):
+    """x.mean(0) of a [T, D] feature matrix: the 'VC' / 'VH' scene contexts (CaptionGenerator.py:95-99)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+        L.check(L.load().echr_col_mean_fwd(L.ptr(x), x.shape[0], x.shape[1], x.shape[1], L.ptr(out), L.stream_ptr()), 'col_mean_fwd')
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        T, D = ctx.shape
+        gx = torch.zeros(T, D, device=g.device, dtype=torch.float32)
+        L.check(L.load().echr_col_mean_bwd(L.ptr(_f32c(g)), T, D, D, L.ptr(gx), L.stream_ptr()), 'col_mean_bwd')
+        return gx
+
+
 class DecoderFunction(torch.autograd.Function):
     """OldModel.forward with the ThreeStream core (OldModel_NEW.py:98-137, :376-401, :801-823): log-probs [N,S,V1]."""
 

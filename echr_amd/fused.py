@@ -199,6 +199,16 @@ class FusedTrainStep(object):
             raise ValueError('labels have %d rows for %d events' % (labels.shape[0], N))
         c3d, lda = EF._f32c(c3d_feats), EF._f32c(lda_feats)
         tap = None if tap_feats is None else EF._f32c(tap_feats)
+        vt = m.opt.video_context_type
+        if vt != 'VL':
+            # scene context 'VC' / 'VH' (CaptionGenerator.py:87-104): the mean rows are formed ahead of the call (two small launches); what the
+            # library sees as its `video` vector is the concatenation.  'VH' makes the scene vector a function of tap_feats: its gradient is
+            # not routed back through this path
+            if 'VH' in vt and (tap is None or tap_grad is not None):
+                raise NotImplementedError("video_context_type with 'VH': the one-call path has no d tap_feats through the scene context "
+                                          "(use the autograd path for joint training, or prepare()-free calls with tap_grad=None)")
+            with torch.no_grad():
+                lda = EF._f32c(m.get_video_context(tap, c3d, lda, ind_select_list, soi_select_list))
         self._tv_needed = int(max(soi[:, 1].max(), ind.max() + 1))
         # Criterion inputs.  On the host (numpy / CPU tensors, as the reference's loader hands them over, train.py:273-279): they travel with
         # the index vectors, and the rows whose mask is non-zero are listed -- the masked-out label positions behind a caption's end cannot

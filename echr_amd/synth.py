@@ -40,7 +40,9 @@ def state_dict_shapes(opt):
     Df = opt.d_feats
     G = opt.n_head
     tsrm_in = opt.video_dim + opt.hidden_dim          # 'ER3'
-    ev, cl, vi = opt.d_o, opt.video_dim, opt.lda_dim  # context widths for ER3 / CC / VL
+    vt = opt.video_context_type
+    vi = (opt.lda_dim if 'VL' in vt else 0) + (opt.video_dim if 'VC' in vt else 0) + (opt.hidden_dim if 'VH' in vt else 0)
+    ev, cl = opt.d_o, opt.video_dim                   # context widths for ER3 / CC; vi: VL / VC / VH (CaptionGenerator.py:56-64)
     s = {
         'fusion_model.h2a_layer.weight': (10, 10), 'fusion_model.h2a_layer.bias': (10,),
         'fusion_model.event_emb.weight': (Df, tsrm_in), 'fusion_model.event_emb.bias': (Df,),
@@ -143,6 +145,8 @@ CASES = {
     'c2': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=31)),
     # config 2/3 shape, every event 128 segments long (the dense batch 64 x 128 seg x 500-d bench workload)
     'c2full': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=41, full_len=True)),
+    # scene context from all three sources (CaptionGenerator.py:87-104): cat(lda, c3d.mean(0), tap.mean(0)), 100 + 500 + 512 wide
+    'vctx': dict(opt=dict(video_context_type='VLVCVH', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=61)),
     # EXACTLY the layout bench.py times (BASELINE config 3): 64 disjoint 128-segment events on a T_v = 8192 video
     'c3bench': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=1234, disjoint=True)),
 }

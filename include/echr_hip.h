@@ -123,6 +123,10 @@ int echr_event_pool_gather_fwd(const float* c3d, const float* tap, const int32_t
                                const int32_t* ind, float* ech, int32_t N, int32_t D, int32_t Ht, void* stream);
 int echr_event_pool_gather_bwd(const float* d_ech, const int32_t* ind, float* d_tap, int32_t N, int32_t D, int32_t Ht,
                                void* stream);
+/* Scene context 'VC' / 'VH' (CaptionGenerator.get_video_context, CaptionGenerator.py:95-99: `c3d_feats.mean(0)`, `tap_feats.mean(0)`):
+ * out[c] = mean over the `rows` rows of x[:, c] (x row-major with leading dimension ld); bwd: gx[r, c] += g[c] / rows. */
+int echr_col_mean_fwd(const float* x, int32_t rows, int32_t cols, int64_t ld, float* out, void* stream);
+int echr_col_mean_bwd(const float* g, int32_t rows, int32_t cols, int64_t ld, float* gx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * TSRM event-relation encoder.  Replaces MA_Attention8.forward (MA_attention_8_NEW.py:35-49) and

@@ -91,9 +91,16 @@ def tsrm_forward(P, feats, soi, n_head=16, drop_mask=None, prefix='fusion_model.
 # context builders: CaptionGenerator.py
 # ----------------------------------------------------------------------------------------------
 
-def video_context(lda):
-    """'VL' scene context.  CaptionGenerator.py:87-104."""
-    return lda
+def video_context(lda, c3d=None, tap=None, video_context_type='VL'):
+    """Scene context: 'VL' -> lda_feats, 'VC' -> c3d_feats.mean(0), 'VH' -> tap_feats.mean(0), concatenated.  CaptionGenerator.py:87-104."""
+    parts = []
+    if 'VL' in video_context_type:
+        parts.append(lda)
+    if 'VC' in video_context_type:
+        parts.append(c3d.mean(0))
+    if 'VH' in video_context_type:
+        parts.append(tap.mean(0))
+    return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
 
 
 def event_pool(c3d, soi):
@@ -245,9 +252,9 @@ def lm_criterion(logp, target, mask):
     return nll.sum() / (mask.sum() + 1e-6)
 
 
-def caption_forward(P, tap, c3d, lda, labels, ind, soi, mode='train', drop=None, n_head=16, seq_length=None):
+def caption_forward(P, tap, c3d, lda, labels, ind, soi, mode='train', drop=None, n_head=16, seq_length=None, video_context_type='VL'):
     """CaptionGenerator.forward for the live modes 'train' / 'eval'.  CaptionGenerator.py:17-43."""
-    video = video_context(lda)
+    video = video_context(lda, c3d, tap, video_context_type)
     N = len(soi)
     dmask = drop('tsrm', 0, (N, n_head, N)) if drop is not None else None
     event = event_context(P, tap, c3d, ind, soi, n_head, dmask)

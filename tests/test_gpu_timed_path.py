@@ -273,3 +273,61 @@ def test_peaked_regime_timed_path_vs_reference():
                     assert U.grad_close(k, p.grad.detach().cpu().numpy(), rgrads[k], TOL_GRAD_PEAKED_ALT), (cfg, k, U.relerr(p.grad.detach().cpu().numpy(), rgrads[k]))
     finally:
         lib.echr_config_set(b'gemm_h2', 1); lib.echr_config_set(b'gemm_bf16x3', 1); lib.echr_config_set(b'persist_h2', 1)
+
+
+# ---- scene-context variants (CaptionGenerator.py:87-104: 'VC' = c3d_feats.mean(0), 'VH' = tap_feats.mean(0)) ------------------------------
+
+@pytest.mark.parametrize('vt', ['VLVCVH', 'VC', 'VLVH'])
+def test_scene_context_variants_vs_oracle(vt):
+    """Every combination's scene vector feeds stream 2's gates: log-probs, loss, every parameter gradient AND d tap_feats (through 'VH' and
+    through the event encoder's anchors) against the oracle; 'VLVCVH' is additionally pinned to the reference by case_vctx.npz."""
+    from echr_amd.misc.utils import LanguageModelCriterion
+    from oracle import echr_ref_cpu as O
+    from tests.test_gpu_parity import TOL_LOGP
+    opt = synth.default_opt(vocab_size=300, seq_length=7, video_context_type=vt)
+    params = synth.make_params(opt, 4)
+    vid = synth.make_video(12, 40, 9, 301, seed=61)
+    m = U.build_gpu_model(opt, params, True)
+    dev = torch.device('cuda')
+    tap = torch.from_numpy(vid['tap']).to(dev).requires_grad_(True)
+    c3d, lda = torch.from_numpy(vid['c3d']).to(dev), torch.from_numpy(vid['lda']).to(dev)
+    labels, masks = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    pred = m(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train')
+    loss = LanguageModelCriterion()(pred, labels[:, 1:].to(dev), masks[:, 1:].to(dev))
+    loss.backward()
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    otap = torch.from_numpy(vid['tap']).requires_grad_(True)
+    opred = O.caption_forward(P, otap, torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), labels, vid['ind'], vid['soi'], 'train',
+                              U.oracle_drop(opt), opt.n_head, video_context_type=vt)
+    oloss = O.lm_criterion(opred, labels[:, 1:], masks[:, 1:])
+    oloss.backward()
+    assert np.abs(pred.detach().cpu().numpy() - opred.detach().numpy()).max() < TOL_LOGP
+    assert abs(float(loss) - float(oloss)) < TOL_LOSS * abs(float(oloss))
+    for k, p in m.named_parameters():
+        if P[k].grad is None:
+            assert p.grad is None, k
+        else:
+            assert U.grad_close(k, p.grad.cpu().numpy(), P[k].grad.numpy(), TOL_GRAD), (k, U.relerr(p.grad.cpu().numpy(), P[k].grad.numpy()))
+    assert U.grad_close('tap_feats', tap.grad.cpu().numpy(), otap.grad.numpy(), TOL_GRAD), U.relerr(tap.grad.cpu().numpy(), otap.grad.numpy())
+    if 'VH' in vt:          # every row of tap_feats receives the mean's share of the scene-context gradient
+        assert float((tap.grad.abs().sum(1) > 0).float().mean()) == 1.0
+
+
+def test_scene_context_through_the_one_call_path():
+    """echr_train_step with a 'VLVC' scene vector (formed ahead of the call): loss and gradients against the oracle; 'VH' with d tap_feats
+    asked for is refused (the one-call path does not route that gradient)."""
+    opt = synth.default_opt(vocab_size=300, seq_length=7, video_context_type='VLVC')
+    params = synth.make_params(opt, 4)
+    vid = synth.make_video(12, 40, 9, 301, seed=61)
+    _, rloss, rgrads = U.run_oracle(opt, params, vid, True)
+    m, o, f = _fused(opt, params)
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False))
+    assert abs(loss - rloss) < TOL_LOSS * abs(rloss)
+    for k, p in m.named_parameters():
+        if rgrads[k] is not None:
+            assert U.grad_close(k, p.grad.cpu().numpy(), rgrads[k], TOL_GRAD), (k, U.relerr(p.grad.cpu().numpy(), rgrads[k]))
+    opt2 = synth.default_opt(vocab_size=300, seq_length=7, video_context_type='VH')
+    m2, o2, f2 = _fused(opt2, synth.make_params(opt2, 4))
+    with pytest.raises(NotImplementedError):
+        f2(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False, tap_grad=torch.zeros_like(tap))
