@@ -593,8 +593,9 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (storage and accumulation are fp32; the reverse recurrences use native fp32 MFMAs; the 11 large batched projections '
-                     'and the forward recurrences run as fp16-pair "h2" MFMA emulation: 2 scaled fp16 planes per operand, 3 products, fp32 '
-                     'accumulate; parity-gated at 1e-5 on random-init AND peaked-softmax fixtures; native_f32 = the same run with every product on fp32 MFMAs)',
+                     'and the forward recurrences run as fp16-pair "h2" MFMA emulation: 2 block-scaled fp16 planes per operand, 3 products, fp32 '
+                     'accumulate; gradients within 1e-5 of the reference on its random-init AND peaked-softmax fixtures (tests/golden/case_peaked.npz); '
+                     'native_f32 = the same run with every product on fp32 MFMAs)',
             'data': 'synthetic',
             'config': {'workload': res['workload'],
                        'global_events': N_EV * world, 'timesteps_per_step': S_STEPS, 'parallelism': 'dp%d' % world,

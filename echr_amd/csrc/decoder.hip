@@ -1577,7 +1577,7 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     // async_tail = 2: only d event (what the caller's next backward kernels, the event encoder's, wait for) is formed on the caller's stream,
     // first; the rest of part A -- nine transposing packs, the grouped weight-gradient product, bias sums, the context halves of W_ih: ~0.13 ms
     // -- moves to the prepare stream (idle during a backward pass) and is joined by echr_stream_join like the tail
-    static const int dxt_stream = [] { const char* e = getenv("ECHR_DXT_STREAM"); return (e && e[0] == '1') ? 1 : 2; }();
+    static const int dxt_stream = [] { const char* e = getenv("ECHR_DXT_STREAM"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();          // 0 = the caller's stream
     bool dxt_done = false;
     //    token embedding: dXT = sum_k DG_k . W_ih_k[:, :E], scatter-added into the (caller-zeroed) table gradient.  Reads what the recurrence
     //    left (DG) and parameters only, so the chain can ride on either helper stream (ECHR_DXT_STREAM: 1 = tail stream, 2 = prepare stream
@@ -1751,7 +1751,7 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     d.beta = zb;
     RC(gemm(d, st));
     if (!z) RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
-    if (!dxt_done) RC(dxt_chain(st));
+    if (!dxt_done && !(async_tail && dxt_stream == 0)) RC(dxt_chain(st));
     if (async_tail) {
         if (hipEventRecord(tail().done, st) != hipSuccess) { set_error("decoder_bwd: event record failed"); return -5; }
         tail().pending = true;
@@ -1763,6 +1763,7 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     if (async_tail && config().tail_early) { rcp = part_b(); if (!rcp) rcp = part_a(); }
     else { rcp = part_a(); if (!rcp) rcp = part_b(); }
     fork_event(nullptr);
+    if (!rcp && !dxt_done && do_pb) rcp = dxt_chain(sm);          // (ECHR_DXT_STREAM=0: on the caller's stream, ahead of the event encoder's backward)
     return rcp;
 }
 

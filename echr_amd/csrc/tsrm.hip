@@ -293,7 +293,8 @@ static TsrmWs carve(int N, int Din, int Df, int Do, int G, float* base) {
     w.total = off;
     return w;
 }
-struct TsrmWsB { float *DWD, *DGATE, *DAFF, *DQ, *DK, *DXW, *DX, *DP1, *PK_DP1T, *PK_POST; long total; };
+struct TsrmWsB { float *DWD, *DGATE, *DAFF, *DQ, *DK, *DXW, *DX, *DP1, *PK_DP1T, *PK_POST, *PMP; long total; };
+constexpr int PM_ROWS = 32, PM_LD = 16 * 512 + 512 + 64;          // pair_mlp_bwd_kernel: pair rows per block; floats per block of its partial sums (d W_fc2 | d b_fc1 | d b_fc2)
 static TsrmWsB carve_b(int N, int Din, int Df, int Do, int G, float* base) {
     TsrmWsB w;
     long off = 0;
@@ -303,8 +304,68 @@ static TsrmWsB carve_b(int N, int Din, int Df, int Do, int G, float* base) {
     w.DQ = take((long)N * Df); w.DK = take((long)N * Df); w.DXW = take((long)N * Do); w.DX = take((long)N * Df);
     w.DP1 = take(NN * Df);
     w.PK_DP1T = take(h2_floats(Df, (int)NN)); w.PK_POST = take(h2_floats(Df, (int)NN));  // transposed packs for the fc1 weight gradient
+    w.PMP = take(((NN + PM_ROWS - 1) / PM_ROWS) * (long)PM_LD);                          // per-block partial sums of pair_mlp_bwd_kernel
     w.total = off;
     return w;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Position-MLP backward in ONE pass over the fc1 activations of the N^2 pairs (MA_attention_8_NEW.py:108-116 backward):
+//     d P1   = (d GATE . W_fc2) * (1 - P1^2)      [NN, 512]   (gradient at the input of tanh: feeds d W_fc1)
+//     d W_fc2 += d GATE^T . P1                    [16, 512]
+//     d b_fc1 += column sums of d P1,  d b_fc2 += column sums of d GATE
+// A thread owns two adjacent fc1 columns: its 16 x 2 slice of W_fc2 and its 16 x 2 accumulators of d W_fc2 live in registers; a block walks
+// PM_ROWS pair rows (d GATE rows through LDS, broadcast reads).  Replaces two fp32 GEMM launches whose shapes (M = 16, resp. K = 16) left them
+// latency-bound (68 + 17 us beside the backward tail's other kernels) and two of the six column-sum jobs.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restrict__ DGATE, const float* __restrict__ P1, const float* __restrict__ W2,
+                                                           float* __restrict__ DP1, float* __restrict__ PART, int NN) {
+    constexpr int G = 16, Df = 512;
+    __shared__ float dg[PM_ROWS][G];
+    const int tid = threadIdx.x, c0 = 2 * tid;
+    const long r0 = (long)blockIdx.x * PM_ROWS;
+    const int nr = (int)min((long)PM_ROWS, (long)NN - r0);
+    for (int i = tid; i < PM_ROWS * G; i += 256) dg[i / G][i % G] = (i / G) < nr ? DGATE[(r0 + i / G) * G + (i % G)] : 0.f;
+    float2 w2[G], gw[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { w2[g] = *reinterpret_cast<const float2*>(W2 + (long)g * Df + c0); gw[g] = make_float2(0.f, 0.f); }
+    float2 pv[PM_ROWS / 4];
+    float2 bsum = make_float2(0.f, 0.f);
+    __syncthreads();
+#pragma unroll 1          // (fully unrolled the compiler hoisted every load of the block and spilled 850 registers: 270 us instead of 10)
+    for (int rb = 0; rb < PM_ROWS; rb += PM_ROWS / 4) {
+#pragma unroll
+        for (int i = 0; i < PM_ROWS / 4; ++i) pv[i] = (rb + i) < nr ? *reinterpret_cast<const float2*>(P1 + (r0 + rb + i) * Df + c0) : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < PM_ROWS / 4; ++i) {
+            const int r = rb + i;
+            float2 sacc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int g4 = 0; g4 < G; g4 += 4) {
+                const float4 d4 = *reinterpret_cast<const float4*>(&dg[r][g4]);
+                const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sacc.x = fmaf(dv[j], w2[g4 + j].x, sacc.x); sacc.y = fmaf(dv[j], w2[g4 + j].y, sacc.y);
+                    gw[g4 + j].x = fmaf(dv[j], pv[i].x, gw[g4 + j].x); gw[g4 + j].y = fmaf(dv[j], pv[i].y, gw[g4 + j].y);
+                }
+            }
+            const float2 dp = make_float2(sacc.x * (1.f - pv[i].x * pv[i].x), sacc.y * (1.f - pv[i].y * pv[i].y));
+            if (r < nr) *reinterpret_cast<float2*>(DP1 + (r0 + r) * Df + c0) = dp;
+            bsum.x += dp.x; bsum.y += dp.y;
+        }
+    }
+    // per-block partial sums, plain coalesced stores: [16 x 512] d W_fc2 | [512] d b_fc1 | [16] d b_fc2; a multi-problem column-sum launch folds
+    // the blocks (128 blocks adding atomically into the same 8.7 K addresses ran at the contended-atomic rate: 100 us)
+    float* part = PART + (long)blockIdx.x * PM_LD;
+#pragma unroll
+    for (int g = 0; g < G; ++g) *reinterpret_cast<float2*>(part + g * Df + c0) = gw[g];
+    *reinterpret_cast<float2*>(part + G * Df + c0) = bsum;
+    if (tid < G) {
+        float s = 0.f;
+        for (int r = 0; r < nr; ++r) s += dg[r][tid];
+        part[G * Df + Df + tid] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -803,12 +864,20 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
     hipStream_t sp = (config().tsrm_fork && !fork2_off && part == 0) ? aux2_fork(st) : nullptr;
     const bool fork2 = sp != nullptr;
     if (!fork2) sp = st;
+    // one streaming pass instead of two latency-bound fp32 products + two column sums (pair_mlp_bwd_kernel; ECHR_TSRM_PAIR_BWD=0: the products)
+    static const bool pm_off = [] { const char* e = getenv("ECHR_TSRM_PAIR_BWD"); return e && e[0] == '0'; }();
+    const bool pair_fused = z && !pm_off && Df == 512 && G == 16 && ((reinterpret_cast<uintptr_t>(w.P1) | reinterpret_cast<uintptr_t>(a->w_fc2) | reinterpret_cast<uintptr_t>(b.DP1)) & 15) == 0;
     if (rest_part) {
         // position MLP (depends on d GATE only)
+        if (pair_fused) {
+            hipLaunchKernelGGL(pair_mlp_bwd_kernel, dim3((NN + PM_ROWS - 1) / PM_ROWS), dim3(256), 0, sp, b.DGATE, w.P1, a->w_fc2, b.DP1, b.PMP, NN);
+            RC(check_launch("pair_mlp_bwd"));
+        } else {
         d = desc_tn(b.DGATE, G, w.P1, Df, g->g_w_fc2, Df, G, Df, NN); d.beta = zb; d.split_k = -1;
         RC(gemm(d, sp));
         d = desc_nn(b.DGATE, G, a->w_fc2, Df, b.DP1, Df, NN, Df, G); d.act = ECHR_ACT_MUL_DTANH; d.aux = w.P1; d.ld_aux = Df;
         RC(gemm(d, sp));
+        }
         if (config().gemm_h2 && NN >= 1024) {
             H2PackJob pj[2] = {pack_cols(b.DP1, Df, Df, NN, b.PK_DP1T), pack_cols(w.POS, Df, Df, NN, b.PK_POST)};
             RC(h2_pack_multi(pj, 2, sp));
@@ -862,7 +931,10 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
     // Only for callers that keep the workspaces alive until that join (echr_train_step: tsrm_bwd_defer_join); the plain entry joins here
     if (z && fork2 && g_tsrm_nojoin) {
         const ColsumJob cp[2] = {{b.DGATE, G, NN, G, g->g_b_fc2, nullptr, nullptr}, {b.DP1, Df, NN, Df, g->g_b_fc1, nullptr, nullptr}};
-        RC(colsum_multi(cp, 2, sp));
+        const int nblk = (NN + PM_ROWS - 1) / PM_ROWS;
+        const ColsumJob cq[3] = {{b.PMP, PM_LD, nblk, G * Df, g->g_w_fc2, nullptr, nullptr}, {b.PMP + G * Df, PM_LD, nblk, Df, g->g_b_fc1, nullptr, nullptr},
+                                 {b.PMP + G * Df + Df, PM_LD, nblk, G, g->g_b_fc2, nullptr, nullptr}};
+        if (pair_fused) RC(colsum_multi(cq, 3, sp)); else RC(colsum_multi(cp, 2, sp));
         RC(aux2_publish());
         const ColsumJob cj[4] = {{g->g_out, Do, N, Do, g->g_b_out, nullptr, nullptr}, {b.DQ, Df, N, Df, g->g_b_q, nullptr, nullptr},
                                  {b.DK, Df, N, Df, g->g_b_k, nullptr, nullptr},        {b.DX, Df, N, Df, g->g_b_emb, nullptr, nullptr}};
@@ -871,9 +943,14 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
     if (fork2) RC(aux2_join(st));
     if (z) {
         const ColsumJob cj[6] = {{g->g_out, Do, N, Do, g->g_b_out, nullptr, nullptr}, {b.DQ, Df, N, Df, g->g_b_q, nullptr, nullptr},
-                                 {b.DK, Df, N, Df, g->g_b_k, nullptr, nullptr},        {b.DGATE, G, NN, G, g->g_b_fc2, nullptr, nullptr},
-                                 {b.DP1, Df, NN, Df, g->g_b_fc1, nullptr, nullptr},    {b.DX, Df, N, Df, g->g_b_emb, nullptr, nullptr}};
-        RC(colsum_multi(cj, 6, st));
+                                 {b.DK, Df, N, Df, g->g_b_k, nullptr, nullptr},        {b.DX, Df, N, Df, g->g_b_emb, nullptr, nullptr},
+                                 {b.DGATE, G, NN, G, g->g_b_fc2, nullptr, nullptr},    {b.DP1, Df, NN, Df, g->g_b_fc1, nullptr, nullptr}};
+        ColsumJob cf[7] = {cj[0], cj[1], cj[2], cj[3]};
+        const int nblk = (NN + PM_ROWS - 1) / PM_ROWS;          // pair_fused: the per-block partials of pair_mlp_bwd_kernel -> d W_fc2, d b_fc1, d b_fc2
+        cf[4] = ColsumJob{b.PMP, PM_LD, nblk, G * Df, g->g_w_fc2, nullptr, nullptr};
+        cf[5] = ColsumJob{b.PMP + G * Df, PM_LD, nblk, Df, g->g_b_fc1, nullptr, nullptr};
+        cf[6] = ColsumJob{b.PMP + G * Df + Df, PM_LD, nblk, G, g->g_b_fc2, nullptr, nullptr};
+        if (pair_fused) RC(colsum_multi(cf, 7, st)); else RC(colsum_multi(cj, 6, st));
     } else {
         RC(colsum(b.DQ, Df, N, Df, g->g_b_q, false, st));
         RC(colsum(b.DK, Df, N, Df, g->g_b_k, false, st));

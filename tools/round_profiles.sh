@@ -4,7 +4,7 @@
 #   <tag>_pmc_traffic.json / <tag>_pmc_mfma.json (separate --pmc passes, commit hash stored inside), <tag>_rocprof_kernel_stats_final.txt
 #   (rocprofv3 --kernel-trace --stats of the bench command), <tag>_bench_final.json (the bench line, written AFTER the PMC files so that
 #   it carries their traffic numbers), the same pair for --c5, and the greedy decoder's kernel stats / timings / stamps.  Results land in gpurun_out/<tag>_profiles/ (copy them into profiles/).
-tag=${1:-r04}; commit=${2:-unknown}
+tag=${1:-r05}; commit=${2:-unknown}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/${tag}_profiles
 rm -rf $out; mkdir -p $out
@@ -21,9 +21,9 @@ bash tools/pmc_mfma.sh ${tag}_pmc_mfma_raw5 --c5 > $out/pmc_mfma_c5.log 2>&1
 python3 tools/pmc_mfma_summary.py gpurun_out/${tag}_pmc_mfma_raw5 $commit > $out/${tag}_pmc_mfma_c5.json && cp $out/${tag}_pmc_mfma_c5.json profiles/
 rm -rf gpurun_out/${tag}_pmc_traffic_raw5 gpurun_out/${tag}_pmc_mfma_raw5
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $root/bench.py --steps 12 --warmup 3 --no-cpu --no-roofline --no-native > $out/prof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $root/bench.py --steps 12 --warmup 3 --regions 1 --no-others --no-cpu --no-roofline --no-native > $out/prof.log 2>&1
 python3 $root/tools/prof_summary.py $out/prof 15 40 > $out/${tag}_rocprof_kernel_stats_final.txt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -- python3 $root/bench.py --c5 --steps 12 --warmup 3 --no-cpu --no-roofline --no-native > $out/prof5.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -- python3 $root/bench.py --c5 --steps 12 --warmup 3 --regions 1 --no-others --no-cpu --no-roofline --no-native > $out/prof5.log 2>&1
 python3 $root/tools/prof_summary.py $out/prof5 15 40 > $out/${tag}_rocprof_kernel_stats_c5.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profs -- python3 $root/tools/sample_bench.py 64 > $out/profs.log 2>&1
 python3 $root/tools/prof_summary.py $out/profs 7 30 > $out/${tag}_rocprof_kernel_stats_sampler64.txt          # 2 warm-up + 5 timed decodes
@@ -42,7 +42,7 @@ timeout -k 10 400 python3 bench.py --c5 > $out/${tag}_bench_c5.json 2> $out/benc
 # BASELINE config 2 (forward + criterion only, train-mode dropout): bench line and kernel stats
 timeout -k 10 300 python3 bench.py --mode fwd --no-cpu > $out/${tag}_bench_c2.json 2> $out/bench2.err; echo bench2_exit=$?
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof2 -- python3 $root/bench.py --mode fwd --steps 12 --warmup 3 --no-cpu --no-roofline --no-native > $out/prof2.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof2 -- python3 $root/bench.py --mode fwd --steps 12 --warmup 3 --regions 1 --no-others --no-cpu --no-roofline --no-native > $out/prof2.log 2>&1
 python3 $root/tools/prof_summary.py $out/prof2 15 30 > $out/${tag}_rocprof_kernel_stats_c2.txt; rm -rf $out/prof2
 cd $root
 timeout -k 10 120 python3 tools/host_time.py > $out/${tag}_host_time.txt 2>&1; timeout -k 10 120 python3 tools/host_time.py autograd >> $out/${tag}_host_time.txt 2>&1
