@@ -25,9 +25,9 @@ class CaptionGenerator(nn.Module):
             self.fusion_model = models.setup_fusion(opt)
         self.lm_model = models.setup_lm(opt)
         self.overlap_encoder = os.environ.get('ECHR_OVERLAP_ENCODER', '1') != '0'        # 'train' mode: run the decoder's event-independent precompute concurrently with the event encoder
-        if not any(k in opt.video_context_type for k in ('VL', 'VC', 'VH')) or opt.event_context_type != 'ER3' or opt.clip_context_type != 'CC':
+        if not any(k in opt.video_context_type for k in ('VL', 'VC', 'VH')) or opt.event_context_type not in ('ER1', 'ER2', 'ER3') or opt.clip_context_type != 'CC':
             raise NotImplementedError('the HIP path implements the ECHR recipe: video_context_type from VL / VC / VH (any combination), '
-                                      'event_context_type=ER3, clip_context_type=CC (experiments/train_ECHR.sh)')
+                                      'event_context_type ER1 / ER2 / ER3, clip_context_type=CC (experiments/train_ECHR.sh)')
 
     def _require_live_decoder(self):
         if type(self.lm_model).__name__ != 'ThreestreamModel':
@@ -100,9 +100,11 @@ class CaptionGenerator(nn.Module):
         return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
 
     def get_event_context(self, tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=None, _drop=None):
-        """'ER3': TSRM over cat(mean-pooled C3D, SST state at the anchor) (CaptionGenerator.py:106-130)."""
+        """TSRM over the per-event features (CaptionGenerator.py:106-130): 'ER1' the mean-pooled C3D rows, 'ER2' the SST state at the anchor,
+        'ER3' (the recipe) both, concatenated."""
         ev_start, ev_len, ind, _ = _ev if _ev is not None else EF.event_index_tensors(soi_select_list, ind_select_list, c3d_feats.device)
-        ech = EF.EventPoolGather.apply(c3d_feats, tap_feats, ev_start, ev_len, ind)
+        parts = {'ER1': 1, 'ER2': 2, 'ER3': 3}[self.opt.event_context_type]
+        ech = EF.EventPoolGather.apply(c3d_feats, tap_feats, ev_start, ev_len, ind, parts)
         return self.fusion_model(ech, soi_select_list, ev_tensors=(ev_start, ev_len), drop=_drop)
 
     def get_clip_context(self, tap_feats, c3d_feats, lda_feats, ind_select_list, soi_select_list, _ev=None):

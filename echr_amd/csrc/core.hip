@@ -643,6 +643,7 @@ __global__ __launch_bounds__(256) void event_pool_gather_kernel(const float* __r
         o[c0 + threadIdx.x] = t / (float)len;
     }
     // the anchor's SST state: the chunks share the Ht columns
+    if (Ht == 0) return;
     const long trow = ind[n];
     const int per = (Ht + gridDim.y - 1) / gridDim.y, j0 = blockIdx.y * per;
     for (int j = j0 + threadIdx.x; j < min(Ht, j0 + per); j += 256) o[D + j] = tap[trow * Ht + j];
@@ -958,9 +959,10 @@ extern "C" int echr_col_mean_bwd(const float* g, int32_t rows, int32_t cols, int
 
 extern "C" int echr_event_pool_gather_fwd(const float* c3d, const float* tap, const int32_t* ev_start, const int32_t* ev_len,
                                           const int32_t* ind, float* ech, int32_t N, int32_t D, int32_t Ht, void* stream) {
-    ECHR_REQUIRE(c3d && tap && ev_start && ev_len && ind && ech && N > 0 && D > 0 && Ht > 0, "event_pool_gather_fwd: bad arguments");
+    // D = 0: the anchors' SST states only ('ER2', CaptionGenerator.py:120-125); Ht = 0: the pooled C3D rows only ('ER1', :109-117)
+    ECHR_REQUIRE(ev_start && ev_len && ind && ech && N > 0 && D >= 0 && Ht >= 0 && D + Ht > 0 && (c3d || D == 0) && (tap || Ht == 0), "event_pool_gather_fwd: bad arguments");
     const int vec = (D % 4 == 0) && ((uintptr_t)c3d % 16 == 0) && D >= 4;
-    hipLaunchKernelGGL(event_pool_gather_kernel, dim3(N, (D + 63) / 64), dim3(256), 0, (hipStream_t)stream, c3d, tap, ev_start, ev_len, ind, ech, D,
+    hipLaunchKernelGGL(event_pool_gather_kernel, dim3(N, D > 0 ? (D + 63) / 64 : 1), dim3(256), 0, (hipStream_t)stream, c3d, tap, ev_start, ev_len, ind, ech, D,
                        Ht, vec);
     return check_launch("event_pool_gather_fwd");
 }

@@ -318,7 +318,7 @@ static TsrmWsB carve_b(int N, int Din, int Df, int Do, int G, float* base) {
 // PM_ROWS pair rows (d GATE rows through LDS, broadcast reads).  Replaces two fp32 GEMM launches whose shapes (M = 16, resp. K = 16) left them
 // latency-bound (68 + 17 us beside the backward tail's other kernels) and two of the six column-sum jobs.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restrict__ DGATE, const float* __restrict__ P1, const float* __restrict__ W2,
+__global__ __launch_bounds__(256, 4) void pair_mlp_bwd_kernel(const float* __restrict__ DGATE, const float* __restrict__ P1, const float* __restrict__ W2,
                                                            float* __restrict__ DP1, float* __restrict__ PART, int NN) {
     constexpr int G = 16, Df = 512;
     __shared__ float dg[PM_ROWS][G];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void pair_mlp_bwd_kernel(const float* __restri
     for (int rb = 0; rb < PM_ROWS; rb += PM_ROWS / 4) {
 #pragma unroll
         for (int i = 0; i < PM_ROWS / 4; ++i) pv[i] = (rb + i) < nr ? *reinterpret_cast<const float2*>(P1 + (r0 + rb + i) * Df + c0) : make_float2(0.f, 0.f);
-#pragma unroll
+#pragma unroll 1
         for (int i = 0; i < PM_ROWS / 4; ++i) {
             const int r = rb + i;
             float2 sacc = make_float2(0.f, 0.f);

@@ -125,13 +125,15 @@ class GradSink(object):
 
 # --------------------------------------------------------------------------------------------------
 class EventPoolGather(torch.autograd.Function):
-    """ech = [mean-pooled C3D rows | tap[ind]]  (CaptionGenerator.py:111-114,121,128)."""
+    """ech = [mean-pooled C3D rows | tap[ind]]  (CaptionGenerator.py:111-114,121,128); `parts`: 3 = both ('ER3'), 1 = the pooled rows only
+    ('ER1'), 2 = the anchors' SST states only ('ER2')."""
 
     @staticmethod
-    def forward(ctx, c3d, tap, ev_start, ev_len, ind):
+    def forward(ctx, c3d, tap, ev_start, ev_len, ind, parts=3):
         lib = L.load()
         c3d, tap = _f32c(c3d), _f32c(tap)
-        N, D, Ht = ev_start.numel(), c3d.shape[1], tap.shape[1]
+        N = ev_start.numel()
+        D, Ht = (c3d.shape[1] if parts & 1 else 0), (tap.shape[1] if parts & 2 else 0)
         ech = torch.empty(N, D + Ht, device=c3d.device, dtype=torch.float32)
         L.check(lib.echr_event_pool_gather_fwd(L.ptr(c3d), L.ptr(tap), L.ptr(ev_start, torch.int32), L.ptr(ev_len, torch.int32),
                                                L.ptr(ind, torch.int32), L.ptr(ech), N, D, Ht, L.stream_ptr()), 'event_pool_gather_fwd')
@@ -145,11 +147,11 @@ class EventPoolGather(torch.autograd.Function):
         (ind,) = ctx.saved_tensors
         tap_shape, D, Ht, N = ctx.shape
         g_tap = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and Ht > 0:
             g_tap = torch.zeros(tap_shape, device=g_ech.device, dtype=torch.float32)
             L.check(lib.echr_event_pool_gather_bwd(L.ptr(_f32c(g_ech)), L.ptr(ind, torch.int32), L.ptr(g_tap), N, D, Ht,
                                                    L.stream_ptr()), 'event_pool_gather_bwd')
-        return None, g_tap, None, None, None
+        return None, g_tap, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------

@@ -39,7 +39,8 @@ def state_dict_shapes(opt):
     D = opt.video_dim
     Df = opt.d_feats
     G = opt.n_head
-    tsrm_in = opt.video_dim + opt.hidden_dim          # 'ER3'
+    et = opt.event_context_type                       # TSRM input (MA_attention_8_NEW.py:13-20): ER1 pooled C3D, ER2 SST state, ER3 both
+    tsrm_in = opt.video_dim if 'ER1' in et else (opt.hidden_dim if 'ER2' in et else opt.video_dim + opt.hidden_dim)
     vt = opt.video_context_type
     vi = (opt.lda_dim if 'VL' in vt else 0) + (opt.video_dim if 'VC' in vt else 0) + (opt.hidden_dim if 'VH' in vt else 0)
     ev, cl = opt.d_o, opt.video_dim                   # context widths for ER3 / CC; vi: VL / VC / VH (CaptionGenerator.py:56-64)
@@ -147,6 +148,9 @@ CASES = {
     'c2full': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=41, full_len=True)),
     # scene context from all three sources (CaptionGenerator.py:87-104): cat(lda, c3d.mean(0), tap.mean(0)), 100 + 500 + 512 wide
     'vctx': dict(opt=dict(video_context_type='VLVCVH', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=61)),
+    # event-context variants (CaptionGenerator.py:106-130): TSRM over the pooled C3D rows only / the anchors' SST states only
+    'er1': dict(opt=dict(event_context_type='ER1', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=62)),
+    'er2': dict(opt=dict(event_context_type='ER2', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=63)),
     # EXACTLY the layout bench.py times (BASELINE config 3): 64 disjoint 128-segment events on a T_v = 8192 video
     'c3bench': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=1234, disjoint=True)),
 }

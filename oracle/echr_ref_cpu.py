@@ -108,10 +108,15 @@ def event_pool(c3d, soi):
     return torch.cat([c3d[int(s):int(e)].mean(0, keepdim=True) for s, e in soi], 0)
 
 
-def event_context(P, tap, c3d, ind, soi, n_head=16, drop_mask=None):
-    """'ER3' event context: cat(mean-pooled C3D, SST hidden at the anchor) -> TSRM.  CaptionGenerator.py:106-130."""
+def event_context(P, tap, c3d, ind, soi, n_head=16, drop_mask=None, event_context_type='ER3'):
+    """Event context: 'ER1' mean-pooled C3D -> TSRM, 'ER2' SST hidden at the anchor -> TSRM, 'ER3' their concatenation -> TSRM.
+    CaptionGenerator.py:106-130."""
     ec = event_pool(c3d, soi)
+    if 'ER1' in event_context_type:
+        return tsrm_forward(P, ec, soi, n_head, drop_mask)                                # :115-117
     eh = tap[torch.as_tensor(np.asarray(ind), dtype=torch.long)]                          # :121
+    if 'ER2' in event_context_type:
+        return tsrm_forward(P, eh, soi, n_head, drop_mask)                                # :123-125
     return tsrm_forward(P, torch.cat((ec, eh), 1), soi, n_head, drop_mask)
 
 
@@ -252,12 +257,13 @@ def lm_criterion(logp, target, mask):
     return nll.sum() / (mask.sum() + 1e-6)
 
 
-def caption_forward(P, tap, c3d, lda, labels, ind, soi, mode='train', drop=None, n_head=16, seq_length=None, video_context_type='VL'):
+def caption_forward(P, tap, c3d, lda, labels, ind, soi, mode='train', drop=None, n_head=16, seq_length=None, video_context_type='VL',
+                    event_context_type='ER3'):
     """CaptionGenerator.forward for the live modes 'train' / 'eval'.  CaptionGenerator.py:17-43."""
     video = video_context(lda, c3d, tap, video_context_type)
     N = len(soi)
     dmask = drop('tsrm', 0, (N, n_head, N)) if drop is not None else None
-    event = event_context(P, tap, c3d, ind, soi, n_head, dmask)
+    event = event_context(P, tap, c3d, ind, soi, n_head, dmask, event_context_type)
     clip, mask = clip_context(c3d, soi)
     if mode == 'train':
         return decoder_forward(P, video, event, clip, mask, labels, drop)
