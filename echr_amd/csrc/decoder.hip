@@ -1261,14 +1261,25 @@ static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, vo
     auto logits_chunk = [&](int t0, int t1, hipStream_t q) -> int {
         // echr_train_step with the criterion's active rows: logits only for the rows that can reach the loss (compact [n_active, V1] in the
         // log-prob buffer, which nothing else reads on that path), then log-softmax + criterion + d logits in one pass over them
-        if (fz && fz->active_rows && fz->n_active > 0 && config().gemm_h2 && t0 == 0 && t1 == S && fz->nll_target && fz->nll_mask && fz->g_loss && fz->ws_bwd) {
+        static const bool native_compact = [] { const char* e = getenv("ECHR_NATIVE_COMPACT"); return !(e && e[0] == '0'); }();      // A/B switch
+        if (fz && fz->active_rows && fz->n_active > 0 && (config().gemm_h2 || native_compact) && t0 == 0 && t1 == S && fz->nll_target && fz->nll_mask && fz->g_loss && fz->ws_bwd) {
             const DecWsBwd b = carve_ws_bwd(a, fz->ws_bwd);
             if (logsoftmax_nll_dlg_ok(a->V1, b.ldg)) {
+                echr_gemm_desc dc;
+                if (config().gemm_h2) {
                 H2PackJob pj = pack_rows(w.OUTD, 3 * H, fz->n_active, 3 * H, w.PK_OUTD);
                 pj.gather = fz->active_rows;
                 RC(h2_pack_multi(&pj, 1, q));
-                echr_gemm_desc dc = desc_h2(w.PK_OUTD, w.PK_WL, a->logp, a->V1, fz->n_active, a->V1, 3 * H);
-                dc.split_k = 1; dc.bias = a->b_logit;
+                dc = desc_h2(w.PK_OUTD, w.PK_WL, a->logp, a->V1, fz->n_active, a->V1, 3 * H);
+                dc.split_k = 1;
+                } else {
+                // native fp32 / bf16x3 products: the active rows are gathered into a dense [n_active, 3H] operand (in the region the h2
+                // path packs into; the backward pass reads it again for d W_logit) and the products run on n_active rows
+                RC(embed_gather(w.OUTD, fz->active_rows, w.PK_OUTD, fz->n_active, 3 * H, S * N, q));
+                dc = desc_nt(w.PK_OUTD, 3 * H, a->w_logit, 3 * H, a->logp, a->V1, fz->n_active, a->V1, 3 * H);
+                dc.algo = ECHR_GEMM_BF16X3;
+                }
+                dc.bias = a->b_logit;
                 RC(gemm(dc, q));
                 if (fused_out) *fused_out = true;
                 if (compact_out) *compact_out = true;
@@ -1371,10 +1382,10 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     const int* act = compact ? g->active_rows : nullptr;
     // the recurrent weight gradients / d XT on the active rows too (ECHR_COMPACT_REC=0: all S*N rows, for A/B runs)
     static const bool rec_env = [] { const char* e = getenv("ECHR_COMPACT_REC"); return !(e && e[0] == '0'); }();
-    const bool crec = compact && rec_env;
+    const bool crec = compact && rec_env && config().gemm_h2;          // (the k gather rides in the h2 packs: the native products keep all rows there)
     const int SNr = crec ? SNc : SN;
     const int* actr = crec ? act : nullptr;
-    ECHR_REQUIRE(!compact || (config().gemm_h2 && g->phase == 0 && g->async_tail != 0), "decoder_bwd: active_rows needs the h2 path and the asynchronous tail");
+    ECHR_REQUIRE(!compact || (g->phase == 0 && g->async_tail != 0), "decoder_bwd: active_rows needs the asynchronous tail");
 
     ECHR_REQUIRE(g->phase >= 0 && g->phase <= 4, "decoder_bwd: phase must be 0..4");
     // stages: late fusion | reverse recurrence + LSTM-layer gradients (part A) | attention + embedding gradients (part B)
@@ -1419,6 +1430,10 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     // bf16-split matrix-core path: d W_logit = DLG^T . OUTD  and  d OUTD = DLG . W_logit.
     echr_gemm_desc d;
     const bool h2 = config().gemm_h2 && !ov;
+    static const bool native_tail = [] { const char* e = getenv("ECHR_NATIVE_TAIL"); return !(e && e[0] == '0'); }();      // A/B switch
+    const bool native_defer_wl = native_tail && !h2 && !ov && part == 0 && g->phase == 0 && g->async_tail != 0 && tail().ok;
+    ECHR_REQUIRE(h2 || !compact || native_defer_wl, "decoder_bwd: active_rows on the native product path needs the deferred logit-layer gradients");
+    const float* outd_rows = (compact && !h2) ? w.PK_OUTD : w.OUTD;          // native + compact: the forward's gathered [n_active, 3H] operand
     if (!do_a) {
     } else if (h2) {
         // d W_logit = DLG^T . OUTD and d OUTD = DLG . W_logit on h2-packed operands; the four packs (two of them transposing) are one launch
@@ -1442,15 +1457,20 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
         if (compact) { d.row_index = act; d.row_index_max = SN - 1; }          // compacted row i is row act[i] of d OUTD (the others stay zero)
         RC(gemm(d, st));
     } else {
+    // (native fp32 / bf16x3 products.  With an asynchronous tail the logit-layer gradients -- which nothing in the backward pass reads -- are formed
+    // on the tail stream behind the reverse recurrence, as on the h2 path, instead of in front of it: 0.2 ms off the caller's stream)
+    if (!native_defer_wl) {
     RC(transpose(b.DLG, b.ldg, b.DLGT, b.snp, SN, V1, (int)b.snp, sq));
     RC(transpose(w.OUTD, 3 * H, b.OUTDT, b.snp, SN, 3 * H, (int)b.snp, sq));
     d = desc_nt(b.DLGT, b.snp, b.OUTDT, b.snp, g->g_w_logit, 3 * H, V1, 3 * H, (int)b.snp);
     d.beta = zb; d.split_k = -1; d.algo = ECHR_GEMM_BF16X3;
     RC(gemm(d, sq));
     RC(colsum(b.DLG, b.ldg, SN, V1, g->g_b_logit, z, sq));
+    }
     RC(transpose(a->w_logit, 3 * H, b.WLT, b.ldg, V1, 3 * H, (int)b.ldg, st));
-    d = desc_nt(b.DLG, b.ldg, b.WLT, b.ldg, b.DOUT, 3 * H, SN, 3 * H, (int)b.ldg);
+    d = desc_nt(b.DLG, b.ldg, b.WLT, b.ldg, b.DOUT, 3 * H, SNc, 3 * H, (int)b.ldg);
     d.split_k = -1; d.algo = ECHR_GEMM_BF16X3; d.beta = 1.f;
+    if (compact) { d.row_index = act; d.row_index_max = SN - 1; d.algo = ECHR_GEMM_F32; }          // compacted row i adds into row act[i] of d OUTD
     RC(gemm(d, st));
     }
     // 3. reverse recurrence
@@ -1615,7 +1635,7 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     hipStream_t sa2 = nullptr;
     auto part_a = [&]() -> int {
     if (!do_rec) return 0;
-    if (g->phase == 0 && g->async_tail == 2 && z && h2 && !ov && tail().ok) {
+    if (g->phase == 0 && g->async_tail == 2 && z && (h2 || (native_tail && part == 0)) && !ov && tail().ok) {
         // Both helper streams fork RIGHT BEHIND the reverse recurrence, off ONE recorded event (ECHR_FORK_FIRST=0: behind d event, one record
         // each): the two records used to sit between the d event product and everything that follows on all three streams (~15 us of an idle
         // chip).  The prepare stream then forms its own copy of the per-event gate-gradient sums (6 us) instead of waiting for this stream's
@@ -1721,6 +1741,16 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
             const bool ho = handover().want;
             RC(logit_grads(a, g, w, b, z, st, !z || ho));
             bias_pending = z && !ho;
+            RC(handover_mark(ECHR_HANDOVER_LOGIT, st));
+        } else if (native_defer_wl) {
+            // (compact: SNc rows of d logits against the gathered OUTD rows; the transposes zero-pad the contraction to its padded length)
+            const int kp = (SNc + 3) / 4 * 4;
+            RC(transpose(b.DLG, b.ldg, b.DLGT, b.snp, SNc, V1, kp, st));
+            RC(transpose(outd_rows, 3 * H, b.OUTDT, b.snp, SNc, 3 * H, kp, st));
+            d = desc_nt(b.DLGT, b.snp, b.OUTDT, b.snp, g->g_w_logit, 3 * H, V1, 3 * H, kp);
+            d.beta = zb; d.split_k = -1; d.algo = ECHR_GEMM_BF16X3;
+            RC(gemm(d, st));
+            RC(colsum(b.DLG, b.ldg, SNc, V1, g->g_b_logit, z, st));
             RC(handover_mark(ECHR_HANDOVER_LOGIT, st));
         }
     }
