@@ -32,7 +32,8 @@ class TsrmArgs(C.Structure):
     _fields_ = [('N', i32), ('Din', i32), ('Df', i32), ('Do', i32), ('G', i32),
                 ('w_emb', c_f), ('b_emb', c_f), ('w_fc1', c_f), ('b_fc1', c_f), ('w_fc2', c_f), ('b_fc2', c_f),
                 ('w_q', c_f), ('b_q', c_f), ('w_k', c_f), ('b_k', c_f), ('w_out', c_f), ('b_out', c_f),
-                ('ech', c_f), ('ev_start', c_f), ('ev_len', c_f), ('ws', c_f), ('out', c_f), ('inference', i32), ('max_len', i32), ('max_span', i32)]
+                ('ech', c_f), ('ev_start', c_f), ('ev_len', c_f), ('ws', c_f), ('out', c_f), ('inference', i32), ('max_len', i32), ('max_span', i32),
+                ('fst_mode', i32)]
 
 
 class TsrmGrads(C.Structure):

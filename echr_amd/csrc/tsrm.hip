@@ -70,20 +70,43 @@ __global__ __launch_bounds__(256) void posemb_kernel(const int* __restrict__ ev_
     }
 }
 
+// How the position gate and the scaled affinity combine ahead of the softmax (MA_attention_8_NEW.py:148-157): fST0 gate * aff (the recipe),
+// fST1 gate + aff, fST2 log(clamp(gate, 1e-6)) + aff, fST3 the gate alone; 4 = use_posit = 0: the affinity alone (no position branch at all).
+__device__ __forceinline__ float fst_combine(int mode, float gate, float aff) {
+    switch (mode) {
+        case 0: return gate * aff;
+        case 1: return gate + aff;
+        case 2: return logf(fmaxf(gate, 1e-6f)) + aff;
+        case 3: return gate;
+        default: return aff;
+    }
+}
+// gradients of the combination w.r.t. (gate, aff) times ds
+__device__ __forceinline__ void fst_grad(int mode, float gate, float aff, float ds, float& dgate, float& daff) {
+    switch (mode) {
+        case 0: dgate = ds * aff; daff = ds * gate; break;
+        case 1: dgate = ds; daff = ds; break;
+        case 2: dgate = gate >= 1e-6f ? ds / gate : 0.f; daff = ds; break;          // (torch.clamp(min): the gradient passes where x >= min)
+        case 3: dgate = ds; daff = 0.f; break;
+        default: dgate = 0.f; daff = ds; break;
+    }
+}
+
 // one wave per (event n, head g): w[m] = softmax_m(gate[n,m,g] * aff[g,n,m]); wd = w * dropout
 __global__ __launch_bounds__(64) void tsrm_softmax_fwd_kernel(const float* __restrict__ GATE, const float* __restrict__ AFF,
-                                                              float* __restrict__ WSM, float* __restrict__ WD, int N, int G, DropCfg dc) {
+                                                              float* __restrict__ WSM, float* __restrict__ WD, int N, int G, DropCfg dc, int mode) {
     const int n = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
     const float* aff = AFF + ((long)g * N + n) * N;
+    auto gt = [&](int j) { return mode == 4 ? 0.f : GATE[((long)n * N + j) * G + g]; };
     float m = -INFINITY;
-    for (int j = lane; j < N; j += 64) m = fmaxf(m, GATE[((long)n * N + j) * G + g] * aff[j]);
+    for (int j = lane; j < N; j += 64) m = fmaxf(m, fst_combine(mode, gt(j), aff[j]));
     m = wave_max(m);
     float s = 0.f;
-    for (int j = lane; j < N; j += 64) s += expf(GATE[((long)n * N + j) * G + g] * aff[j] - m);
+    for (int j = lane; j < N; j += 64) s += expf(fst_combine(mode, gt(j), aff[j]) - m);
     s = wave_sum(s);
     const float inv = 1.f / s;
     for (int j = lane; j < N; j += 64) {
-        const float w = expf(GATE[((long)n * N + j) * G + g] * aff[j] - m) * inv;
+        const float w = expf(fst_combine(mode, gt(j), aff[j]) - m) * inv;
         const long o = ((long)g * N + n) * N + j;
         WSM[o] = w;
         WD[o] = w * drop_mult(dc, (unsigned)(((long)n * G + g) * N + j), 0u, SITE_TSRM);
@@ -94,23 +117,23 @@ __global__ __launch_bounds__(64) void tsrm_softmax_fwd_kernel(const float* __res
 // coalesced -- in LDS (row pitch G + 1: conflict-free column reads), then each wave takes heads g = wave, wave + 4, ... and streams
 // the affinity row of (g, n), contiguous over m.  The form above reads the gates 64 bytes apart, three times (0.29 ms at N = 1000).
 __global__ __launch_bounds__(256) void tsrm_softmax_rows_kernel(const float* __restrict__ GATE, const float* __restrict__ AFF,
-                                                               float* __restrict__ WSM, float* __restrict__ WD, int N, int G, DropCfg dc) {
+                                                               float* __restrict__ WSM, float* __restrict__ WD, int N, int G, DropCfg dc, int mode) {
     extern __shared__ float sg[];                      // [N][G + 1]
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, P = G + 1;
     const float* gp = GATE + (long)n * N * G;
-    for (int i = tid; i < N * G; i += 256) sg[(i / G) * P + (i % G)] = gp[i];
+    for (int i = tid; i < N * G; i += 256) sg[(i / G) * P + (i % G)] = mode == 4 ? 0.f : gp[i];
     __syncthreads();
     for (int g = w; g < G; g += 4) {
         const float* aff = AFF + ((long)g * N + n) * N;
         float m = -INFINITY;
-        for (int j = lane; j < N; j += 64) m = fmaxf(m, sg[j * P + g] * aff[j]);
+        for (int j = lane; j < N; j += 64) m = fmaxf(m, fst_combine(mode, sg[j * P + g], aff[j]));
         m = wave_max(m);
         float s = 0.f;
-        for (int j = lane; j < N; j += 64) s += expf(sg[j * P + g] * aff[j] - m);
+        for (int j = lane; j < N; j += 64) s += expf(fst_combine(mode, sg[j * P + g], aff[j]) - m);
         s = wave_sum(s);
         const float inv = 1.f / s;
         for (int j = lane; j < N; j += 64) {
-            const float wv = expf(sg[j * P + g] * aff[j] - m) * inv;
+            const float wv = expf(fst_combine(mode, sg[j * P + g], aff[j]) - m) * inv;
             const long o = ((long)g * N + n) * N + j;
             WSM[o] = wv;
             WD[o] = wv * drop_mult(dc, (unsigned)(((long)n * G + g) * N + j), 0u, SITE_TSRM);
@@ -121,7 +144,7 @@ __global__ __launch_bounds__(256) void tsrm_softmax_rows_kernel(const float* __r
 // ds = w * (dw - sum_m w dw), dw = dWD * dropout;  dGATE[n,m,g] = ds * aff, dAFF[g,n,m] = ds * gate
 __global__ __launch_bounds__(64) void tsrm_softmax_bwd_kernel(const float* __restrict__ GATE, const float* __restrict__ AFF,
                                                               const float* __restrict__ WSM, const float* __restrict__ DWD,
-                                                              float* __restrict__ DGATE, float* __restrict__ DAFF, int N, int G, DropCfg dc) {
+                                                              float* __restrict__ DGATE, float* __restrict__ DAFF, int N, int G, DropCfg dc, int mode) {
     const int n = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
     const long base = ((long)g * N + n) * N;
     float s = 0.f;
@@ -132,8 +155,10 @@ __global__ __launch_bounds__(64) void tsrm_softmax_bwd_kernel(const float* __res
         const float dw = DWD[base + j] * drop_mult(dc, (unsigned)(((long)n * G + g) * N + j), 0u, SITE_TSRM);
         const float ds = WSM[base + j] * (dw - s);
         const long go = ((long)n * N + j) * G + g;
-        DGATE[go] = ds * AFF[base + j];
-        DAFF[base + j] = ds * GATE[go];
+        float dgt, daf;
+        fst_grad(mode, mode == 4 ? 0.f : GATE[go], AFF[base + j], ds, dgt, daf);
+        DGATE[go] = dgt;
+        DAFF[base + j] = daf;
     }
 }
 
@@ -177,12 +202,12 @@ __device__ __forceinline__ float head_contract(const float* srow, const float (&
 __global__ __launch_bounds__(64) void tsrm_rowhead_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ XW,
                                                               const float* __restrict__ GATE, const float* __restrict__ b_out,
                                                               float* __restrict__ AFF, float* __restrict__ WSM, float* __restrict__ WD,
-                                                              float* __restrict__ OUT, int N, int Df, int Do, int G, float scale, DropCfg dc) {
+                                                              float* __restrict__ OUT, int N, int Df, int Do, int G, float scale, DropCfg dc, int mode) {
     __shared__ __attribute__((aligned(16))) float sw[HEAD_MAXN];
     constexpr int DG = HEAD_DG;
     const int r = blockIdx.x, g = blockIdx.y, j = threadIdx.x;
     const bool on = j < N;
-    const float gate = on ? GATE[((long)r * N + j) * G + g] : 0.f;
+    const float gate = (on && mode != 4) ? GATE[((long)r * N + j) * G + g] : 0.f;
     float kj[DG], xw[DG];
     head_row32(K + (long)j * Df + g * DG, kj, on);
     head_col32(XW + g * DG, Do, N, j, xw);
@@ -192,7 +217,7 @@ __global__ __launch_bounds__(64) void tsrm_rowhead_fwd_kernel(const float* __res
     for (int k = 0; k < DG; ++k) acc = fmaf(qr[k], kj[k], acc);
     const float aff = scale * acc;
     // gated softmax over j (the arithmetic of tsrm_softmax_fwd_kernel)
-    const float v = on ? gate * aff : -INFINITY;
+    const float v = on ? fst_combine(mode, gate, aff) : -INFINITY;
     const float m = wave_max(v);
     const float e = on ? expf(v - m) : 0.f;
     const float inv = 1.f / wave_sum(e);
@@ -214,14 +239,14 @@ __global__ __launch_bounds__(64) void tsrm_rowhead_fwd_kernel(const float* __res
 __global__ __launch_bounds__(64) void tsrm_rowhead_bwd_kernel(const float* __restrict__ DOUT, const float* __restrict__ K, const float* __restrict__ XW,
                                                               const float* __restrict__ GATE, const float* __restrict__ AFF, const float* __restrict__ WSM,
                                                               float* __restrict__ DGATE, float* __restrict__ DAFF, float* __restrict__ DQ,
-                                                              int N, int Df, int Do, int G, float scale, DropCfg dc) {
+                                                              int N, int Df, int Do, int G, float scale, DropCfg dc, int mode) {
     __shared__ __attribute__((aligned(16))) float sw[HEAD_MAXN];
     constexpr int DG = HEAD_DG;
     const int r = blockIdx.x, g = blockIdx.y, j = threadIdx.x;
     const bool on = j < N;
     const long base = ((long)g * N + r) * N;
     const long go = ((long)r * N + j) * G + g;
-    const float gate = on ? GATE[go] : 0.f;
+    const float gate = (on && mode != 4) ? GATE[go] : 0.f;
     const float wsm = on ? WSM[base + j] : 0.f;
     const float aff = on ? AFF[base + j] : 0.f;
     float xj[DG], kc[DG];
@@ -235,9 +260,10 @@ __global__ __launch_bounds__(64) void tsrm_rowhead_bwd_kernel(const float* __res
     const float dw = on ? dwd * drop_mult(dc, (unsigned)(((long)r * G + g) * N + j), 0u, SITE_TSRM) : 0.f;
     const float s = wave_sum(wsm * dw);
     const float ds = wsm * (dw - s);
-    const float daff = on ? ds * gate : 0.f;
+    float dgt = 0.f, daff = 0.f;
+    if (on) fst_grad(mode, gate, aff, ds, dgt, daff);
     if (on) {
-        DGATE[go] = ds * aff;
+        DGATE[go] = dgt;
         DAFF[base + j] = daff;
     }
     sw[j] = daff;
@@ -683,7 +709,7 @@ static const void* g_pos_early_ws = nullptr;
 int echr::tsrm_position_early(const echr_tsrm_args* a, hipStream_t from) {
     g_pos_early_ws = nullptr;
     static const bool off = [] { const char* e = getenv("ECHR_TSRM_EARLY"); return e && e[0] == '0'; }();      // A/B switch
-    if (off || !config().tsrm_fork || !a || a->inference || !a->ws || !a->ev_start || !a->ev_len) return 0;
+    if (off || !config().tsrm_fork || !a || a->inference || !a->ws || !a->ev_start || !a->ev_len || a->fst_mode == 4) return 0;
     const int N = a->N, Df = a->Df, G = a->G, NN = N * N;
     if (N <= 0 || Df <= 0 || G <= 0 || Df % 4 != 0) return 0;
     TsrmWs w = carve(N, a->Din, Df, a->Do, G, a->ws);
@@ -704,6 +730,9 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
     echr_gemm_desc d;
     const bool early = !x_given && !a->inference && g_pos_early_ws == a->ws;      // tsrm_position_early already runs the position branch
     g_pos_early_ws = nullptr;
+    const int mode = a->fst_mode;
+    ECHR_REQUIRE(mode >= 0 && mode <= 4, "tsrm_fwd: fst_mode must be 0..4");
+    const bool posit = mode != 4;                 // use_posit = 0: no position branch, the gates are never read
     if (early) {          // X and Q | K | XW: the split-K products below accumulate into zeros; GATE is being STORED by the early branch
         float* zp[2] = {w.X, w.Q};
         const long zn[2] = {(long)(w.GATE - w.X), (long)((w.X + w.zero_floats) - w.Q)};
@@ -719,11 +748,11 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
     }
     // pairwise position features -> per-head gates (:39-41, :108-116): independent of the event features, so the branch runs on the
     // library's helper stream beside the embedding / query / key products (it needs the zero fill above: GATE accumulates)
-    hipStream_t sp = (config().tsrm_fork && !early) ? aux_fork(st) : nullptr;
+    hipStream_t sp = (config().tsrm_fork && !early && posit) ? aux_fork(st) : nullptr;
     const bool fork = sp != nullptr || early;
     if (!sp) sp = st;
     long trc = 0, trl = 0;
-    const long trows = x_given ? 0 : pair_table_rows(a, &trc, &trl);
+    const long trows = (x_given || !posit) ? 0 : pair_table_rows(a, &trc, &trl);
     const bool packed_pos = !x_given && !trows && config().gemm_h2 && NN >= 4096 && posemb_packed_ok(N, Df);
     if (trows) {
         // inference over many pairs: tabulated fc1 (see pair_phi_kernel).  The tables live in the workspace regions the dense path would
@@ -762,7 +791,7 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
         d = desc_nt(a->ech, Din, a->w_emb, Din, w.X, Df, N, Df, Din); d.bias = a->b_emb; d.split_k = -1; d.beta = 1.f;
         RC(gemm(d, st));
     }
-    if (!trows && !early) RC(position_branch(a, w, !x_given, packed_pos, sp));
+    if (!trows && !early && posit) RC(position_branch(a, w, !x_given, packed_pos, sp));
     // query / key / (pre-applied) output projection of X: one grouped launch when the three problems have one shape
     {
         echr_gemm_desc q3[3];
@@ -778,7 +807,7 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
         // few events: affinities, gated softmax, dropout and the weighted sum in one launch, one wave per (event, head) (:138-160)
         if (fork) RC(aux_join(st));
         hipLaunchKernelGGL(tsrm_rowhead_fwd_kernel, dim3(N, G), dim3(64), 0, st, w.Q, w.K, w.XW, w.GATE, a->b_out, w.AFF, w.WSM, w.WD, a->out,
-                           N, Df, Do, G, 1.0f / sqrtf((float)dgq), dc);
+                           N, Df, Do, G, 1.0f / sqrtf((float)dgq), dc, mode);
         return check_launch("tsrm_rowhead_fwd");
     }
     // per-head scaled affinities AFF[g] = Q_g . K_g^T / sqrt(dgq)   (:138-140)
@@ -795,9 +824,9 @@ static int tsrm_fwd_impl(const echr_tsrm_args* a, const echr_dropout* drop, void
         rows_attr.store(ok ? 1 : 2, std::memory_order_relaxed);
     }
     if (N >= 128 && sm_rows <= 150 * 1024 && rows_attr.load(std::memory_order_relaxed) == 1) {
-        hipLaunchKernelGGL(tsrm_softmax_rows_kernel, dim3(N), dim3(256), sm_rows, st, w.GATE, w.AFF, w.WSM, w.WD, N, G, dc);
+        hipLaunchKernelGGL(tsrm_softmax_rows_kernel, dim3(N), dim3(256), sm_rows, st, w.GATE, w.AFF, w.WSM, w.WD, N, G, dc, mode);
     } else {
-        hipLaunchKernelGGL(tsrm_softmax_fwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, w.WD, N, G, dc);
+        hipLaunchKernelGGL(tsrm_softmax_fwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, w.WD, N, G, dc, mode);
     }
     RC(check_launch("tsrm_softmax_fwd"));
     // OUT[:, g] = WD_g . XW_g + b_out_g
@@ -832,6 +861,9 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
     if (!z) RC(colsum(g->g_out, Do, N, Do, g->g_b_out, false, st));
     const DropCfg dc = make_drop(drop, drop ? drop->p_tsrm : 0.f);
     const bool heads = head_fused_ok(N, Df, Do, G);
+    const int mode = a->fst_mode;
+    ECHR_REQUIRE(mode >= 0 && mode <= 4, "tsrm_bwd: fst_mode must be 0..4");
+    const bool posit = mode != 4;                 // use_posit = 0: pair_pos_fc1 / fc2 are not part of the graph (their gradients stay untouched)
     if (main_part) {
     {   // accumulated (split-K) outputs zeroed by one launch: dX and, when requested, d ech
         float* zp[2] = {b.DX, g->g_ech};
@@ -841,7 +873,7 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
     if (heads) {
         // few events: d WD, the softmax backward and d Q per (event, head) wave; then d XW and d K per (column, head) wave
         hipLaunchKernelGGL(tsrm_rowhead_bwd_kernel, dim3(N, G), dim3(64), 0, st, g->g_out, w.K, w.XW, w.GATE, w.AFF, w.WSM, b.DGATE, b.DAFF, b.DQ,
-                           N, Df, Do, G, scale, dc);
+                           N, Df, Do, G, scale, dc, mode);
         hipLaunchKernelGGL(tsrm_colhead_bwd_kernel, dim3(N, G), dim3(64), 0, st, g->g_out, w.Q, w.WD, b.DAFF, b.DXW, b.DK, N, Df, Do, G, scale);
         RC(check_launch("tsrm_rowhead_bwd"));
     } else {
@@ -852,7 +884,7 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
     d = desc_tn(w.WD, N, g->g_out, Do, b.DXW, Do, N, dgo, N);
     d.batch = G; d.bsa = (long)NN; d.bsb = dgo; d.bsc = dgo;
     RC(gemm(d, st));
-    hipLaunchKernelGGL(tsrm_softmax_bwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, b.DWD, b.DGATE, b.DAFF, N, G, dc);
+    hipLaunchKernelGGL(tsrm_softmax_bwd_kernel, dim3(N, G), dim3(64), 0, st, w.GATE, w.AFF, w.WSM, b.DWD, b.DGATE, b.DAFF, N, G, dc, mode);
     RC(check_launch("tsrm_softmax_bwd"));
     }
     }
@@ -861,13 +893,13 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
     // (round 5: off by default.  With the token-embedding chain on the prepare stream behind the LSTM-layer stage (decoder.hip, ECHR_DXT_STREAM)
     // the three streams of the backward tail end together when THIS stream keeps the position MLP: 1.48 vs 1.54 ms per iteration, same box)
     static const bool fork2_off = [] { const char* e = getenv("ECHR_TSRM_FORK2"); return !(e && e[0] == '1'); }();      // A/B switch
-    hipStream_t sp = (config().tsrm_fork && !fork2_off && part == 0) ? aux2_fork(st) : nullptr;
+    hipStream_t sp = (config().tsrm_fork && !fork2_off && part == 0 && posit) ? aux2_fork(st) : nullptr;
     const bool fork2 = sp != nullptr;
     if (!fork2) sp = st;
     // one streaming pass instead of two latency-bound fp32 products + two column sums (pair_mlp_bwd_kernel; ECHR_TSRM_PAIR_BWD=0: the products)
     static const bool pm_off = [] { const char* e = getenv("ECHR_TSRM_PAIR_BWD"); return e && e[0] == '0'; }();
-    const bool pair_fused = z && !pm_off && Df == 512 && G == 16 && ((reinterpret_cast<uintptr_t>(w.P1) | reinterpret_cast<uintptr_t>(a->w_fc2) | reinterpret_cast<uintptr_t>(b.DP1)) & 15) == 0;
-    if (rest_part) {
+    const bool pair_fused = posit && z && !pm_off && Df == 512 && G == 16 && ((reinterpret_cast<uintptr_t>(w.P1) | reinterpret_cast<uintptr_t>(a->w_fc2) | reinterpret_cast<uintptr_t>(b.DP1)) & 15) == 0;
+    if (rest_part && posit) {
         // position MLP (depends on d GATE only)
         if (pair_fused) {
             hipLaunchKernelGGL(pair_mlp_bwd_kernel, dim3((NN + PM_ROWS - 1) / PM_ROWS), dim3(256), 0, sp, b.DGATE, w.P1, a->w_fc2, b.DP1, b.PMP, NN);
@@ -950,12 +982,14 @@ int echr::tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, cons
         cf[4] = ColsumJob{b.PMP, PM_LD, nblk, G * Df, g->g_w_fc2, nullptr, nullptr};
         cf[5] = ColsumJob{b.PMP + G * Df, PM_LD, nblk, Df, g->g_b_fc1, nullptr, nullptr};
         cf[6] = ColsumJob{b.PMP + G * Df + Df, PM_LD, nblk, G, g->g_b_fc2, nullptr, nullptr};
-        if (pair_fused) RC(colsum_multi(cf, 7, st)); else RC(colsum_multi(cj, 6, st));
+        if (pair_fused) RC(colsum_multi(cf, 7, st)); else RC(colsum_multi(cj, posit ? 6 : 4, st));
     } else {
         RC(colsum(b.DQ, Df, N, Df, g->g_b_q, false, st));
         RC(colsum(b.DK, Df, N, Df, g->g_b_k, false, st));
+        if (posit) {
         RC(colsum(b.DGATE, G, NN, G, g->g_b_fc2, false, st));
         RC(colsum(b.DP1, Df, NN, Df, g->g_b_fc1, false, st));
+        }
         RC(colsum(b.DX, Df, N, Df, g->g_b_emb, false, st));
     }
     }

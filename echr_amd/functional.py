@@ -163,7 +163,7 @@ class TSRMFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ech, ev_start, ev_len, n_head, drop, sink, bounds, *params):
-        # bounds: None or (inference, max_len, max_span) = echr_tsrm_args' last three fields.  `inference` must be decided by the CALLER
+        # bounds: None or (inference, max_len, max_span[, fst_mode]) = echr_tsrm_args' last fields.  `inference` must be decided by the CALLER
         # (grad mode is always off inside forward, and needs_input_grad ignores torch.no_grad())
         lib = L.load()
         ctx.sink = sink
@@ -181,14 +181,14 @@ class TSRMFunction(torch.autograd.Function):
         d = drop.c()
         L.check(lib.echr_tsrm_fwd(C.byref(a), C.byref(d), L.stream_ptr()), 'tsrm_fwd')
         ctx.save_for_backward(ech, ev_start, ev_len, ws, out, *ps)
-        ctx.meta = (N, Din, Df, Do, n_head, drop)
+        ctx.meta = (N, Din, Df, Do, n_head, drop, int(a.fst_mode))
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = L.load()
         ech, ev_start, ev_len, ws, out, *ps = ctx.saved_tensors
-        N, Din, Df, Do, G, drop = ctx.meta
+        N, Din, Df, Do, G, drop, fst_mode = ctx.meta
         g_out = _f32c(g_out)
         zeroed = 1 if (ctx.sink is not None and ctx.sink.usable()) else 0
         grads = ctx.sink.take() if zeroed else [torch.empty_like(p) for p in ps]
@@ -197,8 +197,11 @@ class TSRMFunction(torch.autograd.Function):
         g_ech = torch.empty_like(ech)
         wsb = torch.empty(lib.echr_tsrm_ws_bwd_floats(N, Din, Df, Do, G), device=ech.device, dtype=torch.float32)
         a = L.TsrmArgs(N, Din, Df, Do, G, *[L.ptr(p) for p in ps], L.ptr(ech), L.ptr(ev_start, torch.int32),
-                       L.ptr(ev_len, torch.int32), L.ptr(ws), L.ptr(out))
+                       L.ptr(ev_len, torch.int32), L.ptr(ws), L.ptr(out), 0, 0, 0, fst_mode)
         g = L.TsrmGrads(*[L.ptr(x) for x in grads], L.ptr(g_ech), L.ptr(g_out), L.ptr(wsb), zeroed)
+        if not zeroed and fst_mode in (3, 4):          # parameters the chosen combination does not reach: the library writes nothing there
+            for i in ((6, 7, 8, 9) if fst_mode == 3 else (2, 3, 4, 5)):
+                grads[i].zero_()
         d = drop.c()
         L.check(lib.echr_tsrm_bwd(C.byref(a), C.byref(g), C.byref(d), L.stream_ptr()), 'tsrm_bwd')
         return (g_ech, None, None, None, None, None, None) + tuple(grads)
@@ -475,7 +478,7 @@ def decoder_step(it, video, event, c3d, ev_start, ev_len, A, state, params, drop
     return logp, (h_out, c_out)
 
 
-def tsrm_attention(roi_feat, position_embedding, n_head, params, d_o, drop=None):
+def tsrm_attention(roi_feat, position_embedding, n_head, params, d_o, drop=None, fst_mode=0):
     """attention_module_multi_head.forward (MA_attention_8_NEW.py:101-177) on the embedded events roi_feat [N,Df] and the pairwise
     position embedding [N,N,Df].  params = (fc1.w, fc1.b, fc2.w, fc2.b, q.w, q.b, k.w, k.b, out.w [Do,Df], out.b).  Forward only."""
     lib = L.load()
@@ -487,7 +490,7 @@ def tsrm_attention(roi_feat, position_embedding, n_head, params, d_o, drop=None)
     Din = Df
     ws = torch.empty(lib.echr_tsrm_ws_floats(N, Din, Df, d_o, n_head), device=x.device, dtype=torch.float32)
     out = torch.empty(N, d_o, device=x.device, dtype=torch.float32)
-    a = L.TsrmArgs(N, Din, Df, d_o, n_head, None, None, *[L.ptr(p) for p in ps], None, None, None, L.ptr(ws), L.ptr(out))
+    a = L.TsrmArgs(N, Din, Df, d_o, n_head, None, None, *[L.ptr(p) for p in ps], None, None, None, L.ptr(ws), L.ptr(out), 0, 0, 0, fst_mode)
     d = (drop if drop is not None else DropState(training=False)).c()
     L.check(lib.echr_tsrm_attn_fwd(C.byref(a), L.ptr(x), L.ptr(pos), C.byref(d), L.stream_ptr()), 'tsrm_attn_fwd')
     return out

@@ -66,6 +66,7 @@ class FusedTrainStep(object):
             setattr(a.tsrm, name, L.ptr(v))
             setattr(a.tsrm_g, 'g_' + name, gp(p))
         a.tsrm.Din, a.tsrm.Df, a.tsrm.Do, a.tsrm.G = tp[0].shape[1], tp[0].shape[0], tp[10].shape[0], fm.enc_attn.group
+        a.tsrm.fst_mode = fm.fst_mode()
         ps = lm.native_params()
         (embed, w_logit, b_logit, wi0, wi1, wi2, wh0, wh1, wh2, bi0, bi1, bi2, bh0, bh1, bh2, w_c2a, b_c2a, w_h2a, b_h2a, w_alpha, b_alpha) = ps
         d, g = a.dec, a.dec_g

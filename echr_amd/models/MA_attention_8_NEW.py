@@ -44,9 +44,11 @@ class MA_Attention8(nn.Module):
                 e.pair_pos_fc2.weight, e.pair_pos_fc2.bias, e.query_1.weight, e.query_1.bias,
                 e.key_1.weight, e.key_1.bias, w_out, e.linear_out_1.bias)
 
+    def fst_mode(self):
+        """echr_tsrm_args.fst_mode: how gate and affinity combine (MA_attention_8_NEW.py:148-157); 4 = use_posit off."""
+        return fst_mode_of(self.fST_type, self.use_posit)
+
     def forward(self, feats, soi_select_list, ev_tensors=None, drop=None):
-        if not self.use_posit or self.fST_type != 'fST0':
-            raise NotImplementedError('the HIP path implements the shipped ECHR recipe: use_posit=1, fST_type=fST0')
         if ev_tensors is None:
             soi = np.asarray(soi_select_list, dtype=np.int64).reshape(-1, 2)
             t = torch.from_numpy(np.stack([soi[:, 0], soi[:, 1] - soi[:, 0]]).astype(np.int32)).to(feats.device)
@@ -59,7 +61,7 @@ class MA_Attention8(nn.Module):
         params = self.native_params()
         infer = not (torch.is_grad_enabled() and (feats.requires_grad or any(p.requires_grad for p in params)))      # no backward pass can follow
         return EF.TSRMFunction.apply(feats, ev_start, ev_len, self.enc_attn.group, drop, self._grad_sink(),
-                                     (1 if infer else 0,) + tuple(getattr(ev_len, 'echr_bounds', (0, 0))), *params)
+                                     (1 if infer else 0,) + tuple(getattr(ev_len, 'echr_bounds', (0, 0))) + (self.fst_mode(),), *params)
 
     def _grad_sink(self):
         arena = getattr(self, '_echr_arena_ref', None)
@@ -92,6 +94,15 @@ class MA_Attention8(nn.Module):
         return np.concatenate([np.sin(ang), np.cos(ang)], axis=3).reshape(n, m, feat_dim)
 
 
+def fst_mode_of(fST_type, use_posit):
+    if not use_posit:
+        return 4
+    if fST_type not in ('fST0', 'fST1', 'fST2', 'fST3'):
+        # (the reference leaves `weighted_aff` undefined for any other string and fails with a NameError at :159)
+        raise ValueError('fST_type must be fST0..fST3 (got %r)' % (fST_type,))
+    return int(fST_type[-1])
+
+
 class attention_module_multi_head(nn.Module):
     """Parameter container with the reference's layout (MA_attention_8_NEW.py:82-99); used through MA_Attention8."""
 
@@ -117,8 +128,6 @@ class attention_module_multi_head(nn.Module):
         """The gated multi-head relation attention on its own (MA_attention_8_NEW.py:101-177): roi_feat [N,d_feats] = embedded events,
         position_embedding [N,N,pos_emb_dim].  Runs through echr_tsrm_attn_fwd; forward only (MA_Attention8.forward is the
         differentiable, fused entry the caption path uses)."""
-        if not use_posit or self.fST_type != 'fST0':
-            raise NotImplementedError('the HIP path implements the shipped ECHR recipe: use_posit=1, fST_type=fST0')
         w_out = self.linear_out_1.weight.reshape(self.linear_out_1.weight.shape[0], -1)
         ps = (self.pair_pos_fc1.weight, self.pair_pos_fc1.bias, self.pair_pos_fc2.weight, self.pair_pos_fc2.bias,
               self.query_1.weight, self.query_1.bias, self.key_1.weight, self.key_1.bias, w_out, self.linear_out_1.bias)
@@ -126,4 +135,6 @@ class attention_module_multi_head(nn.Module):
         if self.training:
             self._drop_calls += 1
         with torch.no_grad():
-            return EF.tsrm_attention(roi_feat, position_embedding, self.group, ps, self.d_o, drop)
+            if position_embedding is None:          # (use_posit off: the kernels never read it)
+                position_embedding = roi_feat.new_zeros(roi_feat.shape[0], roi_feat.shape[0], self.pos_emb_dim)
+            return EF.tsrm_attention(roi_feat, position_embedding, self.group, ps, self.d_o, drop, fst_mode_of(self.fST_type, use_posit))

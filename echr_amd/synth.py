@@ -151,6 +151,13 @@ CASES = {
     # event-context variants (CaptionGenerator.py:106-130): TSRM over the pooled C3D rows only / the anchors' SST states only
     'er1': dict(opt=dict(event_context_type='ER1', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=62)),
     'er2': dict(opt=dict(event_context_type='ER2', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=63)),
+    # gate / affinity combinators of the event encoder (MA_attention_8_NEW.py:148-157) and the encoder without its position branch
+    'fst1': dict(opt=dict(fST_type='fST1', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=64)),
+    # (fST2 takes log(clamp(gate, 1e-6)): a gate just above zero amplifies the documented 1-ulp deviation of the device's position embedding by
+    # 1 / gate, so the case keeps its gates away from zero -- heads 0..7 shifted by +1 (gates 0.36 .. 1.73), heads 8..15 by -1 (all clamped))
+    'fst2': dict(opt=dict(fST_type='fST2', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=65), gate_shift=1.0),
+    'fst3': dict(opt=dict(fST_type='fST3', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=66)),
+    'noposit': dict(opt=dict(use_posit=0, CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=67)),
     # EXACTLY the layout bench.py times (BASELINE config 3): 64 disjoint 128-segment events on a T_v = 8192 video
     'c3bench': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=1234, disjoint=True)),
 }
@@ -197,7 +204,12 @@ def make_case(name, param_seed=0):
     opt = default_opt(**c['opt'])
     vid = make_video(V1=opt.CG_vocab_size + 1, video_dim=opt.video_dim, hidden_dim=opt.hidden_dim,
                      lda_dim=opt.lda_dim, **c['video'])
-    return opt, make_params(opt, param_seed), vid
+    params = make_params(opt, param_seed)
+    if c.get('gate_shift'):
+        b = params['fusion_model.enc_attn.pair_pos_fc2.bias']
+        b[:len(b) // 2] += np.float32(c['gate_shift'])
+        b[len(b) // 2:] -= np.float32(c['gate_shift'])
+    return opt, params, vid
 
 
 # Greedy-decoding cases whose captions END AT DIFFERENT STEPS (OldModel_NEW.py:171-183: per-row `unfinished` state).  With the plain

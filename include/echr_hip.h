@@ -154,6 +154,10 @@ typedef struct {
     int32_t max_len, max_span;       /* optional, known to the host from the index lists: max ev_len and max |(2 start_i + len_i) - (2 start_j +
                                         len_j)| over the events (0 / -1... leave max_len = 0 when unknown).  With `inference` and >= 16384 pairs
                                         they let the pair MLP run from tables over the distinct (|2 dc|, l_i) and (l_i, l_j) keys */
+    int32_t fst_mode;                /* how position gate and scaled affinity combine ahead of the softmax (MA_attention_8_NEW.py:148-157):
+                                        0 = fST0 gate * aff (the recipe), 1 = fST1 gate + aff, 2 = fST2 log(clamp(gate, 1e-6)) + aff,
+                                        3 = fST3 the gate alone, 4 = use_posit = 0: the affinity alone (the position branch is not run and
+                                        pair_pos_fc1 / fc2 receive no gradient) */
 } echr_tsrm_args;
 
 typedef struct {

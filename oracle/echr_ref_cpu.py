@@ -54,22 +54,24 @@ def position_embedding(pos_mat, feat_dim, wave_length=10000):
     return emb.reshape(n, m, feat_dim)
 
 
-def tsrm_forward(P, feats, soi, n_head=16, drop_mask=None, prefix='fusion_model.'):
-    """MA_Attention8.forward + attention_module_multi_head.forward (fST0, use_posit=1).
+def tsrm_forward(P, feats, soi, n_head=16, drop_mask=None, prefix='fusion_model.', fST_type='fST0', use_posit=1):
+    """MA_Attention8.forward + attention_module_multi_head.forward (the recipe: fST0, use_posit=1; the other combinators of :148-157 too).
 
     MA_attention_8_NEW.py:35-49 and :101-177.  feats [N,Din] -> [N,d_o].
     drop_mask: multiplicative mask for the post-softmax dropout (:162), shape [N,G,N]."""
     N = feats.shape[0]
     G = n_head
-    pos = position_embedding(position_matrix(soi), P[prefix + 'enc_attn.pair_pos_fc1.weight'].shape[1])
-    pos = torch.tensor(pos, dtype=torch.float32)                   # :41 (float64 -> float32)
     x = F.linear(feats, P[prefix + 'event_emb.weight'], P[prefix + 'event_emb.bias'])     # :44
     d = x.shape[1]
-    p1 = F.linear(pos.view(-1, pos.shape[2]), P[prefix + 'enc_attn.pair_pos_fc1.weight'],
-                  P[prefix + 'enc_attn.pair_pos_fc1.bias'])        # :110
-    gate = F.linear(torch.tanh(p1), P[prefix + 'enc_attn.pair_pos_fc2.weight'],
-                    P[prefix + 'enc_attn.pair_pos_fc2.bias'])      # :114
-    gate = gate.view(N, N, G).transpose(1, 2)                      # [N,G,N]  :116
+    gate = None
+    if use_posit:                                                  # :38-43, :105-116
+        pos = position_embedding(position_matrix(soi), P[prefix + 'enc_attn.pair_pos_fc1.weight'].shape[1])
+        pos = torch.tensor(pos, dtype=torch.float32)               # :41 (float64 -> float32)
+        p1 = F.linear(pos.view(-1, pos.shape[2]), P[prefix + 'enc_attn.pair_pos_fc1.weight'],
+                      P[prefix + 'enc_attn.pair_pos_fc1.bias'])    # :110
+        gate = F.linear(torch.tanh(p1), P[prefix + 'enc_attn.pair_pos_fc2.weight'],
+                        P[prefix + 'enc_attn.pair_pos_fc2.bias'])  # :114
+        gate = gate.view(N, N, G).transpose(1, 2)                  # [N,G,N]  :116
     q = F.linear(x, P[prefix + 'enc_attn.query_1.weight'], P[prefix + 'enc_attn.query_1.bias'])
     k = F.linear(x, P[prefix + 'enc_attn.key_1.weight'], P[prefix + 'enc_attn.key_1.bias'])
     dg = d // G                                                    # python-2 integer division (:125)
@@ -77,7 +79,19 @@ def tsrm_forward(P, feats, soi, n_head=16, drop_mask=None, prefix='fusion_model.
     kb = k.view(N, G, dg).transpose(0, 1)
     aff = torch.bmm(qb, kb.transpose(1, 2)) * (1.0 / math.sqrt(float(dg)))   # [G,N,N]  :138-140
     aff = aff.transpose(0, 1)                                      # [N,G,N]  :143
-    w = torch.softmax(gate * aff, dim=2)                           # fST0 :149, softmax :160
+    if not use_posit:
+        wa = aff                                                   # :157
+    elif fST_type == 'fST0':
+        wa = gate * aff                                            # :149
+    elif fST_type == 'fST1':
+        wa = gate + aff                                            # :151
+    elif fST_type == 'fST2':
+        wa = torch.log(gate.clamp(min=1e-6)) + aff                 # :153
+    elif fST_type == 'fST3':
+        wa = gate                                                  # :155
+    else:
+        raise ValueError(fST_type)
+    w = torch.softmax(wa, dim=2)                                   # :160
     if drop_mask is not None:
         w = w * drop_mask                                          # :162
     out_t = w.reshape(N * G, N).matmul(x)                          # [N*G, d]  V = un-projected x (:135,:169)
@@ -108,16 +122,16 @@ def event_pool(c3d, soi):
     return torch.cat([c3d[int(s):int(e)].mean(0, keepdim=True) for s, e in soi], 0)
 
 
-def event_context(P, tap, c3d, ind, soi, n_head=16, drop_mask=None, event_context_type='ER3'):
+def event_context(P, tap, c3d, ind, soi, n_head=16, drop_mask=None, event_context_type='ER3', fST_type='fST0', use_posit=1):
     """Event context: 'ER1' mean-pooled C3D -> TSRM, 'ER2' SST hidden at the anchor -> TSRM, 'ER3' their concatenation -> TSRM.
     CaptionGenerator.py:106-130."""
     ec = event_pool(c3d, soi)
     if 'ER1' in event_context_type:
-        return tsrm_forward(P, ec, soi, n_head, drop_mask)                                # :115-117
+        return tsrm_forward(P, ec, soi, n_head, drop_mask, fST_type=fST_type, use_posit=use_posit)   # :115-117
     eh = tap[torch.as_tensor(np.asarray(ind), dtype=torch.long)]                          # :121
     if 'ER2' in event_context_type:
-        return tsrm_forward(P, eh, soi, n_head, drop_mask)                                # :123-125
-    return tsrm_forward(P, torch.cat((ec, eh), 1), soi, n_head, drop_mask)
+        return tsrm_forward(P, eh, soi, n_head, drop_mask, fST_type=fST_type, use_posit=use_posit)   # :123-125
+    return tsrm_forward(P, torch.cat((ec, eh), 1), soi, n_head, drop_mask, fST_type=fST_type, use_posit=use_posit)
 
 
 def clip_context(c3d, soi):
@@ -258,12 +272,12 @@ def lm_criterion(logp, target, mask):
 
 
 def caption_forward(P, tap, c3d, lda, labels, ind, soi, mode='train', drop=None, n_head=16, seq_length=None, video_context_type='VL',
-                    event_context_type='ER3'):
+                    event_context_type='ER3', fST_type='fST0', use_posit=1):
     """CaptionGenerator.forward for the live modes 'train' / 'eval'.  CaptionGenerator.py:17-43."""
     video = video_context(lda, c3d, tap, video_context_type)
     N = len(soi)
     dmask = drop('tsrm', 0, (N, n_head, N)) if drop is not None else None
-    event = event_context(P, tap, c3d, ind, soi, n_head, dmask, event_context_type)
+    event = event_context(P, tap, c3d, ind, soi, n_head, dmask, event_context_type, fST_type, use_posit)
     clip, mask = clip_context(c3d, soi)
     if mode == 'train':
         return decoder_forward(P, video, event, clip, mask, labels, drop)

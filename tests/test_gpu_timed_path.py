@@ -331,3 +331,54 @@ def test_scene_context_through_the_one_call_path():
     m2, o2, f2 = _fused(opt2, synth.make_params(opt2, 4))
     with pytest.raises(NotImplementedError):
         f2(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False, tap_grad=torch.zeros_like(tap))
+
+
+# ---- the event encoder's other gate / affinity combinators (MA_attention_8_NEW.py:148-157) and use_posit = 0 ------------------------------
+
+@pytest.mark.parametrize('train_mode', [True, False])
+@pytest.mark.parametrize('case', ['fst1', 'fst2', 'fst3', 'noposit'])
+def test_event_encoder_combinators_vs_oracle_and_reference(case, train_mode):
+    """fST1 gate + aff, fST2 log(clamp(gate)) + aff, fST3 the gate alone, use_posit = 0 the affinity alone: log-probs, loss, every gradient against
+    the oracle, loss / summaries / greedy sequence against the reference's fixture.  Parameters the chosen combination does not reach (query / key
+    under fST3, the pair MLP without the position branch) have `grad None` in the reference; here their gradient is None or exactly zero (the
+    flat-arena optimiser treats both alike: no moment, no update)."""
+    from tests.test_gpu_parity import TOL_LOGP
+    opt, params, vid = synth.make_case(case)
+    g = U.gold('case_%s.npz' % case)
+    mode = 'train' if train_mode else 'eval'
+    pred, loss, grads, m = U.run_gpu(opt, params, vid, train_mode)
+    rpred, rloss, rgrads = U.run_oracle(opt, params, vid, train_mode)
+    assert np.abs(pred - rpred).max() < TOL_LOGP
+    assert abs(loss - rloss) < TOL_LOSS * abs(rloss) and abs(loss - float(g[mode + '|loss'])) < TOL_LOSS * abs(float(g[mode + '|loss']))
+    unreached = [k for k, v in rgrads.items() if v is None and 'fusion_layer' not in k and 'h2a_layer' not in k]
+    assert len(unreached) == (0 if case in ('fst1', 'fst2') else 4), unreached
+    for k, rg in rgrads.items():
+        if rg is None:
+            assert grads[k] is None or not np.any(grads[k]), k
+        else:
+            assert U.grad_close(k, grads[k], rg, TOL_GRAD), (k, U.relerr(grads[k], rg))
+    # (fST1 / fST3: the fc2 bias shifts every softmax input of a row alike, so its true gradient is exactly zero -- both sides hold rounding noise
+    # ~1e-10, compared on the absolute scale by grad_close above, not by the relative summary gate)
+    noise = ('fusion_model.enc_attn.pair_pos_fc2.bias',) if case in ('fst1', 'fst3') else ()
+    _check_grad_summaries(g, mode, {k: v for k, v in grads.items() if rgrads[k] is not None and k not in noise})
+    if not train_mode:
+        dev = torch.device('cuda')
+        with torch.no_grad():
+            seq, _ = m(torch.from_numpy(vid['tap']).to(dev), torch.from_numpy(vid['c3d']).to(dev), torch.from_numpy(vid['lda']).to(dev), [], vid['ind'], vid['soi'], mode='eval')
+        assert np.array_equal(seq.cpu().numpy(), g['sample|seq'])
+
+
+def test_event_encoder_combinators_through_the_one_call_path():
+    """echr_train_step with fST2 and without the position branch: loss and gradients against the oracle."""
+    for case in ('fst2', 'noposit'):
+        opt, params, vid = synth.make_case(case)
+        _, rloss, rgrads = U.run_oracle(opt, params, vid, True)
+        m, o, f = _fused(opt, params)
+        tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+        loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False))
+        assert abs(loss - rloss) < TOL_LOSS * abs(rloss), (case, loss, rloss)
+        for k, p in m.named_parameters():
+            if rgrads[k] is not None:
+                assert U.grad_close(k, p.grad.cpu().numpy(), rgrads[k], TOL_GRAD), (case, k, U.relerr(p.grad.cpu().numpy(), rgrads[k]))
+            else:
+                assert p.grad is None or not bool(p.grad.abs().max() > 0), (case, k)

@@ -33,7 +33,7 @@ def test_tiny_full_tensors(train_mode):
             assert U.relerr(v, g[mode + '|grad|' + k]) < 1e-5, k
 
 
-@pytest.mark.parametrize('case', ['c1', 'c2', 'c3bench', 'vctx', 'er1', 'er2'])
+@pytest.mark.parametrize('case', ['c1', 'c2', 'c3bench', 'vctx', 'er1', 'er2', 'fst1', 'fst2', 'fst3', 'noposit'])
 def test_config_summaries(case):
     opt, params, vid = synth.make_case(case)
     g = U.gold('case_%s.npz' % case)
