@@ -49,7 +49,7 @@ class DecArgs(C.Structure):
                 ('w_ih', c_f * 3), ('w_hh', c_f * 3), ('b_ih', c_f * 3), ('b_hh', c_f * 3),
                 ('w_c2a', c_f), ('b_c2a', c_f), ('w_h2a', c_f), ('b_h2a', c_f), ('w_alpha', c_f), ('b_alpha', c_f),
                 ('c3d', c_f), ('ev_start', c_f), ('ev_len', c_f), ('event', c_f), ('video', c_f), ('tokens', c_f),
-                ('ws', c_f), ('logp', c_f), ('prepared', i32), ('train', i32), ('zero_extra', c_f), ('zero_extra_count', i64)]
+                ('ws', c_f), ('logp', c_f), ('prepared', i32), ('train', i32), ('zero_extra', c_f), ('zero_extra_count', i64), ('h0', c_f)]
 
 
 class DecGrads(C.Structure):
@@ -58,7 +58,16 @@ class DecGrads(C.Structure):
                 ('g_w_c2a', c_f), ('g_b_c2a', c_f), ('g_w_h2a', c_f), ('g_b_h2a', c_f), ('g_w_alpha', c_f), ('g_b_alpha', c_f),
                 ('g_event', c_f), ('g_video', c_f), ('g_logp', c_f),
                 ('nll_target', c_f), ('nll_mask', c_f), ('g_loss', c_f), ('ws_bwd', c_f), ('zeroed', i32), ('phase', i32), ('async_tail', i32), ('nll_msum', c_f),
-                ('zero_extra', c_f), ('zero_extra_count', i64), ('nll_target_i64', i32), ('dlg_ready', i32), ('active_rows', c_f), ('n_active', i32)]
+                ('zero_extra', c_f), ('zero_extra_count', i64), ('nll_target_i64', i32), ('dlg_ready', i32), ('active_rows', c_f), ('n_active', i32), ('g_h0', c_f)]
+
+
+class InitStateArgs(C.Structure):
+    _fields_ = [('N', i32), ('Dv', i32), ('De', i32), ('D', i32), ('H3', i32), ('use_v', i32), ('use_e', i32), ('use_c', i32), ('A', i32),
+                ('video', c_f), ('event', c_f), ('c3d', c_f), ('ev_start', c_f), ('ev_len', c_f), ('w', c_f), ('b', c_f), ('feats', c_f), ('h0', c_f)]
+
+
+class InitStateGrads(C.Structure):
+    _fields_ = [('g_h0', c_f), ('g_w', c_f), ('g_b', c_f), ('g_video', c_f), ('g_event', c_f), ('dfeats', c_f), ('zeroed', i32)]
 
 
 class SstArgs(C.Structure):
@@ -99,6 +108,8 @@ SYMBOLS = [
     ('echr_gemm_f32', i32, [C.POINTER(GemmDesc), C.c_void_p]),
     ('echr_event_pool_gather_fwd', i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
     ('echr_event_pool_gather_bwd', i32, [c_f, c_f, c_f, i32, i32, i32, C.c_void_p]),
+    ('echr_init_state_fwd', i32, [C.POINTER(InitStateArgs), C.c_void_p]),
+    ('echr_init_state_bwd', i32, [C.POINTER(InitStateArgs), C.POINTER(InitStateGrads), C.c_void_p]),
     ('echr_col_mean_fwd', i32, [c_f, i32, i32, i64, c_f, C.c_void_p]),
     ('echr_col_mean_bwd', i32, [c_f, i32, i32, i64, c_f, C.c_void_p]),
     ('echr_tsrm_ws_floats', i64, [i32, i32, i32, i32, i32]),
@@ -148,7 +159,7 @@ SYMBOLS = [
 
 ABI_STRUCTS = {'echr_gemm_desc': GemmDesc, 'echr_dropout': Dropout, 'echr_tsrm_args': TsrmArgs, 'echr_tsrm_grads': TsrmGrads,
                'echr_dec_args': DecArgs, 'echr_dec_grads': DecGrads, 'echr_sample_args': SampleArgs, 'echr_sst_args': SstArgs,
-               'echr_sst_grads': SstGrads, 'echr_train_step_args': TrainStepArgs}
+               'echr_sst_grads': SstGrads, 'echr_train_step_args': TrainStepArgs, 'echr_init_state_args': InitStateArgs, 'echr_init_state_grads': InitStateGrads}
 
 ABI_VERSION = 2          # include/echr_hip.h ECHR_ABI_VERSION
 _lib = None

@@ -926,10 +926,73 @@ extern "C" int64_t echr_abi_sizeof(const char* name) {
 #define ECHR_SZ(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T)
     ECHR_SZ(echr_gemm_desc); ECHR_SZ(echr_dropout); ECHR_SZ(echr_tsrm_args); ECHR_SZ(echr_tsrm_grads); ECHR_SZ(echr_dec_args); ECHR_SZ(echr_dec_grads);
     ECHR_SZ(echr_sample_args); ECHR_SZ(echr_sst_args); ECHR_SZ(echr_sst_grads); ECHR_SZ(echr_train_step_args);
+    ECHR_SZ(echr_init_state_args); ECHR_SZ(echr_init_state_grads);
 #undef ECHR_SZ
     return -1;
 }
 extern "C" const char* echr_last_error(void) { return g_err; }
+
+// ---- non-zero initial decoder state (OldModel.init_hidden, OldModel_NEW.py:72-96) ----
+// feats[n] = [video | event[n] | sum over the event's C3D rows / A]   (one block per event; A = the PADDED clip length of clip.mean(1))
+__global__ __launch_bounds__(256) void init_feats_kernel(echr_init_state_args a, int Dtot) {
+    const int n = blockIdx.x;
+    float* o = a.feats + (long)n * Dtot;
+    int off = 0;
+    if (a.use_v) { for (int j = threadIdx.x; j < a.Dv; j += 256) o[j] = a.video[j]; off += a.Dv; }
+    if (a.use_e) { for (int j = threadIdx.x; j < a.De; j += 256) o[off + j] = a.event[(long)n * a.De + j]; off += a.De; }
+    if (a.use_c) {
+        const int s = a.ev_start[n], len = a.ev_len[n];
+        const float inv = 1.0f / (float)a.A;
+        for (int j = threadIdx.x; j < a.D; j += 256) {
+            float acc = 0.f;
+            for (int r = 0; r < len; ++r) acc += a.c3d[(long)(s + r) * a.D + j];
+            o[off + j] = acc * inv;
+        }
+    }
+}
+// g_event[n, :] += dfeats[n, off : off + De]
+__global__ __launch_bounds__(256) void init_event_grad_kernel(const float* __restrict__ dfeats, float* __restrict__ g_event, int N, int De, int Dtot, int off) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * De) return;
+    const int n = (int)(i / De), j = (int)(i % De);
+    g_event[i] += dfeats[(long)n * Dtot + off + j];
+}
+static int init_dtot(const echr_init_state_args* a) { return (a->use_v ? a->Dv : 0) + (a->use_e ? a->De : 0) + (a->use_c ? a->D : 0); }
+extern "C" int echr_init_state_fwd(const echr_init_state_args* a, void* stream) {
+    ECHR_REQUIRE(a && a->N > 0 && a->H3 > 0 && a->w && a->b && a->feats && a->h0 && init_dtot(a) > 0, "init_state_fwd: bad arguments");
+    ECHR_REQUIRE((!a->use_v || a->video) && (!a->use_e || a->event) && (!a->use_c || (a->c3d && a->ev_start && a->ev_len && a->A > 0)), "init_state_fwd: missing inputs");
+    hipStream_t st = (hipStream_t)stream;
+    const int Dtot = init_dtot(a);
+    hipLaunchKernelGGL(init_feats_kernel, dim3(a->N), dim3(256), 0, st, *a, Dtot);
+    if (int rc = check_launch("init_feats")) return rc;
+    echr_gemm_desc d = desc_nt(a->feats, Dtot, a->w, Dtot, a->h0, a->H3, a->N, a->H3, Dtot);          // init_linear (:89)
+    d.bias = a->b;
+    return gemm(d, st);
+}
+extern "C" int echr_init_state_bwd(const echr_init_state_args* a, const echr_init_state_grads* g, void* stream) {
+    ECHR_REQUIRE(a && g && g->g_h0 && g->g_w && g->g_b && g->dfeats && a->feats && a->w, "init_state_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int Dtot = init_dtot(a);
+    const bool z = g->zeroed != 0;
+    echr_gemm_desc d = desc_tn(g->g_h0, a->H3, a->feats, Dtot, g->g_w, Dtot, a->H3, Dtot, a->N);          // d W = d h0^T . feats
+    d.beta = z ? 1.f : 0.f;
+    if (int rc = gemm(d, st)) return rc;
+    if (int rc = colsum(g->g_h0, a->H3, a->N, a->H3, g->g_b, z, st)) return rc;
+    if (!(g->g_video && a->use_v) && !(g->g_event && a->use_e)) return 0;
+    d = desc_nn(g->g_h0, a->H3, a->w, Dtot, g->dfeats, Dtot, a->N, Dtot, a->H3);                          // d feats = d h0 . W
+    if (int rc = gemm(d, st)) return rc;
+    int off = 0;
+    if (a->use_v) {
+        if (g->g_video) { if (int rc = colsum(g->dfeats, Dtot, a->N, a->Dv, g->g_video, false, st)) return rc; }          // the scene vector is shared by the N rows
+        off += a->Dv;
+    }
+    if (a->use_e && g->g_event) {
+        const long n = (long)a->N * a->De;
+        hipLaunchKernelGGL(init_event_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g->dfeats, g->g_event, a->N, a->De, Dtot, off);
+        return check_launch("init_event_grad");
+    }
+    return 0;
+}
 
 // ---- scene context 'VC' / 'VH' (CaptionGenerator.py:95-99): the mean over all T_v rows of c3d_feats / tap_feats ----
 __global__ __launch_bounds__(256) void col_scale_kernel(float* __restrict__ v, int n, float s) {

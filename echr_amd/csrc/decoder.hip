@@ -935,6 +935,30 @@ __global__ __launch_bounds__(256) void add_bcast_rows_kernel(float* __restrict__
     reinterpret_cast<float4*>(G)[i] = g;
 }
 
+// non-zero initial state (echr_dec_args.h0 [N, 3H]): h(-1) = HS[0] (same layout) and c_k(-1) = CS[k][0] = h0[:, kH:(k+1)H]
+__global__ __launch_bounds__(256) void init_state_copy_kernel(const float* __restrict__ h0, float* __restrict__ HS0, float* __restrict__ C0, float* __restrict__ C1,
+                                                              float* __restrict__ C2, int N, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * 3 * H) return;
+    const int n = (int)(i / (3 * H)), c = (int)(i % (3 * H)), k = c / H, j = c % H;
+    const float v = h0[i];
+    HS0[i] = v;
+    (k == 0 ? C0 : (k == 1 ? C1 : C2))[(long)n * H + j] = v;
+}
+// d loss / d h0 [N, 3H] = d h(-1) (what step 0's recurrent products left in the d h accumulators) + d c(-1) (the carried cell gradient)
+__global__ __launch_bounds__(256) void init_state_grad_kernel(const float* __restrict__ DH0, const float* __restrict__ DH1, const float* __restrict__ DH2,
+                                                              const float* __restrict__ DC, float* __restrict__ g_h0, int N, int H) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * 3 * H) return;
+    const int n = (int)(i / (3 * H)), c = (int)(i % (3 * H)), k = c / H, j = c % H;
+    g_h0[i] = (k == 0 ? DH0 : (k == 1 ? DH1 : DH2))[(long)n * H + j] + DC[i];
+}
+static int init_state_copy(const echr_dec_args* a, const DecWs& w, hipStream_t st) {
+    const long n = (long)a->N * 3 * a->H;
+    hipLaunchKernelGGL(init_state_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->h0, w.HS, w.CS[0], w.CS[1], w.CS[2], a->N, a->H);
+    return check_launch("init_state_copy");
+}
+
 // one decoder timestep given the input-side gate pre-activations already in GATES[k][t]
 //   launch 1: q and the three W_hh . h(t-1) products (all depend only on h(t-1))      -> slabs
 //   launch 2,3: attention scores, softmax + context
@@ -1256,6 +1280,7 @@ static int decoder_fwd_impl(const echr_dec_args* a, const echr_dropout* drop, vo
         RC(embed_gather(a->embed, a->tokens, w.XT, S * N, E, a->V1, st));
         RC(input_gates(a, w, w.XT, 0, S, st));
     }
+    if (a->h0) RC(init_state_copy(a, w, st));          // OldModel.init_hidden with CG_init_feats_type (:79-96): behind the zero fill of HS[0] / CS[k][0]
     // late fusion: logits = OUTD . W_logit^T + b, written [N,S,V1], then row log-softmax in place.  Timesteps [0,th) are
     // projected on the side stream while the recurrence of [th,S) is still running.
     auto logits_chunk = [&](int t0, int t1, hipStream_t q) -> int {
@@ -1544,12 +1569,13 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
         hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((N * H + 255) / 256, nk), dim3(256), 0, q, P,
                            b.DOUT + (long)t * N * 3 * H, b.DC, N, H, t, dh, dout);
         RC(check_launch("lstm_pointwise_bwd"));
-        // d h(t-1) = dG_k(t) . W_hh_k  (skipped at t = 0: h(-1) is the constant zero state);  d ATT = dG_1(t) . W_ih1[:,E:]
+        // d h(t-1) = dG_k(t) . W_hh_k  (skipped at t = 0 when h(-1) is the constant zero state; with echr_dec_args.h0 it is d h0);  d ATT = dG_1(t) . W_ih1[:,E:]
+        const bool rec0 = t > 0 || (a->h0 && g->g_h0);
         RecArgs ra;
         ra.M = N; ra.njobs = 0;
         float* datt = b.DASL + (long)t * N * D;     // re-read by every attention workgroup of an event: one atomically summed buffer
         if (do1) ra.job[ra.njobs++] = mkjob(P.dgates[1], 4 * H, 4 * H, b.WT_ATT, 4 * H, D, datt, as, D, 1);
-        if (t > 0)
+        if (rec0)
             for (int k = 0; k < 3; ++k)
                 if (k == 1 ? do1 : do02) ra.job[ra.njobs++] = mkjob(P.dgates[k], 4 * H, 4 * H, b.WT_HH[k], 4 * H, H, b.DHACC[k], hs, H, 1);
         if (ra.njobs > 0) RC(rec_gemm(ra, q));
@@ -1562,7 +1588,7 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
         RC(launch_att_bwd(ad, w.PALL, a->c3d, w.QS + (long)t * N * Ha, a->w_alpha, w.WT + (long)t * N * A, w.ATT + (long)t * N * D,
                           datt, 1, as, a->ev_start, a->ev_len, b.DSC + (long)t * N * A, dq, q));
         }
-        if (t > 0) {   // d h1(t-1) += dq . W_h : extra slabs behind stream 1's W_hh slabs
+        if (rec0) {   // d h1(t-1) += dq . W_h : extra slabs behind stream 1's W_hh slabs
             ra.njobs = 1;
             ra.job[0] = mkjob(dq, Ha, Ha, b.WT_H2A, Ha, H, b.DHACC[1], hs, H, 1);
             RC(rec_gemm(ra, q));
@@ -1591,6 +1617,11 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
                 RC(wgrad_chunk(th_b, S, zb, sq));
             }
         }
+    }
+    if (do_rec_main && a->h0 && g->g_h0) {          // d loss / d (initial state): what step 0 left in the d h accumulators + the carried d c
+        const long n = (long)N * 3 * H;
+        hipLaunchKernelGGL(init_state_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b.DHACC[0], b.DHACC[1], b.DHACC[2], b.DC, g->g_h0, N, H);
+        RC(check_launch("init_state_grad"));
     }
     // 4. batched parameter gradients, part A: everything of the three LSTM layers (core.layer0..2) -- final after this block, so a
     //    data-parallel caller can start reducing them (phase 3) while part B runs
@@ -1954,6 +1985,7 @@ extern "C" int echr_decoder_sample(const echr_sample_args* sa, void* stream) {
         long zn[8] = {L + 1, (long)N * 3 * H, (long)N * H, (long)N * H, (long)N * H, N, 2L * N * L, (long)N * L};
         RC(fill_zero_multi(zp, zn, persistent ? 1 : 8, st));
     }
+    if (a.h0 && !persistent) RC(init_state_copy(&a, w, st));          // OldModel.sample starts from init_hidden too (:141)
     // many events (evaluation: up to 1000 proposals): the per-step token-side gate products and the logits product are 6 + 15 GF -- they run
     // on h2 operands (weights packed once per decode, the step's N rows packed per step; one fixed-order k loop per tile, so the decode stays
     // bitwise reproducible).  Few events: exact fp32 MFMA as before (the products are launch-bound there).

@@ -3182,7 +3182,7 @@ static bool persist_shape_ok(const echr_dec_args* a) {
     // A <= 129: every form; 129 < A <= 258: the one-launch pairs of two half-chip machines only (their BIG instantiations: second slot set)
     const bool a_ok = a->A <= PSET2 || (a->A <= 2 * PSET2 && config().persist_split && config().persist_merge);
     return h.ok && h.cus >= NWG && a->N <= PROWS && a_ok && a->H == PH && a->Ha == PH && a->D <= PH && a->D % 4 == 0 && a->D >= 8 &&
-           a->S >= 1;
+           a->S >= 1 && !a->h0;          // (a non-zero initial state: the persistent kernels assume h(-1) = c(-1) = 0)
 }
 
 bool persist_fwd_eligible(const echr_dec_args* a) { return config().persist && persist_shape_ok(a); }
@@ -3320,7 +3320,7 @@ long persist_logit_image_floats(int V1) { const long nvb = (long)LWG * logit_chu
 bool persist_sample_shape_ok(const echr_dec_args* a) {
     PersistHost& h = phost();
     return h.ok && h.cus >= NWG && a->N >= 1 && a->A <= 2 * PSET2 && a->H == PH && a->Ha == PH && a->D <= PH && a->D % 4 == 0 && a->D >= 8 && a->S >= 1 && a->S <= 64 &&
-           a->V1 <= LWG * LCOLS * LCHMAX && a->V1 >= 2;
+           a->V1 <= LWG * LCOLS * LCHMAX && a->V1 >= 2 && !a->h0;          // (the persistent decoder starts from the zero state)
 }
 // ... and with the switches that select it
 bool persist_sample_eligible(const echr_dec_args* a) {

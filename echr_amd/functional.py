@@ -224,7 +224,7 @@ DEC_PARAMS = ('embed', 'w_logit', 'b_logit',
               'w_c2a', 'b_c2a', 'w_h2a', 'b_h2a', 'w_alpha', 'b_alpha')
 
 
-def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint=False, n_de=None, prepared=0, train=0):
+def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint=False, n_de=None, prepared=0, train=0, h0=None):
     (embed, w_logit, b_logit, wi0, wi1, wi2, wh0, wh1, wh2, bi0, bi1, bi2, bh0, bh1, bh2, w_c2a, b_c2a, w_h2a, b_h2a,
      w_alpha, b_alpha) = ps
     N, De = event.shape if event is not None else n_de
@@ -242,7 +242,7 @@ def _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, d
                      L.ptr(w_c2a), L.ptr(b_c2a), L.ptr(w_h2a), L.ptr(b_h2a), L.ptr(w_alpha), L.ptr(b_alpha),
                      L.ptr(c3d), L.ptr(ev_start, torch.int32), L.ptr(ev_len, torch.int32), L.ptr(event), L.ptr(video),
                      L.ptr(tokens, torch.int32) if tokens is not None else None, L.ptr(ws), L.ptr(logp) if logp is not None else None,
-                     int(prepared), int(train), None, 0)
+                     int(prepared), int(train), None, 0, L.ptr(h0) if h0 is not None else None)
 
 
 def decoder_prepare(video, c3d, ev_start, ev_len, tokens, A, disjoint, params):
@@ -270,6 +270,49 @@ def decoder_prepare_cancel():
     L.check(L.load().echr_decoder_fwd_prepare_cancel(L.stream_ptr()), 'decoder_fwd_prepare_cancel')
 
 
+class InitState(torch.autograd.Function):
+    """OldModel.init_hidden with CG_init_feats_type (OldModel_NEW.py:79-96): h0 [N, 3H] = init_linear(cat([video | event | clip.mean(1)])) -- the
+    tensor the reference then views as (N, 3, H) and transposes; the decoder entry points take it in this layout (echr_dec_args.h0)."""
+
+    @staticmethod
+    def forward(ctx, video, event, c3d, ev_start, ev_len, A, use, sink, w, b):
+        lib = L.load()
+        use_v, use_e, use_c = use
+        video, event, c3d, w, b = _f32c(video), _f32c(event), _f32c(c3d), _f32c(w), _f32c(b)
+        N, De = event.shape
+        Dv, D, H3, Dtot = video.numel(), c3d.shape[1], w.shape[0], w.shape[1]
+        if Dtot != (Dv if use_v else 0) + (De if use_e else 0) + (D if use_c else 0):
+            raise L.EchrHipError('init_linear is %d wide, the selected contexts give %d' % (Dtot, (Dv if use_v else 0) + (De if use_e else 0) + (D if use_c else 0)))
+        feats = torch.empty(N, Dtot, device=event.device, dtype=torch.float32)
+        h0 = torch.empty(N, H3, device=event.device, dtype=torch.float32)
+        a = L.InitStateArgs(N, Dv, De, D, H3, int(use_v), int(use_e), int(use_c), int(A), L.ptr(video), L.ptr(event), L.ptr(c3d),
+                            L.ptr(ev_start, torch.int32), L.ptr(ev_len, torch.int32), L.ptr(w), L.ptr(b), L.ptr(feats), L.ptr(h0))
+        L.check(lib.echr_init_state_fwd(C.byref(a), L.stream_ptr()), 'init_state_fwd')
+        ctx.save_for_backward(video, event, c3d, ev_start, ev_len, w, b, feats)
+        ctx.meta = (A, use)
+        ctx.sink = sink
+        return h0
+
+    @staticmethod
+    def backward(ctx, g_h0):
+        lib = L.load()
+        video, event, c3d, ev_start, ev_len, w, b, feats = ctx.saved_tensors
+        A, (use_v, use_e, use_c) = ctx.meta
+        N, De = event.shape
+        g_h0 = _f32c(g_h0)
+        zeroed = 1 if (ctx.sink is not None and ctx.sink.usable()) else 0
+        g_w, g_b = ctx.sink.take() if zeroed else (torch.empty_like(w), torch.empty_like(b))
+        g_video = torch.empty_like(video) if (use_v and ctx.needs_input_grad[0]) else None
+        g_event = torch.zeros_like(event) if (use_e and ctx.needs_input_grad[1]) else None
+        dfeats = torch.empty_like(feats)
+        a = L.InitStateArgs(N, video.numel(), De, c3d.shape[1], w.shape[0], int(use_v), int(use_e), int(use_c), int(A), L.ptr(video), L.ptr(event),
+                            L.ptr(c3d), L.ptr(ev_start, torch.int32), L.ptr(ev_len, torch.int32), L.ptr(w), L.ptr(b), L.ptr(feats), None)
+        g = L.InitStateGrads(L.ptr(g_h0), L.ptr(g_w), L.ptr(g_b), L.ptr(g_video) if g_video is not None else None,
+                             L.ptr(g_event) if g_event is not None else None, L.ptr(dfeats), zeroed)
+        L.check(lib.echr_init_state_bwd(C.byref(a), C.byref(g), L.stream_ptr()), 'init_state_bwd')
+        return g_video, g_event, None, None, None, None, None, None, g_w, g_b
+
+
 class ColMean(torch.autograd.Function):
     """x.mean(0) of a [T, D] feature matrix: the 'VC' / 'VH' scene contexts (CaptionGenerator.py:95-99)."""
 
@@ -293,27 +336,29 @@ class DecoderFunction(torch.autograd.Function):
     """OldModel.forward with the ThreeStream core (OldModel_NEW.py:98-137, :376-401, :801-823): log-probs [N,S,V1]."""
 
     @staticmethod
-    def forward(ctx, video, event, c3d, ev_start, ev_len, tokens, A, disjoint, drop, sink, prep, *params):
+    def forward(ctx, video, event, c3d, ev_start, ev_len, tokens, A, disjoint, drop, sink, prep, h0, *params):
         lib = L.load()
         ctx.sink = sink
         event = _f32c(event)
+        h0 = _f32c(h0) if h0 is not None else None          # [N, 3H] initial state (OldModel.init_hidden, CG_init_feats_type); None = zeros
         S, N = tokens.shape
         if prep is not None:          # decoder_prepare() already ran the event-independent part on this workspace
             video, c3d, ps, logp, ws = prep['video'], prep['c3d'], prep['ps'], prep['logp'], prep['ws']
             train = prep['train']
-            a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint, prepared=1, train=train)
+            a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint, prepared=1, train=train, h0=h0)
         else:
             video, c3d = _f32c(video), _f32c(c3d)
             ps = [_f32c(p) for p in params]
             V1 = ps[0].shape[0]
             logp = torch.empty(N, S, V1, device=event.device, dtype=torch.float32)
             train = 1 if any(ctx.needs_input_grad) else 0
-            a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, None, logp, disjoint, train=train)
+            a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, None, logp, disjoint, train=train, h0=h0)
             ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=event.device, dtype=torch.float32)
             a.ws = L.ptr(ws)
         d = drop.c()
         L.check(lib.echr_decoder_fwd(C.byref(a), C.byref(d), L.stream_ptr()), 'decoder_fwd')
         ctx.save_for_backward(video, event, c3d, ev_start, ev_len, tokens, ws, logp, *ps)
+        ctx.h0 = h0
         ctx.meta = (A, S, drop, disjoint, train)
         return logp
 
@@ -345,7 +390,9 @@ class DecoderFunction(torch.autograd.Function):
             grads[0].zero_()                                 # embedding table gradient is scatter-added
         g_event = torch.empty_like(event)
         g_video = torch.empty_like(video) if ctx.needs_input_grad[0] else None
-        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint, train=train)
+        h0 = ctx.h0
+        g_h0 = torch.empty_like(h0) if (h0 is not None and ctx.needs_input_grad[11]) else None
+        a = _dec_args(ps, c3d, ev_start, ev_len, event, video, tokens, A, S, ws, logp, disjoint, train=train, h0=h0)
         wsb = torch.empty(lib.echr_decoder_ws_bwd_floats(C.byref(a)), device=event.device, dtype=torch.float32)
         gp = [L.ptr(x) for x in grads]
         g = L.DecGrads(gp[0], gp[1], gp[2], (L.c_f * 3)(*gp[3:6]), (L.c_f * 3)(*gp[6:9]), (L.c_f * 3)(*gp[9:12]),
@@ -354,7 +401,7 @@ class DecoderFunction(torch.autograd.Function):
                        L.ptr(fused[0], fused[0].dtype) if fused else None, L.ptr(fused[1]) if fused else None, L.ptr(fused[3]) if fused else None,
                        L.ptr(wsb), zeroed, 0, 0, L.ptr(fused[2][1:2]) if fused else None,
                        L.ptr(zero_span) if zero_span is not None else None, zero_span.numel() if zero_span is not None else 0,
-                       1 if (fused and fused[0].dtype == torch.int64) else 0)
+                       1 if (fused and fused[0].dtype == torch.int64) else 0, 0, None, 0, L.ptr(g_h0) if g_h0 is not None else None)
         d = drop.c()
         hook = getattr(ctx.sink.arena, 'early_grad_hook', None) if zeroed else None
         staged = hook is not None and getattr(ctx.sink.arena, 'early_staged', True)
@@ -393,11 +440,11 @@ class DecoderFunction(torch.autograd.Function):
                     L.check(lib.echr_stream_join(sp), 'stream_join')
                     del keep[:]
                 torch.autograd.Variable._execution_engine.queue_callback(_join)
-        return (g_video, g_event, None, None, None, None, None, None, None, None, None) + tuple(grads)
+        return (g_video, g_event, None, None, None, None, None, None, None, None, None, g_h0) + tuple(grads)
 
 
 def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, debug=None, multinomial=False, temperature=1.0, seed=0,
-                  table_cache=None):
+                  table_cache=None, h0=None):
     """OldModel.sample (OldModel_NEW.py:139-187) with every step on device; one host sync at the end.  Greedy arg-max by default
     (sample_max = 1); multinomial=True draws each token from softmax(logp / temperature) (:160-168) with the library's Philox stream
     keyed by `seed`.
@@ -412,7 +459,8 @@ def greedy_sample(video, event, c3d, ev_start, ev_len, A, seq_length, params, de
     ps = [_f32c(p) for p in params]
     N = event.shape[0]
     dev = event.device
-    a = _dec_args(ps, c3d, ev_start, ev_len, event, video, None, A, seq_length, None, None)
+    h0 = _f32c(h0) if h0 is not None else None
+    a = _dec_args(ps, c3d, ev_start, ev_len, event, video, None, A, seq_length, None, None, h0=h0)
     ws = torch.empty(lib.echr_decoder_ws_floats(C.byref(a)), device=dev, dtype=torch.float32)
     a.ws = L.ptr(ws)
     wss = torch.empty(lib.echr_sampler_ws_floats(C.byref(a)), device=dev, dtype=torch.float32)

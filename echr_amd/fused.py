@@ -34,6 +34,8 @@ class FusedTrainStep(object):
         arena = optimizer.arena
         if getattr(model, '_echr_arena', None) is not arena or not arena.params_in_arena():
             raise ValueError('the optimiser\'s arena is not the model\'s (call model.build_arena() after .cuda(), pass it to ClampAdam)')
+        if getattr(model.lm_model, 'CG_init_feats_dim', 0):
+            raise NotImplementedError('the fused step implements the ECHR recipe (zero initial state); CG_init_feats_type runs on the autograd path')
         if not hasattr(model, 'fusion_model') or model.opt.event_context_type != 'ER3':
             raise NotImplementedError('the fused step implements the ECHR recipe (event_context_type ER3 + TSRM8); ER1 / ER2 run on the autograd path')
         if len(optimizer.param_groups) != 1 or {id(p) for p in optimizer.param_groups[0]['params']} != {id(p) for p in arena.params}:

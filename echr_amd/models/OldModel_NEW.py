@@ -76,8 +76,9 @@ class OldModel(nn.Module):
         self.CG_init_feats_dim = self.decide_init_feats_dim()
         self.ss_prob = 0.0
         if self.CG_init_feats_dim:
-            raise NotImplementedError('CG_init_feats_type=%r: the HIP path implements the ECHR recipe (zero initial state, '
-                                      'train_ECHR.sh)' % (opt.CG_init_feats_type,))
+            # non-zero initial state (OldModel_NEW.py:38-39, :79-96): h(-1) = c(-1) = init_linear(cat(selected contexts)); registered ahead of
+            # `embed` like the reference does
+            self.init_linear = nn.Linear(self.CG_init_feats_dim, self.num_layers * self.rnn_size)
         self.embed = nn.Embedding(self.vocab_size + 1, self.input_encoding_size)
         if 'three_stream' not in opt.caption_model or 'three_stream_2stream' in opt.caption_model:
             raise NotImplementedError('caption_model=%r: only the three_stream decoder is on the HIP path' % (opt.caption_model,))
@@ -189,13 +190,28 @@ class OldModel(nn.Module):
         arena = getattr(self, '_echr_arena_ref', None)
         sink = EF.GradSink(arena, self.native_params()) if arena is not None else None
         return EF.DecoderFunction.apply(video, event, cv.feats, cv.ev_start, cv.ev_len, tokens, cv.max_len, cv.rows_disjoint, drop, sink,
-                                        prepared, *self.native_params())
+                                        prepared, self._initial_state(video, event, cv), *self.native_params())
 
-    def init_hidden(self, video, event, clip):
-        """Zero initial state (h, c), each [3,N,H] (OldModel_NEW.py:72-78 with CG_init_feats_type = '')."""
+    def _initial_state(self, video, event, cv):
+        """None (the recipe: zero state) or h0 [N, 3H] = init_linear(cat([video | event | clip.mean(1)])) (OldModel_NEW.py:79-92) -- the decoder
+        entry points take the map in this layout; the reference's view(N, 3, H).transpose(0, 1) is `init_hidden`'s."""
+        if not self.CG_init_feats_dim:
+            return None
+        t = self.CG_init_feats_type
+        arena = getattr(self, '_echr_arena_ref', None)
+        sink = EF.GradSink(arena, (self.init_linear.weight, self.init_linear.bias)) if arena is not None else None
+        return EF.InitState.apply(video, event, cv.feats, cv.ev_start, cv.ev_len, cv.max_len, ('V' in t, 'E' in t, 'C' in t), sink,
+                                  self.init_linear.weight, self.init_linear.bias)
+
+    def init_hidden(self, video, event, clip, clip_mask=None):
+        """Initial state (h, c), each [3,N,H] (OldModel_NEW.py:72-96): zeros, or -- with CG_init_feats_type -- the init_linear map for both."""
         n = event.shape[0] if event is not None else clip.shape[0]
         w = self.logit.weight
-        return (w.new_zeros(self.num_layers, n, self.rnn_size), w.new_zeros(self.num_layers, n, self.rnn_size))
+        if not self.CG_init_feats_dim:
+            return (w.new_zeros(self.num_layers, n, self.rnn_size), w.new_zeros(self.num_layers, n, self.rnn_size))
+        h0 = self._initial_state(video, event, self._clip_view(clip, clip_mask))
+        m = h0.view(n, self.num_layers, self.rnn_size).transpose(0, 1)
+        return (m, m)
 
     def get_logprobs_state(self, it, video, event, clip, clip_mask, state):
         """One decoder timestep, state in / state out (OldModel_NEW.py:133-137): (log-probs [N,V+1], (h', c')).
@@ -227,7 +243,7 @@ class OldModel(nn.Module):
                 self._sample_tables = {}          # decoding operands derived from the parameters alone, reused across calls (EF.greedy_sample)
             return EF.greedy_sample(video, event, cv.feats, cv.ev_start, cv.ev_len, cv.max_len, self.seq_length,
                                     self.native_params(), multinomial=multinomial, temperature=float(opt.get('temperature', 1.0)),
-                                    seed=seed, table_cache=self._sample_tables)
+                                    seed=seed, table_cache=self._sample_tables, h0=self._initial_state(video, event, cv))
 
 
 class Attention(nn.Module):

@@ -55,6 +55,11 @@ def state_dict_shapes(opt):
         'lm_model.embed.weight': (V1, E),
         'lm_model.logit.weight': (V1, 3 * H), 'lm_model.logit.bias': (V1,),
     }
+    it = getattr(opt, 'CG_init_feats_type', '')       # non-zero initial state (OldModel_NEW.py:38-39,55-63): Linear(selected context widths -> 3H)
+    init_in = (vi if 'V' in it else 0) + (ev if 'E' in it else 0) + (cl if 'C' in it else 0)
+    if init_in:
+        s['lm_model.init_linear.weight'] = (3 * H, init_in)
+        s['lm_model.init_linear.bias'] = (3 * H,)
     for k, cin in ((0, ev + E), (1, cl + E), (2, vi + E)):
         s['lm_model.core.layer%d.weight_ih' % k] = (4 * H, cin)
         s['lm_model.core.layer%d.weight_hh' % k] = (4 * H, H)
@@ -158,6 +163,10 @@ CASES = {
     'fst2': dict(opt=dict(fST_type='fST2', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=65), gate_shift=1.0),
     'fst3': dict(opt=dict(fST_type='fST3', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=66)),
     'noposit': dict(opt=dict(use_posit=0, CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=67)),
+    # non-zero initial decoder state (OldModel_NEW.py:79-96): h(-1) = c(-1) = init_linear(cat([scene | event | clip.mean(1)])), ragged events so
+    # that the mean over the PADDED frame slots differs from a mean over each event's own rows
+    'init': dict(opt=dict(CG_init_feats_type='VEC', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=68)),
+    'initc': dict(opt=dict(CG_init_feats_type='C', CG_vocab_size=300, CG_seq_length=7), video=dict(N=12, A=40, L=9, seed=69)),
     # EXACTLY the layout bench.py times (BASELINE config 3): 64 disjoint 128-segment events on a T_v = 8192 video
     'c3bench': dict(opt=dict(CG_vocab_size=5000, CG_seq_length=19), video=dict(N=64, A=128, L=21, seed=1234, disjoint=True)),
 }

@@ -123,6 +123,30 @@ int echr_event_pool_gather_fwd(const float* c3d, const float* tap, const int32_t
                                const int32_t* ind, float* ech, int32_t N, int32_t D, int32_t Ht, void* stream);
 int echr_event_pool_gather_bwd(const float* d_ech, const int32_t* ind, float* d_tap, int32_t N, int32_t D, int32_t Ht,
                                void* stream);
+/* Non-zero initial decoder state (OldModel.init_hidden, OldModel_NEW.py:72-96; CG_init_feats_type from 'V', 'E', 'C'):
+ *   feats = cat([video broadcast over the N events | event | clip.mean(1)], 1);   h0 = init_linear(feats)   [N, 3H]
+ * `clip.mean(1)` is the mean over the A PADDED slots of CaptionGenerator.get_clip_context (zeros behind an event's end): sum over the event's
+ * rows / A.  bwd: gradients of init_linear (written, or accumulated when `zeroed`), d video (written), d event (ADDED to g_event); c3d is data. */
+typedef struct {
+    int32_t N, Dv, De, D, H3;                  /* events; widths of the scene / event context, of a C3D row; 3 * rnn_size */
+    int32_t use_v, use_e, use_c;               /* 'V' / 'E' / 'C' in CG_init_feats_type */
+    int32_t A;                                 /* padded clip length (max event length of the batch) */
+    const float *video, *event, *c3d;          /* [Dv], [N,De], [Tv,D] */
+    const int32_t *ev_start, *ev_len;
+    const float *w, *b;                        /* init_linear.weight [H3, Dtot], .bias [H3] */
+    float* feats;                              /* [N, Dtot] scratch; the backward pass reads it again */
+    float* h0;                                 /* out [N, H3] */
+} echr_init_state_args;
+typedef struct {
+    const float* g_h0;                         /* [N, H3] */
+    float *g_w, *g_b;                          /* [H3, Dtot], [H3] */
+    float *g_video, *g_event;                  /* [Dv] written (NULL: not wanted), [N,De] added into (NULL: not wanted) */
+    float* dfeats;                             /* [N, Dtot] scratch */
+    int32_t zeroed;                            /* 1: g_w / g_b are pre-zeroed accumulation targets */
+} echr_init_state_grads;
+int echr_init_state_fwd(const echr_init_state_args* a, void* stream);
+int echr_init_state_bwd(const echr_init_state_args* a, const echr_init_state_grads* g, void* stream);
+
 /* Scene context 'VC' / 'VH' (CaptionGenerator.get_video_context, CaptionGenerator.py:95-99: `c3d_feats.mean(0)`, `tap_feats.mean(0)`):
  * out[c] = mean over the `rows` rows of x[:, c] (x row-major with leading dimension ld); bwd: gx[r, c] += g[c] / rows. */
 int echr_col_mean_fwd(const float* x, int32_t rows, int32_t cols, int64_t ld, float* out, void* stream);
@@ -219,6 +243,10 @@ typedef struct {
     float* zero_extra;                         /* echr_decoder_fwd / _prepare, optional: a range the caller wants zero-filled before the backward pass (its
                                                   gradient arena), folded into the forward's first fill launch; NULL = none */
     int64_t zero_extra_count;                  /* floats */
+    const float* h0;                           /* optional [N, 3H]: the initial state, `init_linear(cat(...))` BEFORE its view / transpose
+                                                  (OldModel_NEW.py:72-96, CG_init_feats_type non-empty): stream k starts from h = c = h0[:, kH:(k+1)H].
+                                                  NULL = the recipe's zero state.  With it the recurrences run launch per phase (the persistent
+                                                  kernels assume h(-1) = 0) */
 } echr_dec_args;
 
 typedef struct {
@@ -272,6 +300,7 @@ typedef struct {
                                                   rows (logits and d logits exist as [n_active, V1], d OUTD is scattered back by row, d W_logit contracts
                                                   over n_active rows) and the recurrent weight gradients and d XT contract / run over the same rows */
     int32_t n_active;
+    float* g_h0;                               /* optional [N, 3H] out (written): d loss / d h0 = d h(-1) + d c(-1) of every stream (echr_dec_args.h0) */
 } echr_dec_grads;
 
 /* make `stream` wait for an asynchronous decoder-backward tail (echr_dec_grads.async_tail); no-op when none is pending */

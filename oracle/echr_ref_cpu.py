@@ -213,14 +213,33 @@ def n_decoder_steps(seq):
     return S
 
 
-def decoder_forward(P, video, event, clip, mask, seq, drop=None):
+def init_hidden(P, video, event, clip, init_feats_type=''):
+    """OldModel.init_hidden.  OldModel_NEW.py:72-96: zeros, or h(-1) = c(-1) = init_linear(cat([video (broadcast) | event | clip.mean(1)]))
+    viewed [N,3,H] and transposed to [3,N,H].  clip.mean(1) runs over all A PADDED slots of the clip tensor, like the reference's."""
+    N = event.shape[0]
+    H = P['lm_model.core.layer0.weight_hh'].shape[1]
+    if not any(k in init_feats_type for k in 'VEC'):
+        return (event.new_zeros(3, N, H), event.new_zeros(3, N, H))            # :75-78
+    feats = []
+    if 'V' in init_feats_type:
+        feats.append(video.reshape(1, -1).expand(N, video.numel()))
+    if 'E' in init_feats_type:
+        feats.append(event)
+    if 'C' in init_feats_type:
+        feats.append(clip.mean(1))
+    x = torch.cat(feats, 1)
+    m = (x @ P['lm_model.init_linear.weight'].t() + P['lm_model.init_linear.bias']).view(N, 3, H).transpose(0, 1)
+    return (m, m)
+
+
+def decoder_forward(P, video, event, clip, mask, seq, drop=None, init_feats_type=''):
     """OldModel.forward, teacher forcing (ss_prob = 0).  OldModel_NEW.py:98-130.
 
     drop: None (eval) or callable (site, step, shape) -> multiplicative mask tensor, with
     site in {'h0','h1','h2','out'}.  Returns log-probs [N,S,V1]."""
     N = event.shape[0]
     H = P['lm_model.core.layer0.weight_hh'].shape[1]
-    state = (event.new_zeros(3, N, H), event.new_zeros(3, N, H))               # init_hidden :75-78
+    state = init_hidden(P, video, event, clip, init_feats_type)
     outs = []
     for i in range(seq.shape[1] - 1):
         if i >= 1 and int(seq[:, i].sum()) == 0:                               # :122
@@ -234,13 +253,13 @@ def decoder_forward(P, video, event, clip, mask, seq, drop=None):
     return torch.stack(outs, 1)
 
 
-def decoder_sample(P, video, event, clip, mask, seq_length):
+def decoder_sample(P, video, event, clip, mask, seq_length, init_feats_type=''):
     """Greedy OldModel.sample (sample_max=1, eval mode).  OldModel_NEW.py:139-187.
 
     Returns (seq int64 [N,<=seq_length], logp float32 same shape), or ([],[]) if nothing generated."""
     N = event.shape[0]
     H = P['lm_model.core.layer0.weight_hh'].shape[1]
-    state = (event.new_zeros(3, N, H), event.new_zeros(3, N, H))
+    state = init_hidden(P, video, event, clip, init_feats_type)
     seq, slp = [], []
     logprobs = None
     unfinished = None
@@ -272,7 +291,7 @@ def lm_criterion(logp, target, mask):
 
 
 def caption_forward(P, tap, c3d, lda, labels, ind, soi, mode='train', drop=None, n_head=16, seq_length=None, video_context_type='VL',
-                    event_context_type='ER3', fST_type='fST0', use_posit=1):
+                    event_context_type='ER3', fST_type='fST0', use_posit=1, init_feats_type=''):
     """CaptionGenerator.forward for the live modes 'train' / 'eval'.  CaptionGenerator.py:17-43."""
     video = video_context(lda, c3d, tap, video_context_type)
     N = len(soi)
@@ -280,8 +299,8 @@ def caption_forward(P, tap, c3d, lda, labels, ind, soi, mode='train', drop=None,
     event = event_context(P, tap, c3d, ind, soi, n_head, dmask, event_context_type, fST_type, use_posit)
     clip, mask = clip_context(c3d, soi)
     if mode == 'train':
-        return decoder_forward(P, video, event, clip, mask, labels, drop)
-    return decoder_sample(P, video, event, clip, mask, seq_length)
+        return decoder_forward(P, video, event, clip, mask, labels, drop, init_feats_type)
+    return decoder_sample(P, video, event, clip, mask, seq_length, init_feats_type)
 
 
 # ----------------------------------------------------------------------------------------------

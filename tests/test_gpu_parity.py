@@ -339,7 +339,7 @@ def test_event_context_inference_tables_vs_oracle():
     assert U.relerr(tab, dense) < 2e-6 and U.relerr(tab, dense_ng) < 2e-6 and U.relerr(nob, dense) < 2e-6
 
 
-@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full', 'c3bench', 'vctx', 'er1', 'er2'])
+@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full', 'c3bench', 'vctx', 'er1', 'er2', 'init', 'initc'])
 @pytest.mark.parametrize('train_mode', [False, True])
 def test_full_path_vs_oracle(case, train_mode):
     """CaptionGenerator forward + criterion + backward against the oracle run on the host with identical dropout masks: EVERY log-prob
@@ -357,7 +357,7 @@ def test_full_path_vs_oracle(case, train_mode):
             assert U.grad_close(k, grads[k], g, TOL_GRAD), (k, U.relerr(grads[k], g))
 
 
-@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full', 'c3bench', 'vctx', 'er1', 'er2'])
+@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full', 'c3bench', 'vctx', 'er1', 'er2', 'init', 'initc'])
 @pytest.mark.parametrize('train_mode', [False, True])
 def test_full_path_vs_reference_golden(case, train_mode):
     """Same, against the fixtures the reference itself produced (full tensors for 'tiny', summaries otherwise)."""
@@ -548,7 +548,7 @@ def test_long_events_vs_oracle(N, A, min_len):
             assert U.grad_close(k, grads[k], g, TOL_GRAD), (k, U.relerr(grads[k], g))
 
 
-@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full', 'c3bench', 'vctx', 'er1', 'er2'])
+@pytest.mark.parametrize('case', ['tiny', 'c1', 'c2', 'c2full', 'c3bench', 'vctx', 'er1', 'er2', 'init', 'initc'])
 def test_greedy_sample_bit_exact(case):
     """mode='eval': the index output must equal the reference's greedy sequence exactly; log-probs within 1e-4."""
     opt, params, vid = synth.make_case(case)

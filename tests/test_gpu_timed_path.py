@@ -382,3 +382,34 @@ def test_event_encoder_combinators_through_the_one_call_path():
                 assert U.grad_close(k, p.grad.cpu().numpy(), rgrads[k], TOL_GRAD), (case, k, U.relerr(p.grad.cpu().numpy(), rgrads[k]))
             else:
                 assert p.grad is None or not bool(p.grad.abs().max() > 0), (case, k)
+
+
+@pytest.mark.parametrize('case', ['init', 'initc'])
+def test_initial_state_map_vs_oracle_and_module_contract(case):
+    """CG_init_feats_type (OldModel_NEW.py:72-96): `init_hidden` returns the SAME [3,N,H] tensor for h and c -- init_linear over
+    cat([scene | event | clip.mean(1)]), the clip mean over the PADDED frame slots -- element-wise against the oracle, from the zero-copy clip
+    view and from the padded [N,A,D] tensor an external caller passes; the one-call step refuses the option (the recipe has a zero state)."""
+    from echr_amd import functional as EF
+    from oracle import echr_ref_cpu as O
+    opt, params, vid = synth.make_case(case)
+    m = U.build_gpu_model(opt, params, False)
+    dev = torch.device('cuda')
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    with torch.no_grad():
+        ovideo = O.video_context(torch.from_numpy(vid['lda']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['tap']), opt.video_context_type)
+        oevent = O.event_context(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), vid['ind'], vid['soi'], opt.n_head, None)
+        oclip, _ = O.clip_context(torch.from_numpy(vid['c3d']), vid['soi'])
+        oh, oc = O.init_hidden(P, ovideo, oevent, oclip, opt.CG_init_feats_type)
+        ev = EF.event_index_tensors(vid['soi'], vid['ind'], dev)
+        video = m.get_video_context(tap, c3d, lda, vid['ind'], vid['soi'])
+        event = oevent.to(dev)
+        view, _ = m.get_clip_context(tap, c3d, lda, vid['ind'], vid['soi'], _ev=ev)
+        clip, clip_mask = m.get_clip_context(tap, c3d, lda, vid['ind'], vid['soi'])
+        h_view, c_view = m.lm_model.init_hidden(video, event, view)
+        h_pad, _ = m.lm_model.init_hidden(video, event, clip, clip_mask)
+    assert h_view is c_view and tuple(h_view.shape) == (3, len(vid['soi']), opt.CG_rnn_size)
+    assert U.relerr(h_view.cpu().numpy(), oh.numpy()) < 2e-6
+    assert U.relerr(h_pad.cpu().numpy(), oh.numpy()) < 2e-6
+    with pytest.raises(NotImplementedError):
+        _fused(opt, params)

@@ -33,7 +33,7 @@ def test_tiny_full_tensors(train_mode):
             assert U.relerr(v, g[mode + '|grad|' + k]) < 1e-5, k
 
 
-@pytest.mark.parametrize('case', ['c1', 'c2', 'c3bench', 'vctx', 'er1', 'er2', 'fst1', 'fst2', 'fst3', 'noposit'])
+@pytest.mark.parametrize('case', ['c1', 'c2', 'c3bench', 'vctx', 'er1', 'er2', 'fst1', 'fst2', 'fst3', 'noposit', 'init', 'initc'])
 def test_config_summaries(case):
     opt, params, vid = synth.make_case(case)
     g = U.gold('case_%s.npz' % case)
@@ -85,14 +85,14 @@ def test_peaked_regime_noise_floor_of_fp32_itself():
         assert dlogp > 1e-6          # (the case really is in the regime where fp32 summation order shows)
 
 
-@pytest.mark.parametrize('case', ['tiny', 'c1'])
+@pytest.mark.parametrize('case', ['tiny', 'c1', 'init', 'initc'])
 def test_greedy_sample(case):
     opt, params, vid = synth.make_case(case)
     g = U.gold('case_%s.npz' % case)
     P = {k: torch.from_numpy(v) for k, v in params.items()}
     with torch.no_grad():
         seq, lp = O.caption_forward(P, torch.from_numpy(vid['tap']), torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), None,
-                                    vid['ind'], vid['soi'], 'eval', None, opt.n_head, opt.CG_seq_length)
+                                    vid['ind'], vid['soi'], 'eval', None, opt.n_head, opt.CG_seq_length, init_feats_type=opt.CG_init_feats_type)
     assert np.array_equal(seq.numpy(), g['sample|seq'])
     assert np.abs(lp.numpy() - g['sample|logp']).max() < 1e-5
 

@@ -31,7 +31,8 @@ def run_oracle(opt, params, vid, train_mode, backward=True):
     labels = torch.from_numpy(vid['labels'])
     masks = torch.from_numpy(vid['masks'])
     drop = oracle_drop(opt) if train_mode else None
-    pred = O.caption_forward(P, tap, c3d, lda, labels, vid['ind'], vid['soi'], 'train', drop, opt.n_head, video_context_type=opt.video_context_type, event_context_type=opt.event_context_type, fST_type=getattr(opt, 'fST_type', 'fST0'), use_posit=opt.use_posit)
+    pred = O.caption_forward(P, tap, c3d, lda, labels, vid['ind'], vid['soi'], 'train', drop, opt.n_head, video_context_type=opt.video_context_type, event_context_type=opt.event_context_type, fST_type=getattr(opt, 'fST_type', 'fST0'), use_posit=opt.use_posit,
+                             init_feats_type=opt.CG_init_feats_type)
     loss = O.lm_criterion(pred, labels[:, 1:], masks[:, 1:])
     grads = None
     if backward:

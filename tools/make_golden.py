@@ -128,7 +128,7 @@ def run_oracle(opt, params, vid, train_mode):
     labels = torch.from_numpy(vid['labels'])
     masks = torch.from_numpy(vid['masks'])
     drop = oracle_drop(opt) if train_mode else None
-    pred = O.caption_forward(P, tap, c3d, lda, labels, vid['ind'], vid['soi'], 'train', drop, opt.n_head, video_context_type=opt.video_context_type, event_context_type=opt.event_context_type, fST_type=getattr(opt, 'fST_type', 'fST0'), use_posit=opt.use_posit)
+    pred = O.caption_forward(P, tap, c3d, lda, labels, vid['ind'], vid['soi'], 'train', drop, opt.n_head, video_context_type=opt.video_context_type, event_context_type=opt.event_context_type, fST_type=getattr(opt, 'fST_type', 'fST0'), use_posit=opt.use_posit, init_feats_type=opt.CG_init_feats_type)
     loss = O.lm_criterion(pred, labels[:, 1:], masks[:, 1:])
     loss.backward()
     grads = {k: (p.grad.numpy().copy() if p.grad is not None else None) for k, p in P.items()}
@@ -176,7 +176,7 @@ def do_case(name):
     P = {k: torch.from_numpy(v) for k, v in params.items()}
     with torch.no_grad():
         oseq, oslp = O.caption_forward(P, tap, c3d, lda, None, vid['ind'], vid['soi'], 'eval', None, opt.n_head,
-                                       opt.CG_seq_length, video_context_type=opt.video_context_type, event_context_type=opt.event_context_type, fST_type=getattr(opt, 'fST_type', 'fST0'), use_posit=opt.use_posit)
+                                       opt.CG_seq_length, video_context_type=opt.video_context_type, event_context_type=opt.event_context_type, fST_type=getattr(opt, 'fST_type', 'fST0'), use_posit=opt.use_posit, init_feats_type=opt.CG_init_feats_type)
     assert torch.equal(seq, oseq), 'oracle greedy seq differs'
     print('[%s/sample] seq %s  oracle max|dlogp| %.2e' % (name, tuple(seq.shape), float((slp - oslp).abs().max())))
     out['sample|seq'] = seq.numpy().astype(np.int64)
