@@ -672,7 +672,9 @@ extern "C" int echr_tsrm_attn_fwd(const echr_tsrm_args* a, const float* roi_feat
 }
 
 // the dense position branch (:39-41, :108-116): pair embedding -> fc1 (+ tanh) -> fc2 gates, on stream sp.  Independent of the event features.
-static int position_branch(const echr_tsrm_args* a, const TsrmWs& w, bool do_posemb, bool packed_pos, hipStream_t sp) {
+// wfc1_ready: the packed image of W_fc1 is produced on another stream (tsrm_position_early: the caller's, which has slack there), this one waits
+// for that event in front of the product instead of running the pack between the embedding and the product
+static int position_branch(const echr_tsrm_args* a, const TsrmWs& w, bool do_posemb, bool packed_pos, hipStream_t sp, hipEvent_t wfc1_ready = nullptr) {
     const int N = a->N, Df = a->Df, G = a->G, NN = N * N;
     echr_gemm_desc d;
     if (do_posemb) {
@@ -683,7 +685,11 @@ static int position_branch(const echr_tsrm_args* a, const TsrmWs& w, bool do_pos
     // fc1 over the N*N event pairs: the one TSRM product big enough for the h2 path (tanh fused in the epilogue)
     if (config().gemm_h2 && NN >= 1024) {
         H2PackJob pj[2] = {pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1), pack_rows(w.POS, Df, NN, Df, w.PK_POS)};
-        RC(h2_pack_multi(pj, packed_pos ? 1 : 2, sp));
+        if (!wfc1_ready) RC(h2_pack_multi(pj, packed_pos ? 1 : 2, sp));
+        else {
+            if (!packed_pos) RC(h2_pack_multi(pj + 1, 1, sp));
+            if (hipStreamWaitEvent(sp, wfc1_ready, 0) != hipSuccess) { set_error("tsrm_fwd: stream wait failed"); return -5; }
+        }
         d = desc_h2(w.PK_POS, w.PK_WFC1, w.P1, Df, NN, Df, Df);
         d.split_k = 1;
     } else {
@@ -717,7 +723,20 @@ int echr::tsrm_position_early(const echr_tsrm_args* a, hipStream_t from) {
     hipStream_t sp = aux_fork(from);
     if (!sp) return 0;
     const bool packed_pos = config().gemm_h2 && NN >= 4096 && posemb_packed_ok(N, Df);
-    RC(position_branch(a, w, true, packed_pos, sp));
+    // the W_fc1 pack (parameters only) leaves the branch's chain: it runs on the caller's stream, which idles ~40 us waiting for the gates anyway
+    static const bool wfc1_here = [] { const char* e = getenv("ECHR_WFC1_ON_CALLER"); return !(e && e[0] == '0'); }();      // A/B switch
+    static hipEvent_t ev_wfc1 = nullptr;
+    hipEvent_t ready = nullptr;
+    if (wfc1_here && config().gemm_h2 && NN >= 1024) {
+        if (!ev_wfc1 && hipEventCreateWithFlags(&ev_wfc1, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev_wfc1 = nullptr; }
+        if (ev_wfc1) {
+            H2PackJob pj = pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1);
+            RC(h2_pack_multi(&pj, 1, from));
+            if (hipEventRecord(ev_wfc1, from) != hipSuccess) { set_error("tsrm_fwd: event record failed"); return -5; }
+            ready = ev_wfc1;
+        }
+    }
+    RC(position_branch(a, w, true, packed_pos, sp, ready));
     g_pos_early_ws = a->ws;
     return 0;
 }

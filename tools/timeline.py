@@ -5,9 +5,9 @@ rows = []
 for f in glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# iterations end with clamp_adam
-ends = [i for i, r in enumerate(rows) if 'clamp_adam' in r['Kernel_Name']]
-a, b = ends[-2] + 1, ends[-1] + 1
+# iterations start with the index staging copy (several clamp_adam launches per iteration since the early range updates)
+starts = [i for i, r in enumerate(rows) if 'stage_copy_kernel' in r['Kernel_Name']]
+a, b = starts[-2], starts[-1]
 t0 = int(rows[a]['Start_Timestamp']); prev = int(rows[a - 1]['End_Timestamp'])
 busy = gap = 0.0
 for r in rows[a:b]:
