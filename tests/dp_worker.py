@@ -1,4 +1,5 @@
-"""Worker of test_two_rank_data_parallel_on_one_gpu: one data-parallel rank (gloo transport, both ranks on cuda:0)."""
+"""Worker of test_two_rank_data_parallel_on_one_gpu: one data-parallel rank (gloo transport, both ranks on cuda:0) -- and, with
+ECHR_DP_WORKER_BACKEND=nccl and world size 1, of test_single_rank_rccl_one_call_path (the RCCL code path of every collective on a 1-GPU box)."""
 import os
 import sys
 
@@ -13,7 +14,12 @@ def main():
     rank, world, port, out, overlap = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5] == '1'
     fused_mode = sys.argv[5] in ('fused', 'fused1')          # the one-call path: echr_train_step + hand-over collectives ('fused1': ONE collective)
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', port
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    backend = os.environ.get('ECHR_DP_WORKER_BACKEND', 'gloo')
+    if backend == 'nccl':          # RCCL wants one device per rank: world size 1 on the one-GPU box
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     import echr_amd
     from echr_amd import parallel, synth
     from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
@@ -39,7 +45,7 @@ def main():
     crit = LanguageModelCriterion()
     if fused_mode:
         from echr_amd.fused import DataParallelStep, FusedTrainStep
-        dp = DataParallelStep(FusedTrainStep(model, optim, grad_clip=0.05), overlap=sys.argv[5] == 'fused')
+        dp = DataParallelStep(FusedTrainStep(model, optim, grad_clip=0.05), overlap=sys.argv[5] == 'fused', algo=os.environ.get('ECHR_DP_WORKER_ALGO') or None)
     n_early = -1
     for step in range(2):
         vid = synth.make_video(2, 16, 11, opt.CG_vocab_size + 1, seed=500 + 10 * step + rank, T_v=40, video_dim=opt.video_dim,

@@ -1882,6 +1882,40 @@ def test_two_rank_data_parallel_on_one_gpu(tmp_path, overlap):
             assert U.grad_close(k, r0['grad|' + k], p.grad.detach().cpu().numpy(), 1e-5), k     # SUM over ranks == accumulation, no 1/R
 
 
+@pytest.mark.parametrize('mode,algo', [('fused', 'allreduce'), ('fused', 'rs_ag'), ('fused1', 'rs_ag')])
+def test_single_rank_rccl_one_call_path(tmp_path, mode, algo):
+    """The collectives of the data-parallel paths on RCCL itself (backend 'nccl'; the gloo rehearsals above never touch it): ONE rank on cuda:0
+    -- RCCL wants a device per rank -- with persistent recurrences launched cooperatively, as bench.py does for N > 1.  A sum over one rank
+    is the identity, so the first step's gradients must equal the same worker's over gloo to the run-to-run noise of the split-K atomics
+    (1e-5 of the tensor's maximum) and the parameters after two Adam steps to 2 x 2 x lr: this pins the nccl-only branches (asynchronous
+    reduce-scatter + all-gather on the collective stream, Work.wait() stream semantics, hand-over waits) -- a collective that ran before its
+    range was final, or was not waited for, shows as a gradient off by orders of magnitude more."""
+    import socket
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for backend in ('nccl', 'gloo'):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = str(s.getsockname()[1]); s.close()
+        out = str(tmp_path / (backend + '.npz'))
+        env = dict(os.environ, ECHR_DP_WORKER_COOP='1', ECHR_DP_WORKER_BACKEND=backend, ECHR_DP_WORKER_ALGO=algo, ECHR_DP_STAGED='0')
+        p = subprocess.Popen([_sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), '0', '1', port, out, mode], cwd=root, env=env)
+        assert p.wait(timeout=600) == 0, backend
+        res[backend] = np.load(out)
+    a, b = res['nccl'], res['gloo']
+    assert int(a['n_collectives']) == int(b['n_collectives']) and int(a['n_collectives']) >= 1
+    if mode == 'fused':
+        assert int(a['n_early']) == 2
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        if k.startswith('grad|'):
+            assert U.grad_close(k[5:], a[k], b[k], 1e-5), (k, U.relerr(a[k], b[k]))
+        elif a[k].dtype.kind == 'f':
+            assert np.abs(a[k] - b[k]).max() <= 4.1e-3, k          # (lr = 1e-3: Adam's first steps move a parameter by <= lr, whatever the gradient's size)
+            if k not in U.NOISE_ONLY:                              # (a true gradient of exactly zero: the update is a coin flip of +-lr)
+                assert np.mean(np.abs(a[k] - b[k]) > 1e-4) < 0.02, k   # ... and only elements whose gradient is at the noise floor differ at all
+
+
 @pytest.mark.parametrize('fused', ['auto', 'off'])
 def test_bench_two_rank_rehearsal_on_one_gpu(fused):
     """(fused = 'auto': every rank's iteration as one echr_train_step call up to the backward pass with the early range collectives started
