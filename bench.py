@@ -552,7 +552,22 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            # the library's helper streams BEFORE RCCL's: the runtime hands out its few hardware queues in stream-creation order, and helper
+            # streams created behind the communicator's share queues with each other (the backward tail's three streams then serialise:
+            # 1.64 vs 1.49 ms per iteration on one MI355X with a single-rank communicator, tools/dp_host_profile.py)
+            if os.environ.get('ECHR_STREAMS_FIRST', '1') != '0':
+                from echr_amd import _lib
+                _lib.check(_lib.load().echr_streams_init(), 'streams_init')
+            # RCCL prints a version banner to STDOUT when the communicator comes up; this program's stdout is ONE JSON line
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+                dist.barrier()
+            finally:
+                os.dup2(keep, 1)
+                os.close(keep)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     if os.environ.get('ECHR_BENCH_DRYRUN') == '1':
@@ -570,17 +585,18 @@ def main():
                  'torch.distributed.run --nproc-per-node %d)' % (args.gpus, world, args.gpus, args.gpus))
     dp_info = {}
     if world > 1:
-        # With several ranks the persistent recurrences are launched cooperatively: a grid only starts once all of its workgroups can be
-        # resident, so a hand-off wait never depends on a workgroup that found no CU because a collective kernel (or, in the one-GPU
-        # rehearsal, another rank's grid) holds it.  By construction every collective of an iteration sits behind the reverse recurrence
-        # (hand-over events) and is waited for before clamp + Adam, so nothing should ever be resident beside a pair and the plain launch
-        # (25 us per pair cheaper) would do -- but that has never been validated on a real multi-GPU run, so the
-        # cooperative launch stays the multi-rank default (ECHR_PERSIST_COOP=0 to measure the plain one).
+        # One rank per GPU: plain persistent launches.  Every collective of an iteration is queued behind the reverse recurrence (hand-over
+        # callbacks / the end of the backward pass) and the caller's stream waits for the last of them before clamp + Adam, i.e. before the next
+        # iteration's forward recurrence -- by stream order no collective kernel is ever resident beside a persistent pair, and should one be,
+        # the pair's bounded waits end in -ETIME, not in a hang.  The cooperative launch (a grid starts only when all of its workgroups can be
+        # resident) costs 0.8 ms per iteration once RCCL is up in the process (tools/dp_host_profile.py: 2.67 vs 1.83 ms) and is kept for
+        # what needs it: the one-GPU rehearsal, where two ranks' grids share a device (ECHR_PERSIST_COOP overrides).
         from echr_amd import _lib
-        coop = int(os.environ.get('ECHR_PERSIST_COOP', '1'))
+        coop = int(os.environ.get('ECHR_PERSIST_COOP', '1' if os.environ.get('ECHR_BENCH_ONE_GPU') == '1' else '0'))
         _lib.load().echr_config_set(b'persist_coop', coop)
         dp_info.update(persist_coop=coop, dp_algo=__import__('echr_amd.parallel', fromlist=['choose_algo']).choose_algo(world),
-                       dp_overlap=os.environ.get('ECHR_DP_OVERLAP', '1') != '0')
+                       dp_overlap=os.environ.get('ECHR_DP_OVERLAP', '1') != '0', dp_via=os.environ.get('ECHR_DP_VIA', 'callback'),
+                       streams_first=os.environ.get('ECHR_STREAMS_FIRST', '1') != '0')
         if os.environ.get('ECHR_BENCH_ONE_GPU') == '1' and os.environ.get('ECHR_BENCH_PERSIST', '0') == '0':
             # rehearsal with every rank on ONE device: two 256-workgroup persistent grids must not share it -> launch-per-phase recurrences
             _lib.load().echr_config_set(b'persist', 0)

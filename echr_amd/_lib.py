@@ -87,6 +87,9 @@ class SampleArgs(C.Structure):
                 ('tables', c_f), ('tables_valid', i32)]
 
 
+HANDOVER_FN = C.CFUNCTYPE(None, i32, C.c_void_p, C.c_void_p)          # echr_handover_fn
+
+
 class TrainStepArgs(C.Structure):
     _fields_ = [('tsrm', TsrmArgs), ('tsrm_g', TsrmGrads), ('dec', DecArgs), ('dec_g', DecGrads), ('drop', Dropout),
                 ('tap', c_f), ('Ht', i32), ('g_tap', c_f), ('host_index', C.c_void_p),
@@ -95,7 +98,7 @@ class TrainStepArgs(C.Structure):
                 ('flat_p', c_f), ('adam_m', c_f), ('adam_v', c_f), ('adam_step', i32),
                 ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('clip', f32),
                 ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32), ('prepared', i32), ('defer_update', i32),
-                ('handover', i32)]
+                ('handover', i32), ('handover_cb', C.c_void_p), ('handover_user', C.c_void_p)]
 
 
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)
@@ -132,6 +135,7 @@ SYMBOLS = [
     ('echr_decoder_sample', i32, [C.POINTER(SampleArgs), C.c_void_p]),
     ('echr_config_set', i32, [C.c_char_p, i32]),
     ('echr_stream_join', i32, [C.c_void_p]),
+    ('echr_streams_init', i32, []),
     ('echr_decoder_step', i32, [C.POINTER(DecArgs), c_f, c_f, c_f, c_f, C.POINTER(Dropout), C.c_void_p]),
     ('echr_tsrm_attn_fwd', i32, [C.POINTER(TsrmArgs), c_f, c_f, C.POINTER(Dropout), C.c_void_p]),
     ('echr_persist_read_stamps', i32, [C.c_void_p, i32]),

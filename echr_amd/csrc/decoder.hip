@@ -126,7 +126,7 @@ int join_tail(hipStream_t st) {
 // Data-parallel hand-over points (echr_train_step_args.handover, echr_handover_wait): events recorded where a contiguous range of the
 // gradient arena becomes final long before the backward pass ends -- the logit layer's gradients on the tail stream right behind their
 // product, the three LSTM layers' gradients on the prepare stream behind the grouped weight-gradient product.
-struct Handover { hipEvent_t ev[2] = {nullptr, nullptr}; bool valid[2] = {false, false}; bool want = false, init = false, ok = false; };
+struct Handover { hipEvent_t ev[2] = {nullptr, nullptr}; bool valid[2] = {false, false}; bool want = false, init = false, ok = false; echr_handover_fn cb = nullptr; void* user = nullptr; };
 static Handover& handover() {
     static Handover h;
     if (!h.init) {
@@ -136,17 +136,19 @@ static Handover& handover() {
     }
     return h;
 }
-void handover_request(bool on) {
+void handover_request(bool on, echr_handover_fn cb, void* user) {
     Handover& h = handover();
     h.want = on && h.ok;
+    h.cb = on ? cb : nullptr; h.user = user;
     h.valid[0] = h.valid[1] = false;
 }
-void handover_close() { handover().want = false; }
+void handover_close() { handover().want = false; handover().cb = nullptr; }
 static int handover_mark(int which, hipStream_t on) {
     Handover& h = handover();
     if (!h.want) return 0;
     if (hipEventRecord(h.ev[which], on) != hipSuccess) { set_error("decoder_bwd: hand-over event record failed"); return -5; }
     h.valid[which] = true;
+    if (h.cb) h.cb(which, on, h.user);          // (host callback: the caller queues its collective behind this point of `on`)
     return 0;
 }
 extern "C" int echr_handover_wait(int which, void* stream) {
@@ -1075,6 +1077,7 @@ extern "C" int64_t echr_decoder_ws_bwd_floats(const echr_dec_args* a) { return a
 
 extern "C" int echr_stream_join(void* stream) { return join_tail((hipStream_t)stream); }
 
+
 // ---- event-independent part of the decoder forward, ahead of (and concurrent with) the event encoder ----
 struct Prep { hipStream_t s = nullptr; hipEvent_t fork = nullptr, done = nullptr, fill_done = nullptr, fill0 = nullptr; bool ok = false, init = false, pending = false, fill_pending = false; const void* ws = nullptr; };
 static Prep& prep() {
@@ -1116,6 +1119,23 @@ int aux2_publish() {
 }
 // echr_train_step's joint mode (step.hip): the helper streams keep working after the call returns
 bool helpers_available() { return tail().ok && prep().ok && !prep().pending; }
+}  // namespace echr
+// see include/echr_hip.h: the helper streams are created in a fixed order and each submits a marker, so that their hardware queues are
+// assigned before any other component (RCCL) creates streams of its own
+extern "C" int echr_streams_init(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); set_error("streams_init: no device"); return -19; }
+    // (only the two streams every iteration uses: with the caller's stream and the collective library's they fill this runtime's four hardware
+    // queues; the opt-in side stream of `overlap` = 1 stays lazy)
+    Tail& t = tail();
+    Prep& p = prep();
+    bool ok = true;
+    if (t.ok) ok = ok && hipEventRecord(t.fork, t.s) == hipSuccess && hipStreamSynchronize(t.s) == hipSuccess;
+    if (p.ok) ok = ok && hipEventRecord(p.fork, p.s) == hipSuccess && hipStreamSynchronize(p.s) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); set_error("streams_init: marker submission failed"); return -5; }
+    return 0;
+}
+namespace echr {
 hipStream_t aux2_stream() { return prep().ok ? prep().s : nullptr; }
 hipStream_t helpers_merge_to_tail() {          // the tail stream continues behind everything queued on the prepare stream; returns the tail stream
     Tail& t = tail();

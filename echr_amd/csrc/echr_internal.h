@@ -78,7 +78,7 @@ int tsrm_bwd_parts(const echr_tsrm_args* a, const echr_tsrm_grads* g, const echr
 int decoder_bwd_scratch_ahead(const echr_dec_args* a, const echr_dec_grads* g);
 int decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, const echr_dropout* drop, void* stream, int part);
 void handover_close();                   // stop recording; the recorded events stay valid for echr_handover_wait
-void handover_request(bool on);          // the next decoder backward records the data-parallel hand-over events (decoder.hip)
+void handover_request(bool on, echr_handover_fn cb = nullptr, void* user = nullptr);          // the next decoder backward records the data-parallel hand-over events (decoder.hip)
 int join_tail(hipStream_t st);          // make st wait for an asynchronous decoder-backward tail (decoder.hip); no-op when none is pending
 int persist_read_stamps(unsigned long long* dst, int max_entries);
 unsigned long long* persist_stamp_buffer(int S, hipStream_t st);      // diagnostic: [4][S <= 256][16] stamps, zeroed on st (nullptr: unavailable)

@@ -279,7 +279,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
         // persistent recurrence that shares its CUs with GEMM workgroups from its first step on loses more than the gap is worth)
         return joint_finish(jp, st);
     }
-    handover_request(a->handover && !a->do_step);
+    handover_request(a->handover && !a->do_step, a->handover_cb, a->handover_user);
     rc = echr_decoder_bwd(&d, &g, &a->drop, stream);
     handover_close();          // (the events stay valid for echr_handover_wait; later backward passes do not re-record them)
     RC(rc);

@@ -117,7 +117,7 @@ class FusedTrainStep(object):
             L.check(self.lib.echr_decoder_fwd_prepare_cancel(L.stream_ptr()), 'decoder_fwd_prepare_cancel')
 
     def __call__(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step=True, forward_only=False,
-                 tap_grad=None, defer_update=False, prepared=False, handover=False):
+                 tap_grad=None, defer_update=False, prepared=False, handover=False, handover_cb=None):
         """One iteration; returns the loss as a 0-d device tensor (no host sync).  `targets` / `masks`: what the reference hands its
         criterion (labels[:, 1:], masks[:, 1:]), host or device tensors.  step=False stops after the backward pass and exposes the
         gradients as `.grad` views of the arena (data-parallel reduce, inspection); the caller then steps the optimiser itself.
@@ -127,7 +127,8 @@ class FusedTrainStep(object):
         once tap_grad and the loss are final in stream order; the parameter gradients and the Adam update finish on the library's helper
         streams beside the proposal encoder's backward.  The next call joins by itself; call `join()` before touching the model's parameters
         in any other way (saving, evaluating, the autograd path).  `prepared=True`: `prepare()` ran with the same arguments.
-        `handover=True` (with step=False): the backward pass records the data-parallel hand-over points (echr_handover_wait; DataParallelStep)."""
+        `handover=True` (with step=False): the backward pass records the data-parallel hand-over points (echr_handover_wait; DataParallelStep);
+        `handover_cb(which, stream_ptr)`: called on the host from inside the call at each point (echr_train_step_args.handover_cb)."""
         a, lib = self.a, self.lib
         rc = lib.echr_check_async()
         if rc:
@@ -151,10 +152,28 @@ class FusedTrainStep(object):
                                    tap_grad, defer_update)
             a.prepared = 0
         a.handover = 1 if (handover and not step and not forward_only) else 0
+        if a.handover and handover_cb is not None:
+            # (the CFUNCTYPE object must outlive the call: kept on self; an exception inside a ctypes callback cannot propagate -- it is kept and
+            # re-raised behind the call)
+            self._cb_error = None
+
+            def _tramp(which, stream, _user, cb=handover_cb):
+                try:
+                    cb(int(which), int(stream))
+                except BaseException as e:          # noqa: BLE001
+                    self._cb_error = e
+            self._cb_keep = L.HANDOVER_FN(_tramp)
+            a.handover_cb = C.cast(self._cb_keep, C.c_void_p)
+        else:
+            a.handover_cb = None
+        a.handover_user = None
         # (set BEFORE the call: if it fails half-way, helper-stream work may already be queued, and the next _setup must join it before it
         # drops the references to this call's inputs)
         self._pending_deferred = bool(a.defer_update)
         L.check(lib.echr_train_step(C.byref(a), L.stream_ptr()), 'train_step')
+        if a.handover_cb and self._cb_error is not None:
+            e, self._cb_error = self._cb_error, None
+            raise e
         return self._finish(slot, st, forward_only)
 
     def _set_tap(self, tap, tap_grad, defer_update, step, forward_only):
@@ -329,16 +348,22 @@ class DataParallelStep(object):
 
     The exchange is staged: the backward pass inside the call hands over two contiguous arena ranges long before its last kernel -- the
     logit layer (35 % of the gradient bytes, final ~0.1 ms behind the reverse recurrence, on the library's tail stream) and the three LSTM
-    layers (39 %, final behind the grouped weight-gradient product on its prepare stream).  For each, a side stream waits for the library's
-    hand-over event (echr_handover_wait) and the range's collective is queued from it (torch.distributed orders its collective stream
-    behind the CURRENT stream), so it runs beside the rest of the tail and the event encoder's backward; the remaining ranges (event
-    encoder + embedding, attention: 26 %) follow from the caller's stream.  Every collective starts behind the reverse recurrence and is
+    layers (39 %, final behind the grouped weight-gradient product on its prepare stream).  For each, the library calls back on the host
+    right behind the last launch that writes the range (echr_train_step_args.handover_cb) and the range's collective is queued with that
+    library stream as the CURRENT stream (torch.distributed orders its collective stream behind the current stream), so it runs beside the
+    rest of the tail and the event encoder's backward without any further stream or event (`via='event'`: the older form -- one side
+    stream per range waits for the hand-over event, echr_handover_wait); the remaining ranges (event encoder + embedding, attention: 26 %)
+    follow from the caller's stream, asynchronously too, and the caller's stream waits ONCE, for the last collective queued.  Every collective starts behind the reverse recurrence and is
     waited for before clamp + Adam, i.e. before the next iteration's forward recurrence: no collective kernel is ever resident beside a
     persistent pair.  `overlap=False`: ONE collective on the whole arena behind the call."""
 
-    def __init__(self, fused, group=None, overlap=True, algo=None):
+    def __init__(self, fused, group=None, overlap=True, algo=None, via=None):
         from . import parallel
         self.P, self.fused, self.group, self.overlap, self.algo = parallel, fused, group, bool(overlap), algo
+        # how an early range reaches the collective stream: 'callback' (default) = queued from inside the call with the library's stream current
+        # (echr_train_step_args.handover_cb), 'event' = a side stream per range that waits for the hand-over event (echr_handover_wait)
+        self.via = via or os.environ.get('ECHR_DP_VIA', 'callback')
+        self._ext, self._keep = {}, None
         ar, lm = fused.arena, fused.model.lm_model
         core = lm.core
         lstm = [p for k in range(3) for p in getattr(core, 'layer%d' % k).parameters()]
@@ -347,19 +372,47 @@ class DataParallelStep(object):
             slots = sorted(ar.slot(p) for p in params)
             if slots == list(range(slots[0], slots[-1] + 1)):          # one contiguous arena range (it is, for the reference's module order)
                 self.ranges.append((which,) + tuple(ar.span(slots)))
-        self.side = [torch.cuda.Stream(device=fused.dev) for _ in self.ranges] if self.overlap else []
+        self._range = {which: (lo, hi) for which, lo, hi in self.ranges}
+        self.side = [torch.cuda.Stream(device=fused.dev) for _ in self.ranges] if (self.overlap and self.via != 'callback') else []
         self.n_collectives = 0
         self.n_early = 0
+
+    def _in_order(self):
+        """True when every collective of this step ran on ONE in-order device stream (the nccl = RCCL backend: one stream per process group
+        and device), so that waiting for the last one queued waits for all of them.  ECHR_DP_WAIT_ALL=1: wait for each."""
+        import torch.distributed as dist
+        if os.environ.get('ECHR_DP_WAIT_ALL') == '1':
+            return False
+        try:
+            return dist.get_backend(self.group) == 'nccl'
+        except Exception:
+            return False
 
     def __call__(self, *args, **kw):
         P, f, ar = self.P, self.fused, self.fused.arena
         import torch.distributed as dist
         active = dist.is_available() and dist.is_initialized()
-        loss = f(*args, step=False, handover=self.overlap and active, **kw)
+        pend = []
+
+        def at_handover(which, stream_ptr):
+            # host callback from inside echr_train_step, right behind the last launch that writes the range: the collective is queued with the
+            # library's own stream as the CURRENT stream, so torch.distributed orders its collective stream behind exactly this point -- no side
+            # stream, no further event (five or more streams on this runtime's four hardware queues share queues, and a wait queued on a shared
+            # queue stalls the unrelated stream behind it: measured +0.2 ms per iteration with two side streams)
+            rng = self._range.get(which)
+            if rng is None:
+                return
+            ext = self._ext.get(stream_ptr)
+            if ext is None:
+                ext = self._ext[stream_ptr] = torch.cuda.ExternalStream(stream_ptr, device=f.dev)
+            with torch.cuda.stream(ext):
+                pend.append((rng[0], rng[1], P.reduce_sum_(ar.flat_g[rng[0]:rng[1]], self.group, self.algo, async_op=True)))
+
+        use_cb = self.overlap and active and self.via == 'callback'
+        loss = f(*args, step=False, handover=self.overlap and active, handover_cb=at_handover if use_cb else None, **kw)
         n = 0
         if active:
-            pend = []
-            if self.overlap:
+            if self.overlap and not use_cb:          # the event form (echr_handover_wait): one side stream per range
                 for (which, lo, hi), s in zip(self.ranges, self.side):
                     with torch.cuda.stream(s):
                         rc = f.lib.echr_handover_wait(which, L.stream_ptr())
@@ -368,15 +421,25 @@ class DataParallelStep(object):
                         if rc == 0:          # (1: this configuration recorded no hand-over point -- the range joins the remainder below)
                             pend.append((lo, hi, P.reduce_sum_(ar.flat_g[lo:hi], self.group, self.algo, async_op=True)))
             self.n_early = len(pend)
+            # the remaining ranges, asynchronously as well: queued back to back on the collective stream behind the caller's stream's position
+            # (= the end of the backward pass), waited for ONCE -- a blocking collective costs two cross-stream edges (10-20 us each on this
+            # runtime) before the next one may even be queued
+            works = [w for _, _, w in pend]
             pos = 0
             for lo, hi, _ in sorted(pend, key=lambda t: t[0]) + [(ar.total, ar.total, None)]:
                 if lo > pos:
-                    P.reduce_sum_(ar.flat_g[pos:lo], self.group, self.algo)
+                    works.append(P.reduce_sum_(ar.flat_g[pos:lo], self.group, self.algo, async_op=True))
                     n += 1
                 pos = max(pos, hi)
-            for _, _, w in pend:
-                w.wait()          # the caller's stream continues behind the early collectives
             n += len(pend)
+            if works and self._in_order():
+                # one process group = one collective stream, in order: the caller's stream waits for the LAST collective queued (the early ones
+                # were queued first); the other handles only have to stay alive until then
+                works[-1].wait()
+                self._keep = works
+            else:
+                for w in works:
+                    w.wait()          # the caller's stream continues behind the collectives
         self.n_collectives = n
         o = f.optim
         if f.grad_clip is not None:

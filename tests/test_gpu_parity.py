@@ -1882,8 +1882,8 @@ def test_two_rank_data_parallel_on_one_gpu(tmp_path, overlap):
             assert U.grad_close(k, r0['grad|' + k], p.grad.detach().cpu().numpy(), 1e-5), k     # SUM over ranks == accumulation, no 1/R
 
 
-@pytest.mark.parametrize('mode,algo', [('fused', 'allreduce'), ('fused', 'rs_ag'), ('fused1', 'rs_ag')])
-def test_single_rank_rccl_one_call_path(tmp_path, mode, algo):
+@pytest.mark.parametrize('mode,algo,via', [('fused', 'allreduce', 'callback'), ('fused', 'rs_ag', 'callback'), ('fused', 'rs_ag', 'event'), ('fused1', 'rs_ag', 'callback')])
+def test_single_rank_rccl_one_call_path(tmp_path, mode, algo, via):
     """The collectives of the data-parallel paths on RCCL itself (backend 'nccl'; the gloo rehearsals above never touch it): ONE rank on cuda:0
     -- RCCL wants a device per rank -- with persistent recurrences launched cooperatively, as bench.py does for N > 1.  A sum over one rank
     is the identity, so the first step's gradients must equal the same worker's over gloo to the run-to-run noise of the split-K atomics
@@ -1898,7 +1898,9 @@ def test_single_rank_rccl_one_call_path(tmp_path, mode, algo):
     for backend in ('nccl', 'gloo'):
         s = socket.socket(); s.bind(('127.0.0.1', 0)); port = str(s.getsockname()[1]); s.close()
         out = str(tmp_path / (backend + '.npz'))
-        env = dict(os.environ, ECHR_DP_WORKER_COOP='1', ECHR_DP_WORKER_BACKEND=backend, ECHR_DP_WORKER_ALGO=algo, ECHR_DP_STAGED='0')
+        # via: how an early range reaches the collective stream -- 'callback' (default): queued from inside echr_train_step at the hand-over point
+        # with the library's stream current; 'event': a side stream per range waits for the hand-over event
+        env = dict(os.environ, ECHR_DP_WORKER_COOP='1', ECHR_DP_WORKER_BACKEND=backend, ECHR_DP_WORKER_ALGO=algo, ECHR_DP_STAGED='0', ECHR_DP_VIA=via)
         p = subprocess.Popen([_sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), '0', '1', port, out, mode], cwd=root, env=env)
         assert p.wait(timeout=600) == 0, backend
         res[backend] = np.load(out)
