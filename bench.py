@@ -321,6 +321,10 @@ def gpu_leg(args, rank, world, local_rank):
     from echr_amd import _lib
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+    if os.environ.get('ECHR_STREAMS_FIRST', '1') != '0':
+        # the library's helper streams first (a no-op if main() already did it ahead of the RCCL communicator): their hardware queues do not
+        # depend on what else in the process creates streams before the first iteration
+        _lib.check(_lib.load().echr_streams_init(), 'streams_init')
     use_dist = dist.is_available() and dist.is_initialized()
     kind = 'c5' if args.c5 else ('fwd' if args.mode == 'fwd' else 'train')
     wl = Workload(args, kind, rank, dev, use_dist)

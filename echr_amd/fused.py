@@ -43,6 +43,10 @@ class FusedTrainStep(object):
         self.model, self.optim, self.arena = model, optimizer, arena
         self.grad_clip = grad_clip if grad_clip is not None else optimizer.grad_clip
         self.lib = L.load()
+        # (the helper streams now rather than at the first iteration: their hardware queues then do not depend on what creates streams in between.
+        # A process that brings up an RCCL communicator should call echr_streams_init() BEFORE init_process_group -- INTEGRATION.md)
+        with torch.cuda.device(arena.flat_p.device):
+            L.check(self.lib.echr_streams_init(), 'streams_init')
         self.dev = arena.flat_p.device
         self.a = L.TrainStepArgs()
         self.ws = None
