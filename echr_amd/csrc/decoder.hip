@@ -1219,6 +1219,9 @@ extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
         if (hipStreamWaitEvent(st, fe, 0) != hipSuccess) { set_error("decoder_fwd_prepare: stream fork failed"); return -5; }
     } else RC(hop(sm, pr.fork, st));
     DecWs w = carve_ws(a, a->ws);
+    // the persistent forward chain's weight images (parameters only) are built now, on the CALLER's stream -- it idles ~20 us waiting for the
+    // position branch's gates -- so that the launch copies them instead of converting them in front of its first step (set-up 24.7 -> ~14 us)
+    if (fwd_uses_persist(a)) RC(persist_fwd_prebuild(a, w.XWS, sm));
     // the caller's gradient arena (echr_train_step: 87 MB) is zero-filled LAST on this stream, behind the event this call publishes: nothing of
     // the forward pass waits for it -- a fill has no LDS and a handful of registers, so it also fits beside the recurrence's workgroups -- and
     // echr_decoder_bwd waits for it on entry.  -10 us per iteration against the fill in front (ECHR_ARENA_FILL_LATE=0, A/B: 1.540 vs 1.550 ms)

@@ -37,6 +37,11 @@ void persist_fwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, lon
 long persist_fwd_ws_floats(int S);
 bool persist_fwd_eligible(const echr_dec_args* a);
 int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st);
+// The forward attention chain's weight images (fp16-pair B fragments of W_hh1 / W_att / W_h2a with their column scales: parameters only) built
+// AHEAD of the launch into the exchange workspace, by a small kernel on `st`; the next persist_fwd on the same workspace copies them into LDS
+// (2 x 64 KB per gate workgroup from L2) instead of converting them from the strided weight rows in front of its first step.  No-op (returns 0)
+// for shapes / configurations the persistent fp16-pair forward kernels do not take.
+int persist_fwd_prebuild(const echr_dec_args* a, float* xws, hipStream_t st);
 struct PersistBwdBufs { const float* GATES[3]; const float* CS[3]; const float *QS, *WT, *ATT, *PALL, *DOUT; float* DG[3]; float *DQ, *DSC, *xws; bool prezeroed = false; };
 void persist_bwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, long* count);
 long persist_bwd_ws_floats(int S);

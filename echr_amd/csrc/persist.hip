@@ -732,7 +732,8 @@ constexpr int HWG = 96, HG1 = 64, HQ = 16;    // workgroups per half: gate, q (t
 constexpr int LDS_W2 = 128 * 1024, LDS_RED2 = 16 * 1024 + 2048 + 1536;
 constexpr int LDS_BYTES_ATT2 = LDS_W2 + LDS_RED2 + 256;
 
-struct PersistLayout2 { long cnt, xc, xs, gran, xcmax, zero_begin, xh1, xq, wu, total; };
+struct PersistLayout2 { long cnt, xc, xs, gran, xcmax, zero_begin, xh1, xq, wu, pimg, total; };
+constexpr long PIMG_G1 = 2 * 16384 + 64, PIMG_Q = 16384 + 64;          // floats per prebuilt image set: gate workgroup (two images + 2 x 32 scales), q workgroup
 static PersistLayout2 persist_layout2(int S) {
     PersistLayout2 L;
     long off = 0;
@@ -740,6 +741,7 @@ static PersistLayout2 persist_layout2(int S) {
     L.xh1 = take((long)S * PROWS * PH);
     L.xq = take((long)S * PROWS * PH);
     L.wu = take((long)S * PROWS * WU_LD);
+    L.pimg = take((long)HG1 * PIMG_G1 + (long)HQ * PIMG_Q);          // prebuilt weight images (persist_fwd_prebuild)
     // the zeroed region comes last: the version-1 layout (whose first region, the counters, is the only part of it the LSTM kernel needs
     // zeroed) follows this one in the workspace, so one memset covers both
     L.zero_begin = off;
@@ -858,7 +860,25 @@ struct PersistK2 {
     u32 spin_limit, inject;          // bound of every hand-off spin; diagnostic: the wait whose code equals `inject` never completes (0 = none)
     unsigned long long* stamps;
     DropCfg dh, dout;
+    const float* pimg;             // prebuilt weight images of this launch's workspace (nullptr: the workgroups build their own)
 };
+
+
+// persist_fwd_prebuild: block lb < HG1 builds gate workgroup lb's two images, block HG1 + j q workgroup j's (both halves of the chip use the same
+// images: the weights do not depend on the event group)
+__global__ __launch_bounds__(256) void dec_persist_prebuild_kernel(PersistK2 P, float* __restrict__ pimg) {
+    const int lb = blockIdx.x, tid = threadIdx.x;
+    if (lb < HG1) {
+        float* dst = pimg + (long)lb * PIMG_G1;
+        auto row = [&](int cc) { return (cc >> 3) * PH + 8 * lb + (cc & 7); };
+        fill_bimg_h2(reinterpret_cast<float4*>(dst), dst + 32768, nullptr, P.w_hh1, PH, PH, 1, row, tid);
+        fill_bimg_h2(reinterpret_cast<float4*>(dst) + 4096, dst + 32768 + 32, nullptr, P.w_att, P.ld_att, P.D, 1, row, tid);
+    } else {
+        float* dst = pimg + (long)HG1 * PIMG_G1 + (long)(lb - HG1) * PIMG_Q;
+        auto row = [&](int cc) { return 32 * (lb - HG1) + cc; };
+        fill_bimg_h2(reinterpret_cast<float4*>(dst), dst + 16384, nullptr, P.w_h2a, PH, PH, 1, row, tid);
+    }
+}
 
 // Greedy decoding inside the forward kernels (SAMP instantiations; OldModel.sample, models/OldModel_NEW.py:139-187): the token fed at step
 // t + 1 is the arg-max of step t's logits, so the three streams can no longer run ahead of each other.  The 64 workgroups of the two plain
@@ -978,7 +998,21 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
             }
     }
     sst_(1);
-    if (is_g1) {
+    if (H2 && P.pimg && (is_g1 || is_qw)) {
+        // images prebuilt by persist_fwd_prebuild (same code, same bits): a straight copy of 128 / 64 KB from L2
+        const float* src = P.pimg + (is_g1 ? (long)lb * PIMG_G1 : (long)HG1 * PIMG_G1 + (long)(lb - HG1) * PIMG_Q);
+        const int n4 = is_g1 ? 8192 : 4096;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll 8
+        for (int i = tid; i < n4; i += 256) wimg[i] = s4[i];
+        if (tid < 64) {
+            const float v = src[4 * n4 + tid];
+            if (tid < 32) invbA[tid] = v; else if (is_g1) invbC[tid - 32] = v;
+        }
+        sst_(2);
+        sst_(3);
+        __syncthreads();
+    } else if (is_g1) {
         auto row = [&](int cc) { return (cc >> 3) * PH + 8 * lb + (cc & 7); };       // tile column cc = gate * 8 + unit
         if (H2) {
             fill_bimg_h2(wimg, invbA, scr, P.w_hh1, PH, PH, 1, row, tid);
@@ -3196,6 +3230,20 @@ void persist_fwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, lon
     else { *ptr = xws; *count = L.zero_end; }
 }
 
+static const float*& prebuilt_for() { static const float* p = nullptr; return p; }          // workspace whose images persist_fwd_prebuild queued last
+int persist_fwd_prebuild(const echr_dec_args* a, float* xws, hipStream_t st) {
+    prebuilt_for() = nullptr;
+    static const bool on = [] { const char* e = getenv("ECHR_PERSIST_PREBUILD"); return !(e && e[0] == '0'); }();      // A/B switch
+    if (!on || !persist_fwd_eligible(a) || !config().persist_h2 || !config().persist_split || !config().persist_merge || !xws) return 0;
+    const PersistLayout2 L2 = persist_layout2(a->S);
+    PersistK2 K2 = {};
+    K2.D = a->D; K2.ld_att = a->E + a->D; K2.w_hh1 = a->w_hh[1]; K2.w_h2a = a->w_h2a; K2.w_att = a->w_ih[1] + a->E;
+    hipLaunchKernelGGL(dec_persist_prebuild_kernel, dim3(HG1 + HQ), dim3(256), 0, st, K2, xws + L2.pimg);
+    if (int rc = check_launch("dec_persist_prebuild")) return rc;
+    prebuilt_for() = xws;
+    return 0;
+}
+
 int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& dh, const DropCfg& dout, hipStream_t st) {
     PersistHost& h = phost();
     ECHR_REQUIRE(h.ok, "persist_fwd: device state unavailable");
@@ -3222,6 +3270,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
     PersistK2 K2;
+    K2.pimg = nullptr;
     if (split) {
         K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
         K2.w_hh1 = a->w_hh[1]; K2.w_h2a = a->w_h2a; K2.b_h2a = a->b_h2a; K2.w_att = K.w_att; K2.w_alpha = a->w_alpha;
@@ -3231,6 +3280,8 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
         K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
         K2.abort_word = h.abort_dev; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = dh; K2.dout = dout;
         K2.spin_limit = K.spin_limit; K2.inject = K.inject;
+        K2.pimg = (prebuilt_for() == x2) ? x2 + L2.pimg : nullptr;          // (queued on an earlier point of this launch's stream chain by the decoder's prepare)
+        prebuilt_for() = nullptr;
         // one memset: version 2's zeroed region and, right behind it, version 1's counters (all the LSTM kernel needs of that layout)
         if (!B.prezeroed && hipMemsetAsync(x2 + L2.zero_begin, 0, (size_t)(L2.total - L2.zero_begin + L.xc) * sizeof(float), st) != hipSuccess) {
             set_error("persist_fwd: memset failed");
@@ -3406,6 +3457,7 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
     K2.GATES1 = nullptr; K2.CS1 = nullptr; K2.HS = nullptr; K2.OUTD = nullptr; K2.QS = nullptr; K2.WT = nullptr; K2.ATT = nullptr;
     K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XC = x2 + L2.xc; K2.XS = x2 + L2.xs; K2.GRAN = reinterpret_cast<unsigned long long*>(x2 + L2.gran);
     K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
+    K2.pimg = nullptr;
     K2.abort_word = stopw; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = off; K2.dout = off;
     K2.spin_limit = K.spin_limit; K2.inject = K.inject;
     PersistS Q;
