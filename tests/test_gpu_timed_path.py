@@ -413,3 +413,39 @@ def test_initial_state_map_vs_oracle_and_module_contract(case):
     assert U.relerr(h_pad.cpu().numpy(), oh.numpy()) < 2e-6
     with pytest.raises(NotImplementedError):
         _fused(opt, params)
+
+
+def test_handover_callback_points_and_error_propagation():
+    """echr_train_step_args.handover_cb: with step=False and handover=True the library calls back on the host once per hand-over point (0 = logit
+    layer, 1 = LSTM layers), from inside the call, with the library stream that carries the range's last writer; what the callback queues on that
+    stream runs behind the point (here: a copy of the range, which must equal the final gradient).  An exception raised inside the callback
+    cannot cross the C frame: it is kept and re-raised behind the call."""
+    opt, params, vid = synth.make_case('c2')
+    m, o, f = _fused(opt, params, clip=opt.grad_clip)
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    ar = m._echr_arena
+    lm = m.lm_model
+    slots = sorted(ar.slot(p) for p in (lm.logit.weight, lm.logit.bias))
+    lo, hi = ar.span(slots)
+    seen, copies = [], {}
+
+    def cb(which, stream_ptr):
+        seen.append(which)
+        if which == 0:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream_ptr, device=ar.flat_g.device)):
+                copies[0] = ar.flat_g[lo:hi].clone()          # queued on the library's stream: behind the logit layer's last gradient launch
+
+    f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False, handover=True, handover_cb=cb)
+    torch.cuda.synchronize()
+    assert sorted(seen) == [0, 1]
+    assert torch.equal(copies[0], ar.flat_g[lo:hi])              # the range was final at the point
+    assert float(copies[0].abs().max()) > 0
+
+    def bad(which, stream_ptr):
+        raise RuntimeError('boom %d' % which)
+    with pytest.raises(RuntimeError, match='boom'):
+        f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False, handover=True, handover_cb=bad)
+    torch.cuda.synchronize()
+    # the object stays usable
+    loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False))
+    assert np.isfinite(loss)
