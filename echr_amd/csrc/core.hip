@@ -782,6 +782,16 @@ __global__ __launch_bounds__(256, 1) void greedy_step_kernel(float* __restrict__
 __device__ __forceinline__ float clamp_keep_nan(float g, float clip) { return (g != g) ? g : fminf(fmaxf(g, -clip), clip); }
 
 // ---- fused clamp + Adam (misc/utils.py:107-111 + torch.optim.Adam) ------------------------------------
+__device__ __forceinline__ float4 nt_load4(const float4* a) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 x = __builtin_nontemporal_load(reinterpret_cast<const v4*>(a));
+    return make_float4(x[0], x[1], x[2], x[3]);
+}
+__device__ __forceinline__ void nt_store4(float4* a, const float4 x) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((v4){x.x, x.y, x.z, x.w}, reinterpret_cast<v4*>(a));
+}
+template <int NT>
 __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
                                                          float omb1, float b2, float omb2, float eps, float clip,
@@ -795,10 +805,17 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 P = reinterpret_cast<float4*>(p)[i];
-        float4 G = reinterpret_cast<const float4*>(g)[i];
-        float4 M = reinterpret_cast<float4*>(m)[i];
-        float4 V = reinterpret_cast<float4*>(v)[i];
+        float4 P = NT >= 2 ? nt_load4(reinterpret_cast<const float4*>(p) + i) : reinterpret_cast<float4*>(p)[i];
+        float4 G, M, V;
+        if (NT) {          // g, m, v are streamed once per step and never re-read before they are rewritten: non-temporal
+            G = nt_load4(reinterpret_cast<const float4*>(g) + i);
+            M = nt_load4(reinterpret_cast<const float4*>(m) + i);
+            V = nt_load4(reinterpret_cast<const float4*>(v) + i);
+        } else {
+            G = reinterpret_cast<const float4*>(g)[i];
+            M = reinterpret_cast<float4*>(m)[i];
+            V = reinterpret_cast<float4*>(v)[i];
+        }
         float* pp = &P.x; float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -808,9 +825,9 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
             const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
             pp[k] -= lr_over_bc1 * (mm[k] / denom);
         }
-        reinterpret_cast<float4*>(p)[i] = P;
-        reinterpret_cast<float4*>(m)[i] = M;
-        reinterpret_cast<float4*>(v)[i] = V;
+        if (NT >= 3) nt_store4(reinterpret_cast<float4*>(p) + i, P); else reinterpret_cast<float4*>(p)[i] = P;
+        if (NT) { nt_store4(reinterpret_cast<float4*>(m) + i, M); nt_store4(reinterpret_cast<float4*>(v) + i, V); }
+        else { reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V; }
     }
     // tail
     const long base = n4 << 2;
@@ -1057,8 +1074,11 @@ extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int
     const double bc2 = 1.0 - pow(beta2, (double)step);
     const long n4 = n >> 2;
     int grid = (int)min(max((n4 + 255) / 256, 1L), 4096L);
-    hipLaunchKernelGGL(clamp_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, (float)(lr / bc1),
-                       (float)(1.0 / sqrt(bc2)), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, clip, persist_abort_word());
+    static const int nt = [] { const char* e = getenv("ECHR_ADAM_NT"); return e ? atoi(e) : 2; }();      // A/B switch: 0 = cached accesses, 1 = g / m / v non-temporal, 2 = + the load of p, 3 = + its store
+#define ECHR_ADAM_LAUNCH(L) hipLaunchKernelGGL(clamp_adam_kernel<L>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, (float)(lr / bc1), \
+                       (float)(1.0 / sqrt(bc2)), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, clip, persist_abort_word())
+    if (nt >= 3) ECHR_ADAM_LAUNCH(3); else if (nt == 2) ECHR_ADAM_LAUNCH(2); else if (nt == 1) ECHR_ADAM_LAUNCH(1); else ECHR_ADAM_LAUNCH(0);
+#undef ECHR_ADAM_LAUNCH
     return check_launch("clamp_adam");
 }
 

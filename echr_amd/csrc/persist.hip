@@ -88,6 +88,7 @@ struct PersistK {
     u32 spin_limit, inject;          // bound of every hand-off spin; diagnostic: the wait whose code equals `inject` never completes (0 = none)
     unsigned long long* stamps;      // diagnostic: [4 roles][S][16] s_memrealtime stamps (null = off)
     DropCfg dh, dout;
+    int nt_saved;                    // saved activations (gate activations, cell states) leave with non-temporal stores
 };
 #define STAMP(role, i) do { if (P.stamps && tid == 0) P.stamps[((role) * S + t) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
@@ -861,6 +862,7 @@ struct PersistK2 {
     unsigned long long* stamps;
     DropCfg dh, dout;
     const float* pimg;             // prebuilt weight images of this launch's workspace (nullptr: the workgroups build their own)
+    int nt_saved;                  // saved activations (gate activations, cell states) leave with non-temporal stores
 };
 
 
@@ -1551,8 +1553,15 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
             if (gn < N) {
                 const int j = 8 * lb + gu;
                 float* go = P.GATES1 + ((long)t * N + gn) * 4 * PH + j;
+                // (saved for the backward pass, read ~0.4 ms from now: non-temporal, they do not displace the hand-off operands in L2)
+                if (P.nt_saved) {
+                    __builtin_nontemporal_store(co.gi, go); __builtin_nontemporal_store(co.gf, go + PH);
+                    __builtin_nontemporal_store(co.gg, go + 2 * PH); __builtin_nontemporal_store(co.go, go + 3 * PH);
+                    __builtin_nontemporal_store(co.c, P.CS1 + ((long)(t + 1) * N + gn) * PH + j);
+                } else {
                 go[0] = co.gi; go[PH] = co.gf; go[2 * PH] = co.gg; go[3 * PH] = co.go;
                 P.CS1[((long)(t + 1) * N + gn) * PH + j] = co.c;
+                }
                 const long o = ((long)gn * 3 + 1) * PH + j;
                 P.HS[(long)(t + 1) * N * 3 * PH + o] = co.h;
                 P.OUTD[(long)t * N * 3 * PH + o] = co.hd;
@@ -1705,8 +1714,14 @@ __device__ __forceinline__ void dec_persist_lstm_h2_body(const PersistK& P, cons
             const int n = 32 * (rd >> 1) + gr, j = 16 * bs + 8 * (rd & 1) + g8;
             if (n < N) {
                 float* go = P.GATES[k] + ((long)t * N + n) * 4 * PH + j;
+                if (P.nt_saved) {
+                    __builtin_nontemporal_store(co[rd].gi, go); __builtin_nontemporal_store(co[rd].gf, go + PH);
+                    __builtin_nontemporal_store(co[rd].gg, go + 2 * PH); __builtin_nontemporal_store(co[rd].go, go + 3 * PH);
+                    __builtin_nontemporal_store(co[rd].c, P.CS[k] + ((long)(t + 1) * N + n) * PH + j);
+                } else {
                 go[0] = co[rd].gi; go[PH] = co[rd].gf; go[2 * PH] = co[rd].gg; go[3 * PH] = co[rd].go;
                 P.CS[k][((long)(t + 1) * N + n) * PH + j] = co[rd].c;
+                }
                 const long o = ((long)n * 3 + k) * PH + j;
                 P.HS[(long)(t + 1) * N * 3 * PH + o] = co[rd].h;
                 P.OUTD[(long)t * N * 3 * PH + o] = co[rd].hd;
@@ -3264,6 +3279,8 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     K.abort_word = h.abort_dev; K.host_flag = h.flag_dev;
     K.spin_limit = config().persist_spin_limit > 0 ? (u32)config().persist_spin_limit : SPIN_LIMIT; K.inject = (u32)config().persist_inject_timeout;
     K.dh = dh; K.dout = dout;
+    static const int nt_saved = [] { const char* e = getenv("ECHR_NT_SAVED"); return e ? atoi(e) : 1; }();      // A/B switch
+    K.nt_saved = nt_saved;
     K.stamps = nullptr;
     if (config().persist_stamps == 1) {
         if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
@@ -3271,6 +3288,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     }
     PersistK2 K2;
     K2.pimg = nullptr;
+    K2.nt_saved = 0;
     if (split) {
         K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
         K2.w_hh1 = a->w_hh[1]; K2.w_h2a = a->w_h2a; K2.b_h2a = a->b_h2a; K2.w_att = K.w_att; K2.w_alpha = a->w_alpha;
@@ -3280,6 +3298,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
         K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
         K2.abort_word = h.abort_dev; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = dh; K2.dout = dout;
         K2.spin_limit = K.spin_limit; K2.inject = K.inject;
+        K2.nt_saved = K.nt_saved;
         K2.pimg = (prebuilt_for() == x2) ? x2 + L2.pimg : nullptr;          // (queued on an earlier point of this launch's stream chain by the decoder's prepare)
         prebuilt_for() = nullptr;
         // one memset: version 2's zeroed region and, right behind it, version 1's counters (all the LSTM kernel needs of that layout)
@@ -3429,6 +3448,7 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
     const PersistLayoutS LS = persist_layout_s(a->S, a->V1);
     const DropCfg off{0u, 0u, 0u, 0u, 1.f, 0};          // decoding runs in eval mode: every dropout multiplier is 1
     PersistK K;
+    K.nt_saved = 0;
     K.N = a->N; K.A = a->A; K.D = a->D; K.S = a->S; K.ld_att = a->E + a->D;
     for (int k = 0; k < 3; ++k) { K.w_hh[k] = a->w_hh[k]; K.GATES[k] = nullptr; K.CS[k] = nullptr; }
     K.w_h2a = a->w_h2a; K.b_h2a = a->b_h2a; K.w_att = a->w_ih[1] + a->E; K.w_alpha = a->w_alpha;
@@ -3458,6 +3478,7 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
     K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XC = x2 + L2.xc; K2.XS = x2 + L2.xs; K2.GRAN = reinterpret_cast<unsigned long long*>(x2 + L2.gran);
     K2.XH1 = x2 + L2.xh1; K2.XQ = x2 + L2.xq; K2.WU = x2 + L2.wu; K2.XCMAX = x2 + L2.xcmax;
     K2.pimg = nullptr;
+    K2.nt_saved = 0;
     K2.abort_word = stopw; K2.host_flag = h.flag_dev; K2.stamps = K.stamps; K2.dh = off; K2.dout = off;
     K2.spin_limit = K.spin_limit; K2.inject = K.inject;
     PersistS Q;
