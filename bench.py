@@ -179,6 +179,9 @@ def timed_regions(iteration, steps, regions, fence, world, dev, use_dist):
     """`regions` back-to-back timed regions of exactly `steps` iterations, each bracketed by barrier + torch.cuda.synchronize() on both sides
     and reduced with MAX over ranks; returns the per-region wall times [s], the host issue time of the first region and the last loss."""
     out, t_issue, loss = [], None, None
+    import gc
+    gc.collect()
+    gc.disable()          # like timeit: a generation-2 collection of the interpreter (~40 ms with torch loaded) is not part of an iteration
     for r in range(regions):
         fence()
         t0 = time.perf_counter()
@@ -193,6 +196,7 @@ def timed_regions(iteration, steps, regions, fence, world, dev, use_dist):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         out.append(dt)
+    gc.enable()
     return out, t_issue, loss
 
 
