@@ -181,7 +181,8 @@ def timed_regions(iteration, steps, regions, fence, world, dev, use_dist):
     out, t_issue, loss = [], None, None
     import gc
     gc.collect()
-    gc.disable()          # like timeit: a generation-2 collection of the interpreter (~40 ms with torch loaded) is not part of an iteration
+    if os.environ.get('ECHR_BENCH_GC') != '1':
+        gc.disable()          # like timeit: a generation-2 collection of the interpreter (~40 ms with torch loaded) is not part of an iteration
     for r in range(regions):
         fence()
         t0 = time.perf_counter()
