@@ -56,9 +56,9 @@ static Side& side() {
         int lo = 0, hi = 0;
         bool good = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
         good = good && hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, lo) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&sd.half, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&sd.fork, echr::sync_event_flags()) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&sd.half, echr::sync_event_flags()) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&sd.join, echr::sync_event_flags()) == hipSuccess;
         sd.ok = good;
     }
     return sd;
@@ -84,11 +84,11 @@ static Tail& tail() {
         // (ECHR_HELPER_PRIO=low: least priority -- the helper streams carry chip-filling throughput kernels whose workgroups otherwise delay the
         // dispatch of the caller's stream's small latency-bound kernels running beside them; A/B switch)
         bool good = helper_stream_create(&t.s);
-        good = good && hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&t.fork2, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&t.done2, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&t.done3, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.fork, echr::sync_event_flags()) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.done, echr::sync_event_flags()) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.fork2, echr::sync_event_flags()) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.done2, echr::sync_event_flags()) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.done3, echr::sync_event_flags()) == hipSuccess;
         t.ok = good;
     }
     return t;
@@ -131,7 +131,7 @@ static Handover& handover() {
     static Handover h;
     if (!h.init) {
         h.init = true;
-        h.ok = hipEventCreateWithFlags(&h.ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h.ev[1], hipEventDisableTiming) == hipSuccess;
+        h.ok = hipEventCreateWithFlags(&h.ev[0], echr::sync_event_flags()) == hipSuccess && hipEventCreateWithFlags(&h.ev[1], echr::sync_event_flags()) == hipSuccess;
         if (!h.ok) (void)hipGetLastError();
     }
     return h;
@@ -1085,10 +1085,10 @@ static Prep& prep() {
     if (!t.init) {
         t.init = true;
         bool good = helper_stream_create(&t.s);
-        good = good && hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&t.fill_done, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&t.fill0, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.fork, echr::sync_event_flags()) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.done, echr::sync_event_flags()) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.fill_done, echr::sync_event_flags()) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&t.fill0, echr::sync_event_flags()) == hipSuccess;
         t.ok = good;
     }
     return t;

@@ -67,6 +67,17 @@ constexpr int ABORT_SKIPPED_WORD = 16;
 unsigned* persist_host_flag();          // device view of the host-mapped flag persist_check_async reads (nullptr when unavailable)
 // the library's helper stream outside a backward pass (the one the asynchronous decoder-backward tail uses): `aux_fork` makes it continue
 // after everything queued on `from` and returns it, `aux_join` makes `to` wait for what was queued on it since
+// Flags of every event the library uses to order its own streams on ONE device: no timing, and no system-scope fence -- the default event
+// release writes the caches back and invalidates them for the host and other devices, which neither a stream-to-stream edge nor the staging
+// ring's "this copy kernel has finished" needs (ECHR_EVENT_SYSTEM_FENCE=1 restores the default)
+inline unsigned sync_event_flags() {
+    static const unsigned f = [] {
+        const char* e = getenv("ECHR_EVENT_SYSTEM_FENCE");
+        if (e && e[0] == '1') return (unsigned)hipEventDisableTiming;
+        return (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+    }();
+    return f;
+}
 void fork_event(hipEvent_t ev);                  // forks that follow wait for `ev` (the caller's stream's last record) instead of recording their own; nullptr ends it
 hipStream_t aux_fork(hipStream_t from);          // nullptr when unavailable
 int aux_join(hipStream_t to);

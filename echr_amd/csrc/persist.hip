@@ -3148,8 +3148,8 @@ static bool side_stream(PersistHost& h) {
         int lo = 0, hi = 0;
         bool good = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
         good = good && hipStreamCreateWithPriority(&h.side, hipStreamNonBlocking, hi) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&h.fork, hipEventDisableTiming) == hipSuccess;
-        good = good && hipEventCreateWithFlags(&h.join, hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&h.fork, echr::sync_event_flags()) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&h.join, echr::sync_event_flags()) == hipSuccess;
         if (!good) { (void)hipGetLastError(); h.side = nullptr; }
     }
     return h.side != nullptr;

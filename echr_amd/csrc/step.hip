@@ -77,7 +77,7 @@ static int stage_indices(const int32_t* host, int32_t* dev, size_t bytes, hipStr
         if (hipHostMalloc(&r.buf[s], want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("train_step: pinned staging buffer (%zu bytes) unavailable", want); return -12; }
         r.cap[s] = want;
     }
-    if (!r.done[s] && hipEventCreateWithFlags(&r.done[s], hipEventDisableTiming) != hipSuccess) { set_error("train_step: event create failed"); return -5; }
+    if (!r.done[s] && hipEventCreateWithFlags(&r.done[s], echr::sync_event_flags()) != hipSuccess) { set_error("train_step: event create failed"); return -5; }
     memcpy(r.buf[s], host, bytes);
     // the pinned buffer is read by a copy KERNEL (host-coherent memory is device-visible at the same address): an in-stream launch of ~3 us.
     // hipMemcpyAsync takes the DMA-engine path for transfers of this size (~19 KB), whose start-up latency (tens of us) sat at the head of

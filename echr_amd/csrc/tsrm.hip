@@ -728,7 +728,7 @@ int echr::tsrm_position_early(const echr_tsrm_args* a, hipStream_t from) {
     static hipEvent_t ev_wfc1 = nullptr;
     hipEvent_t ready = nullptr;
     if (wfc1_here && config().gemm_h2 && NN >= 1024) {
-        if (!ev_wfc1 && hipEventCreateWithFlags(&ev_wfc1, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev_wfc1 = nullptr; }
+        if (!ev_wfc1 && hipEventCreateWithFlags(&ev_wfc1, echr::sync_event_flags()) != hipSuccess) { (void)hipGetLastError(); ev_wfc1 = nullptr; }
         if (ev_wfc1) {
             H2PackJob pj = pack_rows(a->w_fc1, Df, Df, Df, w.PK_WFC1);
             RC(h2_pack_multi(&pj, 1, from));
