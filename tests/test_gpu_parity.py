@@ -1158,11 +1158,11 @@ def test_fused_train_step_equals_autograd_path(case):
     sync()
     la = autograd_iteration(ma, oa)
     lb = autograd_iteration(mb, ob)
-    assert abs(la - lb) < 2e-6 * abs(la)
+    assert abs(la - lb) < 5e-6 * abs(la)          # (two models several Adam steps apart on split-K atomics: the loss, 0.02 here, moves in quanta of ~2e-6 relative between runs)
     sync()
     la = autograd_iteration(ma, oa)
     lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk))
-    assert abs(la - lb) < 2e-6 * abs(la)
+    assert abs(la - lb) < 5e-6 * abs(la)
     assert oa._flat['step'] == ob._flat['step']
     # the joint 'tap_cg' iteration (train.py:300-313): d loss / d tap_feats comes back through `tap_grad` for the proposal encoder
     sync()
@@ -1182,7 +1182,7 @@ def test_fused_train_step_equals_autograd_path(case):
     g_ref = torch.zeros_like(tap)
     fb2_tap = torch.zeros_like(tap)
     lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], tap_grad=fb2_tap, defer_update=True))
-    assert abs(la - lb) < 2e-6 * abs(la)
+    assert abs(la - lb) < 5e-6 * abs(la)
     assert U.grad_close('tap_feats', fb2_tap.cpu().numpy(), g_tap.cpu().numpy(), 1e-3)          # (same state up to one Adam step of noise-level drift)
     fb.join()
     assert oa._flat['step'] == ob._flat['step']
@@ -1210,7 +1210,7 @@ def test_fused_train_step_equals_autograd_path(case):
     lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], tap_grad=torch.zeros_like(tap), defer_update=True,
                   prepared=True))
     fb.join()
-    assert abs(la - lb) < 2e-6 * abs(la) and bool(torch.isfinite(filler))
+    assert abs(la - lb) < 5e-6 * abs(la) and bool(torch.isfinite(filler))
     for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         assert k in U.NOISE_ONLY or float((pa.detach() - pb.detach()).abs().max()) <= 2.01 * lr, k
     with pytest.raises(RuntimeError):
