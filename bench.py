@@ -183,21 +183,23 @@ def timed_regions(iteration, steps, regions, fence, world, dev, use_dist):
     gc.collect()
     if os.environ.get('ECHR_BENCH_GC') != '1':
         gc.disable()          # like timeit: a generation-2 collection of the interpreter (~40 ms with torch loaded) is not part of an iteration
-    for r in range(regions):
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = iteration()
-        if t_issue is None:
-            t_issue = time.perf_counter() - t0          # host time to issue the timed steps (the GPU may still be working)
-        fence()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        out.append(dt)
-    gc.enable()
+    try:
+        for r in range(regions):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = iteration()
+            if t_issue is None:
+                t_issue = time.perf_counter() - t0          # host time to issue the timed steps (the GPU may still be working)
+            fence()
+            dt = time.perf_counter() - t0
+            if use_dist:
+                t = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            out.append(dt)
+    finally:
+        gc.enable()          # (an exception inside iteration() must not leave the collector off for the legs that follow)
     return out, t_issue, loss
 
 

@@ -98,7 +98,7 @@ class TrainStepArgs(C.Structure):
                 ('flat_p', c_f), ('adam_m', c_f), ('adam_v', c_f), ('adam_step', i32),
                 ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('clip', f32),
                 ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32), ('prepared', i32), ('defer_update', i32),
-                ('handover', i32), ('handover_cb', C.c_void_p), ('handover_user', C.c_void_p)]
+                ('handover', i32), ('handover_cb', C.c_void_p), ('handover_user', C.c_void_p), ('adam_applied', c_f)]
 
 
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)
@@ -159,13 +159,14 @@ SYMBOLS = [
     ('echr_handover_wait', i32, [i32, C.c_void_p]),
     ('echr_clamp', i32, [c_f, i64, f32, C.c_void_p]),
     ('echr_clamp_adam', i32, [c_f, c_f, c_f, c_f, i64, i32, C.c_double, C.c_double, C.c_double, C.c_double, f32, C.c_void_p]),
+    ('echr_clamp_adam_counted', i32, [c_f, c_f, c_f, c_f, i64, i32, C.c_double, C.c_double, C.c_double, C.c_double, f32, c_f, C.c_void_p]),
 ]
 
 ABI_STRUCTS = {'echr_gemm_desc': GemmDesc, 'echr_dropout': Dropout, 'echr_tsrm_args': TsrmArgs, 'echr_tsrm_grads': TsrmGrads,
                'echr_dec_args': DecArgs, 'echr_dec_grads': DecGrads, 'echr_sample_args': SampleArgs, 'echr_sst_args': SstArgs,
                'echr_sst_grads': SstGrads, 'echr_train_step_args': TrainStepArgs, 'echr_init_state_args': InitStateArgs, 'echr_init_state_grads': InitStateGrads}
 
-ABI_VERSION = 2          # include/echr_hip.h ECHR_ABI_VERSION
+ABI_VERSION = 3          # include/echr_hip.h ECHR_ABI_VERSION
 _lib = None
 
 
@@ -196,10 +197,21 @@ def load():
     return lib
 
 
+# Objects that keep host-side counts of work the device may have skipped (optimiser step counts): every site that can surface the
+# asynchronous failure -62 goes through check(), which lets them re-read the device's own counts BEFORE the error propagates
+# (persist_check_async has synchronised the device by then: the counts are final).
+import weakref
+ABORT_LISTENERS = weakref.WeakSet()
+
+
 def check(rc, what=''):
     if rc != 0:
         msg = load().echr_last_error()
-        raise EchrHipError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
+        msg = msg.decode() if msg else ''
+        if rc == -62:
+            for o in list(ABORT_LISTENERS):
+                o._on_async_abort()
+        raise EchrHipError('%s failed (rc=%d): %s' % (what, rc, msg))
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)

@@ -795,13 +795,15 @@ template <int NT>
 __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
                                                          float omb1, float b2, float omb2, float eps, float clip,
-                                                         const unsigned* __restrict__ abort_word) {
+                                                         const unsigned* __restrict__ abort_word, unsigned* __restrict__ applied) {
     // a persistent recurrence launch of this iteration gave up (hand-off timeout): its gradients are garbage, so the update is skipped;
     // the host reports -ETIME at its next library call (persist_check_async)
     if (abort_word && *abort_word) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(const_cast<unsigned*>(abort_word) + ABORT_SKIPPED_WORD, 1u);          // counted for echr_async_skipped_updates
         return;
     }
+    // the caller's own count of updates that WERE applied (one word per optimiser state: echr_clamp_adam_counted)
+    if (applied && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(applied, 1u);
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -842,10 +844,7 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
 }
 
 __global__ void clamp_kernel(float* g, long n, float clip, const unsigned* __restrict__ abort_word) {
-    if (abort_word && *abort_word) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(const_cast<unsigned*>(abort_word) + ABORT_SKIPPED_WORD, 1u);
-        return;
-    }
+    if (abort_word && *abort_word) return;          // (a clamp is not an optimiser update: not counted)
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = clamp_keep_nan(g[i], clip);
 }
@@ -1065,6 +1064,10 @@ extern "C" int echr_nll_loss_fwd_i64(const float* logp, const int64_t* target, c
 
 extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
                                double beta2, double eps, float clip, void* stream) {
+    return echr_clamp_adam_counted(p, g, m, v, n, step, lr, beta1, beta2, eps, clip, nullptr, stream);
+}
+extern "C" int echr_clamp_adam_counted(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
+                                       double beta2, double eps, float clip, uint32_t* applied, void* stream) {
     ECHR_REQUIRE(p && g && m && v && n > 0 && step >= 1, "clamp_adam: bad arguments");
     if (int rc = join_tail((hipStream_t)stream)) return rc;
     ECHR_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
@@ -1076,7 +1079,7 @@ extern "C" int echr_clamp_adam(float* p, const float* g, float* m, float* v, int
     int grid = (int)min(max((n4 + 255) / 256, 1L), 4096L);
     static const int nt = [] { const char* e = getenv("ECHR_ADAM_NT"); return e ? atoi(e) : 2; }();      // A/B switch: 0 = cached accesses, 1 = g / m / v non-temporal, 2 = + the load of p, 3 = + its store
 #define ECHR_ADAM_LAUNCH(L) hipLaunchKernelGGL(clamp_adam_kernel<L>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, (float)(lr / bc1), \
-                       (float)(1.0 / sqrt(bc2)), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, clip, persist_abort_word())
+                       (float)(1.0 / sqrt(bc2)), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, clip, persist_abort_word(), applied)
     if (nt >= 3) ECHR_ADAM_LAUNCH(3); else if (nt == 2) ECHR_ADAM_LAUNCH(2); else if (nt == 1) ECHR_ADAM_LAUNCH(1); else ECHR_ADAM_LAUNCH(0);
 #undef ECHR_ADAM_LAUNCH
     return check_launch("clamp_adam");

@@ -131,7 +131,9 @@ static Handover& handover() {
     static Handover h;
     if (!h.init) {
         h.init = true;
-        h.ok = hipEventCreateWithFlags(&h.ev[0], echr::sync_event_flags()) == hipSuccess && hipEventCreateWithFlags(&h.ev[1], echr::sync_event_flags()) == hipSuccess;
+        // (system-scope release, unlike the library's internal edges: what waits for a hand-over point is a consumer OUTSIDE the library -- a
+        // collective that peers read over xGMI, an SDMA copy -- and the events are only recorded when a hand-over was asked for)
+        h.ok = hipEventCreateWithFlags(&h.ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h.ev[1], hipEventDisableTiming) == hipSuccess;
         if (!h.ok) (void)hipGetLastError();
     }
     return h;

@@ -152,7 +152,7 @@ static int joint_finish(JointPending& jp, hipStream_t src) {
     hipStream_t ts = helpers_merge_to_tail();
     if (!ts) return -5;
     const echr_train_step_args& a = jp.args;
-    RC(echr_clamp_adam(a.flat_p, a.flat_g, a.adam_m, a.adam_v, a.n_flat, a.adam_step, a.lr, a.beta1, a.beta2, a.eps, a.clip, ts));
+    RC(echr_clamp_adam_counted(a.flat_p, a.flat_g, a.adam_m, a.adam_v, a.n_flat, a.adam_step, a.lr, a.beta1, a.beta2, a.eps, a.clip, a.adam_applied, ts));
     return tail_publish();
 }
 
@@ -228,7 +228,15 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
         int rc2 = tsrm_position_early(&t, st);
         if (!rc2) rc2 = echr_decoder_fwd_prepare(&d, stream);
         fork_event(nullptr);
-        RC(rc2);
+        if (rc2) {
+            // the position branch may already be queued on the tail stream: forget it (a later echr_tsrm_fwd on this workspace must not take the
+            // `early` form with stale gates) and order this stream behind what was queued, as the event encoder's own failure path does
+            (void)tsrm_position_early(nullptr, nullptr);
+            (void)aux_join(st);
+            (void)aux2_join(st);          // (a prepare chain that failed half-way published nothing: join the stream itself)
+            (void)echr_decoder_fwd_prepare_cancel(stream);
+            return rc2;
+        }
     }
     int rc = echr_event_pool_gather_fwd(a->dec.c3d, a->tap, ev_start, ev_len, ind, ws + L.ech, N, a->dec.D, a->Ht, stream);       // :106-128
     if (!rc) rc = echr_tsrm_fwd(&t, &a->drop, stream);                                                                       // :129
@@ -297,7 +305,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     RC(echr_stream_join(stream));          // the decoder backward's asynchronous tail: every gradient is final in `stream` order now
     step_mark(4, st);
     if (a->do_step)                        // clip_gradient + Adam (misc/utils.py:107-111, train.py:315-317)
-        RC(echr_clamp_adam(a->flat_p, a->flat_g, a->adam_m, a->adam_v, a->n_flat, a->adam_step, a->lr, a->beta1, a->beta2, a->eps, a->clip, stream));
+        RC(echr_clamp_adam_counted(a->flat_p, a->flat_g, a->adam_m, a->adam_v, a->n_flat, a->adam_step, a->lr, a->beta1, a->beta2, a->eps, a->clip, a->adam_applied, stream));
     step_mark(5, st);
     step_timing_end();
     return 0;

@@ -606,12 +606,14 @@ class MaskedNLL(torch.autograd.Function):
 PARAM_EPOCH = [0]
 
 
-def clamp_adam_(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip=100.0):
-    """In-place fused clamp(+-clip) + Adam over flat fp32 buffers (misc/utils.py:107-111 + optim.Adam)."""
+def clamp_adam_(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip=100.0, applied=None):
+    """In-place fused clamp(+-clip) + Adam over flat fp32 buffers (misc/utils.py:107-111 + optim.Adam).  `applied`: optional int32 device
+    tensor [1] the launch increments iff the update was applied (echr_clamp_adam_counted)."""
     lib = L.load()
     PARAM_EPOCH[0] += 1
-    L.check(lib.echr_clamp_adam(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), int(step), float(lr), float(beta1),
-                                float(beta2), float(eps), float(clip), L.stream_ptr()), 'clamp_adam')
+    L.check(lib.echr_clamp_adam_counted(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), int(step), float(lr), float(beta1),
+                                        float(beta2), float(eps), float(clip), None if applied is None else L.ptr(applied, torch.int32),
+                                        L.stream_ptr()), 'clamp_adam')
 
 
 def clamp_(g, clip):

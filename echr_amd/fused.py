@@ -134,14 +134,10 @@ class FusedTrainStep(object):
         `handover=True` (with step=False): the backward pass records the data-parallel hand-over points (echr_handover_wait; DataParallelStep);
         `handover_cb(which, stream_ptr)`: called on the host from inside the call at each point (echr_train_step_args.handover_cb)."""
         a, lib = self.a, self.lib
-        rc = lib.echr_check_async()
-        if rc:
-            # a persistent launch of an EARLIER iteration gave up: the optimiser kernels queued behind it skipped their updates (parameters
-            # and moments untouched) while this object already counted those steps -- wind the count back, then report
-            st = self.optim._flat
-            if st is not None:
-                st['step'] = max(0, st['step'] - int(lib.echr_async_skipped_updates()))
-            L.check(rc, 'train_step (asynchronous failure of an earlier call)')
+        # a persistent launch of an EARLIER iteration gave up: the optimiser kernels queued behind it skipped their updates (parameters and
+        # moments untouched) while the step was already counted -- L.check lets every optimiser wind its count back to the updates its own
+        # device word says were applied (ClampAdam._on_async_abort), here and at every other site that can surface the -62
+        L.check(lib.echr_check_async(), 'train_step (asynchronous failure of an earlier call)')
         if prepared:
             if not getattr(self, '_prepared', False) or not step or forward_only:
                 raise RuntimeError('prepared=True needs a preceding prepare() and a full training step')
@@ -157,17 +153,18 @@ class FusedTrainStep(object):
             a.prepared = 0
         a.handover = 1 if (handover and not step and not forward_only) else 0
         if a.handover and handover_cb is not None:
-            # (the CFUNCTYPE object must outlive the call: kept on self; an exception inside a ctypes callback cannot propagate -- it is kept and
-            # re-raised behind the call)
-            self._cb_error = None
-
-            def _tramp(which, stream, _user, cb=handover_cb):
-                try:
-                    cb(int(which), int(stream))
-                except BaseException as e:          # noqa: BLE001
-                    self._cb_error = e
-            self._cb_keep = L.HANDOVER_FN(_tramp)
-            a.handover_cb = C.cast(self._cb_keep, C.c_void_p)
+            # ONE ctypes trampoline per object (building a CFUNCTYPE per call is host time inside the timed multi-rank loop); it forwards to
+            # the callback of the current call.  An exception inside a ctypes callback cannot propagate: kept and re-raised behind the call
+            self._cb_error, self._cb_cur = None, handover_cb
+            if getattr(self, '_cb_keep', None) is None:
+                def _tramp(which, stream, _user):
+                    try:
+                        self._cb_cur(int(which), int(stream))
+                    except BaseException as e:          # noqa: BLE001
+                        self._cb_error = e
+                self._cb_keep = L.HANDOVER_FN(_tramp)
+                self._cb_ptr = C.cast(self._cb_keep, C.c_void_p)
+            a.handover_cb = self._cb_ptr
         else:
             a.handover_cb = None
         a.handover_user = None
@@ -317,6 +314,7 @@ class FusedTrainStep(object):
             clip = o.pending_clip if o.pending_clip is not None else self.grad_clip
             o.pending_clip = None
             a.adam_m, a.adam_v, a.adam_step = st['m'].data_ptr(), st['v'].data_ptr(), st['step'] + 1
+            a.adam_applied = o.applied_counter(self.dev).data_ptr()
             a.lr, (a.beta1, a.beta2), a.eps = group['lr'], group['betas'], group['eps']
             a.clip = float('inf') if clip is None else float(clip)
         else:
@@ -328,6 +326,7 @@ class FusedTrainStep(object):
         a, m, ar = self.a, self.model, self.arena
         if a.do_step:
             st['step'] += 1
+            self.optim._count_step([st])
             EF.PARAM_EPOCH[0] += 1
             ar._zeroed = []
         elif not forward_only:

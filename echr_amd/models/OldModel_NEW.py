@@ -272,10 +272,11 @@ class ThreeStream_Core(nn.Module):
         self.fc_feat_size = opt.CG_fc_feat_size
         self.att_feat_size = opt.clip_context_dim
         self.att_hid_size = opt.CG_att_hid_size
+        # accepted and ignored, exactly as the reference's ThreeStream_Core does: CG_input_dim is computed (:775-776,:790-799) and never used --
+        # no layer is sized by it and forward (:801-823) never reads it
         self.CG_input_feats_type = opt.CG_input_feats_type
-        if self.CG_input_feats_type:
-            raise NotImplementedError('CG_input_feats_type=%r is not part of the ECHR recipe' % (self.CG_input_feats_type,))
-        self.CG_input_dim = 0
+        self.CG_input_dim = sum(d for c, d in (('V', opt.video_context_dim), ('E', opt.event_context_dim), ('C', opt.clip_context_dim))
+                                if c in self.CG_input_feats_type)
         E = self.input_encoding_size
         self.layer0 = nn.LSTMCell(opt.event_context_dim + E, self.rnn_size)
         self.layer1 = nn.LSTMCell(opt.clip_context_dim + E, self.rnn_size)

@@ -1,5 +1,7 @@
 """Fused clamp + Adam optimiser (reference: misc/utils.py:107-111 clip_gradient + torch.optim.Adam as wired at
 train.py:201-209,315-317: betas (optim_alpha, optim_beta), eps, weight_decay 0, no amsgrad)."""
+import collections
+
 import torch
 
 from . import functional as EF
@@ -27,6 +29,36 @@ class ClampAdam(torch.optim.Optimizer):
         # reference's clamp(clamp(g1) + g2) for any m_batch.  What deferral does change: `.grad` read between clip_gradient and step()
         # holds the unclamped values.  False: clip_gradient clamps in place right away (reference-visible .grad, one more pass).
         self.defer_clamp = True
+        # Step counts against updates the device skipped (an aborted persistent launch: the optimiser kernels queued behind it return without
+        # touching p / m / v, include/echr_hip.h echr_check_async).  The host counts a step when it QUEUES the update; the device counts it,
+        # in this optimiser's own word, when it APPLIES it (echr_clamp_adam_counted; the first launch of a step() carries the word).  After
+        # a -62 -- which every site surfaces through _lib.check -- the last (issued - applied) steps are wound back.  Per optimiser, so two
+        # optimisers stepping in one process (the joint 'tap_cg' iteration) never see each other's skips.
+        self._applied = None          # int32 device tensor [1]
+        self._issued = 0
+        self._step_log = collections.deque(maxlen=1024)       # per counted step(): the state dicts whose 'step' it incremented
+        EF.L.ABORT_LISTENERS.add(self)
+
+    def applied_counter(self, device):
+        if self._applied is None:
+            self._applied = torch.zeros(1, device=device, dtype=torch.int32)
+        return self._applied
+
+    def _count_step(self, states):
+        """The host side of one queued update: `states` are the dicts whose 'step' was just incremented."""
+        self._issued += 1
+        self._step_log.append(list(states))
+
+    def _on_async_abort(self):
+        """Called by _lib.check when a library call returned -62 (the device is idle by then): wind the step counts back to what happened."""
+        if self._applied is None or self._issued == 0:
+            return
+        applied = int(self._applied.item())
+        lost = self._issued - applied
+        for _ in range(max(0, min(lost, len(self._step_log)))):
+            for st in self._step_log.pop():
+                st['step'] = max(0, int(st['step']) - 1)
+        self._issued = applied
 
     def _flat_step(self, clip):
         """Whole-model update in ONE kernel launch; valid when all parameters and all live gradients alias the arena."""
@@ -45,8 +77,10 @@ class ClampAdam(torch.optim.Optimizer):
         ar.zero_unused_grads()                # never-used parameters: g = 0 -> m = v = 0 -> no update (== Adam skipping them)
         st = self._flat
         st['step'] += 1
+        self._count_step([st])
         b1, b2 = group['betas']
-        EF.clamp_adam_(ar.flat_p, ar.flat_g, st['m'], st['v'], st['step'], group['lr'], b1, b2, group['eps'], clip)
+        EF.clamp_adam_(ar.flat_p, ar.flat_g, st['m'], st['v'], st['step'], group['lr'], b1, b2, group['eps'], clip,
+                       applied=self.applied_counter(ar.flat_p.device))
         return True
 
     @torch.no_grad()
@@ -95,6 +129,10 @@ class ClampAdam(torch.optim.Optimizer):
         every live parameter is updated at every step)."""
         super(ClampAdam, self).load_state_dict(state_dict)
         self._flat = None
+        self._step_log.clear()                     # (the logged state dicts were just replaced)
+        self._issued = 0
+        if self._applied is not None:
+            self._applied.zero_()
         ar = self.arena
         if ar is None or not self.state:
             return
@@ -129,6 +167,7 @@ class ClampAdam(torch.optim.Optimizer):
             return None
         if self._flat is not None:
             raise RuntimeError('ClampAdam: gradients left the flat arena after flat optimiser state was created')
+        stepped = []
         for group in self.param_groups:
             b1, b2 = group['betas']
             for p in group['params']:
@@ -141,5 +180,11 @@ class ClampAdam(torch.optim.Optimizer):
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st['step'] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                EF.clamp_adam_(p.data, g, st['exp_avg'], st['exp_avg_sq'], st['step'], group['lr'], b1, b2, group['eps'], clip)
+                # (the abort word is sticky until the host acknowledges it, so the launches of one step() are applied or skipped together:
+                # the first one carries the optimiser's applied-update word)
+                EF.clamp_adam_(p.data, g, st['exp_avg'], st['exp_avg_sq'], st['step'], group['lr'], b1, b2, group['eps'], clip,
+                               applied=None if stepped or not p.is_cuda else self.applied_counter(p.device))
+                stepped.append(st)
+        if stepped:
+            self._count_step(stepped)
         return None

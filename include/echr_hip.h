@@ -28,7 +28,9 @@ extern "C" {
 /* 2 (round 5): echr_train_step_args.handover, echr_handover_wait, echr_async_skipped_updates; round 4 had grown the decoder's
  * argument struct (train, zero_extra, zero_extra_count) and its gradient struct (dlg_ready, active_rows, n_active) under version 1.  A binding that restates
  * the structs MUST also compare its sizeof() of each with echr_abi_sizeof(): the version alone does not describe the layouts. */
-#define ECHR_ABI_VERSION 2
+/* 3 (round 6): echr_clamp_adam_counted, echr_train_step_args.adam_applied (a per-optimiser count of APPLIED updates; the process-wide
+ * echr_async_skipped_updates now counts echr_clamp_adam launches only). */
+#define ECHR_ABI_VERSION 3
 
 int echr_version(void);
 /* sizeof() of an argument struct of this header by its type name ("echr_dec_args", ...), -1 for an unknown name: lets a binding that
@@ -40,8 +42,10 @@ const char* echr_last_error(void);
  * invalid gradients) and the NEXT library call that takes a stream returns -ETIME (-62) once, naming the edge and timestep.
  * echr_check_async() is that check on its own, for callers that want it right after a synchronisation point: 0 or -62. */
 int echr_check_async(void);
-/* Number of echr_clamp_adam / echr_clamp launches that skipped their update because of the asynchronous failure the last -62 reported
- * (read once: the count is cleared).  A caller that keeps its own optimiser step count winds it back by this many steps. */
+/* Number of echr_clamp_adam launches (of ANY optimiser state of the process; echr_clamp is not an update and is not counted) that skipped
+ * their update because of the asynchronous failure the last -62 reported (read once: the count is cleared).  Process-wide, therefore only
+ * a diagnostic when several optimiser states step in one process: a caller that keeps step counts winds each of them back from its OWN
+ * count of applied updates (echr_clamp_adam_counted / echr_train_step_args.adam_applied). */
 int64_t echr_async_skipped_updates(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -440,6 +444,11 @@ int echr_top_proposals_nms(const float* scores, int32_t T, int32_t K, int32_t to
  * ---------------------------------------------------------------------------------------------- */
 int echr_clamp_adam(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
                     double beta2, double eps, float clip, void* stream);
+/* The same, counting itself: `applied` (optional device word, one per optimiser state, zeroed by its owner) is incremented by the launch
+ * iff the update was applied, i.e. not skipped under an unacknowledged asynchronous failure (see echr_check_async).  After a -62 the owner
+ * reads the word (everything queued has retired by then) and sets its step count to the number of updates that really happened. */
+int echr_clamp_adam_counted(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, double beta1,
+                            double beta2, double eps, float clip, uint32_t* applied, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * One training iteration of the caption path as ONE call.  Replaces the per-iteration protocol of train.py:281-317 around the hot
@@ -506,6 +515,7 @@ typedef struct {
                                       no further stream or event (RCCL through torch.distributed: make `stream` current for the call).  The
                                       callback must not call back into this library and must not block on the device */
     void* handover_user;           /* passed through to handover_cb */
+    uint32_t* adam_applied;        /* optional (do_step = 1): the optimiser state's count of applied updates, see echr_clamp_adam_counted */
 } echr_train_step_args;
 int64_t echr_train_step_ws_floats(const echr_train_step_args* a);
 int echr_train_step(const echr_train_step_args* a, void* stream);
@@ -517,6 +527,12 @@ int echr_train_step_prepare(const echr_train_step_args* a, void* stream);
 /* Hand-over points of the LAST echr_train_step issued with handover = 1 (which: 0 = logit layer, 1 = LSTM layers): makes `stream` wait
  * until that range of flat_g is final.  0 = `stream` now waits; 1 = the call recorded no such point (a configuration without the
  * asynchronous tail: the range is final when the call's own stream reaches its end, like every other); < 0 error. */
+/* Memory scope of the library's ordering points.  echr_handover_wait's events carry a system-scope release (their consumers sit outside the
+ * library: collectives read by peers, copy engines).  echr_stream_join -- and every entry that joins the helper streams by itself -- orders
+ * `stream` behind the helper streams with AGENT-scope events (no cache write-back for the host or other devices: ~2 us less per edge, a dozen
+ * edges per iteration): kernels queued on `stream` afterwards see every result; a consumer on another device or the host must follow the join
+ * with a system-scope point of its own on `stream` -- hipStreamSynchronize, or an event created without hipEventDisableSystemFence (what
+ * torch.distributed records in front of every collective).  ECHR_EVENT_SYSTEM_FENCE=1 in the environment makes every library event system-scope. */
 enum { ECHR_HANDOVER_LOGIT = 0, ECHR_HANDOVER_LSTM = 1 };
 int echr_handover_wait(int which, void* stream);
 

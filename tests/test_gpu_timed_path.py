@@ -449,3 +449,126 @@ def test_handover_callback_points_and_error_propagation():
     # the object stays usable
     loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False))
     assert np.isfinite(loss)
+
+
+# ---- optimiser step counts against updates the device skipped (asynchronous -62) -------------------------------------------------------
+def _abort_some_iterations(lib, issue, n_calls=3):
+    """Issue iterations while ONE hand-off wait of the forward recurrence never completes (persist_inject_timeout): every persistent launch
+    queued meanwhile drains through its bounded spins, the optimiser kernels behind it skip.  The -62 may surface at ANY of the sites that
+    check (the next call, prepare(), ClampAdam.step, the explicit check below) -- wherever it does, it goes through _lib.check."""
+    from echr_amd import _lib
+    n_err = 0
+    try:
+        assert lib.echr_config_set(b'persist_spin_limit', 20000) == 0
+        assert lib.echr_config_set(b'persist_inject_timeout', 200000 + 3) == 0
+        for _ in range(n_calls):
+            try:
+                issue()
+            except _lib.EchrHipError as e:
+                assert 'rc=-62' in str(e), e
+                n_err += 1
+        torch.cuda.synchronize()
+    finally:
+        lib.echr_config_set(b'persist_inject_timeout', 0)
+        lib.echr_config_set(b'persist_spin_limit', 0)
+    try:
+        _lib.check(lib.echr_check_async(), 'drain')
+    except _lib.EchrHipError:
+        n_err += 1
+    assert n_err >= 1
+    assert lib.echr_check_async() == 0
+
+
+def _assert_counts_consistent(o):
+    applied = int(o._applied.item())
+    assert o._issued == applied, (o._issued, applied)
+    if o._flat is not None:
+        assert o._flat['step'] == applied, (o._flat['step'], applied)
+    return applied
+
+
+def test_step_count_after_async_abort_one_call_path():
+    """after an asynchronous -62 the optimiser's step count must equal the number of updates the device APPLIED (Adam's bias
+    correction depends on it), the parameters and moments must be those of the applied updates, and training must continue as if the lost
+    iterations had never been issued -- checked against a twin that runs the same number of clean iterations (eval-mode dropout)."""
+    from echr_amd import _lib
+    lib = _lib.load()
+    opt, params, vid = synth.make_case('c2')
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    args = (tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h)
+    m, o, f = _fused(opt, params, train_mode=False, lr=1e-3, clip=opt.grad_clip)
+    f(*args)
+    torch.cuda.synchronize()
+    assert _assert_counts_consistent(o) == 1
+    snap = (m._echr_arena.flat_p.clone(), o._flat['m'].clone(), o._flat['v'].clone())
+    _abort_some_iterations(lib, lambda: f(*args))
+    assert _assert_counts_consistent(o) == 1                     # every update queued behind the aborted launches was skipped, and un-counted
+    assert torch.equal(m._echr_arena.flat_p, snap[0]) and torch.equal(o._flat['m'], snap[1]) and torch.equal(o._flat['v'], snap[2])
+    f(*args)
+    torch.cuda.synchronize()
+    assert _assert_counts_consistent(o) == 2
+    m2, o2, f2 = _fused(opt, params, train_mode=False, lr=1e-3, clip=opt.grad_clip)
+    f2(*args); f2(*args)
+    torch.cuda.synchronize()
+    dp = float((m._echr_arena.flat_p - m2._echr_arena.flat_p).abs().max())
+    # a step count of 3 instead of 2 would scale the second update by (1 - 0.9^2) / (1 - 0.9^3) = 0.70 in its first-moment correction alone
+    assert dp < 0.02 * 1e-3, dp
+    assert float((o._flat['m'] - o2._flat['m']).abs().max()) <= 1e-4 * float(o2._flat['m'].abs().max())
+
+
+def test_step_count_after_async_abort_two_optimisers():
+    """The joint 'tap_cg' iteration as bench.py --c5 issues it: prepare() + the deferred caption update + the proposal encoder's own
+    ClampAdam.  Both optimisers queue updates behind an aborted launch; each winds ITS count back by ITS skipped updates (the advisor's case:
+    a process-wide counter charged both skips to the caption optimiser and none to the other)."""
+    from echr_amd import _lib
+    from echr_amd import models as EM
+    from echr_amd.misc.utils import TAPModelCriterion, clip_gradient
+    from echr_amd.optim import ClampAdam
+    lib = _lib.load()
+    opt, params, sst_params, vid = synth.make_c5()
+    m, o, f = _fused(opt, params, train_mode=False, lr=1e-4, clip=opt.grad_clip)
+    dev = torch.device('cuda')
+    tapm = EM.setup_tap(opt)
+    tapm.load_state_dict({k: torch.from_numpy(v) for k, v in sst_params.items()})
+    tapm = tapm.to(dev)
+    tapm.eval()
+    tap_ar = tapm.build_arena()
+    tap_o = ClampAdam(tapm.parameters(), lr=1e-4, arena=tap_ar)
+    _, c3d, lda, labels, tgt_h, msk_h = _device_inputs(dict(vid, tap=np.zeros((1, 1), np.float32)))
+    tl, tm, tw = (torch.from_numpy(vid[k]).to(dev) for k in ('tap_labels', 'tap_masks', 'w1'))
+    crit = TAPModelCriterion()
+
+    def iteration():
+        tap_o.zero_grad()
+        try:
+            f.prepare(c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h)
+            tap_feats, props = tapm(c3d)
+            g_tap = torch.zeros_like(tap_feats)
+            tap_loss = 0.01 * crit(props, tm, tl, tw)
+            f(tap_feats.detach(), c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, tap_grad=g_tap, defer_update=True, prepared=True)
+            torch.autograd.backward([tap_loss, tap_feats], [None, g_tap])
+            clip_gradient(tap_o, opt.grad_clip)
+            tap_o.step()
+        except _lib.EchrHipError:
+            f.cancel_prepare()
+            raise
+
+    iteration()
+    f.join()
+    torch.cuda.synchronize()
+    assert _assert_counts_consistent(o) == 1 and _assert_counts_consistent(tap_o) == 1
+    snap = (m._echr_arena.flat_p.clone(), tap_ar.flat_p.clone())
+    _abort_some_iterations(lib, iteration)
+    f.join()
+    torch.cuda.synchronize()
+    a_cg, a_tap = _assert_counts_consistent(o), _assert_counts_consistent(tap_o)
+    # the caption update sits behind the aborted caption recurrence in every injected iteration; the proposal encoder's update of such an
+    # iteration is queued behind it too.  Whatever WAS applied, count and state agree per optimiser:
+    assert a_cg == 1, a_cg
+    assert torch.equal(m._echr_arena.flat_p, snap[0])
+    if a_tap == 1:
+        assert torch.equal(tap_ar.flat_p, snap[1])
+    iteration()
+    f.join()
+    torch.cuda.synchronize()
+    assert _assert_counts_consistent(o) == a_cg + 1 and _assert_counts_consistent(tap_o) == a_tap + 1

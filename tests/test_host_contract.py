@@ -62,7 +62,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.echr_version() == 2
+    assert lib.echr_version() == _lib.ABI_VERSION == 3
 
 
 def test_philox_known_answer_and_mask_rate():
@@ -179,3 +179,16 @@ def test_show_attend_tell_recipe_builds_a_state_dict_compatible_container():
         m(torch.zeros(4, 512), torch.zeros(4, 500), torch.zeros(100), torch.zeros(1, 3, dtype=torch.long), [1], [[0, 2]], mode='train')
     opt2 = synth.default_opt(vocab_size=30, seq_length=5, caption_model='show_attend_tell', CG_num_layers=2, CG_input_feats_type='E')
     assert tuple(echr_amd.CaptionGenerator(opt2).state_dict()['lm_model.core.rnn.weight_ih_l0'].shape) == (2048, 1024)
+
+
+def test_three_stream_core_accepts_and_ignores_input_feats_type():
+    """The reference's ThreeStream_Core computes CG_input_dim from CG_input_feats_type and never uses it (models/OldModel_NEW.py:775-776,
+    :790-799; forward :801-823 reads neither): same state_dict, same attribute values here -- no raise."""
+    import echr_amd
+    base = echr_amd.CaptionGenerator(synth.default_opt(vocab_size=30, seq_length=5))
+    opt = synth.default_opt(vocab_size=30, seq_length=5, CG_input_feats_type='VEC')
+    m = echr_amd.CaptionGenerator(opt)
+    core = m.lm_model.core
+    assert core.CG_input_feats_type == 'VEC'
+    assert core.CG_input_dim == opt.video_context_dim + opt.event_context_dim + opt.clip_context_dim
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in base.state_dict().items()}

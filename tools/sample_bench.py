@@ -27,12 +27,14 @@ for N, T_v in SIZES:
         torch.cuda.synchronize()
         gc.collect()
         gc.disable()          # (a generation-2 collection of the interpreter -- ~40 ms with torch loaded -- otherwise lands in one of the five timed decodes)
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            seq, lp = m(tap, c3d, lda, [], vid['ind'], vid['soi'], mode='eval')
-        torch.cuda.synchronize()
+        try:
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                seq, lp = m(tap, c3d, lda, [], vid['ind'], vid['soi'], mode='eval')
+            torch.cuda.synchronize()
+        finally:
+            gc.enable()
     dt = (time.perf_counter() - t0) / reps
-    gc.enable()
     steps = seq.shape[1] if len(seq) else 0
     print('N=%4d events: %.2f ms per decode, %d generated steps (+1 BOS step), %.0f event-timesteps/s' % (N, dt * 1e3, steps, N * (steps + 1) / dt), flush=True)
