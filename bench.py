@@ -225,7 +225,7 @@ PROF_KINDS = {0: ('gemm_f32_kernel', 'gemm_f32_kernel<*> (all tile/layout instan
                                           'launch of 64 workgroups per direction (recurrent matrices in registers, batch-1 GEMV chain: latency-bound)', 'hbm')}
 
 
-def roofline_pass(wl, args, rank, fence, brief=False):
+def roofline_pass(wl, args, rank, fence, brief=False, variant=''):
     """Instrumented pass over the same iterations: HIP events around every launch of each kernel class, on the stream the kernel is launched
     on.  EVERY rank runs the iterations (they contain the gradient collectives); only rank 0 instruments and reports."""
     from echr_amd import _lib
@@ -247,10 +247,11 @@ def roofline_pass(wl, args, rank, fence, brief=False):
     # HBM traffic per launch cannot be collected inside a timed run (PMC needs rocprofv3 --pmc in separate passes): it is read from the
     # committed summary of the SAME command (tools/pmc_traffic.sh -> profiles/rNN_pmc_traffic*.json); null when absent
     # (one pair of files per workload: `_c5` for config 5; other variants -- overlapping rows, forward only -- carry no counters)
-    sfx = '_c5' if wl.kind == 'c5' else ''
+    # (`variant` = '_native': the native_f32 configuration of the same workload has counter files of its own)
+    sfx = ('_c5' if wl.kind == 'c5' else '') + variant
     traffic, traffic_src, mfma_pmc = {}, None, {}
     if not (args.overlap or wl.kind == 'fwd'):
-        for rnd in ('r05', 'r04', 'r03', 'r02'):
+        for rnd in ('r06', 'r05', 'r04', 'r03', 'r02'):
             name = '%s_pmc_traffic%s.json' % (rnd, sfx)
             try:
                 traffic = json.load(open(os.path.join(ROOT, 'profiles', name)))
@@ -260,7 +261,7 @@ def roofline_pass(wl, args, rank, fence, brief=False):
                 pass
         # MFMA activity (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles of the dispatch) likewise comes from the committed --pmc pass of the
         # same command (tools/pmc_mfma.sh -> profiles/rNN_pmc_mfma*.json)
-        for rnd in ('r05', 'r04', 'r03', 'r02'):
+        for rnd in ('r06', 'r05', 'r04', 'r03', 'r02'):
             try:
                 mfma_pmc = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc_mfma%s.json' % (rnd, sfx))))
                 break
@@ -370,11 +371,14 @@ def gpu_leg(args, rank, world, local_rank):
         for _ in range(2):
             wl.iteration()
         tn, _, _ = timed_regions(wl.iteration, args.steps, min(args.regions, 3), fence, world, dev, use_dist)
-        for k in (b'gemm_h2', b'persist_h2', b'gemm_bf16x3'):
-            lib.echr_config_set(k, 1)
         st = region_stats(tn, args.steps, world)
         native = dict(value=st['value'], unit='timesteps/s', ms_per_step=st['ms_per_step'], regions=st['regions'],
                       note='same workload with gemm_h2=0, gemm_bf16x3=0, persist_h2=0: every product on v_mfma_f32_* (exact fp32 MFMA)')
+        if not args.no_roofline:
+            # the same instrumented pass as the headline's, in THIS configuration: its dominant class is the fp32-MFMA products
+            native['roofline'] = roofline_pass(wl, args, rank, fence, variant='_native')
+        for k in (b'gemm_h2', b'persist_h2', b'gemm_bf16x3'):
+            lib.echr_config_set(k, 1)
         for _ in range(2):
             wl.iteration()
         fence()

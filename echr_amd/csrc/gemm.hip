@@ -954,17 +954,73 @@ int h2_pack(const float* src, int rows, int cols, long s_row, long s_col, void* 
     return h2_pack_multi(&j, 1, st);
 }
 
+constexpr int N128_LD = BK + 4;                         // floats per LDS row of a k-contiguous operand: 16-byte aligned, conflict-free b128 fragment reads (as rec_gemm)
 // ------------------------------------------------------------------------------------------------------
-// Native fp32 product for LARGE NT problems (both operands k-contiguous, 16-byte aligned rows): 128 x 128 tile, 4 waves of 64 x 64
-// (2 x 2 v_mfma_f32_32x32x2_f32 tiles), BK = 32, two LDS stages [row][32 + 4] (one barrier per k block: the next block's global loads are in
-// flight during the MFMAs and land in the other stage), fragment reads as ds_read_b128 -- lane (r, kh) takes 4 consecutive k of its row, element
-// j feeds MFMA j of the chunk, A and B use the same k pairing.  The 64 x 64 tile of gemm_f32_kernel needs 32 KB of operand per 0.26 MFLOP and is
-// bound by the CU's L2 -> LDS ingest (~50 GB/s) at 60-88 TF/s on the large shapes; this tile halves the bytes per flop.  Exact fp32 (k-ordered
-// fma chains per slice), same epilogue as gemm_f32_kernel.  Used when the h2 / bf16x3 paths are off (`native_f32` figure of bench.py).
+// Exact-fp32 128 x 128 tile for EVERY layout (round 6; round 3's NT-only gemm_f32_nt128_kernel generalised and replaced): operands whose
+// contiguous axis is k (NT) or the row / column axis (NN data gradients: B = W [K][N]; TN weight gradients: A = dY^T [K][M], B = X [K][N]),
+// aligned or not, ragged in every direction.  4 waves of 64 x 64 (2 x 2 v_mfma_f32_32x32x2_f32 tiles), BK = 32, two LDS stages, ONE barrier per k block,
+// two workgroups per CU (a wave of the other workgroup issues MFMAs while this one stores its stage and waits at the barrier).
+//   k-contiguous operand (KC):  LDS [128 rows][32 + 4]; a lane's fragment of four consecutive MFMAs is one ds_read_b128
+//   row-contiguous operand:     LDS [32 k][128 + 4];    filled by float4 loads along the rows, fragments are ds_read_b32 of 32 consecutive
+//                               floats per half wave (conflict-free); the k pairing of the MFMAs is the same as for KC, so any mix works
+// The 64 x 64 tile of gemm_f32_kernel stages 32 KB of operand per 0.26 MFLOP and has ONE MFMA per fragment pair; this tile halves the bytes
+// per flop and issues four MFMAs per pair.  Same epilogue (biases, addend, tanh, row remap / scatter, split-K atomics), same grouped form.
 // ------------------------------------------------------------------------------------------------------
-constexpr int N128_LD = BK + 4;                         // floats per LDS row: 16-byte aligned, conflict-free b128 fragment reads (as rec_gemm)
-constexpr int N128_STAGE = 2 * 128 * N128_LD;           // floats per stage (A tile | B tile)
-__global__ __launch_bounds__(256, 2) void gemm_f32_nt128_kernel(GemmParams pin) {
+constexpr int T128_OP = 128 * N128_LD;                  // floats per operand and stage (the row-contiguous form needs 32 * 132 = 4224 <= 4608)
+constexpr int T128_STAGE = 2 * T128_OP;
+constexpr int T128_LDM = 128 + 4;
+template <bool KC>
+__device__ __forceinline__ void t128_fetch(float4 (&r)[4], const float* __restrict__ P, long s_mn, long s_k, int mn0, int k0, int MN, int K,
+                                           int kend, bool vec, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        if (KC) {
+            const int row = f >> 3, k = k0 + 4 * (f & 7);
+            const float* src = P + (long)min(mn0 + row, MN - 1) * s_mn;          // rows beyond MN are clamped: their products land in rows / columns the epilogue does not store
+            float4 v;
+            if (vec) {                                                       // (K % 4 == 0 here: a float4 never straddles kend)
+                v = *reinterpret_cast<const float4*>(src + min(k, K - 4));
+                if (k >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                v.x = k < kend ? src[k] : 0.f;
+                v.y = k + 1 < kend ? src[k + 1] : 0.f;
+                v.z = k + 2 < kend ? src[k + 2] : 0.f;
+                v.w = k + 3 < kend ? src[k + 3] : 0.f;
+            }
+            r[i] = v;
+        } else {
+            const int k = k0 + (f >> 5), mn = mn0 + 4 * (f & 31);
+            const float* src = P + (long)min(k, K - 1) * s_k;
+            float4 v;
+            if (vec) {                                                       // (MN % 4 == 0 here)
+                v = *reinterpret_cast<const float4*>(src + min(mn, MN - 4));
+            } else {
+                v.x = src[min(mn, MN - 1)]; v.y = src[min(mn + 1, MN - 1)]; v.z = src[min(mn + 2, MN - 1)]; v.w = src[min(mn + 3, MN - 1)];
+            }
+            if (k >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            r[i] = v;
+        }
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void t128_stash(const float4 (&r)[4], float* __restrict__ S, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        if (KC) *reinterpret_cast<float4*>(S + (f >> 3) * N128_LD + 4 * (f & 7)) = r[i];
+        else    *reinterpret_cast<float4*>(S + (f >> 5) * T128_LDM + 4 * (f & 31)) = r[i];
+    }
+}
+// fragment of chunk c (k = 8c .. 8c + 7) for the 32-row block at `row`: element j feeds MFMA j, which contracts k = 8c + j (lanes 0-31) and 8c + 4 + j (lanes 32-63)
+template <bool KC>
+__device__ __forceinline__ float4 t128_frag(const float* __restrict__ S, int row, int c, int kh) {
+    if (KC) return *reinterpret_cast<const float4*>(S + row * N128_LD + 8 * c + 4 * kh);
+    const float* q = S + (8 * c + 4 * kh) * T128_LDM + row;
+    return make_float4(q[0], q[T128_LDM], q[2 * T128_LDM], q[3 * T128_LDM]);
+}
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_t128_kernel(GemmParams pin) {
     extern __shared__ __attribute__((aligned(16))) float nsm[];
     int z = blockIdx.z;
     const GemmParams p = select_group(pin, z);
@@ -977,6 +1033,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt128_kernel(GemmParams pin) 
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
     }
     const int m0 = (bid / p.tiles_n) * 128, n0 = (bid % p.tiles_n) * 128;
+    if (m0 >= p.M || n0 >= p.N) return;          // grouped problems narrower than the widest of the launch
     const int b = z / p.split_k, ks = z % p.split_k;
     const float* A = p.A + (long)b * p.bsa;
     const float* B = p.B + (long)b * p.bsb;
@@ -991,29 +1048,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt128_kernel(GemmParams pin) 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // staging: thread -> (row = f >> 3, 4 k at 4 (f & 7)) for f = tid + 256 i, i < 4, per operand; rows beyond M / N are clamped (their
-    // products land in output rows / columns the epilogue does not store), k beyond the slice is zero-filled
     float4 ra[4], rb[4];
+    const long sa_mn = AKC ? p.sam : 1, sa_k = AKC ? 1 : p.sak, sb_mn = BKC ? p.sbn : 1, sb_k = BKC ? 1 : p.sbk;
     auto fetch = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i, row = f >> 3, k = k0 + 4 * (f & 7);
-            const int kk = min(k, p.K - 4);
-            ra[i] = *reinterpret_cast<const float4*>(A + (long)min(m0 + row, p.M - 1) * p.sam + kk);
-            rb[i] = *reinterpret_cast<const float4*>(B + (long)min(n0 + row, p.N - 1) * p.sbn + kk);
-            if (k >= kend) { ra[i] = make_float4(0.f, 0.f, 0.f, 0.f); rb[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        }
+        t128_fetch<AKC>(ra, A, sa_mn, sa_k, m0, kt * BK, p.M, p.K, kend, p.vecA, tid);
+        t128_fetch<BKC>(rb, B, sb_mn, sb_k, n0, kt * BK, p.N, p.K, kend, p.vecB, tid);
     };
     auto stash = [&](int stage) {
-        float* As = nsm + stage * N128_STAGE;
-        float* Bs = As + 128 * N128_LD;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i, row = f >> 3, kq = 4 * (f & 7);
-            *reinterpret_cast<float4*>(As + row * N128_LD + kq) = ra[i];
-            *reinterpret_cast<float4*>(Bs + row * N128_LD + kq) = rb[i];
-        }
+        t128_stash<AKC>(ra, nsm + stage * T128_STAGE, tid);
+        t128_stash<BKC>(rb, nsm + stage * T128_STAGE + T128_OP, tid);
     };
     const int l31 = lane & 31, kh = lane >> 5;
     if (kt0 < kt1) { fetch(kt0); stash(0); }
@@ -1021,17 +1064,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_nt128_kernel(GemmParams pin) 
     for (int kt = kt0; kt < kt1; ++kt) {
         const int st = (kt - kt0) & 1;
         if (kt + 1 < kt1) fetch(kt + 1);                         // in flight during the MFMAs below
-        const float* As = nsm + st * N128_STAGE;
-        const float* Bs = As + 128 * N128_LD;
-        const float* ap = As + (wm + l31) * N128_LD + 4 * kh;
-        const float* bp = Bs + (wn + l31) * N128_LD + 4 * kh;
+        const float* As = nsm + st * T128_STAGE;
+        const float* Bs = As + T128_OP;
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
             float4 a4[2], b4[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a4[i] = *reinterpret_cast<const float4*>(ap + i * 32 * N128_LD + 8 * c);
+            for (int i = 0; i < 2; ++i) a4[i] = t128_frag<AKC>(As, wm + i * 32 + l31, c, kh);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b4[j] = *reinterpret_cast<const float4*>(bp + j * 32 * N128_LD + 8 * c);
+            for (int j = 0; j < 2; ++j) b4[j] = t128_frag<BKC>(Bs, wn + j * 32 + l31, c, kh);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1185,14 +1226,18 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     const int env_split = config().gemm_split;
     if (h2) { BMs = env_h2_bm; BNs = 128; }
     if (use_split) { BMs = 128; BNs = ((long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch >= 96) ? 128 : 64; }
-    // large exact-fp32 NT products: the 128 x 128 double-buffered kernel (gemm_f32_nt128_kernel) once its tiles fill most of the chip's 512
-    // workgroup slots (measured, tools/nt128_bench.py: 4096^3 129 vs 107 TF/s, logits 87 vs 80, d W_logit 108 vs 93; with fewer tiles --
-    // 160 for the token-side gates, 120 for d OUTD -- the 64 x 64 tile's finer grain wins: 38 vs 71, 71 vs 89 TF/s)
-    static const int nt128_on = getenv("ECHR_GEMM_NT128") ? atoi(getenv("ECHR_GEMM_NT128")) : 1;
-    const bool nt128 = nt128_on && !h2 && !use_split && akc && bkc && p.vecA && p.vecB && d.K % 4 == 0 && d.K >= 64 && !tile_code &&
-                       (long)((maxM + 127) / 128) * ((maxN + 127) / 128) * d.batch * ng >= 384;
-    if (nt128) { BMs = 128; BNs = 128; }
-    if (tile_code) {          // tuning override (tools/gemm_bench.py); never set in production
+    // large exact-fp32 products: the 128 x 128 double-buffered tile (gemm_f32_t128_kernel) once its tiles fill most of the chip -- measured stand-alone
+    // against the 64 x 64 tile (tools/t128_bench.py, us): logits 762 x 5001 x 1536 (240 tiles) 133 vs 155, d W_logit 5001 x 1536 x 764 (480) 118 vs
+    // 134, 4096^3 NT 1083 vs 1286; with fewer tiles the 64 x 64 tile's finer grain (7 resident waves per SIMD, 2.5 x more tiles to balance) wins
+    // whatever the k split: d OUTD 762 x 1536 x 5004 (72 tiles) 179 vs 143, gin 1280 x 2048 x 512 (160) 48 vs 38, P_all 8192 x 512 x 500 (256) 58 vs 50
+    static const int t128_on = getenv("ECHR_GEMM_T128") ? atoi(getenv("ECHR_GEMM_T128")) : 1;
+    static const int t128_min_tiles = getenv("ECHR_GEMM_T128_TILES") ? atoi(getenv("ECHR_GEMM_T128_TILES")) : 200;
+    static const int t128_min_k = getenv("ECHR_GEMM_T128_K") ? atoi(getenv("ECHR_GEMM_T128_K")) : 1024;
+    const long tiles128 = (long)((maxM + 127) / 128) * ((maxN + 127) / 128) * d.batch * ng;
+    const bool t128 = !h2 && !use_split && d.K >= 64 && d.rowmap_mod == 0 &&
+                      ((tile_code == 't') || (t128_on && !tile_code && tiles128 >= t128_min_tiles && d.K >= t128_min_k && (akc || bkc)));
+    if (t128) { BMs = 128; BNs = 128; }
+    if (tile_code && tile_code != 't') {          // tuning override (tools/gemm_bench.py); never set in production
         const char e0 = tile_code;
         if (e0 == '1') { BMs = 128; BNs = 128; } else if (e0 == '6') { BMs = 64; BNs = 64; }
         else if (e0 == 'a') { BMs = 128; BNs = 64; } else if (e0 == 'b') { BMs = 64; BNs = 128; }
@@ -1229,8 +1274,8 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
                     if (t < best) { best = t; split = sp; }
                 }
             }
-        } else if (d.act == ECHR_ACT_NONE && wgs < (use_split ? 200 : (nt128 ? 256 : 512)) && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
-            split = (int)min((long)kt_total, max(1L, ((use_split ? 400 : (nt128 ? 512 : 1024)) + wgs - 1) / max(wgs, 1L)));
+        } else if (d.act == ECHR_ACT_NONE && wgs < (use_split ? 200 : (t128 ? 0 : 512)) && (d.beta == 0.f || d.beta == 1.f) && d.rowmap_mod == 0) {
+            split = (int)min((long)kt_total, max(1L, ((use_split ? 400 : 1024) + wgs - 1) / max(wgs, 1L)));
             if (split > 1 && kt_total / split < 4) split = max(1, kt_total / 4);
         }
     }
@@ -1268,7 +1313,7 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     if (config().diag_skip & (h2 ? 32 : 16)) return 0;          // diagnostic (tools/skip_bounds.py): the product is not launched, results are wrong
     static const bool log_on = getenv("ECHR_GEMM_LOG") != nullptr;
     if (log_on) fprintf(stderr, "[gemm] M=%d N=%d K=%d batch=%d %s%s tile=%dx%d split=%d algo=%s wgs=%d\n", d.M, d.N, d.K, d.batch, akc ? "N" : "T",
-                        bkc ? "T" : "N", BMs, BNs, split, h2 ? "h2" : use_split ? "bf16x3" : "f32", (int)(grid.x * grid.z));
+                        bkc ? "T" : "N", BMs, BNs, split, h2 ? "h2" : use_split ? "bf16x3" : t128 ? "f32-t128" : "f32", (int)(grid.x * grid.z));
     // algorithmic work of this launch: 2MNK flops; one read of A and B, one write of C
     ProfScope prof(h2 ? PROF_GEMM_H2 : use_split ? PROF_GEMM_SPLIT : PROF_GEMM, 2.0 * d.M * d.N * d.K * d.batch * ng, 4.0 * ((double)d.M * d.K + (double)d.K * d.N + (double)d.M * d.N) * d.batch * ng, st);
     if (h2) {
@@ -1309,13 +1354,24 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
         else if (ns_sel == 3) hipLaunchKernelGGL((gemm_h2_kernel<128, 32, 3>), grid, dim3(512), 3 * ST128, st, p);
         else hipLaunchKernelGGL((gemm_h2_kernel<128, 32, 2>), grid, dim3(512), 2 * ST128, st, p);
     }
-    else if (nt128) {
-        static bool attr128 = false;
-        if (!attr128) {
-            attr128 = true;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_nt128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * N128_STAGE * (int)sizeof(float));
+    else if (t128) {
+        static bool attr_t = false;
+        if (!attr_t) {
+            attr_t = true;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_t128_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T128_STAGE * (int)sizeof(float));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_t128_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T128_STAGE * (int)sizeof(float));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_t128_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T128_STAGE * (int)sizeof(float));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_t128_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T128_STAGE * (int)sizeof(float));
         }
-        hipLaunchKernelGGL(gemm_f32_nt128_kernel, grid, dim3(256), 2 * N128_STAGE * sizeof(float), st, p);
+        // float4 staging needs the vector axis to be a multiple of 4 for EVERY problem of the launch (a float4 never straddles the edge)
+        bool va = p.vecA && (akc ? d.K % 4 == 0 : true), vb = p.vecB && (bkc ? d.K % 4 == 0 : true);
+        for (int gi = 0; gi < ng; ++gi) { if (!akc) va = va && ds[gi].M % 4 == 0; if (!bkc) vb = vb && ds[gi].N % 4 == 0; }
+        p.vecA = va; p.vecB = vb;
+        const size_t lds = 2 * T128_STAGE * sizeof(float);
+        if (akc && bkc) hipLaunchKernelGGL((gemm_f32_t128_kernel<true, true>), grid, dim3(256), lds, st, p);
+        else if (akc) hipLaunchKernelGGL((gemm_f32_t128_kernel<true, false>), grid, dim3(256), lds, st, p);
+        else if (bkc) hipLaunchKernelGGL((gemm_f32_t128_kernel<false, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gemm_f32_t128_kernel<false, false>), grid, dim3(256), lds, st, p);
     }
     else if (use_split && BNs == 128) hipLaunchKernelGGL(gemm_split_kernel<128>, grid, dim3(512), 0, st, p);
     else if (use_split) hipLaunchKernelGGL(gemm_split_kernel<64>, grid, dim3(256), 0, st, p);

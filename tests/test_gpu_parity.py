@@ -1888,8 +1888,12 @@ def test_single_rank_rccl_one_call_path(tmp_path, mode, algo, via):
     -- RCCL wants a device per rank -- with persistent recurrences launched cooperatively, as bench.py does for N > 1.  A sum over one rank
     is the identity, so the first step's gradients must equal the same worker's over gloo to the run-to-run noise of the split-K atomics
     (1e-5 of the tensor's maximum) and the parameters after two Adam steps to 2 x 2 x lr: this pins the nccl-only branches (asynchronous
-    reduce-scatter + all-gather on the collective stream, Work.wait() stream semantics, hand-over waits) -- a collective that ran before its
-    range was final, or was not waited for, shows as a gradient off by orders of magnitude more."""
+    reduce-scatter + all-gather on the collective stream, Work.wait() stream semantics, hand-over waits) as far as ONE rank can: it proves
+    that they run and leave the values alone.  It cannot show a premature hand-over -- over one rank every collective is the identity, in
+    place -- so WHERE the hand-over points sit is pinned separately (test_handover_points_see_final_ranges: a snapshot queued at each point
+    must equal the final range); that RCCL orders its stream behind the library stream made current in the callback, and that waiting for
+    the last collective waits for all (fused.DataParallelStep._in_order), is torch.distributed's documented contract and stays UNVERIFIED
+    on hardware until a run on two or more GPUs exists."""
     import socket
     import subprocess
     import sys as _sys
@@ -1916,6 +1920,40 @@ def test_single_rank_rccl_one_call_path(tmp_path, mode, algo, via):
             assert np.abs(a[k] - b[k]).max() <= 4.1e-3, k          # (lr = 1e-3: Adam's first steps move a parameter by <= lr, whatever the gradient's size)
             if k not in U.NOISE_ONLY:                              # (a true gradient of exactly zero: the update is a coin flip of +-lr)
                 assert np.mean(np.abs(a[k] - b[k]) > 1e-4) < 0.02, k   # ... and only elements whose gradient is at the noise floor differ at all
+
+
+@pytest.mark.parametrize('case', ['c2', 'c3bench'])
+def test_handover_points_see_final_ranges(case):
+    """echr_train_step_args.handover_cb (the data-parallel path's early collectives): what is queued on the stream the callback receives must
+    see the FINAL gradients of its range.  The 'collective' here is a snapshot copy queued exactly where fused.DataParallelStep queues
+    reduce_sum_ (library stream made current); a hand-over point in front of the last launch that writes the range -- or in front of a
+    split-K slice still adding into it -- would leave the snapshot short of the final values.  train.py:281-283,313-317."""
+    from echr_amd.fused import DataParallelStep, FusedTrainStep
+    from echr_amd.optim import ClampAdam
+    opt, params, vid = synth.make_case(case)
+    dev = torch.device('cuda')
+    m = U.build_gpu_model(opt, params, True)
+    ar = m.build_arena()
+    f = FusedTrainStep(m, ClampAdam(m.parameters(), lr=1e-3, arena=ar))
+    ranges = DataParallelStep(f)._range
+    assert set(ranges) == {0, 1}
+    tap, c3d, lda = (torch.from_numpy(vid[k]).to(dev) for k in ('tap', 'c3d', 'lda'))
+    labels = torch.from_numpy(vid['labels'])
+    for rep in range(3):          # (the first call also builds workspaces; later calls run with every stream warm)
+        snaps, ext = {}, {}
+
+        def cb(which, stream_ptr):
+            lo, hi = ranges[which]
+            st = ext.setdefault(stream_ptr, torch.cuda.ExternalStream(stream_ptr, device=dev))
+            with torch.cuda.stream(st):
+                snaps[which] = ar.flat_g[lo:hi].clone()
+        f(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:].numpy(), vid['masks'][:, 1:], step=False, handover=True, handover_cb=cb)
+        torch.cuda.synchronize()
+        assert set(snaps) == {0, 1}, snaps.keys()
+        for which, (lo, hi) in ranges.items():
+            final = ar.flat_g[lo:hi]
+            assert float(final.abs().max()) > 0
+            assert torch.equal(snaps[which], final), (rep, which, float((snaps[which] - final).abs().max()))
 
 
 @pytest.mark.parametrize('fused', ['auto', 'off'])

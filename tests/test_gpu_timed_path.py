@@ -510,9 +510,12 @@ def test_step_count_after_async_abort_one_call_path():
     m2, o2, f2 = _fused(opt, params, train_mode=False, lr=1e-3, clip=opt.grad_clip)
     f2(*args); f2(*args)
     torch.cuda.synchronize()
-    dp = float((m._echr_arena.flat_p - m2._echr_arena.flat_p).abs().max())
-    # a step count of 3 instead of 2 would scale the second update by (1 - 0.9^2) / (1 - 0.9^3) = 0.70 in its first-moment correction alone
-    assert dp < 0.02 * 1e-3, dp
+    dp = (m._echr_arena.flat_p - m2._echr_arena.flat_p).abs()
+    # Adam's first updates move every parameter by ~lr whatever its gradient's size, so elements whose gradient sits at the noise floor of the
+    # split-K atomics differ by up to 2 lr between ANY two runs; everything else agrees closely.  A step count of 3 instead of 2 would scale
+    # the WHOLE second update by (1 - 0.9^2) / (1 - 0.9^3) * sqrt((1 - 0.999^3) / (1 - 0.999^2)) = 0.86: 0.14 lr on every element
+    assert float(dp.max()) <= 2.01e-3
+    assert float((dp > 0.05e-3).float().mean()) < 0.02, float((dp > 0.05e-3).float().mean())
     assert float((o._flat['m'] - o2._flat['m']).abs().max()) <= 1e-4 * float(o2._flat['m'].abs().max())
 
 

@@ -13,7 +13,8 @@ d = sys.argv[1]
 
 def name(k):
     k = k.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('echr::', '')
-    k = k.split('<')[0] if k.startswith(('gemm_f32_kernel', 'gemm_h2_kernel', 'gemm_h2m16_kernel', 'dec_persist')) else k
+    k = k.split('<')[0] if k.startswith(('gemm_f32_kernel', 'gemm_f32_t128_kernel', 'gemm_h2_kernel', 'gemm_h2m16_kernel', 'dec_persist')) else k
+    k = 'gemm_f32_kernel' if k == 'gemm_f32_t128_kernel' else k
     return 'gemm_h2_kernel' if k == 'gemm_h2m16_kernel' else k          # the two MFMA shapes of the h2 product: one class in bench.py
 
 

@@ -19,6 +19,7 @@ def load(sub, counter):
         k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('echr::', '')
         k = k.split('<')[0] if k.startswith(('gemm_f32_kernel', 'gemm_h2_kernel', 'gemm_h2m16_kernel', 'dec_persist', 'att_post_kernel')) else k
         k = 'gemm_h2_kernel' if k == 'gemm_h2m16_kernel' else k          # the two MFMA shapes of the h2 product: one class in bench.py
+        k = 'gemm_f32_kernel' if k.startswith('gemm_f32_t128_kernel') else k          # the two tile sizes of the exact-fp32 product: one class too
         agg[k] += float(r['Counter_Value'])
         cnt[k] += 1
     return agg, cnt

@@ -4,7 +4,7 @@
 #   <tag>_pmc_traffic.json / <tag>_pmc_mfma.json (separate --pmc passes, commit hash stored inside), <tag>_rocprof_kernel_stats_final.txt
 #   (rocprofv3 --kernel-trace --stats of the bench command), <tag>_bench_final.json (the bench line, written AFTER the PMC files so that
 #   it carries their traffic numbers), the same pair for --c5, and the greedy decoder's kernel stats / timings / stamps.  Results land in gpurun_out/<tag>_profiles/ (copy them into profiles/).
-tag=${1:-r05}; commit=${2:-unknown}
+tag=${1:-r06}; commit=${2:-unknown}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/${tag}_profiles
 rm -rf $out; mkdir -p $out
@@ -20,9 +20,21 @@ python3 tools/pmc_traffic_summary.py gpurun_out/${tag}_pmc_traffic_raw5 $commit 
 bash tools/pmc_mfma.sh ${tag}_pmc_mfma_raw5 --c5 > $out/pmc_mfma_c5.log 2>&1
 python3 tools/pmc_mfma_summary.py gpurun_out/${tag}_pmc_mfma_raw5 $commit > $out/${tag}_pmc_mfma_c5.json && cp $out/${tag}_pmc_mfma_c5.json profiles/
 rm -rf gpurun_out/${tag}_pmc_traffic_raw5 gpurun_out/${tag}_pmc_mfma_raw5
+# ... and on the native_f32 configuration of the headline workload (every product on v_mfma_f32_*: the environment switches are read at load)
+( export ECHR_GEMM_H2=0 ECHR_GEMM_BF16X3=0 ECHR_PERSIST_H2=0
+  bash tools/pmc_traffic.sh ${tag}_pmc_traffic_rawn > $out/pmc_traffic_native.log 2>&1
+  python3 tools/pmc_traffic_summary.py gpurun_out/${tag}_pmc_traffic_rawn $commit > $out/${tag}_pmc_traffic_native.json && cp $out/${tag}_pmc_traffic_native.json profiles/
+  bash tools/pmc_mfma.sh ${tag}_pmc_mfma_rawn > $out/pmc_mfma_native.log 2>&1
+  python3 tools/pmc_mfma_summary.py gpurun_out/${tag}_pmc_mfma_rawn $commit > $out/${tag}_pmc_mfma_native.json && cp $out/${tag}_pmc_mfma_native.json profiles/
+  rm -rf gpurun_out/${tag}_pmc_traffic_rawn gpurun_out/${tag}_pmc_mfma_rawn
+  cd /tmp; export TMPDIR=/tmp
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profn -- python3 $root/bench.py --steps 12 --warmup 3 --regions 1 --no-others --no-cpu --no-roofline --no-native > $out/profn.log 2>&1
+  python3 $root/tools/prof_summary.py $out/profn 15 40 > $out/${tag}_rocprof_kernel_stats_native.txt
+  python3 $root/tools/timeline.py $out/profn > $out/${tag}_timeline_native.txt 2>&1; rm -rf $out/profn )
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $root/bench.py --steps 12 --warmup 3 --regions 1 --no-others --no-cpu --no-roofline --no-native > $out/prof.log 2>&1
 python3 $root/tools/prof_summary.py $out/prof 15 40 > $out/${tag}_rocprof_kernel_stats_final.txt
+python3 $root/tools/timeline.py $out/prof > $out/${tag}_timeline.txt 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -- python3 $root/bench.py --c5 --steps 12 --warmup 3 --regions 1 --no-others --no-cpu --no-roofline --no-native > $out/prof5.log 2>&1
 python3 $root/tools/prof_summary.py $out/prof5 15 40 > $out/${tag}_rocprof_kernel_stats_c5.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profs -- python3 $root/tools/sample_bench.py 64 > $out/profs.log 2>&1
