@@ -98,7 +98,9 @@ class TrainStepArgs(C.Structure):
                 ('flat_p', c_f), ('adam_m', c_f), ('adam_v', c_f), ('adam_step', i32),
                 ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double), ('clip', f32),
                 ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32), ('prepared', i32), ('defer_update', i32),
-                ('handover', i32), ('handover_cb', C.c_void_p), ('handover_user', C.c_void_p), ('adam_applied', c_f)]
+                ('handover', i32), ('handover_cb', C.c_void_p), ('handover_user', C.c_void_p), ('adam_applied', c_f),
+                ('event_parts', i32), ('w_init', c_f), ('b_init', c_f), ('g_w_init', c_f), ('g_b_init', c_f),
+                ('init_use_v', i32), ('init_use_e', i32), ('init_use_c', i32), ('vh_offset', i32), ('tap_rows', i32)]
 
 
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)

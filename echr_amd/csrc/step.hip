@@ -22,7 +22,11 @@ static int async_level() {
     return lv;
 }
 
-struct StepWs { long idx, ech, tsrm_ws, event, logp, dec_ws, dec_ws_bwd, g_event, g_ech, tsrm_ws_bwd, total; };
+struct StepWs { long idx, ech, tsrm_ws, event, logp, dec_ws, dec_ws_bwd, g_event, g_ech, tsrm_ws_bwd, h0, g_h0, init_feats, init_dfeats, g_video, g_video_init, total; };
+
+static inline int init_feats_width(const echr_train_step_args* a) {
+    return (a->init_use_v ? a->dec.Dv : 0) + (a->init_use_e ? a->dec.De : 0) + (a->init_use_c ? a->dec.D : 0);
+}
 
 static StepWs carve_step(const echr_train_step_args* a) {
     StepWs w;
@@ -40,6 +44,13 @@ static StepWs carve_step(const echr_train_step_args* a) {
     w.g_event = take((long)d.N * d.De);
     w.g_ech = take((long)t.N * t.Din);
     w.tsrm_ws_bwd = take(echr_tsrm_ws_bwd_floats(t.N, t.Din, t.Df, t.Do, t.G));
+    // non-recipe options: initial state (h0, its gradient, init_linear's input rows and their gradient), d video
+    w.h0 = w.g_h0 = w.init_feats = w.init_dfeats = -1;
+    if (a->w_init) {
+        const long h3 = 3L * d.H, dt = init_feats_width(a);
+        w.h0 = take((long)d.N * h3); w.g_h0 = take((long)d.N * h3); w.init_feats = take((long)d.N * dt); w.init_dfeats = take((long)d.N * dt);
+    }
+    w.g_video = take(d.Dv); w.g_video_init = take(d.Dv);
     w.total = off;
     return w;
 }
@@ -165,6 +176,9 @@ static echr_dec_args step_dec_args(const echr_train_step_args* a, const StepWs& 
     d.train = a->forward_only ? 0 : 1;
     // the gradient arena is zero-filled by the forward's first fill launch (beside the event encoder), not in front of the reverse recurrence
     d.zero_extra = a->forward_only ? nullptr : a->flat_g; d.zero_extra_count = a->n_flat;
+    // (the initial-state buffer is filled behind the event encoder; its ADDRESS is part of the description from the start, so that the prepare
+    // half and the forward agree on which recurrence kernels run -- the persistent ones start from zero and decline h0)
+    d.h0 = a->w_init ? a->ws + L.h0 : nullptr;
     return d;
 }
 static size_t step_index_count(const echr_train_step_args* a) {
@@ -191,9 +205,15 @@ extern "C" int echr_train_step_prepare(const echr_train_step_args* a, void* stre
 }
 
 extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
-    ECHR_REQUIRE(a && a->ws && a->host_index && a->loss && a->g_loss && a->tap && a->flat_g, "train_step: missing buffers");
+    ECHR_REQUIRE(a && a->ws && a->host_index && a->loss && a->g_loss && a->flat_g && (a->tap || a->event_parts == 1), "train_step: missing buffers");
     ECHR_REQUIRE(!a->prepared || a->overlap_encoder, "train_step: prepared = 1 needs overlap_encoder = 1");
-    ECHR_REQUIRE(a->tsrm.N == a->dec.N && a->tsrm.Do == a->dec.De && a->tsrm.Din == a->dec.D + a->Ht, "train_step: encoder / decoder shapes disagree");
+    const int parts = a->event_parts ? a->event_parts : 3;
+    ECHR_REQUIRE(parts >= 1 && parts <= 3, "train_step: event_parts must be 0..3");
+    const int De_c3d = (parts & 1) ? a->dec.D : 0, De_tap = (parts & 2) ? a->Ht : 0;          // the two halves of the event encoder's input rows
+    ECHR_REQUIRE(a->tsrm.N == a->dec.N && a->tsrm.Do == a->dec.De && a->tsrm.Din == De_c3d + De_tap, "train_step: encoder / decoder shapes disagree");
+    const bool vh = a->g_tap && a->vh_offset >= 0;
+    ECHR_REQUIRE(!vh || (a->vh_offset + a->Ht <= a->dec.Dv && a->tap_rows > 0), "train_step: vh_offset / tap_rows do not describe a span of dec.video");
+    ECHR_REQUIRE(!a->w_init || (a->b_init && (a->forward_only || (a->g_w_init && a->g_b_init)) && init_feats_width(a) > 0), "train_step: init_linear pointers incomplete");
     ECHR_REQUIRE(!a->do_step || (a->flat_p && a->adam_m && a->adam_v && a->adam_step >= 1), "train_step: optimiser state missing");
     hipStream_t st = (hipStream_t)stream;
     RC(join_tail(st));          // (a deferred update of the previous call: it reads the index region this call is about to restage)
@@ -238,15 +258,28 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
             return rc2;
         }
     }
-    int rc = echr_event_pool_gather_fwd(a->dec.c3d, a->tap, ev_start, ev_len, ind, ws + L.ech, N, a->dec.D, a->Ht, stream);       // :106-128
+    int rc = echr_event_pool_gather_fwd(a->dec.c3d, a->tap, ev_start, ev_len, ind, ws + L.ech, N, De_c3d, De_tap, stream);       // :106-128
     if (!rc) rc = echr_tsrm_fwd(&t, &a->drop, stream);                                                                       // :129
     if (rc) { (void)tsrm_position_early(nullptr, nullptr); if (a->overlap_encoder) (void)echr_decoder_fwd_prepare_cancel(stream); return rc; }
     d.event = ws + L.event; d.prepared = a->overlap_encoder ? 1 : 0;
+    // OldModel.init_hidden with CG_init_feats_type (OldModel_NEW.py:72-96): h(-1) = c(-1) = init_linear(cat(selected contexts))
+    echr_init_state_args ia;
+    memset(&ia, 0, sizeof(ia));
+    if (a->w_init) {
+        ia.N = N; ia.Dv = a->dec.Dv; ia.De = a->dec.De; ia.D = a->dec.D; ia.H3 = 3 * a->dec.H;
+        ia.use_v = a->init_use_v; ia.use_e = a->init_use_e; ia.use_c = a->init_use_c; ia.A = a->dec.A;
+        ia.video = a->dec.video; ia.event = ws + L.event; ia.c3d = a->dec.c3d; ia.ev_start = ev_start; ia.ev_len = ev_len;
+        ia.w = a->w_init; ia.b = a->b_init; ia.feats = ws + L.init_feats; ia.h0 = ws + L.h0;
+        rc = echr_init_state_fwd(&ia, stream);
+        if (rc) { if (a->overlap_encoder) (void)echr_decoder_fwd_prepare_cancel(stream); return rc; }
+    }
     echr_dec_grads g = a->dec_g;
     g.g_event = ws + L.g_event; g.g_logp = nullptr;
     g.nll_target = static_cast<const int32_t*>(nll_target); g.nll_target_i64 = nll_i64; g.nll_mask = nll_mask;
     g.active_rows = a->n_active > 0 ? active : nullptr; g.n_active = a->n_active;
     g.g_loss = a->g_loss; g.nll_msum = a->loss + 1;
+    g.g_h0 = a->w_init ? ws + L.g_h0 : nullptr;
+    if (vh) g.g_video = ws + L.g_video;          // (the caller's own g_video, if any, is not filled then: the span is routed into g_tap)
     g.ws_bwd = ws + L.dec_ws_bwd; g.zeroed = 1; g.phase = 0; g.async_tail = async_level();
     if (!a->forward_only && a->overlap_encoder) RC(decoder_bwd_scratch_ahead(&d, &g));          // the backward's scratch fill: behind the prepare chain, not between the recurrences
     // forward (:30) + LanguageModelCriterion (misc/utils.py:66-75).  Training: log-softmax, criterion and its gradient are ONE pass over the
@@ -268,7 +301,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     // backward (train.py:313): criterion gradient in fused form
     g.zero_extra = nullptr; g.zero_extra_count = 0;
     handover_request(false);          // (hand-over points of an earlier call are void from here on)
-    if (a->defer_update && a->g_tap && a->do_step && g.async_tail == 2 && fused_nll && config().gemm_h2 && helpers_available()) {
+    if (a->defer_update && a->g_tap && a->do_step && g.async_tail == 2 && fused_nll && config().gemm_h2 && helpers_available() && !vh && !a->w_init) {
         // Joint 'tap_cg' iteration (train.py:300-313): the proposal encoder's backward -- a 64-workgroup persistent launch that leaves three
         // quarters of the chip idle -- waits for d tap_feats alone.  The chain that leads to it (late fusion, reverse recurrence, d event,
         // the event encoder's attention backward, d ech) runs first and alone on the caller's stream; every parameter gradient and the
@@ -278,7 +311,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
         tg.g_ech = ws + L.g_ech; tg.g_out = ws + L.g_event; tg.ws_bwd = ws + L.tsrm_ws_bwd; tg.zeroed = 1;
         RC(decoder_bwd_parts(&d, &g, &a->drop, stream, 1));
         RC(tsrm_bwd_parts(&t, &tg, &a->drop, stream, 1));
-        RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, a->dec.D, a->Ht, stream));
+        if (De_tap > 0) RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, De_c3d, De_tap, stream));
         RC(decoder_fused_loss(&d, &g, a->loss, st));
         JointPending jp;
         jp.d = d; jp.g = g; jp.t = t; jp.tg = tg; jp.drop = a->drop; jp.args = *a;
@@ -292,17 +325,32 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     handover_close();          // (the events stay valid for echr_handover_wait; later backward passes do not re-record them)
     RC(rc);
     step_mark(2, st);
+    if (a->w_init) {
+        // d h0 -> init_linear's gradients, d event (ADDED to what the decoder left there, ahead of the event encoder's backward), d video
+        echr_init_state_grads ig;
+        ig.g_h0 = ws + L.g_h0; ig.g_w = a->g_w_init; ig.g_b = a->g_b_init; ig.zeroed = 1;
+        ig.g_video = (vh && a->init_use_v) ? ws + L.g_video_init : nullptr;
+        ig.g_event = a->init_use_e ? ws + L.g_event : nullptr;
+        ig.dfeats = ws + L.init_dfeats;
+        RC(echr_init_state_bwd(&ia, &ig, stream));
+    }
     echr_tsrm_grads tg = a->tsrm_g;
     // d ech (the gradient of the event encoder's INPUT rows) only matters when d tap_feats is asked for: c3d features are data
-    tg.g_ech = a->g_tap ? ws + L.g_ech : nullptr; tg.g_out = ws + L.g_event; tg.ws_bwd = ws + L.tsrm_ws_bwd; tg.zeroed = 1;
+    tg.g_ech = (a->g_tap && De_tap > 0) ? ws + L.g_ech : nullptr; tg.g_out = ws + L.g_event; tg.ws_bwd = ws + L.tsrm_ws_bwd; tg.zeroed = 1;
     tsrm_bwd_defer_join(true);          // (this call's workspace outlives the echr_stream_join below)
     rc = echr_tsrm_bwd(&t, &tg, &a->drop, stream);
     tsrm_bwd_defer_join(false);
     RC(rc);
-    if (a->g_tap) RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, a->dec.D, a->Ht, stream));
+    if (a->g_tap && De_tap > 0) RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, De_c3d, De_tap, stream));
     if (fused_nll) RC(decoder_fused_loss(&d, &g, a->loss, st));
     step_mark(3, st);
     RC(echr_stream_join(stream));          // the decoder backward's asynchronous tail: every gradient is final in `stream` order now
+    if (vh) {
+        // scene context 'VH' = tap.mean(0) (CaptionGenerator.py:95-99): d tap[r, :] += d video[vh span] / rows, for the decoder's d video (final
+        // behind the join: it is formed in the LSTM-layer stage on a helper stream) and init_linear's
+        RC(echr_col_mean_bwd(ws + L.g_video + a->vh_offset, a->tap_rows, a->Ht, a->Ht, a->g_tap, stream));
+        if (a->w_init && a->init_use_v) RC(echr_col_mean_bwd(ws + L.g_video_init + a->vh_offset, a->tap_rows, a->Ht, a->Ht, a->g_tap, stream));
+    }
     step_mark(4, st);
     if (a->do_step)                        // clip_gradient + Adam (misc/utils.py:107-111, train.py:315-317)
         RC(echr_clamp_adam_counted(a->flat_p, a->flat_g, a->adam_m, a->adam_v, a->n_flat, a->adam_step, a->lr, a->beta1, a->beta2, a->eps, a->clip, a->adam_applied, stream));

@@ -34,10 +34,8 @@ class FusedTrainStep(object):
         arena = optimizer.arena
         if getattr(model, '_echr_arena', None) is not arena or not arena.params_in_arena():
             raise ValueError('the optimiser\'s arena is not the model\'s (call model.build_arena() after .cuda(), pass it to ClampAdam)')
-        if getattr(model.lm_model, 'CG_init_feats_dim', 0):
-            raise NotImplementedError('the fused step implements the ECHR recipe (zero initial state); CG_init_feats_type runs on the autograd path')
-        if not hasattr(model, 'fusion_model') or model.opt.event_context_type != 'ER3':
-            raise NotImplementedError('the fused step implements the ECHR recipe (event_context_type ER3 + TSRM8); ER1 / ER2 run on the autograd path')
+        if not hasattr(model, 'fusion_model') or model.opt.event_context_type not in ('ER1', 'ER2', 'ER3'):
+            raise NotImplementedError('the fused step needs the TSRM event encoder (event_context_type ER1 / ER2 / ER3)')
         if len(optimizer.param_groups) != 1 or {id(p) for p in optimizer.param_groups[0]['params']} != {id(p) for p in arena.params}:
             raise ValueError('the optimiser must hold exactly the model\'s parameters in one group')
         self.model, self.optim, self.arena = model, optimizer, arena
@@ -93,6 +91,17 @@ class FusedTrainStep(object):
             raise ValueError('LSTM input widths do not match the contexts')
         a.flat_g, a.n_flat, a.flat_p = ar.flat_g.data_ptr(), ar.total, ar.flat_p.data_ptr()
         a.g_loss = self.one.data_ptr()
+        # the reference's non-recipe options (CaptionGenerator.py:106-130 event_context_type; OldModel_NEW.py:72-96 CG_init_feats_type)
+        a.event_parts = {'ER1': 1, 'ER2': 2, 'ER3': 3}[m.opt.event_context_type]
+        if getattr(lm, 'CG_init_feats_dim', 0):
+            t = lm.CG_init_feats_type
+            a.w_init, a.b_init = L.ptr(lm.init_linear.weight), L.ptr(lm.init_linear.bias)
+            a.g_w_init, a.g_b_init = gp(lm.init_linear.weight), gp(lm.init_linear.bias)
+            a.init_use_v, a.init_use_e, a.init_use_c = int('V' in t), int('E' in t), int('C' in t)
+        else:
+            a.w_init = a.b_init = a.g_w_init = a.g_b_init = None
+            a.init_use_v = a.init_use_e = a.init_use_c = 0
+        a.vh_offset, a.tap_rows = -1, 0
         self._keep = (tp, ps)          # (fusion_model.native_params() builds a view of linear_out_1.weight: keep it alive)
         self._epoch_ptrs = (ar.flat_p.data_ptr(), ar.flat_g.data_ptr())
 
@@ -179,7 +188,7 @@ class FusedTrainStep(object):
 
     def _set_tap(self, tap, tap_grad, defer_update, step, forward_only):
         a, d = self.a, self.a.dec
-        if tap.shape[1] + d.D != a.tsrm.Din or tap.shape[0] < self._tv_needed:
+        if (tap.shape[1] if a.event_parts & 2 else 0) + (d.D if a.event_parts & 1 else 0) != a.tsrm.Din or tap.shape[0] < self._tv_needed:
             raise L.EchrHipError('tap_feats %s do not match the model / the event anchors' % (tuple(tap.shape),))
         a.tap, a.Ht = tap.data_ptr(), tap.shape[1]
         self._tap_keep = tap
@@ -190,6 +199,14 @@ class FusedTrainStep(object):
         else:
             a.g_tap = None
         a.defer_update = 1 if (defer_update and tap_grad is not None and step and not forward_only) else 0
+        # 'VH' (scene context = tap_feats.mean(0), CaptionGenerator.py:95-99) with tap_grad: the library spreads d video's span back over g_tap
+        vt = self.model.opt.video_context_type
+        if 'VH' in vt and a.g_tap:
+            o = self.model.opt
+            a.vh_offset = (o.lda_dim if 'VL' in vt else 0) + (o.video_dim if 'VC' in vt else 0)
+            a.tap_rows = tap.shape[0]
+        else:
+            a.vh_offset, a.tap_rows = -1, 0
 
     def _setup(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step, forward_only,
                tap_grad, defer_update):
@@ -225,11 +242,11 @@ class FusedTrainStep(object):
         vt = m.opt.video_context_type
         if vt != 'VL':
             # scene context 'VC' / 'VH' (CaptionGenerator.py:87-104): the mean rows are formed ahead of the call (two small launches); what the
-            # library sees as its `video` vector is the concatenation.  'VH' makes the scene vector a function of tap_feats: its gradient is
-            # not routed back through this path
-            if 'VH' in vt and (tap is None or tap_grad is not None):
-                raise NotImplementedError("video_context_type with 'VH': the one-call path has no d tap_feats through the scene context "
-                                          "(use the autograd path for joint training, or prepare()-free calls with tap_grad=None)")
+            # library sees as its `video` vector is the concatenation.  'VH' makes the scene vector a function of tap_feats: with tap_grad the
+            # library routes d video's span back into it (echr_train_step_args.vh_offset, _set_tap).  prepare() runs before tap_feats exist
+            if 'VH' in vt and tap is None:
+                raise NotImplementedError("video_context_type with 'VH': the scene vector needs tap_feats, prepare() runs ahead of them "
+                                          "(call without prepare())")
             with torch.no_grad():
                 lda = EF._f32c(m.get_video_context(tap, c3d, lda, ind_select_list, soi_select_list))
         self._tv_needed = int(max(soi[:, 1].max(), ind.max() + 1))
@@ -276,7 +293,7 @@ class FusedTrainStep(object):
         # before the second half reads them, so they must stay alive until the next _setup)
         self._keep = (c3d, lda, host, tgt, msk)
         if tap is None:                        # prepare(): tap_feats arrive with the second half
-            a.tap, a.Ht, a.g_tap, a.defer_update = None, a.tsrm.Din - d.D, None, 0
+            a.tap, a.Ht, a.g_tap, a.defer_update = None, m.opt.hidden_dim, None, 0
         else:
             self._set_tap(tap, tap_grad, defer_update, step, forward_only)
         a.host_index = host.ctypes.data

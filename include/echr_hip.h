@@ -29,7 +29,8 @@ extern "C" {
  * argument struct (train, zero_extra, zero_extra_count) and its gradient struct (dlg_ready, active_rows, n_active) under version 1.  A binding that restates
  * the structs MUST also compare its sizeof() of each with echr_abi_sizeof(): the version alone does not describe the layouts. */
 /* 3 (round 6): echr_clamp_adam_counted, echr_train_step_args.adam_applied (a per-optimiser count of APPLIED updates; the process-wide
- * echr_async_skipped_updates now counts echr_clamp_adam launches only). */
+ * echr_async_skipped_updates now counts echr_clamp_adam launches only); echr_train_step_args.event_parts / w_init.. / vh_offset: the
+ * reference's 'ER1' / 'ER2' event contexts, CG_init_feats_type and the 'VH' scene context's gradient on the one-call path. */
 #define ECHR_ABI_VERSION 3
 
 int echr_version(void);
@@ -516,6 +517,19 @@ typedef struct {
                                       callback must not call back into this library and must not block on the device */
     void* handover_user;           /* passed through to handover_cb */
     uint32_t* adam_applied;        /* optional (do_step = 1): the optimiser state's count of applied updates, see echr_clamp_adam_counted */
+    /* ---- the reference's non-recipe options on the one-call path (round 6; all zero / NULL = the ECHR recipe) ---- */
+    int32_t event_parts;           /* event_context_type (CaptionGenerator.py:106-130): 0 or 3 = 'ER3' (pooled C3D rows | anchor state), 1 = 'ER1'
+                                      (pooled rows only: tsrm.Din = dec.D), 2 = 'ER2' (anchor states only: tsrm.Din = Ht) */
+    const float *w_init, *b_init;  /* CG_init_feats_type (OldModel_NEW.py:72-96): init_linear.weight [3H, Dtot] / .bias [3H]; h(-1) = c(-1) =
+                                      init_linear(cat([video | event | clip.mean(1)])) with the parts init_use_* select.  NULL = zero state.
+                                      (The persistent recurrence kernels start from zero: such a call runs the launch-per-phase recurrences.) */
+    float *g_w_init, *g_b_init;    /* their gradient slots in flat_g */
+    int32_t init_use_v, init_use_e, init_use_c;
+    int32_t vh_offset;             /* 'VH' in video_context_type with g_tap: dec.video[vh_offset : vh_offset + Ht] is tap.mean(0) over tap_rows rows
+                                      (formed by the caller, CaptionGenerator.py:95-99); d loss / d video of that span -- from the decoder and from
+                                      init_linear -- is spread back over the rows of g_tap.  With it the call does not defer its update.  -1 or
+                                      g_tap = NULL: the scene vector is data */
+    int32_t tap_rows;              /* rows of tap / g_tap (only read with vh_offset >= 0) */
 } echr_train_step_args;
 int64_t echr_train_step_ws_floats(const echr_train_step_args* a);
 int echr_train_step(const echr_train_step_args* a, void* stream);

@@ -315,7 +315,7 @@ def test_scene_context_variants_vs_oracle(vt):
 
 def test_scene_context_through_the_one_call_path():
     """echr_train_step with a 'VLVC' scene vector (formed ahead of the call): loss and gradients against the oracle; 'VH' with d tap_feats
-    asked for is refused (the one-call path does not route that gradient)."""
+    asked for: the scene vector's gradient comes back in `tap_grad`."""
     opt = synth.default_opt(vocab_size=300, seq_length=7, video_context_type='VLVC')
     params = synth.make_params(opt, 4)
     vid = synth.make_video(12, 40, 9, 301, seed=61)
@@ -327,10 +327,26 @@ def test_scene_context_through_the_one_call_path():
     for k, p in m.named_parameters():
         if rgrads[k] is not None:
             assert U.grad_close(k, p.grad.cpu().numpy(), rgrads[k], TOL_GRAD), (k, U.relerr(p.grad.cpu().numpy(), rgrads[k]))
+    # 'VH' alone, d tap_feats asked for (round 6: routed by the library, echr_train_step_args.vh_offset): against the oracle with tap as a leaf;
+    # prepare() runs before tap_feats exist and still declines
+    from oracle import echr_ref_cpu as O
     opt2 = synth.default_opt(vocab_size=300, seq_length=7, video_context_type='VH')
-    m2, o2, f2 = _fused(opt2, synth.make_params(opt2, 4))
+    p2 = synth.make_params(opt2, 4)
+    m2, o2, f2 = _fused(opt2, p2)
+    g_tap = torch.zeros_like(tap)
+    l2 = float(f2(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False, tap_grad=g_tap))
+    P = {k: torch.from_numpy(v.copy()) for k, v in p2.items()}
+    tap_c = torch.from_numpy(vid['tap'].copy()).requires_grad_(True)
+    lab, msk = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    pred = O.caption_forward(P, tap_c, torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), lab, vid['ind'], vid['soi'], 'train', U.oracle_drop(opt2),
+                             opt2.n_head, video_context_type='VH', event_context_type=opt2.event_context_type, fST_type='fST0', use_posit=opt2.use_posit,
+                             init_feats_type=opt2.CG_init_feats_type)
+    rl = O.lm_criterion(pred, lab[:, 1:], msk[:, 1:])
+    rl.backward()
+    assert abs(l2 - float(rl)) < TOL_LOSS * abs(float(rl))
+    assert U.grad_close('tap_feats', g_tap.cpu().numpy(), tap_c.grad.numpy(), TOL_GRAD), U.relerr(g_tap.cpu().numpy(), tap_c.grad.numpy())
     with pytest.raises(NotImplementedError):
-        f2(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False, tap_grad=torch.zeros_like(tap))
+        f2.prepare(c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h)
 
 
 # ---- the event encoder's other gate / affinity combinators (MA_attention_8_NEW.py:148-157) and use_posit = 0 ------------------------------
@@ -575,3 +591,72 @@ def test_step_count_after_async_abort_two_optimisers():
     f.join()
     torch.cuda.synchronize()
     assert _assert_counts_consistent(o) == a_cg + 1 and _assert_counts_consistent(tap_o) == a_tap + 1
+
+
+# ---- the reference's non-recipe options on the ONE-CALL path (round 6) ------------------------------------------------------------------
+@pytest.mark.parametrize('case', ['er1', 'er2', 'init', 'initc', 'vctx'])
+@pytest.mark.parametrize('train_mode', [True, False])
+def test_one_call_path_option_variants_vs_reference_fixture_and_oracle(case, train_mode):
+    """echr_train_step with event_context_type 'ER1' / 'ER2' (CaptionGenerator.py:106-130), a non-zero initial decoder state
+    (CG_init_feats_type 'VEC' / 'C', OldModel_NEW.py:72-96) and the 'VL' + 'VC' + 'VH' scene context (CaptionGenerator.py:87-104): the loss and
+    the gradient summaries against the REFERENCE's own outputs (case_<name>.npz), every gradient element and d loss / d tap_feats (the joint
+    iteration's `tap_grad`, which for 'VH' also carries the scene vector's gradient) against the oracle."""
+    from oracle import echr_ref_cpu as O
+    opt, params, vid = synth.make_case(case)
+    g = U.gold('case_%s.npz' % case)
+    mode = 'train' if train_mode else 'eval'
+    m, o, f = _fused(opt, params, train_mode)
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    g_tap = torch.zeros_like(tap)
+    loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False, tap_grad=g_tap))
+    torch.cuda.synchronize()
+    assert abs(loss - float(g[mode + '|loss'])) < TOL_LOSS * abs(float(g[mode + '|loss'])), (loss, float(g[mode + '|loss']))
+    grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else None) for k, p in m.named_parameters()}
+    _check_grad_summaries(g, mode, {k: v for k, v in grads.items() if v is not None})
+    # the oracle, with tap_feats as a leaf
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    tap_c = torch.from_numpy(vid['tap'].copy()).requires_grad_(True)
+    lab, msk = torch.from_numpy(vid['labels']), torch.from_numpy(vid['masks'])
+    pred = O.caption_forward(P, tap_c, torch.from_numpy(vid['c3d']), torch.from_numpy(vid['lda']), lab, vid['ind'], vid['soi'], 'train',
+                             U.oracle_drop(opt) if train_mode else None, opt.n_head, video_context_type=opt.video_context_type,
+                             event_context_type=opt.event_context_type, fST_type=getattr(opt, 'fST_type', 'fST0'), use_posit=opt.use_posit,
+                             init_feats_type=opt.CG_init_feats_type)
+    rloss = O.lm_criterion(pred, lab[:, 1:], msk[:, 1:])
+    rloss.backward()
+    assert abs(loss - float(rloss)) < TOL_LOSS * abs(float(rloss))
+    for k, p in P.items():
+        if p.grad is None or not bool(p.grad.any()):
+            assert grads[k] is None or not grads[k].any() or U.grad_close(k, grads[k], np.zeros_like(grads[k]), TOL_GRAD), k
+        else:
+            assert grads[k] is not None and U.grad_close(k, grads[k], p.grad.numpy(), TOL_GRAD), (k, U.relerr(grads[k], p.grad.numpy()))
+    if tap_c.grad is None or not bool(tap_c.grad.any()):          # 'ER1' without 'VH': tap_feats do not reach the loss
+        assert not bool(g_tap.any())
+    else:
+        assert U.grad_close('tap_feats', g_tap.cpu().numpy(), tap_c.grad.numpy(), TOL_GRAD), U.relerr(g_tap.cpu().numpy(), tap_c.grad.numpy())
+
+
+@pytest.mark.parametrize('case', ['init', 'vctx'])
+def test_one_call_path_option_variants_full_step_matches_autograd_path(case):
+    """... and as a full iteration (clamp + Adam inside the call, `defer_update` asked for and declined where the options need the whole call):
+    parameters after one step against the autograd path's on a twin model."""
+    from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+    from echr_amd.optim import ClampAdam
+    opt, params, vid = synth.make_case(case)
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    m, o, f = _fused(opt, params, False, lr=1e-3, clip=opt.grad_clip)
+    f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, tap_grad=torch.zeros_like(tap), defer_update=True)
+    f.join()
+    m2 = U.build_gpu_model(opt, params, False)
+    o2 = ClampAdam(m2.parameters(), lr=1e-3, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon, arena=m2.build_arena())
+    dev = torch.device('cuda')
+    crit = LanguageModelCriterion()
+    o2.zero_grad()
+    crit(m2(tap, c3d, lda, labels, vid['ind'], vid['soi'], mode='train'), labels[:, 1:].to(dev), torch.from_numpy(vid['masks'])[:, 1:].to(dev)).backward()
+    clip_gradient(o2, opt.grad_clip)
+    o2.step()
+    torch.cuda.synchronize()
+    for (k, p), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        d = (p - p2).abs()
+        assert float(d.max()) <= 2.01e-3, k                                   # (Adam's first step: +-lr per element)
+        if k not in U.NOISE_ONLY:
+            assert float((d > 0.05e-3).float().mean()) < 0.02, (k, float((d > 0.05e-3).float().mean()))
