@@ -99,7 +99,17 @@ class Workload(object):
             tap_crit = TAPModelCriterion()
             tl, tm, tw = (torch.from_numpy(vid[k]).to(dev) for k in ('tap_labels', 'tap_masks', 'w1'))
 
+            joint = None
+            if fused is not None and tap_arena is not None and os.environ.get('ECHR_JOINT_STEP', '1') != '0':
+                # round 6: the proposal side without an autograd graph, its backward + update issued from inside the caption call right behind
+                # d tap_feats (fused.JointTrainStep, echr_train_step_args.mid_cb).  ECHR_JOINT_STEP=0: the round-5 form below (A/B)
+                from echr_amd.fused import JointTrainStep
+                joint = JointTrainStep(fused, tap_model, tap_optim, lambda1=0.01, tap_grad_clip=opt.grad_clip,
+                                       early_prepare=os.environ.get('ECHR_EARLY_PREPARE', '1') != '0')
+
             def iteration():      # train.py's joint 'tap_cg' iteration: SST -> caption path -> lambda1*tap_loss + lambda2*cg_loss
+                if joint is not None:
+                    return joint(c3d, lda, labels, ind, soi, tgt_h, msk_h, tm, tl, tw)
                 if fused is not None:
                     # the caption side as ONE library call (forward, criterion, backward, clip, Adam); d loss / d tap_feats comes back in g_tap and
                     # is backpropagated into the proposal encoder together with its own loss (same sums as loss.backward() of the joint loss)
@@ -387,6 +397,22 @@ def gpu_leg(args, rank, world, local_rank):
     if not args.no_roofline:
         roof = roofline_pass(wl, args, rank, fence)
 
+    # several ranks: how much of the gradient exchange the backward tail did NOT hide (HIP events around the caller's stream's wait for the
+    # last collective, fused.DataParallelStep), per step, in a pass of its own behind the timed regions; MAX over ranks like the timing
+    exchange = None
+    if wl.dp is not None and use_dist:
+        wl.dp.measure = True
+        for _ in range(max(3, min(args.steps, 10))):
+            wl.iteration()
+        fence()
+        wl.dp.measure = False
+        exchange = wl.dp.exchange_report()
+        t = torch.tensor([exchange['exposed_ms_median'] or 0.0, exchange['exposed_ms_max'] or 0.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange['exposed_ms_median'], exchange['exposed_ms_max'] = round(float(t[0]), 4), round(float(t[1]), 4)
+        exchange['note'] = ('time the caller\'s stream waits for the collectives behind the backward pass (max over ranks); the early ranges '
+                            'start inside the backward tail, the remainder behind it')
+
     # the other single-GPU configurations of BASELINE.json in the same process: config 2 (forward + criterion only, same one-call entry) and
     # config 5 (SST proposal encoder + caption path, joint iteration) -- each with its own timed regions and its dominant kernel's roofline
     others = None
@@ -407,7 +433,7 @@ def gpu_leg(args, rank, world, local_rank):
             torch.cuda.synchronize()
             del w2
             say('%s: %.3f ms per step' % (name, st['ms_per_step']))
-    return dict(head=head, loss=final_loss, roof=roof, native=native, host_path=wl.host_path(), workload=wl.describe(args),
+    return dict(head=head, loss=final_loss, roof=roof, native=native, exchange=exchange, host_path=wl.host_path(), workload=wl.describe(args),
                 active_rows=wl.active_rows_str() if kind != 'fwd' else None, others=others)
 
 
@@ -637,6 +663,9 @@ def main():
         if res['active_rows']:
             out['config']['active_rows'] = res['active_rows']
         out['config'].update(dp_info)
+        if res.get('exchange'):
+            out['config']['exchange'] = res['exchange']
+            out['config']['exchange_exposed_ms'] = res['exchange']['exposed_ms_median']
         if res['native'] is not None:
             out['native_f32'] = res['native']
             out['config']['native_f32'] = {k: res['native'][k] for k in ('value', 'ms_per_step')}

@@ -88,6 +88,7 @@ class SampleArgs(C.Structure):
 
 
 HANDOVER_FN = C.CFUNCTYPE(None, i32, C.c_void_p, C.c_void_p)          # echr_handover_fn
+MID_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)                    # echr_mid_fn
 
 
 class TrainStepArgs(C.Structure):
@@ -100,7 +101,8 @@ class TrainStepArgs(C.Structure):
                 ('do_step', i32), ('overlap_encoder', i32), ('forward_only', i32), ('n_active', i32), ('host_nll', i32), ('prepared', i32), ('defer_update', i32),
                 ('handover', i32), ('handover_cb', C.c_void_p), ('handover_user', C.c_void_p), ('adam_applied', c_f),
                 ('event_parts', i32), ('w_init', c_f), ('b_init', c_f), ('g_w_init', c_f), ('g_b_init', c_f),
-                ('init_use_v', i32), ('init_use_e', i32), ('init_use_c', i32), ('vh_offset', i32), ('tap_rows', i32)]
+                ('init_use_v', i32), ('init_use_e', i32), ('init_use_c', i32), ('vh_offset', i32), ('tap_rows', i32),
+                ('mid_cb', C.c_void_p), ('mid_user', C.c_void_p)]
 
 
 # every symbol include/echr_hip.h declares: (name, restype, argtypes)

@@ -313,6 +313,9 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
         RC(tsrm_bwd_parts(&t, &tg, &a->drop, stream, 1));
         if (De_tap > 0) RC(echr_event_pool_gather_bwd(ws + L.g_ech, ind, a->g_tap, N, De_c3d, De_tap, stream));
         RC(decoder_fused_loss(&d, &g, a->loss, st));
+        // the caller's hook: the proposal encoder's backward (+ update) goes onto `stream` HERE, right behind g_tap; the helper streams fork
+        // behind it (joint_finish), so the chip-filling tail never shares CUs with that 64-workgroup latency chain
+        if (a->mid_cb) a->mid_cb(stream, a->mid_user);
         JointPending jp;
         jp.d = d; jp.g = g; jp.t = t; jp.tg = tg; jp.drop = a->drop; jp.args = *a;
         // (issuing the helper work only after the caller has queued the proposal encoder's backward -- a second entry point, tried -- is worse:

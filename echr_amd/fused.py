@@ -130,7 +130,7 @@ class FusedTrainStep(object):
             L.check(self.lib.echr_decoder_fwd_prepare_cancel(L.stream_ptr()), 'decoder_fwd_prepare_cancel')
 
     def __call__(self, tap_feats, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, step=True, forward_only=False,
-                 tap_grad=None, defer_update=False, prepared=False, handover=False, handover_cb=None):
+                 tap_grad=None, defer_update=False, prepared=False, handover=False, handover_cb=None, mid_cb=None):
         """One iteration; returns the loss as a 0-d device tensor (no host sync).  `targets` / `masks`: what the reference hands its
         criterion (labels[:, 1:], masks[:, 1:]), host or device tensors.  step=False stops after the backward pass and exposes the
         gradients as `.grad` views of the arena (data-parallel reduce, inspection); the caller then steps the optimiser itself.
@@ -141,7 +141,10 @@ class FusedTrainStep(object):
         streams beside the proposal encoder's backward.  The next call joins by itself; call `join()` before touching the model's parameters
         in any other way (saving, evaluating, the autograd path).  `prepared=True`: `prepare()` ran with the same arguments.
         `handover=True` (with step=False): the backward pass records the data-parallel hand-over points (echr_handover_wait; DataParallelStep);
-        `handover_cb(which, stream_ptr)`: called on the host from inside the call at each point (echr_train_step_args.handover_cb)."""
+        `handover_cb(which, stream_ptr)`: called on the host from inside the call at each point (echr_train_step_args.handover_cb).
+        `mid_cb()` (joint form): called on the host from inside the call right behind the work that leads to tap_grad, before the
+        parameter-gradient tail is forked (echr_train_step_args.mid_cb; JointTrainStep queues the proposal encoder's backward there);
+        `self.mid_called` says whether the library took that form."""
         a, lib = self.a, self.lib
         # a persistent launch of an EARLIER iteration gave up: the optimiser kernels queued behind it skipped their updates (parameters and
         # moments untouched) while the step was already counted -- L.check lets every optimiser wind its count back to the updates its own
@@ -177,11 +180,28 @@ class FusedTrainStep(object):
         else:
             a.handover_cb = None
         a.handover_user = None
+        self.mid_called = False
+        if mid_cb is not None:
+            self._mid_cur = mid_cb
+            if getattr(self, '_mid_keep', None) is None:
+                def _mid(_stream, _user):
+                    self.mid_called = True
+                    try:
+                        self._mid_cur()
+                    except BaseException as e:          # noqa: BLE001  (cannot propagate through ctypes: re-raised behind the call)
+                        self._cb_error = e
+                self._mid_keep = L.MID_FN(_mid)
+                self._mid_ptr = C.cast(self._mid_keep, C.c_void_p)
+            self._cb_error = None
+            a.mid_cb = self._mid_ptr
+        else:
+            a.mid_cb = None
+        a.mid_user = None
         # (set BEFORE the call: if it fails half-way, helper-stream work may already be queued, and the next _setup must join it before it
         # drops the references to this call's inputs)
         self._pending_deferred = bool(a.defer_update)
         L.check(lib.echr_train_step(C.byref(a), L.stream_ptr()), 'train_step')
-        if a.handover_cb and self._cb_error is not None:
+        if (a.handover_cb or a.mid_cb) and getattr(self, '_cb_error', None) is not None:
             e, self._cb_error = self._cb_error, None
             raise e
         return self._finish(slot, st, forward_only)
@@ -359,6 +379,106 @@ class FusedTrainStep(object):
         return slot[0]
 
 
+class JointTrainStep(object):
+    """The joint 'tap_cg' iteration of the reference (train.py:292-329: tap_feats, props = tap_model(c3d); cg forward; loss = lambda1 *
+    tap_loss + lambda2 * cg_loss; backward; clip + step of both optimisers) around `FusedTrainStep`, without an autograd graph:
+
+        [prepare: the caption side's tap-independent half starts]  ->  proposal encoder forward + weighted BCE (echr_sst_fwd,
+        echr_tap_bce_fwd)  ->  echr_train_step(tap_grad, defer_update) -- and from INSIDE that call, right behind the work that leads to
+        d loss / d tap_feats (echr_train_step_args.mid_cb): the proposal encoder's backward (echr_tap_bce_bwd, echr_sst_bwd) and its clamp +
+        Adam; the caption side's parameter-gradient tail and update are forked behind it.
+
+    Why the hook: the proposal encoder's reverse recurrence is one 64-workgroup launch that waits for d tap_feats alone.  Issued from
+    Python after the call returned (torch.autograd.backward walking the SST graph) it started ~0.57 ms after d tap_feats was final, behind
+    the host's issue of the caption tail; issued from the hook it starts at once and the chip-filling tail follows it instead of
+    preceding it.  Same sums as loss.backward() on the joint loss: gradients of both models, both updates."""
+
+    def __init__(self, fused, tap_model, tap_optim, lambda1=1.0, tap_grad_clip=None, early_prepare=True, order=None):
+        ar = getattr(tap_model, '_echr_arena', None)
+        if not isinstance(tap_optim, ClampAdam) or tap_optim.arena is None or tap_optim.arena is not ar or not ar.params_in_arena():
+            raise ValueError('JointTrainStep needs the proposal encoder on a flat arena (tap_model.build_arena()) and a ClampAdam built with it')
+        if len(tap_optim.param_groups) != 1 or {id(p) for p in tap_optim.param_groups[0]['params']} != {id(p) for p in ar.params}:
+            raise ValueError('the proposal encoder\'s optimiser must hold exactly its parameters in one group')
+        self.fused, self.tap_model, self.tap_optim, self.tap_arena = fused, tap_model, tap_optim, ar
+        self.lambda1, self.tap_grad_clip, self.early = float(lambda1), tap_grad_clip, bool(early_prepare)
+        # 'after' (default): the proposal encoder's backward is queued when the caption call has returned -- on the caller's stream right behind
+        # d tap_feats, BESIDE the caption side's tail on the library's streams; 'hook': from inside the call, the tail forked behind it
+        # (serialised: measured 3.19 vs 3.00 ms per config-5 iteration, DESIGN.md section 4h)
+        self.order = order or os.environ.get('ECHR_JOINT_ORDER', 'after')
+        self.lib, self.dev = fused.lib, fused.dev
+        self.lam = torch.full((1,), self.lambda1, device=self.dev, dtype=torch.float32)
+        self._buf_key, self._bufs = None, None
+        self.tap_loss = None
+
+    def _buffers(self, T, D, H, K):
+        key = (T, D, H, K)
+        if self._buf_key != key:
+            self.fused.join()          # (a deferred update may still read the old tap_feats)
+            lib, dev, f32 = self.lib, self.dev, torch.float32
+            self._bufs = dict(ws=torch.empty(lib.echr_sst_ws_floats(T, D, H, K), device=dev, dtype=f32),
+                              wsb=torch.empty(lib.echr_sst_ws_bwd_floats(T, D, H, K), device=dev, dtype=f32),
+                              tap=torch.empty(T, H, device=dev, dtype=f32), scores=torch.empty(T, K, device=dev, dtype=f32),
+                              g_tap=torch.empty(T, H, device=dev, dtype=f32), g_scores=torch.empty(T, K, device=dev, dtype=f32),
+                              loss=torch.zeros(65, device=dev, dtype=f32))
+            self._buf_key = key
+        return self._bufs
+
+    def __call__(self, c3d_feats, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, tap_masks, tap_labels, w1):
+        """Returns (lambda1 * tap_loss + cg_loss) as a 0-d device tensor; `self.tap_loss` / `self.cg_loss` hold the two terms."""
+        lib, f, tm = self.lib, self.fused, self.tap_model
+        c3d = EF._f32c(c3d_feats)
+        ps = [EF._f32c(p) for p in tm.native_params()]
+        T, D = c3d.shape
+        H, K = ps[1].shape[1], ps[8].shape[0]
+        B = self._buffers(T, D, H, K)
+        ar = self.tap_arena
+        for p in ar.params:
+            p.grad = None
+        ar.deferred_clamp = None
+        ar.end_backward_pass()
+        if self.early:          # the caption side's tap-independent half beside the proposal encoder's forward (which leaves 192 CUs idle)
+            f.prepare(c3d, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks)
+        try:
+            # the gradient span of the proposal encoder and d tap_feats: zero-filled HERE, off the chain that later leads to its backward
+            ar.flat_g.zero_()
+            B['g_tap'].zero_()
+            p_drop = float(tm.rnn.dropout)
+            if tm._drop_seed is None:
+                tm._drop_seed = (int(torch.initial_seed()) ^ 0x55AA) & 0xFFFFFFFFFFFFFFFF
+            drop = EF.DropState(tm._drop_seed, tm._drop_calls, p_drop > 0.0)
+            if p_drop > 0.0:
+                tm._drop_calls += 1
+            sa = EF.SSTFunction._args(ps, c3d, p_drop, B['ws'], B['tap'], B['scores'])
+            dc = drop.c()
+            L.check(lib.echr_sst_fwd(C.byref(sa), C.byref(dc), L.stream_ptr()), 'sst_fwd')                           # models/sst_model.py:31-40
+            mk, lb, ww = (EF._f32c(x if x.is_cuda else x.to(self.dev)) for x in (tap_masks, tap_labels, w1))
+            ww = ww.reshape(-1)
+            L.check(lib.echr_tap_bce_fwd_ws(L.ptr(B['scores']), L.ptr(mk), L.ptr(lb), L.ptr(ww), L.ptr(B['loss'][:1]), L.ptr(B['loss'][1:]), T, K,
+                                            L.stream_ptr()), 'tap_bce_fwd')                                            # misc/utils.py:78-99
+
+            def sst_backward():
+                # d (lambda1 * tap_loss) / d scores, then the proposal encoder's backward with d loss / d tap_feats from the caption side
+                L.check(lib.echr_tap_bce_bwd(L.ptr(B['scores']), L.ptr(mk), L.ptr(lb), L.ptr(ww), L.ptr(self.lam), L.ptr(B['g_scores']), T, K,
+                                             L.stream_ptr()), 'tap_bce_bwd')
+                two = lambda i, j: (L.c_f * 2)(ar.flat_g.data_ptr() + 4 * ar.offsets[ar.slot(tm.native_params()[i])],
+                                               ar.flat_g.data_ptr() + 4 * ar.offsets[ar.slot(tm.native_params()[j])])
+                one = lambda i: ar.flat_g.data_ptr() + 4 * ar.offsets[ar.slot(tm.native_params()[i])]
+                sg = L.SstGrads(two(0, 4), two(1, 5), two(2, 6), two(3, 7), one(8), one(9), L.ptr(B['g_tap']), L.ptr(B['g_scores']), L.ptr(B['wsb']), 1)
+                L.check(lib.echr_sst_bwd(C.byref(sa), C.byref(sg), C.byref(dc), L.stream_ptr()), 'sst_bwd')
+                self.tap_optim.step_flat_raw(self.tap_grad_clip)                                                         # train.py:315-317 for tap_optimizer
+
+            cg = f(B['tap'], c3d, lda_feats, lm_labels, ind_select_list, soi_select_list, targets, masks, tap_grad=B['g_tap'], defer_update=True,
+                   prepared=self.early, mid_cb=sst_backward if self.order == 'hook' else None)
+        except BaseException:
+            f.cancel_prepare()
+            raise
+        if not f.mid_called:          # the library ran the plain form (options the deferred form declines): the same work, behind the call
+            sst_backward()
+        self._keep = (c3d, mk, lb, ww, ps)
+        self.tap_loss, self.cg_loss = B['loss'][0], cg
+        return self.lam[0] * B['loss'][0] + cg
+
+
 class DataParallelStep(object):
     """One data-parallel iteration on the one-call path: the SAME host path for every world size.
 
@@ -376,6 +496,17 @@ class DataParallelStep(object):
     follow from the caller's stream, asynchronously too, and the caller's stream waits ONCE, for the last collective queued.  Every collective starts behind the reverse recurrence and is
     waited for before clamp + Adam, i.e. before the next iteration's forward recurrence: no collective kernel is ever resident beside a
     persistent pair.  `overlap=False`: ONE collective on the whole arena behind the call."""
+
+    def exchange_report(self):
+        """After a measured pass (`self.measure = True`, then a device synchronisation): median / max of the time the caller's stream
+        waited for the collectives per step [ms] -- the EXPOSED part of the exchange -- and the ranges of the last step."""
+        ms = sorted(a.elapsed_time(b) for a, b in self.exposed_ms)
+        self.exposed_ms = []
+        names = {0: 'logit layer', 1: 'LSTM layers'}
+        rmap = {(lo, hi): names[w] for w, (lo, hi) in self._range.items()}
+        return dict(exposed_ms_median=round(ms[len(ms) // 2], 4) if ms else None, exposed_ms_max=round(ms[-1], 4) if ms else None, steps=len(ms),
+                    ranges=[dict(name=rmap.get((r['lo'], r['hi']), 'remainder'), bytes=r['bytes'], early=r['early']) for r in self.last_ranges],
+                    n_collectives=self.n_collectives, n_early=self.n_early)
 
     def __init__(self, fused, group=None, overlap=True, algo=None, via=None):
         from . import parallel
@@ -396,6 +527,11 @@ class DataParallelStep(object):
         self.side = [torch.cuda.Stream(device=fused.dev) for _ in self.ranges] if (self.overlap and self.via != 'callback') else []
         self.n_collectives = 0
         self.n_early = 0
+        # opt-in instrumentation (bench.py's exchange pass): HIP events around the caller's stream's wait for the collectives -- what of the
+        # exchange the backward tail did NOT hide -- and the ranges of the last step (name, bytes, early or not)
+        self.measure = False
+        self.exposed_ms = []
+        self.last_ranges = []
 
     def _in_order(self):
         """True when every collective of this step ran on ONE in-order device stream (the nccl = RCCL backend: one stream per process group
@@ -446,12 +582,19 @@ class DataParallelStep(object):
             # runtime) before the next one may even be queued
             works = [w for _, _, w in pend]
             pos = 0
+            rng_log = [dict(lo=lo, hi=hi, bytes=4 * (hi - lo), early=True) for lo, hi, _ in pend]
             for lo, hi, _ in sorted(pend, key=lambda t: t[0]) + [(ar.total, ar.total, None)]:
                 if lo > pos:
                     works.append(P.reduce_sum_(ar.flat_g[pos:lo], self.group, self.algo, async_op=True))
+                    rng_log.append(dict(lo=pos, hi=lo, bytes=4 * (lo - pos), early=False))
                     n += 1
                 pos = max(pos, hi)
             n += len(pend)
+            self.last_ranges = rng_log
+            ev = None
+            if self.measure:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()          # the caller's stream is behind the whole backward pass here: what follows is waiting for the wire
             if works and self._in_order():
                 # one process group = one collective stream, in order: the caller's stream waits for the LAST collective queued (the early ones
                 # were queued first); the other handles only have to stay alive until then
@@ -460,6 +603,9 @@ class DataParallelStep(object):
             else:
                 for w in works:
                     w.wait()          # the caller's stream continues behind the collectives
+            if ev is not None:
+                ev[1].record()
+                self.exposed_ms.append(ev)
         self.n_collectives = n
         o = f.optim
         if f.grad_clip is not None:

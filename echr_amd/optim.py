@@ -84,6 +84,26 @@ class ClampAdam(torch.optim.Optimizer):
         return True
 
     @torch.no_grad()
+    def step_flat_raw(self, clip=None):
+        """clip_gradient + step on the flat arena for callers that filled `arena.flat_g` through raw pointers (fused.JointTrainStep: the
+        proposal encoder's backward writes its gradients there without autograd): the arena's gradient buffer IS this step's gradient, slots of
+        parameters that received none are zero.  One launch, the same kernel and step accounting as step()."""
+        ar = self.arena
+        if ar is None or len(self.param_groups) != 1 or not ar.params_in_arena():
+            raise RuntimeError('step_flat_raw needs the flat arena')
+        if self._flat is None:
+            if any(self.state[p] for p in ar.params):
+                raise RuntimeError('per-tensor optimiser state exists: load it with load_state_dict on an arena optimiser first')
+            self._flat = dict(step=0, m=torch.zeros_like(ar.flat_p), v=torch.zeros_like(ar.flat_p))
+        group, st = self.param_groups[0], self._flat
+        clip = self.grad_clip if clip is None else clip
+        st['step'] += 1
+        self._count_step([st])
+        b1, b2 = group['betas']
+        EF.clamp_adam_(ar.flat_p, ar.flat_g, st['m'], st['v'], st['step'], group['lr'], b1, b2, group['eps'], float('inf') if clip is None else float(clip),
+                       applied=self.applied_counter(ar.flat_p.device))
+
+    @torch.no_grad()
     def clamp_grads_(self, clip, fused_step_follows=False):
         """In-place element-wise clamp of every live gradient (misc/utils.py:107-111).  With the flat arena: one launch."""
         ar = self.arena

@@ -465,6 +465,8 @@ int echr_clamp_adam_counted(float* p, const float* g, float* m, float* v, int64_
  * ---------------------------------------------------------------------------------------------- */
 /* hand-over callback (echr_train_step_args.handover_cb); which = ECHR_HANDOVER_LOGIT or ECHR_HANDOVER_LSTM */
 typedef void (*echr_handover_fn)(int32_t which, void* stream, void* user);
+/* mid-call hook of the joint form (echr_train_step_args.mid_cb) */
+typedef void (*echr_mid_fn)(void* stream, void* user);
 typedef struct {
     echr_tsrm_args tsrm;
     echr_tsrm_grads tsrm_g;
@@ -530,6 +532,14 @@ typedef struct {
                                       init_linear -- is spread back over the rows of g_tap.  With it the call does not defer its update.  -1 or
                                       g_tap = NULL: the scene vector is data */
     int32_t tap_rows;              /* rows of tap / g_tap (only read with vh_offset >= 0) */
+    echr_mid_fn mid_cb;            /* optional, joint form (defer_update = 1): called on the HOST from inside the call once everything that leads to
+                                      g_tap and the loss has been queued on `stream`, BEFORE the parameter-gradient tail and the update are forked onto
+                                      the library's streams.  What the callback queues on `stream` -- the proposal encoder's backward and update,
+                                      train.py:313 -- starts right behind g_tap, and the tail is ordered BEHIND it (the proposal encoder's reverse
+                                      recurrence is a 64-workgroup latency chain that loses more beside chip-filling kernels than the overlap
+                                      gains).  Called exactly once per call that takes the deferred form, never otherwise; may call other entry
+                                      points of this library on `stream`; must not block on the device */
+    void* mid_user;
 } echr_train_step_args;
 int64_t echr_train_step_ws_floats(const echr_train_step_args* a);
 int echr_train_step(const echr_train_step_args* a, void* stream);

@@ -1978,6 +1978,11 @@ def test_bench_two_rank_rehearsal_on_one_gpu(fused):
     assert out['config']['host_path'].startswith('echr_train_step + early range collectives' if fused == 'auto' else 'autograd')
     assert out['config']['dp_overlap'] is True
     assert out['config']['dp_algo'] == 'allreduce' and out['config']['persist_coop'] == 1      # two ranks: one link; a shared device: cooperative launches
+    if fused == 'auto':          # the exchange pass: exposed wait per step, the ranges and which of them started inside the backward tail
+        ex = out['config']['exchange']
+        assert out['config']['exchange_exposed_ms'] == ex['exposed_ms_median'] and ex['exposed_ms_median'] >= 0 and ex['steps'] >= 3
+        assert [r['name'] for r in ex['ranges'] if r['early']] == ['logit layer', 'LSTM layers'] and ex['n_early'] == 2
+        assert sum(r['bytes'] for r in ex['ranges']) == 4 * 21712392 or sum(r['bytes'] for r in ex['ranges']) % 256 == 0
     assert out['n_gpus'] == 2 and out['steps'] == 4 and out['scaling'] == 'weak' and out['config']['global_events'] == 128
     assert out['value'] > 0 and abs(out['value'] - 4 * 20 * 2 / (out['ms_per_step'] * 4 / 1e3)) < 0.01 * out['value']
     assert np.isfinite(out['config']['final_loss'])

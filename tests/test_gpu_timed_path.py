@@ -660,3 +660,54 @@ def test_one_call_path_option_variants_full_step_matches_autograd_path(case):
         assert float(d.max()) <= 2.01e-3, k                                   # (Adam's first step: +-lr per element)
         if k not in U.NOISE_ONLY:
             assert float((d > 0.05e-3).float().mean()) < 0.02, (k, float((d > 0.05e-3).float().mean()))
+
+
+@pytest.mark.parametrize('train_mode', [True, False])
+@pytest.mark.parametrize('early,order', [(True, 'after'), (False, 'after'), (True, 'hook'), (False, 'hook')])
+def test_joint_train_step_vs_reference_fixture(train_mode, early, order):
+    """fused.JointTrainStep (what bench.py --c5 times since round 6): the proposal encoder run through the library directly, its backward
+    and update issued from echr_train_step's mid-call hook right behind d tap_feats, the caption side's tail behind that -- both losses, the
+    caption model's gradients and the SST's gradients against the reference's own joint iteration (case_c5.npz; train.py:292-329)."""
+    from echr_amd import models as EM
+    from echr_amd.fused import JointTrainStep
+    from echr_amd.optim import ClampAdam
+    opt, params, sst_params, vid = synth.make_c5()
+    g = U.gold('case_c5.npz')
+    mode = 'train' if train_mode else 'eval'
+    m, o, f = _fused(opt, params, train_mode, lr=1e-9)
+    dev = torch.device('cuda')
+    tapm = EM.setup_tap(opt)
+    tapm.load_state_dict({k: torch.from_numpy(v) for k, v in sst_params.items()})
+    tapm = tapm.to(dev)
+    tapm.eval()                                          # the fixture's SST runs without inter-layer dropout
+    tap_ar = tapm.build_arena()
+    tap_o = ClampAdam(tapm.parameters(), lr=1e-9, arena=tap_ar)
+    j = JointTrainStep(f, tapm, tap_o, lambda1=opt.lambda1, early_prepare=early, order=order)
+    _, c3d, lda, labels, tgt_h, msk_h = _device_inputs(dict(vid, tap=np.zeros((1, 1), np.float32)))
+    tl, tm, tw = (torch.from_numpy(vid[k]).to(dev) for k in ('tap_labels', 'tap_masks', 'w1'))
+    assert opt.lambda2 == 1.0
+    for rep in range(2):          # (twice: the second call re-uses every buffer and joins the first one's deferred tail)
+        total = j(c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, tm, tl, tw)
+        assert f.mid_called == (order == 'hook')         # the deferred form ran and called the hook
+        f.join()
+        torch.cuda.synchronize()
+        tap_loss, cg_loss = float(j.tap_loss), float(j.cg_loss)
+        assert abs(tap_loss - float(g[mode + '|tap_loss'])) < TOL_LOSS * abs(float(g[mode + '|tap_loss']))
+        assert abs(cg_loss - float(g[mode + '|cg_loss'])) < TOL_LOSS * abs(float(g[mode + '|cg_loss'])), (cg_loss, float(g[mode + '|cg_loss']))
+        assert abs(float(total) - (opt.lambda1 * tap_loss + cg_loss)) < 1e-5 * abs(float(total))
+        assert np.abs(j._bufs['tap'].cpu().numpy()[::8, ::16] - g['tap_feats|slice']).max() < 1e-5
+        ar = m._echr_arena
+        unused = {'lm_model.core.fusion_layer.weight', 'lm_model.core.fusion_layer.bias', 'fusion_model.h2a_layer.weight', 'fusion_model.h2a_layer.bias'}
+        grads = {}
+        for i, (k, p) in enumerate(m.named_parameters()):
+            gv = ar.grad_view(i).detach().cpu().numpy()
+            if k in unused:
+                assert not gv.any(), k
+            else:
+                grads[k] = gv
+        _check_grad_summaries(g, mode, grads)
+        _check_grad_summaries(g, mode, {k: tap_ar.grad_view(i).detach().cpu().numpy() for i, (k, p) in enumerate(tapm.named_parameters())}, tag='|sstgrad|')
+        assert o._flat['step'] == rep + 1 and tap_o._flat['step'] == rep + 1
+        assert int(o._applied.item()) == rep + 1 and int(tap_o._applied.item()) == rep + 1
+        if train_mode:
+            m.set_dropout_state(U.SEED, U.OFFSET)        # the fixture's dropout masks again for the second pass
