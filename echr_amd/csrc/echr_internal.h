@@ -18,7 +18,7 @@ struct ProfScope {
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
 struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; int persist_coop; int persist_inject_timeout; int persist_spin_limit; int sst_persist; int tail_early; int diag_skip; int embed_fused; int persist_sample; int posemb_rows; int gemm_skinny; int posemb_packed; int pair_tables; int persist_sample_force_eos; int persist_sample_max; };
-// diag_skip (diagnostic, tools/skip_bounds.py; results are WRONG while a bit is set): 1 = h2 operand packs, 2 = clamp+Adam kernel, 4 = att_post, 16 = every fp32-path product (gemm_f32 / t128 / bf16x3), 32 = every h2 product,
+// diag_skip (diagnostic, tools/skip_bounds.py; results are WRONG while a bit is set): 1 = h2 operand packs, 2 = clamp+Adam kernel, 4 = att_post, 16 = every fp32-path product (gemm_f32 / t128 / bf16x3), 32 = every h2 product, 64 / 128 = the h2m16 product kernel loads only / computes only (tools/h2_ablate.py),
 // 8 = embedding scatter-add -- the launch is skipped, which bounds what removing / hiding that work could gain
 Config& config();
 

@@ -44,6 +44,7 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int xcd_n, xr_m, xr_n;      // h2 kernel: XCD grid columns, tiles per XCD rectangle (rows, cols)
     int vecA, vecB;
+    int diag;                  // diagnostic ablation of the h2 kernels (config diag_skip bits 64 / 128; results WRONG): 1 = loads only, 2 = compute only
     // grouped launch: up to GEMM_MAXG problems in one grid (blockIdx.z = group * split_k + k-slice); per-group operands.  The problems share
     // K and the epilogue mode; h2 problems may differ in M and N (the grid is sized for the largest, smaller ones retire their spare tiles)
     int ngroup;
@@ -855,9 +856,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2m16_kernel(GemmParams pin) {
     const int scA = PLANES + (wm + 4 * kq) * 4;          // + 16 i * 4: rows 16 i + 4 kq .. + 3
     const int scB = PLANES + H2_SCALES + (wn + l15) * 4;  // + 16 j * 4
 
+    const bool do_load = p.diag != 2, do_math = p.diag != 1;
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
-        if (kt0 + s0 < kt1) stage(s0);
+        if (kt0 + s0 < kt1 && do_load) stage(s0);
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         if (NS > 2 && kt + NS - 2 < kt1) {
@@ -867,7 +869,8 @@ __global__ __launch_bounds__(512, 2) void gemm_h2m16_kernel(GemmParams pin) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < kt1) stage(cur == 0 ? NS - 1 : cur - 1);
+        if (kt + NS - 1 < kt1 && do_load) stage(cur == 0 ? NS - 1 : cur - 1);
+        if (!do_math) { cur = (cur + 1 == NS) ? 0 : cur + 1; continue; }
         const unsigned char* sb = sm + cur * STAGE;
         f16x8 a[4][2], bb[2][2];
 #pragma unroll
@@ -1191,6 +1194,7 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     ECHR_REQUIRE(!d.row_index || (d.beta == 1.f && d.act == ECHR_ACT_NONE && d.rowmap_mod == 0 && d.row_index_max >= 0),
                  "gemm: row_index scatters with atomic adds: needs beta = 1 (accumulate), no activation, no row remap");
     p.ngroup = ng;
+    p.diag = (config().diag_skip >> 6) & 3;
     int maxN = d.N, maxM = d.M;
     for (int i = 0; i < GEMM_MAXG; ++i) {
         const echr_gemm_desc& g = ds[i < ng ? i : 0];
