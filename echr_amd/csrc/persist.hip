@@ -863,6 +863,7 @@ struct PersistK2 {
     DropCfg dh, dout;
     const float* pimg;             // prebuilt weight images of this launch's workspace (nullptr: the workgroups build their own)
     int nt_saved;                  // saved activations (gate activations, cell states) leave with non-temporal stores
+    int xcd_map;                   // 1: role index from (XCD, slot) instead of blockIdx.x, see persist_role_index
 };
 
 
@@ -2179,11 +2180,22 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(const unsigned long 
 // Two concurrent launches on two HIP streams need two hardware queues; a process that owns more streams than the runtime has queues
 // (collective streams of a data-parallel run, user streams) can find both streams on one queue, and the pair then runs back to back.
 // One grid of 256 workgroups has no such dependence.
+// Which role a workgroup of the merged 256-workgroup launches plays.  Plain: blockIdx.x (workgroups 0..95 = half machine 0, 96..191 = half machine
+// 1, 192..255 = the two plain LSTM streams).  Workgroup b of a one-workgroup-per-CU grid runs on XCD b % 8 (round-robin dispatch: speed only, never
+// correctness), so in that order EVERY half machine -- and with it every handed-off operand -- is spread over all eight XCDs, each of whose L2s
+// fetches the operand across the fabric.  xcd_map = 1 (ECHR_PERSIST_XCD): a half machine's 96 workgroups are exactly the 3 x 32 CUs of three
+// XCDs (0-2, 3-5), the 64 LSTM-stream workgroups the two remaining ones: an operand is then fetched into three L2s (LSTM: two) instead of eight.
+__device__ __forceinline__ int persist_role_index(int bx, int xcd_map) {
+    if (!xcd_map) return bx;
+    const int x = bx & 7, s = bx >> 3;
+    return x < 6 ? (x / 3) * HWG + (x % 3) * 32 + s : 2 * HWG + (x - 6) * 32 + s;
+}
 template <bool H2, bool BIG>
 __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(PersistK2 P2, PersistK P1) {
-    if (blockIdx.x < 2 * HWG) dec_persist_att2_body<H2, BIG>(P2, blockIdx.x);
-    else if (H2) dec_persist_lstm_h2_body(P1, blockIdx.x - 2 * HWG);
-    else dec_persist_lstm_body(P1, blockIdx.x - 2 * HWG);
+    const int rb = persist_role_index(blockIdx.x, P2.xcd_map);
+    if (rb < 2 * HWG) dec_persist_att2_body<H2, BIG>(P2, rb);
+    else if (H2) dec_persist_lstm_h2_body(P1, rb - 2 * HWG);
+    else dec_persist_lstm_body(P1, rb - 2 * HWG);
 }
 
 // ==========================================================================================================================
@@ -2239,6 +2251,7 @@ struct PersistB {
     u32 spin_limit, inject;          // bound of every hand-off spin; diagnostic: the wait whose code equals `inject` never completes (0 = none)
     unsigned long long* stamps;
     DropCfg dh, dout;
+    int xcd_map;                   // 1: role index from (XCD, slot) instead of blockIdx.x, see persist_role_index
 };
 #define BSTAMP(role, i) do { if (P.stamps && tid == 0 && t >= 0) P.stamps[((role) * S + t) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
@@ -3094,9 +3107,10 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_bwd2_kernel(PersistB P
 // ---- the reverse pair as one launch (see dec_persist_fwd_kernel) ----
 template <bool BIG>
 __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(PersistB P2, PersistB P1) {
-    if (blockIdx.x < 2 * HWG) dec_persist_att_bwd2_body<BIG>(P2, blockIdx.x);
-    else if (P1.lstm_kgroups) dec_persist_lstm_bwd_kg_body(P1, blockIdx.x - 2 * HWG);
-    else dec_persist_lstm_bwd_body(P1, blockIdx.x - 2 * HWG);
+    const int rb = persist_role_index(blockIdx.x, P2.xcd_map);
+    if (rb < 2 * HWG) dec_persist_att_bwd2_body<BIG>(P2, rb);
+    else if (P1.lstm_kgroups) dec_persist_lstm_bwd_kg_body(P1, rb - 2 * HWG);
+    else dec_persist_lstm_bwd_body(P1, rb - 2 * HWG);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
@@ -3289,6 +3303,8 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     PersistK2 K2;
     K2.pimg = nullptr;
     K2.nt_saved = 0;
+    static const int xcd_map = [] { const char* e = getenv("ECHR_PERSIST_XCD"); return e ? atoi(e) : 0; }();      // A/B switch
+    K2.xcd_map = (xcd_map && 2 * HWG + 2 * NS == 256 && HWG == 96) ? 1 : 0;
     if (split) {
         K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
         K2.w_hh1 = a->w_hh[1]; K2.w_h2a = a->w_h2a; K2.b_h2a = a->b_h2a; K2.w_att = K.w_att; K2.w_alpha = a->w_alpha;
@@ -3471,6 +3487,7 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
     PersistK2 K2;
+    K2.xcd_map = 0;
     K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
     K2.w_hh1 = a->w_hh[1]; K2.w_h2a = a->w_h2a; K2.b_h2a = a->b_h2a; K2.w_att = K.w_att; K2.w_alpha = a->w_alpha;
     K2.PALL = B.PALL; K2.c3d = a->c3d; K2.ev_start = a->ev_start; K2.ev_len = a->ev_len; K2.c3d_bytes = (unsigned)((size_t)a->Tv * a->D * 4);
@@ -3553,6 +3570,8 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
         if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
+    static const int xcd_map = [] { const char* e = getenv("ECHR_PERSIST_XCD"); return e ? atoi(e) : 0; }();      // A/B switch
+    K.xcd_map = (xcd_map && 2 * HWG + 2 * NS == 256 && HWG == 96) ? 1 : 0;
     PersistB K2 = K;
     if (split) {
         K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XDQ = x2 + L2.xdq; K2.XDA = x2 + L2.xda; K2.XDH = x2 + L2.xdh; K2.XDG = x2 + L2.xdg;
