@@ -25,7 +25,7 @@ TOL_GRAD = 1e-5     # relative to the tensor's max-norm
 def test_library_loaded_on_gpu():
     from echr_amd import _lib
     lib = _lib.load()
-    assert lib.echr_version() == 2
+    assert lib.echr_version() == _lib.ABI_VERSION == 3
 
 
 @pytest.mark.parametrize('M,N,K,trans_b', [(64, 64, 32, True), (130, 70, 100, True), (1280, 513, 1536, True),
@@ -1981,7 +1981,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu(fused):
     if fused == 'auto':          # the exchange pass: exposed wait per step, the ranges and which of them started inside the backward tail
         ex = out['config']['exchange']
         assert out['config']['exchange_exposed_ms'] == ex['exposed_ms_median'] and ex['exposed_ms_median'] >= 0 and ex['steps'] >= 3
-        assert [r['name'] for r in ex['ranges'] if r['early']] == ['logit layer', 'LSTM layers'] and ex['n_early'] == 2
+        assert sorted(r['name'] for r in ex['ranges'] if r['early']) == ['LSTM layers', 'logit layer'] and ex['n_early'] == 2
         assert sum(r['bytes'] for r in ex['ranges']) == 4 * 21712392 or sum(r['bytes'] for r in ex['ranges']) % 256 == 0
     assert out['n_gpus'] == 2 and out['steps'] == 4 and out['scaling'] == 'weak' and out['config']['global_events'] == 128
     assert out['value'] > 0 and abs(out['value'] - 4 * 20 * 2 / (out['ms_per_step'] * 4 / 1e3)) < 0.01 * out['value']
