@@ -427,8 +427,7 @@ def test_initial_state_map_vs_oracle_and_module_contract(case):
     assert h_view is c_view and tuple(h_view.shape) == (3, len(vid['soi']), opt.CG_rnn_size)
     assert U.relerr(h_view.cpu().numpy(), oh.numpy()) < 2e-6
     assert U.relerr(h_pad.cpu().numpy(), oh.numpy()) < 2e-6
-    with pytest.raises(NotImplementedError):
-        _fused(opt, params)
+    _fused(opt, params)          # (round 6: the one-call path takes the initial state too -- test_one_call_path_option_variants_* hold it to the fixtures)
 
 
 def test_handover_callback_points_and_error_propagation():

@@ -58,10 +58,11 @@ if __name__ == '__main__':
           ('pall', 'NT', 8192, 512, 500), ('fc1', 'NT', 4096, 512, 512), ('dXT', 'NN', 1280, 512, 2048), ('g_w_hh', 'TN', 2048, 512, 1280),
           ('g_w_att', 'TN', 2048, 500, 1280), ('g_w_h2a', 'TN', 512, 512, 1280), ('g_w_c2a', 'TN', 512, 500, 8192), ('g_w_fc1', 'TN', 512, 512, 4096),
           ('4096^3', 'NT', 4096, 4096, 4096), ('4096^3', 'NN', 4096, 4096, 4096), ('4096^3', 'TN', 4096, 4096, 4096)]
-    print('%-9s %-3s %5s %5s %5s | %16s %16s %16s %16s' % ('name', 'lay', 'M', 'N', 'K', 'auto', '64x64', 't128', 't128 split 1/2/4/8'))
+    SH += [('g_w_ih0', 'TN', 2048, 1024, 764), ('g_w_ih2', 'TN', 2048, 612, 764), ('dXT_c', 'NN', 764, 512, 2048), ('dOUTD_NN', 'NN', 764, 1536, 5001)]
+    print('%-9s %-3s %5s %5s %5s | %16s %16s %16s %16s %16s %16s' % ('name', 'lay', 'M', 'N', 'K', 'auto', '64x64', 't128', '128x64 (a)', '64x128 (b)', 't128 split 1/2/4/8'))
     for sh in SH:
         cells = []
-        for code in (0, ord('6'), ord('t')):
+        for code in (0, ord('6'), ord('t'), ord('a'), ord('b')):
             lib.echr_config_set(b'gemm_tile', code)
             us, tf = run(*sh)
             cells.append('%7.1fus %5.1fTF' % (us, tf))
