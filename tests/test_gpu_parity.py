@@ -177,6 +177,43 @@ def test_cooperative_persistent_launch_equals_plain_launch():
             assert U.grad_close(k, outs[1][2][k], g, TOL_GRAD), k
 
 
+@pytest.mark.parametrize('layout', ['NT', 'NN', 'TN'])
+@pytest.mark.parametrize('M,N,K,pad', [(128, 128, 64, 0), (762, 1536, 1001, 0), (762, 1536, 1001, 3), (130, 257, 100, 0), (513, 502, 1000, 1), (300, 131, 67, 2)])
+def test_gemm_f32_t128_every_layout(layout, M, N, K, pad):
+    """gemm_f32_t128_kernel (the exact-fp32 128 x 128 tile, round 6) forced on every layout the path issues -- NT (nn.Linear forward), NN (data
+    gradients), TN (weight gradients) -- with aligned, ragged and unaligned (pad: leading dimensions that are not multiples of 4, i.e. the
+    scalar staging path) operands, unsplit and with the automatic k split: against float64.  One fp32 fma chain over K terms: ~sqrt(K) ulp."""
+    import ctypes as C
+    from echr_amd import _lib as L
+    lib = L.load()
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N * 3 + K)
+    if layout == 'NT':
+        A = torch.randn(M, K + pad, generator=g).to(dev)[:, :K]; B = torch.randn(N, K + pad, generator=g).to(dev)[:, :K]
+        st = (K + pad, 1, 1, K + pad); ref = A.double() @ B.double().t()
+    elif layout == 'NN':
+        A = torch.randn(M, K + pad, generator=g).to(dev)[:, :K]; B = torch.randn(K, N + pad, generator=g).to(dev)[:, :N]
+        st = (K + pad, 1, N + pad, 1); ref = A.double() @ B.double()
+    else:
+        A = torch.randn(K, M + pad, generator=g).to(dev)[:, :M]; B = torch.randn(K, N + pad, generator=g).to(dev)[:, :N]
+        st = (1, M + pad, N + pad, 1); ref = A.double().t() @ B.double()
+    try:
+        assert lib.echr_config_set(b'gemm_tile', ord('t')) == 0
+        for split in (-1, 1):
+            Cc = torch.full((M, N), 7.0, device=dev)
+            d = L.GemmDesc()
+            d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cc.data_ptr()
+            d.M, d.N, d.K = M, N, K
+            d.sam, d.sak, d.sbk, d.sbn = st
+            d.ldc, d.batch, d.alpha, d.beta, d.split_k, d.algo = N, 1, 1.0, 0.0, split, 0
+            L.check(lib.echr_gemm_f32(C.byref(d), L.stream_ptr()), 'gemm')
+            torch.cuda.synchronize()
+            err = float((Cc.double() - ref).abs().max() / ref.abs().max())
+            assert err < 1e-5, (layout, M, N, K, pad, split, err)
+    finally:
+        lib.echr_config_set(b'gemm_tile', 0)
+
+
 def test_gemm_row_index_scatter():
     """echr_gemm_desc.row_index: row i of A . B^T is ADDED into C[row_index[i]] (duplicates allowed, out-of-range indices clamped)."""
     import ctypes as C
