@@ -137,11 +137,15 @@ __device__ __forceinline__ float xrow_sum4(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// which of a counter's SHARDS lines a workgroup adds to: x + slot of its (XCD x, slot) dispatch position, so that the producers of one edge
+// spread evenly over the lines under BOTH role placements (persist_role_index: with XCD-aware roles a half machine's workgroups share three
+// values of blockIdx.x % 8, which alone would put 32 adders on each of three lines instead of 12 on each of eight)
+__device__ __forceinline__ int publish_shard() { return (int)((blockIdx.x + (blockIdx.x >> 3)) % SHARDS); }
 // every thread of the workgroup, after its write-through stores / atomics
 __device__ __forceinline__ void publish(u32* line) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(line + (blockIdx.x % SHARDS) * SHSTRIDE, 1u, __ATOMIC_RELAXED, ECHR_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(line + publish_shard() * SHSTRIDE, 1u, __ATOMIC_RELAXED, ECHR_AGENT);
 }
 // the same, leaving the wave's KEEP youngest vector-memory operations in flight: loads issued AFTER the stores / atomics being published
 // (the counter retires in issue order, so everything older than those loads has completed)
@@ -149,7 +153,7 @@ template <int KEEP>
 __device__ __forceinline__ void publish_keep(u32* line) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(line + (blockIdx.x % SHARDS) * SHSTRIDE, 1u, __ATOMIC_RELAXED, ECHR_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(line + publish_shard() * SHSTRIDE, 1u, __ATOMIC_RELAXED, ECHR_AGENT);
 }
 
 // every thread; false = the launch is being aborted (timeout somewhere): the caller returns
@@ -3303,7 +3307,7 @@ int persist_fwd(const echr_dec_args* a, const PersistFwdBufs& B, const DropCfg& 
     PersistK2 K2;
     K2.pimg = nullptr;
     K2.nt_saved = 0;
-    static const int xcd_map = [] { const char* e = getenv("ECHR_PERSIST_XCD"); return e ? atoi(e) : 0; }();      // A/B switch
+    static const int xcd_map = [] { const char* e = getenv("ECHR_PERSIST_XCD"); return e ? atoi(e) : 1; }();      // A/B switch (default on, round 6)
     K2.xcd_map = (xcd_map && 2 * HWG + 2 * NS == 256 && HWG == 96) ? 1 : 0;
     if (split) {
         K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
@@ -3570,7 +3574,7 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
         if (!h.stamps && hipMalloc(&h.stamps, 4 * 256 * 16 * 8) != hipSuccess) h.stamps = nullptr;
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
-    static const int xcd_map = [] { const char* e = getenv("ECHR_PERSIST_XCD"); return e ? atoi(e) : 0; }();      // A/B switch
+    static const int xcd_map = [] { const char* e = getenv("ECHR_PERSIST_XCD"); return e ? atoi(e) : 1; }();      // A/B switch (default on, round 6)
     K.xcd_map = (xcd_map && 2 * HWG + 2 * NS == 256 && HWG == 96) ? 1 : 0;
     PersistB K2 = K;
     if (split) {
