@@ -734,6 +734,16 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HR = 32;                        // rows per half machine
 constexpr int HWG = 96, HG1 = 64, HQ = 16;    // workgroups per half: gate, q (the remaining 16 are attention-only)
+// Which role a workgroup of the merged 256-workgroup launches plays.  Plain: blockIdx.x (workgroups 0..95 = half machine 0, 96..191 = half machine
+// 1, 192..255 = the two plain LSTM streams).  Workgroup b of a one-workgroup-per-CU grid runs on XCD b % 8 (round-robin dispatch: speed only, never
+// correctness), so in that order EVERY half machine -- and with it every handed-off operand -- is spread over all eight XCDs, each of whose L2s
+// fetches the operand across the fabric.  xcd_map = 1 (ECHR_PERSIST_XCD): a half machine's 96 workgroups are exactly the 3 x 32 CUs of three
+// XCDs (0-2, 3-5), the 64 LSTM-stream workgroups the two remaining ones: an operand is then fetched into three L2s (LSTM: two) instead of eight.
+__device__ __forceinline__ int persist_role_index(int bx, int xcd_map) {
+    if (!xcd_map) return bx;
+    const int x = bx & 7, s = bx >> 3;
+    return x < 6 ? (x / 3) * HWG + (x % 3) * 32 + s : 2 * HWG + (x - 6) * 32 + s;
+}
 constexpr int LDS_W2 = 128 * 1024, LDS_RED2 = 16 * 1024 + 2048 + 1536;
 constexpr int LDS_BYTES_ATT2 = LDS_W2 + LDS_RED2 + 256;
 
@@ -2085,8 +2095,9 @@ __device__ __forceinline__ void dec_persist_lstm_samp_body(const PersistK& P, co
 
 template <bool BIG>
 __global__ __launch_bounds__(256, 1) void dec_persist_sample_kernel(PersistK2 P2, PersistK P1, PersistS Q) {
-    if (blockIdx.x < 2 * HWG) dec_persist_att2_body<true, BIG, true>(P2, blockIdx.x, &Q);
-    else dec_persist_lstm_samp_body(P1, Q, blockIdx.x - 2 * HWG);
+    const int rb = persist_role_index(blockIdx.x, P2.xcd_map);
+    if (rb < 2 * HWG) dec_persist_att2_body<true, BIG, true>(P2, rb, &Q);
+    else dec_persist_lstm_samp_body(P1, Q, rb - 2 * HWG);
 }
 
 // logit weights -> the image the logits role streams: one power-of-two scale per vocabulary column over the whole contraction (3 x 512)
@@ -2184,16 +2195,6 @@ __global__ __launch_bounds__(256) void sample_finish_kernel(const unsigned long 
 // Two concurrent launches on two HIP streams need two hardware queues; a process that owns more streams than the runtime has queues
 // (collective streams of a data-parallel run, user streams) can find both streams on one queue, and the pair then runs back to back.
 // One grid of 256 workgroups has no such dependence.
-// Which role a workgroup of the merged 256-workgroup launches plays.  Plain: blockIdx.x (workgroups 0..95 = half machine 0, 96..191 = half machine
-// 1, 192..255 = the two plain LSTM streams).  Workgroup b of a one-workgroup-per-CU grid runs on XCD b % 8 (round-robin dispatch: speed only, never
-// correctness), so in that order EVERY half machine -- and with it every handed-off operand -- is spread over all eight XCDs, each of whose L2s
-// fetches the operand across the fabric.  xcd_map = 1 (ECHR_PERSIST_XCD): a half machine's 96 workgroups are exactly the 3 x 32 CUs of three
-// XCDs (0-2, 3-5), the 64 LSTM-stream workgroups the two remaining ones: an operand is then fetched into three L2s (LSTM: two) instead of eight.
-__device__ __forceinline__ int persist_role_index(int bx, int xcd_map) {
-    if (!xcd_map) return bx;
-    const int x = bx & 7, s = bx >> 3;
-    return x < 6 ? (x / 3) * HWG + (x % 3) * 32 + s : 2 * HWG + (x - 6) * 32 + s;
-}
 template <bool H2, bool BIG>
 __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(PersistK2 P2, PersistK P1) {
     const int rb = persist_role_index(blockIdx.x, P2.xcd_map);
@@ -3491,7 +3492,10 @@ static int persist_sample_group(const echr_dec_args* a, const PersistSampleBufs&
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
     PersistK2 K2;
-    K2.xcd_map = 0;
+    // the decoder keeps the plain placement: its 64 LSTM + logits workgroups stream 492 KB of logit weights each per step -- spread over eight
+    // XCDs that is 3.9 MB per 4 MB L2, packed onto two it is 15.7 MB (measured: 256 events 2.93 vs 2.61 ms per decode; 64 and 1000 events equal)
+    static const int xcd_map_s = [] { const char* e = getenv("ECHR_PERSIST_XCD_SAMPLE"); return e ? atoi(e) : 0; }();      // A/B switch
+    K2.xcd_map = (xcd_map_s && 2 * HWG + 2 * NS == 256 && HWG == 96) ? 1 : 0;
     K2.N = K.N; K2.A = K.A; K2.D = K.D; K2.S = K.S; K2.ld_att = K.ld_att;
     K2.w_hh1 = a->w_hh[1]; K2.w_h2a = a->w_h2a; K2.b_h2a = a->b_h2a; K2.w_att = K.w_att; K2.w_alpha = a->w_alpha;
     K2.PALL = B.PALL; K2.c3d = a->c3d; K2.ev_start = a->ev_start; K2.ev_len = a->ev_len; K2.c3d_bytes = (unsigned)((size_t)a->Tv * a->D * 4);
