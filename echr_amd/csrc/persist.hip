@@ -742,7 +742,13 @@ constexpr int HWG = 96, HG1 = 64, HQ = 16;    // workgroups per half: gate, q (t
 __device__ __forceinline__ int persist_role_index(int bx, int xcd_map) {
     if (!xcd_map) return bx;
     const int x = bx & 7, s = bx >> 3;
-    return x < 6 ? (x / 3) * HWG + (x % 3) * 32 + s : 2 * HWG + (x - 6) * 32 + s;
+    if (x >= 6) return 2 * HWG + (x - 6) * 32 + s;
+    const int xr = x % 3;
+    // xcd_map = 2 (reverse pair, ECHR_PERSIST_XCD_BWD): the 64 product workgroups of a half machine (roles 16..79: four k-slices of 16 column tiles)
+    // fill two XCDs, two k-slices each, so that each of them fetches only ITS half of d G1; the 16 gate-gradient and 16 attention-only roles share
+    // the third
+    if (xcd_map == 2) return (x / 3) * HWG + (xr == 0 ? (s < 16 ? s : 64 + s) : (xr == 1 ? 16 + s : 48 + s));
+    return (x / 3) * HWG + xr * 32 + s;
 }
 constexpr int LDS_W2 = 128 * 1024, LDS_RED2 = 16 * 1024 + 2048 + 1536;
 constexpr int LDS_BYTES_ATT2 = LDS_W2 + LDS_RED2 + 256;
@@ -3579,7 +3585,8 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
         if (h.stamps && a->S <= 256) { K.stamps = h.stamps; h.stamps_S = a->S; (void)hipMemsetAsync(h.stamps, 0, 4 * 256 * 16 * 8, st); }
     }
     static const int xcd_map = [] { const char* e = getenv("ECHR_PERSIST_XCD"); return e ? atoi(e) : 1; }();      // A/B switch (default on, round 6)
-    K.xcd_map = (xcd_map && 2 * HWG + 2 * NS == 256 && HWG == 96) ? 1 : 0;
+    static const int xcd_bwd = [] { const char* e = getenv("ECHR_PERSIST_XCD_BWD"); return e ? atoi(e) : 2; }();      // A/B switch: 2 (default) = product roles on two XCDs, 1 = roles in order
+    K.xcd_map = (xcd_map && 2 * HWG + 2 * NS == 256 && HWG == 96) ? (xcd_bwd == 2 ? 2 : 1) : 0;
     PersistB K2 = K;
     if (split) {
         K2.cnt = reinterpret_cast<u32*>(x2 + L2.cnt); K2.XDQ = x2 + L2.xdq; K2.XDA = x2 + L2.xda; K2.XDH = x2 + L2.xdh; K2.XDG = x2 + L2.xdg;
