@@ -201,7 +201,19 @@ extern "C" int echr_train_step_prepare(const echr_train_step_args* a, void* stre
     int32_t* idx = reinterpret_cast<int32_t*>(a->ws + L.idx);
     RC(stage_indices(a->host_index, idx, sizeof(int32_t) * step_index_count(a), st));
     echr_dec_args d = step_dec_args(a, L, idx);
-    return echr_decoder_fwd_prepare(&d, stream);
+    // the event encoder's position branch reads indices and parameters only: it starts here too (ECHR_PREPARE_POS=0: with the second half, behind
+    // the proposal encoder's forward, where its ~70 us chain sits in front of the forward recurrence)
+    static const bool prep_pos = [] { const char* e = getenv("ECHR_PREPARE_POS"); return !(e && e[0] == '0'); }();      // A/B switch
+    if (prep_pos) {
+        echr_tsrm_args t = a->tsrm;
+        t.ech = a->ws + L.ech; t.ev_start = idx; t.ev_len = idx + a->dec.N; t.ws = a->ws + L.tsrm_ws; t.out = a->ws + L.event;
+        t.inference = 0; t.max_len = 0; t.max_span = 0;
+        const int rc = tsrm_position_early(&t, st);
+        if (rc) { (void)tsrm_position_early(nullptr, nullptr); (void)aux_join(st); return rc; }
+    }
+    const int rc = echr_decoder_fwd_prepare(&d, stream);
+    if (rc && prep_pos) { (void)tsrm_position_early(nullptr, nullptr); (void)aux_join(st); }
+    return rc;
 }
 
 extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {

@@ -453,11 +453,16 @@ class JointTrainStep(object):
             L.check(lib.echr_sst_fwd(C.byref(sa), C.byref(dc), L.stream_ptr()), 'sst_fwd')                           # models/sst_model.py:31-40
             mk, lb, ww = (EF._f32c(x if x.is_cuda else x.to(self.dev)) for x in (tap_masks, tap_labels, w1))
             ww = ww.reshape(-1)
-            L.check(lib.echr_tap_bce_fwd_ws(L.ptr(B['scores']), L.ptr(mk), L.ptr(lb), L.ptr(ww), L.ptr(B['loss'][:1]), L.ptr(B['loss'][1:]), T, K,
-                                            L.stream_ptr()), 'tap_bce_fwd')                                            # misc/utils.py:78-99
+
+            def tap_criterion():
+                # (queued BEHIND the caption call: the caption side waits for tap_feats alone, and the two criterion kernels would sit between the
+                # proposal encoder's forward and the event encoder on the one stream that is the iteration's critical chain there)
+                L.check(lib.echr_tap_bce_fwd_ws(L.ptr(B['scores']), L.ptr(mk), L.ptr(lb), L.ptr(ww), L.ptr(B['loss'][:1]), L.ptr(B['loss'][1:]), T, K,
+                                                L.stream_ptr()), 'tap_bce_fwd')                                        # misc/utils.py:78-99
 
             def sst_backward():
                 # d (lambda1 * tap_loss) / d scores, then the proposal encoder's backward with d loss / d tap_feats from the caption side
+                tap_criterion()
                 L.check(lib.echr_tap_bce_bwd(L.ptr(B['scores']), L.ptr(mk), L.ptr(lb), L.ptr(ww), L.ptr(self.lam), L.ptr(B['g_scores']), T, K,
                                              L.stream_ptr()), 'tap_bce_bwd')
                 two = lambda i, j: (L.c_f * 2)(ar.flat_g.data_ptr() + 4 * ar.offsets[ar.slot(tm.native_params()[i])],
