@@ -149,6 +149,8 @@ SYMBOLS = [
     ('echr_sst_ws_floats', i64, [i32, i32, i32, i32]),
     ('echr_sst_ws_bwd_floats', i64, [i32, i32, i32, i32]),
     ('echr_sst_fwd', i32, [C.POINTER(SstArgs), C.POINTER(Dropout), C.c_void_p]),
+    ('echr_sst_fwd_states', i32, [C.POINTER(SstArgs), C.POINTER(Dropout), C.c_void_p]),
+    ('echr_sst_head_fwd', i32, [C.POINTER(SstArgs), C.c_void_p]),
     ('echr_sst_bwd', i32, [C.POINTER(SstArgs), C.POINTER(SstGrads), C.POINTER(Dropout), C.c_void_p]),
     ('echr_tap_bce_fwd', i32, [c_f, c_f, c_f, c_f, c_f, i32, i32, C.c_void_p]),
     ('echr_tap_bce_fwd_ws', i32, [c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, C.c_void_p]),

@@ -694,7 +694,17 @@ static int sst_check(const echr_sst_args* a, const char* who) {
     return 0;
 }
 
-extern "C" int echr_sst_fwd(const echr_sst_args* a, const echr_dropout* drop, void* stream) {
+static int sst_head_impl(const echr_sst_args* a, hipStream_t st);
+static int sst_fwd_impl(const echr_sst_args* a, const echr_dropout* drop, void* stream, bool with_head);
+extern "C" int echr_sst_fwd(const echr_sst_args* a, const echr_dropout* drop, void* stream) { return sst_fwd_impl(a, drop, stream, true); }
+// the two halves of echr_sst_fwd on their own (joint iteration: the caption side waits for tap_feats alone, so its caller queues the proposal
+// head -- scores = sigmoid(tap_feats . W_sc^T + b_sc), models/sst_model.py:38-39 -- BEHIND the caption call instead of in front of it)
+extern "C" int echr_sst_fwd_states(const echr_sst_args* a, const echr_dropout* drop, void* stream) { return sst_fwd_impl(a, drop, stream, false); }
+extern "C" int echr_sst_head_fwd(const echr_sst_args* a, void* stream) {
+    RC(sst_check(a, "sst_head_fwd"));
+    return sst_head_impl(a, (hipStream_t)stream);
+}
+static int sst_fwd_impl(const echr_sst_args* a, const echr_dropout* drop, void* stream, bool with_head) {
     RC(sst_check(a, "sst_fwd"));
     hipStream_t st = (hipStream_t)stream;
     const int T = a->T, D = a->D, H = a->H, K = a->K;
@@ -743,6 +753,10 @@ extern "C" int echr_sst_fwd(const echr_sst_args* a, const echr_dropout* drop, vo
         }
         RC(check_launch("sst_wave_fwd"));
     }
+    return with_head ? sst_head_impl(a, st) : 0;
+}
+static int sst_head_impl(const echr_sst_args* a, hipStream_t st) {
+    const int T = a->T, H = a->H, K = a->K;
     // proposal head
     echr_gemm_desc d = desc_nt(a->tap_feats, H, a->w_sc, H, a->scores, K, T, K, H);
     d.bias = a->b_sc; d.split_k = -1;

@@ -450,13 +450,14 @@ class JointTrainStep(object):
                 tm._drop_calls += 1
             sa = EF.SSTFunction._args(ps, c3d, p_drop, B['ws'], B['tap'], B['scores'])
             dc = drop.c()
-            L.check(lib.echr_sst_fwd(C.byref(sa), C.byref(dc), L.stream_ptr()), 'sst_fwd')                           # models/sst_model.py:31-40
+            L.check(lib.echr_sst_fwd_states(C.byref(sa), C.byref(dc), L.stream_ptr()), 'sst_fwd_states')           # models/sst_model.py:31-37
             mk, lb, ww = (EF._f32c(x if x.is_cuda else x.to(self.dev)) for x in (tap_masks, tap_labels, w1))
             ww = ww.reshape(-1)
 
             def tap_criterion():
-                # (queued BEHIND the caption call: the caption side waits for tap_feats alone, and the two criterion kernels would sit between the
+                # (the proposal head and its criterion, queued BEHIND the caption call: the caption side waits for tap_feats alone, and these kernels would sit between the
                 # proposal encoder's forward and the event encoder on the one stream that is the iteration's critical chain there)
+                L.check(lib.echr_sst_head_fwd(C.byref(sa), L.stream_ptr()), 'sst_head_fwd')                          # models/sst_model.py:38-39
                 L.check(lib.echr_tap_bce_fwd_ws(L.ptr(B['scores']), L.ptr(mk), L.ptr(lb), L.ptr(ww), L.ptr(B['loss'][:1]), L.ptr(B['loss'][1:]), T, K,
                                                 L.stream_ptr()), 'tap_bce_fwd')                                        # misc/utils.py:78-99
 

@@ -412,6 +412,11 @@ typedef struct {
 int64_t echr_sst_ws_floats(int32_t T, int32_t D, int32_t H, int32_t K);
 int64_t echr_sst_ws_bwd_floats(int32_t T, int32_t D, int32_t H, int32_t K);
 int echr_sst_fwd(const echr_sst_args* a, const echr_dropout* drop, void* stream);
+/* The two halves of echr_sst_fwd as calls of their own (round 6): the recurrence -> tap_feats (models/sst_model.py:33-37), and the proposal head
+ * scores = sigmoid(tap_feats . W_sc^T + b_sc) (:38-39) from the tap_feats of the same arguments.  The joint iteration's caption side waits for
+ * tap_feats alone; its caller queues the head behind the caption call (fused.JointTrainStep). */
+int echr_sst_fwd_states(const echr_sst_args* a, const echr_dropout* drop, void* stream);
+int echr_sst_head_fwd(const echr_sst_args* a, void* stream);
 int echr_sst_bwd(const echr_sst_args* a, const echr_sst_grads* g, const echr_dropout* drop, void* stream);
 /* weighted BCE of the proposal head: loss (device scalar) and its gradient w.r.t. the scores */
 int echr_tap_bce_fwd(const float* scores, const float* masks, const float* labels, const float* w1, float* loss, int32_t T,
