@@ -1139,6 +1139,12 @@ extern "C" int echr_streams_init(void) {
 }
 namespace echr {
 hipStream_t aux2_stream() { return prep().ok ? prep().s : nullptr; }
+hipStream_t tail_stream_raw() { return tail().ok ? tail().s : nullptr; }
+int prep_stream_wait(hipEvent_t ev) {
+    Prep& pr = prep();
+    if (!pr.ok || hipStreamWaitEvent(pr.s, ev, 0) != hipSuccess) { set_error("prepare stream wait failed"); return -5; }
+    return 0;
+}
 hipStream_t helpers_merge_to_tail() {          // the tail stream continues behind everything queued on the prepare stream; returns the tail stream
     Tail& t = tail();
     Prep& pr = prep();

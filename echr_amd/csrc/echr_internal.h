@@ -86,6 +86,8 @@ int aux2_join(hipStream_t to);
 int aux2_publish();                             // instead of a join: echr_stream_join / the next library call wait for what the prepare stream carries now
 bool helpers_available();
 hipStream_t aux2_stream();
+hipStream_t tail_stream_raw();                   // the tail stream itself, NOT ordered behind anything (echr_train_step's stage-ahead form); nullptr when unavailable
+int prep_stream_wait(hipEvent_t ev);             // the prepare stream waits for `ev` (in addition to whatever its next fork waits for)
 hipStream_t helpers_merge_to_tail();
 int tail_publish();
 int tsrm_position_early(const echr_tsrm_args* a, hipStream_t from);          // echr_train_step: start the event encoder's position branch right behind the index staging

@@ -108,6 +108,25 @@ static int stage_indices(const int32_t* host, int32_t* dev, size_t bytes, hipStr
     return 0;
 }
 
+// Stage-ahead (round 6): the LAST kernel of an iteration is clamp + Adam, ~95 us of pure HBM streaming on the caller's stream, and the FIRST
+// things of the next one -- the index staging copy and, behind it, the event encoder's position embedding (indices only: the head of the chain
+// the forward recurrence waits for) -- need nothing that update writes.  When a call ends with its own update it records an event in front of
+// it (every reader of the workspace and the index region is complete there: the helper streams were just joined) and one behind it; the next
+// call on the same stream, workspace and arena stages its indices on the TAIL stream behind the first event, so that copy and embedding run
+// beside the update, and orders everything else behind the second.
+struct StageAhead { hipEvent_t pre = nullptr, post = nullptr; bool valid = false; hipStream_t st = nullptr; const void* ws = nullptr; const void* flat_g = nullptr; bool init = false, ok = false; };
+static StageAhead& stage_ahead() {
+    static StageAhead s;
+    if (!s.init) {
+        s.init = true;
+        const char* e = getenv("ECHR_STAGE_AHEAD");          // A/B switch
+        s.ok = !(e && e[0] == '0') && hipEventCreateWithFlags(&s.pre, echr::sync_event_flags()) == hipSuccess &&
+               hipEventCreateWithFlags(&s.post, echr::sync_event_flags()) == hipSuccess;
+        if (!s.ok) (void)hipGetLastError();
+    }
+    return s;
+}
+
 }  // namespace echr
 
 using namespace echr;
@@ -236,7 +255,18 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     step_mark(0, st);
     int32_t* idx = reinterpret_cast<int32_t*>(ws + L.idx);
     ECHR_REQUIRE(a->n_active >= 0 && a->n_active <= S * N, "train_step: n_active out of range");
-    if (!a->prepared) RC(stage_indices(a->host_index, idx, sizeof(int32_t) * step_index_count(a), st));
+    StageAhead& sa = stage_ahead();
+    const bool ahead = sa.ok && sa.valid && !a->prepared && a->overlap_encoder && sa.st == st && sa.ws == a->ws && sa.flat_g == a->flat_g &&
+                       helpers_available() && tail_stream_raw();
+    sa.valid = false;          // (consumed, or void: whatever this call does, the recorded pair no longer brackets the stream's last work)
+    if (ahead) {
+        hipStream_t ts = tail_stream_raw();
+        if (hipStreamWaitEvent(ts, sa.pre, 0) != hipSuccess) { set_error("train_step: stream wait failed"); return -5; }
+        RC(stage_indices(a->host_index, idx, sizeof(int32_t) * step_index_count(a), ts));
+        // the caller's stream: behind the staging copy (its own position is already behind the update); the prepare stream: behind the update too
+        if (hipStreamWaitEvent(st, ring_last(), 0) != hipSuccess) { set_error("train_step: stream wait failed"); return -5; }
+        RC(prep_stream_wait(sa.post));
+    } else if (!a->prepared) RC(stage_indices(a->host_index, idx, sizeof(int32_t) * step_index_count(a), st));
     const int32_t *ev_start = idx, *ev_len = idx + N, *ind = idx + 2 * N, *active = idx + (3 + S) * N;          // (tokens at idx + 3 N: step_dec_args)
     const void* nll_target = a->nll_target;
     const float* nll_mask = a->nll_mask;
@@ -256,7 +286,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     // CaptionGenerator.forward (:23-30): the decoder's event-independent part starts on the library's second stream and overlaps the event encoder
     if (a->overlap_encoder && !a->prepared) {
         static const bool one_event = [] { const char* e = getenv("ECHR_ONE_FORK_EVENT"); return !(e && e[0] == '0'); }();      // A/B switch
-        if (one_event) fork_event(ring_last());          // both forks hang off the staging copy's event: no further record in front of event pooling
+        if (one_event || ahead) fork_event(ring_last());          // both forks hang off the staging copy's event: no further record in front of event pooling
         int rc2 = tsrm_position_early(&t, st);
         if (!rc2) rc2 = echr_decoder_fwd_prepare(&d, stream);
         fork_event(nullptr);
@@ -367,8 +397,12 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
         if (a->w_init && a->init_use_v) RC(echr_col_mean_bwd(ws + L.g_video_init + a->vh_offset, a->tap_rows, a->Ht, a->Ht, a->g_tap, stream));
     }
     step_mark(4, st);
-    if (a->do_step)                        // clip_gradient + Adam (misc/utils.py:107-111, train.py:315-317)
+    if (a->do_step) {                      // clip_gradient + Adam (misc/utils.py:107-111, train.py:315-317)
+        const bool rec = sa.ok && hipEventRecord(sa.pre, st) == hipSuccess;          // (stage-ahead: every helper stream was joined just above)
         RC(echr_clamp_adam_counted(a->flat_p, a->flat_g, a->adam_m, a->adam_v, a->n_flat, a->adam_step, a->lr, a->beta1, a->beta2, a->eps, a->clip, a->adam_applied, stream));
+        if (rec && hipEventRecord(sa.post, st) == hipSuccess) { sa.valid = true; sa.st = st; sa.ws = a->ws; sa.flat_g = a->flat_g; }
+        else (void)hipGetLastError();
+    }
     step_mark(5, st);
     step_timing_end();
     return 0;
