@@ -710,3 +710,42 @@ def test_joint_train_step_vs_reference_fixture(train_mode, early, order):
         assert int(o._applied.item()) == rep + 1 and int(tap_o._applied.item()) == rep + 1
         if train_mode:
             m.set_dropout_state(U.SEED, U.OFFSET)        # the fixture's dropout masks again for the second pass
+
+
+def test_stage_ahead_with_changing_videos():
+    """Stage-ahead (csrc/step.hip): from the second consecutive `echr_train_step` on, the index staging copy and the event encoder's position
+    embedding of iteration i + 1 run on the tail stream BESIDE iteration i's clamp + Adam.  Six back-to-back iterations (no host sync in
+    between) on videos whose event lists, lengths and captions all differ -- a staging copy or an embedding that ran too early or too late
+    would feed one iteration the other's indices -- against the autograd path stepping a twin model through the same videos
+    (train.py:281-317 six times)."""
+    from echr_amd.misc.utils import LanguageModelCriterion, clip_gradient
+    from echr_amd.optim import ClampAdam
+    opt, params, _ = synth.make_case('c2')
+    dev = torch.device('cuda')
+    vids = [synth.make_video(64 if i % 2 == 0 else 48, 128 if i % 3 else 96, 21, opt.CG_vocab_size + 1, seed=900 + i, T_v=160 + 16 * i,
+                             video_dim=opt.video_dim, hidden_dim=opt.hidden_dim, lda_dim=opt.lda_dim) for i in range(6)]
+    m, o, f = _fused(opt, params, False, lr=1e-3, clip=opt.grad_clip)
+    m2 = U.build_gpu_model(opt, params, False)
+    o2 = ClampAdam(m2.parameters(), lr=1e-3, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon, arena=m2.build_arena())
+    crit = LanguageModelCriterion()
+    dev_in = [tuple(torch.from_numpy(v[k]).to(dev) for k in ('tap', 'c3d', 'lda')) for v in vids]
+    losses = []
+    for v, (tap, c3d, lda) in zip(vids, dev_in):          # back to back: the host runs ahead, every iteration but the first stages ahead
+        labels = torch.from_numpy(v['labels'])
+        losses.append(f(tap, c3d, lda, labels, v['ind'], v['soi'], labels[:, 1:].numpy(), v['masks'][:, 1:]))
+    torch.cuda.synchronize()
+    ref = []
+    for v, (tap, c3d, lda) in zip(vids, dev_in):
+        labels = torch.from_numpy(v['labels'])
+        o2.zero_grad()
+        loss = crit(m2(tap, c3d, lda, labels, v['ind'], v['soi'], mode='train'), labels[:, 1:].to(dev), torch.from_numpy(v['masks'])[:, 1:].to(dev))
+        loss.backward()
+        clip_gradient(o2, opt.grad_clip)
+        o2.step()
+        ref.append(float(loss))
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(losses, ref)):
+        # (the trajectories separate slowly: Adam moves noise-floor gradient elements by +-lr on both sides independently)
+        assert abs(float(a) - b) < 2e-3 * abs(b), (i, float(a), b)
+    assert abs(float(losses[0]) - ref[0]) < 1e-5 * abs(ref[0])
+    assert o._flat['step'] == 6 and int(o._applied.item()) == 6
