@@ -547,6 +547,11 @@ typedef struct {
     void* mid_user;
 } echr_train_step_args;
 int64_t echr_train_step_ws_floats(const echr_train_step_args* a);
+/* Back-to-back calls (round 6, "stage-ahead"): a call that ends with its own update (do_step = 1, not deferred) lets the NEXT call on the same
+ * stream, workspace and arena start its index staging copy and the event encoder's position embedding -- which read host_index and nothing the
+ * update writes -- on a library stream beside that update; everything else of the next call is ordered behind the update as before.  Nothing
+ * changes for the caller: host_index is copied inside the call, and `ws` must stay untouched between calls as it always had to (it holds the
+ * saved activations until the call's last kernel).  ECHR_STAGE_AHEAD=0 in the environment switches it off. */
 int echr_train_step(const echr_train_step_args* a, void* stream);
 /* Optional first half for the joint 'tap_cg' iteration (train.py:300-313): stages the index vectors and starts everything of the call that
  * does not read tap_feats (the decoder's event-independent part, the gradient-arena fill) on the library's prepare stream, so that it runs
