@@ -8,7 +8,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libechr_hip.so')
+# (ECHR_LIB: a differently built library for same-box A/B runs of kernel variants -- tools/ab_lib.sh; never set in production)
+LIB_PATH = os.environ.get('ECHR_LIB') or os.path.join(_HERE, 'lib', 'libechr_hip.so')
 
 c_f = C.c_void_p   # device pointers travel as void*
 i32, i64, f32 = C.c_int32, C.c_int64, C.c_float

@@ -178,7 +178,7 @@ __device__ __forceinline__ bool wait_total(const PK& P, u32* line, u32 target, i
                     break;
                 }
             }
-            __builtin_amdgcn_s_sleep(1);
+            // (no s_sleep between polls: a poll is one dependent round trip, and 64 idle clocks per poll measured +8 us per iteration -- round 6)
         }
         if (lane == 0) *flag = ok ? 1 : 0;
     }
@@ -211,7 +211,7 @@ __device__ __forceinline__ bool wait_total2(const PK& P, u32* line_a, u32 target
                     break;
                 }
             }
-            __builtin_amdgcn_s_sleep(1);
+            // (no s_sleep between polls: a poll is one dependent round trip, and 64 idle clocks per poll measured +8 us per iteration -- round 6)
         }
         if (lane == 0) *flag = ok ? 1 : 0;
     }
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_att_kernel(PersistK P) {
                                     break;
                                 }
                             }
-                            __builtin_amdgcn_s_sleep(1);
+                            // (no s_sleep between polls: a poll is one dependent round trip, and 64 idle clocks per poll measured +8 us per iteration -- round 6)
                         }
                         mm = wave_max(mm);
                         if (lane == 0) sx[32] = mm;
@@ -1287,7 +1287,7 @@ __device__ __forceinline__ void dec_persist_att2_body(const PersistK2& P, const 
                                     break;
                                 }
                             }
-                            __builtin_amdgcn_s_sleep(1);
+                            // (no s_sleep between polls: a poll is one dependent round trip, and 64 idle clocks per poll measured +8 us per iteration -- round 6)
                         }
                         mm = wave_max(mm);
                         if (lane == 0) sx[32] = mm;
