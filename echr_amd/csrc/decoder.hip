@@ -898,7 +898,11 @@ static RecJob mkjob(const float* A, long lda, int K, const float* B, long ldb, i
 // P_all = c3d . W_c^T + b_c over the Tv video rows; EVB0 = event . W_ih0[:,E:]^T + b_ih0 + b_hh0;
 // VIDB = W_ih2[:,E:] . video + b_ih2 + b_hh2   (all time-invariant)
 // parts: 1 = everything that does not read the event context (operand packs, P_all, VIDB), 2 = EVB0
-static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t st, bool teacher_forced, bool evb0_zeroed = false, int parts = 3) {
+// wl: optional second stream for the two packed images of W_logit (the logits product's operand and, in training, its transpose for d OUTD): they
+// are 60 % of the pack launch's bytes and nothing in front of the forward recurrence reads them, so echr_decoder_fwd_prepare puts them on the
+// CALLER's stream -- whose later logits / d OUTD products follow in stream order -- instead of at the head of the prepare chain
+static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t st, bool teacher_forced, bool evb0_zeroed = false, int parts = 3,
+                             hipStream_t wl = nullptr) {
     const int H = a->H, E = a->E;
     echr_gemm_desc d;
     if (!(parts & 1)) goto event_part;
@@ -908,6 +912,11 @@ static int precompute_static(const echr_dec_args* a, const DecWs& w, hipStream_t
                            pack_rows(a->w_logit, 3 * H, a->V1, 3 * H, w.PK_WL), pack_rows(a->w_ih[0], E + a->De, 4 * H, E, w.PK_WIH[0]),
                            pack_rows(a->w_ih[1], E + a->D, 4 * H, E, w.PK_WIH[1]), pack_rows(a->w_ih[2], E + a->Dv, 4 * H, E, w.PK_WIH[2]),
                            pack_cols(a->w_logit, 3 * H, 3 * H, a->V1, w.PK_WLT)};      // (train: the backward's operand, off its critical path)
+        if (wl && teacher_forced) {
+            H2PackJob pa[5] = {pj[0], pj[1], pj[3], pj[4], pj[5]}, pb[2] = {pj[2], pj[6]};
+            RC(h2_pack_multi(pb, a->train ? 2 : 1, wl));
+            RC(h2_pack_multi(pa, 5, st));
+        } else
         RC(h2_pack_multi(pj, teacher_forced ? (a->train ? 7 : 6) : 2, st));      // the sampler's per-step products stay on the skinny-GEMM path
         d = desc_h2(w.PK_C3D, w.PK_WC, w.PALL, a->Ha, a->Tv, a->Ha, a->D);
     } else {
@@ -1239,7 +1248,11 @@ extern "C" int echr_decoder_fwd_prepare(const echr_dec_args* a, void* stream) {
     // (the event-context gate product of echr_decoder_fwd accumulates into EVB0, zeroed by this fill: it waits for THIS event, not for the
     // whole chain below -- the product then runs beside the chain's last GEMM instead of behind it)
     if (hipEventRecord(pr.fill0, st) != hipSuccess) { set_error("decoder_fwd_prepare: event record failed"); return -5; }
-    RC(precompute_static(a, w, st, true, true, 1));
+    // ECHR_WL_ON_CALLER (default 1): the two W_logit images leave the head of the prepare chain for the caller's stream, which has slack in front of
+    // the recurrence since the position branch starts beside the previous update (stage-ahead): 1.450-1.454 vs 1.445-1.465 ms and 1.414-1.422 vs
+    // 1.418-1.431 on two boxes (-5 us in the mean); issued later still, where the forward joins the prepare chain: 1.454-1.463, not kept
+    static const bool wl_caller = [] { const char* e = getenv("ECHR_WL_ON_CALLER"); return !(e && e[0] == '0'); }();      // A/B switch
+    RC(precompute_static(a, w, st, true, true, 1, wl_caller ? sm : nullptr));
     RC(embed_gather(a->embed, a->tokens, w.XT, a->S * a->N, a->E, a->V1, st));
     RC(input_gates(a, w, w.XT, 0, a->S, st, true));
     if (hipEventRecord(pr.done, st) != hipSuccess) { set_error("decoder_fwd_prepare: event record failed"); return -5; }
