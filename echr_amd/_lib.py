@@ -144,6 +144,7 @@ SYMBOLS = [
     ('echr_decoder_step', i32, [C.POINTER(DecArgs), c_f, c_f, c_f, c_f, C.POINTER(Dropout), C.c_void_p]),
     ('echr_tsrm_attn_fwd', i32, [C.POINTER(TsrmArgs), c_f, c_f, C.POINTER(Dropout), C.c_void_p]),
     ('echr_persist_read_stamps', i32, [C.c_void_p, i32]),
+    ('echr_persist_role_index', i32, [i32, i32]),
     ('echr_prof_enable', i32, [i32]),
     ('echr_prof_event_overhead', i32, [C.POINTER(C.c_double), C.POINTER(i64)]),
     ('echr_prof_read', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]),

@@ -739,7 +739,7 @@ constexpr int HWG = 96, HG1 = 64, HQ = 16;    // workgroups per half: gate, q (t
 // correctness), so in that order EVERY half machine -- and with it every handed-off operand -- is spread over all eight XCDs, each of whose L2s
 // fetches the operand across the fabric.  xcd_map = 1 (ECHR_PERSIST_XCD): a half machine's 96 workgroups are exactly the 3 x 32 CUs of three
 // XCDs (0-2, 3-5), the 64 LSTM-stream workgroups the two remaining ones: an operand is then fetched into three L2s (LSTM: two) instead of eight.
-__device__ __forceinline__ int persist_role_index(int bx, int xcd_map) {
+__host__ __device__ __forceinline__ int persist_role_index(int bx, int xcd_map) {
     if (!xcd_map) return bx;
     const int x = bx & 7, s = bx >> 3;
     if (x >= 6) return 2 * HWG + (x - 6) * 32 + s;
@@ -3625,3 +3625,9 @@ int persist_bwd(const echr_dec_args* a, const PersistBwdBufs& B, const DropCfg& 
 }
 
 }  // namespace echr
+
+// diagnostic / test hook (tests/test_host_contract.py): the role a workgroup of the merged 256-workgroup recurrence launches plays under placement
+// `mode` (0 = blockIdx order, 1 = a half machine per three XCDs, 2 = the reverse pair's form with the product roles on two XCDs).  A placement
+// that is not a bijection of 0..255 would leave roles unfilled and every wait for them timing out.
+extern "C" int32_t echr_persist_role_index(int32_t block, int32_t mode) { return echr::persist_role_index(block, mode); }
+

@@ -630,6 +630,9 @@ int echr_config_set(const char* key, int32_t value);
 /* Diagnostic (never on the product path): with echr_config_set("persist_stamps", 1) the persistent recurrence kernels record
  * s_memrealtime stamps (100 MHz) at their phase boundaries for one workgroup per role; this copies the last launch's stamps
  * ([4 roles][S][16] uint64) to host memory (synchronises the device) and returns S (0 = nothing recorded). */
+/* diagnostic: role index of workgroup `block` of the merged 256-workgroup recurrence launches under placement `mode` (csrc/persist.hip,
+ * persist_role_index); a bijection of 0..255 for every mode. */
+int32_t echr_persist_role_index(int32_t block, int32_t mode);
 int echr_persist_read_stamps(uint64_t* dst, int32_t max_entries);
 
 /* stand-alone element-wise clamp (misc/utils.py:107-111) for optimisers other than the fused one */

@@ -192,3 +192,28 @@ def test_three_stream_core_accepts_and_ignores_input_feats_type():
     assert core.CG_input_feats_type == 'VEC'
     assert core.CG_input_dim == opt.video_context_dim + opt.event_context_dim + opt.clip_context_dim
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in base.state_dict().items()}
+
+
+def test_persistent_role_placement_is_a_bijection():
+    """csrc/persist.hip persist_role_index: under every placement each of the 256 workgroups of a merged recurrence launch plays exactly one
+    role (0..95 half machine 0, 96..191 half machine 1, 192..255 the two LSTM streams), a half machine sits on three XCDs (dispatch position
+    b % 8) and an LSTM stream on one; mode 2 keeps the 64 product roles (16..79) of a half machine on two of its XCDs."""
+    from echr_amd import _lib
+    lib = _lib.load()
+    for mode in (0, 1, 2):
+        roles = [lib.echr_persist_role_index(b, mode) for b in range(256)]
+        assert sorted(roles) == list(range(256)), mode
+    for mode in (1, 2):
+        xcds = {}
+        for b in range(256):
+            r = lib.echr_persist_role_index(b, mode)
+            group = r // 96 if r < 192 else 2 + (r - 192) // 32
+            xcds.setdefault(group, set()).add(b % 8)
+        assert [len(xcds[g]) for g in range(4)] == [3, 3, 1, 1], (mode, xcds)
+        assert not (xcds[0] & xcds[1]) and not (xcds[2] & xcds[3]) and not ((xcds[0] | xcds[1]) & (xcds[2] | xcds[3]))
+    prod = {}
+    for b in range(256):
+        r = lib.echr_persist_role_index(b, 2)
+        if r < 192 and 16 <= r % 96 < 80:
+            prod.setdefault(r // 96, set()).add(b % 8)
+    assert all(len(v) == 2 for v in prod.values()), prod
