@@ -111,9 +111,9 @@ static int stage_indices(const int32_t* host, int32_t* dev, size_t bytes, hipStr
 // Stage-ahead (round 6): the LAST kernel of an iteration is clamp + Adam, ~95 us of pure HBM streaming on the caller's stream, and the FIRST
 // things of the next one -- the index staging copy and, behind it, the event encoder's position embedding (indices only: the head of the chain
 // the forward recurrence waits for) -- need nothing that update writes.  When a call ends with its own update it records an event in front of
-// it (every reader of the workspace and the index region is complete there: the helper streams were just joined) and one behind it; the next
-// call on the same stream, workspace and arena stages its indices on the TAIL stream behind the first event, so that copy and embedding run
-// beside the update, and orders everything else behind the second.
+// it (every reader of the workspace and the index region is complete there: the helper streams were just joined); the next call on the same
+// stream, workspace and arena stages its indices on the TAIL stream behind that event, so that copy and embedding run beside the update, and
+// orders everything else behind the caller's stream's position at its entry (the update and whatever the caller queued since).
 struct StageAhead { hipEvent_t pre = nullptr, post = nullptr; bool valid = false; hipStream_t st = nullptr; const void* ws = nullptr; const void* flat_g = nullptr; bool init = false, ok = false; };
 static StageAhead& stage_ahead() {
     static StageAhead s;
@@ -263,9 +263,13 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
         hipStream_t ts = tail_stream_raw();
         if (hipStreamWaitEvent(ts, sa.pre, 0) != hipSuccess) { set_error("train_step: stream wait failed"); return -5; }
         RC(stage_indices(a->host_index, idx, sizeof(int32_t) * step_index_count(a), ts));
-        // the caller's stream: behind the staging copy (its own position is already behind the update); the prepare stream: behind the update too
-        if (hipStreamWaitEvent(st, ring_last(), 0) != hipSuccess) { set_error("train_step: stream wait failed"); return -5; }
+        // the caller's stream: behind the staging copy (its own position is already behind the update).  The prepare stream: behind the
+        // caller's stream's position AT ENTRY -- the update, and whatever the caller queued since (this call's inputs: an upload of the next
+        // video's features, the proposal encoder's forward; a write to the parameters) -- since the staging event it forks from no longer
+        // implies that position
+        if (hipEventRecord(sa.post, st) != hipSuccess) { set_error("train_step: event record failed"); return -5; }
         RC(prep_stream_wait(sa.post));
+        if (hipStreamWaitEvent(st, ring_last(), 0) != hipSuccess) { set_error("train_step: stream wait failed"); return -5; }
     } else if (!a->prepared) RC(stage_indices(a->host_index, idx, sizeof(int32_t) * step_index_count(a), st));
     const int32_t *ev_start = idx, *ev_len = idx + N, *ind = idx + 2 * N, *active = idx + (3 + S) * N;          // (tokens at idx + 3 N: step_dec_args)
     const void* nll_target = a->nll_target;
@@ -400,7 +404,7 @@ extern "C" int echr_train_step(const echr_train_step_args* a, void* stream) {
     if (a->do_step) {                      // clip_gradient + Adam (misc/utils.py:107-111, train.py:315-317)
         const bool rec = sa.ok && hipEventRecord(sa.pre, st) == hipSuccess;          // (stage-ahead: every helper stream was joined just above)
         RC(echr_clamp_adam_counted(a->flat_p, a->flat_g, a->adam_m, a->adam_v, a->n_flat, a->adam_step, a->lr, a->beta1, a->beta2, a->eps, a->clip, a->adam_applied, stream));
-        if (rec && hipEventRecord(sa.post, st) == hipSuccess) { sa.valid = true; sa.st = st; sa.ws = a->ws; sa.flat_g = a->flat_g; }
+        if (rec) { sa.valid = true; sa.st = st; sa.ws = a->ws; sa.flat_g = a->flat_g; }
         else (void)hipGetLastError();
     }
     step_mark(5, st);

@@ -728,9 +728,13 @@ def test_stage_ahead_with_changing_videos():
     m2 = U.build_gpu_model(opt, params, False)
     o2 = ClampAdam(m2.parameters(), lr=1e-3, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon, arena=m2.build_arena())
     crit = LanguageModelCriterion()
-    dev_in = [tuple(torch.from_numpy(v[k]).to(dev) for k in ('tap', 'c3d', 'lda')) for v in vids]
-    losses = []
-    for v, (tap, c3d, lda) in zip(vids, dev_in):          # back to back: the host runs ahead, every iteration but the first stages ahead
+    pinned = [tuple(torch.from_numpy(v[k]).pin_memory() for k in ('tap', 'c3d', 'lda')) for v in vids]
+    losses, dev_in = [], []
+    for v, pin in zip(vids, pinned):          # back to back: the host runs ahead, every iteration but the first stages ahead
+        # this iteration's features arrive by an ASYNCHRONOUS upload queued on the caller's stream right in front of the call: everything of
+        # the call that reads them -- on whichever library stream -- has to be ordered behind the caller's stream's position at entry
+        tap, c3d, lda = (x.to(dev, non_blocking=True) for x in pin)
+        dev_in.append((tap, c3d, lda))
         labels = torch.from_numpy(v['labels'])
         losses.append(f(tap, c3d, lda, labels, v['ind'], v['soi'], labels[:, 1:].numpy(), v['masks'][:, 1:]))
     torch.cuda.synchronize()
