@@ -36,7 +36,7 @@ Config& config() {
     static Config c = {env_int("ECHR_GEMM_BF16X3", 1), env_int("ECHR_OVERLAP", 0), env_int("ECHR_ATT_SLOTS", 2), env_int("ECHR_CHAINS2", 0),
                        env_int("ECHR_GEMM_H2", 1), env_int("ECHR_PERSIST", 1), env_int("ECHR_PERSIST_STAMPS", 0),
                        getenv("ECHR_GEMM_TILE") ? (int)getenv("ECHR_GEMM_TILE")[0] : 0, env_int("ECHR_GEMM_SPLIT", 0), env_int("ECHR_PERSIST_BWD", 1), env_int("ECHR_PERSIST_SPLIT", 1), env_int("ECHR_PERSIST_H2", 1), env_int("ECHR_PERSIST_MERGE", 1), env_int("ECHR_PERSIST_KGROUPS", 1), env_int("ECHR_TSRM_FORK", 1),
-                       env_int("ECHR_PERSIST_COOP", 0), 0, env_int("ECHR_PERSIST_SPIN_LIMIT", 0), env_int("ECHR_SST_PERSIST", 1), env_int("ECHR_TAIL_EARLY", 0), 0, env_int("ECHR_EMBED_FUSED", 0), env_int("ECHR_PERSIST_SAMPLE", 1), env_int("ECHR_POSEMB_ROWS", 1), env_int("ECHR_GEMM_SKINNY", 1), env_int("ECHR_POSEMB_PACKED", 1), env_int("ECHR_PAIR_TABLES", 1), 0, env_int("ECHR_PERSIST_SAMPLE_MAX", 512)};
+                       env_int("ECHR_PERSIST_COOP", 0), 0, env_int("ECHR_PERSIST_SPIN_LIMIT", 0), env_int("ECHR_SST_PERSIST", 1), env_int("ECHR_TAIL_EARLY", 0), 0, env_int("ECHR_EMBED_FUSED", 0), env_int("ECHR_PERSIST_SAMPLE", 1), env_int("ECHR_POSEMB_ROWS", 1), env_int("ECHR_GEMM_SKINNY", 1), env_int("ECHR_POSEMB_PACKED", 1), env_int("ECHR_PAIR_TABLES", 1), 0, env_int("ECHR_PERSIST_SAMPLE_MAX", 512), env_int("ECHR_DETERMINISTIC", 0)};
     return c;
 }
 
@@ -230,7 +230,51 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
         else { atomicAdd(&out[col], t); if (out2) atomicAdd(&out2[col], t); }   // accumulate / multi-chunk
     }
 }
+// scratch slabs of the fixed-order ("deterministic") variants
+float* det_scratch(int kind, size_t floats) {
+    static float* buf[DET_KINDS] = {nullptr, nullptr, nullptr};
+    static size_t cap[DET_KINDS] = {0, 0, 0};
+    if (kind < 0 || kind >= DET_KINDS) return nullptr;
+    if (floats <= cap[kind]) return buf[kind];
+    if (buf[kind]) { (void)hipDeviceSynchronize(); (void)hipFree(buf[kind]); buf[kind] = nullptr; cap[kind] = 0; }
+    const size_t want = floats + floats / 4 + 1024;
+    if (hipMalloc(&buf[kind], want * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); set_error("deterministic: no memory for %zu scratch floats", want); return nullptr; }
+    cap[kind] = want;
+    return buf[kind];
+}
+
+// fixed-order column sum ("deterministic" = 1): ONE workgroup owns 64 columns over all rows -- 16 waves stride the rows with four loads in flight
+// each, combined through LDS in wave order; the output is overwritten or updated by its single writer (no atomics, no chunk order)
+__global__ __launch_bounds__(1024) void colsum_det_kernel(const float* __restrict__ X, long ld, int rows, int cols, float* __restrict__ out,
+                                                          float* __restrict__ out2, float* __restrict__ out3, int accumulate) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < cols) {
+        int r = wave;
+        for (; r + 48 < rows; r += 64) {
+            s0 += X[(long)r * ld + col]; s1 += X[(long)(r + 16) * ld + col]; s2 += X[(long)(r + 32) * ld + col]; s3 += X[(long)(r + 48) * ld + col];
+        }
+        for (; r < rows; r += 16) s0 += X[(long)r * ld + col];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && col < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        if (accumulate) { out[col] += t; if (out2) out2[col] += t; if (out3) out3[col] += t; }
+        else { out[col] = t; if (out2) out2[col] = t; if (out3) out3[col] = t; }
+    }
+}
+static int colsum_det(const float* X, long ld, int rows, int cols, float* out, float* out2, float* out3, bool accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_det_kernel, dim3((cols + 63) / 64), dim3(1024), 0, st, X, ld, rows, cols, out, out2, out3, accumulate ? 1 : 0);
+    return check_launch("colsum_det");
+}
+
 int colsum2(const float* X, long ld, int rows, int cols, float* out, float* out2, bool accumulate, hipStream_t st) {
+    if (det_mode()) return colsum_det(X, ld, rows, cols, out, out2, nullptr, accumulate, st);
     const int chunks = (rows + CS_ROWS - 1) / CS_ROWS;
     int mode = (accumulate || chunks > 1) ? 1 : 0;
     if (!accumulate && chunks > 1) {
@@ -269,6 +313,13 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumArgs a) {
 }
 int colsum_multi(const ColsumJob* jobs, int n, hipStream_t st) {
     ECHR_REQUIRE(jobs && n >= 1 && n <= COLSUM_MAX_JOBS, "colsum_multi: 1..%d jobs", COLSUM_MAX_JOBS);
+    if (det_mode()) {          // one fixed-order launch per job; the outputs accumulate (single writer per column)
+        for (int i = 0; i < n; ++i) {
+            ECHR_REQUIRE(jobs[i].X && jobs[i].out && jobs[i].rows > 0 && jobs[i].cols > 0, "colsum_multi: bad job %d", i);
+            if (int rc = colsum_det(jobs[i].X, jobs[i].ld, jobs[i].rows, jobs[i].cols, jobs[i].out, jobs[i].out2, jobs[i].out3, true, st)) return rc;
+        }
+        return 0;
+    }
     ColsumArgs a;
     int total = 0;
     for (int i = 0; i < n; ++i) {
@@ -380,8 +431,36 @@ __global__ void embed_scatter_add_kernel(const float* __restrict__ dX, const int
     if (!__syncthreads_or(any)) return;
     for (int j = threadIdx.x; j < E; j += blockDim.x) atomicAdd(&gW[(long)t * E + j], dX[(long)row * E + j]);
 }
+// fixed-order scatter-add ("deterministic" = 1): workgroup b owns the table rows of tokens [b * tpb, (b + 1) * tpb), walks ALL gradient rows in
+// order, 256 at a time (their tokens staged through LDS), and adds the rows of its tokens into the table with plain read-modify-writes -- every
+// table row has one writer and receives its rows in row order
+__global__ __launch_bounds__(256) void embed_scatter_det_kernel(const float* __restrict__ dX, const int* __restrict__ tok, float* __restrict__ gW,
+                                                                int rows, int E, int V1, const int* __restrict__ rowmap, int tpb) {
+    __shared__ int stok[256];
+    const int t0 = blockIdx.x * tpb, t1 = min(V1, t0 + tpb);
+    for (int r0 = 0; r0 < rows; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        int t = -1;
+        if (r < rows) { t = tok[rowmap ? rowmap[r] : r]; t = min(max(t, 0), V1 - 1); }
+        const int mine = (t >= t0 && t < t1) ? 1 : 0;
+        __syncthreads();          // the previous round's readers of stok are done
+        stok[threadIdx.x] = mine ? t : -1;
+        if (!__syncthreads_or(mine)) continue;
+        const int nr = min(256, rows - r0);
+        for (int i = 0; i < nr; ++i) {
+            const int ti = stok[i];
+            if (ti < 0) continue;
+            for (int j = threadIdx.x; j < E; j += 256) gW[(long)ti * E + j] += dX[(long)(r0 + i) * E + j];
+        }
+    }
+}
 int embed_scatter_add(const float* dX, const int* tok, float* gW, int rows, int E, int V1, hipStream_t st, const int* rowmap) {
     if (config().diag_skip & 8) return 0;
+    if (det_mode()) {
+        const int tpb = max(1, (V1 + 1023) / 1024);
+        hipLaunchKernelGGL(embed_scatter_det_kernel, dim3((V1 + tpb - 1) / tpb), dim3(256), 0, st, dX, tok, gW, rows, E, V1, rowmap, tpb);
+        return check_launch("embed_scatter_det");
+    }
     hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(rows), dim3(128), 0, st, dX, tok, gW, rows, E, V1, rowmap);
     return check_launch("embed_scatter_add");
 }
@@ -653,6 +732,21 @@ __global__ void event_gather_bwd_kernel(const float* __restrict__ d_ech, const i
     const int n = blockIdx.x;
     const long trow = ind[n];
     for (int j = threadIdx.x; j < Ht; j += blockDim.x) atomicAdd(&d_tap[trow * Ht + j], d_ech[(long)n * (D + Ht) + D + j]);
+}
+
+// fixed-order form ("deterministic" = 1): the first event of every anchor row owns it and adds the events that share it in event order
+__global__ void event_gather_bwd_det_kernel(const float* __restrict__ d_ech, const int* __restrict__ ind, float* __restrict__ d_tap,
+                                            int D, int Ht, int N) {
+    const int n = blockIdx.x;
+    const long trow = ind[n];
+    for (int m = 0; m < n; ++m)
+        if (ind[m] == trow) return;          // uniform: an earlier event owns this row
+    for (int j = threadIdx.x; j < Ht; j += blockDim.x) {
+        float acc = 0.f;
+        for (int m = n; m < N; ++m)
+            if (ind[m] == trow) acc += d_ech[(long)m * (D + Ht) + D + j];
+        d_tap[trow * Ht + j] += acc;
+    }
 }
 
 // ---- greedy arg-max over logits rows: lowest index on ties (torch.max semantics, OldModel_NEW.py:158) ---
@@ -1048,7 +1142,8 @@ extern "C" int echr_event_pool_gather_fwd(const float* c3d, const float* tap, co
 extern "C" int echr_event_pool_gather_bwd(const float* d_ech, const int32_t* ind, float* d_tap, int32_t N, int32_t D, int32_t Ht,
                                           void* stream) {
     ECHR_REQUIRE(d_ech && ind && d_tap && N > 0, "event_pool_gather_bwd: bad arguments");
-    hipLaunchKernelGGL(event_gather_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, d_ech, ind, d_tap, D, Ht);
+    if (det_mode()) hipLaunchKernelGGL(event_gather_bwd_det_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, d_ech, ind, d_tap, D, Ht, N);
+    else hipLaunchKernelGGL(event_gather_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, d_ech, ind, d_tap, D, Ht);
     return check_launch("event_pool_gather_bwd");
 }
 
@@ -1165,6 +1260,7 @@ extern "C" int echr_config_set(const char* key, int32_t value) {
     else if (!strcmp(key, "persist_sample_max")) c.persist_sample_max = value;
     else if (!strcmp(key, "persist_inject_timeout")) c.persist_inject_timeout = value;
     else if (!strcmp(key, "persist_spin_limit")) c.persist_spin_limit = value;
+    else if (!strcmp(key, "deterministic")) c.deterministic = value ? 1 : 0;
     else if (!strcmp(key, "gemm_tile")) c.gemm_tile = value;          // tuning only: ASCII code of the tile selector ('1','6','a','b','c','s'), 0 = heuristics
     else if (!strcmp(key, "gemm_split")) c.gemm_split = value;        // tuning only: forced k-slice count of auto-split products, 0 = heuristics
     else if (!strcmp(key, "att_slots")) { ECHR_REQUIRE(value == 2 || value == 4 || value == 8, "config_set: att_slots must be 2, 4 or 8"); c.att_slots = value; }

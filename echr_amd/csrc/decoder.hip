@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ WT, const float* __restrict__ ATT,
                                                       const float* __restrict__ DAS, int nslab, long slab_stride,
                                                       const int* __restrict__ ev_start, const int* __restrict__ ev_len,
-                                                      float* __restrict__ DSC, float* __restrict__ DQ, int A, int Ha, int D) {
+                                                      float* __restrict__ DSC, float* __restrict__ DQ, int A, int Ha, int D, long dq_slab) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sq = sm;                 // [Ha]
     float* sa = sq + Ha;            // [Ha]
@@ -387,8 +387,25 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(const float* __restrict__ 
         if (j < Ha) *reinterpret_cast<float4*>(red + wave * Ha + j) = dq[r];
     }
     __syncthreads();
+    // dq_slab != 0 (fixed-order mode): DQ is a stack of per-chunk slabs, summed in chunk order by dq_fold_kernel
+    if (dq_slab) {
+        for (int j = threadIdx.x; j < Ha; j += 256)
+            DQ[(long)blockIdx.y * dq_slab + (long)n * Ha + j] = red[j] + red[Ha + j] + red[2 * Ha + j] + red[3 * Ha + j];
+        return;
+    }
     for (int j = threadIdx.x; j < Ha; j += 256)
         atomicAdd(&DQ[(long)n * Ha + j], red[j] + red[Ha + j] + red[2 * Ha + j] + red[3 * Ha + j]);
+}
+// fixed-order mode: d q[n, :] += the slabs of the event's ceil(len / chunk) attention workgroups, in chunk order
+__global__ __launch_bounds__(256) void dq_fold_kernel(const float* __restrict__ slabs, long slab_stride, const int* __restrict__ ev_len,
+                                                      float* __restrict__ DQ, int N, int Ha, int chunk) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * Ha) return;
+    const int n = (int)(idx / Ha);
+    const int ny = (ev_len[n] + chunk - 1) / chunk;
+    float s = 0.f;
+    for (int y = 0; y < ny; ++y) s += slabs[(long)y * slab_stride + idx];
+    DQ[idx] += s;
 }
 
 // Post-recurrence pass: d P_all[row,:] += sum_t dsc_t * alpha * (1 - tanh^2(P_row + q_t)),
@@ -402,11 +419,12 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
                                                        const float* __restrict__ alpha, const float* __restrict__ DSC,
                                                        const int* __restrict__ ev_start, const int* __restrict__ ev_len,
                                                        float* __restrict__ DPALL, float* __restrict__ g_alpha,
-                                                       float* __restrict__ g_balpha, int S, int N, int A, int Ha, int disjoint) {
+                                                       float* __restrict__ g_balpha, int S, int N, int A, int Ha, int disjoint, int alpha_rows) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sqt = sm;                   // [TT][Ha]
     float* sds = sqt + TT * Ha;        // [TT][8] dscore tile
     float* red = sds + TT * 8;         // [4][Ha]
+    __shared__ float wsum[4];
     const int n = blockIdx.x, a0 = blockIdx.y * 8;
     const int len = ev_len[n];
     if (a0 >= len) return;
@@ -482,7 +500,9 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
                 const int j = lane * 4 + r * 256;
                 if (j < Ha) {
                     const float4 dv = make_float4(4.f * dp[i][r].x * a4[r].x, 4.f * dp[i][r].y * a4[r].y, 4.f * dp[i][r].z * a4[r].z, 4.f * dp[i][r].w * a4[r].w);
-                    if (disjoint) {      // the row belongs to this event alone: plain 16-byte store
+                    if (disjoint == 2) {      // fixed-order mode: DPALL is an [N][A][Ha] slab stack, folded per video row in event order (dpall_fold_kernel)
+                        *reinterpret_cast<float4*>(DPALL + ((long)n * A + a) * Ha + j) = dv;
+                    } else if (disjoint) {      // the row belongs to this event alone: plain 16-byte store
                         *reinterpret_cast<float4*>(drow + j) = dv;
                     } else {
                         atomicAdd(drow + j + 0, dv.x);
@@ -504,10 +524,32 @@ __global__ __launch_bounds__(256) void att_post_kernel(const float* __restrict__
     __syncthreads();
     // ALPHA_REP replicas of the two parameter gradients, summed by a column-sum launch afterwards: the N * ceil(A/8) workgroups used to
     // add into ONE [Ha] vector (1024 adders per address on 16 cache lines: those atomics, not the arithmetic, were the kernel's 66 us)
+    if (alpha_rows) {          // fixed-order mode: one (pre-zeroed) row per workgroup, summed in row order by the column-sum launch behind
+        const long rep = blockIdx.x + (long)blockIdx.y * gridDim.x;
+        for (int j = threadIdx.x; j < Ha; j += 256) g_alpha[rep * Ha + j] = red[j] + red[Ha + j] + red[2 * Ha + j] + red[3 * Ha + j];
+        // d b_alpha: every lane of a wave holds the same dsum over the wave's two slots; the four waves' values in wave order
+        if (lane == 0) wsum[wave] = dsum;
+        __syncthreads();
+        if (threadIdx.x == 0) g_balpha[rep] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        return;
+    }
     const int rep = (int)((blockIdx.x + blockIdx.y * gridDim.x) % ALPHA_REP);
     for (int j = threadIdx.x; j < Ha; j += 256)
         atomicAdd(&g_alpha[(long)rep * Ha + j], red[j] + red[Ha + j] + red[2 * Ha + j] + red[3 * Ha + j]);
     if (lane == 0 && dsum != 0.f) atomicAdd(g_balpha + rep, dsum);
+}
+// fixed-order mode: d P_all[row, :] += the slab rows of the events that cover video row `row`, in event order
+__global__ __launch_bounds__(256) void dpall_fold_kernel(const float* __restrict__ slab, const int* __restrict__ ev_start, const int* __restrict__ ev_len,
+                                                         float* __restrict__ DPALL, int N, int A, int Ha) {
+    const int row = blockIdx.x;
+    for (int j = threadIdx.x; j < Ha; j += 256) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const int a = row - ev_start[n];
+            if (a >= 0 && a < ev_len[n]) s += slab[((long)n * A + a) * Ha + j];
+        }
+        DPALL[(long)row * Ha + j] += s;
+    }
 }
 
 // ---- launch helpers (dispatch on the per-lane row widths) ------------------------------------------------
@@ -541,7 +583,20 @@ static int launch_att_bwd(const AttDims& d, const float* PALL, const float* C3D,
     const dim3 grid(d.N, (d.A + 4 * SL - 1) / (4 * SL)), blk(256);
     const size_t sm = (6 * d.Ha + ((d.D + 3) & ~3)) * sizeof(float);
     const int R = (d.Ha + 255) / 256, RD = (d.D + 255) / 256;
-#define ECHR_CASE3(RR, RRD, SS) if (R == RR && RD == RRD && SL == SS) { hipLaunchKernelGGL((att_bwd_kernel<RR, RRD, SS>), grid, blk, sm, st, PALL, C3D, Q, alpha, WT, ATT, DAS, nslab, slab_stride, ev_start, ev_len, DSC, DQ, d.A, d.Ha, d.D); return check_launch("att_bwd"); }
+    // fixed-order mode: per-chunk slabs of d q + a fold launch in chunk order instead of atomic adds
+    const long dq_slab = det_mode() ? (long)d.N * d.Ha : 0L;
+    float* dq_out = DQ;
+    if (dq_slab) {
+        dq_out = det_scratch(DET_DQ, (size_t)grid.y * dq_slab);
+        if (!dq_out) return -12;
+    }
+    auto fold = [&]() -> int {
+        if (!dq_slab) return check_launch("att_bwd");
+        if (int rc = check_launch("att_bwd")) return rc;
+        hipLaunchKernelGGL(dq_fold_kernel, dim3((unsigned)((dq_slab + 255) / 256)), dim3(256), 0, st, dq_out, dq_slab, ev_len, DQ, d.N, d.Ha, 4 * SL);
+        return check_launch("dq_fold");
+    };
+#define ECHR_CASE3(RR, RRD, SS) if (R == RR && RD == RRD && SL == SS) { hipLaunchKernelGGL((att_bwd_kernel<RR, RRD, SS>), grid, blk, sm, st, PALL, C3D, Q, alpha, WT, ATT, DAS, nslab, slab_stride, ev_start, ev_len, DSC, dq_out, d.A, d.Ha, d.D, dq_slab); return fold(); }
 #define ECHR_CASE(RR, RRD) ECHR_CASE3(RR, RRD, 2) ECHR_CASE3(RR, RRD, 4) ECHR_CASE3(RR, RRD, 8)
     ECHR_CASE(1, 1) ECHR_CASE(1, 2) ECHR_CASE(2, 1) ECHR_CASE(2, 2) ECHR_CASE(2, 3) ECHR_CASE(2, 4) ECHR_CASE(3, 2) ECHR_CASE(4, 2)
     ECHR_CASE(1, 3) ECHR_CASE(1, 4) ECHR_CASE(3, 1) ECHR_CASE(3, 3) ECHR_CASE(3, 4) ECHR_CASE(4, 1) ECHR_CASE(4, 3) ECHR_CASE(4, 4)
@@ -552,12 +607,12 @@ static int launch_att_bwd(const AttDims& d, const float* PALL, const float* C3D,
 }
 
 static int launch_att_post(const AttDims& d, const float* PALL, const float* QS, const float* alpha, const float* DSC, const int* ev_start,
-                           const int* ev_len, float* DPALL, float* g_alpha, float* g_balpha, int S, int disjoint, hipStream_t st) {
+                           const int* ev_len, float* DPALL, float* g_alpha, float* g_balpha, int S, int disjoint, hipStream_t st, int alpha_rows = 0) {
     if (config().diag_skip & 4) return 0;
     const dim3 grid(d.N, (d.A + 7) / 8), blk(256);
     const size_t sm = ((size_t)TT * d.Ha + TT * 8 + 4 * d.Ha) * sizeof(float);
     switch ((d.Ha + 255) / 256) {
-#define ECHR_CASE(R) case R: hipLaunchKernelGGL((att_post_kernel<R>), grid, blk, sm, st, PALL, QS, alpha, DSC, ev_start, ev_len, DPALL, g_alpha, g_balpha, S, d.N, d.A, d.Ha, disjoint); break;
+#define ECHR_CASE(R) case R: hipLaunchKernelGGL((att_post_kernel<R>), grid, blk, sm, st, PALL, QS, alpha, DSC, ev_start, ev_len, DPALL, g_alpha, g_balpha, S, d.N, d.A, d.Ha, disjoint, alpha_rows); break;
         ECHR_CASE(1) ECHR_CASE(2) ECHR_CASE(3) ECHR_CASE(4)
 #undef ECHR_CASE
         default: set_error("att_post: Ha too large"); return -22;
@@ -593,7 +648,7 @@ struct RecJob {
                      //    where summing slabs in every consumer would multiply the traffic); order-dependent last bits
     const int* rowidx;   // optional row gather: row m of the A operand is A[rowidx[m]] (the sampler's embedding rows by token id)
 };
-struct RecArgs { RecJob job[MAXJOBS]; int njobs; int M; };
+struct RecArgs { RecJob job[MAXJOBS]; int njobs; int M; int kloop = 0; };
 
 __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
     constexpr int NT = 256;
@@ -602,10 +657,21 @@ __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
     float* Bs = smem + 64 * RLD;
     const int jz = blockIdx.z % args.njobs, rb = blockIdx.z / args.njobs;
     const RecJob J = args.job[jz];
-    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * RK, m0 = rb * 64;
-    if (n0 >= J.Nout || k0 >= J.K) return;
-    const int k1 = min(J.K, k0 + RK);
+    const int n0 = blockIdx.x * 64, m0 = rb * 64;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int l31 = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // args.kloop (fixed-order mode, grid.y = 1): this workgroup walks ALL k slices of its tile in order and updates the output once
+    const int ks0 = args.kloop ? 0 : (int)blockIdx.y, ks1 = args.kloop ? (J.K + RK - 1) / RK : ks0 + 1;
+    if (n0 >= J.Nout || ks0 * RK >= J.K) return;
+    for (int ks = ks0; ks < ks1; ++ks) {
+    const int k0 = ks * RK;
+    const int k1 = min(J.K, k0 + RK);
+    if (ks > ks0) __syncthreads();          // the previous slice's fragment reads are done
     // branch-free staging: every lane loads from a clamped (always valid) address and zeroes what lies outside the
     // problem, so all global loads of a thread are in flight together before the first LDS write
     constexpr int LP = RLP;
@@ -633,12 +699,6 @@ __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
         *reinterpret_cast<float4*>(&Bs[row * RLD + kq]) = b;
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    const int l31 = lane & 31, h = lane >> 5;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* ap = &As[(wm + l31) * RLD + 4 * h];
     const float* bp = &Bs[(wn + l31) * RLD + 4 * h];
     // the whole slice is always multiplied (tails are zero-filled): a fixed trip count lets the compiler
@@ -652,6 +712,7 @@ __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
     }
+    }
     float* P = J.P + (J.atomic ? 0L : (long)blockIdx.y * J.slab_stride);
     const int col = n0 + wn + l31;
     if (col < J.Nout) {
@@ -659,7 +720,8 @@ __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row < args.M) {
-                if (J.atomic) atomicAdd(&P[(long)row * J.ldp + col], acc[r]);
+                if (J.atomic && args.kloop) P[(long)row * J.ldp + col] += acc[r];          // the tile's only writer in this launch
+                else if (J.atomic) atomicAdd(&P[(long)row * J.ldp + col], acc[r]);
                 else P[(long)row * J.ldp + col] = acc[r];
             }
         }
@@ -681,6 +743,18 @@ static int rec_gemm(const RecArgs& a, hipStream_t st) {
         by += 4.0 * ((double)a.M * J.K + (double)J.Nout * J.K + (double)a.M * J.Nout * ksplit_of(J.K));
     }
     ProfScope prof(PROF_LSTM, fl, by, st);
+    bool any_atomic = false;
+    for (int j = 0; j < a.njobs; ++j) any_atomic = any_atomic || a.job[j].atomic;
+    if (det_mode() && any_atomic) {
+        // fixed-order mode: the jobs that add into shared accumulators run as one k loop per tile (plain update); slab jobs of the same launch
+        // would then all land in slab 0, so the two kinds are not mixed
+        for (int j = 0; j < a.njobs; ++j) ECHR_REQUIRE(a.job[j].atomic, "rec_gemm: fixed-order mode cannot mix slab and accumulator jobs");
+        for (int j = 1; j < a.njobs; ++j) for (int i = 0; i < j; ++i) ECHR_REQUIRE(a.job[i].P != a.job[j].P, "rec_gemm: fixed-order mode needs distinct outputs per launch");
+        RecArgs b = a;
+        b.kloop = 1;
+        hipLaunchKernelGGL(rec_gemm_kernel, dim3(maxn, 1, a.njobs * ((a.M + 63) / 64)), dim3(256), 0, st, b);
+        return check_launch("rec_gemm");
+    }
     hipLaunchKernelGGL(rec_gemm_kernel, dim3(maxn, maxk, a.njobs * ((a.M + 63) / 64)), dim3(256), 0, st, a);
     return check_launch("rec_gemm");
 }
@@ -1696,7 +1770,7 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
         // duplicate once (20 us, `tools/skip_bounds.py`)
         // (with compacted rows the products' row i is position act[i]: the scatter through `rowmap` handles that, the fused epilogue -- indexed
         // by the compact row -- would not, so the switch is ignored there)
-        const bool fused_scatter = config().embed_fused != 0 && !actr;
+        const bool fused_scatter = config().embed_fused != 0 && !actr && !det_mode();          // (the fused epilogue is atomics by construction)
         for (int k = 0; k < 3; ++k) {
             float* out = fused_scatter ? g->g_embed : b.DXT;
             gx[k] = h2 ? desc_h2(b.PK_DG[k], b.PK_WIHT[k], out, E, SNr, E, 4 * H) : desc_nn(b.DG[k], 4 * H, a->w_ih[k], cin[k], out, E, SN, E, 4 * H);
@@ -1833,9 +1907,33 @@ int echr::decoder_bwd_parts(const echr_dec_args* a, const echr_dec_grads* g, con
     {
     ProfScope prof(PROF_ATT_POST, 6.0 * N * A * Ha * S, 4.0 * ((double)N * A * Ha * 2 + (double)S * N * (Ha + A)), st);
     const AttDims ad{N, A, Ha, D};
+    if (det_mode()) {
+        // fixed-order mode: one d alpha / d b_alpha row per workgroup and (for events that share video rows) one d P_all slab row per (event,
+        // position), folded by fixed-order launches -- no atomics
+        const long nblk = (long)N * ((A + 7) / 8);
+        float* ga = det_scratch(DET_ALPHA, (size_t)nblk * (Ha + 1));
+        if (!ga) return -12;
+        float* gb = ga + nblk * Ha;
+        RC(fill_zero(ga, nblk * (Ha + 1), st));          // workgroups behind an event's end return early: their rows stay zero
+        float* dps = nullptr;
+        if (!a->rows_disjoint) { dps = det_scratch(DET_DPALL, (size_t)N * A * Ha); if (!dps) return -12; }
+        RC(launch_att_post(ad, w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, dps ? dps : b.DPALL, ga, gb, S, dps ? 2 : 1, st, 1));
+        if (dps) {
+            hipLaunchKernelGGL(dpall_fold_kernel, dim3(a->Tv), dim3(256), 0, st, dps, a->ev_start, a->ev_len, b.DPALL, N, A, Ha);
+            RC(check_launch("dpall_fold"));
+        }
+        RC(colsum(ga, Ha, (int)nblk, Ha, g->g_w_alpha, z, st));
+        RC(colsum(gb, 1, (int)nblk, 1, g->g_b_alpha, z, st));
+        if (z) {
+            RC(colsum(b.DPALL, Ha, a->Tv, Ha, g->g_b_c2a, z, st));
+            if (bias_pending) RC(colsum(b.DLG, b.ldg, SNc, V1, g->g_b_logit, z, st));
+        }
+    } else {
     RC(launch_att_post(ad, w.PALL, w.QS, a->w_alpha, b.DSC, a->ev_start, a->ev_len, b.DPALL, b.GAREP, b.GBREP, S, a->rows_disjoint ? 1 : 0, st));
     }
-    if (z) {
+    }
+    if (det_mode()) {
+    } else if (z) {
         // accumulate mode: the replicas -> d alpha, d b_alpha, the ctx2att bias gradient (column sums of d P_all) and -- when the logit-layer
         // gradients were formed on this stream just before -- d b_logit: ONE multi-problem launch instead of four
         ColsumJob cj[4] = {{b.GAREP, Ha, ALPHA_REP, Ha, g->g_w_alpha, nullptr, nullptr}, {b.GBREP, 1, ALPHA_REP, 1, g->g_b_alpha, nullptr, nullptr},

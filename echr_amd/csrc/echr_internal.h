@@ -17,7 +17,7 @@ struct ProfScope {
 };
 
 // runtime switches (initial values from the environment, changeable through echr_config_set)
-struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; int persist_coop; int persist_inject_timeout; int persist_spin_limit; int sst_persist; int tail_early; int diag_skip; int embed_fused; int persist_sample; int posemb_rows; int gemm_skinny; int posemb_packed; int pair_tables; int persist_sample_force_eos; int persist_sample_max; };
+struct Config { int gemm_bf16x3; int overlap; int att_slots; int chains2; int gemm_h2; int persist; int persist_stamps; int gemm_tile; int gemm_split; int persist_bwd; int persist_split; int persist_h2; int persist_merge; int persist_kgroups; int tsrm_fork; int persist_coop; int persist_inject_timeout; int persist_spin_limit; int sst_persist; int tail_early; int diag_skip; int embed_fused; int persist_sample; int posemb_rows; int gemm_skinny; int posemb_packed; int pair_tables; int persist_sample_force_eos; int persist_sample_max; int deterministic; };
 // diag_skip (diagnostic, tools/skip_bounds.py; results are WRONG while a bit is set): 1 = h2 operand packs, 2 = clamp+Adam kernel, 4 = att_post, 16 = every fp32-path product (gemm_f32 / t128 / bf16x3), 32 = every h2 product, 64 / 128 = the h2m16 product kernel loads only / computes only (tools/h2_ablate.py),
 // 8 = embedding scatter-add -- the launch is skipped, which bounds what removing / hiding that work could gain
 Config& config();
@@ -27,6 +27,14 @@ int gemm(const echr_gemm_desc& d, hipStream_t st);
 // single fixed-order k loop per output tile
 struct DeterministicScope { DeterministicScope(); ~DeterministicScope(); };
 bool deterministic_gemm();
+// "deterministic" = 1 (echr_config_set / ECHR_DETERMINISTIC): every order-dependent sum of a training iteration (fp32 atomics: split-K epilogues,
+// k-slices of the recurrence products, column sums, scatter-adds, the attention backward's shared rows, the persistent kernels' exchange adds) is
+// replaced by a fixed-order one -- two runs on the same inputs then agree bit for bit.  Slower; the persistent recurrence kernels are not used.
+inline bool det_mode() { return config().deterministic != 0; }
+// scratch slabs of the fixed-order variants: one lazily grown device buffer per use (`kind`), owned by the library, never shrunk; the call
+// that grows one synchronises the device (hipFree / hipMalloc).  One calling thread, like the rest of the library's static state.
+enum { DET_DQ = 0, DET_DPALL = 1, DET_ALPHA = 2, DET_KINDS = 3 };
+float* det_scratch(int kind, size_t floats);
 
 // persistent (one launch for all timesteps) recurrence of the decoder, csrc/persist.hip
 struct DropCfg;

@@ -20,7 +20,7 @@
 namespace echr {
 
 static thread_local int g_det_depth = 0;
-bool deterministic_gemm() { return g_det_depth > 0; }
+bool deterministic_gemm() { return g_det_depth > 0 || det_mode(); }
 DeterministicScope::DeterministicScope() { ++g_det_depth; }
 DeterministicScope::~DeterministicScope() { --g_det_depth; }
 
@@ -1168,6 +1168,18 @@ int gemm_grouped(const echr_gemm_desc* ds, int ng, hipStream_t st) {
                      a.act == b.act && a.split_k == b.split_k && a.algo == b.algo && a.rowmap_mod == b.rowmap_mod &&
                      a.add_mod == b.add_mod && a.ld_add == b.ld_add && a.act == ECHR_ACT_NONE,
                      "gemm_grouped: problems must share shape, layout and epilogue mode");
+    }
+    if (det_mode() && ng > 1) {
+        // fixed-order mode: problems that share an output cannot add atomically -- one launch per problem, in group order, each a single k loop
+        // per tile that updates C in place (beta = 1, accumulate mode)
+        bool shared_c = false;
+        for (int gi = 1; gi < ng; ++gi) for (int gj = 0; gj < gi; ++gj) shared_c = shared_c || ds[gi].C == ds[gj].C;
+        if (shared_c) {
+            ECHR_REQUIRE(ds[0].split_k < 0 && ds[0].beta == 1.f, "gemm_grouped: problems sharing C need auto split-K in accumulate mode");
+            for (int gi = 0; gi < ng; ++gi)
+                if (int rc = gemm_impl(&ds[gi], 1, st)) return rc;
+            return 0;
+        }
     }
     return gemm_impl(ds, ng, st);
 }

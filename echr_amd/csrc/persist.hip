@@ -3259,7 +3259,7 @@ static bool persist_shape_ok(const echr_dec_args* a) {
            a->S >= 1 && !a->h0;          // (a non-zero initial state: the persistent kernels assume h(-1) = c(-1) = 0)
 }
 
-bool persist_fwd_eligible(const echr_dec_args* a) { return config().persist && persist_shape_ok(a); }
+bool persist_fwd_eligible(const echr_dec_args* a) { return config().persist && !det_mode() && persist_shape_ok(a); }          // (fixed-order mode: the exchange adds of the persistent kernels are atomics)
 
 // the part of the exchange workspace the persistent launch needs zeroed (counters, atomically accumulated buffers): callers that run a
 // multi-range fill anyway fold it in (PersistFwdBufs::prezeroed / PersistBwdBufs::prezeroed) instead of paying a memset launch
@@ -3550,7 +3550,7 @@ bool persist_fwd_adds_evb0() {
     static const bool off = [] { const char* e = getenv("ECHR_EVB0_FOLD"); return e && e[0] == '0'; }();      // A/B switch (tools/ab_env.sh)
     return config().persist_h2 != 0 && !off;
 }
-bool persist_bwd_eligible(const echr_dec_args* a) { return config().persist_bwd && persist_shape_ok(a); }
+bool persist_bwd_eligible(const echr_dec_args* a) { return config().persist_bwd && !det_mode() && persist_shape_ok(a); }
 
 void persist_bwd_zero_range(const echr_dec_args* a, float* xws, float** ptr, long* count) {
     const PersistLayoutB L = persist_layout_b(a->S);

@@ -622,6 +622,14 @@ int echr_prof_event_overhead(double* ms, int64_t* n);
  *                      16-row-tile kernel instead of the general tiles
  *   "embed_fused" 0/1   (default 0, ECHR_EMBED_FUSED) token-embedding gradient through echr_gemm_desc.row_index instead of d XT + scatter pass
  *                      (measured slower: atomics of all k-slices contend on the <bos> / frequent-word rows)
+ *   "deterministic" 0/1 (default 0, ECHR_DETERMINISTIC) fixed-order accumulation: every order-dependent fp32 sum of a training iteration is replaced
+ *                      by a fixed-order one -- products run one k loop per output tile (no split-K atomics; grouped problems that share an output run
+ *                      one after the other), the recurrences run launch-per-phase with the accumulator products as one k loop per tile (the
+ *                      persistent kernels' exchange adds are atomics: not used), column sums have one owner workgroup per 64 columns, the token
+ *                      scatter-add and the anchor-row scatter have one owner per destination row and add in source order, the attention backward
+ *                      writes per-chunk / per-(event, position) / per-workgroup slabs that fold launches sum in index order (scratch owned by the
+ *                      library, grown on demand).  Two runs on the same inputs, parameters and dropout seed then agree bit for bit in loss and
+ *                      every gradient (the reference's CPU path is run-to-run deterministic at a fixed thread count); cost: see DESIGN.md section 4h
  *   "tail_early"  0/1   (default 0, ECHR_TAIL_EARLY) fork the asynchronous decoder-backward tail ahead of the LSTM-layer gradient stage
  *   "persist_stamps" 0/1/2 diagnostic phase stamps of the forward (1) / reverse (2) pair, see echr_persist_read_stamps
  *   "gemm_tile", "gemm_split"  tuning overrides of the GEMM tile / split-K heuristics (0 = heuristics; tools/gemm_bench.py only) */

@@ -1085,8 +1085,7 @@ def test_flat_arena_path_matches_per_tensor_path(case):
             assert U.grad_close(k, p.grad.cpu().numpy(), 2 * g1[k].cpu().numpy(), 1e-4), k
 
 
-@pytest.mark.parametrize('case', ['c1', 'c2'])
-def test_fused_train_step_equals_autograd_path(case):
+def _fused_train_step_vs_autograd_path(case, ltol, fixed):
     """echr_train_step (one library call per iteration: zero_grad, forward, criterion, backward, clip_gradient, Adam -- train.py:281-317)
     against the autograd path on a twin model: same losses, same parameters and Adam moments after three iterations (train mode, same
     dropout stream), same gradients with step=False, same validation loss with forward_only; then both paths mixed on one model."""
@@ -1195,11 +1194,12 @@ def test_fused_train_step_equals_autograd_path(case):
     sync()
     la = autograd_iteration(ma, oa)
     lb = autograd_iteration(mb, ob)
-    assert abs(la - lb) < 5e-6 * abs(la)          # (two models several Adam steps apart on split-K atomics: the loss, 0.02 here, moves in quanta of ~2e-6 relative between runs)
+    assert abs(la - lb) < ltol * abs(la)          # (two models several Adam steps apart on split-K atomics: the loss, 0.02 here, moves in quanta of ~2e-6 relative between runs)
+    assert not fixed or la == lb                  # fixed-order accumulation: the SAME path on twins in the same state gives the same bits
     sync()
     la = autograd_iteration(ma, oa)
     lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk))
-    assert abs(la - lb) < 5e-6 * abs(la)
+    assert abs(la - lb) < ltol * abs(la)
     assert oa._flat['step'] == ob._flat['step']
     # the joint 'tap_cg' iteration (train.py:300-313): d loss / d tap_feats comes back through `tap_grad` for the proposal encoder
     sync()
@@ -1219,7 +1219,7 @@ def test_fused_train_step_equals_autograd_path(case):
     g_ref = torch.zeros_like(tap)
     fb2_tap = torch.zeros_like(tap)
     lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], tap_grad=fb2_tap, defer_update=True))
-    assert abs(la - lb) < 5e-6 * abs(la)
+    assert abs(la - lb) < ltol * abs(la)
     assert U.grad_close('tap_feats', fb2_tap.cpu().numpy(), g_tap.cpu().numpy(), 1e-3)          # (same state up to one Adam step of noise-level drift)
     fb.join()
     assert oa._flat['step'] == ob._flat['step']
@@ -1247,11 +1247,25 @@ def test_fused_train_step_equals_autograd_path(case):
     lb = float(fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], labels[:, 1:], masks[:, 1:], tap_grad=torch.zeros_like(tap), defer_update=True,
                   prepared=True))
     fb.join()
-    assert abs(la - lb) < 5e-6 * abs(la) and bool(torch.isfinite(filler))
+    assert abs(la - lb) < ltol * abs(la) and bool(torch.isfinite(filler))
     for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
         assert k in U.NOISE_ONLY or float((pa.detach() - pb.detach()).abs().max()) <= 2.01 * lr, k
     with pytest.raises(RuntimeError):
         fb(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt, msk, prepared=True)                   # no prepare() before
+
+
+@pytest.mark.parametrize('fixed', [False, True], ids=['atomic', 'fixed_order'])
+@pytest.mark.parametrize('case', ['c1', 'c2'])
+def test_fused_train_step_equals_autograd_path(case, fixed):
+    """The comparison above with the default (atomic split-K, persistent recurrences) and with `echr_config_set("deterministic", 1)`: under
+    fixed-order accumulation the loss gates between the two paths tighten from 5e-6 to 2e-6 relative (what is left is the two paths' different
+    association of the same sums, not run-to-run noise)."""
+    import echr_amd
+    echr_amd.set_deterministic(fixed)
+    try:
+        _fused_train_step_vs_autograd_path(case, 2e-6 if fixed else 5e-6, fixed)
+    finally:
+        echr_amd.set_deterministic(False)
 
 
 def test_deferred_update_survives_changing_shapes():

@@ -753,3 +753,85 @@ def test_stage_ahead_with_changing_videos():
         assert abs(float(a) - b) < 2e-3 * abs(b), (i, float(a), b)
     assert abs(float(losses[0]) - ref[0]) < 1e-5 * abs(ref[0])
     assert o._flat['step'] == 6 and int(o._applied.item()) == 6
+
+
+# ---- fixed-order accumulation (round 6: echr_config_set("deterministic", 1)) ------------------------------------------------------------
+def _bits(t):
+    return t.detach().cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize('case', ['c2', 'vctx', 'initc', 'er2'])
+def test_deterministic_switch_two_runs_agree_bit_for_bit(case):
+    """`echr_amd.set_deterministic(True)` (echr_config_set("deterministic", 1)): two runs of FusedTrainStep from the same parameters, inputs and
+    dropout seed give the same BITS -- the loss, every parameter gradient, d loss / d tap_feats, and after three full iterations (clamp + Adam
+    inside the call) the parameters and both moment vectors.  The reference's CPU path has this property at a fixed thread count; the default
+    configuration (split-K atomics, persistent recurrences with atomic exchange adds) does not -- tools/det_probe.py lists what differs there.
+    Overlapping events (shared d P_all rows), repeated tokens (the embedding scatter) and repeated anchor rows are all present in these cases."""
+    import echr_amd
+    opt, params, vid = synth.make_case(case)
+    tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
+    args = (tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h)
+    assert len(set(np.asarray(vid['ind']).tolist())) < len(vid['ind']) or case != 'c2'          # c2 repeats anchor rows
+
+    def run():
+        torch.manual_seed(99)
+        m, o, f = _fused(opt, params, True, lr=1e-3, clip=opt.grad_clip)
+        g_tap = torch.zeros_like(tap)
+        loss = f(*args, step=False, tap_grad=g_tap)
+        torch.cuda.synchronize()
+        out = {'loss': _bits(loss.reshape(1)), 'tap_grad': _bits(g_tap)}
+        out.update({'g|' + k: _bits(p.grad) for k, p in m.named_parameters() if p.grad is not None})
+        losses = [f(*args) for _ in range(3)]
+        torch.cuda.synchronize()
+        out['losses'] = _bits(torch.stack([x.reshape(()) for x in losses]))
+        out['p'], out['m'], out['v'] = _bits(m._echr_arena.flat_p), _bits(o._flat['m']), _bits(o._flat['v'])
+        assert o._flat['step'] == 3 and int(o._applied.item()) == 3
+        return out
+
+    echr_amd.set_deterministic(True)
+    try:
+        a, b = run(), run()
+    finally:
+        echr_amd.set_deterministic(False)
+    assert a.keys() == b.keys() and len(a) > 30
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (k, int((a[k] != b[k]).sum()), a[k].size)
+
+
+def test_deterministic_switch_joint_iteration_bit_for_bit():
+    """... and the joint 'tap_cg' iteration (fused.JointTrainStep: proposal encoder forward / criterion / backward + both updates): both losses and
+    both models' parameters after two iterations, bit for bit between two runs."""
+    import echr_amd
+    from echr_amd import models as EM
+    from echr_amd.fused import JointTrainStep
+    from echr_amd.optim import ClampAdam
+    opt, params, sst_params, vid = synth.make_c5()
+    dev = torch.device('cuda')
+    _, c3d, lda, labels, tgt_h, msk_h = _device_inputs(dict(vid, tap=np.zeros((1, 1), np.float32)))
+    tl, tm, tw = (torch.from_numpy(vid[k]).to(dev) for k in ('tap_labels', 'tap_masks', 'w1'))
+
+    def run():
+        torch.manual_seed(7)
+        m, o, f = _fused(opt, params, True, lr=1e-3, clip=opt.grad_clip)
+        tapm = EM.setup_tap(opt)
+        tapm.load_state_dict({k: torch.from_numpy(v) for k, v in sst_params.items()})
+        tapm = tapm.to(dev)
+        tapm.eval()
+        tap_o = ClampAdam(tapm.parameters(), lr=1e-3, arena=tapm.build_arena())
+        j = JointTrainStep(f, tapm, tap_o, lambda1=opt.lambda1, tap_grad_clip=opt.grad_clip)
+        out = {}
+        for it in range(2):
+            total = j(c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, tm, tl, tw)
+            f.join()
+            torch.cuda.synchronize()
+            out['loss%d' % it] = _bits(torch.stack([total.reshape(()), j.tap_loss.reshape(()), j.cg_loss.reshape(())]))
+        out['p'], out['tap_p'] = _bits(m._echr_arena.flat_p), _bits(tapm._echr_arena.flat_p)
+        return out
+
+    echr_amd.set_deterministic(True)
+    try:
+        a, b = run(), run()
+    finally:
+        echr_amd.set_deterministic(False)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (k, int((a[k] != b[k]).sum()), a[k].size)

@@ -17,13 +17,16 @@ tap, c3d, lda, labels, tgt_h, msk_h = _device_inputs(vid)
 
 
 def run():
+    torch.manual_seed(1234)
     m, o, f = _fused(opt, params, True)
     loss = float(f(tap, c3d, lda, labels, vid['ind'], vid['soi'], tgt_h, msk_h, step=False))
     torch.cuda.synchronize()
     return loss, {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}
 
 
-for name, sets in (('default', {}), ('persist off', {b'persist': 0, b'persist_bwd': 0}), ('persist off + split 1', {b'persist': 0, b'persist_bwd': 0, b'gemm_split': 1})):
+RESET = {b'persist': 1, b'persist_bwd': 1, b'gemm_split': 0, b'deterministic': 0}
+for name, sets in (('default', {}), ('persist off', {b'persist': 0, b'persist_bwd': 0}), ('persist off + split 1', {b'persist': 0, b'persist_bwd': 0, b'gemm_split': 1}),
+                   ('deterministic', {b'deterministic': 1})):
     for k, v in sets.items():
         lib.echr_config_set(k, v)
     a, b = run(), run()
@@ -32,4 +35,4 @@ for name, sets in (('default', {}), ('persist off', {b'persist': 0, b'persist_bw
     for k, v in sorted(diff.items(), key=lambda kv: -kv[1]):
         print('   %-50s %.2e' % (k, v))
     for k in sets:
-        lib.echr_config_set(k, 1 if k != b'gemm_split' else 0)
+        lib.echr_config_set(k, RESET[k])
