@@ -35,6 +35,7 @@ static void run(const char* name, hipStream_t s) {
     int total = 0;
     printf("%-28s", name);
     for (auto& kv : per) { printf(" xcc%u:%zu", kv.first, kv.second.size()); total += (int)kv.second.size(); }
+    if (per.size()) { printf(" | xcc0 ids:"); for (uint32_t id : per.begin()->second) printf(" %02x", id); }
     printf("  | total %d CUs\n", total);
     hipFree(d);
 }
@@ -52,6 +53,14 @@ int main() {
         snprintf(nm, sizeof nm, "first %d bits", wdt);
         run(nm, s);
         hipStreamDestroy(s);
+    }
+    // the LAST 64 bits: which CUs, and are they disjoint from the first 192 bits' CUs?
+    {
+        uint32_t ml[8] = {0, 0, 0, 0, 0, 0, 0xffffffffu, 0xffffffffu};
+        hipStream_t sl;
+        if (hipExtStreamCreateWithCUMask(&sl, 8, ml) == hipSuccess) { run("bits 192..255", sl); hipStreamDestroy(sl); }
+        uint32_t mm[8] = {0, 0, 0, 0, 0xffffffffu, 0xffffffffu, 0, 0};
+        if (hipExtStreamCreateWithCUMask(&sl, 8, mm) == hipSuccess) { run("bits 128..191", sl); hipStreamDestroy(sl); }
     }
     // every fourth bit: 64 CUs spread over the mask
     uint32_t m4[8];
