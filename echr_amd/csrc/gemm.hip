@@ -972,12 +972,12 @@ constexpr int N128_LD = BK + 4;                         // floats per LDS row of
 constexpr int T128_OP = 128 * N128_LD;                  // floats per operand and stage (the row-contiguous form needs 32 * 132 = 4224 <= 4608)
 constexpr int T128_STAGE = 2 * T128_OP;
 constexpr int T128_LDM = 128 + 4;
-template <bool KC>
-__device__ __forceinline__ void t128_fetch(float4 (&r)[4], const float* __restrict__ P, long s_mn, long s_k, int mn0, int k0, int MN, int K,
+template <bool KC, int NT = 256>
+__device__ __forceinline__ void t128_fetch(float4 (&r)[1024 / NT], const float* __restrict__ P, long s_mn, long s_k, int mn0, int k0, int MN, int K,
                                            int kend, bool vec, int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = tid + 256 * i;
+    for (int i = 0; i < 1024 / NT; ++i) {
+        const int f = tid + NT * i;
         if (KC) {
             const int row = f >> 3, k = k0 + 4 * (f & 7);
             const float* src = P + (long)min(mn0 + row, MN - 1) * s_mn;          // rows beyond MN are clamped: their products land in rows / columns the epilogue does not store
@@ -1006,11 +1006,11 @@ __device__ __forceinline__ void t128_fetch(float4 (&r)[4], const float* __restri
         }
     }
 }
-template <bool KC>
-__device__ __forceinline__ void t128_stash(const float4 (&r)[4], float* __restrict__ S, int tid) {
+template <bool KC, int NT = 256>
+__device__ __forceinline__ void t128_stash(const float4 (&r)[1024 / NT], float* __restrict__ S, int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = tid + 256 * i;
+    for (int i = 0; i < 1024 / NT; ++i) {
+        const int f = tid + NT * i;
         if (KC) *reinterpret_cast<float4*>(S + (f >> 3) * N128_LD + 4 * (f & 7)) = r[i];
         else    *reinterpret_cast<float4*>(S + (f >> 5) * T128_LDM + 4 * (f & 31)) = r[i];
     }
@@ -1022,13 +1022,16 @@ __device__ __forceinline__ float4 t128_frag(const float* __restrict__ S, int row
     const float* q = S + (8 * c + 4 * kh) * T128_LDM + row;
     return make_float4(q[0], q[T128_LDM], q[2 * T128_LDM], q[3 * T128_LDM]);
 }
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_t128_kernel(GemmParams pin) {
+// W8: eight waves of 64 x 32 instead of four of 64 x 64 -- for launches of at most one workgroup per CU (the 240-tile logits product), where
+// the four-wave form leaves every SIMD with ONE wave and nothing to issue while that wave fetches, stores its stage or waits at the barrier
+template <bool AKC, bool BKC, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 1 : 2) void gemm_f32_t128_kernel(GemmParams pin) {
+    constexpr int NT = W8 ? 512 : 256, TN = W8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float nsm[];
     int z = blockIdx.z;
     const GemmParams p = select_group(pin, z);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = W8 ? (wave >> 2) * 64 : (wave >> 1) * 64, wn = W8 ? (wave & 3) * 32 : (wave & 1) * 64;
     const int nwg = p.tiles_m * p.tiles_n;
     int bid = blockIdx.x;
     {   // XCD-aware tile order (see gemm_f32_kernel)
@@ -1044,22 +1047,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_t128_kernel(GemmParams pin) {
     const int kt_total = (p.K + BK - 1) / BK;
     const int kt0 = ks * p.k_tiles_per_split, kt1 = min(kt_total, kt0 + p.k_tiles_per_split);
     const int kend = min(p.K, kt1 * BK);
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float4 ra[4], rb[4];
+    float4 ra[1024 / NT], rb[1024 / NT];
     const long sa_mn = AKC ? p.sam : 1, sa_k = AKC ? 1 : p.sak, sb_mn = BKC ? p.sbn : 1, sb_k = BKC ? 1 : p.sbk;
     auto fetch = [&](int kt) {
-        t128_fetch<AKC>(ra, A, sa_mn, sa_k, m0, kt * BK, p.M, p.K, kend, p.vecA, tid);
-        t128_fetch<BKC>(rb, B, sb_mn, sb_k, n0, kt * BK, p.N, p.K, kend, p.vecB, tid);
+        t128_fetch<AKC, NT>(ra, A, sa_mn, sa_k, m0, kt * BK, p.M, p.K, kend, p.vecA, tid);
+        t128_fetch<BKC, NT>(rb, B, sb_mn, sb_k, n0, kt * BK, p.N, p.K, kend, p.vecB, tid);
     };
     auto stash = [&](int stage) {
-        t128_stash<AKC>(ra, nsm + stage * T128_STAGE, tid);
-        t128_stash<BKC>(rb, nsm + stage * T128_STAGE + T128_OP, tid);
+        t128_stash<AKC, NT>(ra, nsm + stage * T128_STAGE, tid);
+        t128_stash<BKC, NT>(rb, nsm + stage * T128_STAGE + T128_OP, tid);
     };
     const int l31 = lane & 31, kh = lane >> 5;
     if (kt0 < kt1) { fetch(kt0); stash(0); }
@@ -1071,15 +1074,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_t128_kernel(GemmParams pin) {
         const float* Bs = As + T128_OP;
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
-            float4 a4[2], b4[2];
+            float4 a4[2], b4[TN];
 #pragma unroll
             for (int i = 0; i < 2; ++i) a4[i] = t128_frag<AKC>(As, wm + i * 32 + l31, c, kh);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b4[j] = t128_frag<BKC>(Bs, wn + j * 32 + l31, c, kh);
+            for (int j = 0; j < TN; ++j) b4[j] = t128_frag<BKC>(Bs, wn + j * 32 + l31, c, kh);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
@@ -1089,7 +1092,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_t128_kernel(GemmParams pin) {
         if (kt + 1 < kt1) stash(st ^ 1);                         // the other stage was last read before the previous barrier
         __syncthreads();
     }
-    epilogue<2, 2>(p, acc, C, b, ks, m0, n0, wm, wn, lane);
+    epilogue<2, TN>(p, acc, C, b, ks, m0, n0, wm, wn, lane);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1250,8 +1253,13 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
     static const int t128_min_tiles = getenv("ECHR_GEMM_T128_TILES") ? atoi(getenv("ECHR_GEMM_T128_TILES")) : 200;
     static const int t128_min_k = getenv("ECHR_GEMM_T128_K") ? atoi(getenv("ECHR_GEMM_T128_K")) : 1024;
     const long tiles128 = (long)((maxM + 127) / 128) * ((maxN + 127) / 128) * d.batch * ng;
+    // ... and K-heavy NT products of 32-128 such tiles (d OUTD 762 x 1536 x 5004: 72 tiles): the eight-wave form on floor(256 / tiles) k slices,
+    // one workgroup per CU -- 132 us against 146 on the 64 x 64 tile's own split (tools/t128_w8.py)
+    static const int t128_ks_on = getenv("ECHR_GEMM_T128_KS") ? atoi(getenv("ECHR_GEMM_T128_KS")) : 1;
+    const bool t128ks = t128_on && t128_ks_on && !h2 && !use_split && !tile_code && akc && bkc && ng == 1 && d.batch == 1 && d.split_k < 0 && d.rowmap_mod == 0 &&
+                        d.act == ECHR_ACT_NONE && (d.beta == 0.f || d.beta == 1.f) && tiles128 >= 32 && tiles128 <= 128 && d.K >= 2048 && !deterministic_gemm();
     const bool t128 = !h2 && !use_split && d.K >= 64 && d.rowmap_mod == 0 &&
-                      ((tile_code == 't') || (t128_on && !tile_code && tiles128 >= t128_min_tiles && d.K >= t128_min_k && (akc || bkc)));
+                      ((tile_code == 't') || t128ks || (t128_on && !tile_code && tiles128 >= t128_min_tiles && d.K >= t128_min_k && (akc || bkc)));
     if (t128) { BMs = 128; BNs = 128; }
     if (tile_code && tile_code != 't') {          // tuning override (tools/gemm_bench.py); never set in production
         const char e0 = tile_code;
@@ -1295,6 +1303,7 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
             if (split > 1 && kt_total / split < 4) split = max(1, kt_total / 4);
         }
     }
+    if (t128ks) split = (int)(256 / tiles128);
     if (env_split > 0 && d.split_k < 0) split = env_split;
     // reproducible mode (greedy sampler: index outputs must be bit-exact run to run): no k-slices that add with fp32 atomics
     if (deterministic_gemm() && d.split_k < 0) split = 1;
@@ -1384,7 +1393,14 @@ static int gemm_impl(const echr_gemm_desc* ds, int ng, hipStream_t st) {
         for (int gi = 0; gi < ng; ++gi) { if (!akc) va = va && ds[gi].M % 4 == 0; if (!bkc) vb = vb && ds[gi].N % 4 == 0; }
         p.vecA = va; p.vecB = vb;
         const size_t lds = 2 * T128_STAGE * sizeof(float);
-        if (akc && bkc) hipLaunchKernelGGL((gemm_f32_t128_kernel<true, true>), grid, dim3(256), lds, st, p);
+        static const int w8_sel = getenv("ECHR_T128_W8") ? atoi(getenv("ECHR_T128_W8")) : 1;
+        static const long w8_max = getenv("ECHR_T128_W8_MAX") ? atol(getenv("ECHR_T128_W8_MAX")) : 256;
+        if (w8_sel && akc && bkc && (long)grid.x * grid.z <= w8_max) {          // at most one workgroup per CU: eight waves per workgroup
+            static bool attr_w8 = false;
+            if (!attr_w8) { attr_w8 = true; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_t128_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
+            hipLaunchKernelGGL((gemm_f32_t128_kernel<true, true, true>), grid, dim3(512), lds, st, p);
+        }
+        else if (akc && bkc) hipLaunchKernelGGL((gemm_f32_t128_kernel<true, true>), grid, dim3(256), lds, st, p);
         else if (akc) hipLaunchKernelGGL((gemm_f32_t128_kernel<true, false>), grid, dim3(256), lds, st, p);
         else if (bkc) hipLaunchKernelGGL((gemm_f32_t128_kernel<false, true>), grid, dim3(256), lds, st, p);
         else hipLaunchKernelGGL((gemm_f32_t128_kernel<false, false>), grid, dim3(256), lds, st, p);

@@ -214,6 +214,39 @@ def test_gemm_f32_t128_every_layout(layout, M, N, K, pad):
         lib.echr_config_set(b'gemm_tile', 0)
 
 
+def test_gemm_f32_t128_k_split_rule_and_wave_forms():
+    """The library's OWN choice (no tile override) for the exact-fp32 products it sends to the 128 x 128 tile: the 240-tile logits shape
+    (eight-wave form of the kernel: launches of at most one workgroup per CU; unsplit, with bias), the K-heavy 72-tile d OUTD shape (eight-wave
+    form on 3 k slices, accumulating into a pre-filled C as the backward pass calls it) and a 480-tile shape (four-wave form, two workgroups per
+    CU) -- against float64."""
+    import ctypes as C
+    from echr_amd import _lib as L
+    lib = L.load()
+    dev = torch.device('cuda')
+    lib.echr_config_set(b'gemm_h2', 0); lib.echr_config_set(b'gemm_bf16x3', 0)
+    try:
+        for (M, N, K, beta, bias) in [(762, 5001, 1536, 0.0, True), (762, 1536, 5004, 1.0, False), (5001, 1536, 764, 0.0, False)]:
+            g = torch.Generator(device='cpu').manual_seed(M + N + K)
+            A, B = torch.randn(M, K, generator=g).to(dev), torch.randn(N, K, generator=g).to(dev)
+            C0 = torch.randn(M, N, generator=g).to(dev) if beta else torch.zeros(M, N, device=dev)
+            bv = torch.randn(N, generator=g).to(dev) if bias else None
+            Cc = C0.clone()
+            d = L.GemmDesc()
+            d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cc.data_ptr()
+            d.M, d.N, d.K = M, N, K
+            d.sam, d.sak, d.sbk, d.sbn = K, 1, 1, K
+            d.ldc, d.batch, d.alpha, d.beta, d.split_k, d.algo = N, 1, 1.0, beta, -1, 0
+            if bias:
+                d.bias = bv.data_ptr()
+            L.check(lib.echr_gemm_f32(C.byref(d), L.stream_ptr()), 'gemm')
+            torch.cuda.synchronize()
+            ref = A.double() @ B.double().t() + (C0.double() if beta else 0.0) + (bv.double() if bias else 0.0)
+            err = float((Cc.double() - ref).abs().max() / ref.abs().max())
+            assert err < 1e-5, (M, N, K, err)
+    finally:
+        lib.echr_config_set(b'gemm_h2', 1); lib.echr_config_set(b'gemm_bf16x3', 1)
+
+
 def test_gemm_row_index_scatter():
     """echr_gemm_desc.row_index: row i of A . B^T is ADDED into C[row_index[i]] (duplicates allowed, out-of-range indices clamped)."""
     import ctypes as C
