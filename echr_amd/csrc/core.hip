@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 }
 // scratch slabs of the fixed-order ("deterministic") variants
 float* det_scratch(int kind, size_t floats) {
-    static float* buf[DET_KINDS] = {nullptr, nullptr, nullptr};
-    static size_t cap[DET_KINDS] = {0, 0, 0};
+    static float* buf[DET_KINDS] = {};
+    static size_t cap[DET_KINDS] = {};
     if (kind < 0 || kind >= DET_KINDS) return nullptr;
     if (floats <= cap[kind]) return buf[kind];
     if (buf[kind]) { (void)hipDeviceSynchronize(); (void)hipFree(buf[kind]); buf[kind] = nullptr; cap[kind] = 0; }

@@ -730,6 +730,21 @@ __global__ __launch_bounds__(256, 2) void rec_gemm_kernel(RecArgs args) {
 
 static inline int ksplit_of(int K) { return (K + RK - 1) / RK; }
 
+// fixed-order mode: P[j][row, col] += the job's k-slice slabs, in slice order (one thread per output element of every job)
+struct RecFold { float* P[MAXJOBS]; const float* slab[MAXJOBS]; long ldp[MAXJOBS]; long start[MAXJOBS + 1]; int Nout[MAXJOBS]; int nslab[MAXJOBS]; int njobs; int M; };
+__global__ __launch_bounds__(256) void rec_fold_kernel(RecFold f) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= f.start[f.njobs]) return;
+    int j = 0;
+    while (j + 1 < f.njobs && idx >= f.start[j + 1]) ++j;
+    const long e = idx - f.start[j];
+    const int row = (int)(e / f.Nout[j]), col = (int)(e % f.Nout[j]);
+    const long sl = (long)f.M * f.Nout[j];
+    float s = 0.f;
+    for (int k = 0; k < f.nslab[j]; ++k) s += f.slab[j][(long)k * sl + e];
+    f.P[j][(long)row * f.ldp[j] + col] += s;
+}
+
 static int rec_gemm(const RecArgs& a, hipStream_t st) {
     int maxn = 0, maxk = 0;
     double fl = 0, by = 0;
@@ -750,6 +765,31 @@ static int rec_gemm(const RecArgs& a, hipStream_t st) {
         // would then all land in slab 0, so the two kinds are not mixed
         for (int j = 0; j < a.njobs; ++j) ECHR_REQUIRE(a.job[j].atomic, "rec_gemm: fixed-order mode cannot mix slab and accumulator jobs");
         for (int j = 1; j < a.njobs; ++j) for (int i = 0; i < j; ++i) ECHR_REQUIRE(a.job[i].P != a.job[j].P, "rec_gemm: fixed-order mode needs distinct outputs per launch");
+        static const bool slabs = [] { const char* e = getenv("ECHR_DET_REC_SLABS"); return !(e && e[0] == '0'); }();      // A/B switch
+        if (slabs) {
+            // every k slice writes its own slab (the launch keeps its k parallelism), then ONE fold launch adds a job's slabs to its accumulator
+            // in slice order: 6 + 4 us instead of one 28-us workgroup per tile walking all sixteen slices
+            RecArgs b = a;
+            RecFold f;
+            f.njobs = a.njobs; f.M = a.M;
+            long need = 0;
+            for (int j = 0; j < a.njobs; ++j) need += (long)ksplit_of(a.job[j].K) * a.M * a.job[j].Nout;
+            float* scr = det_scratch(DET_REC, (size_t)need);
+            if (!scr) return -12;
+            long off = 0, cells = 0;
+            for (int j = 0; j < a.njobs; ++j) {
+                const long sl = (long)a.M * a.job[j].Nout;
+                f.P[j] = a.job[j].P; f.ldp[j] = a.job[j].ldp; f.Nout[j] = a.job[j].Nout; f.nslab[j] = ksplit_of(a.job[j].K); f.slab[j] = scr + off; f.start[j] = cells;
+                b.job[j].P = scr + off; b.job[j].slab_stride = sl; b.job[j].ldp = a.job[j].Nout; b.job[j].atomic = 0;
+                off += sl * f.nslab[j];
+                cells += sl;
+            }
+            f.start[a.njobs] = cells;
+            hipLaunchKernelGGL(rec_gemm_kernel, dim3(maxn, maxk, a.njobs * ((a.M + 63) / 64)), dim3(256), 0, st, b);
+            if (int rc = check_launch("rec_gemm")) return rc;
+            hipLaunchKernelGGL(rec_fold_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, f);
+            return check_launch("rec_fold");
+        }
         RecArgs b = a;
         b.kloop = 1;
         hipLaunchKernelGGL(rec_gemm_kernel, dim3(maxn, 1, a.njobs * ((a.M + 63) / 64)), dim3(256), 0, st, b);

@@ -33,7 +33,7 @@ bool deterministic_gemm();
 inline bool det_mode() { return config().deterministic != 0; }
 // scratch slabs of the fixed-order variants: one lazily grown device buffer per use (`kind`), owned by the library, never shrunk; the call
 // that grows one synchronises the device (hipFree / hipMalloc).  One calling thread, like the rest of the library's static state.
-enum { DET_DQ = 0, DET_DPALL = 1, DET_ALPHA = 2, DET_KINDS = 3 };
+enum { DET_DQ = 0, DET_DPALL = 1, DET_ALPHA = 2, DET_REC = 3, DET_KINDS = 4 };
 float* det_scratch(int kind, size_t floats);
 
 // persistent (one launch for all timesteps) recurrence of the decoder, csrc/persist.hip
