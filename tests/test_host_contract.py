@@ -217,3 +217,19 @@ def test_persistent_role_placement_is_a_bijection():
         if r < 192 and 16 <= r % 96 < 80:
             prod.setdefault(r // 96, set()).add(b % 8)
     assert all(len(v) == 2 for v in prod.values()), prod
+
+
+def test_runtime_switches_are_known_by_name():
+    """echr_config_set (include/echr_hip.h): the switches the documentation names are accepted (a host-side table, no device call), the
+    fixed-order accumulation switch among them (`echr_amd.set_deterministic`), and an unknown key is an error with a message -- never a silent
+    no-op."""
+    import echr_amd
+    from echr_amd import _lib
+    lib = _lib.load()
+    for key, val in ((b'deterministic', 1), (b'deterministic', 0), (b'persist', 1), (b'persist_bwd', 1), (b'gemm_h2', 1), (b'gemm_bf16x3', 1), (b'att_slots', 2)):
+        assert lib.echr_config_set(key, val) == 0, key
+    echr_amd.set_deterministic(True)
+    echr_amd.set_deterministic(False)
+    assert lib.echr_config_set(b'no_such_switch', 1) == -22
+    assert b'no_such_switch' in lib.echr_last_error()
+    assert lib.echr_config_set(b'att_slots', 3) != 0          # (only 2, 4 or 8)
