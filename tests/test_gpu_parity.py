@@ -247,6 +247,60 @@ def test_gemm_f32_t128_k_split_rule_and_wave_forms():
         lib.echr_config_set(b'gemm_h2', 1); lib.echr_config_set(b'gemm_bf16x3', 1)
 
 
+@pytest.mark.parametrize('shape', [(300, 260, 96), (2100, 2100, 96)])          # 9 tiles: the eight-wave form; 289 tiles: the four-wave form
+def test_gemm_f32_t128_epilogues(shape):
+    """Every epilogue mode of echr_gemm_f32 through the 128 x 128 tile (tile override 't'; NT operands; small launch = eight waves of 64 x 32,
+    large launch = four waves of 64 x 64): bias + bias2 + tanh, the broadcast addend, the output row remap, accumulate (beta = 1) and the
+    (1 - aux^2) gradient form -- against float64."""
+    import ctypes as C
+    from echr_amd import _lib as L
+    lib = L.load()
+    dev = torch.device('cuda')
+    M, N, K = shape
+    g = torch.Generator(device='cpu').manual_seed(M + 3 * N + K)
+    A, B = (0.3 * torch.randn(M, K, generator=g)).to(dev), (0.3 * torch.randn(N, K, generator=g)).to(dev)
+    b1, b2 = torch.randn(N, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+    add_mod = 20 if M % 20 == 0 else 1
+    addend = torch.randn(add_mod, N, generator=g).to(dev)
+    aux = torch.tanh(torch.randn(M, N, generator=g)).to(dev)
+    C0 = torch.randn(M, N, generator=g).to(dev)
+    prod = A.double() @ B.double().t()
+    rows = torch.arange(M)
+    cases = {
+        'bias+bias2+tanh': (dict(bias=b1, bias2=b2, act=1), torch.tanh(prod + b1.double() + b2.double())),
+        'addend': (dict(addend=addend, add_mod=add_mod, ld_add=N), prod + addend.double()[rows % add_mod]),
+        'accumulate': (dict(beta=1.0), prod + C0.double()),
+        'mul_dtanh': (dict(act=2, aux=aux, ld_aux=N), prod * (1.0 - aux.double() ** 2)),
+    }
+    if M % 20 == 0:
+        mod, mul = 20, M // 20
+        perm = (rows % mod) * mul + rows // mod
+        ref = torch.empty_like(prod)
+        ref[perm.to(dev)] = prod
+        cases['rowmap'] = (dict(rowmap_mod=mod, rowmap_mul=mul), ref)
+    try:
+        assert lib.echr_config_set(b'gemm_tile', ord('t')) == 0
+        for name, (kw, ref) in cases.items():
+            Cc = C0.clone() if kw.get('beta') else torch.full((M, N), 3.0, device=dev)
+            d = L.GemmDesc()
+            d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cc.data_ptr()
+            d.M, d.N, d.K = M, N, K
+            d.sam, d.sak, d.sbk, d.sbn = K, 1, 1, K
+            d.ldc, d.batch, d.alpha, d.beta, d.split_k, d.algo = N, 1, 1.0, kw.get('beta', 0.0), 1, 0
+            for k in ('bias', 'bias2', 'addend', 'aux'):
+                if k in kw:
+                    setattr(d, k, kw[k].data_ptr())
+            for k in ('add_mod', 'ld_add', 'act', 'ld_aux', 'rowmap_mod', 'rowmap_mul'):
+                if k in kw:
+                    setattr(d, k, kw[k])
+            L.check(lib.echr_gemm_f32(C.byref(d), L.stream_ptr()), 'gemm ' + name)
+            torch.cuda.synchronize()
+            err = float((Cc.double() - ref).abs().max() / ref.abs().max())
+            assert err < 1e-5, (name, shape, err)
+    finally:
+        lib.echr_config_set(b'gemm_tile', 0)
+
+
 def test_gemm_row_index_scatter():
     """echr_gemm_desc.row_index: row i of A . B^T is ADDED into C[row_index[i]] (duplicates allowed, out-of-range indices clamped)."""
     import ctypes as C
